@@ -1,0 +1,171 @@
+"""ctypes front-end of the CPU oracle (oracle/tcsfm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_DIR, "_build")
+MAXP = 7
+
+
+class OrcOpts(C.Structure):
+    _fields_ = [("nparam", C.c_int), ("automask", C.c_int), ("param", C.c_int), ("solver", C.c_int),
+                ("n_iters", C.c_int), ("w_l1", C.c_double), ("w_ssim", C.c_double), ("w_dc", C.c_double),
+                ("irls_eps", C.c_double), ("lambda0", C.c_double), ("lambda_up", C.c_double),
+                ("lambda_down", C.c_double), ("lambda_min", C.c_double)]
+
+
+class LinOut(C.Structure):
+    _fields_ = [("H", C.c_double * (MAXP * MAXP)), ("g", C.c_double * MAXP), ("cost", C.c_double),
+                ("cost_photo", C.c_double), ("cost_dc", C.c_double), ("n_mask", C.c_double)]
+
+
+def default_opts(**kw) -> OrcOpts:
+    o = OrcOpts(nparam=6, automask=1, param=0, solver=0, n_iters=4, w_l1=0.15, w_ssim=0.85, w_dc=0.0,
+                irls_eps=1e-3, lambda0=1e-4, lambda_up=10.0, lambda_down=0.1, lambda_min=1e-7)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+def build(force: bool = False) -> None:
+    """Compile both oracle libraries with gcc (seconds)."""
+    if force or not all(os.path.exists(os.path.join(_BUILD, f"liboracle_{p}.so")) for p in ("f32", "f64")) or \
+            os.path.getmtime(os.path.join(_DIR, "tcsfm_oracle.c")) > os.path.getmtime(os.path.join(_BUILD, "liboracle_f64.so")):
+        subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))
+
+
+class Oracle:
+    """precision 'f64' (the oracle proper) or 'f32' (diagnostic fp32 twin)."""
+
+    def __init__(self, precision: str = "f64"):
+        build()
+        self.dt = {"f64": np.float64, "f32": np.float32}[precision]
+        self.lib = C.CDLL(os.path.join(_BUILD, f"liboracle_{precision}.so"))
+        assert self.lib.orc_sizeof_real() == np.dtype(self.dt).itemsize
+        self.lib.orc_cost.restype = C.c_double
+
+    # -- helpers ---------------------------------------------------------
+    def _r(self, a):
+        return np.ascontiguousarray(a, dtype=self.dt)
+
+    @staticmethod
+    def _p(a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    @staticmethod
+    def _d(a):
+        return np.ascontiguousarray(a, dtype=np.float64)
+
+    # -- SE(3) / pose utilities (double) -----------------------------------
+    def pose_to_T(self, pose):
+        pose = self._d(pose); T = np.zeros(12)
+        self.lib.orc_pose_to_T(self._p(pose), self._p(T))
+        return T.reshape(3, 4)
+
+    def T_to_pose(self, T):
+        T = self._d(T).reshape(12); p = np.zeros(6)
+        self.lib.orc_T_to_pose(self._p(T), self._p(p))
+        return p
+
+    def se3_exp(self, xi):
+        xi = self._d(xi); T = np.zeros(12)
+        self.lib.orc_se3_exp(self._p(xi), self._p(T))
+        return T.reshape(3, 4)
+
+    def se3_log(self, T):
+        T = self._d(T).reshape(12); xi = np.zeros(6)
+        self.lib.orc_se3_log(self._p(T), self._p(xi))
+        return xi
+
+    def euler_left_jacobian(self, pose):
+        pose = self._d(pose); A = np.zeros(36)
+        self.lib.orc_euler_left_jacobian(self._p(pose), self._p(A))
+        return A.reshape(6, 6)
+
+    # -- residual pieces ---------------------------------------------------
+    def disp_to_depth(self, disp, min_depth, max_depth):
+        d = self._r(disp); s = np.empty_like(d); z = np.empty_like(d)
+        self.lib.orc_disp_to_depth(C.c_int(d.size), self._p(d), C.c_double(min_depth), C.c_double(max_depth),
+                                   self._p(s), self._p(z))
+        return s, z
+
+    def warp(self, src, depth_t, depth_s, pose, K, log_scale=0.0, T=None):
+        """inverse_warp2 for one pair: src [3,H,W], depth [H,W] -> rec [3,H,W], valid, proj_depth, comp_depth [H,W]."""
+        src, depth_t, depth_s, K = self._r(src), self._r(depth_t), self._r(depth_s), self._r(K)
+        _, H, W = src.shape
+        T = self._d(self.pose_to_T(pose) if T is None else T).reshape(12)
+        rec = np.empty((3, H, W), self.dt); va, pd, cd = (np.empty((H, W), self.dt) for _ in range(3))
+        self.lib.orc_warp(H, W, self._p(src), self._p(depth_t), self._p(depth_s), self._p(T), self._p(K),
+                          C.c_double(log_scale), self._p(rec), self._p(va), self._p(pd), self._p(cd))
+        return rec, va, pd, cd
+
+    def ssim(self, x, y):
+        x, y = self._r(x), self._r(y)
+        Cn, H, W = x.shape
+        out = np.empty_like(x)
+        self.lib.orc_ssim(Cn, H, W, self._p(x), self._p(y), self._p(out))
+        return out
+
+    def photometric(self, tgt, src, depth_t, depth_s, pose, K, log_scale=0.0, w_l1=0.15, w_ssim=0.85):
+        """compute_photometric_error (helpers.py:8-23) for one pair -> dict of maps."""
+        tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
+        _, H, W = tgt.shape
+        T = self._d(self.pose_to_T(pose)).reshape(12)
+        o = {k: np.empty((H, W), self.dt) for k in ("diff", "valid", "weight", "auto_err", "auto_mask")}
+        o["rec"] = np.empty((3, H, W), self.dt)
+        self.lib.orc_photometric(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(T),
+                                 self._p(K), C.c_double(log_scale), C.c_double(w_l1), C.c_double(w_ssim),
+                                 self._p(o["diff"]), self._p(o["valid"]), self._p(o["weight"]), self._p(o["auto_err"]),
+                                 self._p(o["auto_mask"]), self._p(o["rec"]))
+        return o
+
+    def cost(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
+        opts = opts or default_opts()
+        tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
+        _, H, W = tgt.shape
+        T = self._d(self.pose_to_T(pose)).reshape(12)
+        return self.lib.orc_cost(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(T),
+                                 self._p(K), C.c_double(log_scale), C.byref(opts))
+
+    def linearize(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0, rows=False, T=None):
+        """-> dict(H [np,np], g [np], cost, cost_photo, cost_dc, n_mask [, J1,J2,J3 [H,W,np], E [H,W,3], M [H,W]])."""
+        opts = opts or default_opts()
+        tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
+        _, H, W = tgt.shape
+        n_p = opts.nparam
+        T = self._d(self.pose_to_T(pose) if T is None else T).reshape(12)
+        out = LinOut()
+        J = [np.empty((H, W, n_p), self.dt) if rows else None for _ in range(3)]
+        E = np.empty((H, W, 3), self.dt) if rows else None
+        M = np.empty((H, W), self.dt) if rows else None
+        self.lib.orc_linearize(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(T),
+                               self._p(K), C.c_double(log_scale), C.byref(opts), None, C.byref(out),
+                               self._p(J[0]), self._p(J[1]), self._p(J[2]), self._p(E), self._p(M))
+        r = dict(H=np.array(out.H[:n_p * n_p]).reshape(n_p, n_p), g=np.array(out.g[:n_p]), cost=out.cost,
+                 cost_photo=out.cost_photo, cost_dc=out.cost_dc, n_mask=out.n_mask)
+        if rows:
+            r.update(J1=J[0], J2=J[1], J3=J[2], E=E, M=M)
+        return r
+
+    def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
+        """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4])."""
+        opts = opts or default_opts()
+        tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
+        _, H, W = tgt.shape
+        pose = self._d(pose).copy()
+        ls = C.c_double(log_scale)
+        stats = np.zeros((opts.n_iters + 1, 4))
+        self.lib.orc_refine(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(K),
+                            C.byref(opts), self._p(pose), C.byref(ls), self._p(stats))
+        return pose, ls.value, stats

@@ -1,0 +1,722 @@
+/*
+ * tcsfm_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's photometric pose/depth residual
+ * (utiasSTARS/tightly-coupled-SfM, pure PyTorch) and the float64 Gauss-Newton /
+ * Levenberg-Marquardt twin that the HIP engine is checked against.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product path (tightly_coupled_sfm_amd/) never does.
+ *
+ * Parity pinning (see tests/golden/make_golden.py, tests/test_oracle_vs_golden.py):
+ *   PINNED by outputs of the reference itself, generated in the build container by
+ *   importing /root/reference (float64 and float32):
+ *     warp (img_rec, valid, projected_depth, computed_depth)     models/stn.py:234-273
+ *     SSIM map                                                   losses.py:27-41
+ *     residual maps diff/valid/weight/auto-mask                  optimization_experiments/helpers.py:8-23
+ *     scalar cost                                                optimization_experiments/plot_loss_surface.py:31-33
+ *     d(cost)/d(pose), d(cost)/d(depth) via reference autograd, per-pixel Jacobian rows
+ *   UNPINNED by the reference (it has no GN/LM solver):
+ *     GN/LM iterates, damping, SE(3) retraction -- this file IS the definition.
+ *
+ * Compiled twice: -DREAL=double (liboracle_f64.so, the oracle proper) and
+ * -DREAL=float (liboracle_f32.so, diagnostic twin with fp32 per-pixel arithmetic).
+ * All reductions and the K x K solve are in double in both builds.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef REAL
+#define REAL double
+#endif
+typedef REAL real;
+
+#define MAXP 7 /* 6 pose + 1 log depth-scale */
+
+/* ------------------------------------------------------------------------- */
+/* options (mirrors tcsfm_opts in include/tcsfm.h; kept as plain scalars)      */
+typedef struct {
+    int nparam;      /* 6: pose; 7: pose + log depth-scale                               */
+    int automask;    /* M = valid * (diff < auto_err), helpers.py:18-20                  */
+    int param;       /* 0: SE(3) left retraction T <- exp(d) T ; 1: additive on the       */
+                     /*    reference's [t, euler] 6-vector (stn.py:143-158)               */
+    int solver;      /* 0: Gauss-Newton (fixed damping lambda0) ; 1: Levenberg-Marquardt  */
+    int n_iters;
+    double w_l1, w_ssim; /* 0.15 / 0.85, train_mono.py:87                                */
+    double w_dc;         /* depth-consistency weight, optimizer.py:83-86 (0 = off)       */
+    double irls_eps;
+    double lambda0, lambda_up, lambda_down, lambda_min;
+} orc_opts;
+
+/* ------------------------------------------------------------------------- */
+/* small dense helpers (double)                                                */
+
+static void mat3_mul(const double *A, const double *B, double *C) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j];
+            C[3 * i + j] = s;
+        }
+}
+
+/* general 3x3 inverse (torch.inverse at stn.py:257) */
+static void mat3_inv(const double *A, double *B) {
+    double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    double id = 1.0 / det;
+    B[0] = c00 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    B[3] = c01 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    B[6] = c02 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+/* R = Rx(x) Ry(y) Rz(z), euler2mat stn.py:81-116 */
+static void euler_R(const double r[3], double R[9]) {
+    double cx = cos(r[0]), sx = sin(r[0]), cy = cos(r[1]), sy = sin(r[1]), cz = cos(r[2]), sz = sin(r[2]);
+    double Rx[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+    double Ry[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
+    double Rz[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+    double t[9];
+    mat3_mul(Rx, Ry, t);
+    mat3_mul(t, Rz, R);
+}
+
+/* T(3x4,row-major) = pose_vec2mat(-pose)  (stn.py:143-158 called with -pose at helpers.py:11, train_mono.py:69) */
+void orc_pose_to_T(const double pose[6], double T[12]) {
+    double r[3] = {-pose[3], -pose[4], -pose[5]}, R[9];
+    euler_R(r, R);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * i + j];
+        T[4 * i + 3] = -pose[i];
+    }
+}
+
+void orc_T_to_pose(const double T[12], double pose[6]) {
+    double s = T[2];
+    if (s > 1) s = 1;
+    if (s < -1) s = -1;
+    double b = asin(s), a = atan2(-T[6], T[10]), c = atan2(-T[1], T[0]);
+    pose[0] = -T[3]; pose[1] = -T[7]; pose[2] = -T[11];
+    pose[3] = -a; pose[4] = -b; pose[5] = -c;
+}
+
+/* SE(3) exp, xi = [rho(3), phi(3)] translation first (liegroups convention, validate.py:65).
+ * T = [exp(phi^) | J_l(phi) rho]  with the SO(3) left Jacobian J_l. */
+void orc_se3_exp(const double xi[6], double T[12]) {
+    const double *rho = xi, *phi = xi + 3;
+    double th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2], th = sqrt(th2);
+    double A, B, C; /* sin/th, (1-cos)/th^2, (th-sin)/th^3 */
+    if (th < 1e-4) {
+        A = 1 - th2 / 6 + th2 * th2 / 120; B = 0.5 - th2 / 24 + th2 * th2 / 720; C = 1.0 / 6 - th2 / 120 + th2 * th2 / 5040;
+    } else {
+        A = sin(th) / th; B = (1 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th);
+    }
+    double K[9] = {0, -phi[2], phi[1], phi[2], 0, -phi[0], -phi[1], phi[0], 0}, K2[9];
+    mat3_mul(K, K, K2);
+    for (int i = 0; i < 3; i++) {
+        double v = 0;
+        for (int j = 0; j < 3; j++) {
+            double I = (i == j) ? 1.0 : 0.0;
+            T[4 * i + j] = I + A * K[3 * i + j] + B * K2[3 * i + j];
+            v += (I + B * K[3 * i + j] + C * K2[3 * i + j]) * rho[j];
+        }
+        T[4 * i + 3] = v;
+    }
+}
+
+/* SE(3) log, inverse of orc_se3_exp (|phi| < pi) */
+void orc_se3_log(const double T[12], double xi[6]) {
+    double tr = T[0] + T[5] + T[10], c = 0.5 * (tr - 1);
+    if (c > 1) c = 1;
+    if (c < -1) c = -1;
+    double th = acos(c);
+    double w[3] = {T[9] - T[6], T[2] - T[8], T[4] - T[1]};
+    double f = (th < 1e-6) ? 0.5 + th * th / 12 : th / (2 * sin(th));
+    double phi[3] = {f * w[0], f * w[1], f * w[2]};
+    double th2 = th * th;
+    /* J_l^{-1} = I - 1/2 phi^ + D phi^2,  D = 1/th^2 - (1+cos)/(2 th sin) */
+    double D = (th < 1e-4) ? 1.0 / 12 + th2 / 720 : 1.0 / th2 - (1 + cos(th)) / (2 * th * sin(th));
+    double K[9] = {0, -phi[2], phi[1], phi[2], 0, -phi[0], -phi[1], phi[0], 0}, K2[9];
+    mat3_mul(K, K, K2);
+    for (int i = 0; i < 3; i++) {
+        double v = 0;
+        for (int j = 0; j < 3; j++) v += (((i == j) ? 1.0 : 0.0) - 0.5 * K[3 * i + j] + D * K2[3 * i + j]) * T[4 * j + 3];
+        xi[i] = v;
+        xi[3 + i] = phi[i];
+    }
+}
+
+/* C = A * B for 3x4 rigid transforms */
+void orc_se3_mul(const double A[12], const double B[12], double C[12]) {
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[4 * i + k] * B[4 * k + j];
+            C[4 * i + j] = s;
+        }
+        double s = A[4 * i + 3];
+        for (int k = 0; k < 3; k++) s += A[4 * i + k] * B[4 * k + 3];
+        C[4 * i + 3] = s;
+    }
+}
+
+void orc_se3_inv(const double A[12], double B[12]) {
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) B[4 * i + j] = A[4 * j + i];
+        B[4 * i + 3] = -(A[i] * A[3] + A[4 + i] * A[7] + A[8 + i] * A[11]);
+    }
+}
+
+/* d(xi_left)/d(pose): T(pose + dp) = exp((A dp)^) T(pose) to first order.
+ * With t' = -t, theta = -r, J_e(theta) = [e_x | Rx e_y | Rx Ry e_z]:
+ *   dphi = -J_e dr ,  drho = -dt - [t']x J_e dr                                  */
+void orc_euler_left_jacobian(const double pose[6], double A[36]) {
+    double th[3] = {-pose[3], -pose[4], -pose[5]};
+    double cx = cos(th[0]), sx = sin(th[0]), cy = cos(th[1]), sy = sin(th[1]);
+    double Je[9] = {1, 0, sy, 0, cx, -sx * cy, 0, sx, cx * cy}; /* columns e_x, Rx e_y, Rx Ry e_z */
+    double tp[3] = {-pose[0], -pose[1], -pose[2]};
+    double Tx[9] = {0, -tp[2], tp[1], tp[2], 0, -tp[0], -tp[1], tp[0], 0}, TJ[9];
+    mat3_mul(Tx, Je, TJ);
+    memset(A, 0, 36 * sizeof(double));
+    for (int i = 0; i < 3; i++) {
+        A[6 * i + i] = -1;
+        for (int j = 0; j < 3; j++) {
+            A[6 * i + 3 + j] = -TJ[3 * i + j];
+            A[6 * (3 + i) + 3 + j] = -Je[3 * i + j];
+        }
+    }
+}
+
+/* in-place Cholesky solve of the n x n SPD system A x = b (row-major, n <= MAXP). returns 0 ok */
+static int chol_solve(int n, double *A, double *b) {
+    for (int j = 0; j < n; j++) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+        if (!(d > 0)) return -1;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= A[i * n + k] * b[k];
+        b[i] = s / A[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= A[k * n + i] * b[k];
+        b[i] = s / A[i * n + i];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a1: disp_to_depth, utils/learning_helpers.py:77-86                          */
+void orc_disp_to_depth(int n, const real *disp, double min_depth, double max_depth, real *scaled, real *depth) {
+    real min_disp = (real)(1.0 / max_depth), max_disp = (real)(1.0 / min_depth);
+    for (int i = 0; i < n; i++) {
+        real s = min_disp + (max_disp - min_disp) * disp[i];
+        if (scaled) scaled[i] = s;
+        if (depth) depth[i] = (real)1 / s;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* per-pixel warp geometry, a2-a5                                              */
+
+typedef struct {
+    real M[9], m[3];    /* proj_cam_to_src_pixel = K @ [R|t], stn.py:262-264 */
+    real K[9], Kinv[9], R[9], t[3];
+    real es;            /* exp(log depth-scale) */
+    int H, W;
+} cam_t;
+
+typedef struct {
+    real ix, iy;        /* grid_sample un-normalised sample location                     */
+    real Z;             /* computed_depth (clamped), stn.py:215                           */
+    real Xp[3];         /* point in the source camera frame                               */
+    real p[3];          /* K Xp                                                           */
+    int oobx, ooby, zclamp;
+} geo_t;
+
+static void cam_setup(cam_t *c, int H, int W, const real *K, const double T[12], double log_scale) {
+    double Kd[9], Ki[9];
+    for (int i = 0; i < 9; i++) Kd[i] = K[i];
+    mat3_inv(Kd, Ki);
+    for (int i = 0; i < 9; i++) { c->K[i] = K[i]; c->Kinv[i] = (real)Ki[i]; }
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) c->R[3 * i + j] = (real)T[4 * i + j];
+        c->t[i] = (real)T[4 * i + 3];
+    }
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += Kd[3 * i + k] * T[4 * k + j];
+            c->M[3 * i + j] = (real)a;
+        }
+        double a = 0;
+        for (int k = 0; k < 3; k++) a += Kd[3 * i + k] * T[4 * k + 3];
+        c->m[i] = (real)a;
+    }
+    c->es = (real)exp(log_scale);
+    c->H = H; c->W = W;
+}
+
+/* pixel2cam stn.py:33-48, pose_vec2mat stn.py:143-158, cam2pixel2 stn.py:198-231,
+ * grid un-normalisation of F.grid_sample(align_corners=False) stn.py:266 */
+static void warp_geo(const cam_t *c, int u, int v, real depth, geo_t *g) {
+    const real *Ki = c->Kinv, *R = c->R, *M = c->M;
+    real D = c->es * depth;
+    real ray[3], X[3];
+    /* same operation order as the reference: (Kinv @ pix) * depth, then (K@R) @ X + K@t */
+    for (int i = 0; i < 3; i++) ray[i] = Ki[3 * i] * (real)u + Ki[3 * i + 1] * (real)v + Ki[3 * i + 2];
+    for (int i = 0; i < 3; i++) X[i] = ray[i] * D;
+    for (int i = 0; i < 3; i++) g->p[i] = M[3 * i] * X[0] + M[3 * i + 1] * X[1] + M[3 * i + 2] * X[2] + c->m[i];
+    /* source-frame point, needed by the Jacobian only */
+    for (int i = 0; i < 3; i++) g->Xp[i] = R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2] + c->t[i];
+    g->zclamp = g->p[2] < (real)1e-3;
+    g->Z = g->zclamp ? (real)1e-3 : g->p[2];
+    real xn = 2 * (g->p[0] / g->Z) / (real)(c->W - 1) - 1;
+    real yn = 2 * (g->p[1] / g->Z) / (real)(c->H - 1) - 1;
+    g->oobx = (xn > 1) || (xn < -1);
+    g->ooby = (yn > 1) || (yn < -1);
+    if (g->oobx) xn = 2; /* stn.py:223-227: OOB sentinel, detached */
+    if (g->ooby) yn = 2;
+    g->ix = ((xn + 1) * (real)c->W - 1) / 2;
+    g->iy = ((yn + 1) * (real)c->H - 1) / 2;
+}
+
+/* bilinear tap with zero padding: value and d/dix, d/diy (grid_sampler_2d fwd/bwd semantics) */
+static void bilinear(const real *img, int H, int W, real ix, real iy, real *val, real *gx, real *gy) {
+    real fx = floor(ix), fy = floor(iy);
+    real wx = ix - fx, wy = iy - fy;
+    /* far-out sentinel coordinates: avoid int overflow */
+    if (!(fx > -4 && fx < W + 4 && fy > -4 && fy < H + 4)) { *val = 0; if (gx) { *gx = 0; *gy = 0; } return; }
+    int x0 = (int)fx, y0 = (int)fy;
+    real v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+    if (y0 >= 0 && y0 < H) {
+        if (x0 >= 0 && x0 < W) v00 = img[y0 * W + x0];
+        if (x0 + 1 >= 0 && x0 + 1 < W) v01 = img[y0 * W + x0 + 1];
+    }
+    if (y0 + 1 >= 0 && y0 + 1 < H) {
+        if (x0 >= 0 && x0 < W) v10 = img[(y0 + 1) * W + x0];
+        if (x0 + 1 >= 0 && x0 + 1 < W) v11 = img[(y0 + 1) * W + x0 + 1];
+    }
+    *val = (1 - wx) * (1 - wy) * v00 + wx * (1 - wy) * v01 + (1 - wx) * wy * v10 + wx * wy * v11;
+    if (gx) {
+        *gx = (1 - wy) * (v01 - v00) + wy * (v11 - v10);
+        *gy = (1 - wx) * (v10 - v00) + wx * (v11 - v01);
+    }
+}
+
+/* inverse_warp2, stn.py:234-273.  src [3,H,W]; depth_t, depth_s [H,W]; T 3x4; K 3x3.
+ * Outputs (any may be NULL): rec [3,H,W], valid [H,W], proj_depth [H,W], comp_depth [H,W]. */
+void orc_warp(int H, int W, const real *src, const real *depth_t, const real *depth_s, const double T[12],
+              const real *K, double log_scale, real *rec, real *valid, real *proj_depth, real *comp_depth) {
+    cam_t c;
+    cam_setup(&c, H, W, K, T, log_scale);
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            geo_t g;
+            int i = v * W + u;
+            warp_geo(&c, u, v, depth_t[i], &g);
+            for (int ch = 0; ch < 3; ch++) {
+                real val;
+                bilinear(src + ch * H * W, H, W, g.ix, g.iy, &val, NULL, NULL);
+                if (rec) rec[ch * H * W + i] = val;
+            }
+            if (valid) valid[i] = (g.oobx || g.ooby) ? 0 : 1;
+            if (proj_depth) {
+                real val;
+                bilinear(depth_s, H, W, g.ix, g.iy, &val, NULL, NULL);
+                proj_depth[i] = c.es * val;
+            }
+            if (comp_depth) comp_depth[i] = g.Z;
+        }
+}
+
+/* ReflectionPad2d(1) index, losses.py:22 */
+static inline int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+#define SSIM_C1 ((real)(0.01 * 0.01))
+#define SSIM_C2 ((real)(0.03 * 0.03))
+
+typedef struct { real mux, muy, n1, n2, d1, d2, s; int clamped; } ssim_t;
+
+/* SSIM_Loss.forward at one pixel/channel, losses.py:27-41 */
+static void ssim_at(const real *x, const real *y, int H, int W, int u, int v, ssim_t *o) {
+    real sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int dv = -1; dv <= 1; dv++)
+        for (int du = -1; du <= 1; du++) {
+            int j = refl(v + dv, H) * W + refl(u + du, W);
+            real a = x[j], b = y[j];
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+    const real ninth = (real)1 / 9;
+    real mux = sx * ninth, muy = sy * ninth;
+    real sigx = sxx * ninth - mux * mux, sigy = syy * ninth - muy * muy, sigxy = sxy * ninth - mux * muy;
+    o->mux = mux; o->muy = muy;
+    o->n1 = 2 * mux * muy + SSIM_C1; o->n2 = 2 * sigxy + SSIM_C2;
+    o->d1 = mux * mux + muy * muy + SSIM_C1; o->d2 = sigx + sigy + SSIM_C2;
+    real raw = (1 - (o->n1 * o->n2) / (o->d1 * o->d2)) / 2;
+    o->clamped = (raw < 0) || (raw > 1);
+    o->s = raw < 0 ? 0 : (raw > 1 ? 1 : raw);
+}
+
+/* SSIM map over C planes, losses.py:27-41 */
+void orc_ssim(int C, int H, int W, const real *x, const real *y, real *out) {
+    for (int c = 0; c < C; c++)
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                ssim_t s;
+                ssim_at(x + c * H * W, y + c * H * W, H, W, u, v, &s);
+                out[c * H * W + v * W + u] = s.s;
+            }
+}
+
+static inline real clamp01(real a) { return a < 0 ? 0 : (a > 1 ? 1 : a); }
+
+/* (0.15 |a-b|.clamp(0,1) + 0.85 SSIM(tgt=b... ) ).mean(1): train_mono.py:84,87 / helpers.py:12,17
+ * x = reconstruction target, y = other image; returns mean over the 3 channels. */
+static void photo_err_map(int H, int W, const real *x, const real *y, double w_l1, double w_ssim, real *out) {
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            real acc = 0;
+            for (int c = 0; c < 3; c++) {
+                ssim_t s;
+                ssim_at(x + c * H * W, y + c * H * W, H, W, u, v, &s);
+                real l1 = clamp01(fabs(y[c * H * W + v * W + u] - x[c * H * W + v * W + u]));
+                acc += (real)w_l1 * l1 + (real)w_ssim * s.s;
+            }
+            out[v * W + u] = acc / 3;
+        }
+}
+
+/* compute_photometric_error, helpers.py:8-23 (single directed pair) == the per-pair slice of
+ * solve_pose_iteratively's residual assembly, train_mono.py:82-100.
+ * Outputs (any may be NULL): diff, valid (warp validity, stn.py:268-269), weight, auto_err, auto_mask, rec[3HW]. */
+void orc_photometric(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                     const double T[12], const real *K, double log_scale, double w_l1, double w_ssim,
+                     real *diff, real *valid, real *weight, real *auto_err, real *auto_mask, real *rec_out) {
+    int n = H * W;
+    real *rec = (real *)malloc(sizeof(real) * 3 * n), *pd = (real *)malloc(sizeof(real) * n),
+         *cd = (real *)malloc(sizeof(real) * n), *d = (real *)malloc(sizeof(real) * n), *ae = (real *)malloc(sizeof(real) * n);
+    orc_warp(H, W, src, depth_t, depth_s, T, K, log_scale, rec, valid, pd, cd);
+    photo_err_map(H, W, tgt, rec, w_l1, w_ssim, d);
+    photo_err_map(H, W, tgt, src, w_l1, w_ssim, ae);
+    for (int i = 0; i < n; i++) {
+        if (diff) diff[i] = d[i];
+        if (weight) weight[i] = 1 - clamp01(fabs(cd[i] - pd[i]) / (cd[i] + pd[i])); /* helpers.py:13-14 */
+        if (auto_err) auto_err[i] = ae[i];
+        if (auto_mask) auto_mask[i] = d[i] < ae[i] ? 1 : 0;                             /* helpers.py:18 */
+    }
+    if (rec_out) memcpy(rec_out, rec, sizeof(real) * 3 * n);
+    free(rec); free(pd); free(cd); free(d); free(ae);
+}
+
+/* ------------------------------------------------------------------------- */
+/* linearisation: cost, gradient, Gauss-Newton matrix                          */
+
+typedef struct {
+    real rec[3], gx[3], gy[3]; /* warped source + d/d(ix,iy)                               */
+    real pd, dgx, dgy, cd;     /* projected (sampled, scaled) / computed depth              */
+    real a[MAXP], b[MAXP], zc[MAXP], dpd[MAXP]; /* d ix, d iy, d cd, d pd  w.r.t. parameters */
+    int valid;
+} px_t;
+
+/* Parameters: xi = [rho, phi] left perturbation of T (T <- exp(xi^) T), optional 7th = log depth-scale
+ * applied to BOTH depth maps.  dXp/drho_j = e_j ; dXp/dphi_j = e_j x Xp ; dXp/dsigma = Xp - t. */
+static void px_jac(const cam_t *c, const geo_t *g, int np, px_t *o) {
+    real cw = (real)c->W / (real)(c->W - 1), chh = (real)c->H / (real)(c->H - 1);
+    const real *Xp = g->Xp;
+    real dX[MAXP][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, -Xp[2], Xp[1]}, {Xp[2], 0, -Xp[0]}, {-Xp[1], Xp[0], 0},
+                        {Xp[0] - c->t[0], Xp[1] - c->t[1], Xp[2] - c->t[2]}};
+    real uz = g->p[0] / g->Z, vz = g->p[1] / g->Z;
+    for (int j = 0; j < np; j++) {
+        real dp[3];
+        for (int i = 0; i < 3; i++) dp[i] = c->K[3 * i] * dX[j][0] + c->K[3 * i + 1] * dX[j][1] + c->K[3 * i + 2] * dX[j][2];
+        real dZ = g->zclamp ? 0 : dp[2];
+        o->zc[j] = dZ;
+        o->a[j] = g->oobx ? 0 : cw * (dp[0] - uz * dZ) / g->Z;
+        o->b[j] = g->ooby ? 0 : chh * (dp[1] - vz * dZ) / g->Z;
+    }
+}
+
+static void px_eval(const cam_t *c, const real *src, const real *depth_t, const real *depth_s, int u, int v, int np, px_t *o) {
+    geo_t g;
+    int H = c->H, W = c->W;
+    warp_geo(c, u, v, depth_t[v * W + u], &g);
+    for (int ch = 0; ch < 3; ch++) bilinear(src + ch * H * W, H, W, g.ix, g.iy, &o->rec[ch], &o->gx[ch], &o->gy[ch]);
+    real dval;
+    bilinear(depth_s, H, W, g.ix, g.iy, &dval, &o->dgx, &o->dgy);
+    o->pd = c->es * dval; o->dgx *= c->es; o->dgy *= c->es;
+    o->cd = g.Z;
+    o->valid = !(g.oobx || g.ooby);
+    px_jac(c, &g, np, o);
+    for (int j = 0; j < np; j++) o->dpd[j] = o->dgx * o->a[j] + o->dgy * o->b[j] + ((j == 6) ? o->pd : 0);
+}
+
+/* outputs of one linearisation */
+typedef struct {
+    double H[MAXP * MAXP], g[MAXP];
+    double cost, cost_photo, cost_dc, n_mask;
+} lin_t;
+
+/*
+ * Cost (per directed pair), the reference's masked mean (plot_loss_surface.py:31-33, optimizer.py:69,79)
+ * plus the optional depth-consistency mean (optimizer.py:83-86):
+ *     C = sum_p M_p W_p diff_p / sum_p M_p  +  w_dc * mean_p dd_p
+ *   diff = e1 + e2,  e1 = w_l1/3 sum_c clamp|rec-tgt|,  e2 = w_ssim/3 sum_c SSIM_c      (train_mono.py:87)
+ *   dd   = clamp(|cd-pd|/(cd+pd),0,1), W = 1-dd                                          (train_mono.py:91-92)
+ *   M    = valid * [diff < auto_err]  (non-differentiable, as in the reference)           (helpers.py:18-20)
+ * Per-pixel error maps (E_k >= 0):  E1 = W e1, E2 = W e2, E3 = dd, with rows J_k = dE_k/dtheta.
+ *     g = sum a (J1+J2) + b J3           == EXACT gradient of C (masks detached, as reference autograd)
+ *   with a = M/sum(M), b = w_dc/(H W).
+ * Gauss-Newton matrix (a generalised GN: exact gradient, PSD curvature model).  With the 2 x np
+ * geometric Jacobian  Jg_p = [d ix/dtheta ; d iy/dtheta]  of the sample position and the bilinear image
+ * gradient  gr_c = [d rec_c/d ix, d rec_c/d iy]:
+ *     H = sum_p a_p Jg_p' Lam_p Jg_p  +  b J3 J3'/max(E3,eps)
+ *     Lam_p = W_p sum_c {  w_l1/3 * gr_c gr_c' / max(|r_c|, eps)                 (IRLS for the L1 term)
+ *                        + w_ssim/3 * ( Cov_3x3(gr_c)/d2_c + mean_3x3(gr_c) mean_3x3(gr_c)'/d1_c ) }
+ *   The SSIM part is the Gauss-Newton matrix of the exact decomposition
+ *     1 - l  = (mu_x-mu_y)^2/d1 ,  1 - cs = Var_3x3(x-y)/d2 ,  SSIM loss = (1 - l cs)/2
+ *   (d1, d2 = the two SSIM denominators, losses.py:38) with d1, d2 and the geometry frozen over the 3x3 window.
+ *   Curvature of the W factor (e dW/dtheta) is neglected in H; it is present in g.
+ * J1/J2/J3/E (optional, [H*W*np] / [H*W*3]) return the per-pixel rows for Jacobian pinning.
+ */
+void orc_linearize(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                   const double T[12], const real *K, double log_scale, const orc_opts *op, const real *auto_err_in,
+                   lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
+    int n = H * W, np = op->nparam;
+    cam_t c;
+    cam_setup(&c, H, W, K, T, log_scale);
+    px_t *px = (px_t *)malloc(sizeof(px_t) * n);
+    real *ae = (real *)malloc(sizeof(real) * n);
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) px_eval(&c, src, depth_t, depth_s, u, v, np, &px[v * W + u]);
+    if (auto_err_in) memcpy(ae, auto_err_in, sizeof(real) * n);
+    else photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
+
+    real *rec = (real *)malloc(sizeof(real) * 3 * n);
+    for (int i = 0; i < n; i++)
+        for (int ch = 0; ch < 3; ch++) rec[ch * n + i] = px[i].rec[ch];
+
+    real *J1 = (real *)calloc((size_t)n * np, sizeof(real)), *J2 = (real *)calloc((size_t)n * np, sizeof(real)),
+         *J3 = (real *)calloc((size_t)n * np, sizeof(real));
+    real *E = (real *)calloc((size_t)n * 3, sizeof(real)), *M = (real *)calloc(n, sizeof(real));
+    real *Lam = (real *)calloc((size_t)n * 3, sizeof(real)); /* lxx, lxy, lyy */
+    const real reps = (real)op->irls_eps;
+    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3);
+    double nmask = 0;
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            int i = v * W + u;
+            const px_t *P = &px[i];
+            /* depth consistency, train_mono.py:91-92 */
+            real sum = P->cd + P->pd, dif = P->cd - P->pd;
+            real raw = fabs(dif) / sum;
+            real dd = clamp01(raw), Wt = 1 - dd;
+            real sg = (raw >= 0 && raw <= 1) ? (dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0)) : (real)0;
+            real ddJ[MAXP];
+            for (int j = 0; j < np; j++) ddJ[j] = sg * 2 * (P->pd * P->zc[j] - P->cd * P->dpd[j]) / (sum * sum);
+            /* photometric rows */
+            real e1 = 0, e2 = 0, de1[MAXP] = {0}, de2[MAXP] = {0};
+            for (int ch = 0; ch < 3; ch++) {
+                const real *x = tgt + ch * n, *y = rec + ch * n;
+                real r = y[i] - x[i], ar = fabs(r);
+                e1 += wl * clamp01(ar);
+                real sgn = (ar <= 1) ? (r > 0 ? (real)1 : (r < 0 ? (real)-1 : (real)0)) : (real)0;
+                for (int j = 0; j < np; j++) de1[j] += wl * sgn * (P->gx[ch] * P->a[j] + P->gy[ch] * P->b[j]);
+                if (ar <= 1) { /* IRLS curvature of the L1 term */
+                    real w1 = wl * Wt / (ar > reps ? ar : reps);
+                    Lam[3 * i] += w1 * P->gx[ch] * P->gx[ch]; Lam[3 * i + 1] += w1 * P->gx[ch] * P->gy[ch];
+                    Lam[3 * i + 2] += w1 * P->gy[ch] * P->gy[ch];
+                }
+                ssim_t s;
+                ssim_at(x, y, H, W, u, v, &s);
+                e2 += ws * s.s;
+                if (!s.clamped) {
+                    /* d s / d y_q = cA + cB y_q + cC x_q  (q in the reflect-padded 3x3 window) */
+                    real nn = s.n1 * s.n2, dn = s.d1 * s.d2, ratio = nn / dn;
+                    real pre = -(real)0.5 / dn / 9;
+                    real cA = pre * (2 * s.mux * s.n2 - 2 * s.n1 * s.mux - ratio * (2 * s.muy * s.d2 - 2 * s.d1 * s.muy));
+                    real cB = pre * (-ratio * 2 * s.d1);
+                    real cC = pre * (2 * s.n1);
+                    real Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0;
+                    for (int dv = -1; dv <= 1; dv++)
+                        for (int du = -1; du <= 1; du++) {
+                            int q = refl(v + dv, H) * W + refl(u + du, W);
+                            const px_t *Q = &px[q];
+                            real cf = ws * (cA + cB * y[q] + cC * x[q]);
+                            for (int j = 0; j < np; j++) de2[j] += cf * (Q->gx[ch] * Q->a[j] + Q->gy[ch] * Q->b[j]);
+                            Sx += Q->gx[ch]; Sy += Q->gy[ch];
+                            Sxx += Q->gx[ch] * Q->gx[ch]; Sxy += Q->gx[ch] * Q->gy[ch]; Syy += Q->gy[ch] * Q->gy[ch];
+                        }
+                    /* GN curvature of the SSIM term: Cov/d2 + mean mean'/d1 */
+                    const real ninth = (real)1 / 9;
+                    real mx = Sx * ninth, my = Sy * ninth;
+                    real w2 = ws * Wt / s.d2, w3 = ws * Wt / s.d1;
+                    Lam[3 * i] += w2 * (Sxx * ninth - mx * mx) + w3 * mx * mx;
+                    Lam[3 * i + 1] += w2 * (Sxy * ninth - mx * my) + w3 * mx * my;
+                    Lam[3 * i + 2] += w2 * (Syy * ninth - my * my) + w3 * my * my;
+                }
+            }
+            real diff = e1 + e2;
+            real m = (real)P->valid;
+            if (op->automask) m *= (diff < ae[i]) ? (real)1 : (real)0;
+            M[i] = m; nmask += m;
+            E[3 * i] = Wt * e1; E[3 * i + 1] = Wt * e2; E[3 * i + 2] = dd;
+            for (int j = 0; j < np; j++) {
+                J1[i * np + j] = Wt * de1[j] - e1 * ddJ[j];
+                J2[i * np + j] = Wt * de2[j] - e2 * ddJ[j];
+                J3[i * np + j] = ddJ[j];
+            }
+        }
+    memset(out, 0, sizeof(*out));
+    out->n_mask = nmask;
+    double a = nmask > 0 ? 1.0 / nmask : 0.0, b = op->w_dc / (double)n, eps = op->irls_eps;
+    for (int i = 0; i < n; i++) {
+        double am = a * M[i];
+        double E1 = E[3 * i], E2 = E[3 * i + 1], E3 = E[3 * i + 2];
+        out->cost_photo += am * (E1 + E2);
+        out->cost_dc += b * E3;
+        double k3 = b / fmax(E3, eps);
+        double lxx = am * Lam[3 * i], lxy = am * Lam[3 * i + 1], lyy = am * Lam[3 * i + 2];
+        const px_t *P = &px[i];
+        for (int j = 0; j < np; j++) {
+            double j1 = J1[i * np + j], j2 = J2[i * np + j], j3 = J3[i * np + j];
+            out->g[j] += am * (j1 + j2) + b * j3;
+            double la = lxx * P->a[j] + lxy * P->b[j], lb = lxy * P->a[j] + lyy * P->b[j];
+            for (int k = 0; k <= j; k++)
+                out->H[j * np + k] += la * P->a[k] + lb * P->b[k] + k3 * j3 * J3[i * np + k];
+        }
+    }
+    for (int j = 0; j < np; j++)
+        for (int k = j + 1; k < np; k++) out->H[j * np + k] = out->H[k * np + j];
+    out->cost = out->cost_photo + out->cost_dc;
+    if (J1o) memcpy(J1o, J1, sizeof(real) * n * np);
+    if (J2o) memcpy(J2o, J2, sizeof(real) * n * np);
+    if (J3o) memcpy(J3o, J3, sizeof(real) * n * np);
+    if (Eo) memcpy(Eo, E, sizeof(real) * n * 3);
+    if (Mo) memcpy(Mo, M, sizeof(real) * n);
+    free(px); free(ae); free(rec); free(J1); free(J2); free(J3); free(E); free(M); free(Lam);
+}
+
+/* scalar cost only: the quantity generate_loss_surface sweeps, plot_loss_surface.py:31-33,45-47 */
+double orc_cost(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                const double T[12], const real *K, double log_scale, const orc_opts *op) {
+    int n = H * W;
+    real *d = (real *)malloc(sizeof(real) * n), *va = (real *)malloc(sizeof(real) * n), *w = (real *)malloc(sizeof(real) * n),
+         *am = (real *)malloc(sizeof(real) * n);
+    orc_photometric(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op->w_l1, op->w_ssim, d, va, w, NULL, am, NULL);
+    double num = 0, den = 0, dc = 0;
+    for (int i = 0; i < n; i++) {
+        double m = va[i] * (op->automask ? am[i] : 1);
+        num += m * w[i] * d[i]; den += m; dc += 1 - w[i];
+    }
+    free(d); free(va); free(w); free(am);
+    return (den > 0 ? num / den : 0.0) + op->w_dc * dc / n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GN / LM step and loop (float64; this is the DEFINITION the HIP solve kernel is checked against) */
+
+/* Solve (H + lambda diag(H) + 1e-12 I) d = -g ; returns 0 ok. Marquardt scaling keeps the step
+ * invariant to the translation/rotation unit mismatch. */
+int orc_solve_step(int np, const double *Hm, const double *g, double lambda, double *delta) {
+    double A[MAXP * MAXP], b[MAXP];
+    for (int i = 0; i < np; i++) {
+        for (int j = 0; j < np; j++) A[i * np + j] = Hm[i * np + j];
+        A[i * np + i] += lambda * Hm[i * np + i] + 1e-12;
+        b[i] = -g[i];
+    }
+    if (chol_solve(np, A, b)) { memset(delta, 0, sizeof(double) * np); return -1; }
+    memcpy(delta, b, sizeof(double) * np);
+    return 0;
+}
+
+/* apply a solved step to the state (T, pose6, log_scale) under the chosen parameterisation */
+static void apply_step(const orc_opts *op, const double *Hm, const double *g, double lambda,
+                       const double Tin[12], double s_in, double Tout[12], double *s_out) {
+    int np = op->nparam;
+    double delta[MAXP];
+    if (op->param == 0) {
+        orc_solve_step(np, Hm, g, lambda, delta);
+        double E[12];
+        orc_se3_exp(delta, E);
+        orc_se3_mul(E, Tin, Tout);
+    } else {
+        /* additive on the reference's 6-vector: J_pose = J_xi A  =>  H_p = A' H A, g_p = A' g */
+        double pose[6], A[36], Hp[MAXP * MAXP], gp[MAXP], Af[MAXP * MAXP];
+        orc_T_to_pose(Tin, pose);
+        orc_euler_left_jacobian(pose, A);
+        memset(Af, 0, sizeof(Af));
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) Af[i * np + j] = A[6 * i + j];
+        if (np == 7) Af[6 * np + 6] = 1;
+        for (int i = 0; i < np; i++) {
+            gp[i] = 0;
+            for (int k = 0; k < np; k++) gp[i] += Af[k * np + i] * g[k];
+            for (int j = 0; j < np; j++) {
+                double s = 0;
+                for (int k = 0; k < np; k++)
+                    for (int l = 0; l < np; l++) s += Af[k * np + i] * Hm[k * np + l] * Af[l * np + j];
+                Hp[i * np + j] = s;
+            }
+        }
+        orc_solve_step(np, Hp, gp, lambda, delta);
+        for (int i = 0; i < 6; i++) pose[i] += delta[i];
+        orc_pose_to_T(pose, Tout);
+    }
+    *s_out = s_in + (np == 7 ? delta[6] : 0.0);
+}
+
+/*
+ * Refine one directed pair.  pose_io: reference 6-vector in/out.  log_scale_io in/out (ignored for nparam 6).
+ * stats (optional, [n_iters+1][4]): cost, cost_photo, n_mask, lambda at each linearisation point.
+ *
+ * GN  (solver 0): n_iters x { linearise at T ; T <- step(T) } with fixed damping lambda0.
+ * LM  (solver 1): n_iters linearisations with accept/reject on the cost, then one cost-only
+ *                 evaluation deciding whether the last step is kept.
+ */
+void orc_refine(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats) {
+    int n = H * W, np = op->nparam;
+    real *ae = (real *)malloc(sizeof(real) * n);
+    photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
+    double Tcur[12], Ttry[12], scur = (np == 7 && log_scale_io) ? *log_scale_io : 0.0, stry;
+    orc_pose_to_T(pose_io, Tcur);
+    memcpy(Ttry, Tcur, sizeof(Tcur));
+    stry = scur;
+    lin_t cur, tr;
+    double lambda = op->lambda0;
+    int have_cur = 0;
+    for (int it = 0; it < op->n_iters; it++) {
+        orc_linearize(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op, ae, &tr, NULL, NULL, NULL, NULL, NULL);
+        if (stats) { stats[4 * it] = tr.cost; stats[4 * it + 1] = tr.cost_photo; stats[4 * it + 2] = tr.n_mask; stats[4 * it + 3] = lambda; }
+        if (op->solver == 0 || !have_cur || tr.cost < cur.cost) {
+            if (op->solver == 1 && have_cur) lambda = fmax(lambda * op->lambda_down, op->lambda_min);
+            cur = tr; memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry; have_cur = 1;
+        } else {
+            lambda *= op->lambda_up;
+        }
+        apply_step(op, cur.H, cur.g, lambda, Tcur, scur, Ttry, &stry);
+    }
+    if (op->solver == 1 && op->n_iters > 0) {
+        double c = orc_cost(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op);
+        if (stats) { int it = op->n_iters; stats[4 * it] = c; stats[4 * it + 1] = c; stats[4 * it + 2] = 0; stats[4 * it + 3] = lambda; }
+        if (c < cur.cost) { memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry; }
+    } else {
+        memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry;
+    }
+    orc_T_to_pose(Tcur, pose_io);
+    if (np == 7 && log_scale_io) *log_scale_io = scur;
+    free(ae);
+}
+
+int orc_sizeof_real(void) { return (int)sizeof(real); }

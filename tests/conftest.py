@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, f"golden_{name}.npz")))
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    from oracle.oracle import Oracle
+    return Oracle("f64")
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    from oracle.oracle import Oracle
+    return Oracle("f32")

@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE ITSELF (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference, pure PyTorch) is imported with its absent third-party
+dependencies stubbed (liegroups, cv2, pykitti, pyslam, torchvision, tensorboardX, imageio --
+none of them is touched by the hot path).  It is executed on seeded
+synthetic inputs from tightly_coupled_sfm_amd.synth in float64 and float32, and inputs +
+outputs are stored as small .npz fixtures.  Nothing from the reference's source text is
+copied: fixtures are data only.  /root/reference does not exist on the GPU box; tests read
+the committed .npz files.
+
+Goldens (SURVEY.md section 8c naming):
+  G1 inverse_warp2 4 outputs incl. OOB / border / Z<1e-3            models/stn.py:234-273
+  G2 SSIM_Loss map                                                   losses.py:27-41
+  G3 compute_photometric_error dict, several poses                   optimization_experiments/helpers.py:8-23
+  G4 solve_pose_iteratively error images, constant-pose PoseNet      train_mono.py:41-120
+  G5 compute_optimization_loss scalar, default options + toggles     optimization_experiments/optimizer.py:29-134
+  G6 autograd d(cost)/d(pose), d(cost)/d(depth); per-pixel Jacobian rows of the three residual maps
+  G7 generate_loss_surface tz / yaw sweeps                           optimization_experiments/plot_loss_surface.py:11-87
+  G8 disp_to_depth, batch_post_process_disparity, avg_final_predictions
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+
+def import_reference():
+    _stub("liegroups", SE3=_Dummy, SO3=_Dummy); _stub("liegroups.torch", SE3=_Dummy, SO3=_Dummy)
+    _stub("cv2"); _stub("pykitti"); _stub("pyslam"); _stub("pyslam.metrics", TrajectoryMetrics=_Dummy)
+    tv = _stub("torchvision"); tv.models = _stub("torchvision.models", ResNet=nn.Module)
+    _stub("torchvision.models.resnet"); tv.transforms = _stub("torchvision.transforms")
+    _stub("torchvision.transforms.functional"); tv.utils = _stub("torchvision.utils", make_grid=lambda *a, **k: None)
+    _stub("tensorboardX", SummaryWriter=_Dummy); _stub("imageio")
+    sys.path.insert(0, REF); sys.path.insert(0, os.path.join(REF, "optimization_experiments"))
+    cwd = os.getcwd()
+    os.chdir(os.path.join(REF, "optimization_experiments"))
+    import warnings
+    warnings.simplefilter("ignore")
+    import helpers, losses, train_mono, optimizer, plot_loss_surface  # noqa
+    from models import stn
+    from utils import learning_helpers
+    os.chdir(cwd)
+    return dict(helpers=helpers, losses=losses, train_mono=train_mono, optimizer=optimizer,
+                plot_loss_surface=plot_loss_surface, stn=stn, learning_helpers=learning_helpers)
+
+
+def main():
+    from tightly_coupled_sfm_amd import synth
+    ref = import_reference()
+    stn, helpers, losses, lh = ref["stn"], ref["helpers"], ref["losses"], ref["learning_helpers"]
+    out = {}
+
+    def T(a, dt):
+        return torch.tensor(np.asarray(a), dtype=dt)
+
+    def N(t):
+        return t.detach().cpu().numpy()
+
+    def reset_grid():
+        # the reference caches its pixel grid in a module global keyed only on height (stn.py:10-21,43-44)
+        stn.pixel_coords = None
+
+    # ------------------------------------------------------------------ G1/G2/G3/G6 per size & dtype
+    cases = [("s8x16", 8, 16, 11), ("s24x40", 24, 40, 3), ("s48x160", 48, 160, 5)]
+    for name, H, W, seed in cases:
+        p = synth.make_pair(H, W, seed=seed, dtype=np.float64)
+        poses = [synth.perturb_pose(p["pose_gt"], seed + k) for k in range(3)]
+        # stress poses: large yaw (OOB columns), strong backwards translation (Z clamp), identity
+        poses += [np.array([0.0, 0, 0, 0, 0.35, 0]), np.array([0.0, 0.0, 2.0, 0.0, 0.0, 0.0]),
+                  np.zeros(6), np.array([0.05, -0.02, -0.1, 0.02, -0.03, 0.04])]
+        if H * W > 2000:      # keep the larger fixture small: one nominal, one OOB-heavy, one mixed pose
+            poses = [poses[0], poses[3], poses[6]]
+        poses = np.stack(poses)
+        g = dict(tgt=p["tgt"], src=p["src"], depth_t=p["depth_t"], depth_s=p["depth_s"], K=p["K"], poses=poses)
+        for dtn, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            reset_grid()
+            t, s = T(p["tgt"], dt)[None], T(p["src"], dt)[None]
+            dpt, dps = T(p["depth_t"], dt)[None, None], T(p["depth_s"], dt)[None, None]
+            K = T(p["K"], dt)[None]
+            recs, vals, pds, cds, diffs, wts, masks = [], [], [], [], [], [], []
+            costs, gposes = [], []
+            for k in range(len(poses)):
+                po = T(poses[k], dt)[None].clone().requires_grad_()
+                rec, valid, pd, cd = stn.inverse_warp2(s, dpt, dps, -po, K, "zeros")
+                recs.append(N(rec[0])); vals.append(N(valid[0, 0])); pds.append(N(pd[0, 0])); cds.append(N(cd[0, 0]))
+                r = helpers.compute_photometric_error(t, s, dpt, dps, po, K)
+                diffs.append(N(r["diff_img"][0, 0])); wts.append(N(r["weight_mask"][0, 0])); masks.append(N(r["valid_mask"][0, 0]))
+                den = r["valid_mask"].sum()
+                L = (r["diff_img"] * r["valid_mask"] * r["weight_mask"]).sum() / den
+                costs.append(L.item() if den.item() > 0 else 0.0)
+                if den.item() > 0:
+                    L.backward()
+                    gposes.append(N(po.grad[0]))
+                else:
+                    gposes.append(np.zeros(6))
+            g[f"{dtn}_rec"] = np.stack(recs); g[f"{dtn}_valid"] = np.stack(vals)
+            g[f"{dtn}_proj_depth"] = np.stack(pds); g[f"{dtn}_comp_depth"] = np.stack(cds)
+            g[f"{dtn}_diff"] = np.stack(diffs); g[f"{dtn}_weight"] = np.stack(wts); g[f"{dtn}_mask"] = np.stack(masks)
+            g[f"{dtn}_cost"] = np.array(costs); g[f"{dtn}_grad_pose"] = np.stack(gposes)
+            g[f"{dtn}_ssim_ts"] = N(losses.SSIM_Loss()(t, s)[0])
+        out[name] = g
+
+    # ------------------------------------------------------------------ G6: depth gradients + Jacobian rows (f64, 24x40)
+    H, W, seed = 24, 40, 3
+    p = synth.make_pair(H, W, seed=seed, dtype=np.float64)
+    pose = synth.perturb_pose(p["pose_gt"], seed)
+    dt = torch.float64
+    reset_grid()
+    t, s = T(p["tgt"], dt)[None], T(p["src"], dt)[None]
+    K = T(p["K"], dt)[None]
+    ssim = losses.SSIM_Loss()
+
+    def rows(po, dpt, dps):
+        """the three per-pixel residual maps the GN engine uses, composed from reference functions only
+        (same composition as helpers.py:11-14): E1 = W*mean_c .15|.|, E2 = W*mean_c .85 SSIM, E3 = 1-W"""
+        rec, valid, pd, cd = stn.inverse_warp2(s, dpt, dps, -po, K, "zeros")
+        e1 = (0.15 * (rec - t).abs().clamp(0, 1)).mean(1, True)
+        e2 = (0.85 * ssim(t, rec)).mean(1, True)
+        dd = ((cd - pd).abs() / (cd + pd)).clamp(0, 1)
+        w = 1 - dd
+        return torch.stack([w * e1, w * e2, dd], 0).reshape(3, H, W)
+
+    po = T(pose, dt)[None]
+    dpt, dps = T(p["depth_t"], dt)[None, None], T(p["depth_s"], dt)[None, None]
+    Jp = torch.autograd.functional.jacobian(lambda q: rows(q, dpt, dps), po, vectorize=True)  # [3,H,W,1,6]
+    # depth-scale column: d/d(log s) with both depth maps scaled by s
+    ls = torch.zeros((), dtype=dt)
+    Js = torch.autograd.functional.jacobian(lambda q: rows(po, dpt * torch.exp(q), dps * torch.exp(q)), ls, vectorize=True)
+    po2 = po.clone().requires_grad_(); d1 = dpt.clone().requires_grad_(); d2 = dps.clone().requires_grad_()
+    r = helpers.compute_photometric_error(t, s, d1, d2, po2, K)
+    L = (r["diff_img"] * r["valid_mask"] * r["weight_mask"]).sum() / r["valid_mask"].sum()
+    L.backward()
+    out["jac24x40"] = dict(tgt=p["tgt"], src=p["src"], depth_t=p["depth_t"], depth_s=p["depth_s"], K=p["K"], pose=pose,
+                           E=N(rows(po, dpt, dps)), J_pose=N(Jp.reshape(3, H, W, 6)), J_logscale=N(Js.reshape(3, H, W)),
+                           cost=L.item(), grad_pose=N(po2.grad[0]), grad_depth_t=N(d1.grad[0, 0]), grad_depth_s=N(d2.grad[0, 0]),
+                           mask=N(r["valid_mask"][0, 0]))
+
+    # ------------------------------------------------------------------ G4/G5: batched solve_pose_iteratively + loss
+    class ConstPose(nn.Module):
+        """stand-in PoseNet: returns fixed per-sample poses on the first call and fixed small
+        corrections on later calls (bypasses the conv net, keeps the reference control flow)."""
+        def __init__(self, first, corr):
+            super().__init__(); self.first, self.corr, self.calls = first, corr, 0
+        def forward(self, x):
+            self.calls += 1
+            return self.first.clone() if self.calls == 1 else self.corr.clone()
+
+    B, S, H, W = 2, 2, 24, 40
+    dt = torch.float64
+    reset_grid()
+    tg, srcs, dts, dss, Ks, pgt = [], [[] for _ in range(S)], [], [[] for _ in range(S)], [], [[] for _ in range(S)]
+    for b in range(B):
+        for si in range(S):
+            sign = 1.0 if si == 0 else -1.0
+            base = np.array([0.003, -0.002, 0.033, 0.002, -0.004, 0.0015]) * sign
+            p = synth.make_pair(H, W, seed=20 + b, pose_gt=base, dtype=np.float64)
+            if si == 0:
+                tg.append(p["tgt"]); dts.append(p["depth_t"]); Ks.append(p["K"])
+            srcs[si].append(p["src"]); dss[si].append(p["depth_s"]); pgt[si].append(p["pose_gt"])
+    target = T(np.stack(tg), dt); source_list = [T(np.stack(x), dt) for x in srcs]
+    depths = [T(np.stack(dts), dt)[:, None]] + [T(np.stack(x), dt)[:, None] for x in dss]
+    Kb = T(np.stack(Ks), dt)
+    rng = np.random.default_rng(7)
+    # stacked order of solve_pose_iteratively: [fwd s0 b0..bB-1, fwd s1 ..., inv s0 ..., inv s1 ...]
+    gt_f = np.concatenate([np.stack(x) for x in pgt]); first = np.concatenate([gt_f, -gt_f]) + rng.normal(scale=2e-3, size=(2 * S * B, 6))
+    corr = rng.normal(scale=3e-4, size=(2 * S * B, 6))
+    g4 = dict(target=N(target), sources=np.stack([N(x) for x in source_list]), depths=np.stack([N(d) for d in depths]),
+              K=N(Kb), first=first, corr=corr)
+    for iters in (1, 4):
+        pm = ConstPose(T(first, dt), T(corr, dt))
+        poses, poses_inv, outputs = ref["train_mono"].solve_pose_iteratively(iters, depths, pm, target, source_list, Kb, return_errors=True)
+        for d in ("fwd", "inv"):
+            for k in ("diff_img", "valid_mask", "weight_mask", "auto_mask_error", "auto_mask", "poses", "img_rec"):
+                g4[f"it{iters}_{d}_{k}"] = N(outputs[d][k])
+        g4[f"it{iters}_poses"] = np.stack([N(x) for x in poses]); g4[f"it{iters}_poses_inv"] = np.stack([N(x) for x in poses_inv])
+        # G5: scalar optimisation loss under the default options and toggles
+        base_opts = {'epochs': 20, 'diff_img_argmin': True, 'automasking': True, 'l_depth_consist': True,
+                     'l_depth_consist_weight': 0.15, 'l_depth_init': True, 'l_depth_init_weight': 0.1,
+                     'l_inverse_reconstruction': True, 'l_smooth': False, 'l_smooth_weight': 2,
+                     'l_pose_consist': False, 'num_source_imgs': S, 'plotting': False}
+        DO = ref["optimizer"].DepthOptimizer
+        for tag, upd in (("default", {}), ("noargmin", {'diff_img_argmin': False}), ("noauto", {'automasking': False}),
+                         ("noinv", {'l_inverse_reconstruction': False}), ("nodc", {'l_depth_consist': False}),
+                         ("smooth", {'l_smooth': True}), ("posec", {'l_pose_consist': True}), ("noinit", {'l_depth_init': False})):
+            o = object.__new__(DO)
+            o.options = dict(base_opts, **upd); o.ssim_loss = losses.SSIM_Loss()
+            disp = T(synth.depth_to_sigmoid_disp(np.stack(dts)), dt)[:, None]
+            o.target_disparity = (disp * 0.97 + 0.004).clone()
+            loss = DO.compute_optimization_loss(o, 0, 0, target, disp, outputs['fwd'], outputs['inv'])
+            g4[f"it{iters}_loss_{tag}"] = np.array(loss.reshape(-1)[0].item())
+        g4["loss_disp"] = N(disp); g4["loss_disp0"] = N(o.target_disparity)
+    out["batch24x40"] = g4
+
+    # ------------------------------------------------------------------ G7: loss-surface sweeps (f32, as the reference runs it)
+    H, W, seed = 48, 160, 5
+    p = synth.make_pair(H, W, seed=seed, dtype=np.float32)
+    pose = synth.perturb_pose(p["pose_gt"], seed)
+    dt = torch.float32
+    reset_grid()
+    data = (T(p["tgt"], dt)[None], [T(p["src"], dt)[None]], None, None, None, T(p["K"], dt)[None], None, None, None, None, None)
+    depths = [T(p["depth_t"], dt)[None, None], T(p["depth_s"], dt)[None, None]]
+    rs = ref["plot_loss_surface"].generate_loss_surface(data, depths, T(pose, dt)[None].clone(), sample_trans=True, sample_yaw=True)
+    out["sweep48x160"] = dict(tgt=p["tgt"], src=p["src"], depth_t=p["depth_t"], depth_s=p["depth_s"], K=p["K"], pose=pose,
+                              delta_list=rs["delta_list"], delta_list_yaw=rs["delta_list_yaw"],
+                              errors=rs["reconstruction_errors"], errors_yaw=rs["reconstruction_errors_yaw"],
+                              original_error=np.array(rs["original_error"]), best_trans_delta=np.array(rs["best_trans_delta"]),
+                              best_yaw_delta=np.array(rs["best_yaw_delta"]))
+
+    # ------------------------------------------------------------------ G8: small helpers
+    rng = np.random.default_rng(9)
+    disp = rng.uniform(0.02, 0.95, size=(2, 1, 6, 10))
+    sd, dep = lh.disp_to_depth(T(disp, torch.float64), 0.06, 2.67)
+    l, r_ = rng.uniform(0.1, 1, size=(2, 6, 10)), rng.uniform(0.1, 1, size=(2, 6, 10))
+    lst = [T(rng.normal(size=(4, 6)), torch.float32) for _ in range(7)]
+    out["helpers"] = dict(disp=disp, scaled_disp=N(sd), depth=N(dep), l_disp=l, r_disp=r_,
+                          post=lh.batch_post_process_disparity(l, r_), avg_list=np.stack([N(x) for x in lst]),
+                          avg5=N(helpers.avg_final_predictions(lst, 5)))
+
+    # ------------------------------------------------------------------ full-size summary (192x640, f32 as run by the reference)
+    H, W, seed = 192, 640, 0
+    p = synth.make_pair(H, W, seed=seed, dtype=np.float32)
+    pose = synth.perturb_pose(p["pose_gt"], seed)
+    full = dict(pose=pose, pose_gt=p["pose_gt"], K=p["K"],
+                in_checksum=np.array([p["tgt"].astype(np.float64).sum(), p["src"].astype(np.float64).sum(),
+                                      p["depth_t"].astype(np.float64).sum(), p["depth_s"].astype(np.float64).sum()]))
+    for dtn, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        reset_grid()
+        t, s = T(p["tgt"], dt)[None], T(p["src"], dt)[None]
+        dpt, dps = T(p["depth_t"], dt)[None, None], T(p["depth_s"], dt)[None, None]
+        K = T(p["K"], dt)[None]
+        po = T(pose, dt)[None].clone().requires_grad_()
+        r = helpers.compute_photometric_error(t, s, dpt, dps, po, K)
+        L = (r["diff_img"] * r["valid_mask"] * r["weight_mask"]).sum() / r["valid_mask"].sum()
+        L.backward()
+        full[f"{dtn}_cost"] = np.array(L.item()); full[f"{dtn}_grad_pose"] = N(po.grad[0])
+        full[f"{dtn}_n_mask"] = np.array(r["valid_mask"].sum().item())
+        full[f"{dtn}_sum_diff"] = np.array(r["diff_img"].double().sum().item())
+        full[f"{dtn}_sum_weight"] = np.array(r["weight_mask"].double().sum().item())
+        full[f"{dtn}_diff_sub"] = N(r["diff_img"][0, 0, ::7, ::7]); full[f"{dtn}_weight_sub"] = N(r["weight_mask"][0, 0, ::7, ::7])
+        full[f"{dtn}_mask_sub"] = N(r["valid_mask"][0, 0, ::7, ::7]); full[f"{dtn}_rec_sub"] = N(r["img_rec"][0, :, ::7, ::7])
+    out["full192x640"] = full
+
+    for name, d in out.items():
+        path = os.path.join(HERE, f"golden_{name}.npz")
+        np.savez_compressed(path, **d)
+        print(f"{name:14s} {os.path.getsize(path) / 1024:8.1f} KiB  keys={len(d)}")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    main()
