@@ -1,0 +1,137 @@
+/*
+ * tcsfm.h -- C ABI of libtcsfm_hip.so, the MI355X (gfx950) photometric pose/depth refinement engine.
+ *
+ * This is the drop-in boundary for the hot path of utiasSTARS/tightly-coupled-SfM
+ * (SURVEY.md section 8a/8b).  The reference is pure Python/PyTorch and has no FFI; every entry
+ * point below names the reference function (file:line under /root/reference) it replaces.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch types.  All array arguments are fp32, contiguous, NCHW like the reference:
+ *       images [N,3,H,W], depth maps [N,1,H,W] (== [N,H,W]), intrinsics [N,3,3] row-major, poses [N,6].
+ *   - a "pair" is one DIRECTED frame pair (target, source); the reference stacks forward and inverse
+ *     pairs along N the same way (train_mono.py:54-62).
+ *   - pose 6-vector = the reference's [tx,ty,tz,rx,ry,rz] (models/stn.py:143-158).  The warp uses
+ *     pose_vec2mat(-pose) exactly like the reference call sites (train_mono.py:69, helpers.py:11).
+ *   - intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1] (all of the reference's loaders produce
+ *     this form); anything else returns TCSFM_E_INTRINSICS.
+ *   - pointers are DEVICE pointers unless tcsfm_opts.host_ptrs != 0, in which case the library stages
+ *     them through its own device buffers (PCIe-inclusive path).
+ *   - every call is asynchronous on the handle's HIP stream when given device pointers, except that
+ *     host-pointer calls and calls returning host scalars synchronise that stream before returning.
+ *   - return value: 0 = ok, negative = error; tcsfm_last_error() gives the message.  Nothing throws.
+ *   - one handle = one device + one stream; calls on a handle are not re-entrant.
+ */
+#ifndef TCSFM_H
+#define TCSFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tcsfm_ctx *tcsfm_handle;
+
+enum {
+    TCSFM_OK = 0,
+    TCSFM_E_ARG = -1,        /* bad argument (null pointer, size out of range, ...)   */
+    TCSFM_E_HIP = -2,        /* a HIP runtime call failed                              */
+    TCSFM_E_INTRINSICS = -3, /* non-pinhole intrinsics                                 */
+    TCSFM_E_NOMEM = -4
+};
+
+enum { TCSFM_SOLVER_GN = 0, TCSFM_SOLVER_LM = 1 };
+enum { TCSFM_PARAM_SE3 = 0,    /* T <- exp(delta^) T, delta = [rho, phi] (liegroups ordering, validate.py:65) */
+       TCSFM_PARAM_EULER = 1   /* pose <- pose + delta on the reference's [t, euler] vector                    */ };
+enum { TCSFM_REFINE_POSE = 0,        /* 6 DoF                                                  */
+       TCSFM_REFINE_POSE_SCALE = 1   /* 6 DoF + log depth-scale shared by both depth maps (7x7) */ };
+
+typedef struct tcsfm_opts {
+    int32_t n_iters;       /* linearisations per refine call (BASELINE.json: 4)                         */
+    int32_t solver;        /* TCSFM_SOLVER_*                                                             */
+    int32_t param;         /* TCSFM_PARAM_*                                                              */
+    int32_t refine;        /* TCSFM_REFINE_*                                                             */
+    int32_t automask;      /* mask = valid * (diff < auto_err), helpers.py:17-19; options['automasking'] */
+    int32_t depth_is_disp; /* depth inputs are sigmoid disparities: disp_to_depth is fused (learning_helpers.py:77-86) */
+    int32_t host_ptrs;     /* array arguments are host pointers                                          */
+    int32_t reserved0;
+    float w_l1, w_ssim;    /* 0.15 / 0.85, train_mono.py:87                                              */
+    float w_dc;            /* options['l_depth_consist_weight'] if options['l_depth_consist'] else 0, optimizer.py:83-86 */
+    float irls_eps;        /* floor of the IRLS denominators                                             */
+    float lambda0, lambda_up, lambda_down, lambda_min; /* Marquardt damping (relative to diag H)        */
+    float min_depth, max_depth; /* config['min_depth'], config['max_depth'] (depth_is_disp only)       */
+} tcsfm_opts;
+
+/* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32 */
+enum { TCSFM_STAT_COST = 0, TCSFM_STAT_COST_PHOTO = 1, TCSFM_STAT_NMASK = 2, TCSFM_STAT_LAMBDA = 3, TCSFM_NSTAT = 4 };
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Allocates all device scratch for up to max_pairs directed pairs of H x W images on `device`.
+ * Nothing in the reference corresponds to this: PyTorch owns memory there (optimizer.py:15-27). */
+int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs);
+void tcsfm_destroy(tcsfm_handle h);
+const char *tcsfm_last_error(tcsfm_handle h); /* h may be NULL: last create() error */
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own stream. */
+int tcsfm_set_stream(tcsfm_handle h, void *hip_stream);
+int tcsfm_synchronize(tcsfm_handle h);
+void tcsfm_default_opts(tcsfm_opts *o);
+/* bytes of HBM traffic the algorithm must move per pixel per pair per linearisation: 32 */
+int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *o);
+
+/* ---- reference-function drop-ins (a1, a5, a7, a12) -------------------------------------------- */
+
+/* disp_to_depth, utils/learning_helpers.py:77-86.  n elements; scaled/depth may be NULL. */
+int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const float *disp, float *scaled_disp, float *depth);
+
+/* inverse_warp2(src, depth_t, depth_s, -pose, K), models/stn.py:234-273.
+ * Outputs (any may be NULL): img_rec [N,3,H,W], valid [N,1,H,W], proj_depth, comp_depth [N,1,H,W]. */
+int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,
+               const float *pose, const float *K, float *img_rec, float *valid, float *proj_depth, float *comp_depth);
+
+/* compute_photometric_error, optimization_experiments/helpers.py:8-23 == per-pair residual assembly of
+ * solve_pose_iteratively, train_mono.py:82-100.  Outputs (any may be NULL), all [N,1,H,W] except img_rec:
+ * diff (diff_img), valid (warp validity, stn.py:268-269), weight (weight_mask), auto_err (auto_mask_error),
+ * auto_mask (diff < auto_err), img_rec [N,3,H,W]. */
+int tcsfm_photometric(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                      const float *depth_s, const float *pose, const float *K, float *diff, float *valid, float *weight,
+                      float *auto_err, float *auto_mask, float *img_rec);
+
+/* The scalar generate_loss_surface sweeps, optimization_experiments/plot_loss_surface.py:31-33,45-47:
+ * cost[i] = sum(diff*mask*weight)/sum(mask) (+ w_dc*mean(1-weight)) of ONE pair (first pair of the arrays)
+ * under P candidate poses [P,6].  cost_out: P doubles (host pointer always). */
+int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, int P, const float *poses, double *cost_out);
+
+/* ---- the Gauss-Newton / LM engine (new functionality; north star) ------------------------------ */
+
+/* One linearisation of N pairs at the given poses (and log depth-scales, may be NULL): normal equations
+ * for parity tests.  np = 6 or 7 per o->refine.  Host outputs (doubles): Hmat [N,np,np], g [N,np],
+ * stats [N,4] = cost, cost_photo, cost_dc, n_mask. */
+int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                    const float *depth_s, const float *pose, const float *log_scale, const float *K,
+                    double *Hmat, double *g, double *stats);
+
+/* Refine N directed pairs: replaces the epoch loop of DepthOptimizer.optimize_window
+ * (optimization_experiments/optimizer.py:217-274) for the pose / pose+scale unknowns with
+ * o->n_iters Gauss-Newton (or LM) iterations on the reference's residual.
+ *   pose_io       [N,6] in: initial pose (e.g. PoseNet output), out: refined pose
+ *   log_scale_io  [N]   in/out, NULL unless refine == POSE_SCALE (NULL then means start at 0, result dropped)
+ *   stats_out     [N,n_iters+1,TCSFM_NSTAT] or NULL */
+int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                 const float *depth_s, const float *K, float *pose_io, float *log_scale_io, float *stats_out);
+
+/* ---- SE(3) utilities, host, double (replace liegroups.SE3 at data/kitti_loader_stereo.py:129-147,
+ *      validate.py:65-71; liegroups is an absent third-party dependency, version unpinned) ---------- */
+void tcsfm_pose_to_matrix(const double pose[6], double T[12]);   /* pose_vec2mat(-pose), 3x4 row-major  */
+void tcsfm_matrix_to_pose(const double T[12], double pose[6]);
+void tcsfm_se3_exp(const double xi[6], double T[12]);            /* xi = [rho, phi]                     */
+void tcsfm_se3_log(const double T[12], double xi[6]);
+void tcsfm_se3_mul(const double A[12], const double B[12], double C[12]);
+void tcsfm_se3_inv(const double A[12], double B[12]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCSFM_H */

@@ -1,0 +1,94 @@
+"""CPU-only checks of the product boundary: the C-ABI library loads without a GPU, exports every
+symbol include/tcsfm.h declares, its host-side SE(3) utilities agree with the oracle, and error
+paths that need no device behave.  (No compute calls: those are the -m gpu tests.)"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tightly_coupled_sfm_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "tcsfm.h")).read()
+    declared = set(re.findall(r"\b(tcsfm_[a-z0-9_]+)\s*\(", hdr))
+    from tightly_coupled_sfm_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_opts_struct_matches_header(lib):
+    from tightly_coupled_sfm_amd import _lib
+    o = _lib.default_opts()
+    assert (o.n_iters, o.solver, o.param, o.refine, o.automask) == (4, 0, 0, 0, 1)
+    assert abs(o.w_l1 - 0.15) < 1e-7 and abs(o.w_ssim - 0.85) < 1e-7 and abs(o.max_depth - 2.67) < 1e-6
+    assert C.sizeof(_lib.Opts) == 8 * 4 + 10 * 4
+    assert lib.tcsfm_algorithmic_bytes_per_pixel(C.byref(o)) == 32
+
+
+def test_se3_host_utilities_match_oracle(lib, oracle64):
+    from tightly_coupled_sfm_amd import engine as E
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        pose = rng.normal(scale=[0.05, 0.05, 0.05, 0.3, 0.3, 0.3])
+        T = E.pose_to_matrix(pose)
+        assert np.allclose(T, oracle64.pose_to_T(pose), atol=1e-15)
+        assert np.allclose(E.matrix_to_pose(T), pose, atol=1e-13)
+        xi = rng.normal(scale=[0.1, 0.1, 0.1, 0.5, 0.5, 0.5])
+        X = E.se3_exp(xi)
+        assert np.allclose(X, oracle64.se3_exp(xi), atol=1e-15)
+        assert np.allclose(E.se3_log(X), xi, atol=1e-12)
+        assert np.allclose(X[:, :3] @ X[:, :3].T, np.eye(3), atol=1e-14)
+        Xi = E.se3_inv(X)
+        assert np.allclose(E.se3_mul(X, Xi), np.eye(4)[:3], atol=1e-14)
+    # small-angle series branch
+    xi = np.array([0.01, -0.02, 0.03, 1e-7, -2e-7, 3e-7])
+    assert np.allclose(E.se3_log(E.se3_exp(xi)), xi, atol=1e-15)
+    # liegroups convention: translation first, exp of a pure translation twist is that translation
+    assert np.allclose(E.se3_exp([1, 2, 3, 0, 0, 0])[:, 3], [1, 2, 3])
+
+
+def test_euler_chain_rule(oracle64):
+    """A = d(xi_left)/d(pose) used by the additive-Euler parameterisation, by finite differences"""
+    from tightly_coupled_sfm_amd import engine as E
+    pose = np.array([0.02, -0.01, 0.04, 0.2, -0.1, 0.15])
+    A = oracle64.euler_left_jacobian(pose)
+    T0 = E.pose_to_matrix(pose)
+    h = 1e-6
+    for j in range(6):
+        dp = np.zeros(6); dp[j] = h
+        xi = E.se3_log(E.se3_mul(E.pose_to_matrix(pose + dp), E.se3_inv(T0)))
+        assert np.allclose(xi / h, A[:, j], atol=2e-6)
+
+
+def test_create_without_gpu_fails_cleanly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.tcsfm_create(C.byref(h), 0, 192, 640, 2) < 0
+    assert h.value is None and b"tcsfm_create" in lib.tcsfm_last_error(None)
+    assert lib.tcsfm_create(C.byref(h), 0, 2, 2, 1) == -1       # bad sizes
+    from tightly_coupled_sfm_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(192, 640, 1)
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under the product package may reference it"""
+    pkg = os.path.join(REPO, "tightly_coupled_sfm_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f

@@ -1,0 +1,245 @@
+"""GPU parity: the HIP engine, called through the C ABI (libtcsfm_hip.so), against
+  (a) the committed golden vectors produced by the reference itself, and
+  (b) the float64 CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 engine vs float64 truth):
+  warp / residual maps   2e-5 absolute on [0,1] images; discrete decisions (valid / auto-mask) may differ
+                         on <=0.3% of pixels (near-ties decided in fp32 vs fp64)
+  cost                   1e-5 relative;  gradient / GN matrix  2e-4 of their largest entry
+  refined pose           1e-4 relative (translation norm and rotation norm separately) -- BASELINE.json's bar
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+SMALL = ["s8x16", "s24x40", "s48x160"]
+
+
+def _eng(H, W, n):
+    from tightly_coupled_sfm_amd.engine import Engine
+    return Engine(H, W, n)
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def _stack_pair(g, poses):
+    n = len(poses)
+    rep = lambda a: np.repeat(a[None], n, 0)
+    return (_t(rep(g["tgt"])), _t(rep(g["src"])), _t(rep(g["depth_t"])[:, None]), _t(rep(g["depth_s"])[:, None]),
+            _t(rep(g["K"])), _t(poses))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_warp_vs_reference_golden(name):
+    """inverse_warp2 (stn.py:234-273) incl. OOB sentinel, zero-pad border blending, Z clamp"""
+    g = load_golden(name)
+    H, W = g["tgt"].shape[1:]
+    tgt, src, dt, ds, K, poses = _stack_pair(g, g["poses"])
+    e = _eng(H, W, len(poses))
+    rec, valid, pd, cd = e.inverse_warp2(src, dt, ds, -poses, K)   # reference call form: -pose (train_mono.py:69)
+    rec, valid, pd, cd = (x.cpu().numpy() for x in (rec, valid, pd, cd))
+    for k in range(len(poses)):
+        bad = valid[k, 0] != g["f64_valid"][k]
+        assert bad.mean() <= 0.003 or (not bad[1:-1, 1:-1].any()), (name, k, int(bad.sum()))
+        ok = ~bad
+        assert _maxabs(rec[k][:, ok], g["f64_rec"][k][:, ok]) < 1e-4      # |ix| up to W: ulp(ix)*gradient
+        assert _maxabs(pd[k, 0][ok], g["f64_proj_depth"][k][ok]) < 2e-4
+        scale = max(1.0, float(np.abs(g["f64_comp_depth"][k]).max()))
+        assert _maxabs(cd[k, 0], g["f64_comp_depth"][k]) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_photometric_vs_reference_golden(name):
+    """compute_photometric_error (helpers.py:8-23): diff, weight, combined mask"""
+    g = load_golden(name)
+    H, W = g["tgt"].shape[1:]
+    tgt, src, dt, ds, K, poses = _stack_pair(g, g["poses"])
+    e = _eng(H, W, len(poses))
+    r = e.compute_photometric_error(tgt, src, dt, ds, poses, K)
+    diff, mask, weight, wv = (r[k].cpu().numpy()[:, 0] for k in ("diff_img", "valid_mask", "weight_mask", "warp_valid"))
+    for k in range(len(poses)):
+        vbad = wv[k] != g["f64_valid"][k]
+        if vbad.any():      # exact-tie border pixels at the identity pose / a handful of fp32 ties
+            assert vbad.mean() <= 0.003 or not vbad[1:-1, 1:-1].any()
+            continue
+        assert _maxabs(diff[k], g["f64_diff"][k]) < 3e-5
+        assert _maxabs(weight[k], g["f64_weight"][k]) < 1e-4
+        assert (mask[k] != g["f64_mask"][k]).mean() <= 0.003
+
+
+def test_batched_fwd_inv_stack_vs_solve_pose_iteratively():
+    """the [fwd ; inv] directed-pair stacking of solve_pose_iteratively (train_mono.py:54-62,82-100) with a
+    constant-pose PoseNet stand-in, iterations=1: error images of all 8 directed pairs in ONE engine call"""
+    g = load_golden("batch24x40")
+    B, S = 2, 2
+    target, sources, depths, K = g["target"], g["sources"], g["depths"], g["K"]
+    H, W = target.shape[2:]
+    tg = np.concatenate([target] * S); sr = np.concatenate(list(sources))
+    dtg = np.concatenate([depths[0]] * S); dsr = np.concatenate(list(depths[1:]))
+    tgt = np.concatenate([tg, sr]); src = np.concatenate([sr, tg])
+    dt = np.concatenate([dtg, dsr]); ds = np.concatenate([dsr, dtg])
+    Ks = np.concatenate([K] * (2 * S))
+    e = _eng(H, W, 2 * S * B)
+    r = e.compute_photometric_error(_t(tgt), _t(src), _t(dt), _t(ds), _t(g["first"]), _t(Ks))
+    split = S * B
+    for d, sl in (("fwd", slice(0, split)), ("inv", slice(split, None))):
+        assert _maxabs(r["diff_img"].cpu().numpy()[sl], g[f"it1_{d}_diff_img"]) < 3e-5
+        assert _maxabs(r["weight_mask"].cpu().numpy()[sl], g[f"it1_{d}_weight_mask"]) < 1e-4
+        assert _maxabs(r["auto_mask_error"].cpu().numpy()[sl], g[f"it1_{d}_auto_mask_error"]) < 3e-5
+        assert (r["warp_valid"].cpu().numpy()[sl] != g[f"it1_{d}_valid_mask"]).mean() <= 0.003
+        assert (r["auto_mask"].cpu().numpy()[sl] != g[f"it1_{d}_auto_mask"]).mean() <= 0.003
+        assert _maxabs(r["img_rec"].cpu().numpy()[sl], g[f"it1_{d}_img_rec"]) < 1e-4
+
+
+def test_loss_surface_vs_reference_golden():
+    """generate_loss_surface (plot_loss_surface.py:11-87): both 50-point sweeps in one launch each"""
+    g = load_golden("sweep48x160")
+    H, W = g["tgt"].shape[1:]
+    e = _eng(H, W, 64)
+    args = (_t(g["tgt"][None]), _t(g["src"][None]), _t(g["depth_t"][None, None]), _t(g["depth_s"][None, None]), _t(g["K"][None]))
+    for deltas, errs, idx in ((g["delta_list"], g["errors"], 2), (g["delta_list_yaw"], g["errors_yaw"], 4)):
+        poses = np.repeat(g["pose"][None].astype(np.float32), len(deltas), 0)
+        poses[:, idx] += deltas
+        mine = e.loss_surface(*args, _t(poses))
+        rel = np.abs(mine - errs) / errs
+        assert np.median(rel) < 2e-5 and rel.max() < 2e-3
+        assert abs(int(np.argmin(mine)) - int(np.argmin(errs))) <= 1
+
+
+def test_disp_to_depth_vs_reference_golden():
+    g = load_golden("helpers")
+    e = _eng(8, 8, 1)
+    s, d = e.disp_to_depth(_t(g["disp"]), 0.06, 2.67)
+    assert _maxabs(s.cpu().numpy(), g["scaled_disp"]) < 2e-6 * g["scaled_disp"].max()
+    assert np.max(np.abs(d.cpu().numpy() - g["depth"]) / g["depth"]) < 2e-6
+
+
+def _pairs(N, H, W, seed0=0, both=False):
+    from tightly_coupled_sfm_amd import synth
+    return synth.make_batch(N, H, W, seed0=seed0, both_directions=both)
+
+
+def _dev(b):
+    return (_t(b["tgt"]), _t(b["src"]), _t(b["depth_t"]), _t(b["depth_s"]), _t(b["K"]))
+
+
+@pytest.mark.parametrize("H,W", [(24, 40), (48, 160), (192, 640)])
+@pytest.mark.parametrize("refine,w_dc", [(0, 0.0), (0, 0.15), (1, 0.0), (1, 0.15)])
+def test_linearize_vs_oracle(H, W, refine, w_dc, oracle64):
+    """cost, mask count, exact gradient and GN matrix of one linearisation vs the float64 oracle"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    N = 3
+    b = _pairs(N, H, W, seed0=4)
+    e = _eng(H, W, N)
+    ls = np.array([0.0, 0.03, -0.05], dtype=np.float32)
+    o = default_opts(refine=refine, w_dc=w_dc)
+    out = e.linearize(*_dev(b), _t(b["pose_init"]), o, log_scale=_t(ls) if refine else None)
+    for n in range(N):
+        ref = oracle64.linearize(b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0], b["pose_init"][n], b["K"][n],
+                                 oopts(nparam=6 + refine, w_dc=w_dc), log_scale=float(ls[n]) if refine else 0.0)
+        assert abs(out["cost"][n] - ref["cost"]) < 1e-5 * ref["cost"]
+        assert abs(out["n_mask"][n] - ref["n_mask"]) <= 0.003 * ref["n_mask"] + 1
+        assert _maxabs(out["g"][n], ref["g"]) < 2e-4 * np.abs(ref["g"]).max()
+        assert _maxabs(out["H"][n], ref["H"]) < 2e-4 * np.abs(ref["H"]).max()
+
+
+CASES = [dict(), dict(solver=1, lambda0=1e-3, n_iters=6), dict(param=1), dict(w_dc=0.15), dict(refine=1), dict(refine=1, w_dc=0.15, solver=1),
+         dict(automask=0), dict(n_iters=1), dict(n_iters=8)]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[",".join(f"{k}={v}" for k, v in c.items()) or "default" for c in CASES])
+def test_refine_vs_oracle(kw, oracle64):
+    """N iterations of GN / LM: refined poses within 1e-4 relative of the float64 CPU twin (BASELINE.json bar)"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, N = 96, 320, 4
+    b = _pairs(N, H, W, seed0=10, both=True)
+    e = _eng(H, W, N)
+    o = default_opts(**kw)
+    ls0 = np.array([0.02, -0.02, 0.0, 0.05], dtype=np.float32)
+    refine = kw.get("refine", 0)
+    pose, ls, st = e.refine(*_dev(b), _t(b["pose_init"]), o, log_scale=_t(ls0) if refine else None, stats=True)
+    pose, st = pose.cpu().numpy().astype(np.float64), st.cpu().numpy()
+    okw = dict(kw); okw["nparam"] = 6 + okw.pop("refine", 0)
+    for n in range(N):
+        rp, rls, rst = oracle64.refine(b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0], b["pose_init"][n], b["K"][n],
+                                       oopts(**okw), log_scale=float(ls0[n]) if refine else 0.0)
+        et = np.linalg.norm(pose[n, :3] - rp[:3]) / np.linalg.norm(rp[:3])
+        er = np.linalg.norm(pose[n, 3:] - rp[3:]) / np.linalg.norm(rp[3:])
+        assert et < 1e-4 and er < 1e-4, (n, et, er, pose[n], rp)
+        if refine:
+            assert abs(float(ls[n]) - rls) < 1e-4 * max(1.0, abs(rls)) and abs(float(ls[n]) - rls) < 2e-5
+        nrow = rst.shape[0] if o.solver == 1 else rst.shape[0] - 1
+        assert np.max(np.abs(st[n, :nrow, 0] - rst[:nrow, 0]) / rst[:nrow, 0]) < 2e-5   # cost trajectory
+        assert np.all(pose[n] != b["pose_init"][n].astype(np.float64))                 # something moved
+
+
+def test_full_size_properties():
+    """BASELINE size (640x192): properties that need no oracle run"""
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, N = 192, 640, 6
+    b = _pairs(N, H, W, seed0=0, both=True)
+    e = _eng(H, W, N)
+    d = _dev(b)
+    p0 = _t(b["pose_init"])
+    # 0 iterations is the identity on the pose (round trip pose -> SE(3) -> pose)
+    pz, _, _ = e.refine(*d, p0, default_opts(n_iters=0))
+    assert _maxabs(pz.cpu().numpy(), b["pose_init"]) < 2e-7
+    # monotone cost under LM, and convergence towards the ground truth under GN
+    pl, _, st = e.refine(*d, p0, default_opts(solver=1, n_iters=8, lambda0=1e-3), stats=True)
+    st = st.cpu().numpy()
+    assert np.all(st[:, -1, 0] <= st[:, 0, 0])
+    pg, _, sg = e.refine(*d, p0, default_opts(n_iters=8), stats=True)
+    sg = sg.cpu().numpy()
+    assert np.all(sg[:, 7, 0] < 0.8 * sg[:, 0, 0])
+    # determinism + batch independence: a pair refined alone gives bit-identical results to the same pair in a batch
+    pg2, _, _ = e.refine(*d, p0, default_opts(n_iters=8))
+    assert torch.equal(pg, pg2)
+    one = tuple(x[2:3].contiguous() for x in d)
+    ps, _, _ = e.refine(*one, p0[2:3].contiguous(), default_opts(n_iters=8))
+    assert torch.equal(ps[0], pg[2])
+    # permutation of the batch permutes the result
+    perm = torch.tensor([3, 0, 5, 1, 4, 2], device=p0.device)
+    pp, _, _ = e.refine(*(x[perm].contiguous() for x in d), p0[perm].contiguous(), default_opts(n_iters=8))
+    assert torch.equal(pp, pg[perm])
+
+
+def test_edge_cases():
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W = 24, 40
+    b = _pairs(2, H, W, seed0=1)
+    e = _eng(H, W, 2)
+    d = _dev(b)
+    # pose that throws every pixel out of bounds: nothing is valid, the pose must come back unchanged and finite
+    far = _t(np.array([[0, 0, 0, 0, 1.5, 0], [0, 0, 0, 1.5, 0, 0]], dtype=np.float32))
+    p, _, st = e.refine(*d, far, default_opts(n_iters=3), stats=True)
+    assert torch.isfinite(p).all() and _maxabs(p.cpu().numpy(), far.cpu().numpy()) < 1e-6
+    assert float(st[:, 0, 2].abs().max()) == 0.0
+    # non-pinhole intrinsics are refused with an error, not silently mis-handled
+    Kbad = d[4].clone(); Kbad[:, 0, 1] = 0.5
+    with pytest.raises(RuntimeError, match="pinhole"):
+        e.refine(d[0], d[1], d[2], d[3], Kbad, _t(b["pose_init"]))
+    # more pairs than the handle was created for
+    b3 = _pairs(3, H, W)
+    with pytest.raises(RuntimeError, match="out of range"):
+        e.refine(*_dev(b3), _t(b3["pose_init"]))
+    # reference-style size check (stn.py:24-30)
+    with pytest.raises(AssertionError, match="wrong size"):
+        e.refine(d[0][:, :, :-1], d[1], d[2], d[3], d[4], _t(b["pose_init"]))
+    # sigmoid-disparity inputs with the fused disp_to_depth equal explicit depths
+    from tightly_coupled_sfm_amd import synth
+    sd_t, sd_s = _t(synth.depth_to_sigmoid_disp(b["depth_t"].astype(np.float64))), _t(synth.depth_to_sigmoid_disp(b["depth_s"].astype(np.float64)))
+    pa, _, _ = e.refine(*d, _t(b["pose_init"]), default_opts())
+    pb, _, _ = e.refine(d[0], d[1], sd_t, sd_s, d[4], _t(b["pose_init"]), default_opts(depth_is_disp=1, min_depth=0.06, max_depth=2.67))
+    assert _maxabs(pa.cpu().numpy(), pb.cpu().numpy()) < 5e-5

@@ -1,0 +1,76 @@
+"""ctypes binding of libtcsfm_hip.so (include/tcsfm.h).  There is NO fallback: if the HIP library is
+missing or fails to load, importing the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtcsfm_hip.so")
+
+
+class Opts(C.Structure):
+    """mirror of struct tcsfm_opts"""
+    _fields_ = [("n_iters", C.c_int32), ("solver", C.c_int32), ("param", C.c_int32), ("refine", C.c_int32),
+                ("automask", C.c_int32), ("depth_is_disp", C.c_int32), ("host_ptrs", C.c_int32), ("reserved0", C.c_int32),
+                ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_dc", C.c_float), ("irls_eps", C.c_float),
+                ("lambda0", C.c_float), ("lambda_up", C.c_float), ("lambda_down", C.c_float), ("lambda_min", C.c_float),
+                ("min_depth", C.c_float), ("max_depth", C.c_float)]
+
+
+SOLVER_GN, SOLVER_LM = 0, 1
+PARAM_SE3, PARAM_EULER = 0, 1
+REFINE_POSE, REFINE_POSE_SCALE = 0, 1
+NSTAT = 4
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "tcsfm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tcsfm_destroy": (None, [_P]),
+    "tcsfm_last_error": (C.c_char_p, [_P]),
+    "tcsfm_set_stream": (C.c_int, [_P, _P]),
+    "tcsfm_synchronize": (C.c_int, [_P]),
+    "tcsfm_default_opts": (None, [C.POINTER(Opts)]),
+    "tcsfm_algorithmic_bytes_per_pixel": (C.c_int, [C.POINTER(Opts)]),
+    "tcsfm_disp_to_depth": (C.c_int, [_P, C.POINTER(Opts), C.c_int64, _P, _P, _P]),
+    "tcsfm_warp": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
+    "tcsfm_photometric": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 12),
+    "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
+    "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
+    "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),
+    "tcsfm_pose_to_matrix": (None, [_P, _P]),
+    "tcsfm_matrix_to_pose": (None, [_P, _P]),
+    "tcsfm_se3_exp": (None, [_P, _P]),
+    "tcsfm_se3_log": (None, [_P, _P]),
+    "tcsfm_se3_mul": (None, [_P, _P, _P]),
+    "tcsfm_se3_inv": (None, [_P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises RuntimeError when it is absent: build it with
+    ``python -m tightly_coupled_sfm_amd.build`` or ``__graft_entry__.build()``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    load().tcsfm_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(f"tcsfm_opts has no field {k!r}")
+        setattr(o, k, v)
+    return o

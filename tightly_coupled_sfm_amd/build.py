@@ -1,0 +1,31 @@
+"""Build libtcsfm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "tcsfm_api.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.h"), os.path.join(HERE, "csrc", "se3_math.h"),
+        os.path.join(os.path.dirname(HERE), "include", "tcsfm.h")]
+OUT = os.path.join(HERE, "libtcsfm_hip.so")
+
+
+def needs_build() -> bool:
+    return not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

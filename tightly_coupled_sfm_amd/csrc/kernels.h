@@ -1,0 +1,727 @@
+// kernels.h -- gfx950 device code of the photometric refinement engine.
+//
+// Kernels (one HIP stream, no host sync between them):
+//   k_pack        once per refine call: planar fp32 inputs -> two float4 images per pair
+//                   tgtpack = (tgt r,g,b, auto_err)   auto_err = iteration-invariant auto-mask error (train_mono.py:84)
+//                   srcpack = (src r,g,b, depth_s)    one 16-B gather per bilinear tap instead of four 4-B gathers
+//   k_linearize   THE hot kernel, once per Gauss-Newton iteration: fused
+//                   backproject (stn.py:33-48) -> rigid transform + project (stn.py:198-231) -> bilinear warp of
+//                   RGB+depth with d/d(ix,iy) (stn.py:266,271) -> L1 + 3x3 SSIM (losses.py:27-41, train_mono.py:87)
+//                   -> masks / depth-consistency weight (train_mono.py:89-92) -> exact gradient rows, structure-tensor
+//                   curvature -> per-workgroup J'J / J'r partial sums.  HBM-bound by design: 36 B/pixel read, nothing
+//                   written but one partial-sum record per workgroup.
+//   k_solve       once per iteration, one workgroup per pair: deterministic fp64 reduction of the partial sums,
+//                   LM/GN logic, 6x6 / 7x7 Cholesky, SE(3) retraction, emits the fp32 constants of the next iteration.
+//   k_warp        inverse_warp2 drop-in (stn.py:234-273), planar in / planar out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "se3_math.h"
+
+namespace tc {
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-pair constants of one linearisation (fp32, written by k_init / k_solve, read through the scalar cache)
+struct PairConst {
+    float A[9], kt[3];         // A = K (R - I) K^-1 and K t, both formed in fp64: K[R|t] K^-1 pix = pix + A pix, so the
+                               // projection OFFSET (flow) is computed without cancellation (see warp_geo)
+    float R[9], t[3];          // [R|t] = pose_vec2mat(-pose) (left-multiplied by the GN updates)
+    float fx, fy, cx, cy;      // pinhole intrinsics
+    float ki0, ki2, ki4, ki5;  // K^-1 = [ki0 0 ki2; 0 ki4 ki5; 0 0 1]
+    float es;                  // exp(log depth-scale)
+    int img;                   // which packed image pair this problem reads (loss-surface sweeps share one)
+    int pad[2];
+};
+
+// per-pair optimiser state (fp64)
+struct PairState {
+    double Tcur[12], Ttry[12];
+    double scur, stry;
+    double lambda, cost_cur;
+    double Hcur[TC_MAXP * TC_MAXP], gcur[TC_MAXP];
+    double K[9];
+    int have_cur, pad;
+};
+
+struct LinParams {
+    const float4 *tgtpack;  // [Nimg][H][W]  rgb + auto_err
+    const float4 *srcpack;  // [Nimg][H][W]  rgb + depth_s
+    const float *depth_t;   // [Nimg][H][W]
+    const PairConst *pc;    // [N]
+    float *partials;        // [N][nblk][nacc]
+    // maps mode outputs (may be null)
+    float *o_diff, *o_valid, *o_weight, *o_auto_err, *o_auto_mask, *o_rec;
+    int H, W, tiles_x, tiles_y, nacc;
+    float wl, ws;           // w_l1/3, w_ssim/3
+    float eps;              // irls_eps
+    int automask;
+};
+
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+
+__device__ __forceinline__ int refl_idx(int i, int n) {  // ReflectionPad2d(1), losses.py:22 (clamped for safety)
+    i = i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+    return min(max(i, 0), n - 1);
+}
+__device__ __forceinline__ float clamp01(float a) { return fminf(fmaxf(a, 0.f), 1.f); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// warp geometry of one target pixel
+struct Geo {
+    float rx, ry;        // sample position RELATIVE to the pixel's own integer coordinates: ix = u + rx, iy = v + ry
+    float Z, iz;         // computed depth (clamped at 1e-3, stn.py:215) and 1/Z
+    float uz, vz;        // projected pixel coordinates p0/Z, p1/Z
+    float X0, X1, X2;    // point in the source camera frame
+    bool oobx, ooby, zcl;
+};
+
+// pixel2cam (stn.py:33-48) -> [R|t] -> cam2pixel2 (stn.py:198-231) -> grid_sample un-normalisation (stn.py:266).
+// Same mathematics as the reference, evaluated in a cancellation-free order for fp32:
+//   p = K[R|t](D K^-1 pix) = D (pix + A pix) + K t     =>  p0 - u p2 = D((A pix)_0 - u (A pix)_2) + kt_0 - u kt_2
+// so the flow u_proj - u = (p0 - u Z)/Z is formed from small quantities only, and the bilinear weights come from
+// the fractional part of a small number instead of from ix ~ 10^2..10^3 (ulp 3e-5 px).  Agreement with the float64
+// oracle improves ~300x; versus the reference's own fp32 evaluation only exact ties can differ.
+__device__ __forceinline__ void warp_geo(const PairConst &c, int W, int H, int ui, int vi, float depth, Geo &g) {
+    const float u = (float)ui, v = (float)vi;
+    float D = c.es * depth;
+    float a0 = c.A[0] * u + c.A[1] * v + c.A[2];
+    float a1 = c.A[3] * u + c.A[4] * v + c.A[5];
+    float a2 = c.A[6] * u + c.A[7] * v + c.A[8];
+    float q0 = D * a0 + c.kt[0], q1 = D * a1 + c.kt[1], q2 = D * a2 + c.kt[2];
+    float p2 = D + q2;
+    g.zcl = p2 < 1e-3f;
+    g.Z = g.zcl ? 1e-3f : p2;
+    g.iz = 1.0f / g.Z;
+    // numerators of the flow: p0 - u Z, p1 - v Z
+    float fu = g.zcl ? (u * D + q0) - u * g.Z : q0 - u * q2;
+    float fv = g.zcl ? (v * D + q1) - v * g.Z : q1 - v * q2;
+    float flx = fu / g.Z, fly = fv / g.Z;
+    g.uz = u + flx;
+    g.vz = v + fly;
+    // |x_norm| > 1  <=>  u_proj outside [0, W-1]   (stn.py:223-227; detached sentinel -> zero sample, zero gradient)
+    g.oobx = (flx > (float)(W - 1 - ui)) || (flx < -u);
+    g.ooby = (fly > (float)(H - 1 - vi)) || (fly < -v);
+    // ix = u_proj W/(W-1) - 0.5 = u + [u/(W-1) - 0.5 + flow W/(W-1)]
+    const float iw = 1.f / (float)(W - 1), ih = 1.f / (float)(H - 1);
+    g.rx = (u * iw - 0.5f) + flx * ((float)W * iw);
+    g.ry = (v * ih - 0.5f) + fly * ((float)H * ih);
+    // point in the source camera frame (Jacobians only)
+    float r0 = c.ki0 * u + c.ki2, r1 = c.ki4 * v + c.ki5;
+    float x0 = r0 * D, x1 = r1 * D, x2 = D;
+    g.X0 = c.R[0] * x0 + c.R[1] * x1 + c.R[2] * x2 + c.t[0];
+    g.X1 = c.R[3] * x0 + c.R[4] * x1 + c.R[5] * x2 + c.t[1];
+    g.X2 = c.R[6] * x0 + c.R[7] * x1 + c.R[8] * x2 + c.t[2];
+}
+
+// bilinear sample of a float4 image at (ui + rx, vi + ry) with zero padding; also d/dix and d/diy
+// (grid_sampler_2d forward/backward semantics).  oob => the reference's sentinel: everything is zero.
+__device__ __forceinline__ void tap4(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob,
+                                     float4 &val, float4 &gx, float4 &gy) {
+    float fx = floorf(rx), fy = floorf(ry);
+    float wx = rx - fx, wy = ry - fy;
+    int xi = ui + (int)fx, yi = vi + (int)fy;
+    bool x0in = (xi >= 0) && (xi < W), x1in = (xi >= -1) && (xi < W - 1);
+    bool y0in = (yi >= 0) && (yi < H), y1in = (yi >= -1) && (yi < H - 1);
+    int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
+    int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
+    float4 v00 = img[y0 * W + x0], v01 = img[y0 * W + x1], v10 = img[y1 * W + x0], v11 = img[y1 * W + x1];
+    const bool m00 = x0in && y0in && !oob, m01 = x1in && y0in && !oob, m10 = x0in && y1in && !oob, m11 = x1in && y1in && !oob;
+    // component-wise selects (a float4 ?: makes hipcc spill both operands to scratch and select the address)
+#define TC_SEL(v, m) v.x = m ? v.x : 0.f; v.y = m ? v.y : 0.f; v.z = m ? v.z : 0.f; v.w = m ? v.w : 0.f;
+    TC_SEL(v00, m00) TC_SEL(v01, m01) TC_SEL(v10, m10) TC_SEL(v11, m11)
+#undef TC_SEL
+    float ax = 1.f - wx, ay = 1.f - wy;
+#define TC_LERP(f)                                                                     \
+    val.f = ax * ay * v00.f + wx * ay * v01.f + ax * wy * v10.f + wx * wy * v11.f;     \
+    gx.f = ay * (v01.f - v00.f) + wy * (v11.f - v10.f);                                \
+    gy.f = ax * (v10.f - v00.f) + wx * (v11.f - v01.f);
+    TC_LERP(x) TC_LERP(y) TC_LERP(z) TC_LERP(w)
+#undef TC_LERP
+}
+
+// Jacobian of the sample position and of Z w.r.t. the left SE(3) perturbation [rho, phi] (+ log depth-scale)
+//   dXp/drho_j = e_j ; dXp/dphi_j = e_j x Xp ; dXp/dsigma = Xp - t   ; pinhole K
+template <int NP>
+__device__ __forceinline__ void geo_jac(const PairConst &c, const Geo &g, int W, int H, float *a, float *b, float *zc) {
+    const float cw = (float)W / (float)(W - 1), ch = (float)H / (float)(H - 1);
+    float dp0[TC_MAXP], dp1[TC_MAXP], dp2[TC_MAXP];
+    dp0[0] = c.fx;  dp1[0] = 0.f;   dp2[0] = 0.f;
+    dp0[1] = 0.f;   dp1[1] = c.fy;  dp2[1] = 0.f;
+    dp0[2] = c.cx;  dp1[2] = c.cy;  dp2[2] = 1.f;
+    dp0[3] = c.cx * g.X1;               dp1[3] = -c.fy * g.X2 + c.cy * g.X1; dp2[3] = g.X1;
+    dp0[4] = c.fx * g.X2 - c.cx * g.X0; dp1[4] = -c.cy * g.X0;               dp2[4] = -g.X0;
+    dp0[5] = -c.fx * g.X1;              dp1[5] = c.fy * g.X0;                dp2[5] = 0.f;
+    if (NP == 7) {
+        float q0 = g.X0 - c.t[0], q1 = g.X1 - c.t[1], q2 = g.X2 - c.t[2];
+        dp0[6] = c.fx * q0 + c.cx * q2; dp1[6] = c.fy * q1 + c.cy * q2; dp2[6] = q2;
+    }
+    float sa = g.oobx ? 0.f : cw * g.iz, sb = g.ooby ? 0.f : ch * g.iz, zf = g.zcl ? 0.f : 1.f;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        float dz = zf * dp2[j];
+        zc[j] = dz;
+        a[j] = sa * (dp0[j] - g.uz * dz);
+        b[j] = sb * (dp1[j] - g.vz * dz);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_pack
+struct PackParams {
+    const float *tgt, *src, *depth_t, *depth_s;  // planar inputs [N,3,H,W] / [N,1,H,W]
+    float4 *tgtpack, *srcpack;
+    float *depth_out;                            // [N,H,W] depth_t (converted if depth_is_disp)
+    int H, W, N;
+    float wl, ws;                                // w_l1/3, w_ssim/3
+    int depth_is_disp;
+    float min_disp, max_disp;
+};
+
+// (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory
+__device__ inline float photo_err_planar(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int u, int v,
+                                         float wl, float ws) {
+    float acc = 0.f;
+    const int hw = H * W;
+    for (int c = 0; c < 3; c++) {
+        const float *xc = x + c * hw, *yc = y + c * hw;
+        float x0 = xc[v * W + u], y0 = yc[v * W + u];
+        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int dv = -1; dv <= 1; dv++)
+            for (int du = -1; du <= 1; du++) {
+                int j = refl_idx(v + dv, H) * W + refl_idx(u + du, W);
+                float a = xc[j] - x0, b = yc[j] - y0;  // shifted by the centre value: fp32-safe variances
+                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        const float n9 = 1.f / 9.f;
+        float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
+        float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
+        float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
+        float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+        acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n / d) * 0.5f);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_pack(PackParams P) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.y;
+    const int hw = P.H * P.W;
+    if (idx >= hw) return;
+    int v = idx / P.W, u = idx - v * P.W;
+    const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
+    float ae = photo_err_planar(t, s, P.H, P.W, u, v, P.wl, P.ws);
+    float dt = P.depth_t[(size_t)n * hw + idx], ds = P.depth_s[(size_t)n * hw + idx];
+    if (P.depth_is_disp) {  // disp_to_depth, learning_helpers.py:77-86
+        dt = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * dt);
+        ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
+    }
+    P.tgtpack[(size_t)n * hw + idx] = make_float4(t[idx], t[hw + idx], t[2 * hw + idx], ae);
+    P.srcpack[(size_t)n * hw + idx] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], ds);
+    P.depth_out[(size_t)n * hw + idx] = dt;
+}
+
+__global__ void k_disp_to_depth(const float *disp, float *scaled, float *depth, long long n, float min_disp, float max_disp) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = min_disp + (max_disp - min_disp) * disp[i];
+    if (scaled) scaled[i] = s;
+    if (depth) depth[i] = 1.f / s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_warp: inverse_warp2 drop-in on planar inputs
+struct WarpParams {
+    const float *src, *depth_t, *depth_s;
+    const PairConst *pc;
+    float *rec, *valid, *pd, *cd;
+    int H, W;
+};
+
+__device__ __forceinline__ float tap1(const float *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob) {
+    float fx = floorf(rx), fy = floorf(ry);
+    float wx = rx - fx, wy = ry - fy;
+    int xi = ui + (int)fx, yi = vi + (int)fy;
+    bool x0in = (xi >= 0) && (xi < W), x1in = (xi >= -1) && (xi < W - 1);
+    bool y0in = (yi >= 0) && (yi < H), y1in = (yi >= -1) && (yi < H - 1);
+    int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
+    int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
+    float v00 = (x0in && y0in && !oob) ? img[y0 * W + x0] : 0.f, v01 = (x1in && y0in && !oob) ? img[y0 * W + x1] : 0.f;
+    float v10 = (x0in && y1in && !oob) ? img[y1 * W + x0] : 0.f, v11 = (x1in && y1in && !oob) ? img[y1 * W + x1] : 0.f;
+    return (1.f - wx) * (1.f - wy) * v00 + wx * (1.f - wy) * v01 + (1.f - wx) * wy * v10 + wx * wy * v11;
+}
+
+__global__ __launch_bounds__(256) void k_warp(WarpParams P) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.y;
+    const int hw = P.H * P.W;
+    if (idx >= hw) return;
+    int v = idx / P.W, u = idx - v * P.W;
+    const PairConst &c = P.pc[n];
+    Geo g;
+    warp_geo(c, P.W, P.H, u, v, P.depth_t[(size_t)n * hw + idx], g);
+    const bool oob = g.oobx || g.ooby;
+    if (P.rec)
+        for (int ch = 0; ch < 3; ch++)
+            P.rec[((size_t)n * 3 + ch) * hw + idx] = tap1(P.src + ((size_t)n * 3 + ch) * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+    if (P.valid) P.valid[(size_t)n * hw + idx] = oob ? 0.f : 1.f;
+    if (P.pd) P.pd[(size_t)n * hw + idx] = c.es * tap1(P.depth_s + (size_t)n * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+    if (P.cd) P.cd[(size_t)n * hw + idx] = g.Z;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_linearize
+//
+// Workgroup = one TW x TH tile of target pixels of one pair.  Phase 1 warps the tile plus a 1-pixel halo
+// (reflect-mapped at the image border, so the halo IS the ReflectionPad2d of losses.py:22) and stages per pixel
+//   y[3] (warped source), x[3] (target), gx[3], gy[3] (d rec/d ix,iy), a[NP], b[NP] (d ix, d iy / d theta)
+// in LDS as an array of 112-byte records (7 x float4: conflict-free ds_read_b128 for consecutive lanes).
+// Phase 2 evaluates SSIM / L1 / masks and the exact gradient rows for the tile's own pixels from the 3x3 LDS
+// neighbourhood and accumulates J'J and J'r in registers; one wave-reduce + LDS reduce per workgroup, one
+// partial-sum record per workgroup to HBM (deterministic: no atomics).
+
+constexpr int LDS_REC = 28;  // floats per staged pixel (12 + 2*NP <= 26, padded to 28 for bank spread)
+
+template <int NP>
+struct AccLayout {
+    static constexpr int NH = NP * (NP + 1) / 2;
+    static constexpr int OFF_HP = 0, OFF_GP = NH, OFF_HD = NH + NP, OFF_GD = 2 * NH + NP, OFF_S = 2 * NH + 2 * NP;
+    static constexpr int NACC = 2 * NH + 2 * NP + 3;  // + sum(M W diff), sum(M), sum(dd)
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+enum { MODE_COST = 0, MODE_LIN = 1, MODE_MAPS = 2 };
+
+template <int NP, bool DC, int MODE, int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_linearize(LinParams P) {
+    constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
+    constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
+    static_assert(NCEN % NT == 0, "tile must be a multiple of the workgroup");
+    using L = AccLayout<NP>;
+    __shared__ float4 lds[NCOMP * (LDS_REC / 4)];
+    __shared__ float red[(NT / 64) * L::NACC];
+
+    // XCD-aware tile order: consecutive workgroups land on different XCDs (round-robin dispatch), so give each
+    // of the 8 XCDs a contiguous band of tiles -> halo / source-texel reuse stays inside one XCD's L2.
+    const int nblk = P.tiles_x * P.tiles_y;
+    int bid = blockIdx.x;
+    {
+        int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = blockIdx.y;
+    const PairConst &c = P.pc[n];
+    const int H = P.H, W = P.W, hw = H * W;
+    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const int x00 = txi * TW, y00 = tyi * TH;
+    const float4 *tgtpack = P.tgtpack + (size_t)c.img * hw;
+    const float4 *srcpack = P.srcpack + (size_t)c.img * hw;
+    const float *depth_t = P.depth_t + (size_t)c.img * hw;
+    const int tid = threadIdx.x;
+
+    // centre-only values carried in registers from phase 1 to phase 2
+    float c_pd[PPT], c_cd[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
+    bool c_valid[PPT], c_in[PPT];
+
+    // ---------------- phase 1: warp + stage (centres first, then the halo ring) ----------------
+    constexpr int NHALO = NCOMP - NCEN;
+    constexpr int ROUNDS = PPT + (NHALO + NT - 1) / NT;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        int lx, ly;  // compute-region coordinates
+        bool active = true;
+        if (r < PPT) {
+            int ci = tid + r * NT;
+            ly = ci / TW + 1; lx = ci - (ci / TW) * TW + 1;
+        } else {
+            int hi = tid + (r - PPT) * NT;
+            active = hi < NHALO;
+            // halo ring enumeration: top row, bottom row, then left/right columns
+            if (hi < CW) { ly = 0; lx = hi; }
+            else if (hi < 2 * CW) { ly = CH - 1; lx = hi - CW; }
+            else { int k = hi - 2 * CW; ly = 1 + (k >> 1); lx = (k & 1) ? CW - 1 : 0; }
+        }
+        if (!active) continue;
+        int px = refl_idx(x00 + lx - 1, W), py = refl_idx(y00 + ly - 1, H);
+        int gi = py * W + px;
+        float4 tp = tgtpack[gi];
+        Geo g;
+        warp_geo(c, W, H, px, py, depth_t[gi], g);
+        float4 val, gx, gy;
+        tap4(srcpack, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, val, gx, gy);
+        float a[NP], b[NP], zc[NP];
+        geo_jac<NP>(c, g, W, H, a, b, zc);
+        float4 *rec = lds + (ly * CW + lx) * (LDS_REC / 4);
+        rec[0] = make_float4(val.x, val.y, val.z, tp.x);
+        rec[1] = make_float4(tp.y, tp.z, gx.x, gx.y);
+        rec[2] = make_float4(gx.z, gy.x, gy.y, gy.z);
+        rec[3] = make_float4(a[0], a[1], a[2], a[3]);
+        rec[4] = make_float4(a[4], a[5], b[0], b[1]);
+        rec[5] = make_float4(b[2], b[3], b[4], b[5]);
+        if (NP == 7) rec[6] = make_float4(a[NP - 1], b[NP - 1], 0.f, 0.f);
+        if (r < PPT) {
+            const int k = r < PPT ? r : 0;
+            c_in[k] = (x00 + lx - 1 < W) && (y00 + ly - 1 < H);
+            c_pd[k] = c.es * val.w; c_dgx[k] = c.es * gx.w; c_dgy[k] = c.es * gy.w; c_cd[k] = g.Z;
+            c_ae[k] = tp.w; c_valid[k] = !(g.oobx || g.ooby);
+#pragma unroll
+            for (int j = 0; j < NP; j++) c_zc[k][j] = zc[j];
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: residuals, gradient rows, curvature, accumulation ----------------
+    float aHP[L::NH], aGP[NP], aHD[DC ? L::NH : 1], aGD[DC ? NP : 1];
+    float sMWd = 0.f, sM = 0.f, sdd = 0.f;
+#pragma unroll
+    for (int i = 0; i < L::NH; i++) { aHP[i] = 0.f; if (DC) aHD[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NP; i++) { aGP[i] = 0.f; if (DC) aGD[i] = 0.f; }
+
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        int ci = tid + k * NT;
+        int ly = ci / TW + 1, lx = ci - (ci / TW) * TW + 1;
+        const float4 *ctr = lds + (ly * CW + lx) * (LDS_REC / 4);
+        float4 q0 = ctr[0], q1 = ctr[1], q2 = ctr[2];
+        const float yc[3] = {q0.x, q0.y, q0.z}, xc[3] = {q0.w, q1.x, q1.y};
+        const float gxc[3] = {q1.z, q1.w, q2.x}, gyc[3] = {q2.y, q2.z, q2.w};
+
+        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances)
+        float Sx[3] = {0, 0, 0}, Sy[3] = {0, 0, 0}, Sxx[3] = {0, 0, 0}, Syy[3] = {0, 0, 0}, Sxy[3] = {0, 0, 0};
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const float4 *nb = lds + ((ly + dy) * CW + lx + dx) * (LDS_REC / 4);
+                float4 n0 = nb[0], n1 = nb[1];
+                const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float a = xq[ch] - xc[ch], b = yq[ch] - yc[ch];
+                    Sx[ch] += a; Sy[ch] += b; Sxx[ch] += a * a; Syy[ch] += b * b; Sxy[ch] += a * b;
+                }
+            }
+        const float n9 = 1.f / 9.f;
+        float e1 = 0.f, e2 = 0.f;
+        float cA[3], cB[3], cC[3], mdx[3], mdy[3], id1[3], id2[3];
+        float l1x = 0.f, l1y = 0.f;          // sum_c wl sgn_c g_c   (centre part of d e1)
+        float lxx = 0.f, lxy = 0.f, lyy = 0.f;  // curvature Lambda (without the W factor)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            mdx[ch] = Sx[ch] * n9; mdy[ch] = Sy[ch] * n9;
+            float mux = xc[ch] + mdx[ch], muy = yc[ch] + mdy[ch];
+            float sigx = Sxx[ch] * n9 - mdx[ch] * mdx[ch], sigy = Syy[ch] * n9 - mdy[ch] * mdy[ch];
+            float sigxy = Sxy[ch] * n9 - mdx[ch] * mdy[ch];
+            float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+            float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+            float idn = 1.f / (d1 * d2), ratio = n1 * n2 * idn;
+            float raw = (1.f - ratio) * 0.5f;
+            bool cl = (raw < 0.f) || (raw > 1.f);
+            e2 += P.ws * clamp01(raw);
+            // d s/d y_q = cA + cB (y_q - mu_y) + cC (x_q - mu_x)
+            float pre = cl ? 0.f : -0.5f * idn * n9 * P.ws;
+            cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2);
+            cB[ch] = pre * (-ratio * 2.f * d1);
+            cC[ch] = pre * (2.f * n1);
+            id1[ch] = cl ? 0.f : P.ws / d1; id2[ch] = cl ? 0.f : P.ws / d2;
+            // L1 term, train_mono.py:87
+            float rr = yc[ch] - xc[ch], ar = fabsf(rr);
+            e1 += P.wl * fminf(ar, 1.f);
+            float sgn = (ar <= 1.f) ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : 0.f;
+            l1x += P.wl * sgn * gxc[ch]; l1y += P.wl * sgn * gyc[ch];
+            float w1 = (ar <= 1.f) ? P.wl / fmaxf(ar, P.eps) : 0.f;
+            lxx += w1 * gxc[ch] * gxc[ch]; lxy += w1 * gxc[ch] * gyc[ch]; lyy += w1 * gyc[ch] * gyc[ch];
+        }
+        float diff = e1 + e2;
+
+        float de[NP];  // d(e1 + e2)/d theta
+#pragma unroll
+        for (int j = 0; j < NP; j++) de[j] = 0.f;
+        if (MODE == MODE_LIN) {
+            // pass B: exact SSIM gradient rows (neighbour geometry included) + gradient moments for the curvature
+            float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0}, Gxx[3] = {0, 0, 0}, Gxy[3] = {0, 0, 0}, Gyy[3] = {0, 0, 0};
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    const float4 *nb = lds + ((ly + dy) * CW + lx + dx) * (LDS_REC / 4);
+                    float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3], n4 = nb[4], n5 = nb[5];
+                    const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
+                    const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
+                    float aq[NP], bq[NP];
+                    aq[0] = n3.x; aq[1] = n3.y; aq[2] = n3.z; aq[3] = n3.w; aq[4] = n4.x; aq[5] = n4.y;
+                    bq[0] = n4.z; bq[1] = n4.w; bq[2] = n5.x; bq[3] = n5.y; bq[4] = n5.z; bq[5] = n5.w;
+                    if (NP == 7) { float4 n6 = nb[6]; aq[NP - 1] = n6.x; bq[NP - 1] = n6.y; }
+                    float sx = 0.f, sy = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        float cf = cA[ch] + cB[ch] * ((yq[ch] - yc[ch]) - mdy[ch]) + cC[ch] * ((xq[ch] - xc[ch]) - mdx[ch]);
+                        sx += cf * gxq[ch]; sy += cf * gyq[ch];
+                        Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
+                        Gxx[ch] += gxq[ch] * gxq[ch]; Gxy[ch] += gxq[ch] * gyq[ch]; Gyy[ch] += gyq[ch] * gyq[ch];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NP; j++) de[j] += sx * aq[j] + sy * bq[j];
+                }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {  // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1
+                float mx = Gx[ch] * n9, my = Gy[ch] * n9;
+                lxx += id2[ch] * (Gxx[ch] * n9 - mx * mx) + id1[ch] * mx * mx;
+                lxy += id2[ch] * (Gxy[ch] * n9 - mx * my) + id1[ch] * mx * my;
+                lyy += id2[ch] * (Gyy[ch] * n9 - my * my) + id1[ch] * my * my;
+            }
+        }
+
+        // depth consistency, train_mono.py:91-92
+        float cd = c_cd[k], pd = c_pd[k];
+        float sum = cd + pd, dif = cd - pd;
+        float raw = fabsf(dif) / sum;
+        float dd = clamp01(raw), Wt = 1.f - dd;
+        bool inimg = c_in[k];
+        bool m = inimg && c_valid[k] && (!P.automask || diff < c_ae[k]);
+
+        if (MODE == MODE_MAPS) {
+            if (inimg) {
+                size_t o = (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
+                if (P.o_diff) P.o_diff[o] = diff;
+                if (P.o_valid) P.o_valid[o] = c_valid[k] ? 1.f : 0.f;
+                if (P.o_weight) P.o_weight[o] = Wt;
+                if (P.o_auto_err) P.o_auto_err[o] = c_ae[k];
+                if (P.o_auto_mask) P.o_auto_mask[o] = diff < c_ae[k] ? 1.f : 0.f;
+                if (P.o_rec) {
+                    size_t o3 = (size_t)n * 3 * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
+                    P.o_rec[o3] = yc[0]; P.o_rec[o3 + hw] = yc[1]; P.o_rec[o3 + 2 * hw] = yc[2];
+                }
+            }
+            continue;
+        }
+
+        if (inimg) sdd += dd;
+        if (m) { sMWd += Wt * diff; sM += 1.f; }
+        if (MODE == MODE_LIN) {
+            // own geometric Jacobian (centre record)
+            float4 q3 = ctr[3], q4 = ctr[4], q5 = ctr[5];
+            float a[NP], b[NP];
+            a[0] = q3.x; a[1] = q3.y; a[2] = q3.z; a[3] = q3.w; a[4] = q4.x; a[5] = q4.y;
+            b[0] = q4.z; b[1] = q4.w; b[2] = q5.x; b[3] = q5.y; b[4] = q5.z; b[5] = q5.w;
+            if (NP == 7) { float4 q6 = ctr[6]; a[NP - 1] = q6.x; b[NP - 1] = q6.y; }
+            float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
+            float kdd = sg * 2.f / (sum * sum);
+            float mf = m ? 1.f : 0.f;
+            float ddJ[NP];
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                float dpd = c_dgx[k] * a[j] + c_dgy[k] * b[j] + ((NP == 7 && j == 6) ? pd : 0.f);
+                ddJ[j] = kdd * (pd * c_zc[k][j] - cd * dpd);
+                float row = Wt * (de[j] + l1x * a[j] + l1y * b[j]) - diff * ddJ[j];  // d(W (e1+e2))/d theta
+                aGP[j] += mf * row;
+            }
+            float wxx = mf * Wt * lxx, wxy = mf * Wt * lxy, wyy = mf * Wt * lyy;
+            int h = 0;
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                float la = wxx * a[j] + wxy * b[j], lb = wxy * a[j] + wyy * b[j];
+#pragma unroll
+                for (int i = 0; i <= j; i++) { aHP[h] += la * a[i] + lb * b[i]; h++; }
+            }
+            if (DC) {
+                float k3 = inimg ? 1.f / fmaxf(dd, P.eps) : 0.f, inf = inimg ? 1.f : 0.f;
+                h = 0;
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    aGD[j] += inf * ddJ[j];
+                    float kj = k3 * ddJ[j];
+#pragma unroll
+                    for (int i = 0; i <= j; i++) { aHD[h] += kj * ddJ[i]; h++; }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_MAPS) return;
+
+    // ---------------- workgroup reduction -> one partial record ----------------
+    const int wave = tid >> 6, lane = tid & 63;
+    float *wr = red + wave * L::NACC;
+#define TC_RED(v, slot) { float s_ = wave_sum(v); if (lane == 0) wr[slot] = s_; }
+    if (MODE == MODE_LIN) {
+#pragma unroll
+        for (int i = 0; i < L::NH; i++) TC_RED(aHP[i], L::OFF_HP + i)
+#pragma unroll
+        for (int i = 0; i < NP; i++) TC_RED(aGP[i], L::OFF_GP + i)
+        if (DC) {
+#pragma unroll
+            for (int i = 0; i < L::NH; i++) TC_RED(aHD[i], L::OFF_HD + i)
+#pragma unroll
+            for (int i = 0; i < NP; i++) TC_RED(aGD[i], L::OFF_GD + i)
+        }
+    }
+    TC_RED(sMWd, L::OFF_S) TC_RED(sM, L::OFF_S + 1) TC_RED(sdd, L::OFF_S + 2)
+#undef TC_RED
+    __syncthreads();
+    float *out = P.partials + ((size_t)n * nblk + bid) * L::NACC;
+    for (int i = tid; i < L::NACC; i += NT) {
+        bool live = (i >= L::OFF_S) || (MODE == MODE_LIN && (DC || i < L::OFF_HD));
+        float s = 0.f;
+        if (live)
+            for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + i];
+        out[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_init / k_solve / k_finish (fp64 per-pair logic; mirrors oracle/tcsfm_oracle.c orc_refine)
+
+__device__ inline void write_const(const PairState &S, const double *T, double s, int img, PairConst &c) {
+    const double *K = S.K;
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double Ki[9] = {1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1};
+    double RmI[9], KR[9], A[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) RmI[3 * i + j] = T[4 * i + j] - (i == j ? 1.0 : 0.0);
+    mat3_mul(K, RmI, KR);
+    mat3_mul(KR, Ki, A);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            c.A[3 * i + j] = (float)A[3 * i + j];
+            c.R[3 * i + j] = (float)T[4 * i + j];
+        }
+        c.kt[i] = (float)(K[3 * i] * T[3] + K[3 * i + 1] * T[7] + K[3 * i + 2] * T[11]);
+        c.t[i] = (float)T[4 * i + 3];
+    }
+    c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
+    c.ki0 = (float)(1.0 / fx); c.ki2 = (float)(-cx / fx); c.ki4 = (float)(1.0 / fy); c.ki5 = (float)(-cy / fy);
+    c.es = (float)exp(s);
+    c.img = img;
+}
+
+struct InitParams {
+    const float *pose, *log_scale, *K;  // [N,6], [N] or null, [Nimg,3,3]
+    PairState *st;
+    PairConst *pc;
+    int N, shared_image;                // shared_image: all problems read image pair 0 (loss-surface sweep)
+    float lambda0;
+};
+
+__global__ void k_init(InitParams P) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= P.N) return;
+    PairState &S = P.st[n];
+    int img = P.shared_image ? 0 : n;
+    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[img * 9 + i];
+    double pose[6];
+    for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
+    pose_to_T(pose, S.Tcur);
+    for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
+    S.scur = S.stry = P.log_scale ? (double)P.log_scale[n] : 0.0;
+    S.lambda = (double)P.lambda0;
+    S.cost_cur = 0.0;
+    S.have_cur = 0;
+    write_const(S, S.Ttry, S.stry, img, P.pc[n]);
+}
+
+struct SolveParams {
+    const float *partials;  // [N][nblk][nacc]
+    PairState *st;
+    PairConst *pc;
+    float *stats;           // [N][n_iters+1][4] or null
+    double *lin_out;        // linearize debug: [N][np*np + np + 4] or null
+    int nblk, nacc, np, has_dc;
+    int it, n_iters, solver, param, mode;  // mode 0: iteration step, 1: final LM cost check, 2: export only
+    double b_dc;            // w_dc / (H W)
+    double lambda_up, lambda_down, lambda_min;
+    int shared_image;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
+    using L = AccLayout<NP>;
+    __shared__ double sacc[8 * L::NACC];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    constexpr int NG = 256 / L::NACC >= 8 ? 8 : 256 / L::NACC;  // block-groups summed in parallel
+    const int a = tid % L::NACC, grp = tid / L::NACC;
+    if (grp < NG) {
+        double s = 0.0;
+        const float *p = P.partials + (size_t)n * P.nblk * L::NACC + a;
+        for (int b = grp; b < P.nblk; b += NG) s += (double)p[(size_t)b * L::NACC];
+        sacc[grp * L::NACC + a] = s;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    double acc[L::NACC];
+    for (int i = 0; i < L::NACC; i++) {
+        double s = 0.0;
+        for (int g = 0; g < NG; g++) s += sacc[g * L::NACC + i];
+        acc[i] = s;
+    }
+    PairState &S = P.st[n];
+    const double nmask = acc[L::OFF_S + 1];
+    const double an = nmask > 0 ? 1.0 / nmask : 0.0;
+    const double cost_photo = an * acc[L::OFF_S], cost_dc = P.b_dc * acc[L::OFF_S + 2], cost = cost_photo + cost_dc;
+    double Hm[NP * NP], g[NP];
+    {
+        int h = 0;
+        for (int j = 0; j < NP; j++) {
+            g[j] = an * acc[L::OFF_GP + j] + (P.has_dc ? P.b_dc * acc[L::OFF_GD + j] : 0.0);
+            for (int i = 0; i <= j; i++) {
+                double v = an * acc[L::OFF_HP + h] + (P.has_dc ? P.b_dc * acc[L::OFF_HD + h] : 0.0);
+                Hm[j * NP + i] = v; Hm[i * NP + j] = v;
+                h++;
+            }
+        }
+    }
+    if (P.mode == 2) {  // export for tcsfm_linearize / tcsfm_loss_surface
+        double *o = P.lin_out + (size_t)n * (NP * NP + NP + 4);
+        for (int i = 0; i < NP * NP; i++) o[i] = Hm[i];
+        for (int i = 0; i < NP; i++) o[NP * NP + i] = g[i];
+        o[NP * NP + NP] = cost; o[NP * NP + NP + 1] = cost_photo; o[NP * NP + NP + 2] = cost_dc; o[NP * NP + NP + 3] = nmask;
+        return;
+    }
+    if (P.stats) {
+        float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * 4;
+        st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)S.lambda;
+    }
+    if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
+        if (cost < S.cost_cur) {
+            for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
+            S.scur = S.stry;
+        }
+        return;
+    }
+    if (P.solver == 0 || !S.have_cur || cost < S.cost_cur) {  // accept the trial point
+        if (P.solver == 1 && S.have_cur) S.lambda = fmax(S.lambda * P.lambda_down, P.lambda_min);
+        for (int i = 0; i < NP * NP; i++) S.Hcur[i] = Hm[i];
+        for (int i = 0; i < NP; i++) S.gcur[i] = g[i];
+        for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
+        S.scur = S.stry; S.cost_cur = cost; S.have_cur = 1;
+    } else {
+        S.lambda *= P.lambda_up;
+    }
+    apply_step(NP, P.param, S.Hcur, S.gcur, S.lambda, S.Tcur, S.scur, S.Ttry, &S.stry);
+    if (P.solver == 0 && P.it == P.n_iters - 1) {  // GN: the last step is always taken
+        for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
+        S.scur = S.stry;
+    }
+    write_const(S, S.Ttry, S.stry, P.shared_image ? 0 : n, P.pc[n]);
+}
+
+struct FinishParams {
+    const PairState *st;
+    float *pose_out, *log_scale_out;
+    int N;
+};
+
+__global__ void k_finish(FinishParams P) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= P.N) return;
+    double pose[6];
+    T_to_pose(P.st[n].Tcur, pose);
+    for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = (float)pose[i];
+    if (P.log_scale_out) P.log_scale_out[n] = (float)P.st[n].scur;
+}
+
+}  // namespace tc

@@ -1,0 +1,502 @@
+// tcsfm_api.hip -- C ABI (include/tcsfm.h) over the gfx950 kernels in kernels.h.
+// Host logic only: argument checking, scratch management, kernel sequencing on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tcsfm.h"
+#include "kernels.h"
+
+using namespace tc;
+
+namespace {
+
+// tile geometry of the hot kernel (one place to retune)
+constexpr int TILE_W = 32, TILE_H = 8, TILE_NT = 256;
+
+thread_local std::string g_create_error;
+
+struct HostStage {  // device staging for host-pointer calls
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct tcsfm_ctx {
+    int device = 0, H = 0, W = 0, max_pairs = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    float4 *tgtpack = nullptr, *srcpack = nullptr;
+    float *depth_work = nullptr;
+    float *partials = nullptr;
+    PairState *state = nullptr;
+    PairConst *pconst = nullptr;
+    double *lin_out = nullptr;   // device [max_pairs][7*7+7+4]
+    float *pose_dev = nullptr, *ls_dev = nullptr, *K_dev = nullptr, *stats_dev = nullptr;
+    int tiles_x = 0, tiles_y = 0, nblk = 0, stats_cap_iters = 0;
+    std::vector<HostStage> stage;
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return TCSFM_E_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+int fail(tcsfm_ctx *h, int code, const char *msg) {
+    h->err = msg;
+    return code;
+}
+
+constexpr int kMaxAcc = AccLayout<7>::NACC;
+constexpr int kLinOut = 7 * 7 + 7 + 4;
+
+int check_common(tcsfm_ctx *h, const tcsfm_opts *o, int N) {
+    if (!h) return TCSFM_E_ARG;
+    if (!o) return fail(h, TCSFM_E_ARG, "opts is NULL");
+    if (N < 1 || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "N out of range for this handle (1..max_pairs)");
+    if (o->refine != TCSFM_REFINE_POSE && o->refine != TCSFM_REFINE_POSE_SCALE) return fail(h, TCSFM_E_ARG, "opts.refine unsupported");
+    if (o->solver != TCSFM_SOLVER_GN && o->solver != TCSFM_SOLVER_LM) return fail(h, TCSFM_E_ARG, "opts.solver unsupported");
+    if (o->param != TCSFM_PARAM_SE3 && o->param != TCSFM_PARAM_EULER) return fail(h, TCSFM_E_ARG, "opts.param unsupported");
+    if (o->n_iters < 0 || o->n_iters > 1000) return fail(h, TCSFM_E_ARG, "opts.n_iters out of range");
+    if (o->depth_is_disp && !(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
+    return TCSFM_OK;
+}
+
+// Stage a host array on the device (slot-indexed scratch that grows on demand) or pass a device pointer through.
+template <typename T>
+int to_dev(tcsfm_ctx *h, const tcsfm_opts *o, int slot, const T *p, size_t count, const T **out) {
+    if (!o->host_ptrs || !p) { *out = p; return TCSFM_OK; }
+    if ((int)h->stage.size() <= slot) h->stage.resize(slot + 1);
+    HostStage &s = h->stage[slot];
+    size_t bytes = count * sizeof(T);
+    if (s.cap < bytes) {
+        if (s.p) HIPCHK(h, hipFree(s.p));
+        s.p = nullptr; s.cap = 0;
+        HIPCHK(h, hipMalloc(&s.p, bytes));
+        s.cap = bytes;
+    }
+    HIPCHK(h, hipMemcpyAsync(s.p, p, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = (const T *)s.p;
+    return TCSFM_OK;
+}
+
+// Output counterpart: returns a device buffer to write into; copy_back() moves it to the host pointer.
+template <typename T>
+int out_dev(tcsfm_ctx *h, const tcsfm_opts *o, int slot, T *p, size_t count, T **out) {
+    if (!o->host_ptrs || !p) { *out = p; return TCSFM_OK; }
+    if ((int)h->stage.size() <= slot) h->stage.resize(slot + 1);
+    HostStage &s = h->stage[slot];
+    size_t bytes = count * sizeof(T);
+    if (s.cap < bytes) {
+        if (s.p) HIPCHK(h, hipFree(s.p));
+        s.p = nullptr; s.cap = 0;
+        HIPCHK(h, hipMalloc(&s.p, bytes));
+        s.cap = bytes;
+    }
+    *out = (T *)s.p;
+    return TCSFM_OK;
+}
+
+template <typename T>
+int copy_back(tcsfm_ctx *h, const tcsfm_opts *o, T *host, const T *dev, size_t count) {
+    if (!o->host_ptrs || !host) return TCSFM_OK;
+    HIPCHK(h, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    return TCSFM_OK;
+}
+
+// intrinsics must be pinhole; checked on the host when they are host pointers, otherwise after a small D2H copy
+int check_intrinsics(tcsfm_ctx *h, const tcsfm_opts *o, const float *K_host_or_dev, int n) {
+    std::vector<float> k((size_t)n * 9);
+    if (o->host_ptrs) memcpy(k.data(), K_host_or_dev, k.size() * sizeof(float));
+    else {
+        HIPCHK(h, hipMemcpyAsync(k.data(), K_host_or_dev, k.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    for (int i = 0; i < n; i++) {
+        const float *K = &k[(size_t)i * 9];
+        if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || !(K[0] != 0.f) || !(K[4] != 0.f))
+            return fail(h, TCSFM_E_INTRINSICS, "intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1]");
+    }
+    return TCSFM_OK;
+}
+
+template <int NP, bool DC, int MODE>
+void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
+    dim3 grid(h->nblk, N), block(TILE_NT);
+    hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
+}
+
+void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mode) {
+    if (np == 6) {
+        if (mode == MODE_MAPS) launch_lin_t<6, false, MODE_MAPS>(h, P, N);
+        else if (mode == MODE_COST) launch_lin_t<6, false, MODE_COST>(h, P, N);
+        else if (dc) launch_lin_t<6, true, MODE_LIN>(h, P, N);
+        else launch_lin_t<6, false, MODE_LIN>(h, P, N);
+    } else {
+        if (mode == MODE_MAPS) launch_lin_t<7, false, MODE_MAPS>(h, P, N);
+        else if (mode == MODE_COST) launch_lin_t<7, false, MODE_COST>(h, P, N);
+        else if (dc) launch_lin_t<7, true, MODE_LIN>(h, P, N);
+        else launch_lin_t<7, false, MODE_LIN>(h, P, N);
+    }
+}
+
+void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
+    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
+    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
+}
+
+int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
+int nacc_of(int np) { return np == 6 ? AccLayout<6>::NACC : AccLayout<7>::NACC; }
+
+int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds) {
+    PackParams P;
+    P.tgt = tgt; P.src = src; P.depth_t = dt; P.depth_s = ds;
+    P.tgtpack = h->tgtpack; P.srcpack = h->srcpack; P.depth_out = h->depth_work;
+    P.H = h->H; P.W = h->W; P.N = Nimg;
+    P.wl = o->w_l1 / 3.f; P.ws = o->w_ssim / 3.f;
+    P.depth_is_disp = o->depth_is_disp;
+    P.min_disp = o->depth_is_disp ? 1.f / o->max_depth : 0.f;
+    P.max_disp = o->depth_is_disp ? 1.f / o->min_depth : 0.f;
+    int hw = h->H * h->W;
+    hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    return TCSFM_OK;
+}
+
+int run_init(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const float *ls, const float *K, int shared) {
+    InitParams I;
+    I.pose = pose; I.log_scale = ls; I.K = K; I.st = h->state; I.pc = h->pconst; I.N = N; I.shared_image = shared;
+    I.lambda0 = o->lambda0;
+    hipLaunchKernelGGL(k_init, dim3((N + 63) / 64), dim3(64), 0, h->stream, I);
+    HIPCHK(h, hipGetLastError());
+    return TCSFM_OK;
+}
+
+LinParams lin_params(tcsfm_ctx *h, const tcsfm_opts *o, int np) {
+    LinParams P;
+    memset(&P, 0, sizeof(P));
+    P.tgtpack = h->tgtpack; P.srcpack = h->srcpack; P.depth_t = h->depth_work; P.pc = h->pconst; P.partials = h->partials;
+    P.H = h->H; P.W = h->W; P.tiles_x = h->tiles_x; P.tiles_y = h->tiles_y; P.nacc = nacc_of(np);
+    P.wl = o->w_l1 / 3.f; P.ws = o->w_ssim / 3.f; P.eps = o->irls_eps; P.automask = o->automask;
+    return P;
+}
+
+SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) {
+    SolveParams S;
+    memset(&S, 0, sizeof(S));
+    S.partials = h->partials; S.st = h->state; S.pc = h->pconst; S.stats = nullptr; S.lin_out = h->lin_out;
+    S.nblk = h->nblk; S.nacc = nacc_of(np); S.np = np; S.has_dc = o->w_dc > 0.f;
+    S.n_iters = o->n_iters; S.solver = o->solver; S.param = o->param;
+    S.b_dc = (double)o->w_dc / ((double)h->H * (double)h->W);
+    S.lambda_up = o->lambda_up; S.lambda_down = o->lambda_down; S.lambda_min = o->lambda_min;
+    S.shared_image = shared;
+    return S;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+void tcsfm_default_opts(tcsfm_opts *o) {
+    memset(o, 0, sizeof(*o));
+    o->n_iters = 4; o->solver = TCSFM_SOLVER_GN; o->param = TCSFM_PARAM_SE3; o->refine = TCSFM_REFINE_POSE;
+    o->automask = 1; o->depth_is_disp = 0; o->host_ptrs = 0;
+    o->w_l1 = 0.15f; o->w_ssim = 0.85f; o->w_dc = 0.f; o->irls_eps = 1e-3f;
+    o->lambda0 = 1e-4f; o->lambda_up = 10.f; o->lambda_down = 0.1f; o->lambda_min = 1e-7f;
+    o->min_depth = 0.06f; o->max_depth = 2.67f;
+}
+
+int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
+
+const char *tcsfm_last_error(tcsfm_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
+    if (!out) return TCSFM_E_ARG;
+    *out = nullptr;
+    if (H < 4 || W < 4 || H > 16384 || W > 16384 || max_pairs < 1 || (size_t)H * W * max_pairs > ((size_t)1 << 33)) {
+        g_create_error = "tcsfm_create: bad sizes";
+        return TCSFM_E_ARG;
+    }
+    tcsfm_ctx *h = new tcsfm_ctx();
+    h->device = device; h->H = H; h->W = W; h->max_pairs = max_pairs;
+    h->tiles_x = (W + TILE_W - 1) / TILE_W; h->tiles_y = (H + TILE_H - 1) / TILE_H; h->nblk = h->tiles_x * h->tiles_y;
+    size_t hw = (size_t)H * W, n = max_pairs;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    h->stream = h->own_stream;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tgtpack, n * hw * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->srcpack, n * hw * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->depth_work, n * hw * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->partials, n * h->nblk * kMaxAcc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->state, n * sizeof(PairState));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->pconst, n * sizeof(PairConst));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->lin_out, n * kLinOut * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->pose_dev, n * 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->ls_dev, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->K_dev, n * 9 * sizeof(float));
+    if (e != hipSuccess) {
+        g_create_error = std::string("tcsfm_create: ") + hipGetErrorString(e);
+        tcsfm_destroy(h);
+        return e == hipErrorOutOfMemory ? TCSFM_E_NOMEM : TCSFM_E_HIP;
+    }
+    *out = h;
+    return TCSFM_OK;
+}
+
+void tcsfm_destroy(tcsfm_handle h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->state, h->pconst, h->lin_out,
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &s : h->stage)
+        if (s.p) (void)hipFree(s.p);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
+    if (!h) return TCSFM_E_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return TCSFM_OK;
+}
+
+int tcsfm_synchronize(tcsfm_handle h) {
+    if (!h) return TCSFM_E_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const float *disp, float *scaled, float *depth) {
+    if (!h) return TCSFM_E_ARG;
+    if (!o || !disp || n < 1) return fail(h, TCSFM_E_ARG, "tcsfm_disp_to_depth: bad argument");
+    if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
+    HIPCHK(h, hipSetDevice(h->device));
+    const float *d_in; float *d_s, *d_d;
+    int rc;
+    if ((rc = to_dev(h, o, 0, disp, (size_t)n, &d_in))) return rc;
+    if ((rc = out_dev(h, o, 1, scaled, (size_t)n, &d_s))) return rc;
+    if ((rc = out_dev(h, o, 2, depth, (size_t)n, &d_d))) return rc;
+    hipLaunchKernelGGL(k_disp_to_depth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d_in, d_s, d_d, (long long)n,
+                       1.f / o->max_depth, 1.f / o->min_depth);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = copy_back(h, o, scaled, d_s, (size_t)n))) return rc;
+    if ((rc = copy_back(h, o, depth, d_d, (size_t)n))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,
+               const float *pose, const float *K, float *img_rec, float *valid, float *proj_depth, float *comp_depth) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_warp: NULL input");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    size_t hw = (size_t)h->H * h->W;
+    const float *d_src, *d_dt, *d_ds, *d_pose, *d_K;
+    float *d_rec, *d_valid, *d_pd, *d_cd;
+    if ((rc = to_dev(h, o, 0, src, N * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 1, depth_t, N * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_s, N * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 3, pose, (size_t)N * 6, &d_pose))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = out_dev(h, o, 5, img_rec, N * 3 * hw, &d_rec))) return rc;
+    if ((rc = out_dev(h, o, 6, valid, N * hw, &d_valid))) return rc;
+    if ((rc = out_dev(h, o, 7, proj_depth, N * hw, &d_pd))) return rc;
+    if ((rc = out_dev(h, o, 8, comp_depth, N * hw, &d_cd))) return rc;
+    if (o->depth_is_disp) return fail(h, TCSFM_E_ARG, "tcsfm_warp takes depth maps (call tcsfm_disp_to_depth first)");
+    if ((rc = run_init(h, o, N, d_pose, nullptr, d_K, 0))) return rc;
+    WarpParams P;
+    P.src = d_src; P.depth_t = d_dt; P.depth_s = d_ds; P.pc = h->pconst;
+    P.rec = d_rec; P.valid = d_valid; P.pd = d_pd; P.cd = d_cd; P.H = h->H; P.W = h->W;
+    hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = copy_back(h, o, img_rec, d_rec, N * 3 * hw))) return rc;
+    if ((rc = copy_back(h, o, valid, d_valid, N * hw))) return rc;
+    if ((rc = copy_back(h, o, proj_depth, d_pd, N * hw))) return rc;
+    if ((rc = copy_back(h, o, comp_depth, d_cd, N * hw))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_photometric(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                      const float *depth_s, const float *pose, const float *K, float *diff, float *valid, float *weight,
+                      float *auto_err, float *auto_mask, float *img_rec) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_photometric: NULL input");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    size_t hw = (size_t)h->H * h->W;
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K;
+    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, pose, (size_t)N * 6, &d_pose))) return rc;
+    if ((rc = to_dev(h, o, 5, K, (size_t)N * 9, &d_K))) return rc;
+    float *outs[6] = {diff, valid, weight, auto_err, auto_mask, img_rec}, *d_out[6];
+    for (int i = 0; i < 6; i++)
+        if ((rc = out_dev(h, o, 6 + i, outs[i], (i == 5 ? 3 : 1) * N * hw, &d_out[i]))) return rc;
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds))) return rc;
+    if ((rc = run_init(h, o, N, d_pose, nullptr, d_K, 0))) return rc;
+    LinParams P = lin_params(h, o, 6);
+    P.o_diff = d_out[0]; P.o_valid = d_out[1]; P.o_weight = d_out[2]; P.o_auto_err = d_out[3]; P.o_auto_mask = d_out[4]; P.o_rec = d_out[5];
+    launch_lin(h, P, N, 6, false, MODE_MAPS);
+    HIPCHK(h, hipGetLastError());
+    for (int i = 0; i < 6; i++)
+        if ((rc = copy_back(h, o, outs[i], d_out[i], (i == 5 ? 3 : 1) * N * hw))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+// shared by tcsfm_linearize and tcsfm_loss_surface: one evaluation at given poses, results to host doubles
+static int eval_once(tcsfm_ctx *h, const tcsfm_opts *o, int N, int Nimg, const float *d_tgt, const float *d_src, const float *d_dt,
+                     const float *d_ds, const float *d_pose, const float *d_ls, const float *d_K, int mode, std::vector<double> &host) {
+    int rc, np = np_of(o), shared = (Nimg == 1 && N > 1) ? 1 : 0;
+    if ((rc = run_pack(h, o, Nimg, d_tgt, d_src, d_dt, d_ds))) return rc;
+    if ((rc = run_init(h, o, N, d_pose, d_ls, d_K, shared))) return rc;
+    LinParams P = lin_params(h, o, np);
+    launch_lin(h, P, N, np, o->w_dc > 0.f, mode);
+    HIPCHK(h, hipGetLastError());
+    SolveParams S = solve_params(h, o, np, shared);
+    S.mode = 2;
+    if (mode == MODE_COST) S.has_dc = 0;  // only the three scalar sums are live in cost mode
+    launch_solve(h, S, N, np);
+    HIPCHK(h, hipGetLastError());
+    int rec = np * np + np + 4;
+    host.resize((size_t)N * rec);
+    HIPCHK(h, hipMemcpyAsync(host.data(), h->lin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                    const float *depth_s, const float *pose, const float *log_scale, const float *K, double *Hmat, double *g,
+                    double *stats) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_linearize: NULL input");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    size_t hw = (size_t)h->H * h->W;
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K, *d_ls;
+    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, pose, (size_t)N * 6, &d_pose))) return rc;
+    if ((rc = to_dev(h, o, 5, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 6, log_scale, (size_t)N, &d_ls))) return rc;
+    std::vector<double> host;
+    if ((rc = eval_once(h, o, N, N, d_tgt, d_src, d_dt, d_ds, d_pose, d_ls, d_K, MODE_LIN, host))) return rc;
+    int np = np_of(o), rec = np * np + np + 4;
+    for (int n = 0; n < N; n++) {
+        const double *r = &host[(size_t)n * rec];
+        if (Hmat) memcpy(Hmat + (size_t)n * np * np, r, sizeof(double) * np * np);
+        if (g) memcpy(g + (size_t)n * np, r + np * np, sizeof(double) * np);
+        if (stats) memcpy(stats + (size_t)n * 4, r + np * np + np, sizeof(double) * 4);
+    }
+    return TCSFM_OK;
+}
+
+int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, int P, const float *poses, double *cost_out) {
+    int rc = check_common(h, o, P);
+    if (rc) return rc;
+    if (!tgt || !src || !depth_t || !depth_s || !poses || !K || !cost_out) return fail(h, TCSFM_E_ARG, "tcsfm_loss_surface: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, 1))) return rc;
+    size_t hw = (size_t)h->H * h->W;
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K;
+    if ((rc = to_dev(h, o, 0, tgt, 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, poses, (size_t)P * 6, &d_pose))) return rc;
+    if ((rc = to_dev(h, o, 5, K, (size_t)9, &d_K))) return rc;
+    std::vector<double> host;
+    tcsfm_opts oo = *o;
+    oo.refine = TCSFM_REFINE_POSE;
+    if ((rc = eval_once(h, &oo, P, 1, d_tgt, d_src, d_dt, d_ds, d_pose, nullptr, d_K, MODE_COST, host))) return rc;
+    const int rec = 6 * 6 + 6 + 4;
+    for (int i = 0; i < P; i++) cost_out[i] = host[(size_t)i * rec + 42];
+    return TCSFM_OK;
+}
+
+int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                 const float *depth_s, const float *K, float *pose_io, float *log_scale_io, float *stats_out) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !src || !depth_t || !depth_s || !pose_io || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    const size_t hw = (size_t)h->H * h->W;
+    const int np = np_of(o);
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose_in, *d_ls_in;
+    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 5, (const float *)pose_io, (size_t)N * 6, &d_pose_in))) return rc;
+    if ((rc = to_dev(h, o, 6, (const float *)log_scale_io, (size_t)N, &d_ls_in))) return rc;
+    float *d_pose_out = o->host_ptrs ? (float *)d_pose_in : pose_io;
+    float *d_ls_out = (np == 7 && log_scale_io) ? (o->host_ptrs ? (float *)d_ls_in : log_scale_io) : nullptr;
+    float *d_stats = nullptr;
+    const size_t nstats = (size_t)N * (o->n_iters + 1) * TCSFM_NSTAT;
+    if (stats_out) {
+        if ((rc = out_dev(h, o, 7, stats_out, nstats, &d_stats))) return rc;
+        HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
+    }
+
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds))) return rc;
+    if ((rc = run_init(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0))) return rc;
+    LinParams P = lin_params(h, o, np);
+    SolveParams S = solve_params(h, o, np, 0);
+    S.stats = d_stats;
+    const bool dc = o->w_dc > 0.f;
+    for (int it = 0; it < o->n_iters; it++) {
+        launch_lin(h, P, N, np, dc, MODE_LIN);
+        S.it = it; S.mode = 0;
+        launch_solve(h, S, N, np);
+    }
+    if (o->solver == TCSFM_SOLVER_LM && o->n_iters > 0) {  // cost-only pass deciding whether the last step is kept
+        launch_lin(h, P, N, np, dc, MODE_COST);
+        S.it = o->n_iters; S.mode = 1;
+        launch_solve(h, S, N, np);
+    }
+    HIPCHK(h, hipGetLastError());
+    FinishParams F;
+    F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = d_ls_out; F.N = N;
+    hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = copy_back(h, o, pose_io, d_pose_out, (size_t)N * 6))) return rc;
+    if (d_ls_out && (rc = copy_back(h, o, log_scale_io, d_ls_out, (size_t)N))) return rc;
+    if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+// ---- SE(3) host utilities ----------------------------------------------------------------------
+void tcsfm_pose_to_matrix(const double pose[6], double T[12]) { tc::pose_to_T(pose, T); }
+void tcsfm_matrix_to_pose(const double T[12], double pose[6]) { tc::T_to_pose(T, pose); }
+void tcsfm_se3_exp(const double xi[6], double T[12]) { tc::se3_exp(xi, T); }
+void tcsfm_se3_log(const double T[12], double xi[6]) { tc::se3_log(T, xi); }
+void tcsfm_se3_mul(const double A[12], const double B[12], double C[12]) { tc::se3_mul(A, B, C); }
+void tcsfm_se3_inv(const double A[12], double B[12]) { tc::se3_inv(A, B); }
+
+}  // extern "C"

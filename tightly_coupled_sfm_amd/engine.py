@@ -1,0 +1,209 @@
+"""Host-side engine: torch tensors (device memory, streams) over the C ABI of libtcsfm_hip.so.
+
+PyTorch is plumbing here -- it owns device buffers and the current stream; every computation happens
+in the HIP library.  All array arguments are passed as raw device pointers (``tensor.data_ptr()``).
+
+Naming follows the reference: a *pair* is a directed (target, source) frame pair; poses are the
+reference's 6-vectors ``[tx,ty,tz,rx,ry,rz]`` (models/stn.py:143-158).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Opts, default_opts  # noqa: F401
+
+
+def _chk(t: torch.Tensor, shape, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device})")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype})")
+    if tuple(t.shape) != tuple(shape):
+        # same wording as the reference's check_sizes (models/stn.py:24-30)
+        raise AssertionError("wrong size for {}, expected {}, got  {}".format(name, "x".join(map(str, shape)), list(t.shape)))
+    return t.contiguous()
+
+
+class Engine:
+    """One handle = one GPU + one HIP stream (include/tcsfm.h).  ``max_pairs`` directed pairs of HxW."""
+
+    def __init__(self, H: int, W: int, max_pairs: int, device: Optional[int] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("tightly_coupled_sfm_amd.Engine needs a ROCm GPU (torch.cuda.is_available() is False)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.H, self.W, self.max_pairs = int(H), int(W), int(max_pairs)
+        h = C.c_void_p()
+        rc = self.lib.tcsfm_create(C.byref(h), self.device, self.H, self.W, self.max_pairs)
+        if rc != 0:
+            raise RuntimeError(f"tcsfm_create failed ({rc}): {self.lib.tcsfm_last_error(None).decode()}")
+        self._h = h
+        self.use_torch_stream()
+
+    # -- lifetime ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.tcsfm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(f"tcsfm error {rc}: {self.lib.tcsfm_last_error(self._h).decode()}")
+
+    def use_torch_stream(self):
+        """Run on torch's current stream of this device, so tensor producers/consumers stay ordered."""
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._call(self.lib.tcsfm_set_stream(self._h, C.c_void_p(s)))
+
+    def use_own_stream(self):
+        self._call(self.lib.tcsfm_set_stream(self._h, None))
+
+    def synchronize(self):
+        self._call(self.lib.tcsfm_synchronize(self._h))
+
+    @property
+    def dev(self) -> torch.device:
+        return torch.device("cuda", self.device)
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    # -- reference-function drop-ins -----------------------------------------------------------
+    def disp_to_depth(self, disp: torch.Tensor, min_depth: float, max_depth: float):
+        """utils/learning_helpers.py:77-86 -> (scaled_disp, depth)"""
+        d = disp.contiguous()
+        if d.dtype != torch.float32 or not d.is_cuda:
+            raise TypeError("disp must be a float32 GPU tensor")
+        s, z = torch.empty_like(d), torch.empty_like(d)
+        o = default_opts(min_depth=min_depth, max_depth=max_depth)
+        self._call(self.lib.tcsfm_disp_to_depth(self._h, C.byref(o), d.numel(), self._p(d), self._p(s), self._p(z)))
+        return s, z
+
+    def inverse_warp2(self, img, depth, ref_depth, pose, intrinsics):
+        """models/stn.py:234-273 with the reference's argument order; ``pose`` here is what the reference
+        passes, i.e. callers that wrote ``inverse_warp2(src, d_t, d_s, -poses, K)`` keep passing ``-poses``."""
+        N = img.shape[0]
+        H, W = self.H, self.W
+        img = _chk(img, (N, 3, H, W), "img"); depth = _chk(depth, (N, 1, H, W), "depth")
+        ref_depth = _chk(ref_depth, (N, 1, H, W), "ref_depth"); intrinsics = _chk(intrinsics, (N, 3, 3), "intrinsics")
+        pose6 = _chk(pose[:, 0:6].contiguous(), (N, 6), "pose")
+        neg = (-pose6).contiguous()  # the ABI applies pose_vec2mat(-pose) like the reference call sites
+        rec = torch.empty_like(img); valid = torch.empty_like(depth); pd = torch.empty_like(depth); cd = torch.empty_like(depth)
+        o = default_opts()
+        self._call(self.lib.tcsfm_warp(self._h, C.byref(o), N, self._p(img), self._p(depth), self._p(ref_depth), self._p(neg),
+                                       self._p(intrinsics), self._p(rec), self._p(valid), self._p(pd), self._p(cd)))
+        return rec, valid, pd, cd
+
+    def compute_photometric_error(self, target_img, source_img, target_depth, source_depth, pose, intrinsics,
+                                  opts: Optional[Opts] = None):
+        """optimization_experiments/helpers.py:8-23 -> dict with the reference's keys (+ the raw maps)."""
+        N = target_img.shape[0]
+        H, W = self.H, self.W
+        t = _chk(target_img, (N, 3, H, W), "target_img"); s = _chk(source_img, (N, 3, H, W), "source_img")
+        dt = _chk(target_depth, (N, 1, H, W), "target_depth"); ds = _chk(source_depth, (N, 1, H, W), "source_depth")
+        p = _chk(pose, (N, 6), "pose"); K = _chk(intrinsics, (N, 3, 3), "intrinsics")
+        o = opts or default_opts()
+        diff, valid, weight, ae, am = (torch.empty_like(dt) for _ in range(5))
+        rec = torch.empty_like(t)
+        self._call(self.lib.tcsfm_photometric(self._h, C.byref(o), N, self._p(t), self._p(s), self._p(dt), self._p(ds), self._p(p),
+                                              self._p(K), self._p(diff), self._p(valid), self._p(weight), self._p(ae), self._p(am),
+                                              self._p(rec)))
+        return {"diff_img": diff, "img_rec": rec, "valid_mask": am * valid, "weight_mask": weight, "poses": pose,
+                "warp_valid": valid, "auto_mask_error": ae, "auto_mask": am}
+
+    def loss_surface(self, target_img, source_img, target_depth, source_depth, intrinsics, poses, opts: Optional[Opts] = None):
+        """costs of ONE pair under P candidate poses (plot_loss_surface.py:31-33,45-47) -> np.ndarray [P] float64"""
+        H, W = self.H, self.W
+        t = _chk(target_img, (1, 3, H, W), "target_img"); s = _chk(source_img, (1, 3, H, W), "source_img")
+        dt = _chk(target_depth, (1, 1, H, W), "target_depth"); ds = _chk(source_depth, (1, 1, H, W), "source_depth")
+        K = _chk(intrinsics, (1, 3, 3), "intrinsics")
+        P = poses.shape[0]
+        p = _chk(poses, (P, 6), "poses")
+        o = opts or default_opts()
+        out = np.zeros(P, dtype=np.float64)
+        self._call(self.lib.tcsfm_loss_surface(self._h, C.byref(o), self._p(t), self._p(s), self._p(dt), self._p(ds), self._p(K),
+                                               P, self._p(p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # -- Gauss-Newton engine -----------------------------------------------------------------------
+    def _pairs(self, tgt, src, depth_t, depth_s, K, pose):
+        N = tgt.shape[0]
+        H, W = self.H, self.W
+        return (N, _chk(tgt, (N, 3, H, W), "tgt"), _chk(src, (N, 3, H, W), "src"), _chk(depth_t, (N, 1, H, W), "depth_t"),
+                _chk(depth_s, (N, 1, H, W), "depth_s"), _chk(K, (N, 3, 3), "K"), _chk(pose, (N, 6), "pose"))
+
+    def linearize(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None):
+        """normal equations at ``pose`` -> dict(H [N,np,np], g [N,np], cost, cost_photo, cost_dc, n_mask [N]) (numpy f64)"""
+        o = opts or default_opts()
+        N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
+        n_p = 7 if o.refine == _lib.REFINE_POSE_SCALE else 6
+        ls = None if log_scale is None else _chk(log_scale, (N,), "log_scale")
+        Hm = np.zeros((N, n_p, n_p)); g = np.zeros((N, n_p)); st = np.zeros((N, 4))
+        self._call(self.lib.tcsfm_linearize(self._h, C.byref(o), N, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s),
+                                            self._p(pose), self._p(ls), self._p(K), Hm.ctypes.data_as(C.c_void_p),
+                                            g.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
+        return dict(H=Hm, g=g, cost=st[:, 0], cost_photo=st[:, 1], cost_dc=st[:, 2], n_mask=st[:, 3])
+
+    def refine(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None, stats: bool = False):
+        """Refine N directed pairs in place-free style: returns (pose [N,6], log_scale [N] or None, stats or None).
+        Asynchronous on the handle's stream; outputs are GPU tensors."""
+        o = opts or default_opts()
+        N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
+        pose_io = pose.clone()
+        ls_io = None
+        if o.refine == _lib.REFINE_POSE_SCALE:
+            ls_io = torch.zeros(N, device=pose.device, dtype=torch.float32) if log_scale is None else _chk(log_scale, (N,), "log_scale").clone()
+        st = torch.empty((N, o.n_iters + 1, _lib.NSTAT), device=pose.device, dtype=torch.float32) if stats else None
+        self._call(self.lib.tcsfm_refine(self._h, C.byref(o), N, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s),
+                                         self._p(K), self._p(pose_io), self._p(ls_io), self._p(st)))
+        return pose_io, ls_io, st
+
+    def refine_inplace(self, tgt, src, depth_t, depth_s, K, pose_io, opts: Opts, log_scale_io=None, stats_out=None):
+        """Zero-allocation variant used by bench.py: tensors must already be validated/contiguous."""
+        self._call(self.lib.tcsfm_refine(self._h, C.byref(opts), tgt.shape[0], self._p(tgt), self._p(src), self._p(depth_t),
+                                         self._p(depth_s), self._p(K), self._p(pose_io), self._p(log_scale_io), self._p(stats_out)))
+
+
+# -- SE(3) host utilities (liegroups stand-ins; double precision, no GPU needed) ---------------------
+def _vec(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(n)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def pose_to_matrix(pose) -> np.ndarray:
+    a, pa = _vec(pose, 6); T = np.zeros(12); _lib.load().tcsfm_pose_to_matrix(pa, T.ctypes.data_as(C.c_void_p)); return T.reshape(3, 4)
+
+
+def matrix_to_pose(T) -> np.ndarray:
+    a, pa = _vec(T, 12); p = np.zeros(6); _lib.load().tcsfm_matrix_to_pose(pa, p.ctypes.data_as(C.c_void_p)); return p
+
+
+def se3_exp(xi) -> np.ndarray:
+    a, pa = _vec(xi, 6); T = np.zeros(12); _lib.load().tcsfm_se3_exp(pa, T.ctypes.data_as(C.c_void_p)); return T.reshape(3, 4)
+
+
+def se3_log(T) -> np.ndarray:
+    a, pa = _vec(T, 12); x = np.zeros(6); _lib.load().tcsfm_se3_log(pa, x.ctypes.data_as(C.c_void_p)); return x
+
+
+def se3_mul(A, B) -> np.ndarray:
+    a, pa = _vec(A, 12); b, pb = _vec(B, 12); c = np.zeros(12)
+    _lib.load().tcsfm_se3_mul(pa, pb, c.ctypes.data_as(C.c_void_p)); return c.reshape(3, 4)
+
+
+def se3_inv(A) -> np.ndarray:
+    a, pa = _vec(A, 12); b = np.zeros(12); _lib.load().tcsfm_se3_inv(pa, b.ctypes.data_as(C.c_void_p)); return b.reshape(3, 4)
