@@ -73,8 +73,11 @@ enum { TCSFM_STAT_COST = 0, TCSFM_STAT_COST_PHOTO = 1, TCSFM_STAT_NMASK = 2, TCS
 int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs);
 void tcsfm_destroy(tcsfm_handle h);
 const char *tcsfm_last_error(tcsfm_handle h); /* h may be NULL: last create() error */
-/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the handle's own stream. */
+/* Run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is HIP's legacy default
+ * stream (stream 0), which is what PyTorch's default stream is.  A fresh handle runs on its own non-blocking stream;
+ * tcsfm_use_own_stream() switches back to it. */
 int tcsfm_set_stream(tcsfm_handle h, void *hip_stream);
+int tcsfm_use_own_stream(tcsfm_handle h);
 int tcsfm_synchronize(tcsfm_handle h);
 void tcsfm_default_opts(tcsfm_opts *o);
 /* bytes of HBM traffic the algorithm must move per pixel per pair per linearisation: 32 */

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "tcsfm_destroy": (None, [_P]),
     "tcsfm_last_error": (C.c_char_p, [_P]),
     "tcsfm_set_stream": (C.c_int, [_P, _P]),
+    "tcsfm_use_own_stream": (C.c_int, [_P]),
     "tcsfm_synchronize": (C.c_int, [_P]),
     "tcsfm_default_opts": (None, [C.POINTER(Opts)]),
     "tcsfm_algorithmic_bytes_per_pixel": (C.c_int, [C.POINTER(Opts)]),
@@ -56,6 +57,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own ROCm runtime: import it first so that this library binds to the SAME libamdhip64 the
+    # process's tensors live in (loading ours first leaves two runtimes and hipSetDevice then reports "no device").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (no CPU fallback exists)")
     lib = C.CDLL(LIB_PATH)

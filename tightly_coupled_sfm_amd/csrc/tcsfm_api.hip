@@ -269,7 +269,13 @@ void tcsfm_destroy(tcsfm_handle h) {
 
 int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
     if (!h) return TCSFM_E_ARG;
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hipStream_t)hip_stream;  // NULL = legacy default stream
+    return TCSFM_OK;
+}
+
+int tcsfm_use_own_stream(tcsfm_handle h) {
+    if (!h) return TCSFM_E_ARG;
+    h->stream = h->own_stream;
     return TCSFM_OK;
 }
 

@@ -69,7 +69,7 @@ class Engine:
         self._call(self.lib.tcsfm_set_stream(self._h, C.c_void_p(s)))
 
     def use_own_stream(self):
-        self._call(self.lib.tcsfm_set_stream(self._h, None))
+        self._call(self.lib.tcsfm_use_own_stream(self._h))
 
     def synchronize(self):
         self._call(self.lib.tcsfm_synchronize(self._h))
