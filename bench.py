@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- optimised frame-pairs/sec at 640x192, 4 GN iterations (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): one window of B=1 target frame with
+S=1 source frame -> the reference's fwd + inv directed pairs (N_pairs = 2 S B = 2, train_mono.py:54-62),
+640x192, 4 Gauss-Newton iterations of the 6-DoF pose of each directed pair.  One *step* = one
+``tcsfm_refine`` call over that batch; one frame-pair is counted per window (not per directed pair).
+Inputs are synthetic (tightly_coupled_sfm_amd.synth), resident in HBM before the timed region.
+
+Multi-GPU: windows are independent least-squares problems -> every rank refines its own window
+(weak scaling, no collective on the data path); one RCCL all_gather of the refined poses AFTER the
+timed region reproduces the "final gather" of the north star.
+
+The single JSON line also carries
+  roofline      dominant kernel (k_linearize): algorithmic bytes (32 B/pixel/pair/iteration) per launch
+                divided by its average launch duration from HIP events on the launch stream (instrumented second
+                pass over the same K steps; the rocprofv3 --kernel-trace --stats summary of this command is in profiles/)
+  cpu_baseline  the float64 CPU oracle (a scalar C port of the same algorithm, oracle/tcsfm_oracle.c) timed on this
+                box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, ITERS = 192, 640, 4
+WINDOWS_PER_RANK = 1          # B
+SOURCES = 1                   # S
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(sample_windows: int):
+    """Time the CPU oracle on `sample_windows` windows (fwd + inv pair each, 4 GN iterations)."""
+    import numpy as np
+    from oracle.oracle import Oracle, default_opts
+    from tightly_coupled_sfm_amd import synth
+    orc = Oracle("f64")
+    opts = default_opts(n_iters=ITERS)
+    batches = [synth.make_batch(2, H, W, seed0=1000 + i, both_directions=True) for i in range(min(sample_windows, 2))]
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(sample_windows):
+        b = batches[i % len(batches)]
+        for n in range(2):
+            orc.refine(b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0], b["pose_init"][n], b["K"][n], opts)
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{done} windows x (fwd+inv pair) x {ITERS} GN iterations at {W}x{H}, float64 scalar C oracle, {dt:.1f} s"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per k_linearize launch from a separate rocprofv3 --pmc run (profiles/*pmc_traffic.json), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get("hbm_bytes_per_linearize_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--cpu-sample", type=int, default=12, help="windows timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+
+    npairs = 2 * SOURCES * WINDOWS_PER_RANK
+    b = synth.make_batch(npairs, H, W, seed0=100 * rank, both_directions=True)
+    dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    eng = Engine(H, W, npairs)
+    opts = default_opts(n_iters=ITERS)
+    pose_io = dev["pose_init"].clone()
+
+    def step():
+        pose_io.copy_(dev["pose_init"], non_blocking=True)   # every step starts from the same initial poses
+        eng.refine_inplace(dev["tgt"], dev["src"], dev["depth_t"], dev["depth_s"], dev["K"], pose_io, opts)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # final gather of the refined poses (RCCL over xGMI), outside the timed region
+    final = pose_io.clone()
+    if distributed:
+        gathered = [torch.empty_like(final) for _ in range(world)]
+        dist.all_gather(gathered, final)
+        final_all = torch.stack(gathered)
+    else:
+        final_all = final[None]
+    assert torch.isfinite(final_all).all()
+
+    # instrumented pass: HIP events around every kernel launch, same K steps
+    roof = None
+    if rank == 0:
+        eng.profile_begin()
+        for _ in range(min(args.steps, 500)):
+            step()
+        prof = eng.profile_end()
+        lin_ms, lin_n = prof["linearize"]
+        alg_bytes = 32 * H * W * npairs                      # 32 B/pixel/pair/iteration x pixels x pairs/launch
+        avg_s = lin_ms / max(lin_n, 1) * 1e-3
+        achieved = alg_bytes / avg_s / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": load_pmc_traffic(),
+                "kernel": "k_linearize", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(lin_n),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "other_kernels_avg_us": {k: round(v[0] / max(v[1], 1) * 1e3, 3) for k, v in prof.items() if k != "linearize"}}
+
+    if rank == 0:
+        total_windows = args.steps * WINDOWS_PER_RANK * world
+        err_t = float((final[:, :3] - dev["pose_gt"][:, :3]).norm(dim=1).mean() / dev["pose_gt"][:, :3].norm(dim=1).mean())
+        out = {
+            "metric": "optimized frame-pairs/sec at 640x192, 4 GN iters",
+            "value": round(total_windows / elapsed, 2),
+            "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KITTI-like 640x192, batch=1 frame-pair (fwd+inv directed pairs), 4 GN iters, 6-DoF pose",
+                       "windows_per_gpu": WINDOWS_PER_RANK, "sources": SOURCES, "directed_pairs_per_step": npairs,
+                       "gn_iters": ITERS, "solver": "gn", "param": "se3", "parallelism": f"{world} independent shards"},
+            "roofline": roof,
+            "cpu_baseline": cpu_baseline(args.cpu_sample) if args.cpu_sample > 0 else None,
+            "check": {"mean_rel_translation_error_vs_gt_after_refine": round(err_t, 5)},
+        }
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

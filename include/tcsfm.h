@@ -125,6 +125,14 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                  const float *depth_s, const float *K, float *pose_io, float *log_scale_io, float *stats_out);
 
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
+
+/* While profiling is on, every launch of the three kernel classes is bracketed by a pair of HIP events recorded on the
+ * handle's stream.  tcsfm_profile_end() synchronises the stream and returns summed elapsed milliseconds and launch
+ * counts per class: index 0 = k_linearize (the hot kernel), 1 = k_solve, 2 = k_pack. */
+int tcsfm_profile_begin(tcsfm_handle h);
+int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]);
+
 /* ---- SE(3) utilities, host, double (replace liegroups.SE3 at data/kitti_loader_stereo.py:129-147,
  *      validate.py:65-71; liegroups is an absent third-party dependency, version unpinned) ---------- */
 void tcsfm_pose_to_matrix(const double pose[6], double T[12]);   /* pose_vec2mat(-pose), 3x4 row-major  */

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
     "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
     "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),
+    "tcsfm_profile_begin": (C.c_int, [_P]),
+    "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
     "tcsfm_pose_to_matrix": (None, [_P, _P]),
     "tcsfm_matrix_to_pose": (None, [_P, _P]),
     "tcsfm_se3_exp": (None, [_P, _P]),

@@ -38,6 +38,11 @@ struct tcsfm_ctx {
     int tiles_x = 0, tiles_y = 0, nblk = 0, stats_cap_iters = 0;
     std::vector<HostStage> stage;
     std::string err;
+    // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -129,6 +134,27 @@ int check_intrinsics(tcsfm_ctx *h, const tcsfm_opts *o, const float *K_host_or_d
     return TCSFM_OK;
 }
 
+// RAII bracket: records a start event now and a stop event at scope exit when profiling is on
+struct ProfScope {
+    tcsfm_ctx *h;
+    bool on;
+    ProfScope(tcsfm_ctx *h_, int cls) : h(h_), on(h_->profiling) {
+        if (!on) return;
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            size_t old = h->ev_pool.size();
+            h->ev_pool.resize(old + 64);
+            for (size_t i = old; i < h->ev_pool.size(); i++) (void)hipEventCreate(&h->ev_pool[i]);
+        }
+        h->ev_class.push_back(cls);
+        (void)hipEventRecord(h->ev_pool[h->ev_used], h->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(h->ev_pool[h->ev_used + 1], h->stream);
+        h->ev_used += 2;
+    }
+};
+
 template <int NP, bool DC, int MODE>
 void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
     dim3 grid(h->nblk, N), block(TILE_NT);
@@ -136,6 +162,7 @@ void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
 }
 
 void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mode) {
+    ProfScope prof(h, 0);
     if (np == 6) {
         if (mode == MODE_MAPS) launch_lin_t<6, false, MODE_MAPS>(h, P, N);
         else if (mode == MODE_COST) launch_lin_t<6, false, MODE_COST>(h, P, N);
@@ -150,6 +177,7 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mo
 }
 
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
+    ProfScope prof(h, 1);
     if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
     else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
 }
@@ -167,7 +195,10 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
     P.min_disp = o->depth_is_disp ? 1.f / o->max_depth : 0.f;
     P.max_disp = o->depth_is_disp ? 1.f / o->min_depth : 0.f;
     int hw = h->H * h->W;
-    hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P);
+    {
+        ProfScope prof(h, 2);
+        hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P);
+    }
     HIPCHK(h, hipGetLastError());
     return TCSFM_OK;
 }
@@ -263,6 +294,7 @@ void tcsfm_destroy(tcsfm_handle h) {
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
         if (s.p) (void)hipFree(s.p);
+    for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -494,6 +526,30 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     if (d_ls_out && (rc = copy_back(h, o, log_scale_io, d_ls_out, (size_t)N))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_profile_begin(tcsfm_handle h) {
+    if (!h) return TCSFM_E_ARG;
+    h->profiling = true;
+    h->ev_used = 0;
+    h->ev_class.clear();
+    return TCSFM_OK;
+}
+
+int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]) {
+    if (!h || !ms_sum || !launches) return TCSFM_E_ARG;
+    h->profiling = false;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 3; i++) { ms_sum[i] = 0.0; launches[i] = 0; }
+    for (size_t k = 0; k < h->ev_class.size(); k++) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[2 * k], h->ev_pool[2 * k + 1]));
+        ms_sum[h->ev_class[k]] += ms;
+        launches[h->ev_class[k]]++;
+    }
+    h->ev_used = 0;
+    h->ev_class.clear();
     return TCSFM_OK;
 }
 

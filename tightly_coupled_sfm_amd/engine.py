@@ -74,6 +74,16 @@ class Engine:
     def synchronize(self):
         self._call(self.lib.tcsfm_synchronize(self._h))
 
+    def profile_begin(self):
+        """bracket every kernel launch with HIP events on the handle's stream (bench.py roofline leg)"""
+        self._call(self.lib.tcsfm_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> {'linearize'|'solve'|'pack': (summed ms, launches)}"""
+        ms = (C.c_double * 3)(); cnt = (C.c_int64 * 3)()
+        self._call(self.lib.tcsfm_profile_end(self._h, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(("linearize", "solve", "pack"))}
+
     @property
     def dev(self) -> torch.device:
         return torch.device("cuda", self.device)
