@@ -61,6 +61,9 @@ typedef struct tcsfm_opts {
     float irls_eps;        /* floor of the IRLS denominators                                             */
     float lambda0, lambda_up, lambda_down, lambda_min; /* Marquardt damping (relative to diag H)        */
     float min_depth, max_depth; /* config['min_depth'], config['max_depth'] (depth_is_disp only)       */
+    float prior_scale;     /* POSE_SCALE only: weight of (log_scale - initial)^2.  The photometric cost cannot separate
+                              depth scale from |t| (exact gauge); this prior makes the 7-DoF problem well posed.   */
+    float reserved1;
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32 */

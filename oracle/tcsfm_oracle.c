@@ -47,6 +47,7 @@ typedef struct {
     double w_dc;         /* depth-consistency weight, optimizer.py:83-86 (0 = off)       */
     double irls_eps;
     double lambda0, lambda_up, lambda_down, lambda_min;
+    double prior_scale; /* Tikhonov weight on (log_scale - initial log_scale)^2: fixes the scale/translation gauge of nparam 7 */
 } orc_opts;
 
 /* ------------------------------------------------------------------------- */
@@ -696,8 +697,14 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
     lin_t cur, tr;
     double lambda = op->lambda0;
     int have_cur = 0;
+    const double s0 = scur, ps = (np == 7) ? op->prior_scale : 0.0;
     for (int it = 0; it < op->n_iters; it++) {
         orc_linearize(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op, ae, &tr, NULL, NULL, NULL, NULL, NULL);
+        if (np == 7) { /* scale prior: the photometric cost alone cannot separate depth scale from |t| */
+            tr.cost += ps * (stry - s0) * (stry - s0);
+            tr.g[6] += 2 * ps * (stry - s0);
+            tr.H[6 * np + 6] += 2 * ps;
+        }
         if (stats) { stats[4 * it] = tr.cost; stats[4 * it + 1] = tr.cost_photo; stats[4 * it + 2] = tr.n_mask; stats[4 * it + 3] = lambda; }
         if (op->solver == 0 || !have_cur || tr.cost < cur.cost) {
             if (op->solver == 1 && have_cur) lambda = fmax(lambda * op->lambda_down, op->lambda_min);
@@ -708,7 +715,7 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
         apply_step(op, cur.H, cur.g, lambda, Tcur, scur, Ttry, &stry);
     }
     if (op->solver == 1 && op->n_iters > 0) {
-        double c = orc_cost(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op);
+        double c = orc_cost(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op) + ps * (stry - s0) * (stry - s0);
         if (stats) { int it = op->n_iters; stats[4 * it] = c; stats[4 * it + 1] = c; stats[4 * it + 2] = 0; stats[4 * it + 3] = lambda; }
         if (c < cur.cost) { memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry; }
     } else {

@@ -35,7 +35,7 @@ struct PairConst {
 // per-pair optimiser state (fp64)
 struct PairState {
     double Tcur[12], Ttry[12];
-    double scur, stry;
+    double scur, stry, s0;   // log depth-scale: accepted, trial, initial (prior centre)
     double lambda, cost_cur;
     double Hcur[TC_MAXP * TC_MAXP], gcur[TC_MAXP];
     double K[9];
@@ -617,7 +617,7 @@ __global__ void k_init(InitParams P) {
     for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
     pose_to_T(pose, S.Tcur);
     for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
-    S.scur = S.stry = P.log_scale ? (double)P.log_scale[n] : 0.0;
+    S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
     S.lambda = (double)P.lambda0;
     S.cost_cur = 0.0;
     S.have_cur = 0;
@@ -634,6 +634,7 @@ struct SolveParams {
     int it, n_iters, solver, param, mode;  // mode 0: iteration step, 1: final LM cost check, 2: export only
     double b_dc;            // w_dc / (H W)
     double lambda_up, lambda_down, lambda_min;
+    double prior_scale;     // weight of (log_scale - s0)^2 (np == 7)
     int shared_image;
 };
 
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     PairState &S = P.st[n];
     const double nmask = acc[L::OFF_S + 1];
     const double an = nmask > 0 ? 1.0 / nmask : 0.0;
-    const double cost_photo = an * acc[L::OFF_S], cost_dc = P.b_dc * acc[L::OFF_S + 2], cost = cost_photo + cost_dc;
+    const double cost_photo = an * acc[L::OFF_S], cost_dc = P.b_dc * acc[L::OFF_S + 2];
+    double cost = cost_photo + cost_dc;
     double Hm[NP * NP], g[NP];
     {
         int h = 0;
@@ -673,6 +675,12 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
                 h++;
             }
         }
+    }
+    if (NP == 7 && P.mode != 2) {  // scale prior (not part of the exported raw normal equations)
+        const double ds = S.stry - S.s0;
+        cost += P.prior_scale * ds * ds;
+        g[NP - 1] += 2.0 * P.prior_scale * ds;
+        Hm[(NP - 1) * NP + (NP - 1)] += 2.0 * P.prior_scale;
     }
     if (P.mode == 2) {  // export for tcsfm_linearize / tcsfm_loss_surface
         double *o = P.lin_out + (size_t)n * (NP * NP + NP + 4);

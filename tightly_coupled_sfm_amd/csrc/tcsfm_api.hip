@@ -229,6 +229,7 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
     S.n_iters = o->n_iters; S.solver = o->solver; S.param = o->param;
     S.b_dc = (double)o->w_dc / ((double)h->H * (double)h->W);
     S.lambda_up = o->lambda_up; S.lambda_down = o->lambda_down; S.lambda_min = o->lambda_min;
+    S.prior_scale = np == 7 ? (double)o->prior_scale : 0.0;
     S.shared_image = shared;
     return S;
 }
@@ -245,6 +246,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->w_l1 = 0.15f; o->w_ssim = 0.85f; o->w_dc = 0.f; o->irls_eps = 1e-3f;
     o->lambda0 = 1e-4f; o->lambda_up = 10.f; o->lambda_down = 0.1f; o->lambda_min = 1e-7f;
     o->min_depth = 0.06f; o->max_depth = 2.67f;
+    o->prior_scale = 1.0f;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
