@@ -484,6 +484,8 @@ typedef struct {
  *     H = sum_p a_p Jg_p' Lam_p Jg_p  +  b J3 J3'/max(E3,eps)
  *     Lam_p = W_p sum_c {  w_l1/3 * gr_c gr_c' / max(|r_c|, eps)                 (IRLS for the L1 term)
  *                        + w_ssim/3 * ( Cov_3x3(gr_c)/d2_c + mean_3x3(gr_c) mean_3x3(gr_c)'/d1_c ) }
+ *   where Cov_3x3 is taken as its centre-sample estimate 9/8 (gr_c - mean)(gr_c - mean)' (always PSD; summed over
+ *   the pixels it equals the window covariance up to boundary effects).
  *   The SSIM part is the Gauss-Newton matrix of the exact decomposition
  *     1 - l  = (mu_x-mu_y)^2/d1 ,  1 - cs = Var_3x3(x-y)/d2 ,  SSIM loss = (1 - l cs)/2
  *   (d1, d2 = the two SSIM denominators, losses.py:38) with d1, d2 and the geometry frozen over the 3x3 window.
@@ -548,7 +550,7 @@ void orc_linearize(int H, int W, const real *tgt, const real *src, const real *d
                     real cA = pre * (2 * s.mux * s.n2 - 2 * s.n1 * s.mux - ratio * (2 * s.muy * s.d2 - 2 * s.d1 * s.muy));
                     real cB = pre * (-ratio * 2 * s.d1);
                     real cC = pre * (2 * s.n1);
-                    real Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0;
+                    real Sx = 0, Sy = 0;
                     for (int dv = -1; dv <= 1; dv++)
                         for (int du = -1; du <= 1; du++) {
                             int q = refl(v + dv, H) * W + refl(u + du, W);
@@ -556,15 +558,16 @@ void orc_linearize(int H, int W, const real *tgt, const real *src, const real *d
                             real cf = ws * (cA + cB * y[q] + cC * x[q]);
                             for (int j = 0; j < np; j++) de2[j] += cf * (Q->gx[ch] * Q->a[j] + Q->gy[ch] * Q->b[j]);
                             Sx += Q->gx[ch]; Sy += Q->gy[ch];
-                            Sxx += Q->gx[ch] * Q->gx[ch]; Sxy += Q->gx[ch] * Q->gy[ch]; Syy += Q->gy[ch] * Q->gy[ch];
                         }
-                    /* GN curvature of the SSIM term: Cov/d2 + mean mean'/d1 */
+                    /* GN curvature of the SSIM term: Cov_3x3(gr)/d2 + mean mean'/d1, with the window covariance
+                     * replaced by its centre-sample estimate 9/8 (gr_p - mean)(gr_p - mean)' (PSD, one outer product) */
                     const real ninth = (real)1 / 9;
                     real mx = Sx * ninth, my = Sy * ninth;
-                    real w2 = ws * Wt / s.d2, w3 = ws * Wt / s.d1;
-                    Lam[3 * i] += w2 * (Sxx * ninth - mx * mx) + w3 * mx * mx;
-                    Lam[3 * i + 1] += w2 * (Sxy * ninth - mx * my) + w3 * mx * my;
-                    Lam[3 * i + 2] += w2 * (Syy * ninth - my * my) + w3 * my * my;
+                    real ex = P->gx[ch] - mx, ey = P->gy[ch] - my;
+                    real w2 = ws * Wt / s.d2 * (real)1.125, w3 = ws * Wt / s.d1;
+                    Lam[3 * i] += w2 * ex * ex + w3 * mx * mx;
+                    Lam[3 * i + 1] += w2 * ex * ey + w3 * mx * my;
+                    Lam[3 * i + 2] += w2 * ey * ey + w3 * my * my;
                 }
             }
             real diff = e1 + e2;

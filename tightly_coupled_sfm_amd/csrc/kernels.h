@@ -288,16 +288,40 @@ struct AccLayout {
     static constexpr int NACC = 2 * NH + 2 * NP + 3;  // + sum(M W diff), sum(M), sum(dd)
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Sum over the 64 lanes of a wave with 6 DPP-modified v_add_f32 (no LDS traffic, unlike __shfl_xor which lowers to
+// ds_bpermute).  GFX9 DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140 (after these every lane of a 16-lane row holds the row sum), row_bcast15 = 0x142 into rows 1,3,
+// row_bcast31 = 0x143 into rows 2,3.  The total ends up in lane 63.
+__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
+    // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes whose source is disabled keep `old` = 0
+    int r = 0;
+    switch (ctrl) {  // the control must be an immediate
+        case 0xB1: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false); break;
+        case 0x4E: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false); break;
+        case 0x141: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false); break;
+        case 0x140: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false); break;
+        case 0x142: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); break;
+        case 0x143: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); break;
+    }
+    (void)row_mask;
+    return v + __int_as_float(r);
+}
+
+// result valid in lane 63
+__device__ __forceinline__ float wave_sum63(float v) {
+    v = dpp_add(v, 0xB1, 0xF);
+    v = dpp_add(v, 0x4E, 0xF);
+    v = dpp_add(v, 0x141, 0xF);
+    v = dpp_add(v, 0x140, 0xF);
+    v = dpp_add(v, 0x142, 0xA);
+    v = dpp_add(v, 0x143, 0xC);
     return v;
 }
 
 enum { MODE_COST = 0, MODE_LIN = 1, MODE_MAPS = 2 };
 
 template <int NP, bool DC, int MODE, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_linearize(LinParams P) {
+__global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
     constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
     static_assert(NCEN % NT == 0, "tile must be a multiple of the workgroup");
@@ -391,44 +415,44 @@ __global__ __launch_bounds__(NT) void k_linearize(LinParams P) {
         const float yc[3] = {q0.x, q0.y, q0.z}, xc[3] = {q0.w, q1.x, q1.y};
         const float gxc[3] = {q1.z, q1.w, q2.x}, gyc[3] = {q2.y, q2.z, q2.w};
 
-        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances)
+        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances).
+        // Rolled on purpose (one neighbour live at a time): full unrolling costs >256 VGPRs and all the occupancy.
         float Sx[3] = {0, 0, 0}, Sy[3] = {0, 0, 0}, Sxx[3] = {0, 0, 0}, Syy[3] = {0, 0, 0}, Sxy[3] = {0, 0, 0};
+#pragma unroll 1
+        for (int kk = 0; kk < 9; kk++) {
+            const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
+            const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
+            float4 n0 = nb[0], n1 = nb[1];
+            const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
 #pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-            for (int dx = -1; dx <= 1; dx++) {
-                const float4 *nb = lds + ((ly + dy) * CW + lx + dx) * (LDS_REC / 4);
-                float4 n0 = nb[0], n1 = nb[1];
-                const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    float a = xq[ch] - xc[ch], b = yq[ch] - yc[ch];
-                    Sx[ch] += a; Sy[ch] += b; Sxx[ch] += a * a; Syy[ch] += b * b; Sxy[ch] += a * b;
-                }
+            for (int ch = 0; ch < 3; ch++) {
+                float a = xq[ch] - xc[ch], b = yq[ch] - yc[ch];
+                Sx[ch] += a; Sy[ch] += b; Sxx[ch] += a * a; Syy[ch] += b * b; Sxy[ch] += a * b;
             }
+        }
         const float n9 = 1.f / 9.f;
         float e1 = 0.f, e2 = 0.f;
-        float cA[3], cB[3], cC[3], mdx[3], mdy[3], id1[3], id2[3];
+        float cA[3], cB[3], cC[3], id1[3], id2[3];
         float l1x = 0.f, l1y = 0.f;          // sum_c wl sgn_c g_c   (centre part of d e1)
         float lxx = 0.f, lxy = 0.f, lyy = 0.f;  // curvature Lambda (without the W factor)
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
-            mdx[ch] = Sx[ch] * n9; mdy[ch] = Sy[ch] * n9;
-            float mux = xc[ch] + mdx[ch], muy = yc[ch] + mdy[ch];
-            float sigx = Sxx[ch] * n9 - mdx[ch] * mdx[ch], sigy = Syy[ch] * n9 - mdy[ch] * mdy[ch];
-            float sigxy = Sxy[ch] * n9 - mdx[ch] * mdy[ch];
+            float mdx = Sx[ch] * n9, mdy = Sy[ch] * n9;
+            float mux = xc[ch] + mdx, muy = yc[ch] + mdy;
+            float sigx = Sxx[ch] * n9 - mdx * mdx, sigy = Syy[ch] * n9 - mdy * mdy;
+            float sigxy = Sxy[ch] * n9 - mdx * mdy;
             float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
             float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
             float idn = 1.f / (d1 * d2), ratio = n1 * n2 * idn;
             float raw = (1.f - ratio) * 0.5f;
             bool cl = (raw < 0.f) || (raw > 1.f);
             e2 += P.ws * clamp01(raw);
-            // d s/d y_q = cA + cB (y_q - mu_y) + cC (x_q - mu_x)
+            // d s/d y_q = cB (y_q - mu_y) + cC (x_q - mu_x) + cA0  =  cA + cB (y_q - y_c) + cC (x_q - x_c)
             float pre = cl ? 0.f : -0.5f * idn * n9 * P.ws;
-            cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2);
             cB[ch] = pre * (-ratio * 2.f * d1);
             cC[ch] = pre * (2.f * n1);
-            id1[ch] = cl ? 0.f : P.ws / d1; id2[ch] = cl ? 0.f : P.ws / d2;
+            cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2) - cB[ch] * mdy - cC[ch] * mdx;
+            id1[ch] = cl ? 0.f : P.ws / d1; id2[ch] = cl ? 0.f : 1.125f * P.ws / d2;
             // L1 term, train_mono.py:87
             float rr = yc[ch] - xc[ch], ar = fabsf(rr);
             e1 += P.wl * fminf(ar, 1.f);
@@ -443,37 +467,37 @@ __global__ __launch_bounds__(NT) void k_linearize(LinParams P) {
 #pragma unroll
         for (int j = 0; j < NP; j++) de[j] = 0.f;
         if (MODE == MODE_LIN) {
-            // pass B: exact SSIM gradient rows (neighbour geometry included) + gradient moments for the curvature
-            float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0}, Gxx[3] = {0, 0, 0}, Gxy[3] = {0, 0, 0}, Gyy[3] = {0, 0, 0};
+            // pass B: exact SSIM gradient rows (neighbour geometry included) + window means of the image gradient
+            float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0};
+#pragma unroll 1
+            for (int kk = 0; kk < 9; kk++) {
+                const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
+                const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
+                float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3], n4 = nb[4], n5 = nb[5];
+                const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
+                const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
+                float aq[NP], bq[NP];
+                aq[0] = n3.x; aq[1] = n3.y; aq[2] = n3.z; aq[3] = n3.w; aq[4] = n4.x; aq[5] = n4.y;
+                bq[0] = n4.z; bq[1] = n4.w; bq[2] = n5.x; bq[3] = n5.y; bq[4] = n5.z; bq[5] = n5.w;
+                if (NP == 7) { float4 n6 = nb[6]; aq[NP - 1] = n6.x; bq[NP - 1] = n6.y; }
+                float sx = 0.f, sy = 0.f;
 #pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    const float4 *nb = lds + ((ly + dy) * CW + lx + dx) * (LDS_REC / 4);
-                    float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3], n4 = nb[4], n5 = nb[5];
-                    const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
-                    const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
-                    float aq[NP], bq[NP];
-                    aq[0] = n3.x; aq[1] = n3.y; aq[2] = n3.z; aq[3] = n3.w; aq[4] = n4.x; aq[5] = n4.y;
-                    bq[0] = n4.z; bq[1] = n4.w; bq[2] = n5.x; bq[3] = n5.y; bq[4] = n5.z; bq[5] = n5.w;
-                    if (NP == 7) { float4 n6 = nb[6]; aq[NP - 1] = n6.x; bq[NP - 1] = n6.y; }
-                    float sx = 0.f, sy = 0.f;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        float cf = cA[ch] + cB[ch] * ((yq[ch] - yc[ch]) - mdy[ch]) + cC[ch] * ((xq[ch] - xc[ch]) - mdx[ch]);
-                        sx += cf * gxq[ch]; sy += cf * gyq[ch];
-                        Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
-                        Gxx[ch] += gxq[ch] * gxq[ch]; Gxy[ch] += gxq[ch] * gyq[ch]; Gyy[ch] += gyq[ch] * gyq[ch];
-                    }
-#pragma unroll
-                    for (int j = 0; j < NP; j++) de[j] += sx * aq[j] + sy * bq[j];
+                for (int ch = 0; ch < 3; ch++) {
+                    float cf = cA[ch] + cB[ch] * (yq[ch] - yc[ch]) + cC[ch] * (xq[ch] - xc[ch]);
+                    sx += cf * gxq[ch]; sy += cf * gyq[ch];
+                    Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
                 }
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {  // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1
+                for (int j = 0; j < NP; j++) de[j] += sx * aq[j] + sy * bq[j];
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1, Cov ~ 9/8 (g - mean)(g - mean)' (centre sample)
                 float mx = Gx[ch] * n9, my = Gy[ch] * n9;
-                lxx += id2[ch] * (Gxx[ch] * n9 - mx * mx) + id1[ch] * mx * mx;
-                lxy += id2[ch] * (Gxy[ch] * n9 - mx * my) + id1[ch] * mx * my;
-                lyy += id2[ch] * (Gyy[ch] * n9 - my * my) + id1[ch] * my * my;
+                float ex = gxc[ch] - mx, ey = gyc[ch] - my;
+                lxx += id2[ch] * ex * ex + id1[ch] * mx * mx;
+                lxy += id2[ch] * ex * ey + id1[ch] * mx * my;
+                lyy += id2[ch] * ey * ey + id1[ch] * my * my;
             }
         }
 
@@ -547,7 +571,7 @@ __global__ __launch_bounds__(NT) void k_linearize(LinParams P) {
     // ---------------- workgroup reduction -> one partial record ----------------
     const int wave = tid >> 6, lane = tid & 63;
     float *wr = red + wave * L::NACC;
-#define TC_RED(v, slot) { float s_ = wave_sum(v); if (lane == 0) wr[slot] = s_; }
+#define TC_RED(v, slot) { float s_ = wave_sum63(v); if (lane == 63) wr[slot] = s_; }
     if (MODE == MODE_LIN) {
 #pragma unroll
         for (int i = 0; i < L::NH; i++) TC_RED(aHP[i], L::OFF_HP + i)
@@ -636,41 +660,50 @@ struct SolveParams {
     double lambda_up, lambda_down, lambda_min;
     double prior_scale;     // weight of (log_scale - s0)^2 (np == 7)
     int shared_image;
+    float *pose_out, *log_scale_out;  // written by the last launch of a refine call (null otherwise)
 };
 
 template <int NP>
-__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
+__global__ __launch_bounds__(512) void k_solve(SolveParams P) {
     using L = AccLayout<NP>;
-    __shared__ double sacc[8 * L::NACC];
+    constexpr int NG = 512 / L::NACC;  // groups of workgroup-partials summed in parallel
+    __shared__ double sacc[NG * L::NACC];
+    __shared__ double tot[L::NACC];
+    __shared__ double ws[3 * NP * NP];
     const int n = blockIdx.x, tid = threadIdx.x;
-    constexpr int NG = 256 / L::NACC >= 8 ? 8 : 256 / L::NACC;  // block-groups summed in parallel
     const int a = tid % L::NACC, grp = tid / L::NACC;
-    if (grp < NG) {
-        double s = 0.0;
+    if (grp < NG) {  // deterministic: fixed assignment of partial records to groups, fixed summation order
+        double s0 = 0.0, s1 = 0.0;
         const float *p = P.partials + (size_t)n * P.nblk * L::NACC + a;
-        for (int b = grp; b < P.nblk; b += NG) s += (double)p[(size_t)b * L::NACC];
-        sacc[grp * L::NACC + a] = s;
+        int b = grp;
+        for (; b + NG < P.nblk; b += 2 * NG) { s0 += (double)p[(size_t)b * L::NACC]; s1 += (double)p[(size_t)(b + NG) * L::NACC]; }
+        if (b < P.nblk) s0 += (double)p[(size_t)b * L::NACC];
+        sacc[grp * L::NACC + a] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < L::NACC) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) s += sacc[g * L::NACC + tid];
+        tot[tid] = s;
     }
     __syncthreads();
     if (tid != 0) return;
-    double acc[L::NACC];
-    for (int i = 0; i < L::NACC; i++) {
-        double s = 0.0;
-        for (int g = 0; g < NG; g++) s += sacc[g * L::NACC + i];
-        acc[i] = s;
-    }
     PairState &S = P.st[n];
-    const double nmask = acc[L::OFF_S + 1];
+    const double nmask = tot[L::OFF_S + 1];
     const double an = nmask > 0 ? 1.0 / nmask : 0.0;
-    const double cost_photo = an * acc[L::OFF_S], cost_dc = P.b_dc * acc[L::OFF_S + 2];
+    const double cost_photo = an * tot[L::OFF_S], cost_dc = P.b_dc * tot[L::OFF_S + 2];
     double cost = cost_photo + cost_dc;
+    const double bdc = P.has_dc ? P.b_dc : 0.0;
     double Hm[NP * NP], g[NP];
     {
         int h = 0;
+#pragma unroll
         for (int j = 0; j < NP; j++) {
-            g[j] = an * acc[L::OFF_GP + j] + (P.has_dc ? P.b_dc * acc[L::OFF_GD + j] : 0.0);
+            g[j] = an * tot[L::OFF_GP + j] + bdc * tot[L::OFF_GD + j];
+#pragma unroll
             for (int i = 0; i <= j; i++) {
-                double v = an * acc[L::OFF_HP + h] + (P.has_dc ? P.b_dc * acc[L::OFF_HD + h] : 0.0);
+                double v = an * tot[L::OFF_HP + h] + bdc * tot[L::OFF_HD + h];
                 Hm[j * NP + i] = v; Hm[i * NP + j] = v;
                 h++;
             }
@@ -684,7 +717,9 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     }
     if (P.mode == 2) {  // export for tcsfm_linearize / tcsfm_loss_surface
         double *o = P.lin_out + (size_t)n * (NP * NP + NP + 4);
+#pragma unroll
         for (int i = 0; i < NP * NP; i++) o[i] = Hm[i];
+#pragma unroll
         for (int i = 0; i < NP; i++) o[NP * NP + i] = g[i];
         o[NP * NP + NP] = cost; o[NP * NP + NP + 1] = cost_photo; o[NP * NP + NP + 2] = cost_dc; o[NP * NP + NP + 3] = nmask;
         return;
@@ -693,28 +728,50 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * 4;
         st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)S.lambda;
     }
+    bool final_pose = false;
     if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
         if (cost < S.cost_cur) {
+#pragma unroll
             for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
             S.scur = S.stry;
         }
-        return;
-    }
-    if (P.solver == 0 || !S.have_cur || cost < S.cost_cur) {  // accept the trial point
-        if (P.solver == 1 && S.have_cur) S.lambda = fmax(S.lambda * P.lambda_down, P.lambda_min);
-        for (int i = 0; i < NP * NP; i++) S.Hcur[i] = Hm[i];
-        for (int i = 0; i < NP; i++) S.gcur[i] = g[i];
-        for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
-        S.scur = S.stry; S.cost_cur = cost; S.have_cur = 1;
+        final_pose = true;
     } else {
-        S.lambda *= P.lambda_up;
+        double Tc[12], Tt[12], sc, stry;
+        if (P.solver == 0 || !S.have_cur || cost < S.cost_cur) {  // accept the trial point
+            if (P.solver == 1 && S.have_cur) S.lambda = fmax(S.lambda * P.lambda_down, P.lambda_min);
+#pragma unroll
+            for (int i = 0; i < NP * NP; i++) S.Hcur[i] = Hm[i];
+#pragma unroll
+            for (int i = 0; i < NP; i++) S.gcur[i] = g[i];
+#pragma unroll
+            for (int i = 0; i < 12; i++) { Tc[i] = S.Ttry[i]; S.Tcur[i] = Tc[i]; }
+            sc = S.stry; S.scur = sc; S.cost_cur = cost; S.have_cur = 1;
+        } else {
+            S.lambda *= P.lambda_up;
+#pragma unroll
+            for (int i = 0; i < 12; i++) Tc[i] = S.Tcur[i];
+            sc = S.scur;
+        }
+        apply_step<NP>(P.param, S.Hcur, S.gcur, S.lambda, Tc, sc, Tt, &stry, ws);
+#pragma unroll
+        for (int i = 0; i < 12; i++) S.Ttry[i] = Tt[i];
+        S.stry = stry;
+        if (P.solver == 0 && P.it == P.n_iters - 1) {  // GN: the last step is always taken
+#pragma unroll
+            for (int i = 0; i < 12; i++) S.Tcur[i] = Tt[i];
+            S.scur = stry;
+            final_pose = true;
+        }
+        write_const(S, Tt, stry, P.shared_image ? 0 : n, P.pc[n]);
     }
-    apply_step(NP, P.param, S.Hcur, S.gcur, S.lambda, S.Tcur, S.scur, S.Ttry, &S.stry);
-    if (P.solver == 0 && P.it == P.n_iters - 1) {  // GN: the last step is always taken
-        for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
-        S.scur = S.stry;
+    if (final_pose && P.pose_out) {  // last launch of a refine call: emit the reference 6-vector
+        double pose[6];
+        T_to_pose(S.Tcur, pose);
+#pragma unroll
+        for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = (float)pose[i];
+        if (P.log_scale_out) P.log_scale_out[n] = (float)S.scur;
     }
-    write_const(S, S.Ttry, S.stry, P.shared_image ? 0 : n, P.pc[n]);
 }
 
 struct FinishParams {

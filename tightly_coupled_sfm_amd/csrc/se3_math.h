@@ -19,7 +19,9 @@
 namespace tc {
 
 TC_HD void mat3_mul(const double *A, const double *B, double *C) {
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
@@ -128,85 +130,115 @@ TC_HD void euler_left_jacobian(const double *pose, double *A) {
     }
 }
 
-// Cholesky solve of the n x n SPD system (row-major, overwritten); returns false when not SPD
-TC_HD bool chol_solve(int n, double *A, double *b) {
-    for (int j = 0; j < n; j++) {
-        double d = A[j * n + j];
-        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+// Cholesky solve of the N x N SPD system (row-major, overwritten); returns false when not SPD.
+// N is a template parameter and every loop is unrolled so that, on the device, all arrays live in registers
+// (runtime-indexed local arrays go to scratch memory: the first version of k_solve spent ~50 us there).
+template <int N>
+TC_HD bool chol_solve(double *A, double *b) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = A[j * N + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j * N + k] * A[j * N + k];
         if (!(d > 0)) return false;
         d = sqrt(d);
-        A[j * n + j] = d;
-        for (int i = j + 1; i < n; i++) {
-            double s = A[i * n + j];
-            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
-            A[i * n + j] = s / d;
+        A[j * N + j] = d;
+        const double id = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double s = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i * N + k] * A[j * N + k];
+            A[i * N + j] = s * id;
         }
     }
-    for (int i = 0; i < n; i++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
         double s = b[i];
-        for (int k = 0; k < i; k++) s -= A[i * n + k] * b[k];
-        b[i] = s / A[i * n + i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= A[i * N + k] * b[k];
+        b[i] = s / A[i * N + i];
     }
-    for (int i = n - 1; i >= 0; i--) {
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
         double s = b[i];
-        for (int k = i + 1; k < n; k++) s -= A[k * n + i] * b[k];
-        b[i] = s / A[i * n + i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) s -= A[k * N + i] * b[k];
+        b[i] = s / A[i * N + i];
     }
     return true;
 }
 
 // (H + lambda diag(H) + 1e-12 I) d = -g
-TC_HD void damped_step(int n, const double *H, const double *g, double lambda, double *delta) {
-    double A[TC_MAXP * TC_MAXP], b[TC_MAXP];
-    for (int i = 0; i < n; i++) {
-        for (int j = 0; j < n; j++) A[i * n + j] = H[i * n + j];
-        A[i * n + i] += lambda * H[i * n + i] + 1e-12;
+template <int N>
+TC_HD void damped_step(const double *H, const double *g, double lambda, double *delta) {
+    double A[N * N], b[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < N; j++) A[i * N + j] = H[i * N + j];
+        A[i * N + i] += lambda * H[i * N + i] + 1e-12;
         b[i] = -g[i];
     }
-    if (!chol_solve(n, A, b))
-        for (int i = 0; i < n; i++) b[i] = 0;
-    for (int i = 0; i < n; i++) delta[i] = b[i];
+    const bool ok = chol_solve<N>(A, b);
+#pragma unroll
+    for (int i = 0; i < N; i++) delta[i] = ok ? b[i] : 0.0;
 }
 
 // One update of (T, log_scale) from the normal equations under the chosen parameterisation
 // param 0: T <- exp(delta) T ; param 1: additive on the reference [t, euler] vector (H_p = A'HA, g_p = A'g)
-TC_HD void apply_step(int n, int param, const double *H, const double *g, double lambda, const double *Tin, double sin_,
-                      double *Tout, double *sout) {
-    double delta[TC_MAXP];
+// ws: caller-provided workspace of 3 N N doubles for the additive-Euler branch (LDS on the device, so that the
+// common SE(3) branch keeps everything in registers)
+template <int N>
+TC_HD void apply_step(int param, const double *H, const double *g, double lambda, const double *Tin, double sin_,
+                      double *Tout, double *sout, double *ws) {
+    double delta[N];
     if (param == 0) {
-        damped_step(n, H, g, lambda, delta);
+        damped_step<N>(H, g, lambda, delta);
         double E[12];
         se3_exp(delta, E);
         se3_mul(E, Tin, Tout);
     } else {
-        double pose[6], A6[36], Af[TC_MAXP * TC_MAXP], Hp[TC_MAXP * TC_MAXP], gp[TC_MAXP], HA[TC_MAXP * TC_MAXP];
+        double pose[6], A6[36], gp[N];
+        double *Af = ws, *Hp = ws + N * N, *HA = ws + 2 * N * N;
         T_to_pose(Tin, pose);
         euler_left_jacobian(pose, A6);
-        for (int i = 0; i < n * n; i++) Af[i] = 0;
+#pragma unroll
+        for (int i = 0; i < N * N; i++) Af[i] = 0;
+#pragma unroll
         for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 6; j++) Af[i * n + j] = A6[6 * i + j];
-        if (n == 7) Af[6 * n + 6] = 1;
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) Af[i * N + j] = A6[6 * i + j];
+        if (N == 7) Af[6 * N + 6] = 1;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = 0; j < N; j++) {
                 double s = 0;
-                for (int k = 0; k < n; k++) s += H[i * n + k] * Af[k * n + j];
-                HA[i * n + j] = s;
+#pragma unroll
+                for (int k = 0; k < N; k++) s += H[i * N + k] * Af[k * N + j];
+                HA[i * N + j] = s;
             }
-        for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
             double s = 0;
-            for (int k = 0; k < n; k++) s += Af[k * n + i] * g[k];
+#pragma unroll
+            for (int k = 0; k < N; k++) s += Af[k * N + i] * g[k];
             gp[i] = s;
-            for (int j = 0; j < n; j++) {
+#pragma unroll
+            for (int j = 0; j < N; j++) {
                 double h = 0;
-                for (int k = 0; k < n; k++) h += Af[k * n + i] * HA[k * n + j];
-                Hp[i * n + j] = h;
+#pragma unroll
+                for (int k = 0; k < N; k++) h += Af[k * N + i] * HA[k * N + j];
+                Hp[i * N + j] = h;
             }
         }
-        damped_step(n, Hp, gp, lambda, delta);
+        damped_step<N>(Hp, gp, lambda, delta);
+#pragma unroll
         for (int i = 0; i < 6; i++) pose[i] += delta[i];
         pose_to_T(pose, Tout);
     }
-    *sout = sin_ + (n == 7 ? delta[6] : 0.0);
+    *sout = sin_ + (N == 7 ? delta[N - 1] : 0.0);
 }
 
 }  // namespace tc

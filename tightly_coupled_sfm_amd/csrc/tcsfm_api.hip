@@ -178,8 +178,8 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mo
 
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
-    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
-    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
+    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(512), 0, h->stream, S);
+    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(512), 0, h->stream, S);
 }
 
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
@@ -509,21 +509,27 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
     const bool dc = o->w_dc > 0.f;
+    const bool lm = o->solver == TCSFM_SOLVER_LM;
     for (int it = 0; it < o->n_iters; it++) {
         launch_lin(h, P, N, np, dc, MODE_LIN);
         S.it = it; S.mode = 0;
+        const bool last = !lm && it == o->n_iters - 1;   // the last solve also emits the refined pose
+        S.pose_out = last ? d_pose_out : nullptr; S.log_scale_out = last ? d_ls_out : nullptr;
         launch_solve(h, S, N, np);
     }
-    if (o->solver == TCSFM_SOLVER_LM && o->n_iters > 0) {  // cost-only pass deciding whether the last step is kept
+    if (lm && o->n_iters > 0) {  // cost-only pass deciding whether the last step is kept
         launch_lin(h, P, N, np, dc, MODE_COST);
         S.it = o->n_iters; S.mode = 1;
+        S.pose_out = d_pose_out; S.log_scale_out = d_ls_out;
         launch_solve(h, S, N, np);
     }
     HIPCHK(h, hipGetLastError());
-    FinishParams F;
-    F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = d_ls_out; F.N = N;
-    hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
-    HIPCHK(h, hipGetLastError());
+    if (o->n_iters == 0) {  // nothing to solve: round-trip the pose through SE(3)
+        FinishParams F;
+        F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = d_ls_out; F.N = N;
+        hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
+        HIPCHK(h, hipGetLastError());
+    }
     if ((rc = copy_back(h, o, pose_io, d_pose_out, (size_t)N * 6))) return rc;
     if (d_ls_out && (rc = copy_back(h, o, log_scale_io, d_ls_out, (size_t)N))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
