@@ -37,7 +37,7 @@ struct PairState {
     double Tcur[12], Ttry[12];
     double scur, stry, s0;   // log depth-scale: accepted, trial, initial (prior centre)
     double lambda, cost_cur;
-    double Hcur[TC_MAXP * TC_MAXP], gcur[TC_MAXP];
+    double M8[64];             // accepted linearisation as the augmented 8x8 system [H | -g] (undamped), one entry per lane
     double K[9];
     int have_cur, pad;
 };
@@ -619,7 +619,7 @@ __device__ inline void write_const(const PairState &S, const double *T, double s
     }
     c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
     c.ki0 = (float)(1.0 / fx); c.ki2 = (float)(-cx / fx); c.ki4 = (float)(1.0 / fy); c.ki5 = (float)(-cy / fy);
-    c.es = (float)exp(s);
+    c.es = (s == 0.0) ? 1.f : (float)exp(s);
     c.img = img;
 }
 
@@ -663,16 +663,34 @@ struct SolveParams {
     float *pose_out, *log_scale_out;  // written by the last launch of a refine call (null otherwise)
 };
 
+// fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
+// inverse-trig keeps ~1e-7 relative accuracy and stays off the fp64 serial path
+__device__ inline void T_to_pose_f32(const double *T, float *pose) {
+    float sb = fminf(fmaxf((float)T[2], -1.f), 1.f);
+    pose[0] = (float)-T[3]; pose[1] = (float)-T[7]; pose[2] = (float)-T[11];
+    pose[3] = -atan2f((float)-T[6], (float)T[10]);
+    pose[4] = -asinf(sb);
+    pose[5] = -atan2f((float)-T[1], (float)T[0]);
+}
+
+// One workgroup per pair.
+//   1. all 256 threads: deterministic fp64 reduction of the workgroup partial records -> tot[] (LDS)
+//   2. wave 0, one lane per entry of the augmented 8x8 system [H | -g]: assembly, LM accept/reject bookkeeping,
+//      Marquardt damping and an unpivoted Gauss-Jordan elimination (SPD system) with 3 cross-lane reads per pivot
+//   3. lane 0: SE(3) retraction (series exp, no trig), next iteration's fp32 constants, pose output
+// The per-pair logic mirrors orc_refine() of the CPU oracle (which factorises with Cholesky instead).
 template <int NP>
-__global__ __launch_bounds__(512) void k_solve(SolveParams P) {
+__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     using L = AccLayout<NP>;
-    constexpr int NG = 512 / L::NACC;  // groups of workgroup-partials summed in parallel
+    constexpr int NG = 256 / L::NACC;
     __shared__ double sacc[NG * L::NACC];
     __shared__ double tot[L::NACC];
     __shared__ double ws[3 * NP * NP];
+    __shared__ double dl[8];
+    __shared__ double m8[64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int a = tid % L::NACC, grp = tid / L::NACC;
-    if (grp < NG) {  // deterministic: fixed assignment of partial records to groups, fixed summation order
+    if (grp < NG) {  // fixed assignment of partial records to groups, fixed summation order
         double s0 = 0.0, s1 = 0.0;
         const float *p = P.partials + (size_t)n * P.nblk * L::NACC + a;
         int b = grp;
@@ -688,88 +706,116 @@ __global__ __launch_bounds__(512) void k_solve(SolveParams P) {
         tot[tid] = s;
     }
     __syncthreads();
-    if (tid != 0) return;
+    if (tid >= 64) return;  // wave 0 only from here: no workgroup barriers below
+
     PairState &S = P.st[n];
+    const int r = tid >> 3, c = tid & 7;
     const double nmask = tot[L::OFF_S + 1];
     const double an = nmask > 0 ? 1.0 / nmask : 0.0;
     const double cost_photo = an * tot[L::OFF_S], cost_dc = P.b_dc * tot[L::OFF_S + 2];
     double cost = cost_photo + cost_dc;
     const double bdc = P.has_dc ? P.b_dc : 0.0;
-    double Hm[NP * NP], g[NP];
-    {
-        int h = 0;
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            g[j] = an * tot[L::OFF_GP + j] + bdc * tot[L::OFF_GD + j];
-#pragma unroll
-            for (int i = 0; i <= j; i++) {
-                double v = an * tot[L::OFF_HP + h] + bdc * tot[L::OFF_HD + h];
-                Hm[j * NP + i] = v; Hm[i * NP + j] = v;
-                h++;
-            }
-        }
+    // this lane's entry of [H | -g]
+    double M = 0.0;
+    if (r < NP && c < NP) {
+        const int hi = r > c ? r : c, lo = r > c ? c : r, h = hi * (hi + 1) / 2 + lo;
+        M = an * tot[L::OFF_HP + h] + bdc * tot[L::OFF_HD + h];
+    } else if (r < NP && c == 7) {
+        M = -(an * tot[L::OFF_GP + r] + bdc * tot[L::OFF_GD + r]);
     }
     if (NP == 7 && P.mode != 2) {  // scale prior (not part of the exported raw normal equations)
         const double ds = S.stry - S.s0;
         cost += P.prior_scale * ds * ds;
-        g[NP - 1] += 2.0 * P.prior_scale * ds;
-        Hm[(NP - 1) * NP + (NP - 1)] += 2.0 * P.prior_scale;
+        if (r == 6 && c == 6) M += 2.0 * P.prior_scale;
+        if (r == 6 && c == 7) M -= 2.0 * P.prior_scale * ds;
     }
     if (P.mode == 2) {  // export for tcsfm_linearize / tcsfm_loss_surface
         double *o = P.lin_out + (size_t)n * (NP * NP + NP + 4);
-#pragma unroll
-        for (int i = 0; i < NP * NP; i++) o[i] = Hm[i];
-#pragma unroll
-        for (int i = 0; i < NP; i++) o[NP * NP + i] = g[i];
-        o[NP * NP + NP] = cost; o[NP * NP + NP + 1] = cost_photo; o[NP * NP + NP + 2] = cost_dc; o[NP * NP + NP + 3] = nmask;
+        if (r < NP && c < NP) o[r * NP + c] = M;
+        if (r < NP && c == 7) o[NP * NP + r] = -M;
+        if (tid == 0) { o[NP * NP + NP] = cost; o[NP * NP + NP + 1] = cost_photo; o[NP * NP + NP + 2] = cost_dc; o[NP * NP + NP + 3] = nmask; }
         return;
     }
-    if (P.stats) {
+    double lambda = S.lambda;
+    if (P.stats && tid == 0) {
         float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * 4;
-        st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)S.lambda;
+        st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)lambda;
     }
     bool final_pose = false;
     if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
-        if (cost < S.cost_cur) {
-#pragma unroll
+        if (tid == 0 && cost < S.cost_cur) {
             for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
             S.scur = S.stry;
         }
         final_pose = true;
     } else {
-        double Tc[12], Tt[12], sc, stry;
-        if (P.solver == 0 || !S.have_cur || cost < S.cost_cur) {  // accept the trial point
-            if (P.solver == 1 && S.have_cur) S.lambda = fmax(S.lambda * P.lambda_down, P.lambda_min);
-#pragma unroll
-            for (int i = 0; i < NP * NP; i++) S.Hcur[i] = Hm[i];
-#pragma unroll
-            for (int i = 0; i < NP; i++) S.gcur[i] = g[i];
-#pragma unroll
-            for (int i = 0; i < 12; i++) { Tc[i] = S.Ttry[i]; S.Tcur[i] = Tc[i]; }
-            sc = S.stry; S.scur = sc; S.cost_cur = cost; S.have_cur = 1;
+        const bool accept = (P.solver == 0) || !S.have_cur || (cost < S.cost_cur);  // wave-uniform
+        if (accept) {
+            if (P.solver == 1 && S.have_cur) lambda = fmax(lambda * P.lambda_down, P.lambda_min);
+            S.M8[tid] = M;
         } else {
-            S.lambda *= P.lambda_up;
-#pragma unroll
-            for (int i = 0; i < 12; i++) Tc[i] = S.Tcur[i];
-            sc = S.scur;
+            lambda *= P.lambda_up;
+            M = S.M8[tid];
         }
-        apply_step<NP>(P.param, S.Hcur, S.gcur, S.lambda, Tc, sc, Tt, &stry, ws);
+        m8[tid] = M;  // undamped system, for the additive-Euler branch below
+        // Marquardt damping, then Gauss-Jordan on [H + lambda diag(H) + 1e-12 I | -g]
+        if (r == c && r < NP) M += lambda * M + 1e-12;
+        bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 12; i++) S.Ttry[i] = Tt[i];
-        S.stry = stry;
-        if (P.solver == 0 && P.it == P.n_iters - 1) {  // GN: the last step is always taken
-#pragma unroll
-            for (int i = 0; i < 12; i++) S.Tcur[i] = Tt[i];
-            S.scur = stry;
-            final_pose = true;
+        for (int k = 0; k < NP; k++) {
+            const double piv = __shfl(M, k * 8 + k, 64);
+            const double rowv = __shfl(M, k * 8 + c, 64);
+            const double colv = __shfl(M, r * 8 + k, 64);
+            ok = ok && (piv > 0.0);
+            const double f = colv / piv;
+            if (r != k) M -= f * rowv;
         }
-        write_const(S, Tt, stry, P.shared_image ? 0 : n, P.pc[n]);
+        const double diag = __shfl(M, r * 8 + r, 64);
+        if (c == 7 && r < NP) dl[r] = ok ? M / diag : 0.0;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): dl[] written before lane 0 reads it (single wave)
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+            double Tc[12], Tt[12], delta[NP], sc, stry;
+            if (accept) {
+                for (int i = 0; i < 12; i++) { Tc[i] = S.Ttry[i]; S.Tcur[i] = Tc[i]; }
+                sc = S.stry; S.scur = sc; S.cost_cur = cost; S.have_cur = 1;
+            } else {
+                for (int i = 0; i < 12; i++) Tc[i] = S.Tcur[i];
+                sc = S.scur;
+            }
+            S.lambda = lambda;
+#pragma unroll
+            for (int i = 0; i < NP; i++) delta[i] = dl[i];
+            if (P.param == 0) {
+                retract_se3(delta, Tc, Tt);
+                stry = sc + (NP == 7 ? delta[NP - 1] : 0.0);
+            } else {
+                // additive Euler parameterisation: re-solve in pose coordinates from the stored undamped system (rare path,
+                // serial; the lane-parallel solution above is for the SE(3) chart)
+                double Hs[NP * NP], gs[NP];
+                for (int i = 0; i < NP; i++) {
+                    gs[i] = -m8[i * 8 + 7];
+                    for (int j = 0; j < NP; j++) Hs[i * NP + j] = m8[i * 8 + j];
+                }
+                apply_step<NP>(1, Hs, gs, lambda, Tc, sc, Tt, &stry, ws);
+            }
+#pragma unroll
+            for (int i = 0; i < 12; i++) S.Ttry[i] = Tt[i];
+            S.stry = stry;
+            if (P.solver == 0 && P.it == P.n_iters - 1) {  // GN: the last step is always taken
+#pragma unroll
+                for (int i = 0; i < 12; i++) S.Tcur[i] = Tt[i];
+                S.scur = stry;
+            }
+            write_const(S, Tt, stry, P.shared_image ? 0 : n, P.pc[n]);
+        }
+        final_pose = (P.solver == 0 && P.it == P.n_iters - 1);
     }
-    if (final_pose && P.pose_out) {  // last launch of a refine call: emit the reference 6-vector
-        double pose[6];
-        T_to_pose(S.Tcur, pose);
+    if (final_pose && P.pose_out && tid == 0) {  // last launch of a refine call: emit the reference 6-vector
+        float pose[6];
+        T_to_pose_f32(S.Tcur, pose);
 #pragma unroll
-        for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = (float)pose[i];
+        for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
         if (P.log_scale_out) P.log_scale_out[n] = (float)S.scur;
     }
 }

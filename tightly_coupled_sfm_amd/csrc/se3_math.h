@@ -59,10 +59,15 @@ TC_HD void T_to_pose(const double *T, double *pose) {
 // exp: T = [exp(phi^) | J_l(phi) rho]
 TC_HD void se3_exp(const double *xi, double *T) {
     const double *rho = xi, *phi = xi + 3;
-    double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2], t = sqrt(t2), A, B, C;
-    if (t < 1e-4) {
-        A = 1 - t2 / 6 + t2 * t2 / 120; B = 0.5 - t2 / 24 + t2 * t2 / 720; C = 1.0 / 6 - t2 / 120 + t2 * t2 / 5040;
+    double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2], A, B, C;
+    if (t2 < 0.09) {
+        // |phi| < 0.3 rad (every Gauss-Newton step): Taylor series through t^10, truncation < 1e-16.  No libm trig on the
+        // device's serial critical path.
+        A = 1 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 - t2 * (1.0 / 39916800)))));
+        B = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 - t2 * (1.0 / 479001600)))));
+        C = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 - t2 * (1.0 / 6227020800.0)))));
     } else {
+        double t = sqrt(t2);
         A = sin(t) / t; B = (1 - cos(t)) / t2; C = (t - sin(t)) / (t2 * t);
     }
     double K[9], K2[9];
@@ -187,6 +192,13 @@ TC_HD void damped_step(const double *H, const double *g, double lambda, double *
 
 // One update of (T, log_scale) from the normal equations under the chosen parameterisation
 // param 0: T <- exp(delta) T ; param 1: additive on the reference [t, euler] vector (H_p = A'HA, g_p = A'g)
+// T <- exp(delta) T for an already solved step (the device solves the system lane-parallel)
+TC_HD void retract_se3(const double *delta, const double *Tin, double *Tout) {
+    double E[12];
+    se3_exp(delta, E);
+    se3_mul(E, Tin, Tout);
+}
+
 // ws: caller-provided workspace of 3 N N doubles for the additive-Euler branch (LDS on the device, so that the
 // common SE(3) branch keeps everything in registers)
 template <int N>

@@ -178,8 +178,8 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mo
 
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
-    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(512), 0, h->stream, S);
-    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(512), 0, h->stream, S);
+    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
+    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
 }
 
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
