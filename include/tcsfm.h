@@ -135,6 +135,9 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
  * counts per class: index 0 = k_linearize (the hot kernel), 1 = k_solve, 2 = k_pack. */
 int tcsfm_profile_begin(tcsfm_handle h);
 int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]);
+/* Diagnostic builds: 100 MHz wall-clock stamps of the phases of the last k_solve launch of pair 0 (zeros unless the
+ * handle was created with TCSFM_DEBUG_STAMPS set in the environment). */
+int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]);
 
 /* ---- SE(3) utilities, host, double (replace liegroups.SE3 at data/kitti_loader_stereo.py:129-147,
  *      validate.py:65-71; liegroups is an absent third-party dependency, version unpinned) ---------- */

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),
     "tcsfm_profile_begin": (C.c_int, [_P]),
     "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
+    "tcsfm_debug_stamps": (C.c_int, [_P, _P]),
     "tcsfm_pose_to_matrix": (None, [_P, _P]),
     "tcsfm_matrix_to_pose": (None, [_P, _P]),
     "tcsfm_se3_exp": (None, [_P, _P]),

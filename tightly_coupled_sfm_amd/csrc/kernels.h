@@ -47,10 +47,13 @@ struct LinParams {
     const float4 *srcpack;  // [Nimg][H][W]  rgb + depth_s
     const float *depth_t;   // [Nimg][H][W]
     const PairConst *pc;    // [N]
-    float *partials;        // [N][nblk][nacc]
+    float *blockrec;        // [N][nblk][nacc]   one partial-sum record per workgroup (write-through stores)
+    int *tickets;           // [N][ngrp]         arrival counters of the 16-workgroup reduction groups (zero between launches)
+    float *partials;        // [N][nacc][ngrp_pad] group records, accumulator-major: the solve kernel reads 64 per coalesced load
     // maps mode outputs (may be null)
     float *o_diff, *o_valid, *o_weight, *o_auto_err, *o_auto_mask, *o_rec;
     int H, W, tiles_x, tiles_y, nacc;
+    int ngrp, ngrp_pad;     // reduction groups per pair, and that rounded up to a multiple of 64
     float wl, ws;           // w_l1/3, w_ssim/3
     float eps;              // irls_eps
     int automask;
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256) void k_warp(WarpParams P) {
 // neighbourhood and accumulates J'J and J'r in registers; one wave-reduce + LDS reduce per workgroup, one
 // partial-sum record per workgroup to HBM (deterministic: no atomics).
 
+constexpr int RG = 16;       // workgroups per in-launch reduction group
 constexpr int LDS_REC = 28;  // floats per staged pixel (12 + 2*NP <= 26, padded to 28 for bank spread)
 
 template <int NP>
@@ -587,14 +591,45 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     TC_RED(sMWd, L::OFF_S) TC_RED(sM, L::OFF_S + 1) TC_RED(sdd, L::OFF_S + 2)
 #undef TC_RED
     __syncthreads();
-    float *out = P.partials + ((size_t)n * nblk + bid) * L::NACC;
+    // ---- in-launch, deterministic two-level reduction -----------------------------------------------------------
+    // A single workgroup can only pull ~6 GB/s of freshly written records (measured: 110 KB = 480 records in 19 us), so the
+    // solve kernel must not read one record per workgroup.  Groups of RG consecutive workgroups reduce themselves: every
+    // workgroup publishes its record, takes a ticket, and the LAST arriver of the group sums the group's records in index
+    // order (fixed order => bit-reproducible, no float atomics) into one group record.
+    // Protocol (cdna_hip_programming.md Guideline 16, counter form): write-through (sc1) record stores -> every storing
+    // wave drains vmcnt -> workgroup barrier -> one relaxed agent-scope ticket; reducer: agent-scope acquire -> drain ->
+    // barrier -> plain loads.  The reducer zeroes the ticket for the next launch (tickets are also zeroed at create
+    // and at the start of every refine call).
+    float *myrec = P.blockrec + ((size_t)n * nblk + bid) * L::NACC;
     for (int i = tid; i < L::NACC; i += NT) {
         bool live = (i >= L::OFF_S) || (MODE == MODE_LIN && (DC || i < L::OFF_HD));
         float s = 0.f;
         if (live)
             for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + i];
-        out[i] = s;
+        __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    const int grp = bid / RG, gfirst = grp * RG, gcount = min(RG, nblk - gfirst);
+    if (tid == 0) {
+        int t = __hip_atomic_fetch_add(&P.tickets[n * P.ngrp + grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gcount - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const float *grec = P.blockrec + ((size_t)n * nblk + gfirst) * L::NACC;
+    for (int i = tid; i < L::NACC; i += NT) {
+        float s = 0.f;
+        for (int b = 0; b < gcount; b++) s += grec[(size_t)b * L::NACC + i];
+        P.partials[((size_t)n * L::NACC + i) * P.ngrp_pad + grp] = s;
+    }
+    if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -649,18 +684,19 @@ __global__ void k_init(InitParams P) {
 }
 
 struct SolveParams {
-    const float *partials;  // [N][nblk][nacc]
+    const float *partials;  // [N][nacc][ngrp_pad] group records
     PairState *st;
     PairConst *pc;
     float *stats;           // [N][n_iters+1][4] or null
     double *lin_out;        // linearize debug: [N][np*np + np + 4] or null
-    int nblk, nacc, np, has_dc;
+    int ngrp_pad, nacc, np, has_dc;
     int it, n_iters, solver, param, mode;  // mode 0: iteration step, 1: final LM cost check, 2: export only
     double b_dc;            // w_dc / (H W)
     double lambda_up, lambda_down, lambda_min;
     double prior_scale;     // weight of (log_scale - s0)^2 (np == 7)
     int shared_image;
     float *pose_out, *log_scale_out;  // written by the last launch of a refine call (null otherwise)
+    long long *dbg;                   // diagnostic builds only: s_memrealtime stamps of the solve phases (null in production)
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -680,32 +716,53 @@ __device__ inline void T_to_pose_f32(const double *T, float *pose) {
 //   3. lane 0: SE(3) retraction (series exp, no trig), next iteration's fp32 constants, pose output
 // The per-pair logic mirrors orc_refine() of the CPU oracle (which factorises with Cholesky instead).
 template <int NP>
-__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
+__global__ __launch_bounds__(512) void k_solve(SolveParams P) {
     using L = AccLayout<NP>;
-    constexpr int NG = 256 / L::NACC;
-    __shared__ double sacc[NG * L::NACC];
     __shared__ double tot[L::NACC];
     __shared__ double ws[3 * NP * NP];
     __shared__ double dl[8];
     __shared__ double m8[64];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const int a = tid % L::NACC, grp = tid / L::NACC;
-    if (grp < NG) {  // fixed assignment of partial records to groups, fixed summation order
-        double s0 = 0.0, s1 = 0.0;
-        const float *p = P.partials + (size_t)n * P.nblk * L::NACC + a;
-        int b = grp;
-        for (; b + NG < P.nblk; b += 2 * NG) { s0 += (double)p[(size_t)b * L::NACC]; s1 += (double)p[(size_t)(b + NG) * L::NACC]; }
-        if (b < P.nblk) s0 += (double)p[(size_t)b * L::NACC];
-        sacc[grp * L::NACC + a] = s0 + s1;
-    }
-    __syncthreads();
-    if (tid < L::NACC) {
-        double s = 0.0;
+#define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
+    TC_STAMP(0)
+    {
+        // 8 waves; wave w owns accumulators w, w+8, ...  Every lane sums the records lane, lane+64, ... of each of its
+        // accumulators in fp64 (fixed order), then a fixed-order butterfly.  ALL loads of a 512-record chunk (up to
+        // 8 accumulators x 8 records per lane) are issued before the first add: the records were written by the previous
+        // kernel from all 8 XCDs, so each load is an L2 miss (~0.4 us) and a rolled load->add loop serialises 56 of them
+        // (measured: 20 us; this form: one round trip per chunk).
+        const int wave = tid >> 6, lane = tid & 63;
+        constexpr int NA = (L::NACC + 7) / 8, U = 8;
+        double s[NA];
 #pragma unroll
-        for (int g = 0; g < NG; g++) s += sacc[g * L::NACC + tid];
-        tot[tid] = s;
+        for (int k = 0; k < NA; k++) s[k] = 0.0;
+        for (int b0 = 0; b0 < P.ngrp_pad; b0 += 64 * U) {
+            float v[NA][U];
+#pragma unroll
+            for (int k = 0; k < NA; k++) {
+                const int a = wave + 8 * k;
+                const float *p = P.partials + ((size_t)n * L::NACC + (a < L::NACC ? a : 0)) * P.ngrp_pad + lane;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int b = b0 + 64 * j;
+                    v[k][j] = (a < L::NACC && b < P.ngrp_pad) ? p[b] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NA; k++)
+#pragma unroll
+                for (int j = 0; j < U; j++) s[k] += (double)v[k][j];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; k++) {
+            double t = s[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+            if (lane == 0 && wave + 8 * k < L::NACC) tot[wave + 8 * k] = t;
+        }
     }
     __syncthreads();
+    TC_STAMP(1)
     if (tid >= 64) return;  // wave 0 only from here: no workgroup barriers below
 
     PairState &S = P.st[n];
@@ -758,6 +815,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
             M = S.M8[tid];
         }
         m8[tid] = M;  // undamped system, for the additive-Euler branch below
+        TC_STAMP(2)
         // Marquardt damping, then Gauss-Jordan on [H + lambda diag(H) + 1e-12 I | -g]
         if (r == c && r < NP) M += lambda * M + 1e-12;
         bool ok = true;
@@ -774,6 +832,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         if (c == 7 && r < NP) dl[r] = ok ? M / diag : 0.0;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): dl[] written before lane 0 reads it (single wave)
         __builtin_amdgcn_wave_barrier();
+        TC_STAMP(3)
         if (tid == 0) {
             double Tc[12], Tt[12], delta[NP], sc, stry;
             if (accept) {
@@ -799,6 +858,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
                 }
                 apply_step<NP>(1, Hs, gs, lambda, Tc, sc, Tt, &stry, ws);
             }
+            TC_STAMP(4)
 #pragma unroll
             for (int i = 0; i < 12; i++) S.Ttry[i] = Tt[i];
             S.stry = stry;
@@ -808,6 +868,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
                 S.scur = stry;
             }
             write_const(S, Tt, stry, P.shared_image ? 0 : n, P.pc[n]);
+            TC_STAMP(5)
         }
         final_pose = (P.solver == 0 && P.it == P.n_iters - 1);
     }
@@ -818,6 +879,8 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
         if (P.log_scale_out) P.log_scale_out[n] = (float)S.scur;
     }
+    TC_STAMP(6)
+#undef TC_STAMP
 }
 
 struct FinishParams {

@@ -2,6 +2,7 @@
 // Host logic only: argument checking, scratch management, kernel sequencing on one HIP stream.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -30,12 +31,14 @@ struct tcsfm_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     float4 *tgtpack = nullptr, *srcpack = nullptr;
     float *depth_work = nullptr;
-    float *partials = nullptr;
+    float *partials = nullptr, *blockrec = nullptr;
+    int *tickets = nullptr;
     PairState *state = nullptr;
     PairConst *pconst = nullptr;
     double *lin_out = nullptr;   // device [max_pairs][7*7+7+4]
     float *pose_dev = nullptr, *ls_dev = nullptr, *K_dev = nullptr, *stats_dev = nullptr;
-    int tiles_x = 0, tiles_y = 0, nblk = 0, stats_cap_iters = 0;
+    int tiles_x = 0, tiles_y = 0, nblk = 0, ngrp = 0, ngrp_pad = 0, stats_cap_iters = 0;
+    long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
     std::vector<HostStage> stage;
     std::string err;
     // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
@@ -178,8 +181,8 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mo
 
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
-    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
-    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
+    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(512), 0, h->stream, S);
+    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(512), 0, h->stream, S);
 }
 
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
@@ -204,6 +207,8 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
 }
 
 int run_init(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const float *ls, const float *K, int shared) {
+    // group tickets must be zero when k_linearize starts; the reducers re-zero them, this covers an aborted earlier call
+    HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
     InitParams I;
     I.pose = pose; I.log_scale = ls; I.K = K; I.st = h->state; I.pc = h->pconst; I.N = N; I.shared_image = shared;
     I.lambda0 = o->lambda0;
@@ -215,8 +220,8 @@ int run_init(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const 
 LinParams lin_params(tcsfm_ctx *h, const tcsfm_opts *o, int np) {
     LinParams P;
     memset(&P, 0, sizeof(P));
-    P.tgtpack = h->tgtpack; P.srcpack = h->srcpack; P.depth_t = h->depth_work; P.pc = h->pconst; P.partials = h->partials;
-    P.H = h->H; P.W = h->W; P.tiles_x = h->tiles_x; P.tiles_y = h->tiles_y; P.nacc = nacc_of(np);
+    P.tgtpack = h->tgtpack; P.srcpack = h->srcpack; P.depth_t = h->depth_work; P.pc = h->pconst; P.partials = h->partials; P.blockrec = h->blockrec; P.tickets = h->tickets;
+    P.H = h->H; P.W = h->W; P.tiles_x = h->tiles_x; P.tiles_y = h->tiles_y; P.nacc = nacc_of(np); P.ngrp = h->ngrp; P.ngrp_pad = h->ngrp_pad;
     P.wl = o->w_l1 / 3.f; P.ws = o->w_ssim / 3.f; P.eps = o->irls_eps; P.automask = o->automask;
     return P;
 }
@@ -225,12 +230,13 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
     SolveParams S;
     memset(&S, 0, sizeof(S));
     S.partials = h->partials; S.st = h->state; S.pc = h->pconst; S.stats = nullptr; S.lin_out = h->lin_out;
-    S.nblk = h->nblk; S.nacc = nacc_of(np); S.np = np; S.has_dc = o->w_dc > 0.f;
+    S.ngrp_pad = h->ngrp_pad; S.nacc = nacc_of(np); S.np = np; S.has_dc = o->w_dc > 0.f;
     S.n_iters = o->n_iters; S.solver = o->solver; S.param = o->param;
     S.b_dc = (double)o->w_dc / ((double)h->H * (double)h->W);
     S.lambda_up = o->lambda_up; S.lambda_down = o->lambda_down; S.lambda_min = o->lambda_min;
     S.prior_scale = np == 7 ? (double)o->prior_scale : 0.0;
     S.shared_image = shared;
+    S.dbg = h->dbg_stamps;
     return S;
 }
 
@@ -263,6 +269,8 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     tcsfm_ctx *h = new tcsfm_ctx();
     h->device = device; h->H = H; h->W = W; h->max_pairs = max_pairs;
     h->tiles_x = (W + TILE_W - 1) / TILE_W; h->tiles_y = (H + TILE_H - 1) / TILE_H; h->nblk = h->tiles_x * h->tiles_y;
+    h->ngrp = (h->nblk + RG - 1) / RG;
+    h->ngrp_pad = (h->ngrp + 63) / 64 * 64;
     size_t hw = (size_t)H * W, n = max_pairs;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
@@ -270,7 +278,11 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->tgtpack, n * hw * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc((void **)&h->srcpack, n * hw * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc((void **)&h->depth_work, n * hw * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->partials, n * h->nblk * kMaxAcc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->partials, n * h->ngrp_pad * kMaxAcc * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(h->partials, 0, n * h->ngrp_pad * kMaxAcc * sizeof(float));  // pad records stay 0
+    if (e == hipSuccess) e = hipMalloc((void **)&h->blockrec, n * h->nblk * kMaxAcc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tickets, n * h->ngrp * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->tickets, 0, n * h->ngrp * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->state, n * sizeof(PairState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->pconst, n * sizeof(PairConst));
     if (e == hipSuccess) e = hipMalloc((void **)&h->lin_out, n * kLinOut * sizeof(double));
@@ -282,6 +294,10 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
         tcsfm_destroy(h);
         return e == hipErrorOutOfMemory ? TCSFM_E_NOMEM : TCSFM_E_HIP;
     }
+    if (getenv("TCSFM_DEBUG_STAMPS")) {
+        (void)hipMalloc((void **)&h->dbg_stamps, 8 * sizeof(long long));
+        (void)hipMemset(h->dbg_stamps, 0, 8 * sizeof(long long));
+    }
     *out = h;
     return TCSFM_OK;
 }
@@ -290,7 +306,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->state, h->pconst, h->lin_out,
+    void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -534,6 +550,16 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     if (d_ls_out && (rc = copy_back(h, o, log_scale_io, d_ls_out, (size_t)N))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+// diagnostic: copy the k_solve phase stamps to the host (8 values; zeros unless TCSFM_DEBUG_STAMPS was set at create)
+int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]) {
+    if (!h || !out) return TCSFM_E_ARG;
+    memset(out, 0, 8 * sizeof(long long));
+    if (!h->dbg_stamps) return TCSFM_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->dbg_stamps, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return TCSFM_OK;
 }
 
