@@ -30,7 +30,7 @@ class LinOut(C.Structure):
 
 def default_opts(**kw) -> OrcOpts:
     o = OrcOpts(nparam=6, automask=1, param=0, solver=0, n_iters=4, w_l1=0.15, w_ssim=0.85, w_dc=0.0,
-                irls_eps=1e-3, lambda0=1e-4, lambda_up=10.0, lambda_down=0.1, lambda_min=1e-7, prior_scale=1.0)
+                irls_eps=1e-3, lambda0=1e-4, lambda_up=10.0, lambda_down=0.1, lambda_min=1e-5, prior_scale=1.0)
     for k, v in kw.items():
         if not hasattr(o, k):
             raise KeyError(k)

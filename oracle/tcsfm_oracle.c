@@ -476,7 +476,8 @@ typedef struct {
  *   dd   = clamp(|cd-pd|/(cd+pd),0,1), W = 1-dd                                          (train_mono.py:91-92)
  *   M    = valid * [diff < auto_err]  (non-differentiable, as in the reference)           (helpers.py:18-20)
  * Per-pixel error maps (E_k >= 0):  E1 = W e1, E2 = W e2, E3 = dd, with rows J_k = dE_k/dtheta.
- *     g = sum a (J1+J2) + b J3           == EXACT gradient of C (masks detached, as reference autograd)
+ *     g = sum a (J1+J2) + b h J3         == EXACT gradient of C (masks detached, as reference autograd) for the
+ *                                           photometric part; h = min(1, E3/eps) Huberises the depth-consistency part
  *   with a = M/sum(M), b = w_dc/(H W).
  * Gauss-Newton matrix (a generalised GN: exact gradient, PSD curvature model).  With the 2 x np
  * geometric Jacobian  Jg_p = [d ix/dtheta ; d iy/dtheta]  of the sample position and the bilinear image
@@ -594,7 +595,10 @@ void orc_linearize(int H, int W, const real *tgt, const real *src, const real *d
         const px_t *P = &px[i];
         for (int j = 0; j < np; j++) {
             double j1 = J1[i * np + j], j2 = J2[i * np + j], j3 = J3[i * np + j];
-            out->g[j] += am * (j1 + j2) + b * j3;
+            /* depth-consistency gradient: Huber inside |dd| < eps (dd/eps instead of 1).  Where the two depth maps agree
+             * to rounding, sign(cd - pd) is numerical noise -- in the reference's autograd too -- and an exact-L1 gradient is
+             * not reproducible across precisions.  Same region where the IRLS curvature 1/max(dd,eps) is already quadratic. */
+            out->g[j] += am * (j1 + j2) + b * fmin(1.0, E3 / eps) * j3;
             double la = lxx * P->a[j] + lxy * P->b[j], lb = lxy * P->a[j] + lyy * P->b[j];
             for (int k = 0; k <= j; k++)
                 out->H[j * np + k] += la * P->a[k] + lb * P->b[k] + k3 * j3 * J3[i * np + k];

@@ -558,7 +558,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 for (int i = 0; i <= j; i++) { aHP[h] += la * a[i] + lb * b[i]; h++; }
             }
             if (DC) {
-                float k3 = inimg ? 1.f / fmaxf(dd, P.eps) : 0.f, inf = inimg ? 1.f : 0.f;
+                // IRLS curvature 1/max(dd,eps); the gradient is Huberised inside dd < eps (sign(cd-pd) is rounding noise there)
+                float k3 = inimg ? 1.f / fmaxf(dd, P.eps) : 0.f, inf = inimg ? fminf(1.f, dd / P.eps) : 0.f;
                 h = 0;
 #pragma unroll
                 for (int j = 0; j < NP; j++) {

@@ -250,7 +250,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->n_iters = 4; o->solver = TCSFM_SOLVER_GN; o->param = TCSFM_PARAM_SE3; o->refine = TCSFM_REFINE_POSE;
     o->automask = 1; o->depth_is_disp = 0; o->host_ptrs = 0;
     o->w_l1 = 0.15f; o->w_ssim = 0.85f; o->w_dc = 0.f; o->irls_eps = 1e-3f;
-    o->lambda0 = 1e-4f; o->lambda_up = 10.f; o->lambda_down = 0.1f; o->lambda_min = 1e-7f;
+    o->lambda0 = 1e-4f; o->lambda_up = 10.f; o->lambda_down = 0.1f; o->lambda_min = 1e-5f;
     o->min_depth = 0.06f; o->max_depth = 2.67f;
     o->prior_scale = 1.0f;
 }
