@@ -101,11 +101,10 @@ def main():
     dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
     eng = Engine(H, W, npairs)
     opts = default_opts(n_iters=ITERS)
-    pose_io = dev["pose_init"].clone()
+    pose_io = torch.empty_like(dev["pose_init"])
 
-    def step():
-        pose_io.copy_(dev["pose_init"], non_blocking=True)   # every step starts from the same initial poses
-        eng.refine_inplace(dev["tgt"], dev["src"], dev["depth_t"], dev["depth_s"], dev["K"], pose_io, opts)
+    def step():   # every step starts from the same initial poses and writes the refined poses to pose_io
+        eng.refine_into(dev["tgt"], dev["src"], dev["depth_t"], dev["depth_s"], dev["K"], dev["pose_init"], pose_io, opts)
 
     def fence():
         if distributed:

@@ -122,11 +122,12 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
 /* Refine N directed pairs: replaces the epoch loop of DepthOptimizer.optimize_window
  * (optimization_experiments/optimizer.py:217-274) for the pose / pose+scale unknowns with
  * o->n_iters Gauss-Newton (or LM) iterations on the reference's residual.
- *   pose_io       [N,6] in: initial pose (e.g. PoseNet output), out: refined pose
- *   log_scale_io  [N]   in/out, NULL unless refine == POSE_SCALE (NULL then means start at 0, result dropped)
+ *   pose_in       [N,6] initial pose (e.g. PoseNet output);  pose_out [N,6] refined pose (may alias pose_in)
+ *   log_scale_in  [N] or NULL (start at 0), log_scale_out [N] or NULL: only read/written when refine == POSE_SCALE
  *   stats_out     [N,n_iters+1,TCSFM_NSTAT] or NULL */
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
-                 const float *depth_s, const float *K, float *pose_io, float *log_scale_io, float *stats_out);
+                 const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
+                 float *log_scale_out, float *stats_out);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 

@@ -38,7 +38,7 @@ _SIGNATURES = {
     "tcsfm_photometric": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 12),
     "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
     "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
-    "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),
+    "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
     "tcsfm_profile_begin": (C.c_int, [_P]),
     "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
     "tcsfm_debug_stamps": (C.c_int, [_P, _P]),

@@ -169,6 +169,60 @@ __device__ __forceinline__ void geo_jac(const PairConst &c, const Geo &g, int W,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// per-pair fp64 state -> fp32 constants of one linearisation; pair initialisation
+
+__device__ inline void write_const(const PairState &S, const double *T, double s, int img, PairConst &c) {
+    const double *K = S.K;
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double Ki[9] = {1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1};
+    double RmI[9], KR[9], A[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) RmI[3 * i + j] = T[4 * i + j] - (i == j ? 1.0 : 0.0);
+    mat3_mul(K, RmI, KR);
+    mat3_mul(KR, Ki, A);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            c.A[3 * i + j] = (float)A[3 * i + j];
+            c.R[3 * i + j] = (float)T[4 * i + j];
+        }
+        c.kt[i] = (float)(K[3 * i] * T[3] + K[3 * i + 1] * T[7] + K[3 * i + 2] * T[11]);
+        c.t[i] = (float)T[4 * i + 3];
+    }
+    c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
+    c.ki0 = (float)(1.0 / fx); c.ki2 = (float)(-cx / fx); c.ki4 = (float)(1.0 / fy); c.ki5 = (float)(-cy / fy);
+    c.es = (s == 0.0) ? 1.f : (float)exp(s);
+    c.img = img;
+}
+
+struct InitParams {
+    const float *pose, *log_scale, *K;  // [N,6], [N] or null, [Nimg,3,3]
+    PairState *st;
+    PairConst *pc;
+    int N, shared_image;                // shared_image: all problems read image pair 0 (loss-surface sweep)
+    float lambda0;
+};
+
+__device__ inline void init_pair(const InitParams &P, int n) {
+    PairState &S = P.st[n];
+    int img = P.shared_image ? 0 : n;
+    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[img * 9 + i];
+    double pose[6];
+    for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
+    pose_to_T(pose, S.Tcur);
+    for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
+    S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
+    S.lambda = (double)P.lambda0;
+    S.cost_cur = 0.0;
+    S.have_cur = 0;
+    write_const(S, S.Ttry, S.stry, img, P.pc[n]);
+}
+
+__global__ void k_init(InitParams P) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < P.N) init_pair(P, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_pack
 struct PackParams {
     const float *tgt, *src, *depth_t, *depth_s;  // planar inputs [N,3,H,W] / [N,1,H,W]
@@ -178,6 +232,7 @@ struct PackParams {
     float wl, ws;                                // w_l1/3, w_ssim/3
     int depth_is_disp;
     float min_disp, max_disp;
+    InitParams init;                             // init.N > 0: pair initialisation fused into this launch (one thread per pair)
 };
 
 // (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory
@@ -209,6 +264,7 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     int n = blockIdx.y;
     const int hw = P.H * P.W;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n < P.init.N) init_pair(P.init, n);  // independent of the packing below
     if (idx >= hw) return;
     int v = idx / P.W, u = idx - v * P.W;
     const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
@@ -635,54 +691,6 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_init / k_solve / k_finish (fp64 per-pair logic; mirrors oracle/tcsfm_oracle.c orc_refine)
-
-__device__ inline void write_const(const PairState &S, const double *T, double s, int img, PairConst &c) {
-    const double *K = S.K;
-    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    const double Ki[9] = {1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1};
-    double RmI[9], KR[9], A[9];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) RmI[3 * i + j] = T[4 * i + j] - (i == j ? 1.0 : 0.0);
-    mat3_mul(K, RmI, KR);
-    mat3_mul(KR, Ki, A);
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) {
-            c.A[3 * i + j] = (float)A[3 * i + j];
-            c.R[3 * i + j] = (float)T[4 * i + j];
-        }
-        c.kt[i] = (float)(K[3 * i] * T[3] + K[3 * i + 1] * T[7] + K[3 * i + 2] * T[11]);
-        c.t[i] = (float)T[4 * i + 3];
-    }
-    c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
-    c.ki0 = (float)(1.0 / fx); c.ki2 = (float)(-cx / fx); c.ki4 = (float)(1.0 / fy); c.ki5 = (float)(-cy / fy);
-    c.es = (s == 0.0) ? 1.f : (float)exp(s);
-    c.img = img;
-}
-
-struct InitParams {
-    const float *pose, *log_scale, *K;  // [N,6], [N] or null, [Nimg,3,3]
-    PairState *st;
-    PairConst *pc;
-    int N, shared_image;                // shared_image: all problems read image pair 0 (loss-surface sweep)
-    float lambda0;
-};
-
-__global__ void k_init(InitParams P) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= P.N) return;
-    PairState &S = P.st[n];
-    int img = P.shared_image ? 0 : n;
-    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[img * 9 + i];
-    double pose[6];
-    for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
-    pose_to_T(pose, S.Tcur);
-    for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
-    S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
-    S.lambda = (double)P.lambda0;
-    S.cost_cur = 0.0;
-    S.have_cur = 0;
-    write_const(S, S.Ttry, S.stry, img, P.pc[n]);
-}
 
 struct SolveParams {
     const float *partials;  // [N][nacc][ngrp_pad] group records

@@ -188,8 +188,23 @@ void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
 int nacc_of(int np) { return np == 6 ? AccLayout<6>::NACC : AccLayout<7>::NACC; }
 
-int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds) {
+InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const float *ls, const float *K, int shared) {
+    InitParams I;
+    I.pose = pose; I.log_scale = ls; I.K = K; I.st = h->state; I.pc = h->pconst; I.N = N; I.shared_image = shared;
+    I.lambda0 = o->lambda0;
+    return I;
+}
+
+// init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
+int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
+             const InitParams *init = nullptr) {
     PackParams P;
+    memset(&P.init, 0, sizeof(P.init));
+    if (init) {
+        // group tickets must be zero when k_linearize starts; the reducers re-zero them, this covers an aborted earlier call
+        HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
+        P.init = *init;
+    }
     P.tgt = tgt; P.src = src; P.depth_t = dt; P.depth_s = ds;
     P.tgtpack = h->tgtpack; P.srcpack = h->srcpack; P.depth_out = h->depth_work;
     P.H = h->H; P.W = h->W; P.N = Nimg;
@@ -209,9 +224,7 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
 int run_init(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const float *ls, const float *K, int shared) {
     // group tickets must be zero when k_linearize starts; the reducers re-zero them, this covers an aborted earlier call
     HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
-    InitParams I;
-    I.pose = pose; I.log_scale = ls; I.K = K; I.st = h->state; I.pc = h->pconst; I.N = N; I.shared_image = shared;
-    I.lambda0 = o->lambda0;
+    InitParams I = init_params(h, o, N, pose, ls, K, shared);
     hipLaunchKernelGGL(k_init, dim3((N + 63) / 64), dim3(64), 0, h->stream, I);
     HIPCHK(h, hipGetLastError());
     return TCSFM_OK;
@@ -494,10 +507,11 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
 }
 
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
-                 const float *depth_s, const float *K, float *pose_io, float *log_scale_io, float *stats_out) {
+                 const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
+                 float *log_scale_out, float *stats_out) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
-    if (!tgt || !src || !depth_t || !depth_s || !pose_io || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
+    if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
     HIPCHK(h, hipSetDevice(h->device));
     if ((rc = check_intrinsics(h, o, K, N))) return rc;
     const size_t hw = (size_t)h->H * h->W;
@@ -508,19 +522,19 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
     if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
     if ((rc = to_dev(h, o, 4, K, (size_t)N * 9, &d_K))) return rc;
-    if ((rc = to_dev(h, o, 5, (const float *)pose_io, (size_t)N * 6, &d_pose_in))) return rc;
-    if ((rc = to_dev(h, o, 6, (const float *)log_scale_io, (size_t)N, &d_ls_in))) return rc;
-    float *d_pose_out = o->host_ptrs ? (float *)d_pose_in : pose_io;
-    float *d_ls_out = (np == 7 && log_scale_io) ? (o->host_ptrs ? (float *)d_ls_in : log_scale_io) : nullptr;
-    float *d_stats = nullptr;
+    if ((rc = to_dev(h, o, 5, pose_in, (size_t)N * 6, &d_pose_in))) return rc;
+    if ((rc = to_dev(h, o, 6, log_scale_in, (size_t)N, &d_ls_in))) return rc;
+    float *d_pose_out, *d_ls_out = nullptr, *d_stats = nullptr;
+    if ((rc = out_dev(h, o, 7, pose_out, (size_t)N * 6, &d_pose_out))) return rc;
+    if (np == 7 && log_scale_out && (rc = out_dev(h, o, 8, log_scale_out, (size_t)N, &d_ls_out))) return rc;
     const size_t nstats = (size_t)N * (o->n_iters + 1) * TCSFM_NSTAT;
     if (stats_out) {
-        if ((rc = out_dev(h, o, 7, stats_out, nstats, &d_stats))) return rc;
+        if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
     }
 
-    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds))) return rc;
-    if ((rc = run_init(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0))) return rc;
+    InitParams I = init_params(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0);
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I))) return rc;
     LinParams P = lin_params(h, o, np);
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
@@ -546,8 +560,8 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
         hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
         HIPCHK(h, hipGetLastError());
     }
-    if ((rc = copy_back(h, o, pose_io, d_pose_out, (size_t)N * 6))) return rc;
-    if (d_ls_out && (rc = copy_back(h, o, log_scale_io, d_ls_out, (size_t)N))) return rc;
+    if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
+    if (d_ls_out && (rc = copy_back(h, o, log_scale_out, d_ls_out, (size_t)N))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;

@@ -173,19 +173,22 @@ class Engine:
         Asynchronous on the handle's stream; outputs are GPU tensors."""
         o = opts or default_opts()
         N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
-        pose_io = pose.clone()
-        ls_io = None
+        pose_out = torch.empty_like(pose)
+        ls_in = ls_out = None
         if o.refine == _lib.REFINE_POSE_SCALE:
-            ls_io = torch.zeros(N, device=pose.device, dtype=torch.float32) if log_scale is None else _chk(log_scale, (N,), "log_scale").clone()
+            ls_in = torch.zeros(N, device=pose.device, dtype=torch.float32) if log_scale is None else _chk(log_scale, (N,), "log_scale")
+            ls_out = torch.empty_like(ls_in)
         st = torch.empty((N, o.n_iters + 1, _lib.NSTAT), device=pose.device, dtype=torch.float32) if stats else None
         self._call(self.lib.tcsfm_refine(self._h, C.byref(o), N, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s),
-                                         self._p(K), self._p(pose_io), self._p(ls_io), self._p(st)))
-        return pose_io, ls_io, st
+                                         self._p(K), self._p(pose), self._p(ls_in), self._p(pose_out), self._p(ls_out), self._p(st)))
+        return pose_out, ls_out, st
 
-    def refine_inplace(self, tgt, src, depth_t, depth_s, K, pose_io, opts: Opts, log_scale_io=None, stats_out=None):
-        """Zero-allocation variant used by bench.py: tensors must already be validated/contiguous."""
+    def refine_into(self, tgt, src, depth_t, depth_s, K, pose_in, pose_out, opts: Opts, log_scale_in=None, log_scale_out=None,
+                    stats_out=None):
+        """Zero-allocation variant used by bench.py: tensors must already be validated/contiguous; pose_out may alias pose_in."""
         self._call(self.lib.tcsfm_refine(self._h, C.byref(opts), tgt.shape[0], self._p(tgt), self._p(src), self._p(depth_t),
-                                         self._p(depth_s), self._p(K), self._p(pose_io), self._p(log_scale_io), self._p(stats_out)))
+                                         self._p(depth_s), self._p(K), self._p(pose_in), self._p(log_scale_in), self._p(pose_out),
+                                         self._p(log_scale_out), self._p(stats_out)))
 
 
 # -- SE(3) host utilities (liegroups stand-ins; double precision, no GPU needed) ---------------------
