@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "se3_math.h"
+#include "wave_reduce.h"
 
 namespace tc {
 
@@ -67,6 +68,8 @@ __device__ __forceinline__ int refl_idx(int i, int n) {  // ReflectionPad2d(1), 
     return min(max(i, 0), n - 1);
 }
 __device__ __forceinline__ float clamp01(float a) { return fminf(fmaxf(a, 0.f), 1.f); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: the kernel is VALU-bound
+__device__ __forceinline__ float frcp(float a) { return __builtin_amdgcn_rcpf(a); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // warp geometry of one target pixel
@@ -94,18 +97,18 @@ __device__ __forceinline__ void warp_geo(const PairConst &c, int W, int H, int u
     float p2 = D + q2;
     g.zcl = p2 < 1e-3f;
     g.Z = g.zcl ? 1e-3f : p2;
-    g.iz = 1.0f / g.Z;
+    g.iz = frcp(g.Z);
     // numerators of the flow: p0 - u Z, p1 - v Z
     float fu = g.zcl ? (u * D + q0) - u * g.Z : q0 - u * q2;
     float fv = g.zcl ? (v * D + q1) - v * g.Z : q1 - v * q2;
-    float flx = fu / g.Z, fly = fv / g.Z;
+    float flx = fu * g.iz, fly = fv * g.iz;
     g.uz = u + flx;
     g.vz = v + fly;
     // |x_norm| > 1  <=>  u_proj outside [0, W-1]   (stn.py:223-227; detached sentinel -> zero sample, zero gradient)
     g.oobx = (flx > (float)(W - 1 - ui)) || (flx < -u);
     g.ooby = (fly > (float)(H - 1 - vi)) || (fly < -v);
     // ix = u_proj W/(W-1) - 0.5 = u + [u/(W-1) - 0.5 + flow W/(W-1)]
-    const float iw = 1.f / (float)(W - 1), ih = 1.f / (float)(H - 1);
+    const float iw = frcp((float)(W - 1)), ih = frcp((float)(H - 1));
     g.rx = (u * iw - 0.5f) + flx * ((float)W * iw);
     g.ry = (v * ih - 0.5f) + fly * ((float)H * ih);
     // point in the source camera frame (Jacobians only)
@@ -146,7 +149,7 @@ __device__ __forceinline__ void tap4(const float4 *__restrict__ img, int W, int 
 //   dXp/drho_j = e_j ; dXp/dphi_j = e_j x Xp ; dXp/dsigma = Xp - t   ; pinhole K
 template <int NP>
 __device__ __forceinline__ void geo_jac(const PairConst &c, const Geo &g, int W, int H, float *a, float *b, float *zc) {
-    const float cw = (float)W / (float)(W - 1), ch = (float)H / (float)(H - 1);
+    const float cw = (float)W * frcp((float)(W - 1)), ch = (float)H * frcp((float)(H - 1));
     float dp0[TC_MAXP], dp1[TC_MAXP], dp2[TC_MAXP];
     dp0[0] = c.fx;  dp1[0] = 0.f;   dp2[0] = 0.f;
     dp0[1] = 0.f;   dp1[1] = c.fy;  dp2[1] = 0.f;
@@ -348,36 +351,6 @@ struct AccLayout {
     static constexpr int NACC = 2 * NH + 2 * NP + 3;  // + sum(M W diff), sum(M), sum(dd)
 };
 
-// Sum over the 64 lanes of a wave with 6 DPP-modified v_add_f32 (no LDS traffic, unlike __shfl_xor which lowers to
-// ds_bpermute).  GFX9 DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
-// row_mirror = 0x140 (after these every lane of a 16-lane row holds the row sum), row_bcast15 = 0x142 into rows 1,3,
-// row_bcast31 = 0x143 into rows 2,3.  The total ends up in lane 63.
-__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
-    // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes whose source is disabled keep `old` = 0
-    int r = 0;
-    switch (ctrl) {  // the control must be an immediate
-        case 0xB1: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false); break;
-        case 0x4E: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false); break;
-        case 0x141: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false); break;
-        case 0x140: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false); break;
-        case 0x142: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); break;
-        case 0x143: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); break;
-    }
-    (void)row_mask;
-    return v + __int_as_float(r);
-}
-
-// result valid in lane 63
-__device__ __forceinline__ float wave_sum63(float v) {
-    v = dpp_add(v, 0xB1, 0xF);
-    v = dpp_add(v, 0x4E, 0xF);
-    v = dpp_add(v, 0x141, 0xF);
-    v = dpp_add(v, 0x140, 0xF);
-    v = dpp_add(v, 0x142, 0xA);
-    v = dpp_add(v, 0x143, 0xC);
-    return v;
-}
-
 enum { MODE_COST = 0, MODE_LIN = 1, MODE_MAPS = 2 };
 
 template <int NP, bool DC, int MODE, int TW, int TH, int NT>
@@ -477,17 +450,22 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 
         // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances).
         // Rolled on purpose (one neighbour live at a time): full unrolling costs >256 VGPRs and all the occupancy.
+        // Every float4 of a record is consumed whole: a partially used one is narrowed by hipcc to ds_read_b64/b96, whose
+        // banking conflicts on the 112-byte record stride (measured: 45 % of LDS cycles were conflict cycles).
         float Sx[3] = {0, 0, 0}, Sy[3] = {0, 0, 0}, Sxx[3] = {0, 0, 0}, Syy[3] = {0, 0, 0}, Sxy[3] = {0, 0, 0};
+        float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0};  // window sums of the image gradient (curvature model)
 #pragma unroll 1
         for (int kk = 0; kk < 9; kk++) {
             const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
             const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
-            float4 n0 = nb[0], n1 = nb[1];
+            float4 n0 = nb[0], n1 = nb[1], n2 = nb[2];
             const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
+            const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 float a = xq[ch] - xc[ch], b = yq[ch] - yc[ch];
                 Sx[ch] += a; Sy[ch] += b; Sxx[ch] += a * a; Syy[ch] += b * b; Sxy[ch] += a * b;
+                Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
             }
         }
         const float n9 = 1.f / 9.f;
@@ -503,7 +481,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             float sigxy = Sxy[ch] * n9 - mdx * mdy;
             float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
             float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
-            float idn = 1.f / (d1 * d2), ratio = n1 * n2 * idn;
+            float idn = frcp(d1 * d2), ratio = n1 * n2 * idn;
             float raw = (1.f - ratio) * 0.5f;
             bool cl = (raw < 0.f) || (raw > 1.f);
             e2 += P.ws * clamp01(raw);
@@ -512,13 +490,13 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             cB[ch] = pre * (-ratio * 2.f * d1);
             cC[ch] = pre * (2.f * n1);
             cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2) - cB[ch] * mdy - cC[ch] * mdx;
-            id1[ch] = cl ? 0.f : P.ws / d1; id2[ch] = cl ? 0.f : 1.125f * P.ws / d2;
+            id1[ch] = cl ? 0.f : P.ws * idn * d2; id2[ch] = cl ? 0.f : 1.125f * P.ws * idn * d1;
             // L1 term, train_mono.py:87
             float rr = yc[ch] - xc[ch], ar = fabsf(rr);
             e1 += P.wl * fminf(ar, 1.f);
             float sgn = (ar <= 1.f) ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : 0.f;
             l1x += P.wl * sgn * gxc[ch]; l1y += P.wl * sgn * gyc[ch];
-            float w1 = (ar <= 1.f) ? P.wl / fmaxf(ar, P.eps) : 0.f;
+            float w1 = (ar <= 1.f) ? P.wl * frcp(fmaxf(ar, P.eps)) : 0.f;
             lxx += w1 * gxc[ch] * gxc[ch]; lxy += w1 * gxc[ch] * gyc[ch]; lyy += w1 * gyc[ch] * gyc[ch];
         }
         float diff = e1 + e2;
@@ -527,8 +505,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 #pragma unroll
         for (int j = 0; j < NP; j++) de[j] = 0.f;
         if (MODE == MODE_LIN) {
-            // pass B: exact SSIM gradient rows (neighbour geometry included) + window means of the image gradient
-            float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0};
+            // pass B: exact SSIM gradient rows (neighbour geometry included)
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
                 const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
@@ -545,7 +522,6 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 for (int ch = 0; ch < 3; ch++) {
                     float cf = cA[ch] + cB[ch] * (yq[ch] - yc[ch]) + cC[ch] * (xq[ch] - xc[ch]);
                     sx += cf * gxq[ch]; sy += cf * gyq[ch];
-                    Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
                 }
 #pragma unroll
                 for (int j = 0; j < NP; j++) de[j] += sx * aq[j] + sy * bq[j];
@@ -563,8 +539,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 
         // depth consistency, train_mono.py:91-92
         float cd = c_cd[k], pd = c_pd[k];
-        float sum = cd + pd, dif = cd - pd;
-        float raw = fabsf(dif) / sum;
+        float sum = cd + pd, dif = cd - pd, isum = frcp(sum);
+        float raw = fabsf(dif) * isum;
         float dd = clamp01(raw), Wt = 1.f - dd;
         bool inimg = c_in[k];
         bool m = inimg && c_valid[k] && (!P.automask || diff < c_ae[k]);
@@ -595,7 +571,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             b[0] = q4.z; b[1] = q4.w; b[2] = q5.x; b[3] = q5.y; b[4] = q5.z; b[5] = q5.w;
             if (NP == 7) { float4 q6 = ctr[6]; a[NP - 1] = q6.x; b[NP - 1] = q6.y; }
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
-            float kdd = sg * 2.f / (sum * sum);
+            float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;
             float ddJ[NP];
 #pragma unroll
@@ -615,7 +591,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             }
             if (DC) {
                 // IRLS curvature 1/max(dd,eps); the gradient is Huberised inside dd < eps (sign(cd-pd) is rounding noise there)
-                float k3 = inimg ? 1.f / fmaxf(dd, P.eps) : 0.f, inf = inimg ? fminf(1.f, dd / P.eps) : 0.f;
+                float k3 = inimg ? frcp(fmaxf(dd, P.eps)) : 0.f, inf = inimg ? fminf(1.f, dd * frcp(P.eps)) : 0.f;
                 h = 0;
 #pragma unroll
                 for (int j = 0; j < NP; j++) {
@@ -630,23 +606,27 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     if (MODE == MODE_MAPS) return;
 
     // ---------------- workgroup reduction -> one partial record ----------------
+    // live values, compacted: [H photo | g photo | (H dc | g dc) | 3 scalars]; dead accumulators are not reduced
+    constexpr int NPH = L::NH + NP;
+    constexpr int NLIVE = (MODE == MODE_LIN) ? (DC ? L::NACC : NPH + 3) : 3;
     const int wave = tid >> 6, lane = tid & 63;
-    float *wr = red + wave * L::NACC;
-#define TC_RED(v, slot) { float s_ = wave_sum63(v); if (lane == 63) wr[slot] = s_; }
-    if (MODE == MODE_LIN) {
+    {
+        float v[NLIVE];
+        if (MODE == MODE_LIN) {
 #pragma unroll
-        for (int i = 0; i < L::NH; i++) TC_RED(aHP[i], L::OFF_HP + i)
+            for (int i = 0; i < L::NH; i++) v[i] = aHP[i];
 #pragma unroll
-        for (int i = 0; i < NP; i++) TC_RED(aGP[i], L::OFF_GP + i)
-        if (DC) {
+            for (int i = 0; i < NP; i++) v[L::NH + i] = aGP[i];
+            if (DC) {
 #pragma unroll
-            for (int i = 0; i < L::NH; i++) TC_RED(aHD[i], L::OFF_HD + i)
+                for (int i = 0; i < L::NH; i++) v[NPH + i] = aHD[i];
 #pragma unroll
-            for (int i = 0; i < NP; i++) TC_RED(aGD[i], L::OFF_GD + i)
+                for (int i = 0; i < NP; i++) v[NPH + L::NH + i] = aGD[i];
+            }
         }
+        v[NLIVE - 3] = sMWd; v[NLIVE - 2] = sM; v[NLIVE - 1] = sdd;
+        wave_reduce_store<NLIVE>(v, red + wave * L::NACC, lane);
     }
-    TC_RED(sMWd, L::OFF_S) TC_RED(sM, L::OFF_S + 1) TC_RED(sdd, L::OFF_S + 2)
-#undef TC_RED
     __syncthreads();
     // ---- in-launch, deterministic two-level reduction -----------------------------------------------------------
     // A single workgroup can only pull ~6 GB/s of freshly written records (measured: 110 KB = 480 records in 19 us), so the
@@ -659,10 +639,13 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     // and at the start of every refine call).
     float *myrec = P.blockrec + ((size_t)n * nblk + bid) * L::NACC;
     for (int i = tid; i < L::NACC; i += NT) {
-        bool live = (i >= L::OFF_S) || (MODE == MODE_LIN && (DC || i < L::OFF_HD));
+        // accumulator index -> compacted live index (or -1 for a dead accumulator, stored as 0)
+        int li = -1;
+        if (i >= L::OFF_S) li = NLIVE - 3 + (i - L::OFF_S);
+        else if (MODE == MODE_LIN && (DC || i < NPH)) li = i;
         float s = 0.f;
-        if (live)
-            for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + i];
+        if (li >= 0)
+            for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + li];
         __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -682,8 +665,12 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     __syncthreads();
     const float *grec = P.blockrec + ((size_t)n * nblk + gfirst) * L::NACC;
     for (int i = tid; i < L::NACC; i += NT) {
-        float s = 0.f;
-        for (int b = 0; b < gcount; b++) s += grec[(size_t)b * L::NACC + i];
+        float v[RG];
+#pragma unroll
+        for (int b = 0; b < RG; b++) v[b] = (b < gcount) ? grec[(size_t)b * L::NACC + i] : 0.f;  // RG loads in flight, then a
+        float s = 0.f;                                                                          // fixed-order sum
+#pragma unroll
+        for (int b = 0; b < RG; b++) s += v[b];
         P.partials[((size_t)n * L::NACC + i) * P.ngrp_pad + grp] = s;
     }
     if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
