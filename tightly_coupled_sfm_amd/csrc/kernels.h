@@ -50,7 +50,7 @@ struct LinParams {
     const PairConst *pc;    // [N]
     float *blockrec;        // [N][nblk][nacc]   one partial-sum record per workgroup (write-through stores)
     int *tickets;           // [N][ngrp]         arrival counters of the 16-workgroup reduction groups (zero between launches)
-    float *partials;        // [N][nacc][ngrp_pad] group records, accumulator-major: the solve kernel reads 64 per coalesced load
+    float *partials;        // [N][ngrp][nacc] group records (a few dozen per pair): what the solve kernel reads
     // maps mode outputs (may be null)
     float *o_diff, *o_valid, *o_weight, *o_auto_err, *o_auto_mask, *o_rec;
     int H, W, tiles_x, tiles_y, nacc;
@@ -211,6 +211,11 @@ __device__ inline void init_pair(const InitParams &P, int n) {
     for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[img * 9 + i];
     double pose[6];
     for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
+    {   // device-side guard of the pinhole contract (the host validates a given intrinsics buffer only once)
+        const double *K = S.K;
+        if (K[1] != 0.0 || K[3] != 0.0 || K[6] != 0.0 || K[7] != 0.0 || K[8] != 1.0 || K[0] == 0.0 || K[4] == 0.0)
+            for (int i = 0; i < 6; i++) pose[i] = __longlong_as_double(0x7ff8000000000000LL);  // NaN: fail loudly
+    }
     pose_to_T(pose, S.Tcur);
     for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
     S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float s = 0.f;                                                                          // fixed-order sum
 #pragma unroll
         for (int b = 0; b < RG; b++) s += v[b];
-        P.partials[((size_t)n * L::NACC + i) * P.ngrp_pad + grp] = s;
+        P.partials[((size_t)n * P.ngrp + grp) * L::NACC + i] = s;
     }
     if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
 }
@@ -680,12 +685,12 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 // k_init / k_solve / k_finish (fp64 per-pair logic; mirrors oracle/tcsfm_oracle.c orc_refine)
 
 struct SolveParams {
-    const float *partials;  // [N][nacc][ngrp_pad] group records
+    const float *partials;  // [N][ngrp][nacc] group records
     PairState *st;
     PairConst *pc;
     float *stats;           // [N][n_iters+1][4] or null
     double *lin_out;        // linearize debug: [N][np*np + np + 4] or null
-    int ngrp_pad, nacc, np, has_dc;
+    int ngrp, nacc, np, has_dc;
     int it, n_iters, solver, param, mode;  // mode 0: iteration step, 1: final LM cost check, 2: export only
     double b_dc;            // w_dc / (H W)
     double lambda_up, lambda_down, lambda_min;
@@ -712,7 +717,7 @@ __device__ inline void T_to_pose_f32(const double *T, float *pose) {
 //   3. lane 0: SE(3) retraction (series exp, no trig), next iteration's fp32 constants, pose output
 // The per-pair logic mirrors orc_refine() of the CPU oracle (which factorises with Cholesky instead).
 template <int NP>
-__global__ __launch_bounds__(512) void k_solve(SolveParams P) {
+__global__ __launch_bounds__(128) void k_solve(SolveParams P) {
     using L = AccLayout<NP>;
     __shared__ double tot[L::NACC];
     __shared__ double ws[3 * NP * NP];
@@ -721,41 +726,20 @@ __global__ __launch_bounds__(512) void k_solve(SolveParams P) {
     const int n = blockIdx.x, tid = threadIdx.x;
 #define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
     TC_STAMP(0)
-    {
-        // 8 waves; wave w owns accumulators w, w+8, ...  Every lane sums the records lane, lane+64, ... of each of its
-        // accumulators in fp64 (fixed order), then a fixed-order butterfly.  ALL loads of a 512-record chunk (up to
-        // 8 accumulators x 8 records per lane) are issued before the first add: the records were written by the previous
-        // kernel from all 8 XCDs, so each load is an L2 miss (~0.4 us) and a rolled load->add loop serialises 56 of them
-        // (measured: 20 us; this form: one round trip per chunk).
-        const int wave = tid >> 6, lane = tid & 63;
-        constexpr int NA = (L::NACC + 7) / 8, U = 8;
-        double s[NA];
+    if (tid < L::NACC) {
+        // one thread per accumulator: fp64 sum of the pair's group records in index order (deterministic).  Up to 32 loads are
+        // issued before the first add -- the records were written by other CUs, every load is an L2 miss (~0.4 us each if
+        // serialised).
+        const float *p = P.partials + (size_t)n * P.ngrp * L::NACC + tid;
+        double s = 0.0;
+        for (int g0 = 0; g0 < P.ngrp; g0 += 32) {
+            float v[32];
 #pragma unroll
-        for (int k = 0; k < NA; k++) s[k] = 0.0;
-        for (int b0 = 0; b0 < P.ngrp_pad; b0 += 64 * U) {
-            float v[NA][U];
+            for (int j = 0; j < 32; j++) v[j] = (g0 + j < P.ngrp) ? p[(size_t)(g0 + j) * L::NACC] : 0.f;
 #pragma unroll
-            for (int k = 0; k < NA; k++) {
-                const int a = wave + 8 * k;
-                const float *p = P.partials + ((size_t)n * L::NACC + (a < L::NACC ? a : 0)) * P.ngrp_pad + lane;
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const int b = b0 + 64 * j;
-                    v[k][j] = (a < L::NACC && b < P.ngrp_pad) ? p[b] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NA; k++)
-#pragma unroll
-                for (int j = 0; j < U; j++) s[k] += (double)v[k][j];
+            for (int j = 0; j < 32; j++) s += (double)v[j];
         }
-#pragma unroll
-        for (int k = 0; k < NA; k++) {
-            double t = s[k];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-            if (lane == 0 && wave + 8 * k < L::NACC) tot[wave + 8 * k] = t;
-        }
+        tot[tid] = s;
     }
     __syncthreads();
     TC_STAMP(1)

@@ -42,6 +42,9 @@ struct tcsfm_ctx {
     std::vector<HostStage> stage;
     std::string err;
     // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
+    const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
+    int K_checked_n = 0;
+    bool tickets_dirty = false;        // a failed call may have left group tickets non-zero
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;
@@ -55,6 +58,7 @@ namespace {
         hipError_t e_ = (call);                                                                      \
         if (e_ != hipSuccess) {                                                                      \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            (h)->tickets_dirty = true;                                                               \
             return TCSFM_E_HIP;                                                                      \
         }                                                                                            \
     } while (0)
@@ -123,6 +127,10 @@ int copy_back(tcsfm_ctx *h, const tcsfm_opts *o, T *host, const T *dev, size_t c
 
 // intrinsics must be pinhole; checked on the host when they are host pointers, otherwise after a small D2H copy
 int check_intrinsics(tcsfm_ctx *h, const tcsfm_opts *o, const float *K_host_or_dev, int n) {
+    // Device intrinsics are validated with one blocking D2H copy the FIRST time a (pointer, count) is seen; repeated calls
+    // on the same buffer (a sequence, the bench loop) stay fully asynchronous.  The device side guards independently:
+    // init_pair() poisons the pose with NaN when K is not pinhole, so a buffer mutated behind our back still fails loudly.
+    if (!o->host_ptrs && K_host_or_dev == h->K_checked && n <= h->K_checked_n) return TCSFM_OK;
     std::vector<float> k((size_t)n * 9);
     if (o->host_ptrs) memcpy(k.data(), K_host_or_dev, k.size() * sizeof(float));
     else {
@@ -134,6 +142,7 @@ int check_intrinsics(tcsfm_ctx *h, const tcsfm_opts *o, const float *K_host_or_d
         if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || !(K[0] != 0.f) || !(K[4] != 0.f))
             return fail(h, TCSFM_E_INTRINSICS, "intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1]");
     }
+    if (!o->host_ptrs) { h->K_checked = K_host_or_dev; h->K_checked_n = n; }
     return TCSFM_OK;
 }
 
@@ -181,8 +190,8 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mo
 
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
-    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(512), 0, h->stream, S);
-    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(512), 0, h->stream, S);
+    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(128), 0, h->stream, S);
+    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(128), 0, h->stream, S);
 }
 
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
@@ -201,8 +210,12 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
     PackParams P;
     memset(&P.init, 0, sizeof(P.init));
     if (init) {
-        // group tickets must be zero when k_linearize starts; the reducers re-zero them, this covers an aborted earlier call
-        HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
+        // group tickets must be zero when k_linearize starts: zeroed at create, re-zeroed by the reducers after every launch;
+        // only a call that failed midway can leave them dirty
+        if (h->tickets_dirty) {
+            HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
+            h->tickets_dirty = false;
+        }
         P.init = *init;
     }
     P.tgt = tgt; P.src = src; P.depth_t = dt; P.depth_s = ds;
@@ -243,7 +256,7 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
     SolveParams S;
     memset(&S, 0, sizeof(S));
     S.partials = h->partials; S.st = h->state; S.pc = h->pconst; S.stats = nullptr; S.lin_out = h->lin_out;
-    S.ngrp_pad = h->ngrp_pad; S.nacc = nacc_of(np); S.np = np; S.has_dc = o->w_dc > 0.f;
+    S.ngrp = h->ngrp; S.nacc = nacc_of(np); S.np = np; S.has_dc = o->w_dc > 0.f;
     S.n_iters = o->n_iters; S.solver = o->solver; S.param = o->param;
     S.b_dc = (double)o->w_dc / ((double)h->H * (double)h->W);
     S.lambda_up = o->lambda_up; S.lambda_down = o->lambda_down; S.lambda_min = o->lambda_min;
