@@ -1,0 +1,61 @@
+"""The DepthOptimizer drop-in (tightly_coupled_sfm_amd/optimizer.py) against the reference's call surface
+(optimizer.py:15-27,136-297; result keys read at run_sequential_optimization.py:195-216 and
+run_sample_optimization_demo.py:178-186), with stand-in networks like golden G9 of SURVEY 8c."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+class _StandInDepth(torch.nn.Module):
+    """depth net stand-in with the reference model's return convention ([disparities...], skips)"""
+    def __init__(self, table):
+        super().__init__(); self.table = table
+    def forward(self, x):
+        return [self.table[x.shape[0]]], None
+
+
+class _StandInPose(torch.nn.Module):
+    def __init__(self, first):
+        super().__init__(); self.first, self.calls = first, 0
+    def forward(self, x):
+        self.calls += 1
+        return self.first.clone() if self.calls == 1 else torch.zeros_like(self.first)
+
+
+def test_optimize_window_schema_and_improvement():
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.optimizer import DepthOptimizer
+    B, S, H, W = 2, 1, 96, 320
+    pairs = [synth.make_pair(H, W, seed=40 + b) for b in range(B)]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    target = t(np.stack([p["tgt"] for p in pairs])); source = t(np.stack([p["src"] for p in pairs]))
+    K = t(np.stack([p["K"] for p in pairs]))
+    sd = lambda key: t(np.stack([synth.depth_to_sigmoid_disp(p[key].astype(np.float64)) for p in pairs])[:, None])
+    disp_t, disp_s = sd("depth_t"), sd("depth_s")
+    gt = np.stack([p["pose_gt"] for p in pairs])
+    init_f = np.stack([synth.perturb_pose(p["pose_gt"], 40 + b) for b, p in enumerate(pairs)])
+    init_i = np.stack([synth.invert_pose(x) for x in init_f])
+    depth_model = _StandInDepth({(S + 1) * B: torch.cat([disp_t, disp_s], 0), 2 * B: torch.cat([disp_t, torch.flip(disp_t, [3])], 0)})
+    pose_model = _StandInPose(t(np.concatenate([init_f, init_i])))
+    options = {"epochs": 20, "optimize_depth_encoder": True, "automasking": True, "l_depth_consist": True,
+               "l_depth_consist_weight": 0.15, "mode": "scaled", "num_source_imgs": S, "gn_iters": 6}
+    config = {"minibatch": B, "device": "cuda", "min_depth": 0.06, "max_depth": 2.67, "iterations": 2, "camera_height": 1.65}
+    with pytest.warns(UserWarning, match="Gauss-Newton"):
+        opt = DepthOptimizer(options, config, pose_model, depth_model, "09_02")
+    data = (target, [source], [t(gt)], [t(gt)], None, K, None, None, None, None, None)          # the demo's 11-tuple form
+    r = opt.optimize_window(0, data)
+    for k in ("poses_opt", "poses_inv_opt", "poses_init", "poses_inv_init", "gt_poses"):
+        assert tuple(r[k].shape) == (S * B, 6) and r[k].device.type == "cpu" and r[k].dtype == torch.float32, k
+    assert tuple(r["stacked_poses_init"].shape) == (S * B, 2, 6)
+    assert len(r["depths_init"]) == S + 1 and tuple(r["depths_opt"][0].shape) == (B, 1, H, W)
+    assert r["scale_factor"].numel() == 1 and r["scale_factor_init"].numel() == 1
+    assert isinstance(r["disp_opt"], np.ndarray) and r["disp_opt"].shape == (B, H, W)
+    assert pose_model.calls == 2                                    # PoseNet -> HIP warp -> PoseNet correction
+    e0 = np.linalg.norm(r["poses_init"].numpy()[:, :3] - gt[:, :3], axis=1)
+    e1 = np.linalg.norm(r["poses_opt"].numpy()[:, :3] - gt[:, :3], axis=1)
+    assert np.all(r["gn_cost"].numpy()[:, 5] < r["gn_cost"].numpy()[:, 0])
+    assert e1.mean() < e0.mean(), (e0, e1)
+    with pytest.raises(NotImplementedError):
+        DepthOptimizer(dict(options, strict_legacy=True), config, pose_model, depth_model, "09_02")

@@ -1,0 +1,57 @@
+"""N>1 path on CPU: world-size-2 gloo run of the sharding helpers (contiguous split, no data-path collective,
+one all_gather of the refined poses).  The GPU refine is replaced by a deterministic stand-in."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tightly_coupled_sfm_amd import parallel as P
+    pose0 = torch.arange(n_total * 6, dtype=torch.float32).reshape(n_total, 6)
+    tag = torch.arange(n_total, dtype=torch.float32).reshape(n_total, 1)
+    calls = []
+
+    def fake_refine(pose, tag):           # stand-in for Engine.refine: depends only on the pair's own data
+        calls.append(pose.shape[0])
+        return pose * 2 + tag
+
+    out = P.refine_sharded(fake_refine, dict(pose=pose0, tag=tag), n_total)
+    lo, hi = P.shard_range(n_total, rank, world)
+    ok = torch.equal(out, pose0 * 2 + tag) and calls == ([hi - lo] if hi > lo else [])
+    ret[rank] = (bool(ok), lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 5, 1])
+def test_sharded_refine_gloo_world2(n_total):
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(world, port, n_total, ret), nprocs=world, join=True)
+        ranges = [ret[r][1:] for r in range(world)]
+        assert all(ret[r][0] for r in range(world))
+        assert ranges[0][0] == 0 and ranges[-1][1] == n_total and ranges[0][1] == ranges[1][0]   # disjoint, covering
+
+
+def test_shard_range_properties():
+    from tightly_coupled_sfm_amd.parallel import shard_range
+    for n in (0, 1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
