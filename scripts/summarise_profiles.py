@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/<tag>/ (from scripts/collect_profiles.sh) into profiles/<tag>_*: kernel stats CSV, a PMC summary
+and the HBM-traffic JSON bench.py reads (FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950)."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "bench.json")):
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+pmc = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(f)):
+        acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        if "tc::" in k:
+            for c, x in v.items():
+                pmc[k.split("(")[0]][c] = sum(x) / len(x)
+with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
+    json.dump(pmc, f, indent=1, sort_keys=True)
+lin = next((v for k, v in pmc.items() if "k_linearize" in k and "FETCH_SIZE" in v), None)
+if lin:
+    fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
+    traffic = {"hbm_bytes_per_linearize_launch": int((2 * fetch_kb + write_kb) * 1024),
+               "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
+               "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE; "
+                       "separate rocprofv3 --pmc passes of `python bench.py --steps 20 --warmup 5`; per-launch average"}
+    with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    print(traffic)
+for k, v in pmc.items():
+    print(k, {c: round(x, 1) for c, x in sorted(v.items())})
