@@ -91,6 +91,9 @@ int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *o);
 /* disp_to_depth, utils/learning_helpers.py:77-86.  n elements; scaled/depth may be NULL. */
 int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const float *disp, float *scaled_disp, float *depth);
 
+/* SSIM_Loss.forward(x, y), losses.py:27-41: `planes` = N*C images of H x W each (reflect pad 1, 3x3 means, clamp). */
+int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, const float *y, float *out);
+
 /* inverse_warp2(src, depth_t, depth_s, -pose, K), models/stn.py:234-273.
  * Outputs (any may be NULL): img_rec [N,3,H,W], valid [N,1,H,W], proj_depth, comp_depth [N,1,H,W]. */
 int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,

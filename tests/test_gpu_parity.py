@@ -106,6 +106,42 @@ def test_batched_fwd_inv_stack_vs_solve_pose_iteratively():
         assert _maxabs(r["img_rec"].cpu().numpy()[sl], g[f"it1_{d}_img_rec"]) < 1e-4
 
 
+def test_optimization_loss_vs_reference_golden():
+    """compute_optimization_loss (optimizer.py:29-134) under the default options and each toggle (golden G5), assembled
+    from maps the HIP library produced for the stacked fwd/inv batch; SSIM_Loss standalone (losses.py:27-41)"""
+    from tightly_coupled_sfm_amd.losses import compute_optimization_loss
+    g = load_golden("batch24x40")
+    B, S = 2, 2
+    target, sources, depths, K = g["target"], g["sources"], g["depths"], g["K"]
+    H, W = target.shape[2:]
+    tg = np.concatenate([target] * S); sr = np.concatenate(list(sources))
+    dtg = np.concatenate([depths[0]] * S); dsr = np.concatenate(list(depths[1:]))
+    e = _eng(H, W, 2 * S * B)
+    split = S * B
+    for iters in (1, 4):
+        poses = np.concatenate([g[f"it{iters}_fwd_poses"][:, -1], g[f"it{iters}_inv_poses"][:, -1]])
+        r = e.compute_photometric_error(_t(np.concatenate([tg, sr])), _t(np.concatenate([sr, tg])), _t(np.concatenate([dtg, dsr])),
+                                        _t(np.concatenate([dsr, dtg])), _t(poses), _t(np.concatenate([K] * (2 * S))))
+        def part(sl, stacked):
+            return {"diff_img": r["diff_img"][sl], "valid_mask": r["warp_valid"][sl], "weight_mask": r["weight_mask"][sl],
+                    "auto_mask_error": r["auto_mask_error"][sl], "auto_mask": r["auto_mask"][sl], "poses": _t(stacked)}
+        fwd = part(slice(0, split), g[f"it{iters}_fwd_poses"]); inv = part(slice(split, None), g[f"it{iters}_inv_poses"])
+        base = {'diff_img_argmin': True, 'automasking': True, 'l_depth_consist': True, 'l_depth_consist_weight': 0.15,
+                'l_depth_init': True, 'l_depth_init_weight': 0.1, 'l_inverse_reconstruction': True, 'l_smooth': False,
+                'l_smooth_weight': 2, 'l_pose_consist': False, 'num_source_imgs': S}
+        for tag, upd in (("default", {}), ("noargmin", {'diff_img_argmin': False}), ("noauto", {'automasking': False}),
+                         ("noinv", {'l_inverse_reconstruction': False}), ("nodc", {'l_depth_consist': False}),
+                         ("smooth", {'l_smooth': True}), ("posec", {'l_pose_consist': True}), ("noinit", {'l_depth_init': False})):
+            loss = compute_optimization_loss(dict(base, **upd), _t(target), _t(g["loss_disp"]), _t(g["loss_disp0"]), fwd, inv, e.ssim_loss)
+            ref = float(g[f"it{iters}_loss_{tag}"])
+            assert abs(float(loss.reshape(-1)[0]) - ref) < 2e-4 * abs(ref), (iters, tag, float(loss.reshape(-1)[0]), ref)
+    s = e.ssim_loss(_t(target), _t(sources[0])).cpu().numpy()
+    import sys
+    from oracle.oracle import Oracle
+    so = np.stack([Oracle("f64").ssim(target[b], sources[0][b]) for b in range(B)])
+    assert _maxabs(s, so) < 2e-6
+
+
 def test_loss_surface_vs_reference_golden():
     """generate_loss_surface (plot_loss_surface.py:11-87): both 50-point sweeps in one launch each"""
     g = load_golden("sweep48x160")

@@ -287,6 +287,29 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     P.depth_out[(size_t)n * hw + idx] = dt;
 }
 
+// SSIM_Loss.forward, losses.py:27-41, on C planes of N images: x, y [N*C, H, W] -> out (same shape)
+__global__ __launch_bounds__(256) void k_ssim(const float *x, const float *y, float *out, int H, int W) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = H * W;
+    if (idx >= hw) return;
+    int v = idx / W, u = idx - v * W;
+    const float *xc = x + (size_t)blockIdx.y * hw, *yc = y + (size_t)blockIdx.y * hw;
+    float x0 = xc[idx], y0 = yc[idx];
+    float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int dv = -1; dv <= 1; dv++)
+        for (int du = -1; du <= 1; du++) {
+            int j = refl_idx(v + dv, H) * W + refl_idx(u + du, W);
+            float a = xc[j] - x0, b = yc[j] - y0;
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+    const float n9 = 1.f / 9.f;
+    float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
+    float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
+    float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
+    float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+    out[(size_t)blockIdx.y * hw + idx] = clamp01((1.f - n / d) * 0.5f);
+}
+
 __global__ void k_disp_to_depth(const float *disp, float *scaled, float *depth, long long n, float min_disp, float max_disp) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

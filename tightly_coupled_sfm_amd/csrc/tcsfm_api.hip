@@ -380,6 +380,23 @@ int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const fl
     return TCSFM_OK;
 }
 
+int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, const float *y, float *out) {
+    if (!h) return TCSFM_E_ARG;
+    if (!o || !x || !y || !out || planes < 1) return fail(h, TCSFM_E_ARG, "tcsfm_ssim: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t hw = (size_t)h->H * h->W, n = hw * planes;
+    const float *d_x, *d_y; float *d_o;
+    int rc;
+    if ((rc = to_dev(h, o, 0, x, n, &d_x))) return rc;
+    if ((rc = to_dev(h, o, 1, y, n, &d_y))) return rc;
+    if ((rc = out_dev(h, o, 2, out, n, &d_o))) return rc;
+    hipLaunchKernelGGL(k_ssim, dim3((unsigned)((hw + 255) / 256), planes), dim3(256), 0, h->stream, d_x, d_y, d_o, h->H, h->W);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = copy_back(h, o, out, d_o, n))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
 int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,
                const float *pose, const float *K, float *img_rec, float *valid, float *proj_depth, float *comp_depth) {
     int rc = check_common(h, o, N);

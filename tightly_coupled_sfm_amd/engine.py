@@ -103,6 +103,15 @@ class Engine:
         self._call(self.lib.tcsfm_disp_to_depth(self._h, C.byref(o), d.numel(), self._p(d), self._p(s), self._p(z)))
         return s, z
 
+    def ssim_loss(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """SSIM_Loss.forward (losses.py:27-41) for [N,C,H,W] tensors"""
+        N, Cc = x.shape[0], x.shape[1]
+        x = _chk(x, (N, Cc, self.H, self.W), "x"); y = _chk(y, (N, Cc, self.H, self.W), "y")
+        out = torch.empty_like(x)
+        o = default_opts()
+        self._call(self.lib.tcsfm_ssim(self._h, C.byref(o), N * Cc, self._p(x), self._p(y), self._p(out)))
+        return out
+
     def inverse_warp2(self, img, depth, ref_depth, pose, intrinsics):
         """models/stn.py:234-273 with the reference's argument order; ``pose`` here is what the reference
         passes, i.e. callers that wrote ``inverse_warp2(src, d_t, d_s, -poses, K)`` keep passing ``-poses``."""
