@@ -381,6 +381,34 @@ struct AccLayout {
 
 enum { MODE_COST = 0, MODE_LIN = 1, MODE_MAPS = 2 };
 
+// Forced 128-bit LDS accesses.  Left to itself hipcc splits partially-used or register-scattered float4 accesses of the
+// 112-byte records into ds_read2_b64 / ds_write2_b32 / ds_read_b96, whose banking conflicts 2- to 4-way on that stride
+// (PMC: 49 % of LDS cycles were bank-conflict cycles); ds_read_b128 / ds_write_b128 are conflict-free on it.
+// The waits are inside the asm statements because hipcc does not track asm loads (cdna_hip_programming.md section 5.7).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ void lds_read3(const float4 *p, float4 &a, float4 &b, float4 &c) {
+    f32x4 x, y, z;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(lds_addr(p)) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
+__device__ __forceinline__ void lds_read3b(const float4 *p, float4 &a, float4 &b, float4 &c) {  // record floats 12..23
+    f32x4 x, y, z;
+    asm volatile("ds_read_b128 %0, %3 offset:48\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(lds_addr(p)) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
+__device__ __forceinline__ float4 lds_read1(const float4 *p) {
+    f32x4 x;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(lds_addr(p)) : "memory");
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void lds_write1(float4 *p, float a, float b, float c, float d) {
+    f32x4 x = {a, b, c, d};
+    asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr(p)), "v"(x) : "memory");
+}
+
 template <int NP, bool DC, int MODE, int TW, int TH, int NT>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
@@ -441,13 +469,13 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float a[NP], b[NP], zc[NP];
         geo_jac<NP>(c, g, W, H, a, b, zc);
         float4 *rec = lds + (ly * CW + lx) * (LDS_REC / 4);
-        rec[0] = make_float4(val.x, val.y, val.z, tp.x);
-        rec[1] = make_float4(tp.y, tp.z, gx.x, gx.y);
-        rec[2] = make_float4(gx.z, gy.x, gy.y, gy.z);
-        rec[3] = make_float4(a[0], a[1], a[2], a[3]);
-        rec[4] = make_float4(a[4], a[5], b[0], b[1]);
-        rec[5] = make_float4(b[2], b[3], b[4], b[5]);
-        if (NP == 7) rec[6] = make_float4(a[NP - 1], b[NP - 1], 0.f, 0.f);
+        lds_write1(rec + 0, val.x, val.y, val.z, tp.x);
+        lds_write1(rec + 1, tp.y, tp.z, gx.x, gx.y);
+        lds_write1(rec + 2, gx.z, gy.x, gy.y, gy.z);
+        lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
+        lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
+        lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
+        if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
         if (r < PPT) {
             const int k = r < PPT ? r : 0;
             c_in[k] = (x00 + lx - 1 < W) && (y00 + ly - 1 < H);
@@ -457,6 +485,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             for (int j = 0; j < NP; j++) c_zc[k][j] = zc[j];
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm LDS writes above are invisible to hipcc's own waitcnt tracking
     __syncthreads();
 
     // ---------------- phase 2: residuals, gradient rows, curvature, accumulation ----------------
@@ -472,7 +501,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         int ci = tid + k * NT;
         int ly = ci / TW + 1, lx = ci - (ci / TW) * TW + 1;
         const float4 *ctr = lds + (ly * CW + lx) * (LDS_REC / 4);
-        float4 q0 = ctr[0], q1 = ctr[1], q2 = ctr[2];
+        float4 q0, q1, q2;
+        lds_read3(ctr, q0, q1, q2);
         const float yc[3] = {q0.x, q0.y, q0.z}, xc[3] = {q0.w, q1.x, q1.y};
         const float gxc[3] = {q1.z, q1.w, q2.x}, gyc[3] = {q2.y, q2.z, q2.w};
 
@@ -486,7 +516,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         for (int kk = 0; kk < 9; kk++) {
             const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
             const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
-            float4 n0 = nb[0], n1 = nb[1], n2 = nb[2];
+            float4 n0, n1, n2;
+            lds_read3(nb, n0, n1, n2);
             const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
             const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
 #pragma unroll
@@ -538,13 +569,15 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             for (int kk = 0; kk < 9; kk++) {
                 const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
                 const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
-                float4 n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3], n4 = nb[4], n5 = nb[5];
+                float4 n0, n1, n2, n3, n4, n5;
+                lds_read3(nb, n0, n1, n2);
+                lds_read3b(nb, n3, n4, n5);
                 const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
                 const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
                 float aq[NP], bq[NP];
                 aq[0] = n3.x; aq[1] = n3.y; aq[2] = n3.z; aq[3] = n3.w; aq[4] = n4.x; aq[5] = n4.y;
                 bq[0] = n4.z; bq[1] = n4.w; bq[2] = n5.x; bq[3] = n5.y; bq[4] = n5.z; bq[5] = n5.w;
-                if (NP == 7) { float4 n6 = nb[6]; aq[NP - 1] = n6.x; bq[NP - 1] = n6.y; }
+                if (NP == 7) { float4 n6 = lds_read1(nb + 6); aq[NP - 1] = n6.x; bq[NP - 1] = n6.y; }
                 float sx = 0.f, sy = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
@@ -593,11 +626,12 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         if (m) { sMWd += Wt * diff; sM += 1.f; }
         if (MODE == MODE_LIN) {
             // own geometric Jacobian (centre record)
-            float4 q3 = ctr[3], q4 = ctr[4], q5 = ctr[5];
+            float4 q3, q4, q5;
+            lds_read3b(ctr, q3, q4, q5);
             float a[NP], b[NP];
             a[0] = q3.x; a[1] = q3.y; a[2] = q3.z; a[3] = q3.w; a[4] = q4.x; a[5] = q4.y;
             b[0] = q4.z; b[1] = q4.w; b[2] = q5.x; b[3] = q5.y; b[4] = q5.z; b[5] = q5.w;
-            if (NP == 7) { float4 q6 = ctr[6]; a[NP - 1] = q6.x; b[NP - 1] = q6.y; }
+            if (NP == 7) { float4 q6 = lds_read1(ctr + 6); a[NP - 1] = q6.x; b[NP - 1] = q6.y; }
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
             float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;
