@@ -63,6 +63,8 @@ typedef struct tcsfm_opts {
     float min_depth, max_depth; /* config['min_depth'], config['max_depth'] (depth_is_disp only)       */
     float prior_scale;     /* POSE_SCALE only: weight of (log_scale - initial)^2.  The photometric cost cannot separate
                               depth scale from |t| (exact gauge); this prior makes the 7-DoF problem well posed.   */
+    float lambda_depth;    /* dense mode: Marquardt damping of the per-pixel depth block (default 1.0)                */
+    float prior_depth;     /* dense mode: weight of the masked prior sum M ((rho-rho0)/rho0)^2 / sum M (default 10)   */
     float reserved1;
 } tcsfm_opts;
 
@@ -131,6 +133,15 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                  const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
                  float *log_scale_out, float *stats_out);
+
+/* Dense mode (BASELINE config 5): refine the 6-DoF pose AND the per-pixel inverse depth of the target of N directed
+ * pairs: o->n_iters Gauss-Newton iterations, exact depth gradient (equal to reference autograd d loss / d depth), per-pixel
+ * Schur elimination of the depth block, 6x6 reduced pose system, back-substitution.  depth_t is the initial target depth
+ * (or sigmoid disparity with depth_is_disp); depth_out [N,1,H,W] receives the refined DEPTH.  Gauss-Newton only; w_dc
+ * must be 0 (the depth prior of opts.prior_depth regularises instead). */
+int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
+                       float *stats_out);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 

@@ -158,6 +158,34 @@ class Oracle:
             r.update(J1=J[0], J2=J[1], J3=J[2], E=E, M=M)
         return r
 
+    def linearize_dense(self, tgt, src, depth_t, depth_s, pose, K, opts=None, lambda_depth=0.0, w_prior=0.0, depth0=None):
+        """dense mode (pose + per-pixel inverse depth): -> dict(H = Schur complement [6,6], g [6], cost, n_mask,
+        g_rho [H,W], D [H,W], B [H,W,6])"""
+        opts = opts or default_opts()
+        tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
+        _, H, W = tgt.shape
+        T = self._d(self.pose_to_T(pose)).reshape(12)
+        out = LinOut()
+        gr, D, B = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W, 6))
+        self.lib.orc_linearize_dense(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(T), self._p(K),
+                                     C.byref(opts), None, C.c_double(lambda_depth), C.c_double(w_prior),
+                                     self._p(None if depth0 is None else self._r(depth0)), C.byref(out), self._p(gr), self._p(D), self._p(B))
+        return dict(H=np.array(out.H[:36]).reshape(6, 6)[:6, :6].copy() if False else np.array([out.H[j * 6 + k] for j in range(6) for k in range(6)]).reshape(6, 6),
+                    g=np.array(out.g[:6]), cost=out.cost, n_mask=out.n_mask, g_rho=gr, D=D, B=B)
+
+    def refine_dense(self, tgt, src, depth_t, depth_s, pose, K, opts=None, lambda_depth=1e-2, w_prior=0.0, min_depth=0.06, max_depth=2.67):
+        """-> (pose [6], refined depth [H,W], stats)"""
+        opts = opts or default_opts()
+        tgt, src, depth_s, K = map(self._r, (tgt, src, depth_s, K))
+        depth = self._r(depth_t).copy()
+        _, H, W = tgt.shape
+        pose = self._d(pose).copy()
+        stats = np.zeros((opts.n_iters + 1, 4))
+        self.lib.orc_refine_dense(H, W, self._p(tgt), self._p(src), self._p(depth), self._p(depth_s), self._p(K), C.byref(opts),
+                                  C.c_double(lambda_depth), C.c_double(w_prior), C.c_double(min_depth), C.c_double(max_depth),
+                                  self._p(pose), self._p(stats))
+        return pose, depth, stats
+
     def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
         """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4])."""
         opts = opts or default_opts()

@@ -733,4 +733,195 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
     free(ae);
 }
 
+/* ------------------------------------------------------------------------- */
+/* dense mode: pose (6) + per-pixel inverse depth of the target, per-pixel Schur complement                           */
+/*
+ * Unknowns: xi (left SE(3) perturbation) and rho_q = 1 / depth_t(q) for every target pixel q (source depth fixed).
+ * Cost: the photometric masked mean C = sum M W diff / sum M (w_dc must be 0 in this mode).
+ * Gradient (exact, equal to reference autograd; pinned by golden grad_depth_t):
+ *     g_rho[q] = sum_{p : q in window(p)} a_p W_p d diff_p/d rec_q . d rec_q/d rho_q   +  a_q diff_q dW_q/d rho_q
+ * Curvature (same generalised-GN model as the pose mode, the window geometry frozen at the pixel itself, so every
+ * residual sees ONE depth => the depth block is diagonal and can be eliminated per pixel):
+ *     with Jg_p (2 x 6) and alpha_p = d(ix,iy)_p / d rho_p (2 x 1):
+ *     H_xx += a Jg' Lam Jg ,  B_p = a Jg' Lam alpha ,  D_p = a alpha' Lam alpha
+ * Schur complement on the pose:  S = H_xx - sum_p B_p B_p' / Dd_p ,  gs = g_xi - sum_p B_p g_rho_p / Dd_p ,
+ *     Dd_p = (1 + lambda_depth) D_p   (pixels with D_p <= tiny are not updated)
+ *     (S + lambda diag S) dxi = -gs ;  drho_p = -(g_rho_p + B_p' dxi) / Dd_p ;  rho clamped to [1/max_depth, 1/min_depth]
+ * Outputs of one linearisation: S (6x6), gs (6), cost, n_mask and the per-pixel g_rho, D, B (H*W x 6).
+ */
+void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                         const double T[12], const real *K, const orc_opts *op, const real *auto_err_in, double lambda_depth,
+                         double w_prior, const real *depth0, lin_t *out, double *g_rho, double *Dq, double *Bq) {
+    int n = H * W;
+    const int np = 7; /* column 6 of the per-pixel Jacobians is re-purposed as the inverse-depth column */
+    cam_t c;
+    cam_setup(&c, H, W, K, T, 0.0);
+    px_t *px = (px_t *)malloc(sizeof(px_t) * n);
+    real *ae = (real *)malloc(sizeof(real) * n), *rec = (real *)malloc(sizeof(real) * 3 * n);
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            px_t *P = &px[v * W + u];
+            px_eval(&c, src, depth_t, depth_s, u, v, np, P);
+            /* scale column (dXp = Xp - t = D R ray) -> inverse-depth column: dXp/drho = -D^2 R ray = -D (Xp - t);
+             * the projected (source) depth does not scale with the target depth: drop px_eval's "+pd" term */
+            real D = depth_t[v * W + u];
+            P->a[6] *= -D; P->b[6] *= -D; P->zc[6] *= -D;
+            P->dpd[6] = P->dgx * P->a[6] + P->dgy * P->b[6];
+        }
+    if (auto_err_in) memcpy(ae, auto_err_in, sizeof(real) * n);
+    else photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
+    for (int i = 0; i < n; i++)
+        for (int ch = 0; ch < 3; ch++) rec[ch * n + i] = px[i].rec[ch];
+    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3), reps = (real)op->irls_eps;
+    double *gx_adj = (double *)calloc((size_t)n * 2, sizeof(double)); /* adjoint wrt sample position (ix, iy) of q */
+    double *gxi = (double *)calloc(6, sizeof(double)), *Hxx = (double *)calloc(36, sizeof(double));
+    double *own = (double *)calloc((size_t)n, sizeof(double));        /* a_q diff_q dW_q/drho_q */
+    real *M = (real *)calloc(n, sizeof(real));
+    double *Lam = (double *)calloc((size_t)n * 3, sizeof(double));
+    double num = 0, nmask = 0;
+    /* pass 1: masks (needs diff), so that the weights a_p are known */
+    real *diffm = (real *)malloc(sizeof(real) * n), *Wm = (real *)malloc(sizeof(real) * n);
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            int i = v * W + u;
+            const px_t *P = &px[i];
+            real e = 0;
+            for (int ch = 0; ch < 3; ch++) {
+                ssim_t s;
+                ssim_at(tgt + ch * n, rec + ch * n, H, W, u, v, &s);
+                e += wl * clamp01(fabs(rec[ch * n + i] - tgt[ch * n + i])) + ws * s.s;
+            }
+            real sum = P->cd + P->pd, raw = fabs(P->cd - P->pd) / sum;
+            diffm[i] = e; Wm[i] = 1 - clamp01(raw);
+            real m = (real)P->valid;
+            if (op->automask) m *= (e < ae[i]) ? (real)1 : (real)0;
+            M[i] = m; nmask += m; num += (double)m * Wm[i] * e;
+        }
+    /* pass 2: exact gradient by scattering every residual's derivative onto the pixels of its window */
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            int i = v * W + u;
+            const px_t *P = &px[i];
+            double am = M[i];
+            if (am == 0) continue;
+            real Wt = Wm[i];
+            real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum;
+            real sg = (raw >= 0 && raw <= 1) ? (dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0)) : (real)0;
+            double lxx = 0, lxy = 0, lyy = 0;
+            for (int ch = 0; ch < 3; ch++) {
+                const real *x = tgt + ch * n, *y = rec + ch * n;
+                real r = y[i] - x[i], ar = fabs(r);
+                real sgn = (ar <= 1) ? (r > 0 ? (real)1 : (r < 0 ? (real)-1 : (real)0)) : (real)0;
+                gx_adj[2 * i] += am * Wt * wl * sgn * P->gx[ch];
+                gx_adj[2 * i + 1] += am * Wt * wl * sgn * P->gy[ch];
+                if (ar <= 1) {
+                    real w1 = wl * Wt / (ar > reps ? ar : reps);
+                    lxx += w1 * P->gx[ch] * P->gx[ch]; lxy += w1 * P->gx[ch] * P->gy[ch]; lyy += w1 * P->gy[ch] * P->gy[ch];
+                }
+                ssim_t s;
+                ssim_at(x, y, H, W, u, v, &s);
+                if (!s.clamped) {
+                    real nn = s.n1 * s.n2, dn = s.d1 * s.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
+                    real cA = pre * (2 * s.mux * s.n2 - 2 * s.n1 * s.mux - ratio * (2 * s.muy * s.d2 - 2 * s.d1 * s.muy));
+                    real cB = pre * (-ratio * 2 * s.d1), cC = pre * (2 * s.n1);
+                    real Sx = 0, Sy = 0;
+                    for (int dv = -1; dv <= 1; dv++)
+                        for (int du = -1; du <= 1; du++) {
+                            int q = refl(v + dv, H) * W + refl(u + du, W);
+                            real cf = ws * (cA + cB * y[q] + cC * x[q]);
+                            gx_adj[2 * q] += am * Wt * cf * px[q].gx[ch];
+                            gx_adj[2 * q + 1] += am * Wt * cf * px[q].gy[ch];
+                            Sx += px[q].gx[ch]; Sy += px[q].gy[ch];
+                        }
+                    const real ninth = (real)1 / 9;
+                    real mx = Sx * ninth, my = Sy * ninth, ex = P->gx[ch] - mx, ey = P->gy[ch] - my;
+                    real w2 = ws * Wt / s.d2 * (real)1.125, w3 = ws * Wt / s.d1;
+                    lxx += w2 * ex * ex + w3 * mx * mx; lxy += w2 * ex * ey + w3 * mx * my; lyy += w2 * ey * ey + w3 * my * my;
+                }
+            }
+            Lam[3 * i] = lxx; Lam[3 * i + 1] = lxy; Lam[3 * i + 2] = lyy;
+            /* e dW/dtheta = -diff * d dd/dtheta (own pixel) */
+            double kdd = sg * 2.0 / ((double)sum * sum);
+            for (int j = 0; j < 6; j++) gxi[j] -= am * diffm[i] * kdd * (P->pd * P->zc[j] - P->cd * P->dpd[j]);
+            own[i] = -am * diffm[i] * kdd * (P->pd * P->zc[6] - P->cd * P->dpd[6]);
+        }
+    /* assemble: pose gradient and per-pixel depth gradient from the adjoint; curvature blocks; Schur complement */
+    memset(out, 0, sizeof(*out));
+    double a = nmask > 0 ? 1.0 / nmask : 0.0;
+    double S[36] = {0}, gs[6] = {0};
+    for (int i = 0; i < n; i++) {
+        const px_t *P = &px[i];
+        double ax = gx_adj[2 * i], ay = gx_adj[2 * i + 1];
+        for (int j = 0; j < 6; j++) gxi[j] += ax * P->a[j] + ay * P->b[j];
+        double gr = a * (ax * P->a[6] + ay * P->b[6] + own[i]);
+        double am = a * M[i], lxx = am * Lam[3 * i], lxy = am * Lam[3 * i + 1], lyy = am * Lam[3 * i + 2];
+        double la6 = lxx * P->a[6] + lxy * P->b[6], lb6 = lxy * P->a[6] + lyy * P->b[6];
+        double D = la6 * P->a[6] + lb6 * P->b[6], B[6];
+        if (w_prior > 0 && depth0) { /* prior on the masked pixels: w sum M ((rho - rho0)/rho0)^2 / sum M */
+            double rho = 1.0 / (double)depth_t[i], rho0 = 1.0 / (double)depth0[i];
+            gr += am * 2.0 * w_prior * (rho - rho0) / (rho0 * rho0);
+            D += am * 2.0 * w_prior / (rho0 * rho0);
+            out->cost_dc += am * w_prior * (rho - rho0) * (rho - rho0) / (rho0 * rho0);
+        }
+        for (int j = 0; j < 6; j++) {
+            double la = lxx * P->a[j] + lxy * P->b[j], lb = lxy * P->a[j] + lyy * P->b[j];
+            B[j] = la * P->a[6] + lb * P->b[6];
+            for (int k = 0; k <= j; k++) Hxx[j * 6 + k] += la * P->a[k] + lb * P->b[k];
+        }
+        if (g_rho) g_rho[i] = gr;
+        if (Dq) Dq[i] = D;
+        if (Bq) for (int j = 0; j < 6; j++) Bq[i * 6 + j] = B[j];
+        double Dd = (1.0 + lambda_depth) * D;
+        if (Dd > 1e-30) {
+            for (int j = 0; j < 6; j++) {
+                gs[j] -= B[j] * gr / Dd;
+                for (int k = 0; k <= j; k++) S[j * 6 + k] -= B[j] * B[k] / Dd;
+            }
+        }
+    }
+    for (int j = 0; j < 6; j++) {
+        out->g[j] = a * gxi[j] + gs[j];
+        for (int k = 0; k <= j; k++) { out->H[j * 6 + k] = Hxx[j * 6 + k] + S[j * 6 + k]; out->H[k * 6 + j] = out->H[j * 6 + k]; }
+    }
+    out->n_mask = nmask;
+    out->cost_photo = a * num;
+    out->cost = out->cost_photo + out->cost_dc;
+    free(px); free(ae); free(rec); free(gx_adj); free(gxi); free(Hxx); free(own); free(M); free(Lam); free(diffm); free(Wm);
+}
+
+/* GN refinement of pose + per-pixel inverse depth (dense BA with per-pixel Schur elimination); depth_io in/out */
+void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
+                      const orc_opts *op, double lambda_depth, double w_prior, double min_depth, double max_depth,
+                      double pose_io[6], double *stats) {
+    int n = H * W;
+    real *ae = (real *)malloc(sizeof(real) * n), *d0 = (real *)malloc(sizeof(real) * n);
+    memcpy(d0, depth_io, sizeof(real) * n);
+    photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
+    double *gr = (double *)malloc(sizeof(double) * n), *Dq = (double *)malloc(sizeof(double) * n), *Bq = (double *)malloc(sizeof(double) * n * 6);
+    double Tc[12];
+    orc_pose_to_T(pose_io, Tc);
+    for (int it = 0; it < op->n_iters; it++) {
+        lin_t L;
+        orc_linearize_dense(H, W, tgt, src, depth_io, depth_s, Tc, K, op, ae, lambda_depth, w_prior, d0, &L, gr, Dq, Bq);
+        if (stats) { stats[4 * it] = L.cost; stats[4 * it + 1] = L.cost_photo; stats[4 * it + 2] = L.n_mask; stats[4 * it + 3] = op->lambda0; }
+        double delta[6], E[12], Tn[12];
+        orc_solve_step(6, L.H, L.g, op->lambda0, delta);
+        orc_se3_exp(delta, E);
+        orc_se3_mul(E, Tc, Tn);
+        memcpy(Tc, Tn, sizeof(Tc));
+        for (int i = 0; i < n; i++) {
+            double Dd = (1.0 + lambda_depth) * Dq[i];
+            if (!(Dd > 1e-30)) continue;
+            double bd = 0;
+            for (int j = 0; j < 6; j++) bd += Bq[i * 6 + j] * delta[j];
+            double rho = 1.0 / (double)depth_io[i] - (gr[i] + bd) / Dd;
+            double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
+            rho = rho < lo ? lo : (rho > hi ? hi : rho);
+            depth_io[i] = (real)(1.0 / rho);
+        }
+    }
+    orc_T_to_pose(Tc, pose_io);
+    free(ae); free(d0); free(gr); free(Dq); free(Bq);
+}
+
 int orc_sizeof_real(void) { return (int)sizeof(real); }

@@ -32,7 +32,7 @@ def test_opts_struct_matches_header(lib):
     o = _lib.default_opts()
     assert (o.n_iters, o.solver, o.param, o.refine, o.automask) == (4, 0, 0, 0, 1)
     assert abs(o.w_l1 - 0.15) < 1e-7 and abs(o.w_ssim - 0.85) < 1e-7 and abs(o.max_depth - 2.67) < 1e-6
-    assert C.sizeof(_lib.Opts) == 8 * 4 + 12 * 4
+    assert C.sizeof(_lib.Opts) == 8 * 4 + 14 * 4
     assert lib.tcsfm_algorithmic_bytes_per_pixel(C.byref(o)) == 32
 
 

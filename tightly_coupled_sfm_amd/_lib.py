@@ -15,7 +15,7 @@ class Opts(C.Structure):
                 ("automask", C.c_int32), ("depth_is_disp", C.c_int32), ("host_ptrs", C.c_int32), ("reserved0", C.c_int32),
                 ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_dc", C.c_float), ("irls_eps", C.c_float),
                 ("lambda0", C.c_float), ("lambda_up", C.c_float), ("lambda_down", C.c_float), ("lambda_min", C.c_float),
-                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prior_scale", C.c_float), ("reserved1", C.c_float)]
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prior_scale", C.c_float), ("lambda_depth", C.c_float), ("prior_depth", C.c_float), ("reserved1", C.c_float)]
 
 
 SOLVER_GN, SOLVER_LM = 0, 1
@@ -40,6 +40,7 @@ _SIGNATURES = {
     "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
     "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
     "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
+    "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_profile_begin": (C.c_int, [_P]),
     "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
     "tcsfm_debug_stamps": (C.c_int, [_P, _P]),

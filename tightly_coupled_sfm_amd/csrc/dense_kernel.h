@@ -1,0 +1,285 @@
+// dense_kernel.h -- dense mode: pose (6) + per-pixel inverse depth of the target, per-pixel Schur complement
+// (BASELINE.json config 5; north star "block-sparse normal equations").  Mirrors orc_linearize_dense / orc_refine_dense.
+//
+// k_dense_linearize uses the ADJOINT form of the 3x3-coupled SSIM gradient: instead of every residual pixel p visiting
+// the geometry of its 9 window pixels (k_linearize pass B), every pixel q gathers d C / d rec_q from the 9 residuals that
+// see it and applies its OWN geometric Jacobian once -- which is also exactly what the per-pixel depth gradient needs.
+//   phase 1   tile + 2-pixel halo : warp, bilinear tap, depth-consistency weight              -> LDS rec1 / aux
+//   phase 2a  tile + 1-pixel halo : SSIM statistics, L1, mask; adjoint coefficient records      -> LDS coef
+//   phase 2b  tile                : gather 9 coefficient records (reflect-pad multiplicities), own L1 / dW terms,
+//                                   pose gradient, depth gradient, curvature blocks H_xx, B_q, D_q, per-pixel Schur
+//                                   elimination; per-pixel (g_rho, Dd, B[6]) record to HBM for the back-substitution
+// The reduced pose system S, g_S leaves the kernel through the same deterministic reduction as k_linearize and is
+// solved by k_solve; k_dense_update then back-substitutes the depth increments.
+#pragma once
+#include "kernels.h"
+
+namespace tc {
+
+struct DenseParams {
+    float *dense_rec;       // [N][H*W][8]  g_rho, Dd, B[6]   (unnormalised: the common 1/sum(M) cancels per pixel)
+    const float *depth0;    // [N][H*W]     initial depth (prior centre)
+    float lambda_depth;     // Marquardt damping of the depth block
+    float w_prior;          // weight of the masked prior  w sum M ((rho - rho0)/rho0)^2 / sum M
+};
+
+template <int TW, int TH, int NT>
+__global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DenseParams Dn) {
+    constexpr int NP = 6;
+    using L = AccLayout<NP>;
+    constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;   // phase-1 region (2-pixel halo)
+    constexpr int W1 = TW + 2, H1 = TH + 2, N1 = W1 * H1;   // phase-2a region (1-pixel halo)
+    constexpr int NCEN = TW * TH;
+    static_assert(NCEN == NT, "one tile pixel per thread");
+    __shared__ float4 rec1[N2 * 3];   // y[3] x[3] gx[3] gy[3]
+    __shared__ float4 aux[N2];        // W, valid, auto_err, -
+    __shared__ float4 coef[N1 * 3];   // w (cA'', cB, cC) per channel: [A0 A1 A2 B0 | B1 B2 C0 C1 | C2 - - -]
+    __shared__ float red[(NT / 64) * L::NACC];
+
+    const int nblk = P.tiles_x * P.tiles_y;
+    int bid = blockIdx.x;
+    {
+        int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = blockIdx.y;
+    const PairConst &c = P.pc[n];
+    const int H = P.H, W = P.W, hw = H * W;
+    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const int x00 = txi * TW, y00 = tyi * TH;
+    const float4 *tgtpack = P.tgtpack + (size_t)c.img * hw;
+    const float4 *srcpack = P.srcpack + (size_t)c.img * hw;
+    const float *depth_t = P.depth_t + (size_t)c.img * hw;
+    const int tid = threadIdx.x;
+
+    // own pixel (tile coordinates) and values carried from phase 1 to phase 2b
+    const int oy = tid / TW, ox = tid - oy * TW;
+    const int gxo = x00 + ox, gyo = y00 + oy;
+    const bool inimg = gxo < W && gyo < H;
+    float a[7], b[7], zc[7];
+    float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f, o_depth = 1.f;
+
+    // ---------------- phase 1 ----------------
+    constexpr int R1 = (N2 + NT - 1) / NT;
+#pragma unroll
+    for (int r = 0; r < R1; r++) {
+        // round 0: own pixel; later rounds: the rest of the region in raster order, skipping the tile interior
+        int lx, ly;
+        bool active = true;
+        if (r == 0) { lx = ox + 2; ly = oy + 2; }
+        else {
+            int hi = tid + (r - 1) * NT;          // index among the N2 - NCEN halo pixels
+            active = hi < N2 - NCEN;
+            // rows 0,1 and H2-2,H2-1 are full rows of W2; the middle TH rows contribute 4 pixels each (2 left, 2 right)
+            if (hi < 2 * W2) { ly = hi / W2; lx = hi - ly * W2; }
+            else if (hi < 4 * W2) { int k = hi - 2 * W2; ly = H2 - 2 + k / W2; lx = k - (k / W2) * W2; }
+            else { int k = hi - 4 * W2; ly = 2 + (k >> 2); int s = k & 3; lx = s < 2 ? s : W2 - 4 + s; }
+        }
+        if (!active) continue;
+        int px = refl_idx(x00 + lx - 2, W), py = refl_idx(y00 + ly - 2, H);
+        int gi = py * W + px;
+        float4 tp = tgtpack[gi];
+        float dep = depth_t[gi];
+        Geo g;
+        warp_geo(c, W, H, px, py, dep, g);
+        const bool oob = g.oobx || g.ooby;
+        float4 val, gx, gy;
+        tap4(srcpack, W, H, px, py, g.rx, g.ry, oob, val, gx, gy);
+        float pd = c.es * val.w, cd = g.Z;
+        float Wt = 1.f - clamp01(fabsf(cd - pd) * frcp(cd + pd));
+        float4 *rec = rec1 + (ly * W2 + lx) * 3;
+        lds_write1(rec + 0, val.x, val.y, val.z, tp.x);
+        lds_write1(rec + 1, tp.y, tp.z, gx.x, gx.y);
+        lds_write1(rec + 2, gx.z, gy.x, gy.y, gy.z);
+        lds_write1(aux + ly * W2 + lx, Wt, oob ? 0.f : 1.f, tp.w, 0.f);
+        if (r == 0) {
+            geo_jac<7>(c, g, W, H, a, b, zc);
+            // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
+            a[6] *= -dep; b[6] *= -dep; zc[6] *= -dep;
+            o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = dep;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---------------- phase 2a: residual + adjoint coefficients for tile + 1-pixel halo ----------------
+    float o_diff = 0.f, o_w = 0.f, o_m = 0.f, o_lxx = 0.f, o_lxy = 0.f, o_lyy = 0.f, o_l1x = 0.f, o_l1y = 0.f;
+    float o_gx[3] = {0, 0, 0}, o_gy[3] = {0, 0, 0}, o_y[3] = {0, 0, 0}, o_x[3] = {0, 0, 0};
+    constexpr int RA = (N1 + NT - 1) / NT;
+#pragma unroll
+    for (int r = 0; r < RA; r++) {
+        int lx, ly;                          // coordinates in the 1-halo region
+        bool active = true;
+        if (r == 0) { lx = ox + 1; ly = oy + 1; }
+        else {
+            int hi = tid + (r - 1) * NT;
+            active = hi < N1 - NCEN;
+            if (hi < W1) { ly = 0; lx = hi; }
+            else if (hi < 2 * W1) { ly = H1 - 1; lx = hi - W1; }
+            else { int k = hi - 2 * W1; ly = 1 + (k >> 1); lx = (k & 1) ? W1 - 1 : 0; }
+        }
+        if (!active) continue;
+        const int gx_ = x00 + lx - 1, gy_ = y00 + ly - 1;
+        const bool real = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;   // residual pixels must exist (no reflection here)
+        const float4 *ctr = rec1 + ((ly + 1) * W2 + lx + 1) * 3;
+        float4 q0, q1, q2;
+        lds_read3(ctr, q0, q1, q2);
+        const float yc[3] = {q0.x, q0.y, q0.z}, xc[3] = {q0.w, q1.x, q1.y};
+        const float gxc[3] = {q1.z, q1.w, q2.x}, gyc[3] = {q2.y, q2.z, q2.w};
+        float4 ax = lds_read1(aux + (ly + 1) * W2 + lx + 1);
+        float Sx[3] = {0, 0, 0}, Sy[3] = {0, 0, 0}, Sxx[3] = {0, 0, 0}, Syy[3] = {0, 0, 0}, Sxy[3] = {0, 0, 0};
+        float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0};
+#pragma unroll 1
+        for (int kk = 0; kk < 9; kk++) {
+            const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
+            float4 n0, n1, n2;
+            lds_read3(ctr + (dy * W2 + dx) * 3, n0, n1, n2);
+            const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
+            const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                float da = xq[ch] - xc[ch], db = yq[ch] - yc[ch];
+                Sx[ch] += da; Sy[ch] += db; Sxx[ch] += da * da; Syy[ch] += db * db; Sxy[ch] += da * db;
+                Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
+            }
+        }
+        const float n9 = 1.f / 9.f;
+        float e1 = 0.f, e2 = 0.f, cA[3], cB[3], cC[3];
+        float l1x = 0.f, l1y = 0.f, lxx = 0.f, lxy = 0.f, lyy = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float mdx = Sx[ch] * n9, mdy = Sy[ch] * n9;
+            float mux = xc[ch] + mdx, muy = yc[ch] + mdy;
+            float sigx = Sxx[ch] * n9 - mdx * mdx, sigy = Syy[ch] * n9 - mdy * mdy, sigxy = Sxy[ch] * n9 - mdx * mdy;
+            float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+            float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+            float idn = frcp(d1 * d2), ratio = n1 * n2 * idn, raw = (1.f - ratio) * 0.5f;
+            bool cl = (raw < 0.f) || (raw > 1.f);
+            e2 += P.ws * clamp01(raw);
+            float pre = cl ? 0.f : -0.5f * idn * n9 * P.ws;
+            cB[ch] = pre * (-ratio * 2.f * d1);
+            cC[ch] = pre * (2.f * n1);
+            // d s/d y_q = cA + cB (y_q - 1/2) + cC (x_q - 1/2)   (re-centred on 1/2 so that p's record serves every q)
+            cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2) - cB[ch] * (muy - 0.5f) - cC[ch] * (mux - 0.5f);
+            float rr = yc[ch] - xc[ch], ar = fabsf(rr);
+            e1 += P.wl * fminf(ar, 1.f);
+            float sgn = (ar <= 1.f) ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : 0.f;
+            l1x += P.wl * sgn * gxc[ch]; l1y += P.wl * sgn * gyc[ch];
+            float w1 = (ar <= 1.f) ? P.wl * frcp(fmaxf(ar, P.eps)) : 0.f;
+            float id1 = cl ? 0.f : P.ws * idn * d2, id2 = cl ? 0.f : 1.125f * P.ws * idn * d1;
+            float mx = Gx[ch] * n9, my = Gy[ch] * n9, ex = gxc[ch] - mx, ey = gyc[ch] - my;
+            lxx += w1 * gxc[ch] * gxc[ch] + id2 * ex * ex + id1 * mx * mx;
+            lxy += w1 * gxc[ch] * gyc[ch] + id2 * ex * ey + id1 * mx * my;
+            lyy += w1 * gyc[ch] * gyc[ch] + id2 * ey * ey + id1 * my * my;
+        }
+        float diff = e1 + e2;
+        float m = (real && ax.y > 0.5f && (!P.automask || diff < ax.z)) ? 1.f : 0.f;
+        float w = m * ax.x;    // M_p W_p
+        float4 *cr = coef + (ly * W1 + lx) * 3;
+        lds_write1(cr + 0, w * cA[0], w * cA[1], w * cA[2], w * cB[0]);
+        lds_write1(cr + 1, w * cB[1], w * cB[2], w * cC[0], w * cC[1]);
+        lds_write1(cr + 2, w * cC[2], 0.f, 0.f, 0.f);
+        if (r == 0) {
+            o_diff = diff; o_w = w; o_m = m; o_lxx = lxx; o_lxy = lxy; o_lyy = lyy; o_l1x = l1x; o_l1y = l1y;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { o_gx[ch] = gxc[ch]; o_gy[ch] = gyc[ch]; o_y[ch] = yc[ch]; o_x[ch] = xc[ch]; }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---------------- phase 2b: adjoint gather, gradients, curvature blocks, per-pixel Schur elimination ----------------
+    float v[L::NH + NP + 3];
+#pragma unroll
+    for (int i = 0; i < L::NH + NP + 3; i++) v[i] = 0.f;
+    if (inimg) {
+        float lam[3] = {0, 0, 0};
+#pragma unroll 1
+        for (int kk = 0; kk < 9; kk++) {
+            const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
+            const int pxx = gxo + dx, pyy = gyo + dy;
+            // reflect-pad multiplicity: how many window slots of residual pixel p map to this pixel q (losses.py:22)
+            int mult = (1 + ((gxo == 1 && pxx == 0) || (gxo == W - 2 && pxx == W - 1) ? 1 : 0)) *
+                       (1 + ((gyo == 1 && pyy == 0) || (gyo == H - 2 && pyy == H - 1) ? 1 : 0));
+            float4 c0, c1, c2;
+            lds_read3(coef + ((oy + 1 + dy) * W1 + ox + 1 + dx) * 3, c0, c1, c2);
+            const float fm = (float)mult;
+            const float cA[3] = {c0.x, c0.y, c0.z}, cB[3] = {c0.w, c1.x, c1.y}, cC[3] = {c1.z, c1.w, c2.x};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) lam[ch] += fm * (cA[ch] + cB[ch] * (o_y[ch] - 0.5f) + cC[ch] * (o_x[ch] - 0.5f));
+        }
+        // d C / d (ix, iy) of this pixel: SSIM adjoint + own L1 term (both carry M W of the residual pixel)
+        float sx = o_w * o_l1x, sy = o_w * o_l1y;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { sx += lam[ch] * o_gx[ch]; sy += lam[ch] * o_gy[ch]; }
+        // depth-consistency weight derivative (own pixel): -M diff d dd/d theta
+        float sum = o_cd + o_pd, dif = o_cd - o_pd, isum = frcp(sum), raw = fabsf(dif) * isum;
+        float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
+        float kdd = o_m * o_diff * sg * 2.f * isum * isum;
+        float grow[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            float dpd = o_dgx * a[j] + o_dgy * b[j];
+            grow[j] = sx * a[j] + sy * b[j] - kdd * (o_pd * zc[j] - o_cd * dpd);
+        }
+        // curvature blocks with Lam' = M W Lam
+        float wxx = o_w * o_lxx, wxy = o_w * o_lxy, wyy = o_w * o_lyy;
+        float la[7], lb[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) { la[j] = wxx * a[j] + wxy * b[j]; lb[j] = wxy * a[j] + wyy * b[j]; }
+        float D = la[6] * a[6] + lb[6] * b[6];
+        float g_rho = grow[6];
+        if (Dn.w_prior > 0.f) {   // masked prior on the relative inverse-depth change
+            float rho = frcp(o_depth), rho0 = frcp(Dn.depth0[(size_t)c.img * hw + gyo * W + gxo]);
+            float ir2 = frcp(rho0 * rho0), dr = rho - rho0;
+            g_rho += o_m * 2.f * Dn.w_prior * dr * ir2;
+            D += o_m * 2.f * Dn.w_prior * ir2;
+            v[L::NH + NP] += o_m * Dn.w_prior * dr * dr * ir2;     // prior cost rides in the sum(M W diff) slot
+        }
+        float Bq[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) Bq[j] = la[j] * a[6] + lb[j] * b[6];
+        const float Dd = (1.f + Dn.lambda_depth) * D;
+        const bool elim = Dd > 1e-30f;
+        const float iD = elim ? frcp(Dd) : 0.f;
+        int h = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            v[L::NH + j] = grow[j] - Bq[j] * g_rho * iD;
+#pragma unroll
+            for (int i = 0; i <= j; i++) { v[h] = la[j] * a[i] + lb[j] * b[i] - Bq[j] * Bq[i] * iD; h++; }
+        }
+        v[L::NH + NP] += o_w * o_diff;
+        v[L::NH + NP + 1] = o_m;
+        float *dr = Dn.dense_rec + ((size_t)n * hw + gyo * W + gxo) * 8;
+        reinterpret_cast<float4 *>(dr)[0] = make_float4(g_rho, elim ? Dd : 0.f, Bq[0], Bq[1]);
+        reinterpret_cast<float4 *>(dr)[1] = make_float4(Bq[2], Bq[3], Bq[4], Bq[5]);
+    }
+    block_reduce_publish<NP, L::NH + NP + 3, true, false, NT>(P, v, red, n, bid, nblk, tid);
+}
+
+// back-substitution: drho_q = -(g_rho_q + B_q' dxi) / Dd_q ;  rho clamped to [1/max_depth, 1/min_depth]
+struct DenseUpdateParams {
+    const float *dense_rec;   // [N][H*W][8]
+    const double *delta;      // [N][8] pose increment of this iteration (written by k_solve)
+    float *depth;             // [N][H*W] in/out
+    int hw;
+    float rho_lo, rho_hi;
+};
+
+__global__ __launch_bounds__(256) void k_dense_update(DenseUpdateParams P) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.y;
+    if (idx >= P.hw) return;
+    const float4 *r = reinterpret_cast<const float4 *>(P.dense_rec + ((size_t)n * P.hw + idx) * 8);
+    float4 r0 = r[0], r1 = r[1];
+    if (!(r0.y > 0.f)) return;
+    const double *d = P.delta + n * 8;
+    float bd = r0.z * (float)d[0] + r0.w * (float)d[1] + r1.x * (float)d[2] + r1.y * (float)d[3] + r1.z * (float)d[4] + r1.w * (float)d[5];
+    float dep = P.depth[(size_t)n * P.hw + idx];
+    float rho = 1.f / dep - (r0.x + bd) / r0.y;
+    rho = fminf(fmaxf(rho, P.rho_lo), P.rho_hi);
+    P.depth[(size_t)n * P.hw + idx] = 1.f / rho;
+}
+
+}  // namespace tc

@@ -409,6 +409,63 @@ __device__ __forceinline__ void lds_write1(float4 *p, float a, float b, float c,
     asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr(p)), "v"(x) : "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup reduction of NLIVE per-thread values -> one record per workgroup -> deterministic in-launch group reduction.
+//   v[]: compacted live values [H photo | g photo | (H dc | g dc) | 3 scalars]; dead accumulators are stored as 0.
+template <int NP, int NLIVE, bool LIN, bool DC, int NT>
+__device__ __forceinline__ void block_reduce_publish(const LinParams &P, const float *v, float *red, int n, int bid, int nblk, int tid) {
+    using L = AccLayout<NP>;
+    constexpr int NPH = L::NH + NP;
+    const int wave = tid >> 6, lane = tid & 63;
+    wave_reduce_store<NLIVE>(v, red + wave * L::NACC, lane);
+    __syncthreads();
+    // A single workgroup can only pull ~6 GB/s of freshly written records (measured: 110 KB = 480 records in 19 us), so the
+    // solve kernel must not read one record per workgroup.  Groups of RG consecutive workgroups reduce themselves: every
+    // workgroup publishes its record, takes a ticket, and the LAST arriver of the group sums the group's records in index
+    // order (fixed order => bit-reproducible, no float atomics) into one group record.
+    // Protocol (cdna_hip_programming.md Guideline 16, counter form): write-through (sc1) record stores -> every storing
+    // wave drains vmcnt -> workgroup barrier -> one relaxed agent-scope ticket; reducer: agent-scope acquire -> drain ->
+    // barrier -> plain loads.  The reducer zeroes the ticket for the next launch (tickets are also zeroed at create
+    // and after a failed call).
+    float *myrec = P.blockrec + ((size_t)n * nblk + bid) * L::NACC;
+    for (int i = tid; i < L::NACC; i += NT) {
+        // accumulator index -> compacted live index (or -1 for a dead accumulator, stored as 0)
+        int li = -1;
+        if (i >= L::OFF_S) li = NLIVE - 3 + (i - L::OFF_S);
+        else if (LIN && (DC || i < NPH)) li = i;
+        float s = 0.f;
+        if (li >= 0)
+            for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + li];
+        __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    const int grp = bid / RG, gfirst = grp * RG, gcount = min(RG, nblk - gfirst);
+    if (tid == 0) {
+        int t = __hip_atomic_fetch_add(&P.tickets[n * P.ngrp + grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gcount - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const float *grec = P.blockrec + ((size_t)n * nblk + gfirst) * L::NACC;
+    for (int i = tid; i < L::NACC; i += NT) {
+        float w[RG];
+#pragma unroll
+        for (int b = 0; b < RG; b++) w[b] = (b < gcount) ? grec[(size_t)b * L::NACC + i] : 0.f;  // RG loads in flight, then a
+        float s = 0.f;                                                                          // fixed-order sum
+#pragma unroll
+        for (int b = 0; b < RG; b++) s += w[b];
+        P.partials[((size_t)n * P.ngrp + grp) * L::NACC + i] = s;
+    }
+    if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
+}
+
 template <int NP, bool DC, int MODE, int TW, int TH, int NT>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
@@ -667,12 +724,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     }
     if (MODE == MODE_MAPS) return;
 
-    // ---------------- workgroup reduction -> one partial record ----------------
-    // live values, compacted: [H photo | g photo | (H dc | g dc) | 3 scalars]; dead accumulators are not reduced
-    constexpr int NPH = L::NH + NP;
-    constexpr int NLIVE = (MODE == MODE_LIN) ? (DC ? L::NACC : NPH + 3) : 3;
-    const int wave = tid >> 6, lane = tid & 63;
+    // ---------------- workgroup reduction -> group record (shared with the dense kernel) ----------------
     {
+        constexpr int NPH = L::NH + NP;
+        constexpr int NLIVE = (MODE == MODE_LIN) ? (DC ? L::NACC : NPH + 3) : 3;
         float v[NLIVE];
         if (MODE == MODE_LIN) {
 #pragma unroll
@@ -687,55 +742,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             }
         }
         v[NLIVE - 3] = sMWd; v[NLIVE - 2] = sM; v[NLIVE - 1] = sdd;
-        wave_reduce_store<NLIVE>(v, red + wave * L::NACC, lane);
+        block_reduce_publish<NP, NLIVE, (MODE == MODE_LIN), DC, NT>(P, v, red, n, bid, nblk, tid);
     }
-    __syncthreads();
-    // ---- in-launch, deterministic two-level reduction -----------------------------------------------------------
-    // A single workgroup can only pull ~6 GB/s of freshly written records (measured: 110 KB = 480 records in 19 us), so the
-    // solve kernel must not read one record per workgroup.  Groups of RG consecutive workgroups reduce themselves: every
-    // workgroup publishes its record, takes a ticket, and the LAST arriver of the group sums the group's records in index
-    // order (fixed order => bit-reproducible, no float atomics) into one group record.
-    // Protocol (cdna_hip_programming.md Guideline 16, counter form): write-through (sc1) record stores -> every storing
-    // wave drains vmcnt -> workgroup barrier -> one relaxed agent-scope ticket; reducer: agent-scope acquire -> drain ->
-    // barrier -> plain loads.  The reducer zeroes the ticket for the next launch (tickets are also zeroed at create
-    // and at the start of every refine call).
-    float *myrec = P.blockrec + ((size_t)n * nblk + bid) * L::NACC;
-    for (int i = tid; i < L::NACC; i += NT) {
-        // accumulator index -> compacted live index (or -1 for a dead accumulator, stored as 0)
-        int li = -1;
-        if (i >= L::OFF_S) li = NLIVE - 3 + (i - L::OFF_S);
-        else if (MODE == MODE_LIN && (DC || i < NPH)) li = i;
-        float s = 0.f;
-        if (li >= 0)
-            for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + li];
-        __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ int s_last;
-    const int grp = bid / RG, gfirst = grp * RG, gcount = min(RG, nblk - gfirst);
-    if (tid == 0) {
-        int t = __hip_atomic_fetch_add(&P.tickets[n * P.ngrp + grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gcount - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const float *grec = P.blockrec + ((size_t)n * nblk + gfirst) * L::NACC;
-    for (int i = tid; i < L::NACC; i += NT) {
-        float v[RG];
-#pragma unroll
-        for (int b = 0; b < RG; b++) v[b] = (b < gcount) ? grec[(size_t)b * L::NACC + i] : 0.f;  // RG loads in flight, then a
-        float s = 0.f;                                                                          // fixed-order sum
-#pragma unroll
-        for (int b = 0; b < RG; b++) s += v[b];
-        P.partials[((size_t)n * P.ngrp + grp) * L::NACC + i] = s;
-    }
-    if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -755,6 +763,7 @@ struct SolveParams {
     int shared_image;
     float *pose_out, *log_scale_out;  // written by the last launch of a refine call (null otherwise)
     long long *dbg;                   // diagnostic builds only: s_memrealtime stamps of the solve phases (null in production)
+    double *delta_out;                // dense mode: [N][8] pose increment of this iteration for k_dense_update (else null)
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -882,6 +891,8 @@ __global__ __launch_bounds__(128) void k_solve(SolveParams P) {
             S.lambda = lambda;
 #pragma unroll
             for (int i = 0; i < NP; i++) delta[i] = dl[i];
+            if (P.delta_out)
+                for (int i = 0; i < NP; i++) P.delta_out[n * 8 + i] = delta[i];
             if (P.param == 0) {
                 retract_se3(delta, Tc, Tt);
                 stry = sc + (NP == 7 ? delta[NP - 1] : 0.0);

@@ -9,13 +9,14 @@
 
 #include "../../include/tcsfm.h"
 #include "kernels.h"
+#include "dense_kernel.h"
 
 using namespace tc;
 
 namespace {
 
 // tile geometry of the hot kernel (one place to retune)
-constexpr int TILE_W = 32, TILE_H = 8, TILE_NT = 256;
+constexpr int TILE_W = 32, TILE_H = 16, TILE_NT = 512;
 
 thread_local std::string g_create_error;
 
@@ -38,6 +39,9 @@ struct tcsfm_ctx {
     double *lin_out = nullptr;   // device [max_pairs][7*7+7+4]
     float *pose_dev = nullptr, *ls_dev = nullptr, *K_dev = nullptr, *stats_dev = nullptr;
     int tiles_x = 0, tiles_y = 0, nblk = 0, ngrp = 0, ngrp_pad = 0, stats_cap_iters = 0;
+    int nblk_alloc = 0, ngrp_alloc = 0;   // scratch capacity (covers the 32x8 tiling of the dense kernel too)
+    float *dense_rec = nullptr, *depth0 = nullptr;   // dense mode scratch, allocated on first use
+    double *delta = nullptr;
     long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
     std::vector<HostStage> stage;
     std::string err;
@@ -213,7 +217,7 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
         // group tickets must be zero when k_linearize starts: zeroed at create, re-zeroed by the reducers after every launch;
         // only a call that failed midway can leave them dirty
         if (h->tickets_dirty) {
-            HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp_alloc * sizeof(int), h->stream));
             h->tickets_dirty = false;
         }
         P.init = *init;
@@ -236,7 +240,7 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
 
 int run_init(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const float *ls, const float *K, int shared) {
     // group tickets must be zero when k_linearize starts; the reducers re-zero them, this covers an aborted earlier call
-    HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp_alloc * sizeof(int), h->stream));
     InitParams I = init_params(h, o, N, pose, ls, K, shared);
     hipLaunchKernelGGL(k_init, dim3((N + 63) / 64), dim3(64), 0, h->stream, I);
     HIPCHK(h, hipGetLastError());
@@ -279,6 +283,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->lambda0 = 1e-4f; o->lambda_up = 10.f; o->lambda_down = 0.1f; o->lambda_min = 1e-5f;
     o->min_depth = 0.06f; o->max_depth = 2.67f;
     o->prior_scale = 1.0f;
+    o->lambda_depth = 1.0f; o->prior_depth = 10.0f;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -296,7 +301,10 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     h->device = device; h->H = H; h->W = W; h->max_pairs = max_pairs;
     h->tiles_x = (W + TILE_W - 1) / TILE_W; h->tiles_y = (H + TILE_H - 1) / TILE_H; h->nblk = h->tiles_x * h->tiles_y;
     h->ngrp = (h->nblk + RG - 1) / RG;
-    h->ngrp_pad = (h->ngrp + 63) / 64 * 64;
+    h->nblk_alloc = ((W + 31) / 32) * ((H + 7) / 8);
+    if (h->nblk_alloc < h->nblk) h->nblk_alloc = h->nblk;
+    h->ngrp_alloc = (h->nblk_alloc + RG - 1) / RG;
+    h->ngrp_pad = (h->ngrp_alloc + 63) / 64 * 64;
     size_t hw = (size_t)H * W, n = max_pairs;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
@@ -306,9 +314,9 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->depth_work, n * hw * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->partials, n * h->ngrp_pad * kMaxAcc * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->partials, 0, n * h->ngrp_pad * kMaxAcc * sizeof(float));  // pad records stay 0
-    if (e == hipSuccess) e = hipMalloc((void **)&h->blockrec, n * h->nblk * kMaxAcc * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->tickets, n * h->ngrp * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(h->tickets, 0, n * h->ngrp * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->blockrec, n * h->nblk_alloc * kMaxAcc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tickets, n * h->ngrp_alloc * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->tickets, 0, n * h->ngrp_alloc * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->state, n * sizeof(PairState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->pconst, n * sizeof(PairConst));
     if (e == hipSuccess) e = hipMalloc((void **)&h->lin_out, n * kLinOut * sizeof(double));
@@ -333,7 +341,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev};
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -592,6 +600,82 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     }
     if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
     if (d_ls_out && (rc = copy_back(h, o, log_scale_out, d_ls_out, (size_t)N))) return rc;
+    if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
+                       float *stats_out) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
+    if (o->w_dc > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth)");
+    if (o->solver != TCSFM_SOLVER_GN || o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: Gauss-Newton on the SE(3) chart only");
+    if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
+    if (!h->dense_rec) {
+        HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->delta, n * 8 * sizeof(double)));
+    }
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose_in;
+    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 5, pose_in, (size_t)N * 6, &d_pose_in))) return rc;
+    float *d_pose_out, *d_depth_out, *d_stats = nullptr;
+    if ((rc = out_dev(h, o, 7, pose_out, (size_t)N * 6, &d_pose_out))) return rc;
+    if ((rc = out_dev(h, o, 8, depth_out, N * hw, &d_depth_out))) return rc;
+    const size_t nstats = (size_t)N * (o->n_iters + 1) * TCSFM_NSTAT;
+    if (stats_out) {
+        if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
+        HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
+    }
+    tcsfm_opts oo = *o;
+    oo.refine = TCSFM_REFINE_POSE;
+    InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->depth0, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    // the dense kernel uses 32x8 tiles: its own tile grid and reduction-group count
+    constexpr int DTW = 32, DTH = 8, DNT = 256;
+    LinParams P = lin_params(h, &oo, 6);
+    P.tiles_x = (h->W + DTW - 1) / DTW; P.tiles_y = (h->H + DTH - 1) / DTH;
+    const int nblk = P.tiles_x * P.tiles_y;
+    P.ngrp = (nblk + RG - 1) / RG;
+    if ((size_t)nblk > (size_t)h->nblk_alloc || P.ngrp > h->ngrp_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
+    SolveParams S = solve_params(h, &oo, 6, 0);
+    S.ngrp = P.ngrp; S.stats = d_stats; S.delta_out = h->delta;
+    DenseParams Dn;
+    Dn.dense_rec = h->dense_rec; Dn.depth0 = h->depth0; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
+    DenseUpdateParams U;
+    U.dense_rec = h->dense_rec; U.delta = h->delta; U.depth = h->depth_work; U.hw = (int)hw;
+    U.rho_lo = 1.f / o->max_depth; U.rho_hi = 1.f / o->min_depth;
+    for (int it = 0; it < o->n_iters; it++) {
+        {
+            ProfScope prof(h, 0);
+            hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
+        }
+        S.it = it; S.mode = 0;
+        const bool last = it == o->n_iters - 1;
+        S.pose_out = last ? d_pose_out : nullptr; S.log_scale_out = nullptr;
+        launch_solve(h, S, N, 6);
+        hipLaunchKernelGGL(k_dense_update, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, U);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (o->n_iters == 0) {
+        FinishParams F;
+        F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = nullptr; F.N = N;
+        hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
+    }
+    HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
+    if ((rc = copy_back(h, o, depth_out, d_depth_out, N * hw))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;

@@ -192,6 +192,17 @@ class Engine:
                                          self._p(K), self._p(pose), self._p(ls_in), self._p(pose_out), self._p(ls_out), self._p(st)))
         return pose_out, ls_out, st
 
+    def refine_dense(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, stats: bool = False):
+        """Dense mode: refine pose AND per-pixel inverse depth of the target (per-pixel Schur complement).
+        -> (pose [N,6], depth [N,1,H,W], stats or None); opts.lambda_depth / opts.prior_depth / min_depth / max_depth apply."""
+        o = opts or default_opts()
+        N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
+        pose_out, depth_out = torch.empty_like(pose), torch.empty_like(depth_t)
+        st = torch.empty((N, o.n_iters + 1, _lib.NSTAT), device=pose.device, dtype=torch.float32) if stats else None
+        self._call(self.lib.tcsfm_refine_dense(self._h, C.byref(o), N, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s),
+                                               self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out), self._p(st)))
+        return pose_out, depth_out, st
+
     def refine_into(self, tgt, src, depth_t, depth_s, K, pose_in, pose_out, opts: Opts, log_scale_in=None, log_scale_out=None,
                     stats_out=None):
         """Zero-allocation variant used by bench.py: tensors must already be validated/contiguous; pose_out may alias pose_in."""
