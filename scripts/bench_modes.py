@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Secondary timings for DESIGN.md (NOT the bench.py metric): the other BASELINE.json configs on one GPU.
+   #2 B=1 pose, #3 8 windows/GPU (64 over 8 GPUs), #4 pose+scale 8 iters, #5 dense 320x240 and 448x256."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tightly_coupled_sfm_amd import synth
+from tightly_coupled_sfm_amd.engine import Engine, default_opts
+
+def run(name, H, W, npairs, opts, dense=False, steps=300, warm=30):
+    b = synth.make_batch(npairs, H, W, seed0=0, both_directions=True)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    e = Engine(H, W, npairs)
+    out = torch.empty_like(d["pose_init"])
+    def step():
+        if dense:
+            e.refine_dense(d["tgt"], d["src"], d["depth_t"], d["depth_s"], d["K"], d["pose_init"], opts)
+        else:
+            e.refine_into(d["tgt"], d["src"], d["depth_t"], d["depth_s"], d["K"], d["pose_init"], out, opts)
+    for _ in range(warm): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    e.profile_begin()
+    for _ in range(50): step()
+    pr = e.profile_end()
+    lin_us = pr["linearize"][0] / max(pr["linearize"][1], 1) * 1e3
+    bpp = 36 + (64 if dense else 0)
+    print(json.dumps({"config": name, "HxW": f"{H}x{W}", "directed_pairs": npairs, "iters": opts.n_iters, "us_per_call": round(dt * 1e6, 1),
+                      "windows_per_s": round(npairs / 2 / dt, 1), "linearize_us": round(lin_us, 2),
+                      "linearize_GBps_algorithmic32": round(32 * H * W * npairs / lin_us / 1e3, 1)}))
+
+run("#2 B=1 pose", 192, 640, 2, default_opts(n_iters=4))
+run("#3 8 windows per GPU pose", 192, 640, 16, default_opts(n_iters=4))
+run("#3' 64 windows on ONE GPU pose", 192, 640, 128, default_opts(n_iters=4), steps=50, warm=5)
+run("#4 pose+scale 8 iters", 192, 640, 2, default_opts(n_iters=8, refine=1))
+run("#5 dense 320x240", 240, 320, 2, default_opts(n_iters=4, min_depth=0.03, max_depth=3.0), dense=True)
+run("#5 dense 448x256", 256, 448, 2, default_opts(n_iters=4, min_depth=0.03, max_depth=3.0), dense=True)
+run("dense 640x192", 192, 640, 2, default_opts(n_iters=4), dense=True)

@@ -457,10 +457,10 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
     for (int i = tid; i < L::NACC; i += NT) {
         float w[RG];
 #pragma unroll
-        for (int b = 0; b < RG; b++) w[b] = (b < gcount) ? grec[(size_t)b * L::NACC + i] : 0.f;  // RG loads in flight, then a
-        float s = 0.f;                                                                          // fixed-order sum
+        for (int b = 0; b < RG; b++) w[b] = grec[(size_t)(b < gcount ? b : 0) * L::NACC + i];  // RG UNCONDITIONAL loads in flight
+        float s = 0.f;                                         // (a predicated load makes hipcc branch + vmcnt(0) per element)
 #pragma unroll
-        for (int b = 0; b < RG; b++) s += w[b];
+        for (int b = 0; b < RG; b++) s += (b < gcount) ? w[b] : 0.f;   // fixed-order sum
         P.partials[((size_t)n * P.ngrp + grp) * L::NACC + i] = s;
     }
     if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
@@ -801,9 +801,9 @@ __global__ __launch_bounds__(128) void k_solve(SolveParams P) {
         for (int g0 = 0; g0 < P.ngrp; g0 += 32) {
             float v[32];
 #pragma unroll
-            for (int j = 0; j < 32; j++) v[j] = (g0 + j < P.ngrp) ? p[(size_t)(g0 + j) * L::NACC] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 32; j++) s += (double)v[j];
+            for (int j = 0; j < 32; j++) v[j] = p[(size_t)(g0 + j < P.ngrp ? g0 + j : 0) * L::NACC];  // unconditional: a predicated
+#pragma unroll                                                              // load compiles to branch + vmcnt(0) per element (3.9 us)
+            for (int j = 0; j < 32; j++) s += (g0 + j < P.ngrp) ? (double)v[j] : 0.0;
         }
         tot[tid] = s;
     }
