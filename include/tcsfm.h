@@ -143,6 +143,14 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
                        const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
                        float *stats_out);
 
+/* ScaleRecovery.forward, models/dnet_layers.py:249-327 (the step right after the path in optimize_window,
+ * optimizer.py:254-258): camera-height map |P.n| from 8-neighbour surface normals, ground mask, exact lower median of the
+ * masked heights over the batch, scale = real_cam_height / median.  pad_to_batch mirrors the reference's padding of a short
+ * batch with copies of image 0 (dnet_layers.py:307-311; pass config['minibatch'], or 0 for none).
+ * scale_out [1]; optional: median_out [1], height_out / mask_out [N,1,H,W]. */
+int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,
+                         int pad_to_batch, float *scale_out, float *median_out, float *height_out, float *mask_out);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 
 /* While profiling is on, every launch of the three kernel classes is bracketed by a pair of HIP events recorded on the

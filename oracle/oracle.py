@@ -54,6 +54,7 @@ class Oracle:
         self.lib = C.CDLL(os.path.join(_BUILD, f"liboracle_{precision}.so"))
         assert self.lib.orc_sizeof_real() == np.dtype(self.dt).itemsize
         self.lib.orc_cost.restype = C.c_double
+        self.lib.orc_scale_recovery.restype = C.c_double
 
     # -- helpers ---------------------------------------------------------
     def _r(self, a):
@@ -185,6 +186,22 @@ class Oracle:
                                   C.c_double(lambda_depth), C.c_double(w_prior), C.c_double(min_depth), C.c_double(max_depth),
                                   self._p(pose), self._p(stats))
         return pose, depth, stats
+
+    def ground_height(self, depth, K):
+        """DNet camera-height map and ground mask of one image (dnet_layers.py:259-304,319-322)"""
+        depth, K = self._r(depth), self._r(K)
+        H, W = depth.shape
+        h, m = np.empty((H, W), self.dt), np.empty((H, W), self.dt)
+        self.lib.orc_ground_height(H, W, self._p(depth), self._p(K), self._p(h), self._p(m))
+        return h, m
+
+    def scale_recovery(self, depth, K, real_cam_height):
+        """ScaleRecovery.forward for a batch: depth [B,H,W], K [B,3,3] -> (scale, median camera height)"""
+        depth, K = self._r(depth), self._r(K)
+        B, H, W = depth.shape
+        med = C.c_double()
+        s = self.lib.orc_scale_recovery(B, H, W, self._p(depth), self._p(K), C.c_double(real_cam_height), C.byref(med))
+        return s, med.value
 
     def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
         """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4])."""

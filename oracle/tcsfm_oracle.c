@@ -924,4 +924,76 @@ void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *dept
     free(ae); free(d0); free(gr); free(Dq); free(Bq);
 }
 
+/* ------------------------------------------------------------------------- */
+/* DNet ground-plane scale recovery, models/dnet_layers.py:249-327                            */
+
+static void v3_norm(real *v) { /* F.normalize: v / max(|v|, 1e-12) */
+    real n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (n < (real)1e-12) n = (real)1e-12;
+    v[0] /= n; v[1] /= n; v[2] /= n;
+}
+static void v3_cross_norm(const real *a, const real *b, const real *c, real *o) { /* normalize((a-c) x (b-c)) */
+    real u[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]}, w[3] = {b[0] - c[0], b[1] - c[1], b[2] - c[2]};
+    o[0] = u[1] * w[2] - u[2] * w[1]; o[1] = u[2] * w[0] - u[0] * w[2]; o[2] = u[0] * w[1] - u[1] * w[0];
+    v3_norm(o);
+}
+
+/* per image: camera height map |P.n| and ground mask (dnet_layers.py:259-304,319-322); depth [H,W], K 3x3 */
+void orc_ground_height(int H, int W, const real *depth, const real *K, real *height, real *mask) {
+    double Kd[9], Ki[9];
+    for (int i = 0; i < 9; i++) Kd[i] = K[i];
+    mat3_inv(Kd, Ki);
+    int n = H * W;
+    real *P = (real *)malloc(sizeof(real) * 3 * n), *N = (real *)calloc((size_t)3 * n, sizeof(real));
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++)
+            for (int k = 0; k < 3; k++)   /* BackprojectDepth, dnet_layers.py:159-163 */
+                P[3 * (v * W + u) + k] = depth[v * W + u] * ((real)Ki[3 * k] * u + (real)Ki[3 * k + 1] * v + (real)Ki[3 * k + 2]);
+#define PT(vv, uu) (P + 3 * ((vv) * W + (uu)))
+    for (int v = 1; v < H - 1; v++)
+        for (int u = 1; u < W - 1; u++) { /* get_surface_normal, dnet_layers.py:259-287 */
+            const real *c = PT(v, u);
+            real n0[3], n1[3], n2[3], n3[3], m[3];
+            v3_cross_norm(PT(v, u - 1), PT(v - 1, u), c, n0);
+            v3_cross_norm(PT(v, u + 1), PT(v + 1, u), c, n1);
+            v3_cross_norm(PT(v - 1, u - 1), PT(v + 1, u - 1), c, n2);
+            v3_cross_norm(PT(v - 1, u + 1), PT(v + 1, u + 1), c, n3);
+            for (int k = 0; k < 3; k++) m[k] = (n0[k] + n1[k] + n2[k] + n3[k]) / 4;
+            v3_norm(m);
+            for (int k = 0; k < 3; k++) N[3 * (v * W + u) + k] = m[k];
+        }
+    const real thr = (real)cos(5.0 * 3.14159265358979323846 / 180.0);
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            /* ReflectionPad2d(1) of the (H-2)x(W-2) normal map, dnet_layers.py:289-290 */
+            int rv = v == 0 ? 2 : (v == H - 1 ? H - 3 : v), ru = u == 0 ? 2 : (u == W - 1 ? W - 3 : u);
+            const real *nn = N + 3 * (rv * W + ru), *p = PT(v, u);
+            real nrm = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            real cs = nn[1] / (nrm > (real)1e-6 ? nrm : (real)1e-6);      /* CosineSimilarity(eps=1e-6) with (0,1,0) */
+            int g = ((cs > thr) || (cs < -thr)) && (p[1] > 0);
+            mask[v * W + u] = (real)g;
+            height[v * W + u] = fabs(p[0] * nn[0] + p[1] * nn[1] + p[2] * nn[2]);
+        }
+#undef PT
+    free(P); free(N);
+}
+
+static int cmp_real(const void *a, const void *b) { real x = *(const real *)a, y = *(const real *)b; return (x > y) - (x < y); }
+
+/* ScaleRecovery.forward (dnet_layers.py:306-327): lower median of the masked heights of the WHOLE batch */
+double orc_scale_recovery(int nimg, int H, int W, const real *depth, const real *K, double real_cam_height, double *median_out) {
+    int n = H * W;
+    real *h = (real *)malloc(sizeof(real) * n), *m = (real *)malloc(sizeof(real) * n), *sel = (real *)malloc(sizeof(real) * n * nimg);
+    size_t cnt = 0;
+    for (int b = 0; b < nimg; b++) {
+        orc_ground_height(H, W, depth + (size_t)b * n, K + 9 * b, h, m);
+        for (int i = 0; i < n; i++) if (m[i] > 0) sel[cnt++] = h[i];
+    }
+    double med = NAN;
+    if (cnt) { qsort(sel, cnt, sizeof(real), cmp_real); med = sel[(cnt - 1) / 2]; }   /* torch.median: lower median */
+    if (median_out) *median_out = med;
+    free(h); free(m); free(sel);
+    return real_cam_height / med;
+}
+
 int orc_sizeof_real(void) { return (int)sizeof(real); }

@@ -242,6 +242,36 @@ def main():
                           post=lh.batch_post_process_disparity(l, r_), avg_list=np.stack([N(x) for x in lst]),
                           avg5=N(helpers.avg_final_predictions(lst, 5)))
 
+    # ------------------------------------------------------------------ G10: DNet ScaleRecovery
+    # get_ground_mask hard-codes .cuda() (dnet_layers.py:298); on this GPU-less box the call is made a no-op for the
+    # duration of the run -- the arithmetic is untouched.
+    from models import dnet_layers
+    B, H, W = 2, 48, 160
+    ps = [synth.make_pair(H, W, seed=60 + b, dtype=np.float32) for b in range(B)]
+    depth = np.stack([p["depth_t"] for p in ps]) * np.array([1.0, 1.3], dtype=np.float32)[:, None, None]
+    Kb = np.stack([p["K"] for p in ps])
+    K4 = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1)); K4[:, :3, :3] = Kb
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        g10 = dict(depth=depth, K=Kb, cam_height=np.array(1.65 / 30.0))
+        for dtn, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            sr = dnet_layers.ScaleRecovery(B, H, W)
+            if dt == torch.float64:
+                sr = sr.double()
+            d_t, K_t = T(depth, dt)[:, None], T(K4, dt)
+            inv_K = torch.inverse(K_t)
+            cam = sr.backproject_depth(d_t, inv_K)
+            nrm = sr.get_surface_normal(cam)
+            gm = sr.get_ground_mask(cam, nrm)
+            hts = (cam[:, :-1] * nrm).sum(1).abs()
+            g10[f"{dtn}_height"] = N(hts); g10[f"{dtn}_mask"] = N(gm[:, 0].float())
+            g10[f"{dtn}_scale"] = N(sr(d_t, K_t, 1.65 / 30.0))
+            g10[f"{dtn}_median"] = N(torch.median(torch.masked_select(hts.unsqueeze(1), gm)))
+    finally:
+        torch.Tensor.cuda = _cuda
+    out["scale48x160"] = g10
+
     # ------------------------------------------------------------------ full-size summary (192x640, f32 as run by the reference)
     H, W, seed = 192, 640, 0
     p = synth.make_pair(H, W, seed=seed, dtype=np.float32)

@@ -333,3 +333,23 @@ def test_dense_pose_block_equals_pose_mode(oracle64):
     ra = pa.cpu().numpy(); rb = pb.cpu().numpy()
     assert np.max(np.abs(ra - rb)) < 2e-6 * np.abs(ra).max()
     assert _maxabs(depth.cpu().numpy(), b["depth_t"]) < 1e-6
+
+
+def test_scale_recovery_vs_reference_golden(oracle64):
+    """DNet ScaleRecovery (dnet_layers.py:249-327): height map, ground mask, exact batch median and scale against the
+    reference's own run (golden G10) -- the median by an integer-histogram radix select, no sort"""
+    g = load_golden("scale48x160")
+    B, H, W = g["depth"].shape
+    e = _eng(H, W, B)
+    scale, med, hm, mm = e.scale_recovery(_t(g["depth"][:, None]), _t(g["K"]), float(g["cam_height"]), maps=True)
+    assert (mm.cpu().numpy()[:, 0] != g["f64_mask"]).mean() <= 0.002
+    ok = mm.cpu().numpy()[:, 0] == g["f64_mask"]
+    assert _maxabs(hm.cpu().numpy()[:, 0][ok], g["f64_height"][ok]) < 2e-6
+    assert abs(float(med) - float(g["f32_median"])) <= 2e-7 and abs(float(scale) - float(g["f32_scale"][0])) < 1e-5
+    # batch padding with copies of image 0, as the reference does for a short batch
+    one = e.scale_recovery(_t(g["depth"][:1, None]), _t(g["K"][:1]), float(g["cam_height"]), pad_to_batch=4)
+    s1, m1 = oracle64.scale_recovery(np.repeat(g["depth"][:1], 4, 0), np.repeat(g["K"][:1], 4, 0), float(g["cam_height"]))
+    assert abs(float(one) - s1) < 1e-5 * s1
+    # no ground at all -> NaN, not garbage
+    up = _t(np.full((1, 1, H, W), 0.5, dtype=np.float32))
+    assert torch.isnan(_eng(H, W, 1).scale_recovery(up, _t(g["K"][:1]), 0.055))

@@ -168,3 +168,14 @@ def test_helpers_G8(oracle64):
     g = load_golden("helpers")
     s, d = oracle64.disp_to_depth(g["disp"], 0.06, 2.67)
     assert _maxabs(s, g["scaled_disp"]) < 1e-13 and _maxabs(d, g["depth"]) < 1e-13
+
+
+def test_scale_recovery_G10(oracle64, oracle32):
+    """DNet ScaleRecovery (dnet_layers.py:249-327) against the reference run on CPU"""
+    g = load_golden("scale48x160")
+    for O, p, tol in ((oracle64, "f64", 1e-12), (oracle32, "f32", 1e-6)):
+        for b in range(2):
+            h, m = O.ground_height(g["depth"][b], g["K"][b])
+            assert np.array_equal(m, g[f"{p}_mask"][b]) and _maxabs(h, g[f"{p}_height"][b]) < tol
+        s, med = O.scale_recovery(g["depth"], g["K"], float(g["cam_height"]))
+        assert abs(med - float(g[f"{p}_median"])) < tol and abs(s - float(g[f"{p}_scale"][0])) < 10 * tol

@@ -10,6 +10,7 @@
 #include "../../include/tcsfm.h"
 #include "kernels.h"
 #include "dense_kernel.h"
+#include "scale_kernel.h"
 
 using namespace tc;
 
@@ -42,6 +43,7 @@ struct tcsfm_ctx {
     int nblk_alloc = 0, ngrp_alloc = 0;   // scratch capacity (covers the 32x8 tiling of the dense kernel too)
     float *dense_rec = nullptr, *depth0 = nullptr;   // dense mode scratch, allocated on first use
     double *delta = nullptr;
+    unsigned *scale_keys = nullptr, *scale_hist = nullptr;   // scale recovery scratch (keys, 256 bins + 4 state words)
     long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
     std::vector<HostStage> stage;
     std::string err;
@@ -341,7 +343,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta};
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -601,6 +603,49 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
     if (d_ls_out && (rc = copy_back(h, o, log_scale_out, d_ls_out, (size_t)N))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,
+                         int pad_to_batch, float *scale_out, float *median_out, float *height_out, float *mask_out) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!depth || !K || !scale_out) return fail(h, TCSFM_E_ARG, "tcsfm_scale_recovery: NULL argument");
+    if (h->H < 5 || h->W < 5) return fail(h, TCSFM_E_ARG, "tcsfm_scale_recovery: image too small");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    const size_t hw = (size_t)h->H * h->W;
+    if (!h->scale_keys) {
+        HIPCHK(h, hipMalloc((void **)&h->scale_keys, (size_t)h->max_pairs * hw * sizeof(unsigned)));
+        HIPCHK(h, hipMalloc((void **)&h->scale_hist, 260 * sizeof(unsigned)));
+    }
+    const float *d_depth, *d_K;
+    float *d_scale, *d_med, *d_h, *d_m;
+    if ((rc = to_dev(h, o, 0, depth, N * hw, &d_depth))) return rc;
+    if ((rc = to_dev(h, o, 1, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = out_dev(h, o, 2, scale_out, (size_t)1, &d_scale))) return rc;
+    if ((rc = out_dev(h, o, 3, median_out, (size_t)1, &d_med))) return rc;
+    if ((rc = out_dev(h, o, 4, height_out, N * hw, &d_h))) return rc;
+    if ((rc = out_dev(h, o, 5, mask_out, N * hw, &d_m))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->scale_hist, 0, 260 * sizeof(unsigned), h->stream));
+    GroundParams G;
+    G.depth = d_depth; G.K = d_K; G.height = d_h; G.mask = d_m; G.keys = h->scale_keys; G.H = h->H; G.W = h->W;
+    hipLaunchKernelGGL(k_ground, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, G);
+    // the reference pads the batch to config['minibatch'] with copies of image 0 (dnet_layers.py:307-311): weight image 0
+    const int w0 = 1 + (pad_to_batch > N ? pad_to_batch - N : 0);
+    unsigned *hist = h->scale_hist, *state = h->scale_hist + 256;
+    const int nb = (int)((hw + 255) / 256) < 64 ? (int)((hw + 255) / 256) : 64;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(nb, N), dim3(256), 0, h->stream, (const unsigned *)h->scale_keys, (int)hw, w0,
+                           (const unsigned *)state, shift, hist);
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(64), 0, h->stream, hist, state, shift, real_cam_height, d_scale, d_med);
+    }
+    HIPCHK(h, hipGetLastError());
+    if ((rc = copy_back(h, o, scale_out, d_scale, (size_t)1))) return rc;
+    if ((rc = copy_back(h, o, median_out, d_med, (size_t)1))) return rc;
+    if ((rc = copy_back(h, o, height_out, d_h, N * hw))) return rc;
+    if ((rc = copy_back(h, o, mask_out, d_m, N * hw))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;
 }

@@ -203,6 +203,19 @@ class Engine:
                                                self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out), self._p(st)))
         return pose_out, depth_out, st
 
+    def scale_recovery(self, depth, intrinsics, real_cam_height: float, pad_to_batch: int = 0, maps: bool = False):
+        """ScaleRecovery.forward (dnet_layers.py:306-327): depth [N,1,H,W], K [N,3,3] -> scale [1] (GPU tensor)
+        (+ median [1], height [N,1,H,W], mask [N,1,H,W] with maps=True)"""
+        N = depth.shape[0]
+        depth = _chk(depth, (N, 1, self.H, self.W), "depth"); K = _chk(intrinsics, (N, 3, 3), "intrinsics")
+        scale = torch.empty(1, device=depth.device, dtype=torch.float32); med = torch.empty_like(scale)
+        hm = torch.empty_like(depth) if maps else None
+        mm = torch.empty_like(depth) if maps else None
+        o = default_opts()
+        self._call(self.lib.tcsfm_scale_recovery(self._h, C.byref(o), N, self._p(depth), self._p(K), float(real_cam_height),
+                                                 int(pad_to_batch), self._p(scale), self._p(med), self._p(hm), self._p(mm)))
+        return (scale, med, hm, mm) if maps else scale
+
     def refine_into(self, tgt, src, depth_t, depth_s, K, pose_in, pose_out, opts: Opts, log_scale_in=None, log_scale_out=None,
                     stats_out=None):
         """Zero-allocation variant used by bench.py: tensors must already be validated/contiguous; pose_out may alias pose_in."""

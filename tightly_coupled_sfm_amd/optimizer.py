@@ -171,11 +171,9 @@ class DepthOptimizer:
         res["depths_opt"] = depths
 
         if self.options.get("mode", "scaled") == "unscaled":
-            rec = self.options.get("scale_recovery")
-            if rec is None:
-                raise NotImplementedError("mode='unscaled' needs the DNet ground-plane ScaleRecovery (SURVEY 8f, next); "
-                                          "pass options['scale_recovery'] = callable(depth, K, camera_height)")
-            sf = rec(depths[0].clone(), intrinsics, cfg["camera_height"] / 30.0)
+            # DNet ground-plane rescaling, optimizer.py:254-256 (self.dgc = ScaleRecovery(minibatch, 192, 640))
+            sf = eng.scale_recovery(depths[0].contiguous(), intrinsics.float().contiguous(), cfg["camera_height"] / 30.0,
+                                    pad_to_batch=int(cfg.get("minibatch", B))).cpu()
         else:
             sf = torch.FloatTensor([1])
         res["scale_factor"] = sf
