@@ -399,6 +399,15 @@ __device__ __forceinline__ void lds_read3b(const float4 *p, float4 &a, float4 &b
                  : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(lds_addr(p)) : "memory");
     a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
 }
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_read3v(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c) {   // record floats 0..11
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
+__device__ __forceinline__ void lds_read3bv(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c) {  // record floats 12..23
+    asm volatile("ds_read_b128 %0, %3 offset:48\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
 __device__ __forceinline__ float4 lds_read1(const float4 *p) {
     f32x4 x;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(lds_addr(p)) : "memory");
@@ -526,9 +535,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float a[NP], b[NP], zc[NP];
         geo_jac<NP>(c, g, W, H, a, b, zc);
         float4 *rec = lds + (ly * CW + lx) * (LDS_REC / 4);
-        lds_write1(rec + 0, val.x, val.y, val.z, tp.x);
-        lds_write1(rec + 1, tp.y, tp.z, gx.x, gx.y);
-        lds_write1(rec + 2, gx.z, gy.x, gy.y, gy.z);
+        // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0..a3][a4 a5 b0 b1][b2..b5]([a6 b6 - -]) : channel pairs and
+        // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles
+        lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
+        lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+        lds_write1(rec + 2, val.z, tp.z, gx.z, gy.z);
         lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
         lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
         lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
@@ -546,44 +557,47 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     __syncthreads();
 
     // ---------------- phase 2: residuals, gradient rows, curvature, accumulation ----------------
-    float aHP[L::NH], aGP[NP], aHD[DC ? L::NH : 1], aGD[DC ? NP : 1];
+    // Packed fp32 throughout: channels (0,1) travel as one f2, channel 2 shares an f2 with its partner quantity, Jacobian
+    // columns travel as pairs (01)(23)(45).  H is accumulated as 12 (+4 for NP=7) row-pair f2's: rows j, column pairs p <= j/2.
+    constexpr int NHP = (NP == 6) ? 12 : 16;     // f2 accumulators of the lower triangle (some upper entries ride along)
+    f2 aH2[NHP], aG2[3], dH2[DC ? NHP : 1], dG2[DC ? 3 : 1];
+    float aH66 = 0.f, aG6 = 0.f, dH66 = 0.f, dG6 = 0.f;   // NP == 7: the (6,6) entry and g[6]
     float sMWd = 0.f, sM = 0.f, sdd = 0.f;
 #pragma unroll
-    for (int i = 0; i < L::NH; i++) { aHP[i] = 0.f; if (DC) aHD[i] = 0.f; }
+    for (int i = 0; i < NHP; i++) { aH2[i] = (f2){0.f, 0.f}; if (DC) dH2[i] = (f2){0.f, 0.f}; }
 #pragma unroll
-    for (int i = 0; i < NP; i++) { aGP[i] = 0.f; if (DC) aGD[i] = 0.f; }
+    for (int i = 0; i < 3; i++) { aG2[i] = (f2){0.f, 0.f}; if (DC) dG2[i] = (f2){0.f, 0.f}; }
 
 #pragma unroll
     for (int k = 0; k < PPT; k++) {
         int ci = tid + k * NT;
         int ly = ci / TW + 1, lx = ci - (ci / TW) * TW + 1;
         const float4 *ctr = lds + (ly * CW + lx) * (LDS_REC / 4);
-        float4 q0, q1, q2;
-        lds_read3(ctr, q0, q1, q2);
-        const float yc[3] = {q0.x, q0.y, q0.z}, xc[3] = {q0.w, q1.x, q1.y};
-        const float gxc[3] = {q1.z, q1.w, q2.x}, gyc[3] = {q2.y, q2.z, q2.w};
+        f32x4 q0, q1, q2;
+        lds_read3v(ctr, q0, q1, q2);
+        const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = q1.lo, gyc01 = q1.hi, yx2c = q2.lo, g2c = q2.hi;
+        const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
+        const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
 
-        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances).
-        // Rolled on purpose (one neighbour live at a time): full unrolling costs >256 VGPRs and all the occupancy.
-        // Every float4 of a record is consumed whole: a partially used one is narrowed by hipcc to ds_read_b64/b96, whose
-        // banking conflicts on the 112-byte record stride (measured: 45 % of LDS cycles were conflict cycles).
-        float Sx[3] = {0, 0, 0}, Sy[3] = {0, 0, 0}, Sxx[3] = {0, 0, 0}, Syy[3] = {0, 0, 0}, Sxy[3] = {0, 0, 0};
-        float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0};  // window sums of the image gradient (curvature model)
+        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances) + gradient window
+        // sums.  Rolled (one neighbour live at a time); 14 packed instructions per neighbour.
+        f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f};
+        f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f}, G2 = {0.f, 0.f};
+        float Sxy2 = 0.f;
 #pragma unroll 1
         for (int kk = 0; kk < 9; kk++) {
             const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
-            const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
-            float4 n0, n1, n2;
-            lds_read3(nb, n0, n1, n2);
-            const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
-            const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                float a = xq[ch] - xc[ch], b = yq[ch] - yc[ch];
-                Sx[ch] += a; Sy[ch] += b; Sxx[ch] += a * a; Syy[ch] += b * b; Sxy[ch] += a * b;
-                Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
-            }
+            f32x4 n0, n1, n2;
+            lds_read3v(ctr + (dy * CW + dx) * (LDS_REC / 4), n0, n1, n2);
+            f2 ey = n0.lo - yc01, ex = n0.hi - xc01;
+            Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+            Gx01 += n1.lo; Gy01 += n1.hi;
+            f2 e2v = n2.lo - yx2c;               // (y2 - y2c, x2 - x2c)
+            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
         }
+        const float Sx[3] = {Sx01.x, Sx01.y, S2.y}, Sy[3] = {Sy01.x, Sy01.y, S2.x};
+        const float Sxx[3] = {Sxx01.x, Sxx01.y, SS2.y}, Syy[3] = {Syy01.x, Syy01.y, SS2.x}, Sxy[3] = {Sxy01.x, Sxy01.y, Sxy2};
+        const float Gx[3] = {Gx01.x, Gx01.y, G2.x}, Gy[3] = {Gy01.x, Gy01.y, G2.y};
         const float n9 = 1.f / 9.f;
         float e1 = 0.f, e2 = 0.f;
         float cA[3], cB[3], cC[3], id1[3], id2[3];
@@ -617,32 +631,28 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
         float diff = e1 + e2;
 
-        float de[NP];  // d(e1 + e2)/d theta
-#pragma unroll
-        for (int j = 0; j < NP; j++) de[j] = 0.f;
+        f2 de2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // d(e2)/d theta, column pairs (01)(23)(45)
+        float de6 = 0.f;
         if (MODE == MODE_LIN) {
-            // pass B: exact SSIM gradient rows (neighbour geometry included)
+            // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
+            const f2 cA01 = {cA[0], cA[1]}, cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
                 const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
                 const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
-                float4 n0, n1, n2, n3, n4, n5;
-                lds_read3(nb, n0, n1, n2);
-                lds_read3b(nb, n3, n4, n5);
-                const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
-                const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
-                float aq[NP], bq[NP];
-                aq[0] = n3.x; aq[1] = n3.y; aq[2] = n3.z; aq[3] = n3.w; aq[4] = n4.x; aq[5] = n4.y;
-                bq[0] = n4.z; bq[1] = n4.w; bq[2] = n5.x; bq[3] = n5.y; bq[4] = n5.z; bq[5] = n5.w;
-                if (NP == 7) { float4 n6 = lds_read1(nb + 6); aq[NP - 1] = n6.x; bq[NP - 1] = n6.y; }
-                float sx = 0.f, sy = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    float cf = cA[ch] + cB[ch] * (yq[ch] - yc[ch]) + cC[ch] * (xq[ch] - xc[ch]);
-                    sx += cf * gxq[ch]; sy += cf * gyq[ch];
-                }
-#pragma unroll
-                for (int j = 0; j < NP; j++) de[j] += sx * aq[j] + sy * bq[j];
+                f32x4 n0, n1, n2, n3, n4, n5;
+                lds_read3v(nb, n0, n1, n2);
+                lds_read3bv(nb, n3, n4, n5);
+                f2 ey = n0.lo - yc01, ex = n0.hi - xc01;
+                f2 cf = cA01 + cB01 * ey + cC01 * ex;
+                f2 e2v = n2.lo - yx2c;
+                float cf2 = cA[2] + cB[2] * e2v.x + cC[2] * e2v.y;
+                f2 tx = cf * n1.lo, ty = cf * n1.hi;
+                float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
+                de2[0] += sx * n3.lo; de2[0] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
+                de2[1] += sx * n3.hi; de2[1] += sy * n5.lo;
+                de2[2] += sx * n4.lo; de2[2] += sy * n5.hi;
+                if (NP == 7) { float4 n6 = lds_read1(nb + 6); de6 += sx * n6.x + sy * n6.y; }
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
@@ -682,47 +692,99 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         if (inimg) sdd += dd;
         if (m) { sMWd += Wt * diff; sM += 1.f; }
         if (MODE == MODE_LIN) {
-            // own geometric Jacobian (centre record)
-            float4 q3, q4, q5;
-            lds_read3b(ctr, q3, q4, q5);
-            float a[NP], b[NP];
-            a[0] = q3.x; a[1] = q3.y; a[2] = q3.z; a[3] = q3.w; a[4] = q4.x; a[5] = q4.y;
-            b[0] = q4.z; b[1] = q4.w; b[2] = q5.x; b[3] = q5.y; b[4] = q5.z; b[5] = q5.w;
-            if (NP == 7) { float4 q6 = lds_read1(ctr + 6); a[NP - 1] = q6.x; b[NP - 1] = q6.y; }
+            // own geometric Jacobian (centre record), as column pairs
+            f32x4 q3, q4, q5;
+            lds_read3bv(ctr, q3, q4, q5);
+            const f2 a2[3] = {q3.lo, q3.hi, q4.lo}, b2[3] = {q4.hi, q5.lo, q5.hi};
+            float a6 = 0.f, b6 = 0.f;
+            if (NP == 7) { float4 q6 = lds_read1(ctr + 6); a6 = q6.x; b6 = q6.y; }
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
             float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;
-            float ddJ[NP];
+            const float wxx = mf * Wt * lxx, wxy = mf * Wt * lxy, wyy = mf * Wt * lyy;
+            f2 ddJ2[3], la2[3], lb2[3];
 #pragma unroll
-            for (int j = 0; j < NP; j++) {
-                float dpd = c_dgx[k] * a[j] + c_dgy[k] * b[j] + ((NP == 7 && j == 6) ? pd : 0.f);
-                ddJ[j] = kdd * (pd * c_zc[k][j] - cd * dpd);
-                float row = Wt * (de[j] + l1x * a[j] + l1y * b[j]) - diff * ddJ[j];  // d(W (e1+e2))/d theta
-                aGP[j] += mf * row;
+            for (int p = 0; p < 3; p++) {
+                const f2 zc2 = {c_zc[k][2 * p], c_zc[k][2 * p + 1]};
+                f2 dpd = c_dgx[k] * a2[p] + c_dgy[k] * b2[p];
+                ddJ2[p] = kdd * (pd * zc2 - cd * dpd);
+                f2 row = Wt * (de2[p] + l1x * a2[p] + l1y * b2[p]) - diff * ddJ2[p];   // d(W (e1+e2))/d theta
+                aG2[p] += mf * row;
+                la2[p] = wxx * a2[p] + wxy * b2[p];
+                lb2[p] = wxy * a2[p] + wyy * b2[p];
             }
-            float wxx = mf * Wt * lxx, wxy = mf * Wt * lxy, wyy = mf * Wt * lyy;
-            int h = 0;
+            float ddJ6 = 0.f, la6 = 0.f, lb6 = 0.f;
+            if (NP == 7) {
+                float dpd = c_dgx[k] * a6 + c_dgy[k] * b6 + pd;
+                ddJ6 = kdd * (pd * c_zc[k][NP - 1] - cd * dpd);
+                aG6 += mf * (Wt * (de6 + l1x * a6 + l1y * b6) - diff * ddJ6);
+                la6 = wxx * a6 + wxy * b6; lb6 = wxy * a6 + wyy * b6;
+            }
+            // H row j (scalar la_j, lb_j) x column pairs p <= j/2
+            {
+                int h = 0;
 #pragma unroll
-            for (int j = 0; j < NP; j++) {
-                float la = wxx * a[j] + wxy * b[j], lb = wxy * a[j] + wyy * b[j];
+                for (int j = 0; j < 6; j++) {
+                    const float la = (j & 1) ? la2[j >> 1].y : la2[j >> 1].x, lb = (j & 1) ? lb2[j >> 1].y : lb2[j >> 1].x;
 #pragma unroll
-                for (int i = 0; i <= j; i++) { aHP[h] += la * a[i] + lb * b[i]; h++; }
+                    for (int p = 0; p <= (j >> 1); p++) { aH2[h] += la * a2[p] + lb * b2[p]; h++; }
+                }
+                if (NP == 7) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { aH2[h] += la6 * a2[p] + lb6 * b2[p]; h++; }
+                    aH66 += la6 * a6 + lb6 * b6;
+                }
             }
             if (DC) {
                 // IRLS curvature 1/max(dd,eps); the gradient is Huberised inside dd < eps (sign(cd-pd) is rounding noise there)
                 float k3 = inimg ? frcp(fmaxf(dd, P.eps)) : 0.f, inf = inimg ? fminf(1.f, dd * frcp(P.eps)) : 0.f;
-                h = 0;
+                int h = 0;
 #pragma unroll
-                for (int j = 0; j < NP; j++) {
-                    aGD[j] += inf * ddJ[j];
-                    float kj = k3 * ddJ[j];
+                for (int p = 0; p < 3; p++) dG2[p] += inf * ddJ2[p];
 #pragma unroll
-                    for (int i = 0; i <= j; i++) { aHD[h] += kj * ddJ[i]; h++; }
+                for (int j = 0; j < 6; j++) {
+                    const float kj = k3 * ((j & 1) ? ddJ2[j >> 1].y : ddJ2[j >> 1].x);
+#pragma unroll
+                    for (int p = 0; p <= (j >> 1); p++) { dH2[h] += kj * ddJ2[p]; h++; }
+                }
+                if (NP == 7) {
+                    dG6 += inf * ddJ6;
+                    const float kj = k3 * ddJ6;
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { dH2[h] += kj * ddJ2[p]; h++; }
+                    dH66 += kj * ddJ6;
                 }
             }
         }
     }
     if (MODE == MODE_MAPS) return;
+
+    // unpack the row-pair accumulators into the triangular layout the reduction / solve kernel use
+    float aHP[L::NH], aGP[NP], aHD[DC ? L::NH : 1], aGD[DC ? NP : 1];
+    {
+        int h2 = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int npair = (j == 6) ? 3 : (j >> 1) + 1;
+#pragma unroll
+            for (int i = 0; i <= j; i++) {
+                float vp = 0.f, vd = 0.f;
+                if (i < 6) {
+                    vp = (i & 1) ? aH2[h2 + (i >> 1)].y : aH2[h2 + (i >> 1)].x;
+                    if (DC) vd = (i & 1) ? dH2[h2 + (i >> 1)].y : dH2[h2 + (i >> 1)].x;
+                } else { vp = aH66; vd = dH66; }
+                aHP[j * (j + 1) / 2 + i] = vp;
+                if (DC) aHD[j * (j + 1) / 2 + i] = vd;
+            }
+            h2 += npair;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            aGP[j] = (j & 1) ? aG2[j >> 1].y : aG2[j >> 1].x;
+            if (DC) aGD[j] = (j & 1) ? dG2[j >> 1].y : dG2[j >> 1].x;
+        }
+        if (NP == 7) { aGP[NP - 1] = aG6; if (DC) aGD[NP - 1] = dG6; }
+    }
 
     // ---------------- workgroup reduction -> group record (shared with the dense kernel) ----------------
     {
