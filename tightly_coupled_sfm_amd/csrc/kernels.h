@@ -243,27 +243,35 @@ struct PackParams {
     InitParams init;                             // init.N > 0: pair initialisation fused into this launch (one thread per pair)
 };
 
-// (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory
+// (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory.
+// The 9 reflect-padded neighbour offsets are formed once (3 row + 3 column indices) and shared by the 6 planes: the first
+// version recomputed refl_idx per load and spent most of its instructions on addresses.
 __device__ inline float photo_err_planar(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int u, int v,
                                          float wl, float ws) {
     float acc = 0.f;
     const int hw = H * W;
+    const int r0 = refl_idx(v - 1, H) * W, r1 = v * W, r2 = refl_idx(v + 1, H) * W;
+    const int c0 = refl_idx(u - 1, W), c1 = u, c2 = refl_idx(u + 1, W);
+    const int off[9] = {r0 + c0, r0 + c1, r0 + c2, r1 + c0, r1 + c1, r1 + c2, r2 + c0, r2 + c1, r2 + c2};
+#pragma unroll
     for (int c = 0; c < 3; c++) {
         const float *xc = x + c * hw, *yc = y + c * hw;
-        float x0 = xc[v * W + u], y0 = yc[v * W + u];
+        float xv[9], yv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { xv[k] = xc[off[k]]; yv[k] = yc[off[k]]; }
+        const float x0 = xv[4], y0 = yv[4];
         float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
-        for (int dv = -1; dv <= 1; dv++)
-            for (int du = -1; du <= 1; du++) {
-                int j = refl_idx(v + dv, H) * W + refl_idx(u + du, W);
-                float a = xc[j] - x0, b = yc[j] - y0;  // shifted by the centre value: fp32-safe variances
-                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
-            }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float a = xv[k] - x0, b = yv[k] - y0;  // shifted by the centre value: fp32-safe variances
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
         const float n9 = 1.f / 9.f;
         float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
         float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
         float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
         float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
-        acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n / d) * 0.5f);
+        acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n * frcp(d)) * 0.5f);
     }
     return acc;
 }
