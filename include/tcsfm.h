@@ -101,6 +101,11 @@ int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, 
 int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,
                const float *pose, const float *K, float *img_rec, float *valid, float *proj_depth, float *comp_depth);
 
+/* The coupled-iteration input assembly of solve_pose_iteratively, train_mono.py:73-77, fused into the warp:
+ * posenet_in [N,6,H,W] = (tgt * valid_mask, img_rec) for the next PoseNet call; valid [N,1,H,W] optional. */
+int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                             const float *depth_s, const float *pose, const float *K, float *posenet_in, float *valid);
+
 /* compute_photometric_error, optimization_experiments/helpers.py:8-23 == per-pair residual assembly of
  * solve_pose_iteratively, train_mono.py:82-100.  Outputs (any may be NULL), all [N,1,H,W] except img_rec:
  * diff (diff_img), valid (warp validity, stn.py:268-269), weight (weight_mask), auto_err (auto_mask_error),

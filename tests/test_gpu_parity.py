@@ -354,3 +354,57 @@ def test_scale_recovery_vs_reference_golden(oracle64):
     # no ground at all -> NaN, not garbage
     up = _t(np.full((1, 1, H, W), 0.5, dtype=np.float32))
     assert torch.isnan(_eng(H, W, 1).scale_recovery(up, _t(g["K"][:1]), 0.055))
+
+
+def test_posenet_input_assembly_vs_reference_golden():
+    """outputs['comb']['imgs'] of solve_pose_iteratively (train_mono.py:104-107): (tgt * valid | img_rec), produced by the warp"""
+    g = load_golden("batch24x40")
+    B, S = 2, 2
+    target, sources, depths, K = g["target"], g["sources"], g["depths"], g["K"]
+    H, W = target.shape[2:]
+    tg = np.concatenate([target] * S); sr = np.concatenate(list(sources))
+    dtg = np.concatenate([depths[0]] * S); dsr = np.concatenate(list(depths[1:]))
+    e = _eng(H, W, 2 * S * B)
+    out = e.posenet_input(_t(np.concatenate([tg, sr])), _t(np.concatenate([sr, tg])), _t(np.concatenate([dtg, dsr])),
+                          _t(np.concatenate([dsr, dtg])), _t(g["first"]), _t(np.concatenate([K] * (2 * S)))).cpu().numpy()
+    rec = np.concatenate([g["it1_fwd_img_rec"], g["it1_inv_img_rec"]])
+    valid = np.concatenate([g["it1_fwd_valid_mask"], g["it1_inv_valid_mask"]])
+    tgt_all = np.concatenate([tg, sr])
+    assert _maxabs(out[:, 3:6], rec) < 1e-4
+    assert np.mean(np.abs(out[:, 0:3] - tgt_all * valid) > 1e-6) <= 0.003
+
+
+@pytest.mark.parametrize("H,W", [(240, 320)])
+def test_dense_refine_scannet_size(H, W, oracle64):
+    """BASELINE config 5 size (ScanNet 320x240, depth range of run_scannet_exps.sh:3)"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    b = _pairs(1, H, W, seed0=8)
+    d0 = _perturbed_depth(b)
+    e = _eng(H, W, 1)
+    o = default_opts(n_iters=4, lambda_depth=1.0, prior_depth=10.0, min_depth=0.03, max_depth=3.0)
+    pose, depth, _ = e.refine_dense(_t(b["tgt"]), _t(b["src"]), _t(d0), _t(b["depth_s"]), _t(b["K"]), _t(b["pose_init"]), o)
+    rp, rd, _ = oracle64.refine_dense(b["tgt"][0], b["src"][0], d0[0, 0], b["depth_s"][0, 0], b["pose_init"][0], b["K"][0],
+                                      oopts(n_iters=4), lambda_depth=1.0, w_prior=10.0, min_depth=0.03, max_depth=3.0)
+    pose = pose.cpu().numpy().astype(np.float64)[0]
+    assert np.linalg.norm(pose[:3] - rp[:3]) / np.linalg.norm(rp[:3]) < 1e-4
+    assert np.linalg.norm(pose[3:] - rp[3:]) / np.linalg.norm(rp[3:]) < 1e-4
+    assert np.mean(np.abs(depth.cpu().numpy()[0, 0] / rd - 1) < 1e-4) >= 0.998
+
+
+def test_pose_scale_8_iters_config4(oracle64):
+    """BASELINE config 4: depth-scale + 6-DoF joint refinement, 8 iterations (Eigen-split depth range 0.1 .. 2.67)"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, N = 96, 320, 2
+    b = _pairs(N, H, W, seed0=30)
+    e = _eng(H, W, N)
+    ls0 = np.array([0.04, -0.03], dtype=np.float32)
+    pose, ls, _ = e.refine(*_dev(b), _t(b["pose_init"]), default_opts(refine=1, n_iters=8), log_scale=_t(ls0))
+    pose = pose.cpu().numpy().astype(np.float64)
+    for n in range(N):
+        rp, rls, _ = oracle64.refine(b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0], b["pose_init"][n], b["K"][n],
+                                     oopts(nparam=7, n_iters=8), log_scale=float(ls0[n]))
+        assert np.linalg.norm(pose[n, :3] - rp[:3]) / np.linalg.norm(rp[:3]) < 1e-4
+        assert np.linalg.norm(pose[n, 3:] - rp[3:]) / np.linalg.norm(rp[3:]) < 1e-4
+        assert abs(float(ls[n]) - rls) < 1e-4

@@ -179,3 +179,14 @@ def test_scale_recovery_G10(oracle64, oracle32):
             assert np.array_equal(m, g[f"{p}_mask"][b]) and _maxabs(h, g[f"{p}_height"][b]) < tol
         s, med = O.scale_recovery(g["depth"], g["K"], float(g["cam_height"]))
         assert abs(med - float(g[f"{p}_median"])) < tol and abs(s - float(g[f"{p}_scale"][0])) < 10 * tol
+
+
+def test_postprocess_and_averaging_G8():
+    """batch_post_process_disparity (learning_helpers.py:115-123) and avg_final_predictions (helpers.py:25-33) mirrors
+    used on the DepthOptimizer return path"""
+    import torch
+    from tightly_coupled_sfm_amd.optimizer import avg_final_predictions, batch_post_process_disparity
+    g = load_golden("helpers")
+    assert _maxabs(batch_post_process_disparity(g["l_disp"], g["r_disp"]), g["post"]) < 1e-15
+    lst = [torch.tensor(x) for x in g["avg_list"]]
+    assert _maxabs(avg_final_predictions(lst, 5).numpy(), g["avg5"]) < 1e-6

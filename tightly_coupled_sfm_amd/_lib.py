@@ -36,6 +36,7 @@ _SIGNATURES = {
     "tcsfm_disp_to_depth": (C.c_int, [_P, C.POINTER(Opts), C.c_int64, _P, _P, _P]),
     "tcsfm_ssim": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, _P]),
     "tcsfm_warp": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
+    "tcsfm_warp_posenet_input": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),
     "tcsfm_photometric": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 12),
     "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
     "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),

@@ -332,7 +332,9 @@ struct WarpParams {
     const float *src, *depth_t, *depth_s;
     const PairConst *pc;
     float *rec, *valid, *pd, *cd;
-    int H, W;
+    const float *tgt;   // optional: with posenet_in, the target image to be masked by the warp validity
+    float *posenet_in;  // optional [N,6,H,W]: (tgt * valid, img_rec) = the next PoseNet input of solve_pose_iteratively
+    int H, W;           //                     (train_mono.py:74-76), written by the warp itself: no extra HBM round trip
 };
 
 __device__ __forceinline__ float tap1(const float *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob) {
@@ -362,6 +364,13 @@ __global__ __launch_bounds__(256) void k_warp(WarpParams P) {
         for (int ch = 0; ch < 3; ch++)
             P.rec[((size_t)n * 3 + ch) * hw + idx] = tap1(P.src + ((size_t)n * 3 + ch) * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
     if (P.valid) P.valid[(size_t)n * hw + idx] = oob ? 0.f : 1.f;
+    if (P.posenet_in) {
+        const float vm = oob ? 0.f : 1.f;
+        for (int ch = 0; ch < 3; ch++) {
+            P.posenet_in[((size_t)n * 6 + ch) * hw + idx] = P.tgt[((size_t)n * 3 + ch) * hw + idx] * vm;
+            P.posenet_in[((size_t)n * 6 + 3 + ch) * hw + idx] = tap1(P.src + ((size_t)n * 3 + ch) * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+        }
+    }
     if (P.pd) P.pd[(size_t)n * hw + idx] = c.es * tap1(P.depth_s + (size_t)n * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
     if (P.cd) P.cd[(size_t)n * hw + idx] = g.Z;
 }

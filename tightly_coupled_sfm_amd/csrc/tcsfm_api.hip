@@ -431,12 +431,44 @@ int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, con
     WarpParams P;
     P.src = d_src; P.depth_t = d_dt; P.depth_s = d_ds; P.pc = h->pconst;
     P.rec = d_rec; P.valid = d_valid; P.pd = d_pd; P.cd = d_cd; P.H = h->H; P.W = h->W;
+    P.tgt = nullptr; P.posenet_in = nullptr;
     hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, P);
     HIPCHK(h, hipGetLastError());
     if ((rc = copy_back(h, o, img_rec, d_rec, N * 3 * hw))) return rc;
     if ((rc = copy_back(h, o, valid, d_valid, N * hw))) return rc;
     if ((rc = copy_back(h, o, proj_depth, d_pd, N * hw))) return rc;
     if ((rc = copy_back(h, o, comp_depth, d_cd, N * hw))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                             const float *depth_s, const float *pose, const float *K, float *posenet_in, float *valid) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !src || !depth_t || !depth_s || !pose || !K || !posenet_in) return fail(h, TCSFM_E_ARG, "tcsfm_warp_posenet_input: NULL argument");
+    if (o->depth_is_disp) return fail(h, TCSFM_E_ARG, "tcsfm_warp_posenet_input takes depth maps");
+    HIPCHK(h, hipSetDevice(h->device));
+    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    size_t hw = (size_t)h->H * h->W;
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K;
+    float *d_out, *d_valid;
+    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, pose, (size_t)N * 6, &d_pose))) return rc;
+    if ((rc = to_dev(h, o, 5, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = out_dev(h, o, 6, posenet_in, N * 6 * hw, &d_out))) return rc;
+    if ((rc = out_dev(h, o, 7, valid, N * hw, &d_valid))) return rc;
+    if ((rc = run_init(h, o, N, d_pose, nullptr, d_K, 0))) return rc;
+    WarpParams P;
+    P.src = d_src; P.depth_t = d_dt; P.depth_s = d_ds; P.pc = h->pconst;
+    P.rec = nullptr; P.valid = d_valid; P.pd = nullptr; P.cd = nullptr; P.tgt = d_tgt; P.posenet_in = d_out; P.H = h->H; P.W = h->W;
+    hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = copy_back(h, o, posenet_in, d_out, N * 6 * hw))) return rc;
+    if ((rc = copy_back(h, o, valid, d_valid, N * hw))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;
 }

@@ -127,6 +127,20 @@ class Engine:
                                        self._p(intrinsics), self._p(rec), self._p(valid), self._p(pd), self._p(cd)))
         return rec, valid, pd, cd
 
+    def posenet_input(self, target_img, source_img, target_depth, source_depth, pose, intrinsics):
+        """(tgt * valid | img_rec) [N,6,H,W] for the next PoseNet call of the coupled iteration (train_mono.py:73-77);
+        `pose` is the estimate so far in the reference convention (the warp uses -pose like train_mono.py:80)."""
+        N = target_img.shape[0]
+        H, W = self.H, self.W
+        t = _chk(target_img, (N, 3, H, W), "target_img"); s = _chk(source_img, (N, 3, H, W), "source_img")
+        dt = _chk(target_depth, (N, 1, H, W), "target_depth"); ds = _chk(source_depth, (N, 1, H, W), "source_depth")
+        p = _chk(pose, (N, 6), "pose"); K = _chk(intrinsics, (N, 3, 3), "intrinsics")
+        out = torch.empty((N, 6, H, W), device=t.device, dtype=torch.float32)
+        o = default_opts()
+        self._call(self.lib.tcsfm_warp_posenet_input(self._h, C.byref(o), N, self._p(t), self._p(s), self._p(dt), self._p(ds), self._p(p),
+                                                     self._p(K), self._p(out), None))
+        return out
+
     def compute_photometric_error(self, target_img, source_img, target_depth, source_depth, pose, intrinsics,
                                   opts: Optional[Opts] = None):
         """optimization_experiments/helpers.py:8-23 -> dict with the reference's keys (+ the raw maps)."""

@@ -119,12 +119,10 @@ class DepthOptimizer:
         d_s = torch.cat([source_depths, target_depths], 0).contiguous()
         full = self.pose_model(imgs)
         stacked = [full.clone()]
-        src = imgs[:, 3:6].contiguous()
+        tgt, src = imgs[:, 0:3].contiguous(), imgs[:, 3:6].contiguous()
         for _ in range(num_iter - 1):
-            rec, valid, _, _ = eng.inverse_warp2(src, d_t, d_s, -full[:, :6].contiguous(), K)
-            new = imgs.clone()
-            new[:, 0:3] = new[:, 0:3] * valid
-            new[:, 3:6] = rec
+            # (tgt * valid | img_rec) written by the warp kernel itself: no clone / mask / copy round trips (8f row 4)
+            new = eng.posenet_input(tgt, src, d_t, d_s, full[:, :6].contiguous(), K.contiguous())
             full = full + self.pose_model(new)
             stacked.append(full.clone())
         return full[:, :6].contiguous(), torch.stack(stacked, 1), imgs, d_t, d_s, K
