@@ -68,8 +68,12 @@ typedef struct tcsfm_opts {
     float reserved1;
 } tcsfm_opts;
 
-/* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32 */
-enum { TCSFM_STAT_COST = 0, TCSFM_STAT_COST_PHOTO = 1, TCSFM_STAT_NMASK = 2, TCSFM_STAT_LAMBDA = 3, TCSFM_NSTAT = 4 };
+/* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.
+ * Row i < n_iters: the i-th linearisation (cost, photometric part, mask count, damping) and the pose it was evaluated at,
+ * i.e. the trajectory of iterates (the analogue of the reference's stacked poses, train_mono.py:71-79).  Row n_iters:
+ * Gauss-Newton -- the final pose, cost fields 0 (not evaluated); LM -- the cost check of the last trial step. */
+enum { TCSFM_STAT_COST = 0, TCSFM_STAT_COST_PHOTO = 1, TCSFM_STAT_NMASK = 2, TCSFM_STAT_LAMBDA = 3,
+       TCSFM_STAT_POSE = 4 /* ..9: the 6-vector the row was evaluated at */, TCSFM_NSTAT = 10 };
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 

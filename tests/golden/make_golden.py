@@ -20,6 +20,9 @@ Goldens (SURVEY.md section 8c naming):
   G6 autograd d(cost)/d(pose), d(cost)/d(depth); per-pixel Jacobian rows of the three residual maps
   G7 generate_loss_surface tz / yaw sweeps                           optimization_experiments/plot_loss_surface.py:11-87
   G8 disp_to_depth, batch_post_process_disparity, avg_final_predictions
+  G9 one DepthOptimizer.optimize_window (optimize_depth_pred, 5 epochs, stand-in nets): result-dict schema + the values
+     that do not depend on the optimiser (initial poses, depths, flip-averaged disparity)   optimizer.py:136-297
+  G10 ScaleRecovery                                                   models/dnet_layers.py:249-327
 """
 import os
 import sys
@@ -271,6 +274,38 @@ def main():
     finally:
         torch.Tensor.cuda = _cuda
     out["scale48x160"] = g10
+
+    # ------------------------------------------------------------------ G9: optimize_window result dict (schema for the shim)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import standins
+    B, S, H, W, ITER = 2, 2, 48, 160, 3
+    reset_grid()
+    w = standins.make_window(B, S, H, W)
+    pose_model, depth_model = standins.window_models(w, ITER)
+    options = {'epochs': 5, 'lr': 4e-3, 'optimizer': 'adam', 'optimize_depth_weights_bottleneck_beyond': False,
+               'optimize_depth_weights_all': False, 'optimize_depth_encoder': False, 'optimize_pose_weights_all': False,
+               'optimize_depth_pred': True, 'optimize_depth_bottleneck_values': False, 'diff_img_argmin': True,
+               'automasking': True, 'mode': 'scaled', 'l_depth_consist': True, 'l_depth_consist_weight': 0.15,
+               'l_depth_init': True, 'l_depth_init_weight': 0.1, 'l_inverse_reconstruction': True, 'l_smooth': False,
+               'l_smooth_weight': 2, 'l_pose_consist': False, 'avg_final_epochs': 5, 'num_source_imgs': S, 'plotting': False}
+    config = {'minibatch': B, 'device': 'cpu', 'min_depth': 0.06, 'max_depth': 2.67, 'iterations': ITER,
+              'camera_height': 1.65, 'flow_type': 'none'}
+    do = ref["optimizer"].DepthOptimizer(options, config, pose_model, depth_model, "09_02")
+    res = do.optimize_window(0, standins.loader_batch(w))
+    g9 = {f"in_{k}": v for k, v in w.items()}
+    g9["in_iterations"] = np.array(ITER)
+    schema = []
+    for k in sorted(res):
+        v = res[k]
+        if isinstance(v, (list, tuple)):
+            schema.append(f"{k}|list{len(v)}|{tuple(v[0].shape)}|{str(v[0].dtype)}|{v[0].device.type}")
+            g9[f"out_{k}"] = np.stack([N(x) for x in v])
+        elif isinstance(v, np.ndarray):
+            schema.append(f"{k}|ndarray|{v.shape}|{v.dtype}|host"); g9[f"out_{k}"] = v
+        else:
+            schema.append(f"{k}|tensor|{tuple(v.shape)}|{str(v.dtype)}|{v.device.type}"); g9[f"out_{k}"] = N(v)
+    g9["schema"] = np.array(schema)
+    out["window48x160"] = g9
 
     # ------------------------------------------------------------------ full-size summary (192x640, f32 as run by the reference)
     H, W, seed = 192, 640, 0

@@ -1,0 +1,96 @@
+"""Stand-in networks shared by tests/golden/make_golden.py (G9, run through the REFERENCE's optimize_window) and
+tests/test_gpu_optimizer_shim.py (run through the drop-in).  They keep the reference models' call conventions
+(models/depth_models.py forward(x, skips, return_disp, epoch) -> (disparities, skips); PoseNet(x[N,6,H,W]) -> [N,6]) but are
+closed-form functions of their inputs, so both sides see exactly the same "network" outputs.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class LookupDepth(nn.Module):
+    """Depth net stand-in: returns the stored sigmoid-disparity map of whichever known image (or its horizontal flip) each
+    sample of x is.  images [M,3,H,W], disps [M,1,H,W]."""
+
+    def __init__(self, images, disps):
+        super().__init__()
+        self.register_buffer("images", images)
+        self.register_buffer("disps", disps)
+
+    def _lookup(self, x):
+        out = []
+        flipped = torch.flip(self.images, [3])
+        for i in range(x.shape[0]):
+            e = (self.images - x[i:i + 1]).abs().flatten(1).max(1)[0]
+            ef = (flipped - x[i:i + 1]).abs().flatten(1).max(1)[0]
+            if float(e.min()) <= float(ef.min()):
+                out.append(self.disps[int(e.argmin())])
+            else:
+                out.append(torch.flip(self.disps[int(ef.argmin())], [2]))
+        return torch.stack(out).to(x.dtype)
+
+    def forward(self, x=None, skips=None, return_disp=True, epoch=0):
+        if x is not None and not return_disp:          # encoder pass: the "skips" are the images themselves
+            return None, [x, x]
+        src = x if x is not None else skips[-1]
+        return [self._lookup(src)], [src, src]
+
+
+class LinearPose(nn.Module):
+    """PoseNet stand-in: first call of every solve_pose_iteratively round (every `period` calls) -> the stored initial poses;
+    the other calls -> a small correction that depends on the 6-channel input (so the masked-target | reconstruction
+    assembly of train_mono.py:73-77 is exercised)."""
+
+    def __init__(self, first, period, gain=2e-3, seed=3):
+        super().__init__()
+        self.register_buffer("first", first)
+        rng = np.random.default_rng(seed)
+        self.register_buffer("mix", torch.as_tensor(rng.normal(size=(6, 6)), dtype=first.dtype))
+        self.gain, self.period, self.calls = gain, period, 0
+
+    def forward(self, x):
+        self.calls += 1
+        if (self.calls - 1) % self.period == 0:
+            return self.first.clone()
+        return self.gain * torch.tanh(x.mean((2, 3)).to(self.first.dtype) @ self.mix)
+
+
+def make_window(B, S, H, W, seed0=70):
+    """Synthetic window: B target frames, S sources each (second source = opposite motion), analytic depths, PoseNet-level
+    initial poses for the stacked [fwd s0 b.., fwd s1 b.., inv s0.., inv s1..] order of train_mono.py:54-62."""
+    from tightly_coupled_sfm_amd import synth
+    tg, dt, Ks = [], [], []
+    srcs, dss, pgt = [[] for _ in range(S)], [[] for _ in range(S)], [[] for _ in range(S)]
+    for b in range(B):
+        for si in range(S):
+            base = np.array([0.003, -0.002, 0.033, 0.002, -0.004, 0.0015]) * (1.0 if si == 0 else -1.0)
+            p = synth.make_pair(H, W, seed=seed0 + b, pose_gt=base, dtype=np.float32)
+            if si == 0:
+                tg.append(p["tgt"]); dt.append(p["depth_t"]); Ks.append(p["K"])
+            srcs[si].append(p["src"]); dss[si].append(p["depth_s"]); pgt[si].append(p["pose_gt"])
+    gt_f = np.concatenate([np.stack(x) for x in pgt]).astype(np.float32)               # [S*B,6] source-major
+    init_f = np.stack([synth.perturb_pose(g, seed0 + 100 + i) for i, g in enumerate(gt_f)]).astype(np.float32)
+    init_i = np.stack([synth.invert_pose(x) for x in init_f]).astype(np.float32)
+    sd = lambda d: synth.depth_to_sigmoid_disp(np.asarray(d, dtype=np.float64)).astype(np.float32)
+    return dict(target=np.stack(tg).astype(np.float32), sources=np.stack([np.stack(x) for x in srcs]).astype(np.float32),
+                disp_t=sd(np.stack(dt))[:, None], disp_s=np.stack([sd(np.stack(x))[:, None] for x in dss]),
+                K=np.stack(Ks).astype(np.float32), gt=gt_f.reshape(S, B, 6), first=np.concatenate([init_f, init_i]))
+
+
+def loader_batch(w, device="cpu"):
+    """the DataLoader batch form process_sample_batch unpacks (data/kitti_loader.py:60-98)"""
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
+    S = w["sources"].shape[0]
+    target = {"color_left": t(w["target"]), "color_aug_left": t(w["target"])}
+    sources = {"color_left": [t(w["sources"][i]) for i in range(S)], "color_aug_left": [t(w["sources"][i]) for i in range(S)]}
+    lie = [[t(w["gt"][i]), t(w["gt"][i])] for i in range(S)]
+    K = t(w["K"])[:, None]
+    return target, sources, {"color": lie, "color_aug": lie}, {"color_left": K, "color_aug_left": K}, None
+
+
+def window_models(w, iterations, device="cpu"):
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
+    S = w["sources"].shape[0]
+    images = torch.cat([t(w["target"])] + [t(w["sources"][i]) for i in range(S)], 0)
+    disps = torch.cat([t(w["disp_t"])] + [t(w["disp_s"][i]) for i in range(S)], 0)
+    return LinearPose(t(w["first"]), iterations).to(device), LookupDepth(images, disps).to(device)

@@ -1,62 +1,117 @@
 """The DepthOptimizer drop-in (tightly_coupled_sfm_amd/optimizer.py) against the reference's call surface
 (optimizer.py:15-27,136-297; result keys read at run_sequential_optimization.py:195-216 and
-run_sample_optimization_demo.py:178-186), with stand-in networks like golden G9 of SURVEY 8c."""
+run_sample_optimization_demo.py:178-186).  Golden G9 (tests/golden/golden_window48x160.npz) is the result dict of the
+REFERENCE's optimize_window on the same window with the same stand-in networks (tests/standins.py): it pins the schema and
+every value that does not depend on which optimiser runs (PoseNet-in-the-loop initial poses, depths, flip-averaged
+disparity)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-class _StandInDepth(torch.nn.Module):
-    """depth net stand-in with the reference model's return convention ([disparities...], skips)"""
-    def __init__(self, table):
-        super().__init__(); self.table = table
-    def forward(self, x):
-        return [self.table[x.shape[0]]], None
+def _window():
+    from conftest import load_golden
+    g = load_golden("window48x160")
+    w = {k[3:]: g[k] for k in g if k.startswith("in_")}
+    return g, w, int(w.pop("iterations"))
 
 
-class _StandInPose(torch.nn.Module):
-    def __init__(self, first):
-        super().__init__(); self.first, self.calls = first, 0
-    def forward(self, x):
-        self.calls += 1
-        return self.first.clone() if self.calls == 1 else torch.zeros_like(self.first)
+OPTIONS = {"epochs": 5, "lr": 4e-3, "optimizer": "adam", "optimize_depth_weights_bottleneck_beyond": False,
+           "optimize_depth_weights_all": False, "optimize_depth_encoder": False, "optimize_pose_weights_all": False,
+           "optimize_depth_pred": False, "optimize_depth_bottleneck_values": False, "diff_img_argmin": True,
+           "automasking": True, "mode": "scaled", "l_depth_consist": True, "l_depth_consist_weight": 0.15,
+           "l_depth_init": True, "l_depth_init_weight": 0.1, "l_inverse_reconstruction": True, "l_smooth": False,
+           "l_smooth_weight": 2, "l_pose_consist": False, "avg_final_epochs": 5, "num_source_imgs": 2, "plotting": False}
 
 
-def test_optimize_window_schema_and_improvement():
-    from tightly_coupled_sfm_amd import synth
+def _config(B, iters):
+    return {"minibatch": B, "device": "cuda", "min_depth": 0.06, "max_depth": 2.67, "iterations": iters,
+            "camera_height": 1.65, "flow_type": "none"}
+
+
+def _describe(v):
+    if isinstance(v, (list, tuple)):
+        return f"list{len(v)}", tuple(v[0].shape), str(v[0].dtype), v[0].device.type
+    if isinstance(v, np.ndarray):
+        return "ndarray", v.shape, str(v.dtype), "host"
+    return "tensor", tuple(v.shape), str(v.dtype), v.device.type
+
+
+def test_optimize_window_against_reference_result_dict():
+    import standins
     from tightly_coupled_sfm_amd.optimizer import DepthOptimizer
-    B, S, H, W = 2, 1, 96, 320
-    pairs = [synth.make_pair(H, W, seed=40 + b) for b in range(B)]
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
-    target = t(np.stack([p["tgt"] for p in pairs])); source = t(np.stack([p["src"] for p in pairs]))
-    K = t(np.stack([p["K"] for p in pairs]))
-    sd = lambda key: t(np.stack([synth.depth_to_sigmoid_disp(p[key].astype(np.float64)) for p in pairs])[:, None])
-    disp_t, disp_s = sd("depth_t"), sd("depth_s")
-    gt = np.stack([p["pose_gt"] for p in pairs])
-    init_f = np.stack([synth.perturb_pose(p["pose_gt"], 40 + b) for b, p in enumerate(pairs)])
-    init_i = np.stack([synth.invert_pose(x) for x in init_f])
-    depth_model = _StandInDepth({(S + 1) * B: torch.cat([disp_t, disp_s], 0), 2 * B: torch.cat([disp_t, torch.flip(disp_t, [3])], 0)})
-    pose_model = _StandInPose(t(np.concatenate([init_f, init_i])))
-    options = {"epochs": 20, "optimize_depth_encoder": True, "automasking": True, "l_depth_consist": True,
-               "l_depth_consist_weight": 0.15, "mode": "scaled", "num_source_imgs": S, "gn_iters": 6}
-    config = {"minibatch": B, "device": "cuda", "min_depth": 0.06, "max_depth": 2.67, "iterations": 2, "camera_height": 1.65}
-    with pytest.warns(UserWarning, match="Gauss-Newton"):
-        opt = DepthOptimizer(options, config, pose_model, depth_model, "09_02")
-    data = (target, [source], [t(gt)], [t(gt)], None, K, None, None, None, None, None)          # the demo's 11-tuple form
-    r = opt.optimize_window(0, data)
-    for k in ("poses_opt", "poses_inv_opt", "poses_init", "poses_inv_init", "gt_poses"):
-        assert tuple(r[k].shape) == (S * B, 6) and r[k].device.type == "cpu" and r[k].dtype == torch.float32, k
-    assert tuple(r["stacked_poses_init"].shape) == (S * B, 2, 6)
-    assert len(r["depths_init"]) == S + 1 and tuple(r["depths_opt"][0].shape) == (B, 1, H, W)
-    assert r["scale_factor"].numel() == 1 and r["scale_factor_init"].numel() == 1
-    assert isinstance(r["disp_opt"], np.ndarray) and r["disp_opt"].shape == (B, H, W)
-    assert pose_model.calls == 2                                    # PoseNet -> HIP warp -> PoseNet correction
-    # the refinement lowers the reference's own photometric cost for every directed pair and moves every pose
-    # (the cost minimiser sits ~1e-3 away from the synthetic ground truth -- masked mean + interpolation bias --
-    #  so distance-to-GT at PoseNet-level initial accuracy is not a meaningful improvement measure)
-    assert np.all(r["gn_cost"].numpy()[:, 5] < r["gn_cost"].numpy()[:, 0])
+    g, w, iters = _window()
+    B, S = w["target"].shape[0], w["sources"].shape[0]
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    opt = DepthOptimizer(dict(OPTIONS), _config(B, iters), pose_model, depth_model, "09_02")
+    r = opt.optimize_window(0, standins.loader_batch(w, device="cuda"))       # the DataLoader batch form
+    assert pose_model.calls == iters                                            # PoseNet -> HIP warp -> PoseNet correction ...
+
+    # schema: every key of the reference's dict, same container kind / shape / dtype; tensors the reference returns on the CPU
+    # (.cpu() in optimizer.py) are on the CPU; depths_* and stacked_poses_*opt stay on config['device'] there (optimizer.py:
+    # 165,292-294), which was 'cpu' where the golden was made and is 'cuda' here
+    for line in g["schema"]:
+        key, kind, shape, dtype, dev = str(line).split("|")
+        assert key in r, key
+        k2, s2, d2, dev2 = _describe(r[key])
+        assert k2 == kind and d2 == dtype, (key, k2, kind, d2, dtype)
+        if key in ("stacked_poses_opt", "stacked_poses_inv_opt"):
+            # reference: PoseNet iterates of the last epoch [S*B, iterations, 6]; here: the Gauss-Newton iterates
+            assert s2[0] == S * B and s2[2] == 6 and s2[1] == 4 + 1
+        else:
+            assert str(s2) == shape, (key, s2, shape)
+        on_device = key.startswith("depths_") or key in ("stacked_poses_opt", "stacked_poses_inv_opt")
+        assert dev2 == ("cuda" if on_device else dev), (key, dev2)
+
+    # values that do not depend on the optimiser
+    for key, tol in (("poses_init", 2e-6), ("poses_inv_init", 2e-6), ("stacked_poses_init", 2e-6), ("stacked_poses_inv_init", 2e-6),
+                     ("gt_poses", 0), ("gt_poses_inv", 0), ("scale_factor", 0), ("scale_factor_init", 0), ("disp_opt", 1e-6)):
+        assert np.max(np.abs(r[key].numpy() - g["out_" + key])) <= tol, key
+    for i in range(S + 1):
+        assert np.max(np.abs(r["depths_init"][i].cpu().numpy() / g["out_depths_init"][i] - 1)) < 2e-6
+
+    # the refinement lowers the reference's own photometric cost of every directed pair and moves every pose (the cost
+    # minimiser sits ~1e-3 away from the synthetic ground truth, so distance-to-GT is not a meaningful measure here)
+    cost = r["gn_cost"].numpy()
+    assert np.all(cost[:, 3] < cost[:, 0])
     assert np.all(np.abs(r["poses_opt"].numpy() - r["poses_init"].numpy()).max(1) > 1e-6)
+    assert np.array_equal(r["stacked_poses_opt"][:, -1].cpu().numpy(), r["poses_opt"].numpy())
+    assert np.max(np.abs(r["stacked_poses_opt"][:, 0].cpu().numpy() - r["poses_init"].numpy())) < 2e-7
+
+
+def test_tuple_form_dense_mode_and_legacy_switches():
+    import standins
+    from tightly_coupled_sfm_amd.optimizer import DepthOptimizer
+    g, w, iters = _window()
+    B, S = w["target"].shape[0], w["sources"].shape[0]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    gts = [t(w["gt"][i]) for i in range(S)]
+    data = (t(w["target"]), [t(w["sources"][i]) for i in range(S)], gts, gts, None, t(w["K"]), None, None, None, None, None)
+
+    # optimize_depth_pred (Adam on the disparity maps in the reference) -> pose + per-pixel inverse depth by GN + Schur
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    opt = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True), _config(B, iters), pose_model, depth_model, "09_02")
+    r = opt.optimize_window(0, data)                                           # the demo's 11-tuple form
+    assert len(r["depths_opt"]) == S + 1
+    for d0, d1 in zip(r["depths_init"], r["depths_opt"]):
+        assert d1.shape == d0.shape and torch.isfinite(d1).all()
+        rel = ((d1 - d0).abs() / d0)
+        assert 1e-6 < float(rel.mean()) < 0.05                                  # depth moved, and stayed near the prior
+    assert np.all(r["gn_cost"].numpy()[:, 3] < r["gn_cost"].numpy()[:, 0])
+
+    # pose + one depth scale per pair
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    r = DepthOptimizer(dict(OPTIONS, refine="pose+scale", gn_iters=6), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)
+    assert tuple(r["log_depth_scale"].shape) == (2 * S * B,) and tuple(r["stacked_poses_opt"].shape) == (S * B, 7, 6)
+
+    # weight-tuning switches: warned about, or refused
+    with pytest.warns(UserWarning, match="Gauss-Newton"):
+        DepthOptimizer(dict(OPTIONS, optimize_depth_encoder=True), _config(B, iters), pose_model, depth_model, "09_02")
     with pytest.raises(NotImplementedError):
-        DepthOptimizer(dict(options, strict_legacy=True), config, pose_model, depth_model, "09_02")
+        DepthOptimizer(dict(OPTIONS, optimize_depth_encoder=True, strict_legacy=True), _config(B, iters), pose_model, depth_model, "09_02")

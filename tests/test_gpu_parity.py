@@ -244,6 +244,9 @@ def test_full_size_properties():
     pg, _, sg = e.refine(*d, p0, default_opts(n_iters=8), stats=True)
     sg = sg.cpu().numpy()
     assert np.all(sg[:, 7, 0] < 0.8 * sg[:, 0, 0])
+    # the stats rows carry the trajectory of iterates: row 0 = initial pose, row n_iters = refined pose
+    assert _maxabs(sg[:, 0, 4:10], b["pose_init"]) < 2e-7 and np.array_equal(sg[:, 8, 4:10], pg.cpu().numpy())
+    assert np.all(np.abs(np.diff(sg[:, :, 4:10], axis=1)).max(axis=2) > 0)
     # determinism + batch independence: a pair refined alone gives bit-identical results to the same pair in a batch
     pg2, _, _ = e.refine(*d, p0, default_opts(n_iters=8))
     assert torch.equal(pg, pg2)

@@ -4,6 +4,7 @@
 Tolerances: float64 oracle vs float64 reference 1e-10 (pure rounding-order differences);
 float32 twin vs float32 reference 1e-4 absolute on [0,1] maps, masks may flip on <=0.2% of
 pixels (near-ties decided differently in fp32)."""
+import os
 import numpy as np
 import pytest
 
@@ -190,3 +191,44 @@ def test_postprocess_and_averaging_G8():
     assert _maxabs(batch_post_process_disparity(g["l_disp"], g["r_disp"]), g["post"]) < 1e-15
     lst = [torch.tensor(x) for x in g["avg_list"]]
     assert _maxabs(avg_final_predictions(lst, 5).numpy(), g["avg5"]) < 1e-6
+
+
+def test_window_G9_initial_poses(oracle64):
+    """G9: the reference's optimize_window on a B=2, S=2 window with the stand-in networks of tests/standins.py.  The
+    PoseNet-in-the-loop initial poses (train_mono.py:64-80) are reproduced with the oracle's warp: pins the stacked
+    fwd/inv ordering, the (tgt*valid | img_rec) assembly and disp_to_depth on a whole window."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import standins
+    g = load_golden("window48x160")
+    w = {k[3:]: g[k] for k in g if k.startswith("in_")}
+    iters = int(w.pop("iterations"))
+    S, B = w["sources"].shape[:2]
+    depth = lambda d: oracle64.disp_to_depth(d, 0.06, 2.67)[1]
+    d_t, d_s = depth(w["disp_t"]), [depth(w["disp_s"][i]) for i in range(S)]
+    for i in range(S + 1):
+        assert _maxabs((d_t if i == 0 else d_s[i - 1]) / g["out_depths_init"][i], 1.0) < 1e-6
+    # stacked order: fwd pairs source-major, then inv pairs
+    tgt = [w["target"][b] for _ in range(S) for b in range(B)] + [w["sources"][i][b] for i in range(S) for b in range(B)]
+    src = [w["sources"][i][b] for i in range(S) for b in range(B)] + [w["target"][b] for _ in range(S) for b in range(B)]
+    dt = [d_t[b, 0] for _ in range(S) for b in range(B)] + [d_s[i][b, 0] for i in range(S) for b in range(B)]
+    ds = [d_s[i][b, 0] for i in range(S) for b in range(B)] + [d_t[b, 0] for _ in range(S) for b in range(B)]
+    K = [w["K"][b] for _ in range(2 * S) for b in range(B)]
+    pm, _ = standins.window_models(w, iters)
+    x0 = torch.tensor(np.stack([np.concatenate([t, s]) for t, s in zip(tgt, src)]))
+    full = pm(x0).double().numpy()
+    stacked = [full.copy()]
+    for _ in range(iters - 1):
+        new = []
+        for n in range(2 * S * B):
+            rec, valid, _, _ = oracle64.warp(src[n], dt[n], ds[n], full[n], K[n])
+            new.append(np.concatenate([tgt[n] * valid[None], rec]))
+        full = full + pm(torch.tensor(np.stack(new), dtype=torch.float32)).double().numpy()
+        stacked.append(full.copy())
+    stacked = np.stack(stacked, 1)
+    split = S * B
+    assert _maxabs(stacked[:split], g["out_stacked_poses_init"]) < 2e-6
+    assert _maxabs(stacked[split:], g["out_stacked_poses_inv_init"]) < 2e-6
+    assert _maxabs(full[:split], g["out_poses_init"]) < 2e-6 and _maxabs(full[split:], g["out_poses_inv_init"]) < 2e-6
+    assert _maxabs(g["out_gt_poses"], w["gt"].reshape(-1, 6)) == 0 and _maxabs(g["out_gt_poses_inv"], -w["gt"].reshape(-1, 6)) == 0

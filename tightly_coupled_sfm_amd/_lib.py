@@ -21,7 +21,8 @@ class Opts(C.Structure):
 SOLVER_GN, SOLVER_LM = 0, 1
 PARAM_SE3, PARAM_EULER = 0, 1
 REFINE_POSE, REFINE_POSE_SCALE = 0, 1
-NSTAT = 4
+STAT_POSE = 4
+NSTAT = 10        # cost, cost_photo, n_mask, lambda, pose[6]  (include/tcsfm.h TCSFM_STAT_*)
 
 _P = C.c_void_p
 _SIGNATURES = {

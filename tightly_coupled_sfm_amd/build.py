@@ -7,8 +7,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "tcsfm_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.h"), os.path.join(HERE, "csrc", "se3_math.h"), os.path.join(HERE, "csrc", "wave_reduce.h"),
-        os.path.join(os.path.dirname(HERE), "include", "tcsfm.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("kernels.h", "dense_kernel.h", "scale_kernel.h", "se3_math.h", "wave_reduce.h")] + \
+       [os.path.join(os.path.dirname(HERE), "include", "tcsfm.h")]
 OUT = os.path.join(HERE, "libtcsfm_hip.so")
 
 

@@ -832,7 +832,7 @@ struct SolveParams {
     const float *partials;  // [N][ngrp][nacc] group records
     PairState *st;
     PairConst *pc;
-    float *stats;           // [N][n_iters+1][4] or null
+    float *stats;           // [N][n_iters+1][TCSFM_NSTAT] or null
     double *lin_out;        // linearize debug: [N][np*np + np + 4] or null
     int ngrp, nacc, np, has_dc;
     int it, n_iters, solver, param, mode;  // mode 0: iteration step, 1: final LM cost check, 2: export only
@@ -920,8 +920,9 @@ __global__ __launch_bounds__(128) void k_solve(SolveParams P) {
     }
     double lambda = S.lambda;
     if (P.stats && tid == 0) {
-        float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * 4;
+        float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * TCSFM_NSTAT;
         st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)lambda;
+        T_to_pose_f32(S.Ttry, st + TCSFM_STAT_POSE);   // the iterate this linearisation was evaluated at
     }
     bool final_pose = false;
     if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
@@ -1005,6 +1006,11 @@ __global__ __launch_bounds__(128) void k_solve(SolveParams P) {
 #pragma unroll
         for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
         if (P.log_scale_out) P.log_scale_out[n] = (float)S.scur;
+        if (P.stats && P.mode == 0) {                  // GN: last row = final iterate (its cost is not evaluated)
+            float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;
+#pragma unroll
+            for (int i = 0; i < 6; i++) st[i] = pose[i];
+        }
     }
     TC_STAMP(6)
 #undef TC_STAMP

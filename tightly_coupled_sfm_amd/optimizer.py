@@ -10,9 +10,12 @@ optimised: the reference runs Adam over depth-network weights with poses re-pred
 the networks frozen, takes PoseNet's coupled estimate (solve_pose_iteratively, train_mono.py:41-120, with the warp
 done by the HIP library) as the initial pose of every directed pair and refines it with `gn_iters` Gauss-Newton /
 LM iterations on the reference's own residual (libtcsfm_hip.so).  New option keys (all optional):
-    solver 'gn'|'lm', gn_iters (4), refine 'pose'|'pose+scale', lambda0, param 'se3'|'euler'.
-The reference's weight-tuning switches (optimize_depth_encoder, ...) need autograd through the networks, which is out
-of scope: they are ignored with a warning, or refused when options['strict_legacy'] is set.
+    solver 'gn'|'lm', gn_iters (4), refine 'pose'|'pose+scale'|'pose+depth', lambda0, param 'se3'|'euler',
+    prior_depth, lambda_depth (dense mode).
+The reference's `optimize_depth_pred` switch (Adam on the disparity maps themselves, optimizer.py:194-198) selects
+refine='pose+depth' unless `refine` is given: pose + per-pixel inverse depth by Gauss-Newton with a Schur complement.
+Its weight-tuning switches (optimize_depth_encoder, ...) need autograd through the networks, which is out of scope:
+they are ignored with a warning, or refused when options['strict_legacy'] is set.
 """
 from __future__ import annotations
 
@@ -25,7 +28,7 @@ from . import _lib
 from .engine import Engine, default_opts
 
 _LEGACY = ("optimize_depth_weights_bottleneck_beyond", "optimize_depth_weights_all", "optimize_depth_encoder",
-           "optimize_pose_weights_all", "optimize_depth_pred", "optimize_depth_bottleneck_values")
+           "optimize_pose_weights_all", "optimize_depth_bottleneck_values")
 
 
 def process_sample_batch(data, config):
@@ -85,13 +88,22 @@ class DepthOptimizer:
             self._engine = Engine(H, W, npairs)
         return self._engine
 
+    def _refine_mode(self):
+        o = self.options
+        return o.get("refine", "pose+depth" if o.get("optimize_depth_pred", False) else "pose")
+
     def _opts(self):
         o = self.options
+        if self._refine_mode() == "pose+depth":     # dense mode: GN on the SE(3) chart, depth prior instead of the DC term
+            kw = {k: float(o[k]) for k in ("prior_depth", "lambda_depth") if k in o}
+            return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0, w_dc=0.0,
+                                lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
+                                max_depth=float(self.config["max_depth"]), **kw)
         return default_opts(
             n_iters=int(o.get("gn_iters", 4)),
             solver=_lib.SOLVER_LM if o.get("solver", "gn") == "lm" else _lib.SOLVER_GN,
             param=_lib.PARAM_EULER if o.get("param", "se3") == "euler" else _lib.PARAM_SE3,
-            refine=_lib.REFINE_POSE_SCALE if o.get("refine", "pose") == "pose+scale" else _lib.REFINE_POSE,
+            refine=_lib.REFINE_POSE_SCALE if self._refine_mode() == "pose+scale" else _lib.REFINE_POSE,
             automask=1 if o.get("automasking", True) else 0,
             w_dc=float(o.get("l_depth_consist_weight", 0.15)) if o.get("l_depth_consist", False) else 0.0,
             lambda0=float(o.get("lambda0", 1e-4)))
@@ -156,16 +168,27 @@ class DepthOptimizer:
 
         opts = self._opts()
         tgt = stack_imgs[:, 0:3].contiguous(); src = stack_imgs[:, 3:6].contiguous()
-        pose, log_scale, stats = eng.refine(tgt, src, d_t, d_s, K.contiguous(), pose0, opts, stats=True)
+        dense = self._refine_mode() == "pose+depth"
+        if dense:
+            pose, depth_ref, stats = eng.refine_dense(tgt, src, d_t, d_s, K.contiguous(), pose0, opts, stats=True)
+            log_scale = None
+        else:
+            pose, log_scale, stats = eng.refine(tgt, src, d_t, d_s, K.contiguous(), pose0, opts, stats=True)
         res["poses_opt"] = pose[:split].cpu()
         res["poses_inv_opt"] = pose[split:].cpu()
-        res["stacked_poses_opt"] = torch.stack([pose0, pose], 1)[:split]
-        res["stacked_poses_inv_opt"] = torch.stack([pose0, pose], 1)[split:]
+        traj = stats[:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6]      # [2SB, gn_iters+1, 6]: the iterates (cf. train_mono.py:71-79)
+        res["stacked_poses_opt"] = traj[:split]
+        res["stacked_poses_inv_opt"] = traj[split:]
         res["gn_cost"] = stats[:, :, 0].cpu()          # per pair, per linearisation (extra key)
         if log_scale is not None:
             res["log_depth_scale"] = log_scale.cpu()
             s = torch.exp(log_scale[:split].reshape(S, B).mean(0)).reshape(B, 1, 1, 1)
             depths = [d * s for d in depths]
+        if dense:
+            # every directed pair refined the depth of ITS target: the window's target frame was refined once per source
+            # (forward pairs; fused by averaging inverse depths), source frame s by its inverse pair
+            inv_t = (1.0 / depth_ref[:split]).reshape(S, B, 1, H, W).mean(0)
+            depths = [1.0 / inv_t] + [depth_ref[split + i * B: split + (i + 1) * B] for i in range(S)]
         res["depths_opt"] = depths
 
         if self.options.get("mode", "scaled") == "unscaled":
@@ -181,5 +204,6 @@ class DepthOptimizer:
         flipped = self._disparities(torch.cat((target_img, torch.flip(target_img, [3])), 0)).float().contiguous()
         sd, _ = eng.disp_to_depth(flipped, cfg["min_depth"], cfg["max_depth"])
         pd = sd.cpu().numpy()[:, 0]
-        res["disp_opt"] = batch_post_process_disparity(pd[:B], pd[B:, :, ::-1])
+        # the reference hands back a float64 CPU tensor here (avg_final_predictions adds numpy arrays into a tensor, G9)
+        res["disp_opt"] = torch.from_numpy(np.ascontiguousarray(batch_post_process_disparity(pd[:B], pd[B:, :, ::-1])))
         return res
