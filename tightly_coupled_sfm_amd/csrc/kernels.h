@@ -425,6 +425,12 @@ __device__ __forceinline__ void lds_read3bv(const float4 *p, f32x4 &a, f32x4 &b,
     asm volatile("ds_read_b128 %0, %3 offset:48\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:80\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(lds_addr(p)) : "memory");
 }
+// a - b on both halves in ONE instruction (hipcc lowers a float2 subtraction to two v_sub_f32)
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float4 lds_read1(const float4 *p) {
     f32x4 x;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(lds_addr(p)) : "memory");
@@ -433,6 +439,63 @@ __device__ __forceinline__ float4 lds_read1(const float4 *p) {
 __device__ __forceinline__ void lds_write1(float4 *p, float a, float b, float c, float d) {
     f32x4 x = {a, b, c, d};
     asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr(p)), "v"(x) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-channel photometric terms of one pixel from its 3x3 window statistics (centre-shifted sums), written once for
+// T = float and T = float2 (two channels per VALU instruction).
+typedef int i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ f2 vsel(i2 c, f2 a, f2 b) { return c ? a : b; }
+__device__ __forceinline__ float vrcp(float a) { return frcp(a); }
+__device__ __forceinline__ f2 vrcp(f2 a) { return (f2){frcp(a.x), frcp(a.y)}; }
+__device__ __forceinline__ float vabs(float a) { return fabsf(a); }
+__device__ __forceinline__ f2 vabs(f2 a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ f2 vmin(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+template <class T> __device__ __forceinline__ T vsplat(float a);
+template <> __device__ __forceinline__ float vsplat<float>(float a) { return a; }
+template <> __device__ __forceinline__ f2 vsplat<f2>(float a) { return (f2){a, a}; }
+
+template <class T>
+struct ChanTerms {
+    T e1, e2;          // w_l1/3 |y-x|.clamp(0,1),  w_ssim/3 SSIM            (train_mono.py:87, losses.py:27-41)
+    T cA, cB, cC;      // d e2 / d y_q = cA + cB (y_q - y_c) + cC (x_q - x_c)  for the 9 window pixels q
+    T id1, id2;        // curvature weights of the mean / covariance parts of SSIM
+    T l1x, l1y;        // d e1 / d(ix, iy) of the centre sample
+    T lxx, lxy, lyy;   // L1 part of the 2x2 curvature
+};
+
+template <class T>
+__device__ __forceinline__ void ssim_l1_channel(T xc, T yc, T gxc, T gyc, T Sx, T Sy, T Sxx, T Syy, T Sxy, float ws, float wl,
+                                                float eps, ChanTerms<T> &o) {
+    const float n9 = 1.f / 9.f;
+    const T zero = vsplat<T>(0.f), one = vsplat<T>(1.f);
+    T mdx = Sx * n9, mdy = Sy * n9;
+    T mux = xc + mdx, muy = yc + mdy;
+    T sigx = Sxx * n9 - mdx * mdx, sigy = Syy * n9 - mdy * mdy, sigxy = Sxy * n9 - mdx * mdy;
+    T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+    T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+    T idn = vrcp(d1 * d2), ratio = n1 * n2 * idn;
+    T raw = (one - ratio) * 0.5f;
+    auto cl = (raw < zero) || (raw > one);
+    o.e2 = ws * vmin(vmax(raw, zero), one);
+    T pre = vsel(cl, zero, idn * (-0.5f * n9 * ws));
+    o.cB = pre * (ratio * d1) * -2.f;
+    o.cC = pre * n1 * 2.f;
+    o.cA = pre * 2.f * (mux * n2 - ratio * muy * d2) - o.cB * mdy - o.cC * mdx;
+    T wi = vsel(cl, zero, idn * ws);
+    o.id1 = wi * d2; o.id2 = 1.125f * wi * d1;
+    // L1 term
+    T rr = yc - xc, ar = vabs(rr);
+    auto inr = ar <= one;
+    o.e1 = wl * vmin(ar, one);
+    T sgn = vsel(inr, vsel(rr > zero, one, vsel(rr < zero, -one, zero)), zero) * wl;
+    o.l1x = sgn * gxc; o.l1y = sgn * gyc;
+    T w1 = vsel(inr, wl * vrcp(vmax(ar, vsplat<T>(eps))), zero);
+    o.lxx = w1 * gxc * gxc; o.lxy = w1 * gxc * gyc; o.lyy = w1 * gyc * gyc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -601,51 +664,29 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f};
         f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f}, G2 = {0.f, 0.f};
         float Sxy2 = 0.f;
+        // neighbour pointer walks the 3x3 window with ONE vector add per step (the step is wave-uniform)
+        const float4 *nbA = ctr - (CW + 1) * (LDS_REC / 4);
 #pragma unroll 1
         for (int kk = 0; kk < 9; kk++) {
-            const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
             f32x4 n0, n1, n2;
-            lds_read3v(ctr + (dy * CW + dx) * (LDS_REC / 4), n0, n1, n2);
-            f2 ey = n0.lo - yc01, ex = n0.hi - xc01;
+            lds_read3v(nbA, n0, n1, n2);
+            nbA += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
+            f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
             Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
             Gx01 += n1.lo; Gy01 += n1.hi;
-            f2 e2v = n2.lo - yx2c;               // (y2 - y2c, x2 - x2c)
+            f2 e2v = pk_sub(n2.lo, yx2c);        // (y2 - y2c, x2 - x2c)
             S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
         }
-        const float Sx[3] = {Sx01.x, Sx01.y, S2.y}, Sy[3] = {Sy01.x, Sy01.y, S2.x};
-        const float Sxx[3] = {Sxx01.x, Sxx01.y, SS2.y}, Syy[3] = {Syy01.x, Syy01.y, SS2.x}, Sxy[3] = {Sxy01.x, Sxy01.y, Sxy2};
-        const float Gx[3] = {Gx01.x, Gx01.y, G2.x}, Gy[3] = {Gy01.x, Gy01.y, G2.y};
-        const float n9 = 1.f / 9.f;
-        float e1 = 0.f, e2 = 0.f;
-        float cA[3], cB[3], cC[3], id1[3], id2[3];
-        float l1x = 0.f, l1y = 0.f;          // sum_c wl sgn_c g_c   (centre part of d e1)
-        float lxx = 0.f, lxy = 0.f, lyy = 0.f;  // curvature Lambda (without the W factor)
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float mdx = Sx[ch] * n9, mdy = Sy[ch] * n9;
-            float mux = xc[ch] + mdx, muy = yc[ch] + mdy;
-            float sigx = Sxx[ch] * n9 - mdx * mdx, sigy = Syy[ch] * n9 - mdy * mdy;
-            float sigxy = Sxy[ch] * n9 - mdx * mdy;
-            float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
-            float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
-            float idn = frcp(d1 * d2), ratio = n1 * n2 * idn;
-            float raw = (1.f - ratio) * 0.5f;
-            bool cl = (raw < 0.f) || (raw > 1.f);
-            e2 += P.ws * clamp01(raw);
-            // d s/d y_q = cB (y_q - mu_y) + cC (x_q - mu_x) + cA0  =  cA + cB (y_q - y_c) + cC (x_q - x_c)
-            float pre = cl ? 0.f : -0.5f * idn * n9 * P.ws;
-            cB[ch] = pre * (-ratio * 2.f * d1);
-            cC[ch] = pre * (2.f * n1);
-            cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2) - cB[ch] * mdy - cC[ch] * mdx;
-            id1[ch] = cl ? 0.f : P.ws * idn * d2; id2[ch] = cl ? 0.f : 1.125f * P.ws * idn * d1;
-            // L1 term, train_mono.py:87
-            float rr = yc[ch] - xc[ch], ar = fabsf(rr);
-            e1 += P.wl * fminf(ar, 1.f);
-            float sgn = (ar <= 1.f) ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : 0.f;
-            l1x += P.wl * sgn * gxc[ch]; l1y += P.wl * sgn * gyc[ch];
-            float w1 = (ar <= 1.f) ? P.wl * frcp(fmaxf(ar, P.eps)) : 0.f;
-            lxx += w1 * gxc[ch] * gxc[ch]; lxy += w1 * gxc[ch] * gyc[ch]; lyy += w1 * gyc[ch] * gyc[ch];
-        }
+        // per-channel SSIM value / gradient coefficients / curvature weights and the L1 term: channels (0,1) as one packed
+        // evaluation, channel 2 as a scalar one (same code, ssim_l1_channel<T>)
+        ChanTerms<f2> t01;
+        ChanTerms<float> t2;
+        ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
+        ssim_l1_channel<float>(yx2c.y, yx2c.x, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+        const float cA[3] = {t01.cA.x, t01.cA.y, t2.cA}, cB[3] = {t01.cB.x, t01.cB.y, t2.cB}, cC[3] = {t01.cC.x, t01.cC.y, t2.cC};
+        const float e1 = t01.e1.x + t01.e1.y + t2.e1, e2 = t01.e2.x + t01.e2.y + t2.e2;
+        const float l1x = t01.l1x.x + t01.l1x.y + t2.l1x, l1y = t01.l1y.x + t01.l1y.y + t2.l1y;
+        float lxx = t01.lxx.x + t01.lxx.y + t2.lxx, lxy = t01.lxy.x + t01.lxy.y + t2.lxy, lyy = t01.lyy.x + t01.lyy.y + t2.lyy;
         float diff = e1 + e2;
 
         f2 de2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // d(e2)/d theta, column pairs (01)(23)(45)
@@ -653,16 +694,15 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         if (MODE == MODE_LIN) {
             // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
             const f2 cA01 = {cA[0], cA[1]}, cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
+            const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
-                const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
-                const float4 *nb = ctr + (dy * CW + dx) * (LDS_REC / 4);
                 f32x4 n0, n1, n2, n3, n4, n5;
                 lds_read3v(nb, n0, n1, n2);
                 lds_read3bv(nb, n3, n4, n5);
-                f2 ey = n0.lo - yc01, ex = n0.hi - xc01;
+                f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
                 f2 cf = cA01 + cB01 * ey + cC01 * ex;
-                f2 e2v = n2.lo - yx2c;
+                f2 e2v = pk_sub(n2.lo, yx2c);
                 float cf2 = cA[2] + cB[2] * e2v.x + cC[2] * e2v.y;
                 f2 tx = cf * n1.lo, ty = cf * n1.hi;
                 float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
@@ -670,15 +710,17 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 de2[1] += sx * n3.hi; de2[1] += sy * n5.lo;
                 de2[2] += sx * n4.lo; de2[2] += sy * n5.hi;
                 if (NP == 7) { float4 n6 = lds_read1(nb + 6); de6 += sx * n6.x + sy * n6.y; }
+                nb += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
             }
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1, Cov ~ 9/8 (g - mean)(g - mean)' (centre sample)
-                float mx = Gx[ch] * n9, my = Gy[ch] * n9;
-                float ex = gxc[ch] - mx, ey = gyc[ch] - my;
-                lxx += id2[ch] * ex * ex + id1[ch] * mx * mx;
-                lxy += id2[ch] * ex * ey + id1[ch] * mx * my;
-                lyy += id2[ch] * ey * ey + id1[ch] * my * my;
+            {   // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1, Cov ~ 9/8 (g - mean)(g - mean)' (centre sample)
+                const float n9 = 1.f / 9.f;
+                const f2 mx = Gx01 * n9, my = Gy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+                const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
+                         qyy = t01.id2 * ey * ey + t01.id1 * my * my;
+                const float mx2 = G2.x * n9, my2 = G2.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
+                lxx += qxx.x + qxx.y + t2.id2 * ex2 * ex2 + t2.id1 * mx2 * mx2;
+                lxy += qxy.x + qxy.y + t2.id2 * ex2 * ey2 + t2.id1 * mx2 * my2;
+                lyy += qyy.x + qyy.y + t2.id2 * ey2 * ey2 + t2.id1 * my2 * my2;
             }
         }
 
@@ -744,11 +786,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 for (int j = 0; j < 6; j++) {
                     const float la = (j & 1) ? la2[j >> 1].y : la2[j >> 1].x, lb = (j & 1) ? lb2[j >> 1].y : lb2[j >> 1].x;
 #pragma unroll
-                    for (int p = 0; p <= (j >> 1); p++) { aH2[h] += la * a2[p] + lb * b2[p]; h++; }
+                    for (int p = 0; p <= (j >> 1); p++) { aH2[h] += la * a2[p]; aH2[h] += lb * b2[p]; h++; }
                 }
                 if (NP == 7) {
 #pragma unroll
-                    for (int p = 0; p < 3; p++) { aH2[h] += la6 * a2[p] + lb6 * b2[p]; h++; }
+                    for (int p = 0; p < 3; p++) { aH2[h] += la6 * a2[p]; aH2[h] += lb6 * b2[p]; h++; }
                     aH66 += la6 * a6 + lb6 * b6;
                 }
             }
