@@ -55,7 +55,7 @@ typedef struct tcsfm_opts {
     int32_t automask;      /* mask = valid * (diff < auto_err), helpers.py:17-19; options['automasking'] */
     int32_t depth_is_disp; /* depth inputs are sigmoid disparities: disp_to_depth is fused (learning_helpers.py:77-86) */
     int32_t host_ptrs;     /* array arguments are host pointers                                          */
-    int32_t reserved0;
+    int32_t argmin;        /* tcsfm_refine_window with S > 1: per-pixel min over the sources, options['diff_img_argmin'] */
     float w_l1, w_ssim;    /* 0.15 / 0.85, train_mono.py:87                                              */
     float w_dc;            /* options['l_depth_consist_weight'] if options['l_depth_consist'] else 0, optimizer.py:83-86 */
     float irls_eps;        /* floor of the IRLS denominators                                             */
@@ -142,6 +142,20 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                  const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
                  float *log_scale_out, float *stats_out);
+
+/* Window form of tcsfm_refine: the call surface of solve_pose_iteratively / optimize_window (train_mono.py:41-62,
+ * optimizer.py:136-160): B target frames with S source frames each, given ONCE --
+ *   tgt [B,3,H,W], srcs [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W], K [B,3,3] --
+ * and refined as 2*S*B directed pairs in the reference's stacked order (train_mono.py:54-62): pair s*B+b reconstructs
+ * target b from source s (forward), pair S*B+s*B+b the reverse (inverse).  pose_in / pose_out [2*S*B,6],
+ * log_scale_* [2*S*B] or NULL, stats_out [2*S*B,n_iters+1,TCSFM_NSTAT] or NULL, as in tcsfm_refine.
+ * With o->argmin and S > 1 the forward pairs of a target use the reference's per-pixel min over the sources
+ * (compute_optimization_loss, optimizer.py:47-69): at every linearisation a pixel counts only for the source with the
+ * smallest photometric error there, under the union validity mask and the auto-mask of the minima.
+ * The handle must have been created with max_pairs >= 2*S*B. */
+int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                        const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);
 
 /* Dense mode (BASELINE config 5): refine the 6-DoF pose AND the per-pixel inverse depth of the target of N directed
  * pairs: o->n_iters Gauss-Newton iterations, exact depth gradient (equal to reference autograd d loss / d depth), per-pixel

@@ -203,6 +203,31 @@ class Oracle:
         s = self.lib.orc_scale_recovery(B, H, W, self._p(depth), self._p(K), C.c_double(real_cam_height), C.byref(med))
         return s, med.value
 
+    def window_select(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None):
+        """per-pixel min-over-sources selection masks of the forward pairs at the given poses:
+        tgt [B,3,H,W], srcs [S,B,3,H,W], depth_t [B,H,W], depth_s [S,B,H,W], K [B,3,3], poses [S*B,6] -> masks [S*B,H,W]"""
+        opts = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K = map(self._r, (tgt, srcs, depth_t, depth_s, K))
+        S, B, _, H, W = srcs.shape
+        T = np.ascontiguousarray(np.stack([self._d(self.pose_to_T(p)).reshape(12) for p in np.asarray(poses).reshape(-1, 6)]))
+        mask = np.empty((S * B, H, W), self.dt)
+        self.lib.orc_window_select(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
+                                   C.byref(opts), self._p(T), None, self._p(mask))
+        return mask
+
+    def refine_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, log_scale=None):
+        """window mode (forward + inverse pairs, optional min-over-sources selection): poses [2*S*B,6] in the stacked
+        order of train_mono.py:54-62 -> (poses [2SB,6], log_scale [2SB] or None, stats [2SB,n_iters+1,4])"""
+        opts = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K = map(self._r, (tgt, srcs, depth_t, depth_s, K))
+        S, B, _, H, W = srcs.shape
+        pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(2 * S * B, 6)).copy()
+        ls = None if log_scale is None else np.ascontiguousarray(np.asarray(log_scale, dtype=np.float64)).copy()
+        stats = np.zeros((2 * S * B, opts.n_iters + 1, 4))
+        self.lib.orc_refine_window(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
+                                   C.byref(opts), int(bool(argmin)), self._p(pose), self._p(ls), self._p(stats))
+        return pose, ls, stats
+
     def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
         """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4])."""
         opts = opts or default_opts()

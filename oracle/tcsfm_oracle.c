@@ -493,9 +493,9 @@ typedef struct {
  *   Curvature of the W factor (e dW/dtheta) is neglected in H; it is present in g.
  * J1/J2/J3/E (optional, [H*W*np] / [H*W*3]) return the per-pixel rows for Jacobian pinning.
  */
-void orc_linearize(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+static void linearize_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                    const double T[12], const real *K, double log_scale, const orc_opts *op, const real *auto_err_in,
-                   lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
+                   const real *mask_in, lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
     int n = H * W, np = op->nparam;
     cam_t c;
     cam_setup(&c, H, W, K, T, log_scale);
@@ -574,6 +574,7 @@ void orc_linearize(int H, int W, const real *tgt, const real *src, const real *d
             real diff = e1 + e2;
             real m = (real)P->valid;
             if (op->automask) m *= (diff < ae[i]) ? (real)1 : (real)0;
+            if (mask_in) m = mask_in[i];   /* window mode: the per-pixel min-over-sources selection replaces the pair's own mask */
             M[i] = m; nmask += m;
             E[3 * i] = Wt * e1; E[3 * i + 1] = Wt * e2; E[3 * i + 2] = dd;
             for (int j = 0; j < np; j++) {
@@ -613,6 +614,12 @@ void orc_linearize(int H, int W, const real *tgt, const real *src, const real *d
     if (Eo) memcpy(Eo, E, sizeof(real) * n * 3);
     if (Mo) memcpy(Mo, M, sizeof(real) * n);
     free(px); free(ae); free(rec); free(J1); free(J2); free(J3); free(E); free(M); free(Lam);
+}
+
+void orc_linearize(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                   const double T[12], const real *K, double log_scale, const orc_opts *op, const real *auto_err_in,
+                   lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
+    linearize_masked(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op, auto_err_in, NULL, out, J1o, J2o, J3o, Eo, Mo);
 }
 
 /* scalar cost only: the quantity generate_loss_surface sweeps, plot_loss_surface.py:31-33,45-47 */
@@ -731,6 +738,121 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
     orc_T_to_pose(Tcur, pose_io);
     if (np == 7 && log_scale_io) *log_scale_io = scur;
     free(ae);
+}
+
+/* ------------------------------------------------------------------------- */
+/* window mode: B target frames x S sources, forward + inverse directed pairs, per-pixel min over the sources        */
+/*
+ * Pair order = the stacked order of solve_pose_iteratively (train_mono.py:54-62): n = s*B + b are the forward pairs
+ * (target b reconstructed from source s), SB + s*B + b the inverse pairs.  With argmin (optimizer.py:47-69,
+ * options['diff_img_argmin']) the forward pairs of one target share a per-pixel selection evaluated at the CURRENT poses:
+ *     s*(p)   = first argmin_s diff_s(p)                                          (torch.min over the source axis)
+ *     keep(p) = max_s valid_s(p) > 0  and  (automask ? min_s diff_s(p) < min_s auto_err_s(p) : 1)
+ *     M_s(p)  = keep(p) [s == s*(p)]
+ * and pair s is linearised with M_s in place of its own valid x auto-mask.  Each pair keeps its own normaliser sum M_s
+ * and its own weight map W_s (the reference multiplies every source by the weight map of source 0, optimizer.py:69 --
+ * deliberately not reproduced: it would couple the pose of source 0 into the other pairs' gradients).
+ * Inverse pairs are independent problems, exactly as in orc_refine.  Everything else (GN/LM, damping, retraction) is
+ * per pair and identical to orc_refine.
+ */
+void orc_window_select(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, const double *T /* [S*B][12] */, const double *log_scale /* [S*B] or NULL */,
+                       real *mask /* [S*B][H*W] */) {
+    int n = H * W;
+    real *diff = (real *)malloc(sizeof(real) * n * S), *valid = (real *)malloc(sizeof(real) * n * S), *ae = (real *)malloc(sizeof(real) * n * S);
+    for (int b = 0; b < B; b++) {
+        for (int s = 0; s < S; s++) {
+            int m = s * B + b;
+            orc_photometric(H, W, tgt + (size_t)b * 3 * n, srcs + (size_t)m * 3 * n, depth_t + (size_t)b * n, depth_s + (size_t)m * n,
+                            T + 12 * m, K + 9 * b, log_scale ? log_scale[m] : 0.0, op->w_l1, op->w_ssim, diff + (size_t)s * n,
+                            valid + (size_t)s * n, NULL, ae + (size_t)s * n, NULL, NULL);
+        }
+        for (int i = 0; i < n; i++) {
+            int smin = 0;
+            real dmin = diff[i], amin = ae[i], vany = valid[i];
+            for (int s = 1; s < S; s++) {
+                if (diff[(size_t)s * n + i] < dmin) { dmin = diff[(size_t)s * n + i]; smin = s; }
+                if (ae[(size_t)s * n + i] < amin) amin = ae[(size_t)s * n + i];
+                if (valid[(size_t)s * n + i] > vany) vany = valid[(size_t)s * n + i];
+            }
+            int keep = vany > 0 && (!op->automask || dmin < amin);
+            for (int s = 0; s < S; s++) mask[(size_t)(s * B + b) * n + i] = (keep && s == smin) ? 1 : 0;
+        }
+    }
+    free(diff); free(valid); free(ae);
+}
+
+static double cost_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                          const double T[12], const real *K, double log_scale, const orc_opts *op, const real *mask) {
+    int n = H * W;
+    real *d = (real *)malloc(sizeof(real) * n), *va = (real *)malloc(sizeof(real) * n), *w = (real *)malloc(sizeof(real) * n);
+    orc_photometric(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op->w_l1, op->w_ssim, d, va, w, NULL, NULL, NULL);
+    double num = 0, den = 0, dc = 0;
+    for (int i = 0; i < n; i++) { num += mask[i] * w[i] * d[i]; den += mask[i]; dc += 1 - w[i]; }
+    free(d); free(va); free(w);
+    return (den > 0 ? num / den : 0.0) + op->w_dc * dc / n;
+}
+
+void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, int argmin, double *pose_io /* [2SB][6] */,
+                       double *log_scale_io /* [2SB] or NULL */, double *stats /* [2SB][n_iters+1][4] or NULL */) {
+    const int n = H * W, np = op->nparam, SB = S * B, N = 2 * SB, sel = argmin && S > 1;
+    typedef struct { double Tcur[12], Ttry[12], scur, stry, s0, lambda; lin_t cur; int have_cur; } pstate;
+    pstate *ps = (pstate *)calloc(N, sizeof(pstate));
+    real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
+    double *Tf = (double *)malloc(sizeof(double) * 12 * SB), *lsf = (double *)malloc(sizeof(double) * SB);
+    const real **pt = (const real **)malloc(sizeof(real *) * N * 4);
+    for (int m = 0; m < N; m++) {
+        int inv = m >= SB, q = inv ? m - SB : m, b = q % B;
+        const real *ti = tgt + (size_t)b * 3 * n, *si = srcs + (size_t)q * 3 * n, *td = depth_t + (size_t)b * n, *sd = depth_s + (size_t)q * n;
+        pt[4 * m] = inv ? si : ti; pt[4 * m + 1] = inv ? ti : si; pt[4 * m + 2] = inv ? sd : td; pt[4 * m + 3] = inv ? td : sd;
+        photo_err_map(H, W, pt[4 * m], pt[4 * m + 1], op->w_l1, op->w_ssim, ae + (size_t)m * n);
+        orc_pose_to_T(pose_io + 6 * m, ps[m].Tcur);
+        memcpy(ps[m].Ttry, ps[m].Tcur, sizeof(ps[m].Tcur));
+        ps[m].scur = ps[m].stry = ps[m].s0 = (np == 7 && log_scale_io) ? log_scale_io[m] : 0.0;
+        ps[m].lambda = op->lambda0;
+    }
+    const double pw = (np == 7) ? op->prior_scale : 0.0;
+    for (int it = 0; it <= op->n_iters; it++) {
+        const int final = it == op->n_iters;
+        if (final && !(op->solver == 1 && op->n_iters > 0)) break;
+        if (sel) {
+            for (int m = 0; m < SB; m++) { memcpy(Tf + 12 * m, ps[m].Ttry, sizeof(double) * 12); lsf[m] = ps[m].stry; }
+            orc_window_select(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, Tf, lsf, mask);
+        }
+        for (int m = 0; m < N; m++) {
+            pstate *p = &ps[m];
+            const real *mk = (sel && m < SB) ? mask + (size_t)m * n : NULL;
+            const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
+            double *st = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
+            const double prior = pw * (p->stry - p->s0) * (p->stry - p->s0);
+            if (final) { /* LM: cost-only check of the last trial step */
+                double c = (mk ? cost_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, mk)
+                               : orc_cost(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op)) + prior;
+                if (st) { st[0] = c; st[1] = c; st[2] = 0; st[3] = p->lambda; }
+                if (c < p->cur.cost) { memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; }
+                continue;
+            }
+            lin_t tr;
+            linearize_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, ae + (size_t)m * n, mk,
+                             &tr, NULL, NULL, NULL, NULL, NULL);
+            if (np == 7) { tr.cost += prior; tr.g[6] += 2 * pw * (p->stry - p->s0); tr.H[6 * np + 6] += 2 * pw; }
+            if (st) { st[0] = tr.cost; st[1] = tr.cost_photo; st[2] = tr.n_mask; st[3] = p->lambda; }
+            if (op->solver == 0 || !p->have_cur || tr.cost < p->cur.cost) {
+                if (op->solver == 1 && p->have_cur) p->lambda = fmax(p->lambda * op->lambda_down, op->lambda_min);
+                p->cur = tr; memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; p->have_cur = 1;
+            } else {
+                p->lambda *= op->lambda_up;
+            }
+            apply_step(op, p->cur.H, p->cur.g, p->lambda, p->Tcur, p->scur, p->Ttry, &p->stry);
+        }
+    }
+    for (int m = 0; m < N; m++) {
+        if (!(op->solver == 1 && op->n_iters > 0)) { memcpy(ps[m].Tcur, ps[m].Ttry, sizeof(ps[m].Tcur)); ps[m].scur = ps[m].stry; }
+        orc_T_to_pose(ps[m].Tcur, pose_io + 6 * m);
+        if (np == 7 && log_scale_io) log_scale_io[m] = ps[m].scur;
+    }
+    free(ps); free(ae); free(mask); free(Tf); free(lsf); free(pt);
 }
 
 /* ------------------------------------------------------------------------- */

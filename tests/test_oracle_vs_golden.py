@@ -232,3 +232,43 @@ def test_window_G9_initial_poses(oracle64):
     assert _maxabs(stacked[split:], g["out_stacked_poses_inv_init"]) < 2e-6
     assert _maxabs(full[:split], g["out_poses_init"]) < 2e-6 and _maxabs(full[split:], g["out_poses_inv_init"]) < 2e-6
     assert _maxabs(g["out_gt_poses"], w["gt"].reshape(-1, 6)) == 0 and _maxabs(g["out_gt_poses_inv"], -w["gt"].reshape(-1, 6)) == 0
+
+
+def test_window_selection_vs_reference_maps_G4(oracle64):
+    """min-over-sources selection (optimizer.py:47-69) of the oracle's window mode against the selection computed from the
+    reference's own fwd maps of solve_pose_iteratively (golden G4, B=2, S=2)"""
+    g = load_golden("batch24x40")
+    S, B = g["sources"].shape[:2]
+    H, W = g["target"].shape[2:]
+    poses = g["first"][:S * B]                                            # iters=1: the poses the maps were evaluated at
+    mine = oracle64.window_select(g["target"], g["sources"], g["depths"][0][:, 0], g["depths"][1:][:, :, 0], g["K"], poses)
+    diff = g["it1_fwd_diff_img"][:, 0].reshape(S, B, H, W)
+    valid = g["it1_fwd_valid_mask"][:, 0].reshape(S, B, H, W)
+    ae = g["it1_fwd_auto_mask_error"][:, 0].reshape(S, B, H, W)
+    smin = np.argmin(diff, 0)                                             # first minimum, like torch.min
+    keep = (valid.sum(0).clip(0, 1) > 0) & (diff.min(0) < ae.min(0))
+    ref = np.stack([(keep & (smin == s)).astype(np.float64) for s in range(S)]).reshape(S * B, H, W)
+    assert np.array_equal(mine, ref)
+    assert 0.02 < ref.mean() < 0.6 and all(ref[s * B:(s + 1) * B].sum() > 0 for s in range(S))   # both sources get selected
+
+
+def test_window_mode_reduces_to_pair_mode(oracle64):
+    """without the selection (or with one source) the window refinement is the per-pair refinement in the stacked order"""
+    from oracle.oracle import default_opts
+    g = load_golden("batch24x40")
+    S, B = g["sources"].shape[:2]
+    d_t, d_s = g["depths"][0][:, 0], g["depths"][1:][:, :, 0]
+    o = default_opts(n_iters=2)
+    pw, _, sw = oracle64.refine_window(g["target"], g["sources"], d_t, d_s, g["K"], g["first"], o, argmin=False)
+    for m in (0, 3, 5, 6):
+        inv, q = m >= S * B, m % (S * B)
+        s, b = divmod(q, B)
+        t, sr, dt, ds = g["target"][b], g["sources"][s, b], d_t[b], d_s[s, b]
+        if inv:
+            t, sr, dt, ds = sr, t, ds, dt
+        p, _, st = oracle64.refine(t, sr, dt, ds, g["first"][m], g["K"][b], o)
+        assert _maxabs(p, pw[m]) < 1e-14 and _maxabs(st, sw[m]) < 1e-14
+    # with the selection the forward pairs change (fewer pixels each), the inverse pairs do not
+    pa, _, sa = oracle64.refine_window(g["target"], g["sources"], d_t, d_s, g["K"], g["first"], o, argmin=True)
+    assert np.all(sa[:S * B, 0, 2] < sw[:S * B, 0, 2]) and _maxabs(pa[S * B:], pw[S * B:]) == 0
+    assert _maxabs(pa[:S * B], pw[:S * B]) > 1e-7

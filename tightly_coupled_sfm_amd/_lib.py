@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libtcsfm_hip.so")
 class Opts(C.Structure):
     """mirror of struct tcsfm_opts"""
     _fields_ = [("n_iters", C.c_int32), ("solver", C.c_int32), ("param", C.c_int32), ("refine", C.c_int32),
-                ("automask", C.c_int32), ("depth_is_disp", C.c_int32), ("host_ptrs", C.c_int32), ("reserved0", C.c_int32),
+                ("automask", C.c_int32), ("depth_is_disp", C.c_int32), ("host_ptrs", C.c_int32), ("argmin", C.c_int32),
                 ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_dc", C.c_float), ("irls_eps", C.c_float),
                 ("lambda0", C.c_float), ("lambda_up", C.c_float), ("lambda_down", C.c_float), ("lambda_min", C.c_float),
                 ("min_depth", C.c_float), ("max_depth", C.c_float), ("prior_scale", C.c_float), ("lambda_depth", C.c_float), ("prior_depth", C.c_float), ("reserved1", C.c_float)]
@@ -41,6 +41,7 @@ _SIGNATURES = {
     "tcsfm_photometric": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 12),
     "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
     "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
+    "tcsfm_refine_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
     "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
     "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),

@@ -58,6 +58,8 @@ struct LinParams {
     float wl, ws;           // w_l1/3, w_ssim/3
     float eps;              // irls_eps
     int automask;
+    const float *ext_mask;  // window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
+    int n_ext;
 };
 
 constexpr float SSIM_C1 = 0.01f * 0.01f;
@@ -203,12 +205,14 @@ struct InitParams {
     PairConst *pc;
     int N, shared_image;                // shared_image: all problems read image pair 0 (loss-surface sweep)
     float lambda0;
+    int K_mod;                          // window form: pair n uses intrinsics K[n % K_mod] (0: one matrix per pair)
 };
 
 __device__ inline void init_pair(const InitParams &P, int n) {
     PairState &S = P.st[n];
     int img = P.shared_image ? 0 : n;
-    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[img * 9 + i];
+    const int kidx = P.K_mod > 0 ? n % P.K_mod : img;
+    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[kidx * 9 + i];
     double pose[6];
     for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
     {   // device-side guard of the pinhole contract (the host validates a given intrinsics buffer only once)
@@ -241,6 +245,10 @@ struct PackParams {
     int depth_is_disp;
     float min_disp, max_disp;
     InitParams init;                             // init.N > 0: pair initialisation fused into this launch (one thread per pair)
+    // window form (win_B > 0): tgt [B,3,H,W], src [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W]; directed pairs in
+    // the stacked order of train_mono.py:54-62 -- n = s B + b forward (tgt b <- src s), S B + s B + b inverse -- are formed
+    // here by indexing, the caller never materialises the repeated / concatenated tensors
+    int win_B, win_S;
 };
 
 // (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory.
@@ -284,8 +292,15 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     if (idx >= hw) return;
     int v = idx / P.W, u = idx - v * P.W;
     const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
+    const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
+    if (P.win_B > 0) {
+        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
+        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)q * 3 * hw;
+        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)q * hw;
+        t = inv ? si : ti; s = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
+    }
     float ae = photo_err_planar(t, s, P.H, P.W, u, v, P.wl, P.ws);
-    float dt = P.depth_t[(size_t)n * hw + idx], ds = P.depth_s[(size_t)n * hw + idx];
+    float dt = dtp[idx], ds = dsp[idx];
     if (P.depth_is_disp) {  // disp_to_depth, learning_helpers.py:77-86
         dt = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * dt);
         ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
@@ -293,6 +308,31 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     P.tgtpack[(size_t)n * hw + idx] = make_float4(t[idx], t[hw + idx], t[2 * hw + idx], ae);
     P.srcpack[(size_t)n * hw + idx] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], ds);
     P.depth_out[(size_t)n * hw + idx] = dt;
+}
+
+// Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69): from the forward pairs'
+// diff / valid maps at the current poses -> one 0/1 selection mask per forward pair (see oracle orc_window_select).
+struct SelectParams {
+    const float *diff, *valid;   // [S*B][H*W] written by k_linearize<MODE_MAPS>
+    const float4 *tgtpack;       // .w = auto_err of the pair
+    float *mask;                 // [S*B][H*W]
+    int B, S, hw, automask;
+};
+
+__global__ __launch_bounds__(256) void k_select(SelectParams P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (idx >= P.hw) return;
+    int smin = 0;
+    float dmin = 0.f, amin = 0.f, vany = 0.f;
+    for (int s = 0; s < P.S; s++) {
+        const size_t o = (size_t)(s * P.B + b) * P.hw + idx;
+        const float d = P.diff[o], a = P.tgtpack[o].w, v = P.valid[o];
+        if (s == 0 || d < dmin) { dmin = d; smin = s; }      // first minimum, like torch.min
+        amin = (s == 0) ? a : fminf(amin, a);
+        vany = fmaxf(vany, v);
+    }
+    const bool keep = vany > 0.f && (!P.automask || dmin < amin);
+    for (int s = 0; s < P.S; s++) P.mask[(size_t)(s * P.B + b) * P.hw + idx] = (keep && s == smin) ? 1.f : 0.f;
 }
 
 // SSIM_Loss.forward, losses.py:27-41, on C planes of N images: x, y [N*C, H, W] -> out (same shape)
@@ -731,6 +771,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float dd = clamp01(raw), Wt = 1.f - dd;
         bool inimg = c_in[k];
         bool m = inimg && c_valid[k] && (!P.automask || diff < c_ae[k]);
+        if (P.ext_mask != nullptr && n < P.n_ext)   // wave-uniform branch
+            m = inimg && P.ext_mask[(size_t)n * hw + (size_t)(inimg ? (y00 + ly - 1) * W + (x00 + lx - 1) : 0)] != 0.f;
 
         if (MODE == MODE_MAPS) {
             if (inimg) {

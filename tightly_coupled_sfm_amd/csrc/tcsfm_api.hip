@@ -43,6 +43,7 @@ struct tcsfm_ctx {
     int nblk_alloc = 0, ngrp_alloc = 0;   // scratch capacity (covers the 32x8 tiling of the dense kernel too)
     float *dense_rec = nullptr, *depth0 = nullptr;   // dense mode scratch, allocated on first use
     double *delta = nullptr;
+    float *sel_maps = nullptr;   // window mode scratch: diff | valid | selection mask, [3][max_pairs][H*W], allocated on first use
     unsigned *scale_keys = nullptr, *scale_hist = nullptr;   // scale recovery scratch (keys, 256 bins + 4 state words)
     long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
     std::vector<HostStage> stage;
@@ -179,8 +180,8 @@ void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
     hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
 }
 
-void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mode) {
-    ProfScope prof(h, 0);
+void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mode, int prof_class = 0) {
+    ProfScope prof(h, prof_class);
     if (np == 6) {
         if (mode == MODE_MAPS) launch_lin_t<6, false, MODE_MAPS>(h, P, N);
         else if (mode == MODE_COST) launch_lin_t<6, false, MODE_COST>(h, P, N);
@@ -207,14 +208,16 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
     InitParams I;
     I.pose = pose; I.log_scale = ls; I.K = K; I.st = h->state; I.pc = h->pconst; I.N = N; I.shared_image = shared;
     I.lambda0 = o->lambda0;
+    I.K_mod = 0;
     return I;
 }
 
 // init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
 int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
-             const InitParams *init = nullptr) {
+             const InitParams *init = nullptr, int win_B = 0, int win_S = 0) {
     PackParams P;
     memset(&P.init, 0, sizeof(P.init));
+    P.win_B = win_B; P.win_S = win_S;
     if (init) {
         // group tickets must be zero when k_linearize starts: zeroed at create, re-zeroed by the reducers after every launch;
         // only a call that failed midway can leave them dirty
@@ -343,7 +346,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist};
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist, h->sel_maps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -578,22 +581,24 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
     return TCSFM_OK;
 }
 
-int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
-                 const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
-                 float *log_scale_out, float *stats_out) {
+// shared body of tcsfm_refine (win_B == 0: one image set per pair) and tcsfm_refine_window (win_B x win_S window)
+static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
+                       float *pose_out, float *log_scale_out, float *stats_out) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
     HIPCHK(h, hipSetDevice(h->device));
-    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
+    if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W;
     const int np = np_of(o);
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose_in, *d_ls_in;
-    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
-    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
-    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
-    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
-    if ((rc = to_dev(h, o, 4, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 0, tgt, nimg_t * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, nimg_s * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, nimg_t * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, nimg_s * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)nimg_t * 9, &d_K))) return rc;
     if ((rc = to_dev(h, o, 5, pose_in, (size_t)N * 6, &d_pose_in))) return rc;
     if ((rc = to_dev(h, o, 6, log_scale_in, (size_t)N, &d_ls_in))) return rc;
     float *d_pose_out, *d_ls_out = nullptr, *d_stats = nullptr;
@@ -604,15 +609,33 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
         if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
     }
+    // per-pixel min over the sources: the forward pairs get an external selection mask, rebuilt at every linearisation
+    const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
+    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
 
     InitParams I = init_params(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0);
-    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I))) return rc;
+    I.K_mod = win_B;
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S))) return rc;
     LinParams P = lin_params(h, o, np);
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
+    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
+          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
+    auto select_pass = [&]() {   // residual maps of the forward pairs at the current trial poses -> selection masks
+        LinParams M = P;
+        M.o_diff = sel_diff; M.o_valid = sel_valid;
+        launch_lin(h, M, n_sel, np, false, MODE_MAPS, 2);   // profiling class 2 = everything but linearize / solve
+        SelectParams Q;
+        Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
+        Q.B = win_B; Q.S = win_S; Q.hw = (int)hw; Q.automask = o->automask;
+        ProfScope prof(h, 2);
+        hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), win_B), dim3(256), 0, h->stream, Q);
+    };
+    if (n_sel) { P.ext_mask = sel_mask; P.n_ext = n_sel; }
     for (int it = 0; it < o->n_iters; it++) {
+        if (n_sel) select_pass();
         launch_lin(h, P, N, np, dc, MODE_LIN);
         S.it = it; S.mode = 0;
         const bool last = !lm && it == o->n_iters - 1;   // the last solve also emits the refined pose
@@ -620,6 +643,7 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
         launch_solve(h, S, N, np);
     }
     if (lm && o->n_iters > 0) {  // cost-only pass deciding whether the last step is kept
+        if (n_sel) select_pass();
         launch_lin(h, P, N, np, dc, MODE_COST);
         S.it = o->n_iters; S.mode = 1;
         S.pose_out = d_pose_out; S.log_scale_out = d_ls_out;
@@ -637,6 +661,20 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;
+}
+
+int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                 const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
+                 float *log_scale_out, float *stats_out) {
+    return refine_impl(h, o, N, 0, 0, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
+}
+
+int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                        const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out) {
+    if (!h) return TCSFM_E_ARG;
+    if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window: need 1 <= 2*B*S <= max_pairs");
+    return refine_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
 }
 
 int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,

@@ -31,6 +31,12 @@ def _chk(t: torch.Tensor, shape, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _copy_opts(o: Opts) -> Opts:
+    c = Opts()
+    C.memmove(C.byref(c), C.byref(o), C.sizeof(Opts))
+    return c
+
+
 class Engine:
     """One handle = one GPU + one HIP stream (include/tcsfm.h).  ``max_pairs`` directed pairs of HxW."""
 
@@ -204,6 +210,36 @@ class Engine:
         st = torch.empty((N, o.n_iters + 1, _lib.NSTAT), device=pose.device, dtype=torch.float32) if stats else None
         self._call(self.lib.tcsfm_refine(self._h, C.byref(o), N, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s),
                                          self._p(K), self._p(pose), self._p(ls_in), self._p(pose_out), self._p(ls_out), self._p(st)))
+        return pose_out, ls_out, st
+
+    def refine_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None, stats: bool = False,
+                      argmin: Optional[bool] = None):
+        """Window form (the call surface of solve_pose_iteratively, train_mono.py:41-62): tgt [B,3,H,W], srcs [S,B,3,H,W] (or a
+        list of S tensors), depth_t [B,1,H,W], depth_s [S,B,1,H,W] (or list), K [B,3,3], pose [2*S*B,6] in the stacked order
+        (forward pairs source-major, then inverse pairs).  The 2*S*B directed pairs are formed inside the library; with
+        argmin (default: opts.argmin) and S > 1 the forward pairs use the per-pixel min over the sources (optimizer.py:47-69).
+        -> (pose [2SB,6], log_scale [2SB] or None, stats or None)"""
+        o = opts or default_opts()
+        if argmin is not None:
+            o = _copy_opts(o); o.argmin = 1 if argmin else 0
+        if isinstance(srcs, (list, tuple)):
+            srcs = torch.stack(list(srcs), 0)
+        if isinstance(depth_s, (list, tuple)):
+            depth_s = torch.stack(list(depth_s), 0)
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        N = 2 * S * B
+        tgt = _chk(tgt, (B, 3, self.H, self.W), "tgt"); srcs = _chk(srcs, (S, B, 3, self.H, self.W), "srcs")
+        depth_t = _chk(depth_t, (B, 1, self.H, self.W), "depth_t"); depth_s = _chk(depth_s, (S, B, 1, self.H, self.W), "depth_s")
+        K = _chk(K, (B, 3, 3), "K"); pose = _chk(pose, (N, 6), "pose")
+        pose_out = torch.empty_like(pose)
+        ls_in = ls_out = None
+        if o.refine == _lib.REFINE_POSE_SCALE:
+            ls_in = torch.zeros(N, device=pose.device, dtype=torch.float32) if log_scale is None else _chk(log_scale, (N,), "log_scale")
+            ls_out = torch.empty_like(ls_in)
+        st = torch.empty((N, o.n_iters + 1, _lib.NSTAT), device=pose.device, dtype=torch.float32) if stats else None
+        self._call(self.lib.tcsfm_refine_window(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t),
+                                                self._p(depth_s), self._p(K), self._p(pose), self._p(ls_in), self._p(pose_out),
+                                                self._p(ls_out), self._p(st)))
         return pose_out, ls_out, st
 
     def refine_dense(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, stats: bool = False):

@@ -11,6 +11,7 @@ the networks frozen, takes PoseNet's coupled estimate (solve_pose_iteratively, t
 done by the HIP library) as the initial pose of every directed pair and refines it with `gn_iters` Gauss-Newton /
 LM iterations on the reference's own residual (libtcsfm_hip.so).  New option keys (all optional):
     solver 'gn'|'lm', gn_iters (4), refine 'pose'|'pose+scale'|'pose+depth', lambda0, param 'se3'|'euler',
+    (the reference's own `diff_img_argmin`, `automasking`, `l_depth_consist(+_weight)`, `mode` keys are honoured),
     prior_depth, lambda_depth (dense mode).
 The reference's `optimize_depth_pred` switch (Adam on the disparity maps themselves, optimizer.py:194-198) selects
 refine='pose+depth' unless `refine` is given: pose + per-pixel inverse depth by Gauss-Newton with a Schur complement.
@@ -173,7 +174,11 @@ class DepthOptimizer:
             pose, depth_ref, stats = eng.refine_dense(tgt, src, d_t, d_s, K.contiguous(), pose0, opts, stats=True)
             log_scale = None
         else:
-            pose, log_scale, stats = eng.refine(tgt, src, d_t, d_s, K.contiguous(), pose0, opts, stats=True)
+            # window form: the library forms the fwd / inv pairs itself; per-pixel min over the sources as the reference's loss
+            # does when options['diff_img_argmin'] is set (optimizer.py:47-69)
+            pose, log_scale, stats = eng.refine_window(
+                target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
+                intrinsics.float(), pose0, opts, stats=True, argmin=bool(self.options.get("diff_img_argmin", True)))
         res["poses_opt"] = pose[:split].cpu()
         res["poses_inv_opt"] = pose[split:].cpu()
         traj = stats[:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6]      # [2SB, gn_iters+1, 6]: the iterates (cf. train_mono.py:71-79)
