@@ -58,6 +58,7 @@ struct LinParams {
     float wl, ws;           // w_l1/3, w_ssim/3
     float eps;              // irls_eps
     int automask;
+    int direct;             // 1: no in-launch group reduction -- k_solve sums the workgroup records itself (small grids)
     const float *ext_mask;  // window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
 };
@@ -565,8 +566,10 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
         float s = 0.f;
         if (li >= 0)
             for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + li];
-        __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (P.direct) myrec[i] = s;   // plain store: the kernel boundary publishes it
+        else __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (P.direct) return;             // wave-uniform: k_solve reads one record per workgroup (a few hundred at most)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int s_last;
@@ -946,29 +949,45 @@ __device__ inline void T_to_pose_f32(const double *T, float *pose) {
 //   3. lane 0: SE(3) retraction (series exp, no trig), next iteration's fp32 constants, pose output
 // The per-pair logic mirrors orc_refine() of the CPU oracle (which factorises with Cholesky instead).
 template <int NP>
-__global__ __launch_bounds__(128) void k_solve(SolveParams P) {
+__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     using L = AccLayout<NP>;
+    constexpr int NPH = L::NH + NP;
     __shared__ double tot[L::NACC];
+    __shared__ double part[256];
     __shared__ double ws[3 * NP * NP];
     __shared__ double dl[8];
     __shared__ double m8[64];
     const int n = blockIdx.x, tid = threadIdx.x;
 #define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
     TC_STAMP(0)
-    if (tid < L::NACC) {
-        // one thread per accumulator: fp64 sum of the pair's group records in index order (deterministic).  Up to 32 loads are
-        // issued before the first add -- the records were written by other CUs, every load is an L2 miss (~0.4 us each if
-        // serialised).
-        const float *p = P.partials + (size_t)n * P.ngrp * L::NACC + tid;
+    {
+        // Deterministic fp64 reduction of the pair's P.ngrp partial records (group records, or one record per workgroup in
+        // direct mode).  Only the live accumulators are read; they are spread over 256 threads as (accumulator, record
+        // subset) so that ALL loads of a thread are in flight before its first add -- the records were written by other CUs,
+        // every load is a miss (~0.4 us each if serialised; a predicated load compiles to branch + vmcnt(0) per element).
+        const int nlive = P.has_dc ? L::NACC : NPH + 3;
+        const int apad = nlive <= 32 ? 32 : (nlive <= 64 ? 64 : 128), parts = 256 / apad;
+        const int c = tid & (apad - 1), q = tid / apad;
+        const int acc = (P.has_dc || c < NPH) ? c : L::OFF_S + (c - NPH);   // compact live index -> accumulator
+        if (tid < L::NACC) tot[tid] = 0.0;
         double s = 0.0;
-        for (int g0 = 0; g0 < P.ngrp; g0 += 32) {
-            float v[32];
+        if (c < nlive) {
+            const float *p = P.partials + (size_t)n * P.ngrp * L::NACC + acc;
+            for (int r0 = q; r0 < P.ngrp; r0 += 32 * parts) {
+                float v[32];
 #pragma unroll
-            for (int j = 0; j < 32; j++) v[j] = p[(size_t)(g0 + j < P.ngrp ? g0 + j : 0) * L::NACC];  // unconditional: a predicated
-#pragma unroll                                                              // load compiles to branch + vmcnt(0) per element (3.9 us)
-            for (int j = 0; j < 32; j++) s += (g0 + j < P.ngrp) ? (double)v[j] : 0.0;
+                for (int j = 0; j < 32; j++) { const int r = r0 + j * parts; v[j] = p[(size_t)(r < P.ngrp ? r : 0) * L::NACC]; }
+#pragma unroll
+                for (int j = 0; j < 32; j++) s += (r0 + j * parts < P.ngrp) ? (double)v[j] : 0.0;
+            }
         }
-        tot[tid] = s;
+        part[tid] = s;
+        __syncthreads();
+        if (q == 0 && c < nlive) {
+            double t = 0.0;
+            for (int k = 0; k < parts; k++) t += part[k * apad + c];   // fixed order
+            tot[acc] = t;
+        }
     }
     __syncthreads();
     TC_STAMP(1)

@@ -197,8 +197,8 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mo
 
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
-    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(128), 0, h->stream, S);
-    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(128), 0, h->stream, S);
+    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
+    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
 }
 
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
@@ -252,12 +252,18 @@ int run_init(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *pose, const 
     return TCSFM_OK;
 }
 
+// Small tile grids (KITTI 640x192: 240 workgroups per pair) skip the in-launch group reduction: the solve kernel sums the
+// workgroup records itself with all loads in flight (one batch of <= 32 per thread), which is cheaper than the
+// publish / ticket / last-arriver tail of every linearisation.  Larger grids keep the two-level reduction.
+int direct_records(const tcsfm_ctx *h) { return h->nblk <= 256; }
+
 LinParams lin_params(tcsfm_ctx *h, const tcsfm_opts *o, int np) {
     LinParams P;
     memset(&P, 0, sizeof(P));
     P.tgtpack = h->tgtpack; P.srcpack = h->srcpack; P.depth_t = h->depth_work; P.pc = h->pconst; P.partials = h->partials; P.blockrec = h->blockrec; P.tickets = h->tickets;
     P.H = h->H; P.W = h->W; P.tiles_x = h->tiles_x; P.tiles_y = h->tiles_y; P.nacc = nacc_of(np); P.ngrp = h->ngrp; P.ngrp_pad = h->ngrp_pad;
     P.wl = o->w_l1 / 3.f; P.ws = o->w_ssim / 3.f; P.eps = o->irls_eps; P.automask = o->automask;
+    P.direct = direct_records(h);
     return P;
 }
 
@@ -266,6 +272,7 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
     memset(&S, 0, sizeof(S));
     S.partials = h->partials; S.st = h->state; S.pc = h->pconst; S.stats = nullptr; S.lin_out = h->lin_out;
     S.ngrp = h->ngrp; S.nacc = nacc_of(np); S.np = np; S.has_dc = o->w_dc > 0.f;
+    if (direct_records(h)) { S.partials = h->blockrec; S.ngrp = h->nblk; }
     S.n_iters = o->n_iters; S.solver = o->solver; S.param = o->param;
     S.b_dc = (double)o->w_dc / ((double)h->H * (double)h->W);
     S.lambda_up = o->lambda_up; S.lambda_down = o->lambda_down; S.lambda_min = o->lambda_min;
@@ -765,7 +772,9 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
     P.ngrp = (nblk + RG - 1) / RG;
     if ((size_t)nblk > (size_t)h->nblk_alloc || P.ngrp > h->ngrp_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
     SolveParams S = solve_params(h, &oo, 6, 0);
-    S.ngrp = P.ngrp; S.stats = d_stats; S.delta_out = h->delta;
+    P.direct = nblk <= 256;
+    S.partials = P.direct ? h->blockrec : h->partials; S.ngrp = P.direct ? nblk : P.ngrp;
+    S.stats = d_stats; S.delta_out = h->delta;
     DenseParams Dn;
     Dn.dense_rec = h->dense_rec; Dn.depth0 = h->depth0; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
     DenseUpdateParams U;
