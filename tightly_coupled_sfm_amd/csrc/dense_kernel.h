@@ -47,9 +47,9 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     const int H = P.H, W = P.W, hw = H * W;
     const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
     const int x00 = txi * TW, y00 = tyi * TH;
-    const float4 *tgtpack = P.tgtpack + (size_t)c.img * hw;
-    const float4 *srcpack = P.srcpack + (size_t)c.img * hw;
-    const float *depth_t = P.depth_t + (size_t)c.img * hw;
+    const float4 *tgtpack = P.tgtpack + (size_t)n * hw;
+    const float4 *srcpack = P.srcpack + (size_t)n * hw;
+    const float *depth_t = P.depth_t + (size_t)n * hw;
     const int tid = threadIdx.x;
 
     // own pixel (tile coordinates) and values carried from phase 1 to phase 2b
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         float D = la[6] * a[6] + lb[6] * b[6];
         float g_rho = grow[6];
         if (Dn.w_prior > 0.f) {   // masked prior on the relative inverse-depth change
-            float rho = frcp(o_depth), rho0 = frcp(Dn.depth0[(size_t)c.img * hw + gyo * W + gxo]);
+            float rho = frcp(o_depth), rho0 = frcp(Dn.depth0[(size_t)n * hw + gyo * W + gxo]);
             float ir2 = frcp(rho0 * rho0), dr = rho - rho0;
             g_rho += o_m * 2.f * Dn.w_prior * dr * ir2;
             D += o_m * 2.f * Dn.w_prior * ir2;

@@ -58,6 +58,8 @@ struct LinParams {
     float wl, ws;           // w_l1/3, w_ssim/3
     float eps;              // irls_eps
     int automask;
+    int shared_image;       // all problems read packed image pair 0 (loss-surface sweeps); kept OUT of PairConst so that the
+                            // first image loads do not wait for the scalar loads of the pair constants
     int direct;             // 1: no in-launch group reduction -- k_solve sums the workgroup records itself (small grids)
     const float *ext_mask;  // window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
@@ -198,6 +200,38 @@ __device__ inline void write_const(const PairState &S, const double *T, double s
     c.ki0 = (float)(1.0 / fx); c.ki2 = (float)(-cx / fx); c.ki4 = (float)(1.0 / fy); c.ki5 = (float)(-cy / fy);
     c.es = (s == 0.0) ? 1.f : (float)exp(s);
     c.img = img;
+}
+
+// Lane-parallel form of write_const for the solve kernel: lanes 0..8 one entry of A and R each, lanes 0..2 kt and t.
+// Intrinsics and image index never change after init_pair and are not rewritten.  T: 3x4 transform in LDS.
+// 1/x in double precision without the ~35-instruction IEEE division sequence: v_rcp_f64 seed + two Newton steps
+// (quadratic: 2^-26 -> 2^-52).  The solve kernel is one long dependent fp64 chain; every division on it costs ~0.1 us.
+__device__ __forceinline__ double rcp64(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+template <int NP>
+__device__ __forceinline__ void write_const_lanes(int lane, const double *K, const double *T, double s, PairConst &c) {
+    if (lane < 9) {
+        const int i = lane / 3, j = lane - 3 * i;
+        const double ifx = rcp64(K[0]), ify = rcp64(K[4]), cx = K[2], cy = K[5];
+        const double Ki[9] = {ifx, 0, -cx * ifx, 0, ify, -cy * ify, 0, 0, 1};
+        double KR[3];   // row i of K (R - I)
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+            KR[m] = K[3 * i] * (T[m] - (m == 0 ? 1.0 : 0.0)) + K[3 * i + 1] * (T[4 + m] - (m == 1 ? 1.0 : 0.0)) +
+                    K[3 * i + 2] * (T[8 + m] - (m == 2 ? 1.0 : 0.0));
+        c.A[lane] = (float)(KR[0] * Ki[j] + KR[1] * Ki[3 + j] + KR[2] * Ki[6 + j]);
+        c.R[lane] = (float)T[4 * i + j];
+    }
+    if (lane < 3) {
+        c.kt[lane] = (float)(K[3 * lane] * T[3] + K[3 * lane + 1] * T[7] + K[3 * lane + 2] * T[11]);
+        c.t[lane] = (float)T[4 * lane + 3];
+    }
+    if (NP == 7 && lane == 0) c.es = (s == 0.0) ? 1.f : (float)exp(s);
 }
 
 struct InitParams {
@@ -620,9 +654,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     const int H = P.H, W = P.W, hw = H * W;
     const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
     const int x00 = txi * TW, y00 = tyi * TH;
-    const float4 *tgtpack = P.tgtpack + (size_t)c.img * hw;
-    const float4 *srcpack = P.srcpack + (size_t)c.img * hw;
-    const float *depth_t = P.depth_t + (size_t)c.img * hw;
+    const int img = P.shared_image ? 0 : n;
+    const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
+    const float4 *srcpack = P.srcpack + (size_t)img * hw;
+    const float *depth_t = P.depth_t + (size_t)img * hw;
     const int tid = threadIdx.x;
 
     // centre-only values carried in registers from phase 1 to phase 2
@@ -956,10 +991,17 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     __shared__ double part[256];
     __shared__ double ws[3 * NP * NP];
     __shared__ double dl[8];
-    __shared__ double m8[64];
+    __shared__ double eul[NP * NP + NP];
+    __shared__ double Ts[40];
+    constexpr int NST = (int)(sizeof(PairState) / sizeof(double));
+    static_assert(sizeof(PairState) % sizeof(double) == 0 && NST <= 256, "PairState must be a whole number of doubles");
+    __shared__ double sst[NST];
     const int n = blockIdx.x, tid = threadIdx.x;
 #define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
     TC_STAMP(0)
+    // the pair's optimiser state is fetched NOW, together with the partial records, so that the serial phases below never
+    // wait on a global load (each first touch used to cost a miss in the middle of the dependent chain)
+    if (tid < NST) sst[tid] = reinterpret_cast<const double *>(&P.st[n])[tid];
     {
         // Deterministic fp64 reduction of the pair's P.ngrp partial records (group records, or one record per workgroup in
         // direct mode).  Only the live accumulators are read; they are spread over 256 threads as (accumulator, record
@@ -993,10 +1035,11 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     TC_STAMP(1)
     if (tid >= 64) return;  // wave 0 only from here: no workgroup barriers below
 
-    PairState &S = P.st[n];
+    PairState &S = P.st[n];                                        // global: writes (the next launch reads them)
+    const PairState &Lc = *reinterpret_cast<const PairState *>(sst);  // LDS copy taken at kernel start: reads
     const int r = tid >> 3, c = tid & 7;
     const double nmask = tot[L::OFF_S + 1];
-    const double an = nmask > 0 ? 1.0 / nmask : 0.0;
+    const double an = nmask > 0 ? rcp64(nmask) : 0.0;
     const double cost_photo = an * tot[L::OFF_S], cost_dc = P.b_dc * tot[L::OFF_S + 2];
     double cost = cost_photo + cost_dc;
     const double bdc = P.has_dc ? P.b_dc : 0.0;
@@ -1009,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         M = -(an * tot[L::OFF_GP + r] + bdc * tot[L::OFF_GD + r]);
     }
     if (NP == 7 && P.mode != 2) {  // scale prior (not part of the exported raw normal equations)
-        const double ds = S.stry - S.s0;
+        const double ds = Lc.stry - Lc.s0;
         cost += P.prior_scale * ds * ds;
         if (r == 6 && c == 6) M += 2.0 * P.prior_scale;
         if (r == 6 && c == 7) M -= 2.0 * P.prior_scale * ds;
@@ -1021,29 +1064,35 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         if (tid == 0) { o[NP * NP + NP] = cost; o[NP * NP + NP + 1] = cost_photo; o[NP * NP + NP + 2] = cost_dc; o[NP * NP + NP + 3] = nmask; }
         return;
     }
-    double lambda = S.lambda;
+    double lambda = Lc.lambda;
     if (P.stats && tid == 0) {
         float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * TCSFM_NSTAT;
         st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)lambda;
-        T_to_pose_f32(S.Ttry, st + TCSFM_STAT_POSE);   // the iterate this linearisation was evaluated at
+        T_to_pose_f32(Lc.Ttry, st + TCSFM_STAT_POSE);   // the iterate this linearisation was evaluated at
     }
+    // Ts (LDS): [0..11] exp(delta), [12..23] the accepted transform, [24..35] the new trial transform, [36] its log scale
     bool final_pose = false;
+    const double *Tfin = Ts + 24;
+    double sfin = 0.0;
     if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
-        if (tid == 0 && cost < S.cost_cur) {
-            for (int i = 0; i < 12; i++) S.Tcur[i] = S.Ttry[i];
-            S.scur = S.stry;
-        }
+        const bool keep = cost < Lc.cost_cur;
+        if (tid < 12) { const double v = keep ? Lc.Ttry[tid] : Lc.Tcur[tid]; Ts[24 + tid] = v; if (keep) S.Tcur[tid] = v; }
+        sfin = keep ? Lc.stry : Lc.scur;
+        if (tid == 0 && keep) S.scur = sfin;
         final_pose = true;
     } else {
-        const bool accept = (P.solver == 0) || !S.have_cur || (cost < S.cost_cur);  // wave-uniform
+        const bool accept = (P.solver == 0) || !Lc.have_cur || (cost < Lc.cost_cur);  // wave-uniform
         if (accept) {
-            if (P.solver == 1 && S.have_cur) lambda = fmax(lambda * P.lambda_down, P.lambda_min);
+            if (P.solver == 1 && Lc.have_cur) lambda = fmax(lambda * P.lambda_down, P.lambda_min);
             S.M8[tid] = M;
         } else {
             lambda *= P.lambda_up;
-            M = S.M8[tid];
+            M = Lc.M8[tid];
         }
-        m8[tid] = M;  // undamped system, for the additive-Euler branch below
+        if (P.param != 0) {   // undamped system in dense NP x NP form for the additive-Euler branch below
+            if (r < NP && c < NP) eul[r * NP + c] = M;
+            if (r < NP && c == 7) eul[NP * NP + r] = -M;
+        }
         TC_STAMP(2)
         // Marquardt damping, then Gauss-Jordan on [H + lambda diag(H) + 1e-12 I | -g]
         if (r == c && r < NP) M += lambda * M + 1e-12;
@@ -1054,61 +1103,61 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
             const double rowv = __shfl(M, k * 8 + c, 64);
             const double colv = __shfl(M, r * 8 + k, 64);
             ok = ok && (piv > 0.0);
-            const double f = colv / piv;
+            const double f = colv * rcp64(piv);
             if (r != k) M -= f * rowv;
         }
         const double diag = __shfl(M, r * 8 + r, 64);
-        if (c == 7 && r < NP) dl[r] = ok ? M / diag : 0.0;
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): dl[] written before lane 0 reads it (single wave)
+        if (c == 7 && r < NP) dl[r] = ok ? M * rcp64(diag) : 0.0;
+        const double sc = accept ? Lc.stry : Lc.scur;
+        if (tid < 12) { const double v = accept ? Lc.Ttry[tid] : Lc.Tcur[tid]; Ts[12 + tid] = v; if (accept) S.Tcur[tid] = v; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): dl[] / Ts[] written before they are read (single wave)
         __builtin_amdgcn_wave_barrier();
         TC_STAMP(3)
-        if (tid == 0) {
-            double Tc[12], Tt[12], delta[NP], sc, stry;
-            if (accept) {
-                for (int i = 0; i < 12; i++) { Tc[i] = S.Ttry[i]; S.Tcur[i] = Tc[i]; }
-                sc = S.stry; S.scur = sc; S.cost_cur = cost; S.have_cur = 1;
-            } else {
-                for (int i = 0; i < 12; i++) Tc[i] = S.Tcur[i];
-                sc = S.scur;
-            }
+        if (tid == 0) {   // serial part: bookkeeping and the exponential of the step
+            if (accept) { S.scur = sc; S.cost_cur = cost; S.have_cur = 1; }
             S.lambda = lambda;
-#pragma unroll
-            for (int i = 0; i < NP; i++) delta[i] = dl[i];
             if (P.delta_out)
-                for (int i = 0; i < NP; i++) P.delta_out[n * 8 + i] = delta[i];
+                for (int i = 0; i < NP; i++) P.delta_out[n * 8 + i] = dl[i];
             if (P.param == 0) {
-                retract_se3(delta, Tc, Tt);
-                stry = sc + (NP == 7 ? delta[NP - 1] : 0.0);
+                double d6[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) d6[i] = dl[i];
+                se3_exp(d6, Ts);
+                Ts[36] = sc + (NP == 7 ? dl[NP - 1] : 0.0);
             } else {
-                // additive Euler parameterisation: re-solve in pose coordinates from the stored undamped system (rare path,
-                // serial; the lane-parallel solution above is for the SE(3) chart)
-                double Hs[NP * NP], gs[NP];
-                for (int i = 0; i < NP; i++) {
-                    gs[i] = -m8[i * 8 + 7];
-                    for (int j = 0; j < NP; j++) Hs[i * NP + j] = m8[i * 8 + j];
-                }
-                apply_step<NP>(1, Hs, gs, lambda, Tc, sc, Tt, &stry, ws);
+                // additive Euler parameterisation: re-solve in pose coordinates from the undamped system (rare path, serial;
+                // everything stays in LDS so that this branch does not set the register budget of the kernel)
+                double stry;
+                apply_step<NP>(1, eul, eul + NP * NP, lambda, Ts + 12, sc, Ts + 24, &stry, ws);
+                Ts[36] = stry;
             }
-            TC_STAMP(4)
-#pragma unroll
-            for (int i = 0; i < 12; i++) S.Ttry[i] = Tt[i];
-            S.stry = stry;
-            if (P.solver == 0 && P.it == P.n_iters - 1) {  // GN: the last step is always taken
-#pragma unroll
-                for (int i = 0; i < 12; i++) S.Tcur[i] = Tt[i];
-                S.scur = stry;
-            }
-            write_const(S, Tt, stry, P.shared_image ? 0 : n, P.pc[n]);
-            TC_STAMP(5)
         }
-        final_pose = (P.solver == 0 && P.it == P.n_iters - 1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (P.param == 0 && tid < 12) {   // T_try = exp(delta) T_accepted, one entry per lane (se3_mul's operation order)
+            const int i = tid >> 2, j = tid & 3;
+            double v = Ts[4 * i] * Ts[12 + j] + Ts[4 * i + 1] * Ts[16 + j] + Ts[4 * i + 2] * Ts[20 + j];
+            if (j == 3) v += Ts[4 * i + 3];
+            Ts[24 + tid] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        TC_STAMP(4)
+        const double stry = Ts[36];
+        const bool last_gn = (P.solver == 0 && P.it == P.n_iters - 1);   // GN: the last step is always taken
+        if (tid < 12) { const double v = Ts[24 + tid]; S.Ttry[tid] = v; if (last_gn) S.Tcur[tid] = v; }
+        if (tid == 0) { S.stry = stry; if (last_gn) S.scur = stry; }
+        write_const_lanes<NP>(tid, Lc.K, Ts + 24, stry, P.pc[n]);
+        TC_STAMP(5)
+        final_pose = last_gn;
+        sfin = stry;
     }
     if (final_pose && P.pose_out && tid == 0) {  // last launch of a refine call: emit the reference 6-vector
         float pose[6];
-        T_to_pose_f32(S.Tcur, pose);
+        T_to_pose_f32(Tfin, pose);
 #pragma unroll
         for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
-        if (P.log_scale_out) P.log_scale_out[n] = (float)S.scur;
+        if (P.log_scale_out) P.log_scale_out[n] = (float)sfin;
         if (P.stats && P.mode == 0) {                  // GN: last row = final iterate (its cost is not evaluated)
             float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;
 #pragma unroll

@@ -521,6 +521,7 @@ static int eval_once(tcsfm_ctx *h, const tcsfm_opts *o, int N, int Nimg, const f
     if ((rc = run_pack(h, o, Nimg, d_tgt, d_src, d_dt, d_ds))) return rc;
     if ((rc = run_init(h, o, N, d_pose, d_ls, d_K, shared))) return rc;
     LinParams P = lin_params(h, o, np);
+    P.shared_image = shared;
     launch_lin(h, P, N, np, o->w_dc > 0.f, mode);
     HIPCHK(h, hipGetLastError());
     SolveParams S = solve_params(h, o, np, shared);
