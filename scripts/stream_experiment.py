@@ -1,0 +1,35 @@
+"""Host-side enqueue cost and end-to-end step time of the B=1 bench workload on different streams."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tightly_coupled_sfm_amd import synth
+from tightly_coupled_sfm_amd.engine import Engine, default_opts
+H, W = 192, 640
+b = synth.make_batch(2, H, W, seed0=0, both_directions=True)
+dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+e = Engine(H, W, 2)
+o = default_opts(n_iters=4)
+out = torch.empty_like(dev["pose_init"])
+step = lambda: e.refine_into(dev["tgt"], dev["src"], dev["depth_t"], dev["depth_s"], dev["K"], dev["pose_init"], out, o)
+
+def measure(tag):
+    for _ in range(100): step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(8): step()
+    t_burst = (time.perf_counter() - t1) / 8
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2000): step()
+    t_cpu = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"{tag:28s} host burst {t_burst * 1e6:6.1f} us/step | host (queue full) {t_cpu / 2000 * 1e6:6.1f} | end-to-end {t_all / 2000 * 1e6:6.1f} us/step")
+
+measure("legacy default stream")
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    e.use_torch_stream()
+    measure("torch side stream")
+e.use_own_stream()
+measure("library's own stream")

@@ -481,3 +481,36 @@ def test_refine_window_without_argmin_is_the_pair_form():
     assert torch.equal(p1[:B], pw[:B]) and torch.equal(p1[B:], pw[S * B:S * B + B])
     with pytest.raises(RuntimeError, match="max_pairs"):
         _eng(H, W, 4).refine_window(tg, sr, dt, ds, K, p0)
+
+
+def test_engine_follows_torch_stream():
+    """tensor-level calls run on torch's CURRENT stream (also inside a `with torch.cuda.stream(...)` block), so producers
+    and consumers of the tensors stay ordered without explicit synchronisation"""
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W = 96, 320
+    b = _pairs(2, H, W, seed0=3)
+    e = _eng(H, W, 2)
+    d = _dev(b); p0 = _t(b["pose_init"])
+    ref, _, _ = e.refine(*d, p0, default_opts(n_iters=3))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        scale = torch.full((1,), 2.0, device="cuda")
+        tgt2 = d[0] * scale / scale                       # produced on the side stream right before the call
+        out, _, _ = e.refine(tgt2, *d[1:], p0, default_opts(n_iters=3))
+        moved = out + 0.0                                 # consumed on the side stream right after
+    side.synchronize()
+    assert torch.equal(moved, ref)
+    g = torch.cuda.CUDAGraph()                            # ... which also makes a refine call capturable in a HIP graph
+    with torch.cuda.stream(side):
+        e.refine(*d, p0, default_opts(n_iters=3))
+    torch.cuda.synchronize()
+    buf = torch.empty_like(p0)
+    with torch.cuda.graph(g, stream=side):
+        e._bind()
+        e.refine_into(*d, p0, buf, default_opts(n_iters=3))
+    buf.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, ref)

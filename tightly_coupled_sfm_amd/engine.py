@@ -70,11 +70,23 @@ class Engine:
             raise RuntimeError(f"tcsfm error {rc}: {self.lib.tcsfm_last_error(self._h).decode()}")
 
     def use_torch_stream(self):
-        """Run on torch's current stream of this device, so tensor producers/consumers stay ordered."""
+        """Run on torch's current stream of this device, so tensor producers/consumers stay ordered.  Every tensor-level
+        method re-binds on entry (a `with torch.cuda.stream(s):` block is honoured); `refine_into` does not."""
+        self._follow_torch = True
+        self._bound = None
+        self._bind()
+
+    def _bind(self):
+        if not self._follow_torch:
+            return
         s = torch.cuda.current_stream(self.device).cuda_stream
-        self._call(self.lib.tcsfm_set_stream(self._h, C.c_void_p(s)))
+        if s != self._bound:
+            self._call(self.lib.tcsfm_set_stream(self._h, C.c_void_p(s)))
+            self._bound = s
 
     def use_own_stream(self):
+        """Run on the handle's private non-blocking stream; the caller orders it against torch work (synchronize())."""
+        self._follow_torch = False
         self._call(self.lib.tcsfm_use_own_stream(self._h))
 
     def synchronize(self):
@@ -101,6 +113,7 @@ class Engine:
     # -- reference-function drop-ins -----------------------------------------------------------
     def disp_to_depth(self, disp: torch.Tensor, min_depth: float, max_depth: float):
         """utils/learning_helpers.py:77-86 -> (scaled_disp, depth)"""
+        self._bind()
         d = disp.contiguous()
         if d.dtype != torch.float32 or not d.is_cuda:
             raise TypeError("disp must be a float32 GPU tensor")
@@ -111,6 +124,7 @@ class Engine:
 
     def ssim_loss(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """SSIM_Loss.forward (losses.py:27-41) for [N,C,H,W] tensors"""
+        self._bind()
         N, Cc = x.shape[0], x.shape[1]
         x = _chk(x, (N, Cc, self.H, self.W), "x"); y = _chk(y, (N, Cc, self.H, self.W), "y")
         out = torch.empty_like(x)
@@ -121,6 +135,7 @@ class Engine:
     def inverse_warp2(self, img, depth, ref_depth, pose, intrinsics):
         """models/stn.py:234-273 with the reference's argument order; ``pose`` here is what the reference
         passes, i.e. callers that wrote ``inverse_warp2(src, d_t, d_s, -poses, K)`` keep passing ``-poses``."""
+        self._bind()
         N = img.shape[0]
         H, W = self.H, self.W
         img = _chk(img, (N, 3, H, W), "img"); depth = _chk(depth, (N, 1, H, W), "depth")
@@ -136,6 +151,7 @@ class Engine:
     def posenet_input(self, target_img, source_img, target_depth, source_depth, pose, intrinsics):
         """(tgt * valid | img_rec) [N,6,H,W] for the next PoseNet call of the coupled iteration (train_mono.py:73-77);
         `pose` is the estimate so far in the reference convention (the warp uses -pose like train_mono.py:80)."""
+        self._bind()
         N = target_img.shape[0]
         H, W = self.H, self.W
         t = _chk(target_img, (N, 3, H, W), "target_img"); s = _chk(source_img, (N, 3, H, W), "source_img")
@@ -150,6 +166,7 @@ class Engine:
     def compute_photometric_error(self, target_img, source_img, target_depth, source_depth, pose, intrinsics,
                                   opts: Optional[Opts] = None):
         """optimization_experiments/helpers.py:8-23 -> dict with the reference's keys (+ the raw maps)."""
+        self._bind()
         N = target_img.shape[0]
         H, W = self.H, self.W
         t = _chk(target_img, (N, 3, H, W), "target_img"); s = _chk(source_img, (N, 3, H, W), "source_img")
@@ -166,6 +183,7 @@ class Engine:
 
     def loss_surface(self, target_img, source_img, target_depth, source_depth, intrinsics, poses, opts: Optional[Opts] = None):
         """costs of ONE pair under P candidate poses (plot_loss_surface.py:31-33,45-47) -> np.ndarray [P] float64"""
+        self._bind()
         H, W = self.H, self.W
         t = _chk(target_img, (1, 3, H, W), "target_img"); s = _chk(source_img, (1, 3, H, W), "source_img")
         dt = _chk(target_depth, (1, 1, H, W), "target_depth"); ds = _chk(source_depth, (1, 1, H, W), "source_depth")
@@ -187,6 +205,7 @@ class Engine:
 
     def linearize(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None):
         """normal equations at ``pose`` -> dict(H [N,np,np], g [N,np], cost, cost_photo, cost_dc, n_mask [N]) (numpy f64)"""
+        self._bind()
         o = opts or default_opts()
         N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
         n_p = 7 if o.refine == _lib.REFINE_POSE_SCALE else 6
@@ -200,6 +219,7 @@ class Engine:
     def refine(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None, stats: bool = False):
         """Refine N directed pairs in place-free style: returns (pose [N,6], log_scale [N] or None, stats or None).
         Asynchronous on the handle's stream; outputs are GPU tensors."""
+        self._bind()
         o = opts or default_opts()
         N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
         pose_out = torch.empty_like(pose)
@@ -219,6 +239,7 @@ class Engine:
         (forward pairs source-major, then inverse pairs).  The 2*S*B directed pairs are formed inside the library; with
         argmin (default: opts.argmin) and S > 1 the forward pairs use the per-pixel min over the sources (optimizer.py:47-69).
         -> (pose [2SB,6], log_scale [2SB] or None, stats or None)"""
+        self._bind()
         o = opts or default_opts()
         if argmin is not None:
             o = _copy_opts(o); o.argmin = 1 if argmin else 0
@@ -245,6 +266,7 @@ class Engine:
     def refine_dense(self, tgt, src, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, stats: bool = False):
         """Dense mode: refine pose AND per-pixel inverse depth of the target (per-pixel Schur complement).
         -> (pose [N,6], depth [N,1,H,W], stats or None); opts.lambda_depth / opts.prior_depth / min_depth / max_depth apply."""
+        self._bind()
         o = opts or default_opts()
         N, tgt, src, depth_t, depth_s, K, pose = self._pairs(tgt, src, depth_t, depth_s, K, pose)
         pose_out, depth_out = torch.empty_like(pose), torch.empty_like(depth_t)
@@ -256,6 +278,7 @@ class Engine:
     def scale_recovery(self, depth, intrinsics, real_cam_height: float, pad_to_batch: int = 0, maps: bool = False):
         """ScaleRecovery.forward (dnet_layers.py:306-327): depth [N,1,H,W], K [N,3,3] -> scale [1] (GPU tensor)
         (+ median [1], height [N,1,H,W], mask [N,1,H,W] with maps=True)"""
+        self._bind()
         N = depth.shape[0]
         depth = _chk(depth, (N, 1, self.H, self.W), "depth"); K = _chk(intrinsics, (N, 3, 3), "intrinsics")
         scale = torch.empty(1, device=depth.device, dtype=torch.float32); med = torch.empty_like(scale)
