@@ -506,6 +506,11 @@ __device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ void lds_read6v(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f) {  // floats 0..23
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                 "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f) : "v"(lds_addr(p)) : "memory");
+}
 __device__ __forceinline__ float4 lds_read1(const float4 *p) {
     f32x4 x;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(lds_addr(p)) : "memory");
@@ -776,8 +781,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
                 f32x4 n0, n1, n2, n3, n4, n5;
-                lds_read3v(nb, n0, n1, n2);
-                lds_read3bv(nb, n3, n4, n5);
+                lds_read6v(nb, n0, n1, n2, n3, n4, n5);   // one LDS round trip per neighbour
                 f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
                 f2 cf = cA01 + cB01 * ey + cC01 * ex;
                 f2 e2v = pk_sub(n2.lo, yx2c);
