@@ -31,7 +31,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     constexpr int W1 = TW + 2, H1 = TH + 2, N1 = W1 * H1;   // phase-2a region (1-pixel halo)
     constexpr int NCEN = TW * TH;
     static_assert(NCEN == NT, "one tile pixel per thread");
-    __shared__ float4 rec1[N2 * 3];   // y[3] x[3] gx[3] gy[3]
+    __shared__ float4 rec1[N2 * 3];   // [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2]: channel pairs on aligned register pairs
     __shared__ float4 aux[N2];        // W, valid, auto_err, -
     __shared__ float4 coef[N1 * 3];   // w (cA'', cB, cC) per channel: [A0 A1 A2 B0 | B1 B2 C0 C1 | C2 - - -]
     __shared__ float red[(NT / 64) * L::NACC];
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         float pd = c.es * val.w, cd = g.Z;
         float Wt = 1.f - clamp01(fabsf(cd - pd) * frcp(cd + pd));
         float4 *rec = rec1 + (ly * W2 + lx) * 3;
-        lds_write1(rec + 0, val.x, val.y, val.z, tp.x);
-        lds_write1(rec + 1, tp.y, tp.z, gx.x, gx.y);
-        lds_write1(rec + 2, gx.z, gy.x, gy.y, gy.z);
+        lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
+        lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+        lds_write1(rec + 2, val.z, tp.z, gx.z, gy.z);
         lds_write1(aux + ly * W2 + lx, Wt, oob ? 0.f : 1.f, tp.w, 0.f);
         if (r == 0) {
             geo_jac<7>(c, g, W, H, a, b, zc);
@@ -122,55 +122,49 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         const int gx_ = x00 + lx - 1, gy_ = y00 + ly - 1;
         const bool real = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;   // residual pixels must exist (no reflection here)
         const float4 *ctr = rec1 + ((ly + 1) * W2 + lx + 1) * 3;
-        float4 q0, q1, q2;
-        lds_read3(ctr, q0, q1, q2);
-        const float yc[3] = {q0.x, q0.y, q0.z}, xc[3] = {q0.w, q1.x, q1.y};
-        const float gxc[3] = {q1.z, q1.w, q2.x}, gyc[3] = {q2.y, q2.z, q2.w};
+        f32x4 q0, q1, q2;
+        lds_read3v(ctr, q0, q1, q2);
+        const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = q1.lo, gyc01 = q1.hi, yx2c = q2.lo, g2c = q2.hi;
+        const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
+        const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
         float4 ax = lds_read1(aux + (ly + 1) * W2 + lx + 1);
-        float Sx[3] = {0, 0, 0}, Sy[3] = {0, 0, 0}, Sxx[3] = {0, 0, 0}, Syy[3] = {0, 0, 0}, Sxy[3] = {0, 0, 0};
-        float Gx[3] = {0, 0, 0}, Gy[3] = {0, 0, 0};
+        // window statistics, packed exactly as pass A of k_linearize
+        f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f};
+        f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f}, G2 = {0.f, 0.f};
+        float Sxy2 = 0.f;
+        const float4 *nbA = ctr - (W2 + 1) * 3;
 #pragma unroll 1
         for (int kk = 0; kk < 9; kk++) {
-            const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
-            float4 n0, n1, n2;
-            lds_read3(ctr + (dy * W2 + dx) * 3, n0, n1, n2);
-            const float yq[3] = {n0.x, n0.y, n0.z}, xq[3] = {n0.w, n1.x, n1.y};
-            const float gxq[3] = {n1.z, n1.w, n2.x}, gyq[3] = {n2.y, n2.z, n2.w};
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                float da = xq[ch] - xc[ch], db = yq[ch] - yc[ch];
-                Sx[ch] += da; Sy[ch] += db; Sxx[ch] += da * da; Syy[ch] += db * db; Sxy[ch] += da * db;
-                Gx[ch] += gxq[ch]; Gy[ch] += gyq[ch];
-            }
+            f32x4 n0, n1, n2;
+            lds_read3v(nbA, n0, n1, n2);
+            nbA += (kk == 2 || kk == 5) ? (W2 - 2) * 3 : 3;
+            f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+            Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+            Gx01 += n1.lo; Gy01 += n1.hi;
+            f2 e2v = pk_sub(n2.lo, yx2c);
+            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
         }
-        const float n9 = 1.f / 9.f;
-        float e1 = 0.f, e2 = 0.f, cA[3], cB[3], cC[3];
-        float l1x = 0.f, l1y = 0.f, lxx = 0.f, lxy = 0.f, lyy = 0.f;
+        ChanTerms<f2> t01;
+        ChanTerms<float> t2;
+        ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
+        ssim_l1_channel<float>(yx2c.y, yx2c.x, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+        // d s/d y_q = cA' + cB (y_q - 1/2) + cC (x_q - 1/2): re-centred from the centre pixel to 1/2 so that p's record serves every q
+        const float cB[3] = {t01.cB.x, t01.cB.y, t2.cB}, cC[3] = {t01.cC.x, t01.cC.y, t2.cC};
+        float cA[3] = {t01.cA.x, t01.cA.y, t2.cA};
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float mdx = Sx[ch] * n9, mdy = Sy[ch] * n9;
-            float mux = xc[ch] + mdx, muy = yc[ch] + mdy;
-            float sigx = Sxx[ch] * n9 - mdx * mdx, sigy = Syy[ch] * n9 - mdy * mdy, sigxy = Sxy[ch] * n9 - mdx * mdy;
-            float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
-            float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
-            float idn = frcp(d1 * d2), ratio = n1 * n2 * idn, raw = (1.f - ratio) * 0.5f;
-            bool cl = (raw < 0.f) || (raw > 1.f);
-            e2 += P.ws * clamp01(raw);
-            float pre = cl ? 0.f : -0.5f * idn * n9 * P.ws;
-            cB[ch] = pre * (-ratio * 2.f * d1);
-            cC[ch] = pre * (2.f * n1);
-            // d s/d y_q = cA + cB (y_q - 1/2) + cC (x_q - 1/2)   (re-centred on 1/2 so that p's record serves every q)
-            cA[ch] = pre * (2.f * mux * n2 - ratio * 2.f * muy * d2) - cB[ch] * (muy - 0.5f) - cC[ch] * (mux - 0.5f);
-            float rr = yc[ch] - xc[ch], ar = fabsf(rr);
-            e1 += P.wl * fminf(ar, 1.f);
-            float sgn = (ar <= 1.f) ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : 0.f;
-            l1x += P.wl * sgn * gxc[ch]; l1y += P.wl * sgn * gyc[ch];
-            float w1 = (ar <= 1.f) ? P.wl * frcp(fmaxf(ar, P.eps)) : 0.f;
-            float id1 = cl ? 0.f : P.ws * idn * d2, id2 = cl ? 0.f : 1.125f * P.ws * idn * d1;
-            float mx = Gx[ch] * n9, my = Gy[ch] * n9, ex = gxc[ch] - mx, ey = gyc[ch] - my;
-            lxx += w1 * gxc[ch] * gxc[ch] + id2 * ex * ex + id1 * mx * mx;
-            lxy += w1 * gxc[ch] * gyc[ch] + id2 * ex * ey + id1 * mx * my;
-            lyy += w1 * gyc[ch] * gyc[ch] + id2 * ey * ey + id1 * my * my;
+        for (int ch = 0; ch < 3; ch++) cA[ch] += cB[ch] * (0.5f - yc[ch]) + cC[ch] * (0.5f - xc[ch]);
+        const float e1 = t01.e1.x + t01.e1.y + t2.e1, e2 = t01.e2.x + t01.e2.y + t2.e2;
+        const float l1x = t01.l1x.x + t01.l1x.y + t2.l1x, l1y = t01.l1y.x + t01.l1y.y + t2.l1y;
+        float lxx = t01.lxx.x + t01.lxx.y + t2.lxx, lxy = t01.lxy.x + t01.lxy.y + t2.lxy, lyy = t01.lyy.x + t01.lyy.y + t2.lyy;
+        {   // GN curvature of the SSIM term (as in k_linearize)
+            const float n9 = 1.f / 9.f;
+            const f2 mx = Gx01 * n9, my = Gy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+            const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
+                     qyy = t01.id2 * ey * ey + t01.id1 * my * my;
+            const float mx2 = G2.x * n9, my2 = G2.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
+            lxx += qxx.x + qxx.y + t2.id2 * ex2 * ex2 + t2.id1 * mx2 * mx2;
+            lxy += qxy.x + qxy.y + t2.id2 * ex2 * ey2 + t2.id1 * mx2 * my2;
+            lyy += qyy.x + qyy.y + t2.id2 * ey2 * ey2 + t2.id1 * my2 * my2;
         }
         float diff = e1 + e2;
         float m = (real && ax.y > 0.5f && (!P.automask || diff < ax.z)) ? 1.f : 0.f;

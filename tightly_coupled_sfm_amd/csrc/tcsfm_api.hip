@@ -765,15 +765,15 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
     if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->depth0, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    // the dense kernel uses 32x8 tiles: its own tile grid and reduction-group count
-    constexpr int DTW = 32, DTH = 8, DNT = 256;
+    // the dense kernel's own tile grid (same 32x16 / 512 threads as k_linearize today) and reduction-group count
+    constexpr int DTW = 32, DTH = 16, DNT = 512;
     LinParams P = lin_params(h, &oo, 6);
     P.tiles_x = (h->W + DTW - 1) / DTW; P.tiles_y = (h->H + DTH - 1) / DTH;
     const int nblk = P.tiles_x * P.tiles_y;
     P.ngrp = (nblk + RG - 1) / RG;
     if ((size_t)nblk > (size_t)h->nblk_alloc || P.ngrp > h->ngrp_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
     SolveParams S = solve_params(h, &oo, 6, 0);
-    P.direct = nblk <= 256;
+    P.direct = nblk <= 512;
     S.partials = P.direct ? h->blockrec : h->partials; S.ngrp = P.direct ? nblk : P.ngrp;
     S.stats = d_stats; S.delta_out = h->delta;
     DenseParams Dn;
