@@ -89,10 +89,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     distributed = world > 1
+    # rehearsal switches (tests/test_gpu_bench.py): several ranks sharing ONE card over gloo -- RCCL refuses duplicate devices
+    backend = os.environ.get("TCSFM_BENCH_BACKEND", "nccl")
+    if os.environ.get("TCSFM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from tightly_coupled_sfm_amd import synth
     from tightly_coupled_sfm_amd.engine import Engine, default_opts
@@ -121,15 +129,16 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # final gather of the refined poses (RCCL over xGMI), outside the timed region
     final = pose_io.clone()
     if distributed:
-        gathered = [torch.empty_like(final) for _ in range(world)]
-        dist.all_gather(gathered, final)
+        send = final.to(coll_dev)
+        gathered = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(gathered, send)
         final_all = torch.stack(gathered)
     else:
         final_all = final[None]

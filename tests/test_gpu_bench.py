@@ -1,0 +1,46 @@
+"""bench.py contract (one JSON line, the keys the driver reads) -- single process, and a 2-rank rehearsal of the
+torch.distributed path on ONE card (gloo; RCCL refuses two ranks on the same device, the 8-GPU run is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline", "cpu_baseline"}
+
+
+def _line(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_single_process():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--cpu-sample", "1",
+                        "--sat-windows", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["value"] > 100
+    assert d["unit"] == "frame-pairs/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 0.01 * d["value"]                       # one window per step
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches"] == 4 * 60
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["algorithmic_bytes_per_launch"] == 32 * 192 * 640 * 2
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert "workload" in d["config"] and d["roofline_saturated"]["achieved"] > rf["achieved"]
+
+
+def test_bench_two_ranks_one_card():
+    env = dict(os.environ, TCSFM_BENCH_BACKEND="gloo", TCSFM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)                                                                       # rank 0 prints, once
+    assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["value"] > 100
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]                   # whole-job rate: 2 windows per step
