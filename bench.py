@@ -56,17 +56,31 @@ def cpu_baseline(sample_windows: int):
             "sample": f"{done} windows x (fwd+inv pair) x {ITERS} GN iterations at {W}x{H}, float64 scalar C oracle, {dt:.1f} s"}
 
 
-def load_pmc_traffic():
-    """HBM bytes per k_linearize launch from a separate rocprofv3 --pmc run (profiles/*pmc_traffic.json), or None."""
+def load_pmc(key="hbm_bytes_per_linearize_launch"):
+    """Per-launch PMC figures of k_linearize from separate rocprofv3 --pmc runs (profiles/*pmc_traffic.json), or None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not files:
         return None
     try:
         with open(files[-1]) as f:
-            return json.load(f).get("hbm_bytes_per_linearize_launch")
+            return json.load(f).get(key)
     except Exception:
         return None
+
+
+def valu_issue(avg_s, pairs_per_launch):
+    """The bound this kernel actually runs against: VALU issue.  One wave64 VALU instruction occupies a
+    SIMD for 4 clocks, so the chip issues at most 256 CU x 4 SIMD x 2.4 GHz / 4 = 614 G wave-instructions/s
+    (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 64 FLOP/clk/SIMD).  Instruction count: SQ_INSTS_VALU of the committed
+    PMC pass (B=1: 2 pairs per launch), scaled by the pairs in this launch."""
+    insts = load_pmc("valu_insts_per_linearize_launch")
+    if not insts:
+        return None
+    peak = 256 * 4 * 2.4e9 / 4
+    rate = insts * pairs_per_launch / 2 / avg_s
+    return {"wave_insts_per_launch": int(insts * pairs_per_launch / 2), "achieved_Ginst_per_s": round(rate / 1e9, 1),
+            "peak_Ginst_per_s": round(peak / 1e9, 1), "frac": round(rate / peak, 4)}
 
 
 def main():
@@ -156,10 +170,11 @@ def main():
         avg_s = lin_ms / max(lin_n, 1) * 1e-3
         achieved = alg_bytes / avg_s / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": load_pmc_traffic(),
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": load_pmc(),
                 "kernel": "k_linearize", "avg_launch_us": round(avg_s * 1e6, 3), "launches": int(lin_n),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "other_kernels_avg_us": {k: round(v[0] / max(v[1], 1) * 1e3, 3) for k, v in prof.items() if k != "linearize"}}
+                "other_kernels_avg_us": {k: round(v[0] / max(v[1], 1) * 1e3, 3) for k, v in prof.items() if k != "linearize"},
+                "valu_issue": valu_issue(avg_s, npairs)}
 
     # the same kernel with the chip full (32 windows = 64 directed pairs per call): the B=1 figure above is bounded by
     # launch latency and a grid of only 480 workgroups, this one by the kernel itself (report both)
@@ -188,7 +203,7 @@ def main():
         roof_sat = {"workload": f"{rep} windows ({npairs * rep} directed pairs) per call", "achieved": round(alg_b / avg_s / 1e9, 2),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_b / avg_s / 1e9 / HBM_PEAK_GBPS, 5),
                     "avg_launch_us": round(avg_s * 1e6, 2), "algorithmic_bytes_per_launch": alg_b,
-                    "frame_pairs_per_s": round(rep / wall, 1)}
+                    "frame_pairs_per_s": round(rep / wall, 1), "valu_issue": valu_issue(avg_s, npairs * rep)}
         del eng_b, big, out_b
 
     if rank == 0:

@@ -27,6 +27,7 @@ lin = next((v for k, v in pmc.items() if "k_linearize" in k and "FETCH_SIZE" in 
 if lin:
     fetch_kb, write_kb = lin["FETCH_SIZE"], lin.get("WRITE_SIZE", 0.0)
     traffic = {"hbm_bytes_per_linearize_launch": int((2 * fetch_kb + write_kb) * 1024),
+               "valu_insts_per_linearize_launch": lin.get("SQ_INSTS_VALU"), "waves_per_linearize_launch": lin.get("SQ_WAVES"),
                "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
                "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE; "
                        "separate rocprofv3 --pmc passes of `python bench.py --steps 20 --warmup 5`; per-launch average"}
