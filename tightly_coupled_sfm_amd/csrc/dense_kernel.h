@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
     const int x00 = txi * TW, y00 = tyi * TH;
     const float4 *tgtpack = P.tgtpack + (size_t)n * hw;
-    const float4 *srcpack = P.srcpack + (size_t)n * hw;
+    const float4 *srcpack = P.srcpack + (size_t)n * (H + 2) * (W + 2);   // zero-bordered (tap4)
     const float *depth_t = P.depth_t + (size_t)n * hw;
     const int tid = threadIdx.x;
 

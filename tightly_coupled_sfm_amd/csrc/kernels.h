@@ -45,7 +45,7 @@ struct PairState {
 
 struct LinParams {
     const float4 *tgtpack;  // [Nimg][H][W]  rgb + auto_err
-    const float4 *srcpack;  // [Nimg][H][W]  rgb + depth_s
+    const float4 *srcpack;  // [Nimg][H+2][W+2]  rgb + depth_s, 1-texel zero border
     const float *depth_t;   // [Nimg][H][W]
     const PairConst *pc;    // [N]
     float *blockrec;        // [N][nblk][nacc]   one partial-sum record per workgroup (write-through stores)
@@ -126,28 +126,38 @@ __device__ __forceinline__ void warp_geo(const PairConst &c, int W, int H, int u
 
 // bilinear sample of a float4 image at (ui + rx, vi + ry) with zero padding; also d/dix and d/diy
 // (grid_sampler_2d forward/backward semantics).  oob => the reference's sentinel: everything is zero.
-__device__ __forceinline__ void tap4(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob,
-                                     float4 &val, float4 &gx, float4 &gy) {
+// The image is stored with a 1-texel ZERO BORDER ((H+2) x (W+2), k_pack): taps are clamped into the border instead of being
+// masked one by one, and an out-of-bounds sample is sent there as a whole -- 1 select instead of 16 selects + 8 compares.
+struct Tap {
+    float4 v00, v01, v10, v11;
+    float wx, wy;
+};
+// address computation + the four 16-byte gathers (asynchronous: nothing here waits for them)
+__device__ __forceinline__ void tap4_fetch(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob, Tap &t) {
     float fx = floorf(rx), fy = floorf(ry);
-    float wx = rx - fx, wy = ry - fy;
+    t.wx = rx - fx; t.wy = ry - fy;
     int xi = ui + (int)fx, yi = vi + (int)fy;
-    bool x0in = (xi >= 0) && (xi < W), x1in = (xi >= -1) && (xi < W - 1);
-    bool y0in = (yi >= 0) && (yi < H), y1in = (yi >= -1) && (yi < H - 1);
-    int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
-    int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
-    float4 v00 = img[y0 * W + x0], v01 = img[y0 * W + x1], v10 = img[y1 * W + x0], v11 = img[y1 * W + x1];
-    const bool m00 = x0in && y0in && !oob, m01 = x1in && y0in && !oob, m10 = x0in && y1in && !oob, m11 = x1in && y1in && !oob;
-    // component-wise selects (a float4 ?: makes hipcc spill both operands to scratch and select the address)
-#define TC_SEL(v, m) v.x = m ? v.x : 0.f; v.y = m ? v.y : 0.f; v.z = m ? v.z : 0.f; v.w = m ? v.w : 0.f;
-    TC_SEL(v00, m00) TC_SEL(v01, m01) TC_SEL(v10, m10) TC_SEL(v11, m11)
-#undef TC_SEL
-    float ax = 1.f - wx, ay = 1.f - wy;
-#define TC_LERP(f)                                                                     \
-    val.f = ax * ay * v00.f + wx * ay * v01.f + ax * wy * v10.f + wx * wy * v11.f;     \
-    gx.f = ay * (v01.f - v00.f) + wy * (v11.f - v10.f);                                \
-    gy.f = ax * (v10.f - v00.f) + wx * (v11.f - v01.f);
+    xi = oob ? -2 : xi;                                         // both columns clamp to the left border: all four taps are zero
+    const int x0 = min(max(xi, -1), W) + 1, x1 = min(max(xi + 1, -1), W) + 1;   // bordered coordinates 0 .. W+1
+    const int y0 = min(max(yi, -1), H) + 1, y1 = min(max(yi + 1, -1), H) + 1;
+    const int WB = W + 2;
+    t.v00 = img[y0 * WB + x0]; t.v01 = img[y0 * WB + x1]; t.v10 = img[y1 * WB + x0]; t.v11 = img[y1 * WB + x1];
+}
+// bilinear value and d/dix, d/diy of the four channels
+__device__ __forceinline__ void tap4_lerp(const Tap &t, float4 &val, float4 &gx, float4 &gy) {
+    const float wx = t.wx, wy = t.wy, ax = 1.f - wx, ay = 1.f - wy;
+#define TC_LERP(f)                                                                             \
+    val.f = ax * ay * t.v00.f + wx * ay * t.v01.f + ax * wy * t.v10.f + wx * wy * t.v11.f;     \
+    gx.f = ay * (t.v01.f - t.v00.f) + wy * (t.v11.f - t.v10.f);                                \
+    gy.f = ax * (t.v10.f - t.v00.f) + wx * (t.v11.f - t.v01.f);
     TC_LERP(x) TC_LERP(y) TC_LERP(z) TC_LERP(w)
 #undef TC_LERP
+}
+__device__ __forceinline__ void tap4(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob,
+                                     float4 &val, float4 &gx, float4 &gy) {
+    Tap t;
+    tap4_fetch(img, W, H, ui, vi, rx, ry, oob, t);
+    tap4_lerp(t, val, gx, gy);
 }
 
 // Jacobian of the sample position and of Z w.r.t. the left SE(3) perturbation [rho, phi] (+ log depth-scale)
@@ -341,7 +351,20 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
         ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
     }
     P.tgtpack[(size_t)n * hw + idx] = make_float4(t[idx], t[hw + idx], t[2 * hw + idx], ae);
-    P.srcpack[(size_t)n * hw + idx] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], ds);
+    {   // source image with its 1-texel zero border (see tap4); edge pixels also write the border texels next to them
+        const int WB = P.W + 2;
+        float4 *sp = P.srcpack + (size_t)n * (P.H + 2) * WB;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        sp[(v + 1) * WB + u + 1] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], ds);
+        if (u == 0) sp[(v + 1) * WB] = zero;
+        if (u == P.W - 1) sp[(v + 1) * WB + P.W + 1] = zero;
+        if (v == 0) { sp[u + 1] = zero; if (u == 0) sp[0] = zero; if (u == P.W - 1) sp[P.W + 1] = zero; }
+        if (v == P.H - 1) {
+            sp[(P.H + 1) * WB + u + 1] = zero;
+            if (u == 0) sp[(P.H + 1) * WB] = zero;
+            if (u == P.W - 1) sp[(P.H + 1) * WB + P.W + 1] = zero;
+        }
+    }
     P.depth_out[(size_t)n * hw + idx] = dt;
 }
 
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     const int x00 = txi * TW, y00 = tyi * TH;
     const int img = P.shared_image ? 0 : n;
     const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
-    const float4 *srcpack = P.srcpack + (size_t)img * hw;
+    const float4 *srcpack = P.srcpack + (size_t)img * (H + 2) * (W + 2);   // zero-bordered (tap4)
     const float *depth_t = P.depth_t + (size_t)img * hw;
     const int tid = threadIdx.x;
 
@@ -669,51 +692,63 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     float c_pd[PPT], c_cd[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
     bool c_valid[PPT], c_in[PPT];
 
-    // ---------------- phase 1: warp + stage (centres first, then the halo ring) ----------------
+    // ---------------- phase 1: warp + stage (centres, and the halo ring on the first waves) ----------------
+    // The NHALO ring pixels are a second pixel for the first NHALO threads.  Those waves run BOTH pixels as one software-
+    // pipelined sequence -- loads of both, then both warps and gather issues, then both interpolations -- so the dependent
+    // load chain (pixel data -> warp -> source gather) of the ring pixel overlaps the centre pixel's instead of following it
+    // while the rest of the workgroup waits at the barrier.
     constexpr int NHALO = NCOMP - NCEN;
-    constexpr int ROUNDS = PPT + (NHALO + NT - 1) / NT;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        int lx, ly;  // compute-region coordinates
-        bool active = true;
-        if (r < PPT) {
-            int ci = tid + r * NT;
-            ly = ci / TW + 1; lx = ci - (ci / TW) * TW + 1;
-        } else {
-            int hi = tid + (r - PPT) * NT;
-            active = hi < NHALO;
-            // halo ring enumeration: top row, bottom row, then left/right columns
-            if (hi < CW) { ly = 0; lx = hi; }
-            else if (hi < 2 * CW) { ly = CH - 1; lx = hi - CW; }
-            else { int k = hi - 2 * CW; ly = 1 + (k >> 1); lx = (k & 1) ? CW - 1 : 0; }
-        }
-        if (!active) continue;
-        int px = refl_idx(x00 + lx - 1, W), py = refl_idx(y00 + ly - 1, H);
-        int gi = py * W + px;
-        float4 tp = tgtpack[gi];
-        Geo g;
-        warp_geo(c, W, H, px, py, depth_t[gi], g);
+    static_assert(PPT == 1 && NHALO <= NT, "one centre pixel per thread, one ring round");
+    constexpr int HALO_THREADS = (NHALO + 63) / 64 * 64;   // wave-uniform split
+    struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
+    auto s_load = [&](Stage &S) {
+        S.px = refl_idx(x00 + S.lx - 1, W); S.py = refl_idx(y00 + S.ly - 1, H);
+        const int gi = S.py * W + S.px;
+        S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+    };
+    auto s_warp = [&](Stage &S) {
+        warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
+        tap4_fetch(srcpack, W, H, S.px, S.py, S.g.rx, S.g.ry, S.g.oobx || S.g.ooby, S.t);
+    };
+    auto s_store = [&](Stage &S, bool write, bool centre) {
         float4 val, gx, gy;
-        tap4(srcpack, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, val, gx, gy);
+        tap4_lerp(S.t, val, gx, gy);
         float a[NP], b[NP], zc[NP];
-        geo_jac<NP>(c, g, W, H, a, b, zc);
-        float4 *rec = lds + (ly * CW + lx) * (LDS_REC / 4);
+        geo_jac<NP>(c, S.g, W, H, a, b, zc);
+        float4 *rec = lds + (S.ly * CW + S.lx) * (LDS_REC / 4);
         // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0..a3][a4 a5 b0 b1][b2..b5]([a6 b6 - -]) : channel pairs and
         // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles
-        lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
-        lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
-        lds_write1(rec + 2, val.z, tp.z, gx.z, gy.z);
-        lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
-        lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
-        lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
-        if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
-        if (r < PPT) {
-            const int k = r < PPT ? r : 0;
-            c_in[k] = (x00 + lx - 1 < W) && (y00 + ly - 1 < H);
-            c_pd[k] = c.es * val.w; c_dgx[k] = c.es * gx.w; c_dgy[k] = c.es * gy.w; c_cd[k] = g.Z;
-            c_ae[k] = tp.w; c_valid[k] = !(g.oobx || g.ooby);
+        if (write) {
+            lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
+            lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+            lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
+            lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
+            lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
+            lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
+            if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
+        }
+        if (centre) {
+            c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
+            c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
+            c_ae[0] = S.tp.w; c_valid[0] = !(S.g.oobx || S.g.ooby);
 #pragma unroll
-            for (int j = 0; j < NP; j++) c_zc[k][j] = zc[j];
+            for (int j = 0; j < NP; j++) c_zc[0][j] = zc[j];
+        }
+    };
+    {
+        Stage A;
+        A.ly = tid / TW + 1; A.lx = tid - (tid / TW) * TW + 1;
+        if (tid < HALO_THREADS) {
+            Stage B;
+            const int hi = min(tid, NHALO - 1);   // ring enumeration: top row, bottom row, then left/right columns
+            if (hi < CW) { B.ly = 0; B.lx = hi; }
+            else if (hi < 2 * CW) { B.ly = CH - 1; B.lx = hi - CW; }
+            else { const int k = hi - 2 * CW; B.ly = 1 + (k >> 1); B.lx = (k & 1) ? CW - 1 : 0; }
+            s_load(A); s_load(B);
+            s_warp(A); s_warp(B);
+            s_store(A, true, true); s_store(B, tid < NHALO, false);
+        } else {
+            s_load(A); s_warp(A); s_store(A, true, true);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm LDS writes above are invisible to hipcc's own waitcnt tracking

@@ -322,7 +322,7 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
     h->stream = h->own_stream;
     if (e == hipSuccess) e = hipMalloc((void **)&h->tgtpack, n * hw * sizeof(float4));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->srcpack, n * hw * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->srcpack, n * (size_t)(H + 2) * (W + 2) * sizeof(float4));   // zero-bordered
     if (e == hipSuccess) e = hipMalloc((void **)&h->depth_work, n * hw * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->partials, n * h->ngrp_pad * kMaxAcc * sizeof(float));
     if (e == hipSuccess) e = hipMemset(h->partials, 0, n * h->ngrp_pad * kMaxAcc * sizeof(float));  // pad records stay 0
