@@ -60,43 +60,57 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f, o_depth = 1.f;
 
     // ---------------- phase 1 ----------------
-    constexpr int R1 = (N2 + NT - 1) / NT;
-#pragma unroll
-    for (int r = 0; r < R1; r++) {
-        // round 0: own pixel; later rounds: the rest of the region in raster order, skipping the tile interior
-        int lx, ly;
-        bool active = true;
-        if (r == 0) { lx = ox + 2; ly = oy + 2; }
-        else {
-            int hi = tid + (r - 1) * NT;          // index among the N2 - NCEN halo pixels
-            active = hi < N2 - NCEN;
-            // rows 0,1 and H2-2,H2-1 are full rows of W2; the middle TH rows contribute 4 pixels each (2 left, 2 right)
-            if (hi < 2 * W2) { ly = hi / W2; lx = hi - ly * W2; }
-            else if (hi < 4 * W2) { int k = hi - 2 * W2; ly = H2 - 2 + k / W2; lx = k - (k / W2) * W2; }
-            else { int k = hi - 4 * W2; ly = 2 + (k >> 2); int s = k & 3; lx = s < 2 ? s : W2 - 4 + s; }
-        }
-        if (!active) continue;
-        int px = refl_idx(x00 + lx - 2, W), py = refl_idx(y00 + ly - 2, H);
-        int gi = py * W + px;
-        float4 tp = tgtpack[gi];
-        float dep = depth_t[gi];
-        Geo g;
-        warp_geo(c, W, H, px, py, dep, g);
-        const bool oob = g.oobx || g.ooby;
+    // Own pixel for every thread; the N2 - NCEN pixels of the 2-pixel ring are a second pixel for the first threads.  As in
+    // k_linearize those waves run both pixels as one software-pipelined sequence (loads, warps + gather issues,
+    // interpolations) so that the ring pixel's dependent load chain overlaps the own pixel's.
+    constexpr int NRING = N2 - NCEN;
+    static_assert(NRING <= NT, "one ring round");
+    constexpr int RING_THREADS = (NRING + 63) / 64 * 64;
+    struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
+    auto s_load = [&](Stage &S) {
+        S.px = refl_idx(x00 + S.lx - 2, W); S.py = refl_idx(y00 + S.ly - 2, H);
+        const int gi = S.py * W + S.px;
+        S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+    };
+    auto s_warp = [&](Stage &S) {
+        warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
+        tap4_fetch(srcpack, W, H, S.px, S.py, S.g.rx, S.g.ry, S.g.oobx || S.g.ooby, S.t);
+    };
+    auto s_store = [&](Stage &S, bool write, bool own) {
         float4 val, gx, gy;
-        tap4(srcpack, W, H, px, py, g.rx, g.ry, oob, val, gx, gy);
-        float pd = c.es * val.w, cd = g.Z;
+        tap4_lerp(S.t, val, gx, gy);
+        const bool oob = S.g.oobx || S.g.ooby;
+        float pd = c.es * val.w, cd = S.g.Z;
         float Wt = 1.f - clamp01(fabsf(cd - pd) * frcp(cd + pd));
-        float4 *rec = rec1 + (ly * W2 + lx) * 3;
-        lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
-        lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
-        lds_write1(rec + 2, val.z, tp.z, gx.z, gy.z);
-        lds_write1(aux + ly * W2 + lx, Wt, oob ? 0.f : 1.f, tp.w, 0.f);
-        if (r == 0) {
-            geo_jac<7>(c, g, W, H, a, b, zc);
+        if (write) {
+            float4 *rec = rec1 + (S.ly * W2 + S.lx) * 3;
+            lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
+            lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+            lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
+            lds_write1(aux + S.ly * W2 + S.lx, Wt, oob ? 0.f : 1.f, S.tp.w, 0.f);
+        }
+        if (own) {
+            geo_jac<7>(c, S.g, W, H, a, b, zc);
             // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
-            a[6] *= -dep; b[6] *= -dep; zc[6] *= -dep;
-            o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = dep;
+            a[6] *= -S.dep; b[6] *= -S.dep; zc[6] *= -S.dep;
+            o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
+        }
+    };
+    {
+        Stage A;
+        A.lx = ox + 2; A.ly = oy + 2;
+        if (tid < RING_THREADS) {
+            Stage B;
+            const int hi = min(tid, NRING - 1);   // index among the ring pixels, raster order skipping the tile interior
+            // rows 0,1 and H2-2,H2-1 are full rows of W2; the middle TH rows contribute 4 pixels each (2 left, 2 right)
+            if (hi < 2 * W2) { B.ly = hi / W2; B.lx = hi - B.ly * W2; }
+            else if (hi < 4 * W2) { const int k = hi - 2 * W2; B.ly = H2 - 2 + k / W2; B.lx = k - (k / W2) * W2; }
+            else { const int k = hi - 4 * W2; B.ly = 2 + (k >> 2); const int q = k & 3; B.lx = q < 2 ? q : W2 - 4 + q; }
+            s_load(A); s_load(B);
+            s_warp(A); s_warp(B);
+            s_store(A, true, true); s_store(B, tid < NRING, false);
+        } else {
+            s_load(A); s_warp(A); s_store(A, true, true);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
