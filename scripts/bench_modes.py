@@ -37,3 +37,27 @@ run("#4 pose+scale 8 iters", 192, 640, 2, default_opts(n_iters=8, refine=1))
 run("#5 dense 320x240", 240, 320, 2, default_opts(n_iters=4, min_depth=0.03, max_depth=3.0), dense=True)
 run("#5 dense 448x256", 256, 448, 2, default_opts(n_iters=4, min_depth=0.03, max_depth=3.0), dense=True)
 run("dense 640x192", 192, 640, 2, default_opts(n_iters=4), dense=True)
+
+
+def run_host(steps=200, warm=20):
+    """PCIe-inclusive variant of #2: the caller hands over HOST arrays (opts.host_ptrs = 1); never the bench.py metric"""
+    import ctypes as C
+    H, W, npairs = 192, 640, 2
+    b = synth.make_batch(npairs, H, W, seed0=0, both_directions=True)
+    host = {k: np.ascontiguousarray(b[k], dtype=np.float32) for k in ("tgt", "src", "depth_t", "depth_s", "K", "pose_init")}
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    e = Engine(H, W, npairs)
+    o = default_opts(n_iters=4, host_ptrs=1)
+    out = np.zeros((npairs, 6), np.float32)
+    def step():
+        e._call(e.lib.tcsfm_refine(e._h, C.byref(o), npairs, ptr(host["tgt"]), ptr(host["src"]), ptr(host["depth_t"]), ptr(host["depth_s"]),
+                                   ptr(host["K"]), ptr(host["pose_init"]), None, ptr(out), None, None))
+    for _ in range(warm): step()
+    t0 = time.perf_counter()
+    for _ in range(steps): step()
+    dt = (time.perf_counter() - t0) / steps
+    mb = sum(host[k].nbytes for k in ("tgt", "src", "depth_t", "depth_s")) / 1e6
+    print(json.dumps({"config": "#2 B=1 pose, HOST pointers (PCIe-inclusive, synchronous, pageable memory)", "us_per_call": round(dt * 1e6, 1),
+                      "windows_per_s": round(1 / dt, 1), "MB_in_per_call": round(mb, 2)}))
+
+run_host()

@@ -540,3 +540,41 @@ def test_large_frame_uses_group_reduction_and_matches_oracle(oracle64):
         tol = 1e-4 if same else 2e-3                                  # see test_refine_window_argmin_vs_oracle on mask ties
         assert np.linalg.norm(pose[n, :3] - rp[:3]) / np.linalg.norm(rp[:3]) < tol
         assert np.linalg.norm(pose[n, 3:] - rp[3:]) / np.linalg.norm(rp[3:]) < tol
+
+
+def test_host_pointer_calls_match_device_pointer_calls():
+    """opts.host_ptrs = 1: the library stages host arrays itself (what a C caller without device memory uses);
+    results are bit-identical to the device-pointer path"""
+    import ctypes as C
+    from tightly_coupled_sfm_amd import _lib
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, N = 48, 160, 2
+    b = _pairs(N, H, W, seed0=8, both=True)
+    e = _eng(H, W, N)
+    d = _dev(b); p0 = _t(b["pose_init"])
+    ref_pose, _, ref_st = e.refine(*d, p0, default_opts(n_iters=3), stats=True)
+    ref_rec, ref_valid, ref_pd, ref_cd = e.inverse_warp2(d[1], d[2], d[3], -p0, d[4])
+    torch.cuda.synchronize()
+    host = {k: np.ascontiguousarray(b[k], dtype=np.float32) for k in ("tgt", "src", "depth_t", "depth_s", "K", "pose_init")}
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    o = default_opts(n_iters=3, host_ptrs=1)
+    pose = np.zeros((N, 6), np.float32); st = np.zeros((N, 4, _lib.NSTAT), np.float32)
+    e._call(e.lib.tcsfm_refine(e._h, C.byref(o), N, ptr(host["tgt"]), ptr(host["src"]), ptr(host["depth_t"]), ptr(host["depth_s"]),
+                               ptr(host["K"]), ptr(host["pose_init"]), None, ptr(pose), None, ptr(st)))
+    assert np.array_equal(pose, ref_pose.cpu().numpy()) and np.array_equal(st, ref_st.cpu().numpy())
+    rec = np.zeros((N, 3, H, W), np.float32); valid, pd, cd = (np.zeros((N, 1, H, W), np.float32) for _ in range(3))
+    e._call(e.lib.tcsfm_warp(e._h, C.byref(o), N, ptr(host["src"]), ptr(host["depth_t"]), ptr(host["depth_s"]), ptr(host["pose_init"]),
+                             ptr(host["K"]), ptr(rec), ptr(valid), ptr(pd), ptr(cd)))
+    assert np.array_equal(rec, ref_rec.cpu().numpy()) and np.array_equal(valid, ref_valid.cpu().numpy())
+    assert np.array_equal(pd, ref_pd.cpu().numpy()) and np.array_equal(cd, ref_cd.cpu().numpy())
+    # window form from host memory: B=1, S=2 (fwd pairs then inv pairs)
+    tg, sr = host["tgt"][:1], np.stack([host["src"][:1], host["tgt"][1:2]])            # two "sources" for target 0
+    dt, ds = host["depth_t"][:1], np.stack([host["depth_s"][:1], host["depth_t"][1:2]])
+    p4 = np.ascontiguousarray(np.concatenate([host["pose_init"][:1], host["pose_init"][:1], host["pose_init"][1:2], host["pose_init"][1:2]]))
+    e4 = _eng(H, W, 4)
+    out_h = np.zeros((4, 6), np.float32)
+    ow = default_opts(n_iters=2, host_ptrs=1, argmin=1)
+    e4._call(e4.lib.tcsfm_refine_window(e4._h, C.byref(ow), 1, 2, ptr(tg), ptr(sr), ptr(dt), ptr(ds), ptr(host["K"][:1].copy()), ptr(p4), None,
+                                        ptr(out_h), None, None))
+    out_d, _, _ = e4.refine_window(_t(tg), _t(sr), _t(dt), _t(ds), _t(host["K"][:1]), _t(p4), default_opts(n_iters=2), argmin=True)
+    assert np.array_equal(out_h, out_d.cpu().numpy())
