@@ -35,10 +35,17 @@ def test_bench_single_process():
     assert "workload" in d["config"] and d["roofline_saturated"]["achieved"] > rf["achieved"]
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_bench_two_ranks_one_card():
     env = dict(os.environ, TCSFM_BENCH_BACKEND="gloo", TCSFM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5"],
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)                                                                       # rank 0 prints, once
