@@ -31,7 +31,7 @@ def test_bench_single_process():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["launches"] == 4 * 60
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["algorithmic_bytes_per_launch"] == 32 * 192 * 640 * 2
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert "workload" in d["config"] and d["roofline_saturated"]["achieved"] > rf["achieved"]
 
 
