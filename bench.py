@@ -224,7 +224,13 @@ def main():
 
     if rank == 0:
         total_windows = args.steps * WINDOWS_PER_RANK * world
+        # sanity figures from one extra, untimed call: the cost the 4 linearisations saw, and how far the refined poses are from
+        # the scene's true poses (the minimiser of the reference's residual is NOT the true pose on rendered data: its warp
+        # samples at u W/(W-1) - 1/2 and blends borders with zero padding, SURVEY 8a row a5 -- a few per cent of the motion)
+        _, _, st = eng.refine(dev["tgt"], dev["src"], dev["depth_t"], dev["depth_s"], dev["K"], dev["pose_init"], opts, stats=True)
+        cost_traj = [round(float(x), 6) for x in st[:, :ITERS, 0].mean(0).cpu()]
         err_t = float((final[:, :3] - dev["pose_gt"][:, :3]).norm(dim=1).mean() / dev["pose_gt"][:, :3].norm(dim=1).mean())
+        err_0 = float((dev["pose_init"][:, :3] - dev["pose_gt"][:, :3]).norm(dim=1).mean() / dev["pose_gt"][:, :3].norm(dim=1).mean())
         out = {
             "metric": "optimized frame-pairs/sec at 640x192, 4 GN iters",
             "value": round(total_windows / elapsed, 2),
@@ -239,7 +245,9 @@ def main():
             "roofline": roof,
             "roofline_saturated": roof_sat,
             "cpu_baseline": cpu_baseline(args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None,
-            "check": {"mean_rel_translation_error_vs_gt_after_refine": round(err_t, 5)},
+            "check": {"mean_cost_at_each_linearisation": cost_traj,
+                      "rel_translation_distance_to_scene_truth": {"initial": round(err_0, 5), "refined": round(err_t, 5),
+                                                                  "note": "the residual's minimiser is offset from the scene truth by design of the reference's warp"}},
         }
         print(json.dumps(out), flush=True)
     if distributed:
