@@ -578,3 +578,33 @@ def test_host_pointer_calls_match_device_pointer_calls():
                                         ptr(out_h), None, None))
     out_d, _, _ = e4.refine_window(_t(tg), _t(sr), _t(dt), _t(ds), _t(host["K"][:1]), _t(p4), default_opts(n_iters=2), argmin=True)
     assert np.array_equal(out_h, out_d.cpu().numpy())
+
+
+def test_argument_errors_are_codes_not_crashes():
+    """errors never cross the ABI as exceptions or faults: negative return code + tcsfm_last_error (SURVEY 8b 'Errors')"""
+    import ctypes as C
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, N = 24, 40, 2
+    b = _pairs(N, H, W, seed0=2)
+    e = _eng(H, W, N)
+    d = _dev(b); p0 = _t(b["pose_init"]); out = torch.empty_like(p0)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    call = lambda o, n=N, tgt=d[0]: e.lib.tcsfm_refine(e._h, C.byref(o), n, P(tgt), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), None, P(out), None, None)
+    for bad, frag in ((dict(solver=5), "solver"), (dict(param=3), "param"), (dict(refine=9), "refine"), (dict(n_iters=-1), "n_iters"),
+                      (dict(depth_is_disp=1, min_depth=0.0), "min_depth")):
+        rc = call(default_opts(**bad))
+        assert rc < 0 and frag in e.lib.tcsfm_last_error(e._h).decode(), (bad, rc)
+    assert call(default_opts(), n=0) < 0 and call(default_opts(), n=N + 1) < 0
+    assert e.lib.tcsfm_refine(e._h, C.byref(default_opts()), N, None, P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), None, P(out), None, None) < 0
+    assert e.lib.tcsfm_refine(e._h, None, N, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), None, P(out), None, None) < 0
+    dep = torch.empty_like(d[2])
+    rc = e.lib.tcsfm_refine_dense(e._h, C.byref(default_opts(w_dc=0.1)), N, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), P(out), P(dep), None)
+    assert rc < 0 and "w_dc" in e.lib.tcsfm_last_error(e._h).decode()
+    rc = e.lib.tcsfm_refine_dense(e._h, C.byref(default_opts(solver=1)), N, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), P(out), P(dep), None)
+    assert rc < 0
+    h = C.c_void_p()
+    assert e.lib.tcsfm_create(C.byref(h), 0, 2, 2, 1) < 0 and b"sizes" in e.lib.tcsfm_last_error(None)
+    # ... and the handle is still healthy afterwards
+    assert call(default_opts()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
