@@ -608,3 +608,29 @@ def test_argument_errors_are_codes_not_crashes():
     assert call(default_opts()) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
+
+
+def test_full_size_against_the_reference_run(oracle64):
+    """BASELINE size (640x192): the HIP path against the REFERENCE's own float64 run on the same seeded inputs (golden
+    full192x640: cost, mask count, autograd gradient, strided samples of the maps)"""
+    from tightly_coupled_sfm_amd import synth
+    g = load_golden("full192x640")
+    H, W = 192, 640
+    p = synth.make_pair(H, W, seed=0)
+    chk = np.array([p[k].astype(np.float64).sum() for k in ("tgt", "src", "depth_t", "depth_s")])
+    assert np.allclose(chk, g["in_checksum"], rtol=0, atol=1e-6), "synthetic generator drifted from the fixture"
+    e = _eng(H, W, 1)
+    args = (_t(p["tgt"][None]), _t(p["src"][None]), _t(p["depth_t"][None, None]), _t(p["depth_s"][None, None]))
+    pose, K = _t(g["pose"][None]), _t(p["K"][None])
+    lin = e.linearize(*args, K, pose)
+    assert abs(lin["cost"][0] - float(g["f64_cost"])) < 2e-6 * float(g["f64_cost"])
+    assert abs(lin["n_mask"][0] - float(g["f64_n_mask"])) <= 3                       # fp32 ties on the auto-mask threshold
+    gp = oracle64.euler_left_jacobian(g["pose"]).T @ lin["g"][0]                     # d/d xi -> d/d pose (chain rule only)
+    assert _maxabs(gp, g["f64_grad_pose"]) < 2e-4 * np.abs(g["f64_grad_pose"]).max()  # == reference autograd
+    r = e.compute_photometric_error(args[0], args[1], args[2], args[3], pose, K)
+    diff = r["diff_img"][0, 0].cpu().numpy(); wt = r["weight_mask"][0, 0].cpu().numpy()
+    assert _maxabs(diff[::7, ::7], g["f64_diff_sub"]) < 2e-5 and _maxabs(wt[::7, ::7], g["f64_weight_sub"]) < 2e-5   # fp32 SSIM
+    assert _maxabs(r["img_rec"][0].cpu().numpy()[:, ::7, ::7], g["f64_rec_sub"]) < 2e-6
+    m = r["valid_mask"][0, 0].cpu().numpy()
+    assert np.mean(m[::7, ::7] != g["f64_mask_sub"]) < 1e-3
+    assert abs(float(diff.astype(np.float64).sum()) - float(g["f64_sum_diff"])) < 1e-5 * float(g["f64_sum_diff"])
