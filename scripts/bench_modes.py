@@ -31,6 +31,7 @@ def run(name, H, W, npairs, opts, dense=False, steps=300, warm=30):
                       "linearize_GBps_algorithmic32": round(32 * H * W * npairs / lin_us / 1e3, 1)}))
 
 run("#2 B=1 pose", 192, 640, 2, default_opts(n_iters=4))
+run("#2 B=1 pose + depth-consistency term (reference default l_depth_consist)", 192, 640, 2, default_opts(n_iters=4, w_dc=0.15))
 run("#3 8 windows per GPU pose", 192, 640, 16, default_opts(n_iters=4))
 run("#3' 64 windows on ONE GPU pose", 192, 640, 128, default_opts(n_iters=4), steps=50, warm=5)
 run("#4 pose+scale 8 iters", 192, 640, 2, default_opts(n_iters=8, refine=1))
@@ -61,3 +62,24 @@ def run_host(steps=200, warm=20):
                       "windows_per_s": round(1 / dt, 1), "MB_in_per_call": round(mb, 2)}))
 
 run_host()
+
+
+def run_window(steps=300, warm=30):
+    """the reference's KITTI default as a window: B=1 target, S=2 sources -> 4 directed pairs, min over sources, depth consistency"""
+    H, W, B, S = 192, 640, 1, 2
+    b = synth.make_batch(2 * S, H, W, seed0=0)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    tgt, srcs = d["tgt"][:1], d["src"][:S].reshape(S, B, 3, H, W)
+    dt, ds = d["depth_t"][:1], d["depth_s"][:S].reshape(S, B, 1, H, W)
+    pose = torch.cat([d["pose_init"][:S], -d["pose_init"][:S]]).contiguous()
+    e = Engine(H, W, 2 * S * B)
+    for argmin in (False, True):
+        o = default_opts(n_iters=4, w_dc=0.15)
+        for _ in range(warm): e.refine_window(tgt, srcs, dt, ds, d["K"][:1], pose, o, argmin=argmin)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps): e.refine_window(tgt, srcs, dt, ds, d["K"][:1], pose, o, argmin=argmin)
+        torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / steps
+        print(json.dumps({"config": f"KITTI-default window B=1 S=2 (4 directed pairs), depth consistency, min over sources={argmin}",
+                          "us_per_call": round(dt_ * 1e6, 1), "windows_per_s": round(1 / dt_, 1)}))
+
+run_window()
