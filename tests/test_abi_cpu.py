@@ -92,3 +92,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def _build_c_caller(tmp_path):
+    import subprocess
+    from tightly_coupled_sfm_amd import _lib
+    exe = str(tmp_path / "c_caller")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(REPO, "include"),
+                           os.path.join(REPO, "examples", "c_caller.c"), "-L" + libdir, "-ltcsfm_hip", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    return exe
+
+
+def test_header_is_c99_and_a_plain_c_program_links(lib, tmp_path):
+    """the boundary is a C ABI: include/tcsfm.h compiles as strict C99 and examples/c_caller.c (no torch, no C++) links
+    against the library; without a GPU it fails with the library's own error message, not a crash"""
+    import subprocess
+    exe = _build_c_caller(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is covered by tests/test_gpu_parity.py::test_plain_c_caller")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "tcsfm_create" in r.stderr

@@ -634,3 +634,21 @@ def test_full_size_against_the_reference_run(oracle64):
     m = r["valid_mask"][0, 0].cpu().numpy()
     assert np.mean(m[::7, ::7] != g["f64_mask_sub"]) < 1e-3
     assert abs(float(diff.astype(np.float64).sum()) - float(g["f64_sum_diff"])) < 1e-5 * float(g["f64_sum_diff"])
+
+
+def test_plain_c_caller(tmp_path):
+    """examples/c_caller.c: a C99 program using only include/tcsfm.h with host arrays (no torch in the process)"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_abi_cpu import _build_c_caller
+    exe = _build_c_caller(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("pair")]
+    assert len(lines) == 2
+    for l in lines:
+        c0, c1 = (float(x) for x in l.split("cost")[1].split("pose")[0].replace("->", " ").split())
+        assert c1 < 0.5 * c0, l                                   # the refinement found the parallax
+    tx = [float(l.split("[")[1].split(",")[0]) for l in lines]
+    assert tx[0] * tx[1] < 0 and min(abs(tx[0]), abs(tx[1])) > 3e-3          # opposite shifts -> opposite translations
