@@ -652,3 +652,21 @@ def test_plain_c_caller(tmp_path):
         assert c1 < 0.5 * c0, l                                   # the refinement found the parallax
     tx = [float(l.split("[")[1].split(",")[0]) for l in lines]
     assert tx[0] * tx[1] < 0 and min(abs(tx[0]), abs(tx[1])) > 3e-3          # opposite shifts -> opposite translations
+
+
+def test_generate_loss_surface_drop_in_vs_reference_golden():
+    """the plot_loss_surface.generate_loss_surface mirror: same arguments and result dict as the reference (golden G7)"""
+    from tightly_coupled_sfm_amd.plot_loss_surface import generate_loss_surface
+    g = load_golden("sweep48x160")
+    data = (_t(g["tgt"][None]), [_t(g["src"][None])], None, None, None, _t(g["K"][None]), None, None, None, None, None)
+    depths = [_t(g["depth_t"][None, None]), _t(g["depth_s"][None, None])]
+    r = generate_loss_surface(data, depths, _t(g["pose"][None]).clone(), sample_trans=True, sample_yaw=True)
+    assert np.array_equal(r["delta_list"], g["delta_list"]) and np.array_equal(r["delta_list_yaw"], g["delta_list_yaw"])
+    assert abs(r["original_error"] - float(g["original_error"])) < 2e-5 * float(g["original_error"])
+    for mine, ref in ((r["reconstruction_errors"], g["errors"]), (r["reconstruction_errors_yaw"], g["errors_yaw"])):
+        rel = np.abs(mine - ref) / ref
+        assert mine.shape == ref.shape and np.median(rel) < 2e-5 and rel.max() < 2e-3
+    step_t, step_y = g["delta_list"][1] - g["delta_list"][0], g["delta_list_yaw"][1] - g["delta_list_yaw"][0]
+    assert abs(float(r["best_trans_delta"]) - float(g["best_trans_delta"])) <= 1.01 * step_t
+    assert abs(float(r["best_yaw_delta"]) - float(g["best_yaw_delta"])) <= 1.01 * step_y
+    assert r["best_pose_vec"].shape == (1, 6) and r["best_error"] <= r["original_error"]
