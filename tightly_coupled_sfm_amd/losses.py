@@ -7,6 +7,18 @@ from __future__ import annotations
 import torch
 
 
+class SSIM_Loss:
+    """losses.py:16-41: callable like the reference's nn.Module -- SSIM_Loss()(x, y) -> clamp((1 - SSIM) / 2, 0, 1) per pixel
+    and channel, 3x3 windows over a reflect-padded image; one fused HIP kernel (tcsfm_ssim) instead of 2 pads + 5 pools."""
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        from ._shared import get_engine
+        H, W = x.shape[-2:]
+        return get_engine(H, W, max(1, x.shape[0])).ssim_loss(x.float().contiguous(), y.float().contiguous())
+
+    forward = __call__
+
+
 def get_smooth_loss(disp: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
     """losses.py:43-61: edge-aware smoothness of the mean-normalised disparity."""
     mean_disp = disp.mean(2, True).mean(3, True)
