@@ -718,6 +718,11 @@ def test_reference_named_drop_ins_vs_goldens():
     assert _maxabs(rec[0].cpu().numpy(), s["f64_rec"][k]) < 1e-4 and _maxabs(cd[0, 0].cpu().numpy(), s["f64_comp_depth"][k]) < 1e-5
     assert _maxabs(losses.SSIM_Loss()(tgt, src)[0].cpu().numpy(), s["f64_ssim_ts"]) < 3e-5
     assert _maxabs(stn.pose_vec2mat(-pose)[0].cpu().numpy().astype(np.float64), np.asarray(_pose_T(s["poses"][k]))) < 1e-6
+    from tightly_coupled_sfm_amd import dnet_layers
+    sc = load_golden("scale48x160")
+    K4 = np.tile(np.eye(4, dtype=np.float32), (2, 1, 1)); K4[:, :3, :3] = sc["K"]
+    scale = dnet_layers.ScaleRecovery(2, 48, 160).to("cuda")(_t(sc["depth"][:, None]), _t(K4), float(sc["cam_height"]))
+    assert abs(float(scale) - float(sc["f32_scale"][0])) < 2e-5 * float(sc["f32_scale"][0])
     hp = load_golden("helpers")
     sd, dep = learning_helpers.disp_to_depth(_t(hp["disp"]), 0.06, 2.67)
     assert _maxabs(sd.cpu().numpy() / hp["scaled_disp"], 1.0) < 1e-6 and _maxabs(dep.cpu().numpy() / hp["depth"], 1.0) < 1e-6
