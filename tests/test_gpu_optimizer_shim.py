@@ -82,6 +82,9 @@ def test_optimize_window_against_reference_result_dict():
     assert np.all(cost[:, 3] < cost[:, 0])
     assert np.all(np.abs(r["poses_opt"].numpy() - r["poses_init"].numpy()).max(1) > 1e-6)
     assert np.array_equal(r["stacked_poses_opt"][:, -1].cpu().numpy(), r["poses_opt"].numpy())
+    # one result dict per iterate, like the demo variant's `full_results` (optimizer_for_cont_plot.py:270)
+    assert len(opt.full_results) == 4 and np.array_equal(opt.full_results[-1]["poses_opt"].numpy(), r["poses_opt"].numpy())
+    assert set(opt.full_results[0]) == set(r)
     assert np.max(np.abs(r["stacked_poses_opt"][:, 0].cpu().numpy() - r["poses_init"].numpy())) < 2e-7
 
 

@@ -82,6 +82,7 @@ class DepthOptimizer:
                 raise NotImplementedError(msg)
             warnings.warn(msg)
         self._engine = None
+        self.full_results = []
 
     # -- engine / options ------------------------------------------------------------------------------------
     def _eng(self, H, W, npairs):
@@ -211,4 +212,8 @@ class DepthOptimizer:
         pd = sd.cpu().numpy()[:, 0]
         # the reference hands back a float64 CPU tensor here (avg_final_predictions adds numpy arrays into a tensor, G9)
         res["disp_opt"] = torch.from_numpy(np.ascontiguousarray(batch_post_process_disparity(pd[:B], pd[B:, :, ::-1])))
+        # the demo variant of the reference optimiser (optimizer_for_cont_plot.py:27,116,270) keeps one result dict per
+        # optimisation step in `full_results`; here: one per Gauss-Newton iterate
+        self.full_results = [dict(res, poses_opt=traj[:split, k].cpu(), poses_inv_opt=traj[split:, k].cpu())
+                             for k in range(1, traj.shape[1])]
         return res
