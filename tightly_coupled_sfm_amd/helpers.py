@@ -17,12 +17,15 @@ def compute_photometric_error(target_img, source_img, target_depth, source_depth
     return {k: r[k] for k in ("diff_img", "img_rec", "valid_mask", "weight_mask", "poses")}
 
 
+@torch.no_grad()
 def get_disp_for_eigen(depth_model, target_img, config):
-    """optimization_experiments/helpers.py:35-49: flip-averaged, post-processed disparity of the target frames"""
-    with torch.no_grad():
-        both = torch.cat((target_img, torch.flip(target_img, [3])), 0)
-        disparities, _ = depth_model(both, epoch=50)
-        disps, _ = disp_to_depth(disparities[0].float().contiguous(), config["min_depth"], config["max_depth"])
-        pred = disps.cpu().detach()[:, 0].numpy()
-        n = pred.shape[0] // 2
-        return batch_post_process_disparity(pred[:n], pred[n:, :, ::-1])
+    """optimization_experiments/helpers.py:35-49: disparity of the target frames for depth evaluation -- the network is run on
+    the frames and on their mirror images, both go through disp_to_depth (HIP) and the two halves are blended with the
+    Monodepth border ramp (batch_post_process_disparity)."""
+    n_frames = target_img.shape[0]
+    mirrored = torch.flip(target_img, dims=[3])
+    net_out, _ = depth_model(torch.cat([target_img, mirrored], dim=0), epoch=50)
+    scaled, _ = disp_to_depth(net_out[0].float().contiguous(), config["min_depth"], config["max_depth"])
+    scaled = scaled[:, 0].cpu().numpy()
+    straight, flipped_back = scaled[:n_frames], scaled[n_frames:, :, ::-1]
+    return batch_post_process_disparity(straight, flipped_back)
