@@ -113,6 +113,15 @@ def test_tuple_form_dense_mode_and_legacy_switches():
     r = DepthOptimizer(dict(OPTIONS, refine="pose+scale", gn_iters=6), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)
     assert tuple(r["log_depth_scale"].shape) == (2 * S * B,) and tuple(r["stacked_poses_opt"].shape) == (S * B, 7, 6)
 
+    # mode 'unscaled': DNet ground-plane rescaling of the target depth (optimizer.py:254-256) through tcsfm_scale_recovery
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    opt_u = DepthOptimizer(dict(OPTIONS, mode="unscaled"), _config(B, iters), pose_model, depth_model, "09_02")
+    r = opt_u.optimize_window(0, data)
+    from tightly_coupled_sfm_amd.dnet_layers import ScaleRecovery
+    expect = ScaleRecovery(B, *w["target"].shape[2:])(r["depths_opt"][0], t(w["K"]), 1.65 / 30.0)
+    assert r["scale_factor"].device.type == "cpu" and tuple(r["scale_factor"].shape) == (1,)
+    assert abs(float(r["scale_factor"]) - float(expect)) < 1e-6 * float(expect) and 0.05 < float(expect) < 50
+
     # weight-tuning switches: warned about, or refused
     with pytest.warns(UserWarning, match="Gauss-Newton"):
         DepthOptimizer(dict(OPTIONS, optimize_depth_encoder=True), _config(B, iters), pose_model, depth_model, "09_02")
