@@ -106,9 +106,12 @@ class Engine:
     def dev(self) -> torch.device:
         return torch.device("cuda", self.device)
 
-    @staticmethod
-    def _p(t: Optional[torch.Tensor]):
-        return None if t is None else C.c_void_p(t.data_ptr())
+    def _p(self, t: Optional[torch.Tensor]):
+        if t is None:
+            return None
+        if t.device.index != self.device:   # a pointer from another GPU would fault inside the kernel: refuse it here
+            raise ValueError(f"tensor lives on {t.device}, this Engine was created for cuda:{self.device}")
+        return C.c_void_p(t.data_ptr())
 
     # -- reference-function drop-ins -----------------------------------------------------------
     def disp_to_depth(self, disp: torch.Tensor, min_depth: float, max_depth: float):
