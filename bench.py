@@ -67,9 +67,26 @@ def cpu_baseline(seconds: float):
         t.join()
     dt = time.perf_counter() - t0
     done = sum(counts)
-    return {"value": done / dt, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{done} windows x (fwd+inv pair) x {ITERS} GN iterations at {W}x{H}, float64 scalar C oracle, "
-                      f"{cores} threads (one window each at a time), {dt:.1f} s"}
+    out = {"value": done / dt, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+           "sample": f"{done} windows x (fwd+inv pair) x {ITERS} GN iterations at {W}x{H}, float64 scalar C oracle, "
+                     f"{cores} threads (one window each at a time), {dt:.1f} s"}
+    # the reference's OWN style of optimisation step -- autograd through the PyTorch residual + Adam
+    # (oracle/torch_twin.py, a restatement pinned on the reference's golden vectors) -- on the same window and cores
+    try:
+        import torch
+        from oracle import torch_twin
+        b = batches[0]
+        T = lambda a: torch.tensor(a, dtype=torch.float32)
+        sig = lambda d: T(synth.depth_to_sigmoid_disp(d.astype("float64")).astype("float32"))
+        rate, steps = torch_twin.time_adam_steps(T(b["tgt"][:1]), T(b["src"][:1]), sig(b["depth_t"][:1]), sig(b["depth_s"][:1]),
+                                                 T(b["K"][:1]), T(b["pose_init"][:1]), seconds=min(8.0, seconds), threads=cores)
+        out["reference_style"] = {"adam_steps_per_s": round(rate, 2), "pair_iters_per_s": round(2 * rate, 2),
+                                  "frame_pairs_per_s_at_20_epochs": round(rate / 20, 3), "threads": cores, "steps": steps,
+                                  "what": "PyTorch-CPU autograd + Adam step on pose and quarter-resolution disparity of one "
+                                          "window (fwd+inv pair), the reference's way of optimising (20 epochs per window)"}
+    except Exception as ex:      # the headline baseline above does not depend on this leg
+        out["reference_style"] = {"error": repr(ex)}
+    return out
 
 
 def load_pmc(key="hbm_bytes_per_linearize_launch"):

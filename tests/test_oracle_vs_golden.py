@@ -272,3 +272,35 @@ def test_window_mode_reduces_to_pair_mode(oracle64):
     pa, _, sa = oracle64.refine_window(g["target"], g["sources"], d_t, d_s, g["K"], g["first"], o, argmin=True)
     assert np.all(sa[:S * B, 0, 2] < sw[:S * B, 0, 2]) and _maxabs(pa[S * B:], pw[S * B:]) == 0
     assert _maxabs(pa[:S * B], pw[:S * B]) > 1e-7
+
+
+def test_torch_twin_vs_reference_golden():
+    """oracle/torch_twin.py (the reference-style Adam/autograd step that bench.py times on the host cores) against the
+    reference's own float64 outputs: maps, cost and autograd gradient (goldens G1-G3, G6)"""
+    import torch
+    from oracle import torch_twin as tw
+    g = load_golden("s24x40")
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    tgt, src, dt, ds, K = T(g["tgt"])[None], T(g["src"])[None], T(g["depth_t"])[None, None], T(g["depth_s"])[None, None], T(g["K"])[None]
+    for k in range(len(g["poses"])):
+        pose = T(g["poses"][k])[None].clone().requires_grad_()
+        rec, valid, pd, cd = tw.warp(src, dt, ds, -pose, K)
+        assert _maxabs(rec[0].detach(), g["f64_rec"][k]) < 1e-10 and np.array_equal(valid[0, 0].numpy(), g["f64_valid"][k])
+        assert _maxabs(pd[0, 0].detach(), g["f64_proj_depth"][k]) < 1e-10 and _maxabs(cd[0, 0].detach(), g["f64_comp_depth"][k]) < 1e-10
+        r = tw.photometric(tgt, src, dt, ds, pose, K)
+        assert _maxabs(r["diff"][0, 0].detach(), g["f64_diff"][k]) < 1e-10 and _maxabs(r["weight"][0, 0].detach(), g["f64_weight"][k]) < 1e-10
+        assert np.array_equal(r["mask"][0, 0].numpy(), g["f64_mask"][k])
+        if float(r["mask"].sum()) > 0:
+            c = tw.masked_cost(r)
+            assert abs(float(c.detach()) - float(g["f64_cost"][k])) < 1e-12
+            c.backward()
+            assert _maxabs(pose.grad[0], g["f64_grad_pose"][k]) < 1e-10 * max(1.0, np.abs(g["f64_grad_pose"][k]).max())
+    assert _maxabs(tw.ssim(tgt, src)[0], g["f64_ssim_ts"]) < 1e-12
+    # and the timed step runs: two steps on a tiny window
+    from tightly_coupled_sfm_amd import synth
+    p = synth.make_pair(24, 40, seed=3)
+    F32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+    sig = lambda d: F32(synth.depth_to_sigmoid_disp(d.astype(np.float64)))[None, None]
+    rate, steps = tw.time_adam_steps(F32(p["tgt"])[None], F32(p["src"])[None], sig(p["depth_t"]), sig(p["depth_s"]), F32(p["K"])[None],
+                                     F32(synth.perturb_pose(p["pose_gt"], 3))[None], seconds=0.05, threads=1)
+    assert steps >= 1 and rate > 0
