@@ -114,3 +114,29 @@ def test_header_is_c99_and_a_plain_c_program_links(lib, tmp_path):
         pytest.skip("GPU present: the run itself is covered by tests/test_gpu_parity.py::test_plain_c_caller")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "tcsfm_create" in r.stderr
+
+
+def test_liegroups_stand_in(lib, oracle64):
+    """the SE3 / SO3 slice of liegroups the reference uses, on the library's own SE(3) routines (parity unpinned: checked for
+    self-consistency and against the oracle's independent closed forms)"""
+    from tightly_coupled_sfm_amd.liegroups import SE3, SO3
+    rng = np.random.default_rng(3)
+    for scale in (1e-9, 1e-4, 0.3, 2.5):
+        xi = rng.normal(size=6) * np.array([1, 1, 1, scale, scale, scale])
+        T = SE3.exp(xi)
+        assert np.allclose(T.log(), xi, atol=1e-9) and np.allclose(T.as_matrix()[:3], oracle64.se3_exp(xi).reshape(3, 4), atol=1e-12)
+        assert np.allclose(T.dot(T.inv()).as_matrix(), np.eye(4), atol=1e-12)
+        assert np.allclose(T.rot.as_matrix() @ T.rot.as_matrix().T, np.eye(3), atol=1e-12)
+        U = SE3.exp(rng.normal(size=6) * 0.2)
+        assert np.allclose(T.dot(U).as_matrix(), T.as_matrix() @ U.as_matrix(), atol=1e-12)
+        p = rng.normal(size=(5, 3))
+        assert np.allclose(T.dot(p), p @ T.as_matrix()[:3, :3].T + T.trans, atol=1e-12) and np.allclose(T.dot(p[0]), T.dot(p)[0])
+        assert np.allclose(SO3.exp(xi[3:]).as_matrix(), T.rot.as_matrix(), atol=1e-12) and np.allclose(SO3.exp(xi[3:]).log(), xi[3:], atol=1e-9)
+    noisy = SE3.exp([0.1, 0.2, 0.3, 0.2, -0.1, 0.05]).as_matrix()
+    noisy[:3, :3] += 1e-3 * rng.normal(size=(3, 3))
+    R = SE3.from_matrix(noisy, normalize=True).rot.as_matrix()
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+    # the way the reference builds its pose vectors (kitti_loader_stereo.py:135-147): log of the relative transform
+    A, B = SE3.exp([0.5, 0, 2.0, 0, 0.1, 0]), SE3.exp([0.6, 0.05, 3.0, 0.01, 0.12, 0])
+    rel = A.inv().dot(B)
+    assert np.allclose(SE3.exp(rel.log()).as_matrix(), rel.as_matrix(), atol=1e-12)
