@@ -32,3 +32,26 @@ def test_metrics_properties():
     scaled = poses.copy(); scaled[:, :3] *= 1.05          # 5 % translation scale error -> ~5 % segment error, no rotation error
     _, _, errs, _ = compute_trajectory(scaled, gt, compute_seg_err=True)
     assert 3.5 < errs[2] < 5.5 and errs[3] < 0.02 and errs[0] > 1.0      # (curved path: chord error < arc-length scale error)
+
+
+def test_reference_style_trajectory_code_runs_on_the_stand_ins():
+    """the body of the reference's compute_trajectory (validate.py:61-91) written against liegroups.SE3 and
+    pyslam TrajectoryMetrics, executed with this package's stand-ins for both absent dependencies"""
+    from tightly_coupled_sfm_amd.liegroups import SE3
+    from tightly_coupled_sfm_amd.trajectory import TrajectoryMetrics, compute_trajectory
+    rng = np.random.default_rng(1)
+    rel = np.array([0.0, 0.0, 1.0, 0.0, 0.01, 0.0]) + 0.01 * rng.normal(size=(60, 6))
+    gt = [np.eye(4)]
+    for p in rel:
+        gt.append(SE3.as_matrix((SE3.exp(p).dot(SE3.from_matrix(gt[-1], normalize=True).inv())).inv()))
+    noisy = rel + 0.002 * rng.normal(size=rel.shape)
+    est = [gt[0]]
+    for p in noisy:                                                        # validate.py:64-68, verbatim structure
+        dT = SE3.exp(p)
+        est.append(SE3.as_matrix((dT.dot(SE3.from_matrix(est[-1], normalize=True).inv())).inv()))
+    tm = TrajectoryMetrics([SE3.from_matrix(T, normalize=True) for T in gt], [SE3.from_matrix(T, normalize=True) for T in est], convention="Twv")
+    mt, mr = tm.mean_err()
+    _, seg = tm.segment_errors([10, 20, 30], rot_unit="rad")
+    assert mt > 0 and mr > 0 and seg.shape == (3, 3) and np.all(seg[:, 1] < 0.05)
+    e2, g2, errors, cum = compute_trajectory(noisy, np.array(gt))
+    assert np.allclose(e2, np.array(est), atol=1e-12) and abs(errors[0] - round(float(mt), 3)) < 1e-9

@@ -79,3 +79,27 @@ def compute_trajectory(pose_vec, gt_traj, method="odom", compute_seg_err=False, 
     if verbose:
         print(f"{method} mean trans. error: {mt} | mean rot. error: {mr}")
     return est, np.array(gt_traj), (mt, mr, ts, rs), cum
+
+
+class TrajectoryMetrics:
+    """Stand-in for pyslam.metrics.TrajectoryMetrics as validate.py:73-91 uses it (absent, unpinned third-party dependency:
+    PARITY UNPINNED, standard definitions -- see the module docstring).  Trajectories: lists of SE3 objects (anything with
+    `.as_matrix()`) or of 4x4 / 3x4 matrices, camera-to-world ('Twv')."""
+
+    def __init__(self, poses_gt, poses_est, convention="Twv"):
+        if convention != "Twv":
+            raise NotImplementedError("the reference only uses convention='Twv' (validate.py:73)")
+        mat = lambda T: _T4(np.asarray(T.as_matrix() if hasattr(T, "as_matrix") else T, dtype=np.float64)[:3])
+        self.gt, self.est = np.array([mat(T) for T in poses_gt]), np.array([mat(T) for T in poses_est])
+
+    def mean_err(self):
+        """-> (mean translational error, mean rotational error [rad])"""
+        t, r = mean_err(self.gt, self.est)
+        return np.float64(t), np.float64(r)
+
+    def segment_errors(self, segment_lengths, rot_unit="rad"):
+        """-> (per-length rows, array [n_lengths, 3] = (length, translational error / length, rotational error / length))"""
+        rows = segment_errors(self.gt, self.est, list(segment_lengths))
+        if rot_unit == "deg":
+            rows = rows.copy(); rows[:, 2] *= 180.0 / np.pi
+        return rows, rows
