@@ -23,6 +23,9 @@ Goldens (SURVEY.md section 8c naming):
   G9 one DepthOptimizer.optimize_window (optimize_depth_pred, 5 epochs, stand-in nets): result-dict schema + the values
      that do not depend on the optimiser (initial poses, depths, flip-averaged disparity)   optimizer.py:136-297
   G10 ScaleRecovery                                                   models/dnet_layers.py:249-327
+  G11 validate.compute_trajectory run on this package's stand-ins for the absent liegroups / pyslam (pins the
+      composition order, the error bookkeeping and the rounding of the reference code; the SE(3) and metric arithmetic
+      itself stays unpinned)                                          validate.py:61-103
 """
 import os
 import sys
@@ -66,11 +69,13 @@ def import_reference():
     import warnings
     warnings.simplefilter("ignore")
     import helpers, losses, train_mono, optimizer, plot_loss_surface  # noqa
+    sys.path.insert(0, REF)
+    import validate  # noqa
     from models import stn
     from utils import learning_helpers
     os.chdir(cwd)
     return dict(helpers=helpers, losses=losses, train_mono=train_mono, optimizer=optimizer,
-                plot_loss_surface=plot_loss_surface, stn=stn, learning_helpers=learning_helpers)
+                plot_loss_surface=plot_loss_surface, stn=stn, learning_helpers=learning_helpers, validate=validate)
 
 
 def main():
@@ -306,6 +311,22 @@ def main():
             schema.append(f"{k}|tensor|{tuple(v.shape)}|{str(v.dtype)}|{v.device.type}"); g9[f"out_{k}"] = N(v)
     g9["schema"] = np.array(schema)
     out["window48x160"] = g9
+
+    # ------------------------------------------------------------------ G11: the reference's compute_trajectory on the stand-ins
+    from tightly_coupled_sfm_amd.liegroups import SE3 as MySE3
+    from tightly_coupled_sfm_amd.trajectory import TrajectoryMetrics as MyTM
+    val = ref["validate"]
+    val.SE3, val.TrajectoryMetrics = MySE3, MyTM
+    rng = np.random.default_rng(11)
+    rel = np.array([0.0, 0.0, 1.0, 0.0, 0.01, 0.0]) + 0.02 * rng.normal(size=(400, 6)) * np.array([1, 1, 1, 0.3, 0.3, 0.3])
+    gt = [np.eye(4)]
+    for q in rel:
+        gt.append(MySE3.exp(q).dot(MySE3.from_matrix(gt[-1]).inv()).inv().as_matrix())
+    noisy = rel + 0.004 * rng.normal(size=rel.shape) * np.array([1, 1, 1, 0.2, 0.2, 0.2])
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        est, gt_out, errors, cum = val.compute_trajectory(noisy, np.array(gt), method="odom", compute_seg_err=True)
+    out["traj400"] = dict(pose_vec=noisy, gt_traj=np.array(gt), est_traj=est, errors=np.array(errors, dtype=np.float64), cum_dist=cum)
 
     # ------------------------------------------------------------------ full-size summary (192x640, f32 as run by the reference)
     H, W, seed = 192, 640, 0

@@ -55,3 +55,15 @@ def test_reference_style_trajectory_code_runs_on_the_stand_ins():
     assert mt > 0 and mr > 0 and seg.shape == (3, 3) and np.all(seg[:, 1] < 0.05)
     e2, g2, errors, cum = compute_trajectory(noisy, np.array(gt))
     assert np.allclose(e2, np.array(est), atol=1e-12) and abs(errors[0] - round(float(mt), 3)) < 1e-9
+
+
+def test_compute_trajectory_vs_reference_code_G11():
+    """golden G11: the REFERENCE's validate.compute_trajectory (validate.py:61-103), executed with this package's SE3 /
+    TrajectoryMetrics stand-ins in place of the absent liegroups / pyslam: same composition, errors and rounding"""
+    from conftest import load_golden
+    from tightly_coupled_sfm_amd.trajectory import compute_trajectory
+    g = load_golden("traj400")
+    est, gt, errors, cum = compute_trajectory(g["pose_vec"], g["gt_traj"], compute_seg_err=True)
+    assert np.allclose(est, g["est_traj"], atol=1e-12) and np.allclose(cum, g["cum_dist"], atol=1e-12)
+    assert np.allclose(np.array(errors, dtype=np.float64), g["errors"], atol=1e-9)
+    assert g["errors"][2] > 0 and g["errors"][3] > 0          # the 100..800-unit segment errors were actually evaluated
