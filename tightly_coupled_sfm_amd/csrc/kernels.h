@@ -779,20 +779,30 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 
         // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances) + gradient window
         // sums.  Rolled (one neighbour live at a time); 14 packed instructions per neighbour.
-        f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f};
-        f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f}, G2 = {0.f, 0.f};
-        float Sxy2 = 0.f;
-        // neighbour pointer walks the 3x3 window with ONE vector add per step (the step is wave-uniform)
+        // neighbour pointer walks the 3x3 window with ONE vector add per step (the step is wave-uniform).  The first neighbour
+        // is peeled: it INITIALISES the 21 accumulators (no zero-fill instructions), the loop adds the other eight.
         const float4 *nbA = ctr - (CW + 1) * (LDS_REC / 4);
+        f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, Gx01, Gy01, S2, SS2, G2;
+        float Sxy2;
+        {
+            f32x4 n0, n1, n2;
+            lds_read3v(nbA, n0, n1, n2);
+            nbA += LDS_REC / 4;
+            Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
+            Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
+            Gx01 = n1.lo; Gy01 = n1.hi;
+            S2 = pk_sub(n2.lo, yx2c);            // (y2 - y2c, x2 - x2c)
+            SS2 = S2 * S2; Sxy2 = S2.x * S2.y; G2 = n2.hi;
+        }
 #pragma unroll 1
-        for (int kk = 0; kk < 9; kk++) {
+        for (int kk = 1; kk < 9; kk++) {
             f32x4 n0, n1, n2;
             lds_read3v(nbA, n0, n1, n2);
             nbA += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
             f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
             Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
             Gx01 += n1.lo; Gy01 += n1.hi;
-            f2 e2v = pk_sub(n2.lo, yx2c);        // (y2 - y2c, x2 - x2c)
+            f2 e2v = pk_sub(n2.lo, yx2c);
             S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
         }
         // per-channel SSIM value / gradient coefficients / curvature weights and the L1 term: channels (0,1) as one packed
