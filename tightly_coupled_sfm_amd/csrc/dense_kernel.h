@@ -143,12 +143,21 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
         float4 ax = lds_read1(aux + (ly + 1) * W2 + lx + 1);
         // window statistics, packed exactly as pass A of k_linearize
-        f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f};
-        f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f}, G2 = {0.f, 0.f};
-        float Sxy2 = 0.f;
+        f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, Gx01, Gy01, S2, SS2, G2;
+        float Sxy2;
         const float4 *nbA = ctr - (W2 + 1) * 3;
+        {   // first neighbour initialises the accumulators (as in k_linearize)
+            f32x4 n0, n1, n2;
+            lds_read3v(nbA, n0, n1, n2);
+            nbA += 3;
+            Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
+            Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
+            Gx01 = n1.lo; Gy01 = n1.hi;
+            S2 = pk_sub(n2.lo, yx2c);
+            SS2 = S2 * S2; Sxy2 = S2.x * S2.y; G2 = n2.hi;
+        }
 #pragma unroll 1
-        for (int kk = 0; kk < 9; kk++) {
+        for (int kk = 1; kk < 9; kk++) {
             f32x4 n0, n1, n2;
             lds_read3v(nbA, n0, n1, n2);
             nbA += (kk == 2 || kk == 5) ? (W2 - 2) * 3 : 3;
