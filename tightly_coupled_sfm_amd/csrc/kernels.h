@@ -529,6 +529,10 @@ __device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ void lds_read02v(const float4 *p, f32x4 &a, f32x4 &c) {   // record floats 0..3 and 8..11
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
 __device__ __forceinline__ void lds_read6v(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f) {  // floats 0..23
     asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
                  "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\ts_waitcnt lgkmcnt(0)"
@@ -780,30 +784,30 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances) + gradient window
         // sums.  Rolled (one neighbour live at a time); 14 packed instructions per neighbour.
         // neighbour pointer walks the 3x3 window with ONE vector add per step (the step is wave-uniform).  The first neighbour
-        // is peeled: it INITIALISES the 21 accumulators (no zero-fill instructions), the loop adds the other eight.
+        // is peeled: it INITIALISES the accumulators (no zero-fill instructions), the loop adds the other eight.  Only the
+        // colour part of the records is read here (32 of their 112 bytes): the neighbour passes are LDS-bandwidth limited, and
+        // the gradient window sums the curvature needs are gathered in pass B, which reads the gradients anyway.
         const float4 *nbA = ctr - (CW + 1) * (LDS_REC / 4);
-        f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, Gx01, Gy01, S2, SS2, G2;
+        f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, S2, SS2;
         float Sxy2;
         {
-            f32x4 n0, n1, n2;
-            lds_read3v(nbA, n0, n1, n2);
+            f32x4 n0, n2;
+            lds_read02v(nbA, n0, n2);
             nbA += LDS_REC / 4;
             Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
             Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
-            Gx01 = n1.lo; Gy01 = n1.hi;
             S2 = pk_sub(n2.lo, yx2c);            // (y2 - y2c, x2 - x2c)
-            SS2 = S2 * S2; Sxy2 = S2.x * S2.y; G2 = n2.hi;
+            SS2 = S2 * S2; Sxy2 = S2.x * S2.y;
         }
 #pragma unroll 1
         for (int kk = 1; kk < 9; kk++) {
-            f32x4 n0, n1, n2;
-            lds_read3v(nbA, n0, n1, n2);
+            f32x4 n0, n2;
+            lds_read02v(nbA, n0, n2);
             nbA += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
             f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
             Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
-            Gx01 += n1.lo; Gy01 += n1.hi;
             f2 e2v = pk_sub(n2.lo, yx2c);
-            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
+            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
         }
         // per-channel SSIM value / gradient coefficients / curvature weights and the L1 term: channels (0,1) as one packed
         // evaluation, channel 2 as a scalar one (same code, ssim_l1_channel<T>)
@@ -822,11 +826,13 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         if (MODE == MODE_LIN) {
             // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
             const f2 cA01 = {cA[0], cA[1]}, cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
+            f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, G2 = {0.f, 0.f};   // 3x3 sums of the image gradients (curvature model)
             const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
                 f32x4 n0, n1, n2, n3, n4, n5;
                 lds_read6v(nb, n0, n1, n2, n3, n4, n5);   // one LDS round trip per neighbour
+                Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
                 f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
                 f2 cf = cA01 + cB01 * ey + cC01 * ex;
                 f2 e2v = pk_sub(n2.lo, yx2c);
