@@ -166,6 +166,15 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
                        const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
                        float *stats_out);
 
+/* Window form of tcsfm_refine_dense (the `optimize_depth_pred` mode of optimize_window with its default options,
+ * optimizer.py:194-198 + 47-69): B targets x S sources given once as in tcsfm_refine_window; every one of the 2*S*B directed
+ * pairs refines its pose and ITS OWN copy of its target's depth (forward pairs: one copy of target b's depth per source,
+ * inverse pairs: the depth of source (s,b)); depth_out [2*S*B,1,H,W] in the stacked pair order.  With o->argmin and S > 1
+ * the forward pairs use the per-pixel min over the sources, evaluated at the current poses and depth copies. */
+int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                              const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                              float *depth_out, float *stats_out);
+
 /* ScaleRecovery.forward, models/dnet_layers.py:249-327 (the step right after the path in optimize_window,
  * optimizer.py:254-258): camera-height map |P.n| from 8-neighbour surface normals, ground mask, exact lower median of the
  * masked heights over the batch, scale = real_cam_height / median.  pad_to_batch mirrors the reference's padding of a short

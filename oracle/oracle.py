@@ -187,6 +187,22 @@ class Oracle:
                                   self._p(pose), self._p(stats))
         return pose, depth, stats
 
+    def refine_dense_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, lambda_depth=1.0, w_prior=10.0,
+                            min_depth=0.06, max_depth=2.67):
+        """dense window mode: tgt [B,3,H,W], srcs [S,B,3,H,W], depth_t [B,H,W], depth_s [S,B,H,W], poses [2SB,6] ->
+        (poses [2SB,6], refined target depth of every directed pair [2SB,H,W], stats [2SB,n_iters+1,4])"""
+        opts = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K = map(self._r, (tgt, srcs, depth_t, depth_s, K))
+        S, B, _, H, W = srcs.shape
+        dt_pairs = np.ascontiguousarray(np.concatenate([np.tile(depth_t, (S, 1, 1)), depth_s.reshape(S * B, H, W)]))   # own target depth
+        ds_pairs = np.ascontiguousarray(np.concatenate([depth_s.reshape(S * B, H, W), np.tile(depth_t, (S, 1, 1))]))   # source depth
+        pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(2 * S * B, 6)).copy()
+        stats = np.zeros((2 * S * B, opts.n_iters + 1, 4))
+        self.lib.orc_refine_dense_window(H, W, B, S, self._p(tgt), self._p(srcs), self._p(dt_pairs), self._p(ds_pairs), self._p(K),
+                                         C.byref(opts), int(bool(argmin)), C.c_double(lambda_depth), C.c_double(w_prior),
+                                         C.c_double(min_depth), C.c_double(max_depth), self._p(pose), self._p(stats))
+        return pose, dt_pairs, stats
+
     def ground_height(self, depth, K):
         """DNet camera-height map and ground mask of one image (dnet_layers.py:259-304,319-322)"""
         depth, K = self._r(depth), self._r(K)

@@ -871,9 +871,9 @@ void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *
  *     (S + lambda diag S) dxi = -gs ;  drho_p = -(g_rho_p + B_p' dxi) / Dd_p ;  rho clamped to [1/max_depth, 1/min_depth]
  * Outputs of one linearisation: S (6x6), gs (6), cost, n_mask and the per-pixel g_rho, D, B (H*W x 6).
  */
-void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
-                         const double T[12], const real *K, const orc_opts *op, const real *auto_err_in, double lambda_depth,
-                         double w_prior, const real *depth0, lin_t *out, double *g_rho, double *Dq, double *Bq) {
+static void linearize_dense_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                         const double T[12], const real *K, const orc_opts *op, const real *auto_err_in, const real *mask_in,
+                         double lambda_depth, double w_prior, const real *depth0, lin_t *out, double *g_rho, double *Dq, double *Bq) {
     int n = H * W;
     const int np = 7; /* column 6 of the per-pixel Jacobians is re-purposed as the inverse-depth column */
     cam_t c;
@@ -917,6 +917,7 @@ void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const r
             diffm[i] = e; Wm[i] = 1 - clamp01(raw);
             real m = (real)P->valid;
             if (op->automask) m *= (e < ae[i]) ? (real)1 : (real)0;
+            if (mask_in) m = mask_in[i];   /* window mode: min-over-sources selection */
             M[i] = m; nmask += m; num += (double)m * Wm[i] * e;
         }
     /* pass 2: exact gradient by scattering every residual's derivative onto the pixels of its window */
@@ -1012,6 +1013,86 @@ void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const r
 }
 
 /* GN refinement of pose + per-pixel inverse depth (dense BA with per-pixel Schur elimination); depth_io in/out */
+void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                         const double T[12], const real *K, const orc_opts *op, const real *auto_err_in, double lambda_depth,
+                         double w_prior, const real *depth0, lin_t *out, double *g_rho, double *Dq, double *Bq) {
+    linearize_dense_masked(H, W, tgt, src, depth_t, depth_s, T, K, op, auto_err_in, NULL, lambda_depth, w_prior, depth0, out, g_rho, Dq, Bq);
+}
+
+/*
+ * Dense window mode: the 2 S B directed pairs of a window (stacked order as in orc_refine_window), each refining its pose
+ * and ITS OWN copy of its target's depth (forward pairs: a copy of target b's depth per source; inverse pairs: source
+ * (s,b)'s depth), Gauss-Newton only.  With argmin the forward pairs of a target use the min-over-sources selection,
+ * evaluated at every linearisation at the pairs' current poses AND current depth copies.
+ * depth_io [2SB][H*W]: in = initial target depth of every pair, out = refined.  depth_src [2SB][H*W]: the (fixed) source depths.
+ */
+void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_src,
+                             const real *K, const orc_opts *op, int argmin, double lambda_depth, double w_prior, double min_depth,
+                             double max_depth, double *pose_io /* [2SB][6] */, double *stats /* [2SB][n_iters+1][4] or NULL */) {
+    const int n = H * W, SB = S * B, N = 2 * SB, sel = argmin && S > 1;
+    real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *d0 = (real *)malloc(sizeof(real) * (size_t)n * N);
+    real *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
+    real *diff = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL, *valid = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL;
+    double *Tc = (double *)malloc(sizeof(double) * 12 * N);
+    double *gr = (double *)malloc(sizeof(double) * n), *Dq = (double *)malloc(sizeof(double) * n), *Bq = (double *)malloc(sizeof(double) * n * 6);
+    const real **img = (const real **)malloc(sizeof(real *) * N * 2);
+    memcpy(d0, depth_io, sizeof(real) * (size_t)n * N);
+    for (int m = 0; m < N; m++) {
+        int inv = m >= SB, q = inv ? m - SB : m, b = q % B;
+        const real *ti = tgt + (size_t)b * 3 * n, *si = srcs + (size_t)q * 3 * n;
+        img[2 * m] = inv ? si : ti; img[2 * m + 1] = inv ? ti : si;
+        photo_err_map(H, W, img[2 * m], img[2 * m + 1], op->w_l1, op->w_ssim, ae + (size_t)m * n);
+        orc_pose_to_T(pose_io + 6 * m, Tc + 12 * m);
+    }
+    for (int it = 0; it < op->n_iters; it++) {
+        if (sel)
+            for (int b = 0; b < B; b++) {
+                for (int s = 0; s < S; s++) {
+                    int m = s * B + b;
+                    orc_photometric(H, W, img[2 * m], img[2 * m + 1], depth_io + (size_t)m * n, depth_src + (size_t)m * n, Tc + 12 * m, K + 9 * b, 0.0,
+                                    op->w_l1, op->w_ssim, diff + (size_t)s * n, valid + (size_t)s * n, NULL, NULL, NULL, NULL);
+                }
+                for (int i = 0; i < n; i++) {
+                    int smin = 0;
+                    real dmin = diff[i], amin = ae[(size_t)b * n + i], vany = valid[i];
+                    for (int s = 1; s < S; s++) {
+                        if (diff[(size_t)s * n + i] < dmin) { dmin = diff[(size_t)s * n + i]; smin = s; }
+                        real a = ae[(size_t)(s * B + b) * n + i];
+                        if (a < amin) amin = a;
+                        if (valid[(size_t)s * n + i] > vany) vany = valid[(size_t)s * n + i];
+                    }
+                    int keep = vany > 0 && (!op->automask || dmin < amin);
+                    for (int s = 0; s < S; s++) mask[(size_t)(s * B + b) * n + i] = (keep && s == smin) ? 1 : 0;
+                }
+            }
+        for (int m = 0; m < N; m++) {
+            const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
+            real *dep = depth_io + (size_t)m * n;
+            lin_t L;
+            linearize_dense_masked(H, W, img[2 * m], img[2 * m + 1], dep, depth_src + (size_t)m * n, Tc + 12 * m, Km, op, ae + (size_t)m * n,
+                                   (sel && m < SB) ? mask + (size_t)m * n : NULL, lambda_depth, w_prior, d0 + (size_t)m * n, &L, gr, Dq, Bq);
+            if (stats) { double *st = stats + ((size_t)m * (op->n_iters + 1) + it) * 4; st[0] = L.cost; st[1] = L.cost_photo; st[2] = L.n_mask; st[3] = op->lambda0; }
+            double delta[6], E[12], Tn[12];
+            orc_solve_step(6, L.H, L.g, op->lambda0, delta);
+            orc_se3_exp(delta, E);
+            orc_se3_mul(E, Tc + 12 * m, Tn);
+            memcpy(Tc + 12 * m, Tn, sizeof(Tn));
+            for (int i = 0; i < n; i++) {
+                double Dd = (1.0 + lambda_depth) * Dq[i];
+                if (!(Dd > 1e-30)) continue;
+                double bd = 0;
+                for (int j = 0; j < 6; j++) bd += Bq[i * 6 + j] * delta[j];
+                double rho = 1.0 / (double)dep[i] - (gr[i] + bd) / Dd;
+                double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
+                rho = rho < lo ? lo : (rho > hi ? hi : rho);
+                dep[i] = (real)(1.0 / rho);
+            }
+        }
+    }
+    for (int m = 0; m < N; m++) orc_T_to_pose(Tc + 12 * m, pose_io + 6 * m);
+    free(ae); free(d0); free(mask); free(diff); free(valid); free(Tc); free(gr); free(Dq); free(Bq); free(img);
+}
+
 void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
                       const orc_opts *op, double lambda_depth, double w_prior, double min_depth, double max_depth,
                       double pose_io[6], double *stats) {

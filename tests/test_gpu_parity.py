@@ -731,3 +731,34 @@ def test_reference_named_drop_ins_vs_goldens():
 def _pose_T(pose):
     from tightly_coupled_sfm_amd import synth
     return synth.pose_to_T(pose)
+
+
+def test_dense_window_mode_vs_oracle(oracle64):
+    """dense mode in window form (B targets x S sources, every directed pair refines its own copy of its target's depth), with
+    and without the min over the sources, against the float64 oracle"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    B, S, H, W = 1, 2, 96, 320
+    w = _window(B, S, H, W)
+    e = _eng(H, W, 2 * S * B)
+    tg, sr, dt, ds, K, p0 = (_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first"))
+    o = default_opts(n_iters=3, w_dc=0.0, min_depth=0.06, max_depth=2.67)
+    # without the selection it is the pair form on the stacked tensors
+    pw, dw, _ = e.refine_dense_window(tg, sr, dt, ds, K, p0, o, argmin=False)
+    T = tg.repeat(S, 1, 1, 1); Sx = sr.reshape(S * B, 3, H, W); Dt = dt.repeat(S, 1, 1, 1); Ds = ds.reshape(S * B, 1, H, W)
+    pp, dp, _ = e.refine_dense(torch.cat([T, Sx]), torch.cat([Sx, T]), torch.cat([Dt, Ds]), torch.cat([Ds, Dt]), K.repeat(2 * S, 1, 1), p0, o)
+    assert torch.equal(pw, pp) and torch.equal(dw, dp)
+    # with it: parity with the oracle
+    pa, da, st = e.refine_dense_window(tg, sr, dt, ds, K, p0, o, argmin=True, stats=True)
+    rp, rd, rst = oracle64.refine_dense_window(w["target"], w["sources"], w["depth_t"][:, 0], w["depth_s"][:, :, 0], w["K"], w["first"],
+                                               oopts(n_iters=3), argmin=True, lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth))
+    pa, da, st = pa.cpu().numpy().astype(np.float64), da.cpu().numpy()[:, 0], st.cpu().numpy()
+    same = np.all(st[:, :3, 2] == rst[:, :3, 2], axis=1)
+    assert same.sum() >= 2 * S * B - 2 and np.max(np.abs(st[:, :3, 2] - rst[:, :3, 2])) <= 6
+    for n in range(2 * S * B):
+        tol = 1e-4 if same[n] else 3e-3                                   # see test_refine_window_argmin_vs_oracle on mask ties
+        assert np.linalg.norm(pa[n, :3] - rp[n, :3]) / np.linalg.norm(rp[n, :3]) < tol
+        assert np.linalg.norm(pa[n, 3:] - rp[n, 3:]) / np.linalg.norm(rp[n, 3:]) < tol
+        rel = np.abs(da[n] / rd[n] - 1)
+        assert np.quantile(rel, 0.999) < (1e-4 if same[n] else 3e-3), (n, rel.max())
+    assert np.all(st[:S * B, 0, 2] < 0.8 * H * W) and not np.array_equal(pa[:S * B], pw.cpu().numpy()[:S * B])

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
     "tcsfm_refine_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
     "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
+    "tcsfm_refine_dense_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),
     "tcsfm_profile_begin": (C.c_int, [_P]),

@@ -728,9 +728,10 @@ int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float
     return TCSFM_OK;
 }
 
-int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
-                       const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
-                       float *stats_out) {
+// shared body of tcsfm_refine_dense (win_B == 0) and tcsfm_refine_dense_window
+static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+                      const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                      float *depth_out, float *stats_out) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
@@ -738,19 +739,22 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
     if (o->solver != TCSFM_SOLVER_GN || o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: Gauss-Newton on the SE(3) chart only");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
     HIPCHK(h, hipSetDevice(h->device));
-    if ((rc = check_intrinsics(h, o, K, N))) return rc;
+    const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
+    if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
+    const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
+    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
     if (!h->dense_rec) {
         HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->delta, n * 8 * sizeof(double)));
     }
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose_in;
-    if ((rc = to_dev(h, o, 0, tgt, N * 3 * hw, &d_tgt))) return rc;
-    if ((rc = to_dev(h, o, 1, src, N * 3 * hw, &d_src))) return rc;
-    if ((rc = to_dev(h, o, 2, depth_t, N * hw, &d_dt))) return rc;
-    if ((rc = to_dev(h, o, 3, depth_s, N * hw, &d_ds))) return rc;
-    if ((rc = to_dev(h, o, 4, K, (size_t)N * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 0, tgt, nimg_t * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, src, nimg_s * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, nimg_t * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, nimg_s * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)nimg_t * 9, &d_K))) return rc;
     if ((rc = to_dev(h, o, 5, pose_in, (size_t)N * 6, &d_pose_in))) return rc;
     float *d_pose_out, *d_depth_out, *d_stats = nullptr;
     if ((rc = out_dev(h, o, 7, pose_out, (size_t)N * 6, &d_pose_out))) return rc;
@@ -763,7 +767,8 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
-    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I))) return rc;
+    I.K_mod = win_B;
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S))) return rc;   // every pair gets its OWN copy of its target's depth
     HIPCHK(h, hipMemcpyAsync(h->depth0, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     // the dense kernel's own tile grid (same 32x16 / 512 threads as k_linearize today) and reduction-group count
     constexpr int DTW = 32, DTH = 16, DNT = 512;
@@ -781,7 +786,21 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
     DenseUpdateParams U;
     U.dense_rec = h->dense_rec; U.delta = h->delta; U.depth = h->depth_work; U.hw = (int)hw;
     U.rho_lo = 1.f / o->max_depth; U.rho_hi = 1.f / o->min_depth;
+    // min over the sources (window form): selection masks of the forward pairs from their residual maps at the current poses
+    // AND current depth copies, rebuilt before every linearisation (same two launches as in the pose mode)
+    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
+          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
+    if (n_sel) { P.ext_mask = sel_mask; P.n_ext = n_sel; }
     for (int it = 0; it < o->n_iters; it++) {
+        if (n_sel) {
+            LinParams M = lin_params(h, &oo, 6);
+            M.o_diff = sel_diff; M.o_valid = sel_valid;
+            launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
+            SelectParams Q;
+            Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
+            Q.B = win_B; Q.S = win_S; Q.hw = (int)hw; Q.automask = o->automask;
+            hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), win_B), dim3(256), 0, h->stream, Q);
+        }
         {
             ProfScope prof(h, 0);
             hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
@@ -804,6 +823,20 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;
+}
+
+int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
+                       float *stats_out) {
+    return dense_impl(h, o, N, 0, 0, tgt, src, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+}
+
+int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                              const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                              float *depth_out, float *stats_out) {
+    if (!h) return TCSFM_E_ARG;
+    if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: need 1 <= 2*B*S <= max_pairs");
+    return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
 }
 
 // diagnostic: copy the k_solve phase stamps to the host (8 values; zeros unless TCSFM_DEBUG_STAMPS was set at create)

@@ -278,6 +278,31 @@ class Engine:
                                                self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out), self._p(st)))
         return pose_out, depth_out, st
 
+    def refine_dense_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, stats: bool = False,
+                            argmin: Optional[bool] = None):
+        """Dense mode in window form (see refine_window for the layout): every directed pair refines its pose and its own copy
+        of its target's depth -> (pose [2SB,6], depth [2SB,1,H,W] in the stacked pair order, stats or None)"""
+        self._bind()
+        o = opts or default_opts()
+        if argmin is not None:
+            o = _copy_opts(o); o.argmin = 1 if argmin else 0
+        if isinstance(srcs, (list, tuple)):
+            srcs = torch.stack(list(srcs), 0)
+        if isinstance(depth_s, (list, tuple)):
+            depth_s = torch.stack(list(depth_s), 0)
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        N = 2 * S * B
+        tgt = _chk(tgt, (B, 3, self.H, self.W), "tgt"); srcs = _chk(srcs, (S, B, 3, self.H, self.W), "srcs")
+        depth_t = _chk(depth_t, (B, 1, self.H, self.W), "depth_t"); depth_s = _chk(depth_s, (S, B, 1, self.H, self.W), "depth_s")
+        K = _chk(K, (B, 3, 3), "K"); pose = _chk(pose, (N, 6), "pose")
+        pose_out = torch.empty_like(pose)
+        depth_out = torch.empty((N, 1, self.H, self.W), device=pose.device, dtype=torch.float32)
+        st = torch.empty((N, o.n_iters + 1, _lib.NSTAT), device=pose.device, dtype=torch.float32) if stats else None
+        self._call(self.lib.tcsfm_refine_dense_window(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t),
+                                                      self._p(depth_s), self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out),
+                                                      self._p(st)))
+        return pose_out, depth_out, st
+
     def scale_recovery(self, depth, intrinsics, real_cam_height: float, pad_to_batch: int = 0, maps: bool = False):
         """ScaleRecovery.forward (dnet_layers.py:306-327): depth [N,1,H,W], K [N,3,3] -> scale [1] (GPU tensor)
         (+ median [1], height [N,1,H,W], mask [N,1,H,W] with maps=True)"""

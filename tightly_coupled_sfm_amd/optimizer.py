@@ -14,7 +14,9 @@ LM iterations on the reference's own residual (libtcsfm_hip.so).  New option key
     (the reference's own `diff_img_argmin`, `automasking`, `l_depth_consist(+_weight)`, `mode` keys are honoured),
     prior_depth, lambda_depth (dense mode).
 The reference's `optimize_depth_pred` switch (Adam on the disparity maps themselves, optimizer.py:194-198) selects
-refine='pose+depth' unless `refine` is given: pose + per-pixel inverse depth by Gauss-Newton with a Schur complement.
+refine='pose+depth' unless `refine` is given: pose + per-pixel inverse depth by Gauss-Newton with a Schur complement
+(window form: every directed pair refines its own copy of its target's depth; the target frame's copies are fused by averaging
+inverse depths; `diff_img_argmin` is honoured there too).
 Its weight-tuning switches (optimize_depth_encoder, ...) need autograd through the networks, which is out of scope:
 they are ignored with a warning, or refused when options['strict_legacy'] is set.
 """
@@ -172,7 +174,9 @@ class DepthOptimizer:
         tgt = stack_imgs[:, 0:3].contiguous(); src = stack_imgs[:, 3:6].contiguous()
         dense = self._refine_mode() == "pose+depth"
         if dense:
-            pose, depth_ref, stats = eng.refine_dense(tgt, src, d_t, d_s, K.contiguous(), pose0, opts, stats=True)
+            pose, depth_ref, stats = eng.refine_dense_window(
+                target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
+                intrinsics.float(), pose0, opts, stats=True, argmin=bool(self.options.get("diff_img_argmin", True)))
             log_scale = None
         else:
             # window form: the library forms the fwd / inv pairs itself; per-pixel min over the sources as the reference's loss
