@@ -60,6 +60,15 @@ def run_host(steps=200, warm=20):
     mb = sum(host[k].nbytes for k in ("tgt", "src", "depth_t", "depth_s")) / 1e6
     print(json.dumps({"config": "#2 B=1 pose, HOST pointers (PCIe-inclusive, synchronous, pageable memory)", "us_per_call": round(dt * 1e6, 1),
                       "windows_per_s": round(1 / dt, 1), "MB_in_per_call": round(mb, 2)}))
+    # the same with PINNED host arrays (what a caller who cares would hand over)
+    pinned = {k: torch.from_numpy(v).pin_memory() for k, v in host.items()}
+    host = {k: v.numpy() for k, v in pinned.items()}
+    outp = torch.zeros((npairs, 6)).pin_memory(); out = outp.numpy()
+    for _ in range(warm): step()
+    t0 = time.perf_counter()
+    for _ in range(steps): step()
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": "#2 B=1 pose, HOST pointers, pinned memory", "us_per_call": round(dt * 1e6, 1), "windows_per_s": round(1 / dt, 1)}))
 
 run_host()
 
