@@ -122,6 +122,13 @@ def test_tuple_form_dense_mode_and_legacy_switches():
     assert r["scale_factor"].device.type == "cpu" and tuple(r["scale_factor"].shape) == (1,)
     assert abs(float(r["scale_factor"]) - float(expect)) < 1e-6 * float(expect) and 0.05 < float(expect) < 50
 
+    # l_inverse_reconstruction = False: the inverse direction is not optimised (optimizer.py:74-79); unsupported loss terms warn
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    r = DepthOptimizer(dict(OPTIONS, l_inverse_reconstruction=False), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)
+    assert torch.equal(r["poses_inv_opt"], r["poses_inv_init"]) and not torch.equal(r["poses_opt"], r["poses_init"])
+    with pytest.warns(UserWarning, match="l_smooth"):
+        DepthOptimizer(dict(OPTIONS, l_smooth=True), _config(B, iters), pose_model, depth_model, "09_02")
+
     # weight-tuning switches: warned about, or refused
     with pytest.warns(UserWarning, match="Gauss-Newton"):
         DepthOptimizer(dict(OPTIONS, optimize_depth_encoder=True), _config(B, iters), pose_model, depth_model, "09_02")

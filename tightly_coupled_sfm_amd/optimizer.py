@@ -83,6 +83,10 @@ class DepthOptimizer:
             if options.get("strict_legacy", False):
                 raise NotImplementedError(msg)
             warnings.warn(msg)
+        ignored = [k for k in ("l_smooth", "l_pose_consist") if options.get(k, False)]
+        if ignored:   # off by default in the reference (run_sequential_optimization.py:87,89); not part of the per-pair GN cost
+            warnings.warn(f"options {ignored} are not terms of the Gauss-Newton cost and are ignored "
+                          "(losses.get_smooth_loss / compute_optimization_loss still evaluate them for logging)")
         self._engine = None
         self.full_results = []
 
@@ -184,6 +188,11 @@ class DepthOptimizer:
             pose, log_scale, stats = eng.refine_window(
                 target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
                 intrinsics.float(), pose0, opts, stats=True, argmin=bool(self.options.get("diff_img_argmin", True)))
+        if not self.options.get("l_inverse_reconstruction", True):
+            # the reference then leaves the inverse direction out of its objective (optimizer.py:74-79): the inverse poses stay
+            # what the pose network predicted
+            pose = torch.cat([pose[:split], pose0[split:]], 0)
+            stats = stats.clone(); stats[split:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6] = pose0[split:, None, :]
         res["poses_opt"] = pose[:split].cpu()
         res["poses_inv_opt"] = pose[split:].cpu()
         traj = stats[:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6]      # [2SB, gn_iters+1, 6]: the iterates (cf. train_mono.py:71-79)
