@@ -718,25 +718,31 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float4 val, gx, gy;
         tap4_lerp(S.t, val, gx, gy);
         float a[NP], b[NP], zc[NP];
-        geo_jac<NP>(c, S.g, W, H, a, b, zc);
+        if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
         float4 *rec = lds + (S.ly * CW + S.lx) * (LDS_REC / 4);
         // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0..a3][a4 a5 b0 b1][b2..b5]([a6 b6 - -]) : channel pairs and
         // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles
         if (write) {
             lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
-            lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
-            lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
-            lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
-            lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
-            lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
-            if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
+            if (MODE == MODE_LIN) {
+                lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+                lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
+                lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
+                lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
+                lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
+                if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
+            } else {
+                lds_write1(rec + 2, val.z, S.tp.z, 0.f, 0.f);
+            }
         }
         if (centre) {
             c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
             c_ae[0] = S.tp.w; c_valid[0] = !(S.g.oobx || S.g.ooby);
+            if (MODE == MODE_LIN) {
 #pragma unroll
-            for (int j = 0; j < NP; j++) c_zc[0][j] = zc[j];
+                for (int j = 0; j < NP; j++) c_zc[0][j] = zc[j];
+            }
         }
     };
     {
@@ -775,8 +781,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         int ci = tid + k * NT;
         int ly = ci / TW + 1, lx = ci - (ci / TW) * TW + 1;
         const float4 *ctr = lds + (ly * CW + lx) * (LDS_REC / 4);
-        f32x4 q0, q1, q2;
-        lds_read3v(ctr, q0, q1, q2);
+        f32x4 q0, q1 = {0.f, 0.f, 0.f, 0.f}, q2;
+        if (MODE == MODE_LIN) lds_read3v(ctr, q0, q1, q2);
+        else lds_read02v(ctr, q0, q2);               // the gradient part of the records is only staged for linearisations
         const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = q1.lo, gyc01 = q1.hi, yx2c = q2.lo, g2c = q2.hi;
         const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
         const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
