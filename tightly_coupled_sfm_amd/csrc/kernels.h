@@ -3,16 +3,22 @@
 // Kernels (one HIP stream, no host sync between them):
 //   k_pack        once per refine call: planar fp32 inputs -> two float4 images per pair
 //                   tgtpack = (tgt r,g,b, auto_err)   auto_err = iteration-invariant auto-mask error (train_mono.py:84)
-//                   srcpack = (src r,g,b, depth_s)    one 16-B gather per bilinear tap instead of four 4-B gathers
+//                   srcpack = (src r,g,b, depth_s)    one 16-B gather per bilinear tap instead of four 4-B gathers;
+//                                                     stored with a 1-texel zero border so that taps need no masks
+//                 (window form: the fwd / inv directed pairs of train_mono.py:54-62 are formed here by indexing)
 //   k_linearize   THE hot kernel, once per Gauss-Newton iteration: fused
 //                   backproject (stn.py:33-48) -> rigid transform + project (stn.py:198-231) -> bilinear warp of
 //                   RGB+depth with d/d(ix,iy) (stn.py:266,271) -> L1 + 3x3 SSIM (losses.py:27-41, train_mono.py:87)
 //                   -> masks / depth-consistency weight (train_mono.py:89-92) -> exact gradient rows, structure-tensor
-//                   curvature -> per-workgroup J'J / J'r partial sums.  HBM-bound by design: 36 B/pixel read, nothing
-//                   written but one partial-sum record per workgroup.
+//                   curvature -> per-workgroup J'J / J'r partial sums.  Reads 36 B/pixel, writes one partial-sum record
+//                   per workgroup; measured VALU-issue bound (~1050 instructions per 64-pixel wave), see DESIGN.md.
+//                   MODE_COST / MODE_MAPS variants: scalar cost only / the reference's residual maps.
+//   k_select      window form with the min over sources (optimizer.py:47-69): per-pixel selection masks of the forward pairs
 //   k_solve       once per iteration, one workgroup per pair: deterministic fp64 reduction of the partial sums,
-//                   LM/GN logic, 6x6 / 7x7 Cholesky, SE(3) retraction, emits the fp32 constants of the next iteration.
-//   k_warp        inverse_warp2 drop-in (stn.py:234-273), planar in / planar out.
+//                   LM/GN logic, lane-parallel Gauss-Jordan on the 6x6 / 7x7 system, SE(3) retraction, emits the fp32
+//                   constants of the next iteration.
+//   k_warp        inverse_warp2 drop-in (stn.py:234-273), planar in / planar out (+ the next PoseNet input, train_mono.py:73-77).
+//   k_ssim, k_disp_to_depth: SSIM_Loss / disp_to_depth drop-ins.  dense_kernel.h, scale_kernel.h: dense mode, DNet scale.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "se3_math.h"
