@@ -67,8 +67,9 @@ struct LinParams {
     int shared_image;       // all problems read packed image pair 0 (loss-surface sweeps); kept OUT of PairConst so that the
                             // first image loads do not wait for the scalar loads of the pair constants
     int direct;             // 1: no in-launch group reduction -- k_solve sums the workgroup records itself (small grids)
-    const float *ext_mask;  // window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
+    const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
+    int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
 };
 
 constexpr float SSIM_C1 = 0.01f * 0.01f;
@@ -611,6 +612,20 @@ __device__ __forceinline__ void ssim_l1_channel(T xc, T yc, T gxc, T gyc, T Sx, 
     o.lxx = w1 * gxc * gxc; o.lxy = w1 * gxc * gyc; o.lyy = w1 * gyc * gyc;
 }
 
+// value of the per-channel photometric error only (no gradient coefficients): the residual of ANOTHER source, for the
+// min-over-sources selection
+template <class T>
+__device__ __forceinline__ T ssim_l1_value(T xc, T yc, T Sx, T Sy, T Sxx, T Syy, T Sxy, float ws, float wl) {
+    const float n9 = 1.f / 9.f;
+    const T zero = vsplat<T>(0.f), one = vsplat<T>(1.f);
+    T mdx = Sx * n9, mdy = Sy * n9, mux = xc + mdx, muy = yc + mdy;
+    T sigx = Sxx * n9 - mdx * mdx, sigy = Syy * n9 - mdy * mdy, sigxy = Sxy * n9 - mdx * mdy;
+    T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+    T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+    T raw = (one - n1 * n2 * vrcp(d1 * d2)) * 0.5f;
+    return ws * vmin(vmax(raw, zero), one) + wl * vmin(vabs(yc - xc), one);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Workgroup reduction of NLIVE per-thread values -> one record per workgroup -> deterministic in-launch group reduction.
 //   v[]: compacted live values [H photo | g photo | (H dc | g dc) | 3 scalars]; dead accumulators are stored as 0.
@@ -670,7 +685,7 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
     if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
 }
 
-template <int NP, bool DC, int MODE, int TW, int TH, int NT>
+template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
     constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
@@ -701,6 +716,63 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     // centre-only values carried in registers from phase 1 to phase 2
     float c_pd[PPT], c_cd[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
     bool c_valid[PPT], c_in[PPT];
+
+    // ---------------- window mode: the residual of the OTHER sources at this tile (min over sources, optimizer.py:47-69) -------
+    // For a forward pair n = s B + b the other sources of target b are warped with THEIR poses (and their copy of the target
+    // depth), colours only, and their photometric error at the tile's pixels is reduced to four numbers per pixel: the smallest
+    // error among the sources before / after s (torch.min keeps the FIRST minimum), the union of their validity and the
+    // smallest auto-mask threshold.  Same arithmetic as the maps pass + k_select pair it replaces, without the two launches.
+    float sel_before = 3.0e38f, sel_after = 3.0e38f, sel_valid = 0.f, sel_ae = 3.0e38f;
+    const bool sel_pair = SEL && n < P.sel_B * P.sel_S;
+    if (SEL && sel_pair) {
+        const int b_ = n % P.sel_B, s_own = n / P.sel_B;
+        for (int so = 0; so < P.sel_S; so++) {
+            if (so == s_own) continue;
+            const int no = so * P.sel_B + b_;
+            const PairConst &co = P.pc[no];
+            const float4 *tpo = P.tgtpack + (size_t)no * hw, *spo = P.srcpack + (size_t)no * (H + 2) * (W + 2);
+            const float *dto = P.depth_t + (size_t)no * hw;
+            for (int ci = tid; ci < NCOMP; ci += NT) {       // tile + ring, colours only (+ validity and auto-mask threshold)
+                const int ly = ci / CW, lx = ci - ly * CW;
+                const int px = refl_idx(x00 + lx - 1, W), py = refl_idx(y00 + ly - 1, H), gi = py * W + px;
+                const float4 tp = tpo[gi];
+                Geo g;
+                warp_geo(co, W, H, px, py, dto[gi], g);
+                float4 val, gx, gy;
+                tap4(spo, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, val, gx, gy);
+                float4 *rec = lds + ci * (LDS_REC / 4);
+                lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
+                lds_write1(rec + 2, val.z, tp.z, (g.oobx || g.ooby) ? 0.f : 1.f, tp.w);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                const int cy = tid / TW + 1, cx = tid - (tid / TW) * TW + 1;
+                const float4 *ctr = lds + (cy * CW + cx) * (LDS_REC / 4);
+                f32x4 q0, q2;
+                lds_read02v(ctr, q0, q2);
+                const f2 yc01 = q0.lo, xc01 = q0.hi, yx2c = q2.lo;
+                const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
+                f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f};
+                float Sxy2 = 0.f;
+#pragma unroll 1
+                for (int kk = 0; kk < 9; kk++) {
+                    f32x4 n0, n2;
+                    lds_read02v(nb, n0, n2);
+                    nb += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
+                    f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01), e2v = pk_sub(n2.lo, yx2c);
+                    Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+                    S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
+                }
+                const f2 e01 = ssim_l1_value<f2>(xc01, yc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl);
+                const float d_o = e01.x + e01.y + ssim_l1_value<float>(yx2c.y, yx2c.x, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl);
+                if (so < s_own) sel_before = fminf(sel_before, d_o); else sel_after = fminf(sel_after, d_o);
+                sel_valid = fmaxf(sel_valid, q2.z);
+                sel_ae = fminf(sel_ae, q2.w);
+            }
+            __syncthreads();   // the records are overwritten by the next source / by phase 1
+        }
+    }
 
     // ---------------- phase 1: warp + stage (centres, and the halo ring on the first waves) ----------------
     // The NHALO ring pixels are a second pixel for the first NHALO threads.  Those waves run BOTH pixels as one software-
@@ -877,8 +949,12 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float dd = clamp01(raw), Wt = 1.f - dd;
         bool inimg = c_in[k];
         bool m = inimg && c_valid[k] && (!P.automask || diff < c_ae[k]);
-        if (P.ext_mask != nullptr && n < P.n_ext)   // wave-uniform branch
-            m = inimg && P.ext_mask[(size_t)n * hw + (size_t)(inimg ? (y00 + ly - 1) * W + (x00 + lx - 1) : 0)] != 0.f;
+        if (SEL && sel_pair) {   // keep the pixel for the source with the smallest error (first minimum), under the union
+                                 // validity and the auto-mask of the minima
+            const float dmin = fminf(diff, fminf(sel_before, sel_after));
+            const bool keep = (c_valid[k] || sel_valid > 0.f) && (!P.automask || dmin < fminf(c_ae[k], sel_ae));
+            m = inimg && keep && (diff < sel_before) && (diff <= sel_after);
+        }
 
         if (MODE == MODE_MAPS) {
             if (inimg) {

@@ -177,7 +177,10 @@ struct ProfScope {
 template <int NP, bool DC, int MODE>
 void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
     dim3 grid(h->nblk, N), block(TILE_NT);
-    hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
+    if (MODE != MODE_MAPS && P.sel_S > 1)   // window form with the min over sources: selection inside the kernel
+        hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true>), grid, block, 0, h->stream, P);
+    else
+        hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
 }
 
 void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mode, int prof_class = 0) {
@@ -617,9 +620,8 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
     }
-    // per-pixel min over the sources: the forward pairs get an external selection mask, rebuilt at every linearisation
+    // per-pixel min over the sources: the forward pairs also evaluate the other sources' residuals (k_linearize<SEL>)
     const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
-    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
 
     InitParams I = init_params(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0);
     I.K_mod = win_B;
@@ -629,21 +631,8 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     S.stats = d_stats;
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
-    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
-          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
-    auto select_pass = [&]() {   // residual maps of the forward pairs at the current trial poses -> selection masks
-        LinParams M = P;
-        M.o_diff = sel_diff; M.o_valid = sel_valid;
-        launch_lin(h, M, n_sel, np, false, MODE_MAPS, 2);   // profiling class 2 = everything but linearize / solve
-        SelectParams Q;
-        Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
-        Q.B = win_B; Q.S = win_S; Q.hw = (int)hw; Q.automask = o->automask;
-        ProfScope prof(h, 2);
-        hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), win_B), dim3(256), 0, h->stream, Q);
-    };
-    if (n_sel) { P.ext_mask = sel_mask; P.n_ext = n_sel; }
+    if (n_sel) { P.sel_B = win_B; P.sel_S = win_S; }   // min over the sources: evaluated inside k_linearize<SEL>
     for (int it = 0; it < o->n_iters; it++) {
-        if (n_sel) select_pass();
         launch_lin(h, P, N, np, dc, MODE_LIN);
         S.it = it; S.mode = 0;
         const bool last = !lm && it == o->n_iters - 1;   // the last solve also emits the refined pose
@@ -651,7 +640,6 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         launch_solve(h, S, N, np);
     }
     if (lm && o->n_iters > 0) {  // cost-only pass deciding whether the last step is kept
-        if (n_sel) select_pass();
         launch_lin(h, P, N, np, dc, MODE_COST);
         S.it = o->n_iters; S.mode = 1;
         S.pose_out = d_pose_out; S.log_scale_out = d_ls_out;
