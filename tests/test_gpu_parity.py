@@ -762,3 +762,28 @@ def test_dense_window_mode_vs_oracle(oracle64):
         rel = np.abs(da[n] / rd[n] - 1)
         assert np.quantile(rel, 0.999) < (1e-4 if same[n] else 3e-3), (n, rel.max())
     assert np.all(st[:S * B, 0, 2] < 0.8 * H * W) and not np.array_equal(pa[:S * B], pw.cpu().numpy()[:S * B])
+
+
+@pytest.mark.parametrize("H,W", [(17, 33), (16, 32), (31, 65), (50, 70), (5, 9), (33, 16)])
+def test_ragged_and_tiny_frames_vs_oracle(H, W, oracle64):
+    """tile-boundary cases: frames smaller than a tile, one pixel over a tile edge, odd sizes, portrait"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    N = 2
+    b = _pairs(N, H, W, seed0=70 + H)
+    e = _eng(H, W, N)
+    d = _dev(b); p0 = _t(b["pose_init"])
+    lin = e.linearize(*d, p0)
+    pose, _, st = e.refine(*d, p0, default_opts(n_iters=2), stats=True)
+    r = e.compute_photometric_error(d[0], d[1], d[2], d[3], p0, d[4])
+    for n in range(N):
+        args = (b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0])
+        ref = oracle64.linearize(*args, b["pose_init"][n], b["K"][n], oopts())
+        o = oracle64.photometric(*args, b["pose_init"][n], b["K"][n])
+        assert _maxabs(r["diff_img"][n, 0].cpu().numpy(), o["diff"]) < 3e-5 and _maxabs(r["img_rec"][n].cpu().numpy(), o["rec"]) < 1e-5
+        if ref["n_mask"] < 8:
+            continue                                          # nothing to fit on a handful of pixels
+        assert abs(lin["n_mask"][n] - ref["n_mask"]) <= 2 and abs(lin["cost"][n] - ref["cost"]) < 1e-3 * ref["cost"] + 1e-7
+        if lin["n_mask"][n] == ref["n_mask"]:
+            assert _maxabs(lin["g"][n], ref["g"]) < 5e-4 * np.abs(ref["g"]).max() and _maxabs(lin["H"][n], ref["H"]) < 5e-4 * np.abs(ref["H"]).max()
+    assert torch.isfinite(pose).all()
