@@ -160,8 +160,9 @@ int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const
 /* Dense mode (BASELINE config 5): refine the 6-DoF pose AND the per-pixel inverse depth of the target of N directed
  * pairs: o->n_iters Gauss-Newton iterations, exact depth gradient (equal to reference autograd d loss / d depth), per-pixel
  * Schur elimination of the depth block, 6x6 reduced pose system, back-substitution.  depth_t is the initial target depth
- * (or sigmoid disparity with depth_is_disp); depth_out [N,1,H,W] receives the refined DEPTH.  Gauss-Newton only; w_dc
- * must be 0 (the depth prior of opts.prior_depth regularises instead). */
+ * (or sigmoid disparity with depth_is_disp); depth_out [N,1,H,W] receives the refined DEPTH.  w_dc must be 0 (the depth prior of
+ * opts.prior_depth regularises instead).  With TCSFM_SOLVER_LM the pose block is Marquardt-damped and a trial that does not
+ * lower the cost is rolled back -- pose AND depth map -- before the step is recomputed from the accepted linearisation. */
 int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                        const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
                        float *stats_out);

@@ -1019,13 +1019,103 @@ void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const r
     linearize_dense_masked(H, W, tgt, src, depth_t, depth_s, T, K, op, auto_err_in, NULL, lambda_depth, w_prior, depth0, out, g_rho, Dq, Bq);
 }
 
+/* Per-pair state of the dense refinement (shared by the pair form and the window form).
+ * GN (solver 0): every trial is accepted.  LM (solver 1): the pose block is Marquardt-damped; a trial (pose AND depth map)
+ * is accepted when it lowers the cost, otherwise the step is recomputed from the ACCEPTED linearisation -- reduced pose system
+ * and per-pixel records (g_rho, D, B) -- with a larger lambda, starting again from the accepted depth map; lambda_depth
+ * stays fixed.  After the last iteration LM evaluates the last trial once more and keeps it only if it lowered the cost. */
+typedef struct {
+    int n;
+    double Tcur[12], Ttry[12], lambda;
+    int have_cur;
+    lin_t cur;
+    real *dep_try, *dep_acc; /* trial depth map (caller's buffer) / accepted copy */
+    double *gr, *Dq, *Bq;    /* records of the trial linearisation */
+    double *gr_a, *Dq_a, *Bq_a; /* ... of the accepted one */
+} dense_state;
+
+static void dense_state_init(dense_state *st, int n, real *depth_io, const double pose[6], double lambda0) {
+    st->n = n; st->lambda = lambda0; st->have_cur = 0;
+    orc_pose_to_T(pose, st->Tcur); memcpy(st->Ttry, st->Tcur, sizeof(st->Tcur));
+    st->dep_try = depth_io;
+    st->dep_acc = (real *)malloc(sizeof(real) * n);
+    st->gr = (double *)malloc(sizeof(double) * n); st->Dq = (double *)malloc(sizeof(double) * n); st->Bq = (double *)malloc(sizeof(double) * n * 6);
+    st->gr_a = (double *)malloc(sizeof(double) * n); st->Dq_a = (double *)malloc(sizeof(double) * n); st->Bq_a = (double *)malloc(sizeof(double) * n * 6);
+}
+static void dense_state_free(dense_state *st) {
+    free(st->dep_acc); free(st->gr); free(st->Dq); free(st->Bq); free(st->gr_a); free(st->Dq_a); free(st->Bq_a);
+}
+/* after a linearisation `tr` at (Ttry, dep_try) with records in st->gr/Dq/Bq: accept / reject, next trial */
+static void dense_state_step(dense_state *st, const orc_opts *op, const lin_t *tr, double lambda_depth, double min_depth, double max_depth,
+                             double *stats_row) {
+    const int n = st->n;
+    if (stats_row) { stats_row[0] = tr->cost; stats_row[1] = tr->cost_photo; stats_row[2] = tr->n_mask; stats_row[3] = st->lambda; }
+    if (op->solver == 0 || !st->have_cur || tr->cost < st->cur.cost) {
+        if (op->solver == 1 && st->have_cur) st->lambda = fmax(st->lambda * op->lambda_down, op->lambda_min);
+        st->cur = *tr; memcpy(st->Tcur, st->Ttry, sizeof(st->Tcur)); st->have_cur = 1;
+        memcpy(st->dep_acc, st->dep_try, sizeof(real) * n);
+        memcpy(st->gr_a, st->gr, sizeof(double) * n); memcpy(st->Dq_a, st->Dq, sizeof(double) * n); memcpy(st->Bq_a, st->Bq, sizeof(double) * n * 6);
+    } else {
+        st->lambda *= op->lambda_up;
+    }
+    double delta[6], E[12];
+    orc_solve_step(6, st->cur.H, st->cur.g, st->lambda, delta);
+    orc_se3_exp(delta, E);
+    orc_se3_mul(E, st->Tcur, st->Ttry);
+    const double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
+    for (int i = 0; i < n; i++) {
+        double Dd = (1.0 + lambda_depth) * st->Dq_a[i];
+        if (!(Dd > 1e-30)) { st->dep_try[i] = st->dep_acc[i]; continue; }
+        double bd = 0;
+        for (int j = 0; j < 6; j++) bd += st->Bq_a[i * 6 + j] * delta[j];
+        double rho = 1.0 / (double)st->dep_acc[i] - (st->gr_a[i] + bd) / Dd;
+        rho = rho < lo ? lo : (rho > hi ? hi : rho);
+        st->dep_try[i] = (real)(1.0 / rho);
+    }
+}
+/* the end: GN keeps the last trial; LM keeps it only if its cost (tr_final) is lower */
+static void dense_state_finish(dense_state *st, const orc_opts *op, const lin_t *tr_final, double pose_out[6], double *stats_row) {
+    int keep = 1;
+    if (op->solver == 1 && op->n_iters > 0) {
+        if (stats_row) { stats_row[0] = tr_final->cost; stats_row[1] = tr_final->cost_photo; stats_row[2] = tr_final->n_mask; stats_row[3] = st->lambda; }
+        keep = tr_final->cost < st->cur.cost;
+    }
+    if (keep) memcpy(st->Tcur, st->Ttry, sizeof(st->Tcur));
+    else memcpy(st->dep_try, st->dep_acc, sizeof(real) * st->n);
+    orc_T_to_pose(st->Tcur, pose_out);
+}
+
 /*
  * Dense window mode: the 2 S B directed pairs of a window (stacked order as in orc_refine_window), each refining its pose
  * and ITS OWN copy of its target's depth (forward pairs: a copy of target b's depth per source; inverse pairs: source
- * (s,b)'s depth), Gauss-Newton only.  With argmin the forward pairs of a target use the min-over-sources selection,
- * evaluated at every linearisation at the pairs' current poses AND current depth copies.
+ * (s,b)'s depth).  With argmin the forward pairs of a target use the min-over-sources selection, evaluated at every
+ * linearisation at the pairs' current TRIAL poses and depth copies.
  * depth_io [2SB][H*W]: in = initial target depth of every pair, out = refined.  depth_src [2SB][H*W]: the (fixed) source depths.
  */
+static void dense_window_select(int H, int W, int B, int S, const real **img, const real *depth_io, const real *depth_src, const real *K,
+                                const orc_opts *op, const dense_state *st, const real *ae, real *diff, real *valid, real *mask) {
+    const int n = H * W;
+    for (int b = 0; b < B; b++) {
+        for (int s = 0; s < S; s++) {
+            int m = s * B + b;
+            orc_photometric(H, W, img[2 * m], img[2 * m + 1], depth_io + (size_t)m * n, depth_src + (size_t)m * n, st[m].Ttry, K + 9 * b, 0.0,
+                            op->w_l1, op->w_ssim, diff + (size_t)s * n, valid + (size_t)s * n, NULL, NULL, NULL, NULL);
+        }
+        for (int i = 0; i < n; i++) {
+            int smin = 0;
+            real dmin = diff[i], amin = ae[(size_t)b * n + i], vany = valid[i];
+            for (int s = 1; s < S; s++) {
+                if (diff[(size_t)s * n + i] < dmin) { dmin = diff[(size_t)s * n + i]; smin = s; }
+                real a = ae[(size_t)(s * B + b) * n + i];
+                if (a < amin) amin = a;
+                if (valid[(size_t)s * n + i] > vany) vany = valid[(size_t)s * n + i];
+            }
+            int keep = vany > 0 && (!op->automask || dmin < amin);
+            for (int s = 0; s < S; s++) mask[(size_t)(s * B + b) * n + i] = (keep && s == smin) ? 1 : 0;
+        }
+    }
+}
+
 void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_src,
                              const real *K, const orc_opts *op, int argmin, double lambda_depth, double w_prior, double min_depth,
                              double max_depth, double *pose_io /* [2SB][6] */, double *stats /* [2SB][n_iters+1][4] or NULL */) {
@@ -1033,8 +1123,7 @@ void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const 
     real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *d0 = (real *)malloc(sizeof(real) * (size_t)n * N);
     real *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
     real *diff = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL, *valid = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL;
-    double *Tc = (double *)malloc(sizeof(double) * 12 * N);
-    double *gr = (double *)malloc(sizeof(double) * n), *Dq = (double *)malloc(sizeof(double) * n), *Bq = (double *)malloc(sizeof(double) * n * 6);
+    dense_state *st = (dense_state *)calloc(N, sizeof(dense_state));
     const real **img = (const real **)malloc(sizeof(real *) * N * 2);
     memcpy(d0, depth_io, sizeof(real) * (size_t)n * N);
     for (int m = 0; m < N; m++) {
@@ -1042,55 +1131,28 @@ void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const 
         const real *ti = tgt + (size_t)b * 3 * n, *si = srcs + (size_t)q * 3 * n;
         img[2 * m] = inv ? si : ti; img[2 * m + 1] = inv ? ti : si;
         photo_err_map(H, W, img[2 * m], img[2 * m + 1], op->w_l1, op->w_ssim, ae + (size_t)m * n);
-        orc_pose_to_T(pose_io + 6 * m, Tc + 12 * m);
+        dense_state_init(&st[m], n, depth_io + (size_t)m * n, pose_io + 6 * m, op->lambda0);
     }
-    for (int it = 0; it < op->n_iters; it++) {
-        if (sel)
-            for (int b = 0; b < B; b++) {
-                for (int s = 0; s < S; s++) {
-                    int m = s * B + b;
-                    orc_photometric(H, W, img[2 * m], img[2 * m + 1], depth_io + (size_t)m * n, depth_src + (size_t)m * n, Tc + 12 * m, K + 9 * b, 0.0,
-                                    op->w_l1, op->w_ssim, diff + (size_t)s * n, valid + (size_t)s * n, NULL, NULL, NULL, NULL);
-                }
-                for (int i = 0; i < n; i++) {
-                    int smin = 0;
-                    real dmin = diff[i], amin = ae[(size_t)b * n + i], vany = valid[i];
-                    for (int s = 1; s < S; s++) {
-                        if (diff[(size_t)s * n + i] < dmin) { dmin = diff[(size_t)s * n + i]; smin = s; }
-                        real a = ae[(size_t)(s * B + b) * n + i];
-                        if (a < amin) amin = a;
-                        if (valid[(size_t)s * n + i] > vany) vany = valid[(size_t)s * n + i];
-                    }
-                    int keep = vany > 0 && (!op->automask || dmin < amin);
-                    for (int s = 0; s < S; s++) mask[(size_t)(s * B + b) * n + i] = (keep && s == smin) ? 1 : 0;
-                }
-            }
+    const int lm_final = op->solver == 1 && op->n_iters > 0;
+    for (int it = 0; it <= op->n_iters; it++) {
+        const int final = it == op->n_iters;
+        if (final && !lm_final) break;
+        if (sel) dense_window_select(H, W, B, S, img, depth_io, depth_src, K, op, st, ae, diff, valid, mask);
         for (int m = 0; m < N; m++) {
             const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
-            real *dep = depth_io + (size_t)m * n;
             lin_t L;
-            linearize_dense_masked(H, W, img[2 * m], img[2 * m + 1], dep, depth_src + (size_t)m * n, Tc + 12 * m, Km, op, ae + (size_t)m * n,
-                                   (sel && m < SB) ? mask + (size_t)m * n : NULL, lambda_depth, w_prior, d0 + (size_t)m * n, &L, gr, Dq, Bq);
-            if (stats) { double *st = stats + ((size_t)m * (op->n_iters + 1) + it) * 4; st[0] = L.cost; st[1] = L.cost_photo; st[2] = L.n_mask; st[3] = op->lambda0; }
-            double delta[6], E[12], Tn[12];
-            orc_solve_step(6, L.H, L.g, op->lambda0, delta);
-            orc_se3_exp(delta, E);
-            orc_se3_mul(E, Tc + 12 * m, Tn);
-            memcpy(Tc + 12 * m, Tn, sizeof(Tn));
-            for (int i = 0; i < n; i++) {
-                double Dd = (1.0 + lambda_depth) * Dq[i];
-                if (!(Dd > 1e-30)) continue;
-                double bd = 0;
-                for (int j = 0; j < 6; j++) bd += Bq[i * 6 + j] * delta[j];
-                double rho = 1.0 / (double)dep[i] - (gr[i] + bd) / Dd;
-                double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
-                rho = rho < lo ? lo : (rho > hi ? hi : rho);
-                dep[i] = (real)(1.0 / rho);
-            }
+            linearize_dense_masked(H, W, img[2 * m], img[2 * m + 1], st[m].dep_try, depth_src + (size_t)m * n, st[m].Ttry, Km, op, ae + (size_t)m * n,
+                                   (sel && m < SB) ? mask + (size_t)m * n : NULL, lambda_depth, w_prior, d0 + (size_t)m * n, &L, st[m].gr, st[m].Dq, st[m].Bq);
+            double *row = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
+            if (final) dense_state_finish(&st[m], op, &L, pose_io + 6 * m, row);
+            else dense_state_step(&st[m], op, &L, lambda_depth, min_depth, max_depth, row);
         }
     }
-    for (int m = 0; m < N; m++) orc_T_to_pose(Tc + 12 * m, pose_io + 6 * m);
-    free(ae); free(d0); free(mask); free(diff); free(valid); free(Tc); free(gr); free(Dq); free(Bq); free(img);
+    for (int m = 0; m < N; m++) {
+        if (!lm_final) dense_state_finish(&st[m], op, NULL, pose_io + 6 * m, NULL);
+        dense_state_free(&st[m]);
+    }
+    free(ae); free(d0); free(mask); free(diff); free(valid); free(st); free(img);
 }
 
 void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
@@ -1100,31 +1162,20 @@ void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *dept
     real *ae = (real *)malloc(sizeof(real) * n), *d0 = (real *)malloc(sizeof(real) * n);
     memcpy(d0, depth_io, sizeof(real) * n);
     photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
-    double *gr = (double *)malloc(sizeof(double) * n), *Dq = (double *)malloc(sizeof(double) * n), *Bq = (double *)malloc(sizeof(double) * n * 6);
-    double Tc[12];
-    orc_pose_to_T(pose_io, Tc);
-    for (int it = 0; it < op->n_iters; it++) {
+    dense_state st;
+    dense_state_init(&st, n, depth_io, pose_io, op->lambda0);
+    const int lm_final = op->solver == 1 && op->n_iters > 0;
+    for (int it = 0; it <= op->n_iters; it++) {
+        const int final = it == op->n_iters;
+        if (final && !lm_final) break;
         lin_t L;
-        orc_linearize_dense(H, W, tgt, src, depth_io, depth_s, Tc, K, op, ae, lambda_depth, w_prior, d0, &L, gr, Dq, Bq);
-        if (stats) { stats[4 * it] = L.cost; stats[4 * it + 1] = L.cost_photo; stats[4 * it + 2] = L.n_mask; stats[4 * it + 3] = op->lambda0; }
-        double delta[6], E[12], Tn[12];
-        orc_solve_step(6, L.H, L.g, op->lambda0, delta);
-        orc_se3_exp(delta, E);
-        orc_se3_mul(E, Tc, Tn);
-        memcpy(Tc, Tn, sizeof(Tc));
-        for (int i = 0; i < n; i++) {
-            double Dd = (1.0 + lambda_depth) * Dq[i];
-            if (!(Dd > 1e-30)) continue;
-            double bd = 0;
-            for (int j = 0; j < 6; j++) bd += Bq[i * 6 + j] * delta[j];
-            double rho = 1.0 / (double)depth_io[i] - (gr[i] + bd) / Dd;
-            double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
-            rho = rho < lo ? lo : (rho > hi ? hi : rho);
-            depth_io[i] = (real)(1.0 / rho);
-        }
+        orc_linearize_dense(H, W, tgt, src, st.dep_try, depth_s, st.Ttry, K, op, ae, lambda_depth, w_prior, d0, &L, st.gr, st.Dq, st.Bq);
+        if (final) dense_state_finish(&st, op, &L, pose_io, stats ? stats + 4 * it : NULL);
+        else dense_state_step(&st, op, &L, lambda_depth, min_depth, max_depth, stats ? stats + 4 * it : NULL);
     }
-    orc_T_to_pose(Tc, pose_io);
-    free(ae); free(d0); free(gr); free(Dq); free(Bq);
+    if (!lm_final) dense_state_finish(&st, op, NULL, pose_io, NULL);
+    dense_state_free(&st);
+    free(ae); free(d0);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -600,7 +600,7 @@ def test_argument_errors_are_codes_not_crashes():
     dep = torch.empty_like(d[2])
     rc = e.lib.tcsfm_refine_dense(e._h, C.byref(default_opts(w_dc=0.1)), N, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), P(out), P(dep), None)
     assert rc < 0 and "w_dc" in e.lib.tcsfm_last_error(e._h).decode()
-    rc = e.lib.tcsfm_refine_dense(e._h, C.byref(default_opts(solver=1)), N, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), P(out), P(dep), None)
+    rc = e.lib.tcsfm_refine_dense(e._h, C.byref(default_opts(param=1)), N, P(d[0]), P(d[1]), P(d[2]), P(d[3]), P(d[4]), P(p0), P(out), P(dep), None)
     assert rc < 0
     h = C.c_void_p()
     assert e.lib.tcsfm_create(C.byref(h), 0, 2, 2, 1) < 0 and b"sizes" in e.lib.tcsfm_last_error(None)
@@ -809,3 +809,72 @@ def test_refine_window_three_sources_vs_oracle(oracle64):
         tol = 1e-4 if same else 5e-3
         assert np.linalg.norm(pose[n, :3] - rp[n, :3]) / np.linalg.norm(rp[n, :3]) < tol
         assert np.linalg.norm(pose[n, 3:] - rp[n, 3:]) / np.linalg.norm(rp[n, 3:]) < tol
+
+
+@pytest.mark.parametrize("window", [False, True], ids=["pairs", "window+argmin"])
+def test_dense_lm_vs_oracle(oracle64, window):
+    """Levenberg-Marquardt in dense mode: accept / reject on the cost with the pose AND the depth map rolled back on a reject,
+    final cost check -- against the float64 oracle (pair form, and window form with the min over sources)"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, iters = 96, 320, 5
+    o = default_opts(n_iters=iters, solver=1, lambda0=1e-3, w_dc=0.0, min_depth=0.06, max_depth=2.67)
+    oo = oopts(n_iters=iters, solver=1, lambda0=1e-3)
+    if window:
+        B, S = 1, 2
+        w = _window(B, S, H, W)
+        w["depth_t"] = (w["depth_t"] * (1 + 0.02 * np.sin(np.arange(W) / 11.0))[None, None, None, :]).astype(np.float32)
+        e = _eng(H, W, 2 * S * B)
+        pose, dep, st = e.refine_dense_window(_t(w["target"]), _t(w["sources"]), _t(w["depth_t"]), _t(w["depth_s"]), _t(w["K"]), _t(w["first"]), o,
+                                              stats=True, argmin=True)
+        rp, rd, rst = oracle64.refine_dense_window(w["target"], w["sources"], w["depth_t"][:, 0], w["depth_s"][:, :, 0], w["K"], w["first"], oo,
+                                                   argmin=True, lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth))
+        N = 2 * S * B
+    else:
+        N = 2
+        b = _pairs(N, H, W, seed0=31, both=True)
+        d0 = (b["depth_t"] * (1 + 0.03 * np.sin(np.arange(W) / 9.0))[None, None, None, :]).astype(np.float32)
+        e = _eng(H, W, N)
+        far = np.stack([__import__("tightly_coupled_sfm_amd").synth.perturb_pose(g, 5 + i, sigma_t=0.002, sigma_r=0.0006) for i, g in enumerate(b["pose_gt"])])
+        pose, dep, st = e.refine_dense(_t(b["tgt"]), _t(b["src"]), _t(d0), _t(b["depth_s"]), _t(b["K"]), _t(far), o, stats=True)
+        rp, rd, rst = np.zeros((N, 6)), np.zeros((N, H, W)), np.zeros((N, iters + 1, 4))
+        for n in range(N):
+            rp[n], rd[n], rst[n] = oracle64.refine_dense(b["tgt"][n], b["src"][n], d0[n, 0], b["depth_s"][n, 0], far[n], b["K"][n], oo,
+                                                         lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth))
+    pose, dep, st = pose.cpu().numpy().astype(np.float64), dep.cpu().numpy()[:, 0], st.cpu().numpy()
+    assert np.all(st[:, -1, 0] <= st[:, 0, 0])                                   # LM never ends above where it started
+    for n in range(N):
+        same = np.all(st[n, :iters, 2] == rst[n, :iters, 2]) and np.allclose(st[n, :, 3], rst[n, :, 3], rtol=1e-5)   # masks and accept/reject history
+        tol = 1e-4 if same else 5e-3
+        assert np.max(np.abs(st[n, :, 0] - rst[n, :, 0]) / rst[n, :, 0]) < (2e-5 if same else 5e-3)
+        assert np.linalg.norm(pose[n, :3] - rp[n, :3]) / np.linalg.norm(rp[n, :3]) < tol
+        assert np.linalg.norm(pose[n, 3:] - rp[n, 3:]) / np.linalg.norm(rp[n, 3:]) < tol
+        assert np.quantile(np.abs(dep[n] / rd[n] - 1), 0.999) < tol
+
+
+def test_dense_lm_rejects_roll_back_pose_and_depth(oracle64):
+    """cases where Levenberg-Marquardt REJECTS trials inside the loop and at the final check (found by scanning seeds with the
+    oracle): the pose and the depth map must come back from the accepted state exactly as in the float64 oracle"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, iters, seeds = 48, 160, 8, (21, 29, 31, 20)
+    ps = [synth.make_pair(H, W, seed=s) for s in seeds]
+    init = np.stack([synth.perturb_pose(p["pose_gt"], s, sigma_t=0.004, sigma_r=0.0012) for p, s in zip(ps, seeds)])
+    d0 = np.stack([(p["depth_t"] * (1 + 0.05 * np.sin(np.arange(W) / 7.0))[None, :]).astype(np.float32) for p in ps])
+    stack = lambda k: _t(np.stack([p[k] for p in ps]))
+    e = _eng(H, W, len(seeds))
+    kw = dict(n_iters=iters, solver=1, lambda0=1e-4, lambda_min=1e-6)
+    pose, dep, st = e.refine_dense(stack("tgt"), stack("src"), _t(d0[:, None]), stack("depth_s")[:, None], stack("K"), _t(init),
+                                   default_opts(w_dc=0.0, min_depth=0.06, max_depth=2.67, **kw), stats=True)
+    pose, dep, st = pose.cpu().numpy().astype(np.float64), dep.cpu().numpy()[:, 0], st.cpu().numpy()
+    matched_rejects = 0
+    for n, p in enumerate(ps):
+        rp, rd, rst = oracle64.refine_dense(p["tgt"], p["src"], d0[n], p["depth_s"], init[n], p["K"], oopts(**kw), lambda_depth=1.0, w_prior=10.0)
+        same = np.allclose(st[n, :, 3], rst[:, 3], rtol=1e-5) and np.all(st[n, :iters, 2] == rst[:iters, 2])
+        rejected = np.any(np.diff(rst[:, 3]) > 0) or rst[-1, 0] >= rst[:-1, 0].min()
+        matched_rejects += int(same and rejected)
+        tol = 1e-4 if same else 2e-2
+        assert np.linalg.norm(pose[n, :3] - rp[:3]) / np.linalg.norm(rp[:3]) < tol and np.linalg.norm(pose[n, 3:] - rp[3:]) / np.linalg.norm(rp[3:]) < tol
+        assert np.quantile(np.abs(dep[n] / rd - 1), 0.999) < tol
+    assert matched_rejects >= 2        # the roll-back path was exercised with the same decisions as the oracle

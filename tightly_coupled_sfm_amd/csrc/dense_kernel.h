@@ -301,4 +301,49 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdateParams P) {
     P.depth[(size_t)n * P.hw + idx] = 1.f / rho;
 }
 
+// LM variant of the back-substitution: an accepted trial first becomes the accepted state (depth map and per-pixel records),
+// then the next trial depth is formed from the ACCEPTED state with the step k_solve derived from the accepted system.
+struct DenseLmParams {
+    const float *rec_try;     // [N][H*W][8] records of the linearisation just evaluated
+    float *rec_acc;           // [N][H*W][8] accepted records
+    float *depth_acc;         // [N][H*W]    accepted depth
+    float *depth;             // [N][H*W]    trial depth in/out
+    const double *delta;      // [N][8]
+    const int *accept;        // [N]
+    int hw;
+    float rho_lo, rho_hi;
+};
+
+__global__ __launch_bounds__(256) void k_dense_update_lm(DenseLmParams P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (idx >= P.hw) return;
+    const size_t o = (size_t)n * P.hw + idx;
+    float4 *ra = reinterpret_cast<float4 *>(P.rec_acc + o * 8);
+    float4 r0, r1;
+    float base;
+    if (P.accept[n]) {
+        const float4 *rt = reinterpret_cast<const float4 *>(P.rec_try + o * 8);
+        r0 = rt[0]; r1 = rt[1]; base = P.depth[o];
+        ra[0] = r0; ra[1] = r1; P.depth_acc[o] = base;
+    } else {
+        r0 = ra[0]; r1 = ra[1]; base = P.depth_acc[o];
+    }
+    float dep = base;
+    if (r0.y > 0.f) {
+        const double *d = P.delta + n * 8;
+        float bd = r0.z * (float)d[0] + r0.w * (float)d[1] + r1.x * (float)d[2] + r1.y * (float)d[3] + r1.z * (float)d[4] + r1.w * (float)d[5];
+        float rho = 1.f / base - (r0.x + bd) / r0.y;
+        rho = fminf(fmaxf(rho, P.rho_lo), P.rho_hi);
+        dep = 1.f / rho;
+    }
+    P.depth[o] = dep;
+}
+
+// after the final LM cost check: a pair whose last step was rejected falls back to its accepted depth map
+__global__ __launch_bounds__(256) void k_dense_final_lm(const int *keep, const float *depth_acc, float *depth, int hw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (idx >= hw || keep[n]) return;
+    depth[(size_t)n * hw + idx] = depth_acc[(size_t)n * hw + idx];
+}
+
 }  // namespace tc

@@ -1109,6 +1109,7 @@ struct SolveParams {
     float *pose_out, *log_scale_out;  // written by the last launch of a refine call (null otherwise)
     long long *dbg;                   // diagnostic builds only: s_memrealtime stamps of the solve phases (null in production)
     double *delta_out;                // dense mode: [N][8] pose increment of this iteration for k_dense_update (else null)
+    int *accept_out;                  // dense LM: [N] 1 = this launch accepted the trial (mode 0) / kept the last step (mode 1)
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -1220,6 +1221,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     double sfin = 0.0;
     if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
         const bool keep = cost < Lc.cost_cur;
+        if (P.accept_out && tid == 0) P.accept_out[n] = keep ? 1 : 0;
         if (tid < 12) { const double v = keep ? Lc.Ttry[tid] : Lc.Tcur[tid]; Ts[24 + tid] = v; if (keep) S.Tcur[tid] = v; }
         sfin = keep ? Lc.stry : Lc.scur;
         if (tid == 0 && keep) S.scur = sfin;
@@ -1258,6 +1260,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         __builtin_amdgcn_wave_barrier();
         TC_STAMP(3)
         if (tid == 0) {   // serial part: bookkeeping and the exponential of the step
+            if (P.accept_out) P.accept_out[n] = accept ? 1 : 0;
             if (accept) { S.scur = sc; S.cost_cur = cost; S.have_cur = 1; }
             S.lambda = lambda;
             if (P.delta_out)

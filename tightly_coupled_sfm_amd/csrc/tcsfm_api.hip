@@ -42,6 +42,8 @@ struct tcsfm_ctx {
     int tiles_x = 0, tiles_y = 0, nblk = 0, ngrp = 0, ngrp_pad = 0, stats_cap_iters = 0;
     int nblk_alloc = 0, ngrp_alloc = 0;   // scratch capacity (covers the 32x8 tiling of the dense kernel too)
     float *dense_rec = nullptr, *depth0 = nullptr;   // dense mode scratch, allocated on first use
+    float *dense_rec_acc = nullptr, *depth_acc = nullptr;   // dense LM: accepted per-pixel records / depth maps
+    int *lm_accept = nullptr;
     double *delta = nullptr;
     float *sel_maps = nullptr;   // window mode scratch: diff | valid | selection mask, [3][max_pairs][H*W], allocated on first use
     unsigned *scale_keys = nullptr, *scale_hist = nullptr;   // scale recovery scratch (keys, 256 bins + 4 state words)
@@ -356,7 +358,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist, h->sel_maps};
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -724,7 +726,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
     if (o->w_dc > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth)");
-    if (o->solver != TCSFM_SOLVER_GN || o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: Gauss-Newton on the SE(3) chart only");
+    if (o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: SE(3) chart only");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
     HIPCHK(h, hipSetDevice(h->device));
     const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
@@ -732,6 +734,12 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
     if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
+    const bool lm = o->solver == TCSFM_SOLVER_LM;
+    if (lm && !h->dense_rec_acc) {
+        HIPCHK(h, hipMalloc((void **)&h->dense_rec_acc, n * hw * 8 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->depth_acc, n * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
+    }
     if (!h->dense_rec) {
         HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
@@ -779,25 +787,40 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
           *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
     if (n_sel) { P.ext_mask = sel_mask; P.n_ext = n_sel; }
+    auto select_pass = [&]() {
+        LinParams M = lin_params(h, &oo, 6);
+        M.o_diff = sel_diff; M.o_valid = sel_valid;
+        launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
+        SelectParams Q;
+        Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
+        Q.B = win_B; Q.S = win_S; Q.hw = (int)hw; Q.automask = o->automask;
+        hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), win_B), dim3(256), 0, h->stream, Q);
+    };
+    auto linearize = [&]() {
+        if (n_sel) select_pass();
+        ProfScope prof(h, 0);
+        hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
+    };
+    DenseLmParams Ul;
+    Ul.rec_try = h->dense_rec; Ul.rec_acc = h->dense_rec_acc; Ul.depth_acc = h->depth_acc; Ul.depth = h->depth_work; Ul.delta = h->delta;
+    Ul.accept = h->lm_accept; Ul.hw = (int)hw; Ul.rho_lo = U.rho_lo; Ul.rho_hi = U.rho_hi;
+    S.accept_out = lm ? h->lm_accept : nullptr;
+    const dim3 px_grid((unsigned)((hw + 255) / 256), N);
     for (int it = 0; it < o->n_iters; it++) {
-        if (n_sel) {
-            LinParams M = lin_params(h, &oo, 6);
-            M.o_diff = sel_diff; M.o_valid = sel_valid;
-            launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
-            SelectParams Q;
-            Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
-            Q.B = win_B; Q.S = win_S; Q.hw = (int)hw; Q.automask = o->automask;
-            hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), win_B), dim3(256), 0, h->stream, Q);
-        }
-        {
-            ProfScope prof(h, 0);
-            hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
-        }
+        linearize();
         S.it = it; S.mode = 0;
-        const bool last = it == o->n_iters - 1;
+        const bool last = !lm && it == o->n_iters - 1;
         S.pose_out = last ? d_pose_out : nullptr; S.log_scale_out = nullptr;
         launch_solve(h, S, N, 6);
-        hipLaunchKernelGGL(k_dense_update, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, U);
+        if (lm) hipLaunchKernelGGL(k_dense_update_lm, px_grid, dim3(256), 0, h->stream, Ul);
+        else hipLaunchKernelGGL(k_dense_update, px_grid, dim3(256), 0, h->stream, U);
+    }
+    if (lm && o->n_iters > 0) {   // evaluate the last trial once more; keep it only if it lowered the cost (pose and depth map)
+        linearize();
+        S.it = o->n_iters; S.mode = 1;
+        S.pose_out = d_pose_out; S.log_scale_out = nullptr;
+        launch_solve(h, S, N, 6);
+        hipLaunchKernelGGL(k_dense_final_lm, px_grid, dim3(256), 0, h->stream, (const int *)h->lm_accept, (const float *)h->depth_acc, h->depth_work, (int)hw);
     }
     HIPCHK(h, hipGetLastError());
     if (o->n_iters == 0) {
