@@ -105,6 +105,7 @@ class DepthOptimizer:
         if self._refine_mode() == "pose+depth":     # dense mode: GN on the SE(3) chart, depth prior instead of the DC term
             kw = {k: float(o[k]) for k in ("prior_depth", "lambda_depth") if k in o}
             return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0, w_dc=0.0,
+                                solver=_lib.SOLVER_LM if o.get("solver", "gn") == "lm" else _lib.SOLVER_GN,
                                 lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
                                 max_depth=float(self.config["max_depth"]), **kw)
         return default_opts(
