@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""A miniature of the reference's optimization_experiments/run_sequential_optimization.py on synthetic data: per-window
+refinement with the drop-in DepthOptimizer, trajectory composition (validate.compute_trajectory) and odometry errors.
+
+    python examples/run_sequence.py [--frames 40] [--sources 2]          (needs an MI355X)
+
+The two "networks" are stand-ins with the reference models' call conventions: the depth net returns the scene's true
+disparity for whatever frame it is shown, the pose net returns a noisy version of the true relative pose (PoseNet-quality
+initialisation).  Everything between the network calls -- warps, residuals, Gauss-Newton -- runs in libtcsfm_hip.so.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tightly_coupled_sfm_amd import synth                                    # noqa: E402
+from tightly_coupled_sfm_amd.optimizer import DepthOptimizer                  # noqa: E402
+from tightly_coupled_sfm_amd.validate import compute_trajectory               # noqa: E402
+
+H, W = 192, 640
+
+
+class DepthNet(torch.nn.Module):
+    """returns the stored sigmoid disparity of whichever known frame (or its mirror image) each input is"""
+    def __init__(self, frames, disps):
+        super().__init__(); self.frames, self.disps = frames, disps
+    def _one(self, x):
+        err = (self.frames - x).abs().flatten(1).amax(1); errf = (torch.flip(self.frames, [3]) - x).abs().flatten(1).amax(1)
+        return self.disps[int(err.argmin())] if float(err.min()) <= float(errf.min()) else torch.flip(self.disps[int(errf.argmin())], [2])
+    def forward(self, x=None, skips=None, return_disp=True, epoch=0):
+        if x is not None and not return_disp:
+            return None, [x, x]
+        src = x if x is not None else skips[-1]
+        return [torch.stack([self._one(src[i:i + 1]) for i in range(src.shape[0])])], [src, src]
+
+
+class PoseNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__(); self.next = None
+    def forward(self, x):
+        out, self.next = self.next, None
+        return out if out is not None else torch.zeros(x.shape[0], 6, device=x.device)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--sources", type=int, default=1, choices=(1, 2))
+    ap.add_argument("--gn-iters", type=int, default=8)
+    args = ap.parse_args()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    rng = np.random.default_rng(0)
+    options = {"diff_img_argmin": True, "automasking": True, "mode": "scaled", "l_depth_consist": True, "l_depth_consist_weight": 0.15,
+               "l_inverse_reconstruction": True, "num_source_imgs": args.sources, "gn_iters": args.gn_iters}
+    config = {"minibatch": 1, "device": "cuda", "min_depth": 0.06, "max_depth": 2.67, "iterations": 1, "camera_height": 1.65, "flow_type": "none"}
+    gt, init, opt, conv, t_total = [], [], [], [], 0.0
+    for i in range(args.frames):
+        pose = np.array([0.002, -0.001, 0.033, 0.001, -0.003, 0.001]) + rng.normal(scale=[3e-4, 3e-4, 2e-3, 5e-4, 1e-3, 5e-4])
+        pairs = [synth.make_pair(H, W, seed=500 + i, pose_gt=pose * (1 if s == 0 else -1)) for s in range(args.sources)]
+        frames = t(np.stack([pairs[0]["tgt"]] + [p["src"] for p in pairs]))
+        sig = lambda d: synth.depth_to_sigmoid_disp(d.astype(np.float64)).astype(np.float32)
+        disps = t(np.stack([sig(pairs[0]["depth_t"])] + [sig(p["depth_s"]) for p in pairs])[:, None])
+        fwd = np.stack([synth.perturb_pose(p["pose_gt"], 900 + i * 2 + s) for s, p in enumerate(pairs)])
+        pose_net = PoseNet(); pose_net.next = t(np.concatenate([fwd, np.stack([synth.invert_pose(x) for x in fwd])]))
+        optimiser = DepthOptimizer(options, config, pose_net, DepthNet(frames, disps), "synthetic")
+        gts = [t(p["pose_gt"][None]) for p in pairs]
+        data = (frames[0:1], [frames[1 + s:2 + s] for s in range(args.sources)], gts, gts, None, t(pairs[0]["K"][None]), None, None, None, None, None)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = optimiser.optimize_window(i, data)
+        torch.cuda.synchronize(); t_total += time.perf_counter() - t0
+        gt.append(pairs[0]["pose_gt"].astype(np.float64)); init.append(r["poses_init"][0].numpy().astype(np.float64)); opt.append(r["poses_opt"][0].numpy().astype(np.float64))
+        # yardstick: the same window with the same options, started at the true poses and iterated to convergence
+        truth = np.stack([p["pose_gt"] for p in pairs])
+        pose_net.next = t(np.concatenate([truth, np.stack([synth.invert_pose(x) for x in truth])]))
+        conv.append(DepthOptimizer(dict(options, gn_iters=40), config, pose_net, optimiser.depth_model, "synthetic")
+                    .optimize_window(i, data)["poses_opt"][0].numpy().astype(np.float64))
+    conv_traj = compute_trajectory(np.stack(conv), np.eye(4)[None])[0]
+    gt_traj = compute_trajectory(np.stack(gt), np.eye(4)[None])[0]
+    for name, poses in (("PoseNet stand-in", init), (f"refined ({args.gn_iters} GN its)", opt)):
+        _, _, e_conv, _ = compute_trajectory(np.stack(poses), conv_traj)
+        _, _, e_true, _ = compute_trajectory(np.stack(poses), gt_traj)
+        print(f"{name:20s} vs converged photometric solution: trans {e_conv[0]:.4f}, rot {e_conv[1]:.4f} deg   |   vs scene truth: trans {e_true[0]:.4f}, rot {e_true[1]:.4f} deg")
+    print(f"{args.frames} windows, S={args.sources}: {t_total / args.frames * 1e3:.2f} ms per optimize_window call "
+          "(stand-in networks included; the refinement itself is ~0.1 ms)")
+    print("note: what the optimiser minimises is the reference's residual; on rendered data its minimiser is offset from the scene truth "
+          "(half-pixel sampling convention of the reference's warp, interpolation on the near ground plane), so the first column is "
+          "the meaningful one -- in the reference's real pipeline the networks are trained through the same warp")
+
+
+if __name__ == "__main__":
+    main()
