@@ -878,3 +878,74 @@ def test_dense_lm_rejects_roll_back_pose_and_depth(oracle64):
         assert np.linalg.norm(pose[n, :3] - rp[:3]) / np.linalg.norm(rp[:3]) < tol and np.linalg.norm(pose[n, 3:] - rp[3:]) / np.linalg.norm(rp[3:]) < tol
         assert np.quantile(np.abs(dep[n] / rd - 1), 0.999) < tol
     assert matched_rejects >= 2        # the roll-back path was exercised with the same decisions as the oracle
+
+
+def test_fuzz_options_vs_oracle(oracle64):
+    """seeded random sweep over sizes and option combinations (solver, chart, refine mode, depth consistency, auto-mask,
+    iteration count, damping): every configuration against the float64 oracle"""
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    rng = np.random.default_rng(2024)
+    loose = 0
+    for case in range(16):
+        H, W = int(rng.integers(20, 72)), int(rng.integers(36, 150))
+        kw = dict(n_iters=int(rng.integers(1, 6)), solver=int(rng.integers(0, 2)), param=int(rng.integers(0, 2)),
+                  w_dc=float(rng.choice([0.0, 0.15])), automask=int(rng.integers(0, 2)), lambda0=float(rng.choice([1e-4, 1e-3, 1e-2])))
+        refine = int(rng.integers(0, 2))
+        N = 2
+        b = _pairs(N, H, W, seed0=300 + case, both=bool(rng.integers(0, 2)))
+        e = _eng(H, W, N)
+        ls0 = rng.normal(scale=0.03, size=N).astype(np.float32)
+        pose, ls, st = e.refine(*_dev(b), _t(b["pose_init"]), default_opts(refine=refine, **kw), log_scale=_t(ls0) if refine else None, stats=True)
+        pose, st = pose.cpu().numpy().astype(np.float64), st.cpu().numpy()
+        for n in range(N):
+            rp, rls, rst = oracle64.refine(b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0], b["pose_init"][n], b["K"][n],
+                                           oopts(nparam=6 + refine, **kw), log_scale=float(ls0[n]) if refine else 0.0)
+            nlin = kw["n_iters"]
+            same = np.all(st[n, :nlin, 2] == rst[:nlin, 2]) and np.allclose(st[n, :nlin, 3], rst[:nlin, 3], rtol=1e-5)
+            loose += int(not same)
+            tol = 1e-4 if same else 2e-2          # a mask tie or an LM decision taken differently in fp32: see the window tests
+            et = np.linalg.norm(pose[n, :3] - rp[:3]) / np.linalg.norm(rp[:3]); er = np.linalg.norm(pose[n, 3:] - rp[3:]) / np.linalg.norm(rp[3:])
+            assert et < tol and er < tol, (case, H, W, kw, refine, n, et, er)
+            if refine:
+                assert abs(float(ls[n]) - rls) < tol
+    assert loose <= 6                            # the strict tolerance applied to the large majority of the 32 refinements
+
+
+def test_fuzz_window_and_dense_vs_oracle(oracle64):
+    """seeded random sweep over window shapes (B, S), selection on/off, solver, pose / dense mode at small sizes"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import standins
+    from oracle.oracle import default_opts as oopts
+    from tightly_coupled_sfm_amd.engine import default_opts
+    rng = np.random.default_rng(77)
+    loose = total = 0
+    for case in range(8):
+        B, S = int(rng.integers(1, 3)), int(rng.integers(1, 4))
+        H, W = int(rng.integers(24, 56)), int(rng.integers(48, 120))
+        dense, argmin = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        kw = dict(n_iters=int(rng.integers(1, 5)), solver=int(rng.integers(0, 2)), lambda0=float(rng.choice([1e-4, 1e-3])))
+        w = standins.make_window(B, S, H, W, seed0=400 + case)
+        w["depth_t"] = oracle64.disp_to_depth(w["disp_t"], 0.06, 2.67)[1].astype(np.float32)
+        w["depth_s"] = oracle64.disp_to_depth(w["disp_s"], 0.06, 2.67)[1].astype(np.float32)
+        e = _eng(H, W, 2 * S * B)
+        args = (_t(w["target"]), _t(w["sources"]), _t(w["depth_t"]), _t(w["depth_s"]), _t(w["K"]), _t(w["first"]))
+        oargs = (w["target"], w["sources"], w["depth_t"][:, 0], w["depth_s"][:, :, 0], w["K"], w["first"])
+        if dense:
+            pose, dep, st = e.refine_dense_window(*args, default_opts(w_dc=0.0, min_depth=0.06, max_depth=2.67, **kw), stats=True, argmin=argmin)
+            rp, rd, rst = oracle64.refine_dense_window(*oargs, oopts(**kw), argmin=argmin, lambda_depth=1.0, w_prior=10.0)
+        else:
+            pose, _, st = e.refine_window(*args, default_opts(**kw), stats=True, argmin=argmin)
+            rp, _, rst = oracle64.refine_window(*oargs, oopts(**kw), argmin=argmin)
+        pose, st = pose.cpu().numpy().astype(np.float64), st.cpu().numpy()
+        nlin = kw["n_iters"]
+        for n in range(2 * S * B):
+            same = np.all(st[n, :nlin, 2] == rst[n, :nlin, 2]) and np.allclose(st[n, :nlin, 3], rst[n, :nlin, 3], rtol=1e-5)
+            loose += int(not same); total += 1
+            tol = 1e-4 if same else 3e-2
+            et = np.linalg.norm(pose[n, :3] - rp[n, :3]) / np.linalg.norm(rp[n, :3]); er = np.linalg.norm(pose[n, 3:] - rp[n, 3:]) / np.linalg.norm(rp[n, 3:])
+            assert et < tol and er < tol, (case, B, S, H, W, dense, argmin, kw, n, et, er)
+            if dense:
+                assert np.quantile(np.abs(dep[n, 0].cpu().numpy() / rd[n] - 1), 0.995) < tol
+    assert loose <= total // 4
