@@ -335,3 +335,44 @@ def test_oracle_vs_torch_twin_random_sweep(oracle64):
         c.backward()
         gp = oracle64.euler_left_jacobian(pose).T @ lin["g"]
         assert _maxabs(pt.grad[0], gp) < 1e-8 * max(1.0, np.abs(gp).max())
+
+
+def test_dense_depth_gradient_vs_reference_autograd_G6(oracle64):
+    """dense mode: d cost / d (inverse depth of every target pixel) of the oracle (adjoint form) equals the reference's autograd
+    d loss / d depth_t (golden G6) through the chain rule rho = 1 / depth; so does the pose block"""
+    from oracle.oracle import default_opts
+    g = load_golden("jac24x40")
+    r = oracle64.linearize_dense(g["tgt"], g["src"], g["depth_t"], g["depth_s"], g["pose"], g["K"], default_opts(), lambda_depth=0.0, w_prior=0.0)
+    assert abs(r["cost"] - float(g["cost"])) < 1e-12
+    ref = -g["grad_depth_t"] * g["depth_t"] ** 2                       # dC/drho = dC/dD dD/drho = -D^2 dC/dD
+    assert _maxabs(r["g_rho"], ref) < 1e-12 * np.abs(ref).max()
+    assert np.count_nonzero(ref) > 0.3 * ref.size
+    # the Schur-reduced pose gradient with the depth block switched off (D = 0 pixels) must reduce to the pose-mode gradient
+    lin = oracle64.linearize(g["tgt"], g["src"], g["depth_t"], g["depth_s"], g["pose"], g["K"], default_opts())
+    full_g = lin["g"]
+    back = r["g"] + np.einsum("hwj,hw->j", r["B"], np.where(r["D"] > 1e-30, r["g_rho"] / np.where(r["D"] > 1e-30, r["D"], 1.0), 0.0))
+    assert _maxabs(back, full_g) < 1e-9 * np.abs(full_g).max()          # g_S + sum B g_rho / D = g_xi
+
+
+def test_dense_depth_gradient_vs_torch_twin_random(oracle64):
+    """the same identity on random cases against autograd through the torch twin"""
+    import torch
+    from oracle import torch_twin as tw
+    from oracle.oracle import default_opts
+    from tightly_coupled_sfm_amd import synth
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    checked = 0
+    for case in range(6):
+        H, W = 14 + 3 * case, 30 + 7 * case
+        p = synth.make_pair(H, W, seed=700 + case, dtype=np.float64)
+        pose = synth.perturb_pose(p["pose_gt"], 700 + case, sigma_t=0.003, sigma_r=0.001)
+        d = T(p["depth_t"])[None, None].clone().requires_grad_()
+        r = tw.photometric(T(p["tgt"])[None], T(p["src"])[None], d, T(p["depth_s"])[None, None], T(pose)[None], T(p["K"])[None])
+        o = oracle64.linearize_dense(p["tgt"], p["src"], p["depth_t"], p["depth_s"], pose, p["K"], default_opts(), lambda_depth=0.0, w_prior=0.0)
+        if float(r["mask"].sum()) != o["n_mask"]:
+            continue
+        tw.masked_cost(r).backward()
+        ref = -d.grad[0, 0].numpy() * p["depth_t"] ** 2
+        assert _maxabs(o["g_rho"], ref) < 1e-9 * np.abs(ref).max(), case
+        checked += 1
+    assert checked >= 4
