@@ -376,3 +376,27 @@ def test_dense_depth_gradient_vs_torch_twin_random(oracle64):
         assert _maxabs(o["g_rho"], ref) < 1e-9 * np.abs(ref).max(), case
         checked += 1
     assert checked >= 4
+
+
+def test_optimization_loss_mirror_on_reference_maps_G5():
+    """losses.compute_optimization_loss (the mirror of optimizer.py:29-134) fed with the REFERENCE's own fwd / inv maps of
+    solve_pose_iteratively (golden G4), in float64 on the CPU: every option toggle reproduces the reference's scalar (G5)
+    -- pins the loss assembly itself (min over sources, union mask, weight-map quirk, 0.25 / 0.15 / 0.1 weights) without a GPU"""
+    import torch
+    from oracle import torch_twin as tw
+    from tightly_coupled_sfm_amd.losses import compute_optimization_loss
+    g = load_golden("batch24x40")
+    S = g["sources"].shape[0]
+    T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    base = {'diff_img_argmin': True, 'automasking': True, 'l_depth_consist': True, 'l_depth_consist_weight': 0.15,
+            'l_depth_init': True, 'l_depth_init_weight': 0.1, 'l_inverse_reconstruction': True, 'l_smooth': False,
+            'l_smooth_weight': 2, 'l_pose_consist': False, 'num_source_imgs': S}
+    for iters in (1, 4):
+        part = lambda d: {k: T(g[f"it{iters}_{d}_{k}"]) for k in ("diff_img", "valid_mask", "weight_mask", "auto_mask_error", "auto_mask", "poses")}
+        fwd, inv = part("fwd"), part("inv")
+        for tag, upd in (("default", {}), ("noargmin", {'diff_img_argmin': False}), ("noauto", {'automasking': False}),
+                         ("noinv", {'l_inverse_reconstruction': False}), ("nodc", {'l_depth_consist': False}),
+                         ("smooth", {'l_smooth': True}), ("posec", {'l_pose_consist': True}), ("noinit", {'l_depth_init': False})):
+            loss = compute_optimization_loss(dict(base, **upd), T(g["target"]), T(g["loss_disp"]), T(g["loss_disp0"]), fwd, inv, tw.ssim)
+            ref = float(g[f"it{iters}_loss_{tag}"])
+            assert abs(float(loss.reshape(-1)[0]) - ref) < 1e-12 * max(1.0, abs(ref)), (iters, tag)
