@@ -246,7 +246,10 @@ def main():
     sd, dep = lh.disp_to_depth(T(disp, torch.float64), 0.06, 2.67)
     l, r_ = rng.uniform(0.1, 1, size=(2, 6, 10)), rng.uniform(0.1, 1, size=(2, 6, 10))
     lst = [T(rng.normal(size=(4, 6)), torch.float32) for _ in range(7)]
-    out["helpers"] = dict(disp=disp, scaled_disp=N(sd), depth=N(dep), l_disp=l, r_disp=r_,
+    # a3: pose_vec2mat / euler2mat on random 6-vectors, incl. large angles (stn.py:81-116,143-158)
+    vec = rng.normal(size=(12, 6)) * np.array([0.1, 0.1, 0.3, 0.02, 0.05, 0.02]) * np.where(np.arange(12)[:, None] < 8, 1.0, 40.0)
+    p2m = N(stn.pose_vec2mat(T(vec, torch.float64)))
+    out["helpers"] = dict(pose_vec=vec, pose_mat=p2m, disp=disp, scaled_disp=N(sd), depth=N(dep), l_disp=l, r_disp=r_,
                           post=lh.batch_post_process_disparity(l, r_), avg_list=np.stack([N(x) for x in lst]),
                           avg5=N(helpers.avg_final_predictions(lst, 5)))
 

@@ -400,3 +400,16 @@ def test_optimization_loss_mirror_on_reference_maps_G5():
             loss = compute_optimization_loss(dict(base, **upd), T(g["target"]), T(g["loss_disp"]), T(g["loss_disp0"]), fwd, inv, tw.ssim)
             ref = float(g[f"it{iters}_loss_{tag}"])
             assert abs(float(loss.reshape(-1)[0]) - ref) < 1e-12 * max(1.0, abs(ref)), (iters, tag)
+
+
+def test_pose_vec2mat_a3(oracle64):
+    """pose_vec2mat / euler2mat (stn.py:81-116,143-158) of the reference on random 6-vectors incl. large angles: the oracle's
+    pose_to_T, the library's host utility and the torch drop-in all reproduce it"""
+    import torch
+    from tightly_coupled_sfm_amd import engine as E, stn
+    g = load_golden("helpers")
+    for v, M in zip(g["pose_vec"], g["pose_mat"]):
+        assert _maxabs(np.asarray(oracle64.pose_to_T(-v)).reshape(3, 4), M) < 1e-14      # pose_to_T(p) == pose_vec2mat(-p), the call sites' form
+        assert _maxabs(E.pose_to_matrix(-v), M) < 1e-14
+        assert _maxabs(E.matrix_to_pose(M), -v) < 1e-9 or abs(v[4]) > 1.5               # inverse map (inside the Euler chart)
+    assert _maxabs(stn.pose_vec2mat(torch.tensor(g["pose_vec"])).numpy(), g["pose_mat"]) < 1e-14
