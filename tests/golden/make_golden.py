@@ -279,6 +279,11 @@ def main():
             g10[f"{dtn}_height"] = N(hts); g10[f"{dtn}_mask"] = N(gm[:, 0].float())
             g10[f"{dtn}_scale"] = N(sr(d_t, K_t, 1.65 / 30.0))
             g10[f"{dtn}_median"] = N(torch.median(torch.masked_select(hts.unsqueeze(1), gm)))
+            # a short batch is padded with copies of image 0 up to the constructor's batch size (dnet_layers.py:307-311)
+            sr5 = dnet_layers.ScaleRecovery(5, H, W)
+            if dt == torch.float64:
+                sr5 = sr5.double()
+            g10[f"{dtn}_scale_pad5"] = N(sr5(d_t, K_t, 1.65 / 30.0))
     finally:
         torch.Tensor.cuda = _cuda
     out["scale48x160"] = g10

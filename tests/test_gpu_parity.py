@@ -356,6 +356,10 @@ def test_scale_recovery_vs_reference_golden(oracle64):
     one = e.scale_recovery(_t(g["depth"][:1, None]), _t(g["K"][:1]), float(g["cam_height"]), pad_to_batch=4)
     s1, m1 = oracle64.scale_recovery(np.repeat(g["depth"][:1], 4, 0), np.repeat(g["K"][:1], 4, 0), float(g["cam_height"]))
     assert abs(float(one) - s1) < 1e-5 * s1
+    # ... and against the reference itself: its batch-size-5 layer fed with this batch of 2
+    pad5 = e.scale_recovery(_t(g["depth"][:, None]), _t(g["K"]), float(g["cam_height"]), pad_to_batch=5)
+    assert abs(float(pad5) - float(g["f32_scale_pad5"][0])) < 1e-5 * float(g["f32_scale_pad5"][0])
+    assert abs(float(g["f32_scale_pad5"][0]) - float(g["f32_scale"][0])) > 0.05           # the padding does change the median
     # no ground at all -> NaN, not garbage
     up = _t(np.full((1, 1, H, W), 0.5, dtype=np.float32))
     assert torch.isnan(_eng(H, W, 1).scale_recovery(up, _t(g["K"][:1]), 0.055))

@@ -180,6 +180,10 @@ def test_scale_recovery_G10(oracle64, oracle32):
             assert np.array_equal(m, g[f"{p}_mask"][b]) and _maxabs(h, g[f"{p}_height"][b]) < tol
         s, med = O.scale_recovery(g["depth"], g["K"], float(g["cam_height"]))
         assert abs(med - float(g[f"{p}_median"])) < tol and abs(s - float(g[f"{p}_scale"][0])) < 10 * tol
+        # a batch of 2 padded to 5 with copies of image 0 (dnet_layers.py:307-311)
+        pad = lambda a: np.concatenate([a, np.repeat(a[:1], 3, 0)])
+        s5, _ = O.scale_recovery(pad(g["depth"]), pad(g["K"]), float(g["cam_height"]))
+        assert abs(s5 - float(g[f"{p}_scale_pad5"][0])) < 10 * tol
 
 
 def test_postprocess_and_averaging_G8():
