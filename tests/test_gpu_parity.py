@@ -953,3 +953,24 @@ def test_fuzz_window_and_dense_vs_oracle(oracle64):
             if dense:
                 assert np.quantile(np.abs(dep[n, 0].cpu().numpy() / rd[n] - 1), 0.995) < tol
     assert loose <= total // 4
+
+
+def test_handles_release_their_memory():
+    """create / use / destroy many handles (all lazily allocated scratch exercised): device memory comes back"""
+    import gc
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W, N = 96, 320, 4
+    w = _window(1, 2, H, W)
+    args = tuple(_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first"))
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(40):
+        e = Engine(H, W, N)
+        e.refine_window(*args, default_opts(n_iters=1), argmin=True)
+        e.refine_dense_window(*args, default_opts(n_iters=1, solver=1, w_dc=0.0, min_depth=0.06, max_depth=2.67), argmin=True)
+        e.scale_recovery(args[2], args[4], 0.055)
+        torch.cuda.synchronize()
+        e.close()
+    gc.collect(); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, (free0, free1)          # 40 leaked handles would hold > 1 GB
