@@ -68,6 +68,13 @@ class Oracle:
     def _d(a):
         return np.ascontiguousarray(a, dtype=np.float64)
 
+    @staticmethod
+    def _forced(bits, decide):
+        """the engine's decision trace (Engine.trace_*) as C arrays: bits uint8 (bit 0 mask, bit 1 warp validity), decide int32"""
+        b = None if bits is None else np.ascontiguousarray(bits, dtype=np.uint8)
+        d = None if decide is None else np.ascontiguousarray(decide, dtype=np.int32)
+        return b, d
+
     # -- SE(3) / pose utilities (double) -----------------------------------
     def pose_to_T(self, pose):
         pose = self._d(pose); T = np.zeros(12)
@@ -110,6 +117,15 @@ class Oracle:
         self.lib.orc_warp(H, W, self._p(src), self._p(depth_t), self._p(depth_s), self._p(T), self._p(K),
                           C.c_double(log_scale), self._p(rec), self._p(va), self._p(pd), self._p(cd))
         return rec, va, pd, cd
+
+    def sample_positions(self, depth_t, pose, K, log_scale=0.0):
+        """grid_sample's un-normalised sample coordinates (ix, iy) [H,W] of every target pixel under `pose` (diagnostic)"""
+        depth_t, K = self._r(depth_t), self._r(K)
+        H, W = depth_t.shape
+        T = self._d(self.pose_to_T(pose)).reshape(12)
+        ix, iy = np.empty((H, W), self.dt), np.empty((H, W), self.dt)
+        self.lib.orc_sample_positions(H, W, self._p(depth_t), self._p(T), self._p(K), C.c_double(log_scale), self._p(ix), self._p(iy))
+        return ix, iy
 
     def ssim(self, x, y):
         x, y = self._r(x), self._r(y)
@@ -174,21 +190,23 @@ class Oracle:
         return dict(H=np.array(out.H[:36]).reshape(6, 6)[:6, :6].copy() if False else np.array([out.H[j * 6 + k] for j in range(6) for k in range(6)]).reshape(6, 6),
                     g=np.array(out.g[:6]), cost=out.cost, n_mask=out.n_mask, g_rho=gr, D=D, B=B)
 
-    def refine_dense(self, tgt, src, depth_t, depth_s, pose, K, opts=None, lambda_depth=1e-2, w_prior=0.0, min_depth=0.06, max_depth=2.67):
-        """-> (pose [6], refined depth [H,W], stats)"""
+    def refine_dense(self, tgt, src, depth_t, depth_s, pose, K, opts=None, lambda_depth=1e-2, w_prior=0.0, min_depth=0.06, max_depth=2.67,
+                     bits=None, decide=None):
+        """-> (pose [6], refined depth [H,W], stats); bits [n_lin,H,W] / decide [n_lin]: replay the engine's decisions"""
         opts = opts or default_opts()
+        bits, decide = self._forced(bits, decide)
         tgt, src, depth_s, K = map(self._r, (tgt, src, depth_s, K))
         depth = self._r(depth_t).copy()
         _, H, W = tgt.shape
         pose = self._d(pose).copy()
         stats = np.zeros((opts.n_iters + 1, 4))
-        self.lib.orc_refine_dense(H, W, self._p(tgt), self._p(src), self._p(depth), self._p(depth_s), self._p(K), C.byref(opts),
-                                  C.c_double(lambda_depth), C.c_double(w_prior), C.c_double(min_depth), C.c_double(max_depth),
-                                  self._p(pose), self._p(stats))
+        self.lib.orc_refine_dense_forced(H, W, self._p(tgt), self._p(src), self._p(depth), self._p(depth_s), self._p(K), C.byref(opts),
+                                         C.c_double(lambda_depth), C.c_double(w_prior), C.c_double(min_depth), C.c_double(max_depth),
+                                         self._p(pose), self._p(stats), self._p(bits), self._p(decide))
         return pose, depth, stats
 
     def refine_dense_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, lambda_depth=1.0, w_prior=10.0,
-                            min_depth=0.06, max_depth=2.67):
+                            min_depth=0.06, max_depth=2.67, bits=None, decide=None):
         """dense window mode: tgt [B,3,H,W], srcs [S,B,3,H,W], depth_t [B,H,W], depth_s [S,B,H,W], poses [2SB,6] ->
         (poses [2SB,6], refined target depth of every directed pair [2SB,H,W], stats [2SB,n_iters+1,4])"""
         opts = opts or default_opts()
@@ -198,9 +216,11 @@ class Oracle:
         ds_pairs = np.ascontiguousarray(np.concatenate([depth_s.reshape(S * B, H, W), np.tile(depth_t, (S, 1, 1))]))   # source depth
         pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(2 * S * B, 6)).copy()
         stats = np.zeros((2 * S * B, opts.n_iters + 1, 4))
-        self.lib.orc_refine_dense_window(H, W, B, S, self._p(tgt), self._p(srcs), self._p(dt_pairs), self._p(ds_pairs), self._p(K),
-                                         C.byref(opts), int(bool(argmin)), C.c_double(lambda_depth), C.c_double(w_prior),
-                                         C.c_double(min_depth), C.c_double(max_depth), self._p(pose), self._p(stats))
+        bits, decide = self._forced(bits, decide)
+        self.lib.orc_refine_dense_window_forced(H, W, B, S, self._p(tgt), self._p(srcs), self._p(dt_pairs), self._p(ds_pairs), self._p(K),
+                                                C.byref(opts), int(bool(argmin)), C.c_double(lambda_depth), C.c_double(w_prior),
+                                                C.c_double(min_depth), C.c_double(max_depth), self._p(pose), self._p(stats),
+                                                self._p(bits), self._p(decide))
         return pose, dt_pairs, stats
 
     def ground_height(self, depth, K):
@@ -231,7 +251,7 @@ class Oracle:
                                    C.byref(opts), self._p(T), None, self._p(mask))
         return mask
 
-    def refine_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, log_scale=None):
+    def refine_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, log_scale=None, bits=None, decide=None):
         """window mode (forward + inverse pairs, optional min-over-sources selection): poses [2*S*B,6] in the stacked
         order of train_mono.py:54-62 -> (poses [2SB,6], log_scale [2SB] or None, stats [2SB,n_iters+1,4])"""
         opts = opts or default_opts()
@@ -240,18 +260,37 @@ class Oracle:
         pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(2 * S * B, 6)).copy()
         ls = None if log_scale is None else np.ascontiguousarray(np.asarray(log_scale, dtype=np.float64)).copy()
         stats = np.zeros((2 * S * B, opts.n_iters + 1, 4))
-        self.lib.orc_refine_window(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
-                                   C.byref(opts), int(bool(argmin)), self._p(pose), self._p(ls), self._p(stats))
+        bits, decide = self._forced(bits, decide)
+        self.lib.orc_refine_window_forced(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
+                                          C.byref(opts), int(bool(argmin)), self._p(pose), self._p(ls), self._p(stats),
+                                          self._p(bits), self._p(decide))
         return pose, ls, stats
 
-    def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
-        """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4])."""
+    def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0, bits=None, decide=None):
+        """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4]).
+        bits [n_lin,H,W] uint8 / decide [n_lin] int32 (n_lin = n_iters, +1 for LM): replay the engine's per-pixel mask / validity
+        and accept decisions instead of taking them here (tie-proof parity, see g_force_bits in tcsfm_oracle.c)."""
         opts = opts or default_opts()
         tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
         _, H, W = tgt.shape
         pose = self._d(pose).copy()
         ls = C.c_double(log_scale)
         stats = np.zeros((opts.n_iters + 1, 4))
-        self.lib.orc_refine(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(K),
-                            C.byref(opts), self._p(pose), C.byref(ls), self._p(stats))
+        bits, decide = self._forced(bits, decide)
+        self.lib.orc_refine_forced(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(K),
+                                   C.byref(opts), self._p(pose), C.byref(ls), self._p(stats), self._p(bits), self._p(decide))
         return pose, ls.value, stats
+
+    def refine_record(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0):
+        """free-running refine that also returns its own decision trace -> (pose, log_scale, stats, bits [n_lin,H,W], decide [n_lin])"""
+        opts = opts or default_opts()
+        tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
+        _, H, W = tgt.shape
+        pose = self._d(pose).copy()
+        ls = C.c_double(log_scale)
+        n_lin = opts.n_iters + (1 if opts.solver == 1 and opts.n_iters > 0 else 0)
+        stats = np.zeros((opts.n_iters + 1, 4))
+        bits = np.zeros((n_lin, H, W), np.uint8); decide = np.zeros(n_lin, np.int32)
+        self.lib.orc_refine_record(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(K),
+                                   C.byref(opts), self._p(pose), C.byref(ls), self._p(stats), self._p(bits), self._p(decide))
+        return pose, ls.value, stats, bits, decide

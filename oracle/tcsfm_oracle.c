@@ -243,6 +243,7 @@ typedef struct {
     real Xp[3];         /* point in the source camera frame                               */
     real p[3];          /* K Xp                                                           */
     int oobx, ooby, zclamp;
+    int adjx, adjy;     /* forced replay only: shift of the bilinear cell (-1, 0, +1) to the one the engine sampled */
 } geo_t;
 
 static void cam_setup(cam_t *c, int H, int W, const real *K, const double T[12], double log_scale) {
@@ -268,6 +269,28 @@ static void cam_setup(cam_t *c, int H, int W, const real *K, const double T[12],
     c->H = H; c->W = W;
 }
 
+/* Forced decisions (parity tests only).  The reference's masks are discontinuous in the pose: a pixel whose error ties with its
+ * auto-mask threshold, or whose projection lands on the image border, to fp32 rounding can be decided differently by the fp32
+ * HIP engine and by this float64 restatement.  The *_forced entry points below replay the ENGINE's decisions -- per pixel and
+ * linearisation: bit 0 = the pixel counts (final mask M, including the min-over-sources selection), bit 1 = the warp is valid
+ * (stn.py:268-269), bits 2 / 3 = parity of the bilinear cell (floor of the sample coordinate ix / iy: the sample VALUE is
+ * continuous across a texel boundary, its derivative -- grid_sample's backward -- is not), bit 4 = [cd - pd > 0] (the sign in
+ * the derivative of the depth-consistency weight, train_mono.py:91), bits 5..7 = [rec_c - tgt_c > 0] of the three colour
+ * channels (the sign in the derivative of the L1 term, train_mono.py:87); per linearisation: the LM accept /
+ * keep decision -- so that the continuous arithmetic can be compared at the north-star tolerance in every case, while the
+ * number of flipped decisions is bounded by a separate assertion. */
+static __thread const unsigned char *g_force_bits = NULL; /* [H*W] of the linearisation being evaluated, or NULL: decide here */
+static __thread unsigned char *g_record_bits = NULL;      /* [H*W]: record the decisions taken here in the same format (CPU self-test) */
+
+/* sign of a quantity whose sign is a discrete decision of the residual's derivative (L1 term: rec - tgt of a channel, bit 5 + c;
+ * depth-consistency term: cd - pd, bit 4).  Replay: within `tie` of zero the engine's recorded sign wins. */
+static inline real forced_sign(real x, real tie, int i, int bit) {
+    real sgn = x > 0 ? (real)1 : (x < 0 ? (real)-1 : (real)0);
+    if (g_force_bits && fabs(x) < tie) sgn = ((g_force_bits[i] >> bit) & 1) ? (real)1 : (real)-1;
+    if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~(1 << bit)) | ((sgn > 0 ? 1 : 0) << bit));
+    return sgn;
+}
+
 /* pixel2cam stn.py:33-48, pose_vec2mat stn.py:143-158, cam2pixel2 stn.py:198-231,
  * grid un-normalisation of F.grid_sample(align_corners=False) stn.py:266 */
 static void warp_geo(const cam_t *c, int u, int v, real depth, geo_t *g) {
@@ -286,15 +309,32 @@ static void warp_geo(const cam_t *c, int u, int v, real depth, geo_t *g) {
     real yn = 2 * (g->p[1] / g->Z) / (real)(c->H - 1) - 1;
     g->oobx = (xn > 1) || (xn < -1);
     g->ooby = (yn > 1) || (yn < -1);
+    if (g_force_bits) { /* replay the engine's validity decision (the sample of an invalid pixel is zero as a whole) */
+        const int valid = (g_force_bits[v * c->W + u] >> 1) & 1;
+        if (valid) g->oobx = g->ooby = 0;
+        else if (!(g->oobx || g->ooby)) g->oobx = g->ooby = 1;
+    }
+    if (g_record_bits) g_record_bits[v * c->W + u] = (unsigned char)((g_record_bits[v * c->W + u] & ~2) | ((g->oobx || g->ooby) ? 0 : 2));
     if (g->oobx) xn = 2; /* stn.py:223-227: OOB sentinel, detached */
     if (g->ooby) yn = 2;
     g->ix = ((xn + 1) * (real)c->W - 1) / 2;
     g->iy = ((yn + 1) * (real)c->H - 1) / 2;
+    g->adjx = g->adjy = 0;
+    if (!(g->oobx || g->ooby)) {
+        const int cx = (int)floor(g->ix), cy = (int)floor(g->iy);
+        if (g_record_bits) g_record_bits[v * c->W + u] = (unsigned char)((g_record_bits[v * c->W + u] & ~12) | ((cx & 1) << 2) | ((cy & 1) << 3));
+        if (g_force_bits) { /* a sample within 1e-4 px of a texel boundary follows the engine's side of it */
+            const int b = g_force_bits[v * c->W + u];
+            const real rx = g->ix - floor(g->ix + (real)0.5), ry = g->iy - floor(g->iy + (real)0.5);
+            if (((cx & 1) != ((b >> 2) & 1)) && fabs(rx) < (real)1e-4) g->adjx = rx >= 0 ? -1 : 1;
+            if (((cy & 1) != ((b >> 3) & 1)) && fabs(ry) < (real)1e-4) g->adjy = ry >= 0 ? -1 : 1;
+        }
+    }
 }
 
 /* bilinear tap with zero padding: value and d/dix, d/diy (grid_sampler_2d fwd/bwd semantics) */
-static void bilinear(const real *img, int H, int W, real ix, real iy, real *val, real *gx, real *gy) {
-    real fx = floor(ix), fy = floor(iy);
+static void bilinear_cell(const real *img, int H, int W, real ix, real iy, int adjx, int adjy, real *val, real *gx, real *gy) {
+    real fx = floor(ix) + (real)adjx, fy = floor(iy) + (real)adjy;   /* adj != 0: the neighbouring cell, weights extrapolated by <= 1e-4 */
     real wx = ix - fx, wy = iy - fy;
     /* far-out sentinel coordinates: avoid int overflow */
     if (!(fx > -4 && fx < W + 4 && fy > -4 && fy < H + 4)) { *val = 0; if (gx) { *gx = 0; *gy = 0; } return; }
@@ -313,6 +353,10 @@ static void bilinear(const real *img, int H, int W, real ix, real iy, real *val,
         *gx = (1 - wy) * (v01 - v00) + wy * (v11 - v10);
         *gy = (1 - wx) * (v10 - v00) + wx * (v11 - v01);
     }
+}
+
+static void bilinear(const real *img, int H, int W, real ix, real iy, real *val, real *gx, real *gy) {
+    bilinear_cell(img, H, W, ix, iy, 0, 0, val, gx, gy);
 }
 
 /* inverse_warp2, stn.py:234-273.  src [3,H,W]; depth_t, depth_s [H,W]; T 3x4; K 3x3.
@@ -338,6 +382,18 @@ void orc_warp(int H, int W, const real *src, const real *depth_t, const real *de
                 proj_depth[i] = c.es * val;
             }
             if (comp_depth) comp_depth[i] = g.Z;
+        }
+}
+
+/* diagnostic: the bilinear sample positions (grid_sample's un-normalised ix, iy) of every target pixel */
+void orc_sample_positions(int H, int W, const real *depth_t, const double T[12], const real *K, double log_scale, real *ix, real *iy) {
+    cam_t c;
+    cam_setup(&c, H, W, K, T, log_scale);
+    for (int v = 0; v < H; v++)
+        for (int u = 0; u < W; u++) {
+            geo_t g;
+            warp_geo(&c, u, v, depth_t[v * W + u], &g);
+            ix[v * W + u] = g.ix; iy[v * W + u] = g.iy;
         }
 }
 
@@ -452,14 +508,43 @@ static void px_eval(const cam_t *c, const real *src, const real *depth_t, const 
     geo_t g;
     int H = c->H, W = c->W;
     warp_geo(c, u, v, depth_t[v * W + u], &g);
-    for (int ch = 0; ch < 3; ch++) bilinear(src + ch * H * W, H, W, g.ix, g.iy, &o->rec[ch], &o->gx[ch], &o->gy[ch]);
+    for (int ch = 0; ch < 3; ch++) bilinear_cell(src + ch * H * W, H, W, g.ix, g.iy, g.adjx, g.adjy, &o->rec[ch], &o->gx[ch], &o->gy[ch]);
     real dval;
-    bilinear(depth_s, H, W, g.ix, g.iy, &dval, &o->dgx, &o->dgy);
+    bilinear_cell(depth_s, H, W, g.ix, g.iy, g.adjx, g.adjy, &dval, &o->dgx, &o->dgy);
     o->pd = c->es * dval; o->dgx *= c->es; o->dgy *= c->es;
     o->cd = g.Z;
     o->valid = !(g.oobx || g.ooby);
     px_jac(c, &g, np, o);
     for (int j = 0; j < np; j++) o->dpd[j] = o->dgx * o->a[j] + o->dgy * o->b[j] + ((j == 6) ? o->pd : 0);
+}
+
+/* diagnostic: quantities at ONE pixel that sit next to a discontinuity of the residual's derivative:
+ * out = [ix, iy, cd - pd, (cd-pd)/(cd+pd), valid, then per channel c: rec_c - tgt_c, raw SSIM value before the clamp] */
+void orc_pixel_debug(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s, const double T[12],
+                     const real *K, int u, int v, double *out) {
+    int n = H * W;
+    cam_t c;
+    cam_setup(&c, H, W, K, T, 0.0);
+    real *rec = (real *)malloc(sizeof(real) * 3 * n);
+    px_t P0;
+    memset(&P0, 0, sizeof(P0));
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            px_t P;
+            px_eval(&c, src, depth_t, depth_s, x, y, 6, &P);
+            for (int ch = 0; ch < 3; ch++) rec[ch * n + y * W + x] = P.rec[ch];
+            if (x == u && y == v) P0 = P;
+        }
+    geo_t g;
+    warp_geo(&c, u, v, depth_t[v * W + u], &g);
+    out[0] = g.ix; out[1] = g.iy; out[2] = P0.cd - P0.pd; out[3] = (P0.cd - P0.pd) / (P0.cd + P0.pd); out[4] = P0.valid;
+    for (int ch = 0; ch < 3; ch++) {
+        ssim_t s;
+        ssim_at(tgt + ch * n, rec + ch * n, H, W, u, v, &s);
+        out[5 + 2 * ch] = rec[ch * n + v * W + u] - tgt[ch * n + v * W + u];
+        out[6 + 2 * ch] = (1 - (s.n1 * s.n2) / (s.d1 * s.d2)) / 2;
+    }
+    free(rec);
 }
 
 /* outputs of one linearisation */
@@ -525,7 +610,7 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
             real sum = P->cd + P->pd, dif = P->cd - P->pd;
             real raw = fabs(dif) / sum;
             real dd = clamp01(raw), Wt = 1 - dd;
-            real sg = (raw >= 0 && raw <= 1) ? (dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0)) : (real)0;
+            real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
             real ddJ[MAXP];
             for (int j = 0; j < np; j++) ddJ[j] = sg * 2 * (P->pd * P->zc[j] - P->cd * P->dpd[j]) / (sum * sum);
             /* photometric rows */
@@ -534,7 +619,7 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
                 const real *x = tgt + ch * n, *y = rec + ch * n;
                 real r = y[i] - x[i], ar = fabs(r);
                 e1 += wl * clamp01(ar);
-                real sgn = (ar <= 1) ? (r > 0 ? (real)1 : (r < 0 ? (real)-1 : (real)0)) : (real)0;
+                real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 5 + ch) : (real)0;
                 for (int j = 0; j < np; j++) de1[j] += wl * sgn * (P->gx[ch] * P->a[j] + P->gy[ch] * P->b[j]);
                 if (ar <= 1) { /* IRLS curvature of the L1 term */
                     real w1 = wl * Wt / (ar > reps ? ar : reps);
@@ -575,6 +660,8 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
             real m = (real)P->valid;
             if (op->automask) m *= (diff < ae[i]) ? (real)1 : (real)0;
             if (mask_in) m = mask_in[i];   /* window mode: the per-pixel min-over-sources selection replaces the pair's own mask */
+            if (g_force_bits) m = (real)(g_force_bits[i] & 1);
+            if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
             M[i] = m; nmask += m;
             E[3 * i] = Wt * e1; E[3 * i + 1] = Wt * e2; E[3 * i + 2] = dd;
             for (int j = 0; j < np; j++) {
@@ -632,6 +719,7 @@ double orc_cost(int H, int W, const real *tgt, const real *src, const real *dept
     double num = 0, den = 0, dc = 0;
     for (int i = 0; i < n; i++) {
         double m = va[i] * (op->automask ? am[i] : 1);
+        if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
         num += m * w[i] * d[i]; den += m; dc += 1 - w[i];
     }
     free(d); free(va); free(w); free(am);
@@ -699,8 +787,25 @@ static void apply_step(const orc_opts *op, const double *Hm, const double *g, do
  * LM  (solver 1): n_iters linearisations with accept/reject on the cost, then one cost-only
  *                 evaluation deciding whether the last step is kept.
  */
-void orc_refine(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
-                const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats) {
+static double cost_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                          const double T[12], const real *K, double log_scale, const orc_opts *op, const real *mask);
+
+/* cost of one pair under the engine's decisions `bits` (see g_force_bits) */
+static double cost_forced(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                          const double T[12], const real *K, double log_scale, const orc_opts *op, const unsigned char *bits) {
+    int n = H * W;
+    real *mk = (real *)malloc(sizeof(real) * n);
+    for (int i = 0; i < n; i++) mk[i] = (real)(bits[i] & 1);
+    g_force_bits = bits;
+    double c = cost_masked(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op, mk);
+    g_force_bits = NULL;
+    free(mk);
+    return c;
+}
+
+static void refine_impl(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats,
+                       const unsigned char *bits, const int *decide, unsigned char *bits_out, int *decide_out) {
     int n = H * W, np = op->nparam;
     real *ae = (real *)malloc(sizeof(real) * n);
     photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
@@ -713,14 +818,19 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
     int have_cur = 0;
     const double s0 = scur, ps = (np == 7) ? op->prior_scale : 0.0;
     for (int it = 0; it < op->n_iters; it++) {
+        g_force_bits = bits ? bits + (size_t)it * n : NULL;
+        g_record_bits = bits_out ? bits_out + (size_t)it * n : NULL;
         orc_linearize(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op, ae, &tr, NULL, NULL, NULL, NULL, NULL);
+        g_force_bits = NULL; g_record_bits = NULL;
         if (np == 7) { /* scale prior: the photometric cost alone cannot separate depth scale from |t| */
             tr.cost += ps * (stry - s0) * (stry - s0);
             tr.g[6] += 2 * ps * (stry - s0);
             tr.H[6 * np + 6] += 2 * ps;
         }
         if (stats) { stats[4 * it] = tr.cost; stats[4 * it + 1] = tr.cost_photo; stats[4 * it + 2] = tr.n_mask; stats[4 * it + 3] = lambda; }
-        if (op->solver == 0 || !have_cur || tr.cost < cur.cost) {
+        const int acc = op->solver == 0 || !have_cur || (decide ? decide[it] != 0 : tr.cost < cur.cost);
+        if (decide_out) decide_out[it] = acc;
+        if (acc) {
             if (op->solver == 1 && have_cur) lambda = fmax(lambda * op->lambda_down, op->lambda_min);
             cur = tr; memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry; have_cur = 1;
         } else {
@@ -729,15 +839,40 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
         apply_step(op, cur.H, cur.g, lambda, Tcur, scur, Ttry, &stry);
     }
     if (op->solver == 1 && op->n_iters > 0) {
-        double c = orc_cost(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op) + ps * (stry - s0) * (stry - s0);
+        g_record_bits = bits_out ? bits_out + (size_t)op->n_iters * n : NULL;
+        double c = (bits ? cost_forced(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op, bits + (size_t)op->n_iters * n)
+                         : orc_cost(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op)) + ps * (stry - s0) * (stry - s0);
+        g_record_bits = NULL;
         if (stats) { int it = op->n_iters; stats[4 * it] = c; stats[4 * it + 1] = c; stats[4 * it + 2] = 0; stats[4 * it + 3] = lambda; }
-        if (c < cur.cost) { memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry; }
+        const int keep = decide ? decide[op->n_iters] != 0 : c < cur.cost;
+        if (decide_out) decide_out[op->n_iters] = keep;
+        if (keep) { memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry; }
     } else {
         memcpy(Tcur, Ttry, sizeof(Tcur)); scur = stry;
     }
     orc_T_to_pose(Tcur, pose_io);
     if (np == 7 && log_scale_io) *log_scale_io = scur;
     free(ae);
+}
+
+/* orc_refine with the engine's decisions replayed: bits [n_lin][H*W] (bit 0 mask, bit 1 warp validity) and decide [n_lin]
+ * (LM: 1 = trial accepted / last step kept), n_lin = n_iters (+1 for LM's final cost check); either may be NULL. */
+void orc_refine_forced(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats,
+                       const unsigned char *bits, const int *decide) {
+    refine_impl(H, W, tgt, src, depth_t, depth_s, K, op, pose_io, log_scale_io, stats, bits, decide, NULL, NULL);
+}
+
+/* free-running refinement that RECORDS its own decisions in the trace format (CPU self-test of the replay mechanism) */
+void orc_refine_record(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats,
+                       unsigned char *bits_out, int *decide_out) {
+    refine_impl(H, W, tgt, src, depth_t, depth_s, K, op, pose_io, log_scale_io, stats, NULL, NULL, bits_out, decide_out);
+}
+
+void orc_refine(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats) {
+    refine_impl(H, W, tgt, src, depth_t, depth_s, K, op, pose_io, log_scale_io, stats, NULL, NULL, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -793,10 +928,13 @@ static double cost_masked(int H, int W, const real *tgt, const real *src, const 
     return (den > 0 ? num / den : 0.0) + op->w_dc * dc / n;
 }
 
-void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+/* bits [n_lin][2SB][H*W], decide [n_lin][2SB] (layout of the engine's trace): see orc_refine_forced.  With bits the
+ * min-over-sources selection is not evaluated here -- bit 0 IS the selected mask. */
+void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, int argmin, double *pose_io /* [2SB][6] */,
-                       double *log_scale_io /* [2SB] or NULL */, double *stats /* [2SB][n_iters+1][4] or NULL */) {
-    const int n = H * W, np = op->nparam, SB = S * B, N = 2 * SB, sel = argmin && S > 1;
+                       double *log_scale_io /* [2SB] or NULL */, double *stats /* [2SB][n_iters+1][4] or NULL */,
+                       const unsigned char *bits, const int *decide) {
+    const int n = H * W, np = op->nparam, SB = S * B, N = 2 * SB, sel = argmin && S > 1 && !bits;
     typedef struct { double Tcur[12], Ttry[12], scur, stry, s0, lambda; lin_t cur; int have_cur; } pstate;
     pstate *ps = (pstate *)calloc(N, sizeof(pstate));
     real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
@@ -826,19 +964,24 @@ void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *
             const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
             double *st = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
             const double prior = pw * (p->stry - p->s0) * (p->stry - p->s0);
+            const unsigned char *fb = bits ? bits + ((size_t)it * N + m) * n : NULL;
+            const int *dec = decide ? decide + (size_t)it * N + m : NULL;
             if (final) { /* LM: cost-only check of the last trial step */
-                double c = (mk ? cost_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, mk)
+                double c = (fb ? cost_forced(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, fb)
+                            : mk ? cost_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, mk)
                                : orc_cost(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op)) + prior;
                 if (st) { st[0] = c; st[1] = c; st[2] = 0; st[3] = p->lambda; }
-                if (c < p->cur.cost) { memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; }
+                if (dec ? *dec != 0 : c < p->cur.cost) { memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; }
                 continue;
             }
             lin_t tr;
+            g_force_bits = fb;
             linearize_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, ae + (size_t)m * n, mk,
                              &tr, NULL, NULL, NULL, NULL, NULL);
+            g_force_bits = NULL;
             if (np == 7) { tr.cost += prior; tr.g[6] += 2 * pw * (p->stry - p->s0); tr.H[6 * np + 6] += 2 * pw; }
             if (st) { st[0] = tr.cost; st[1] = tr.cost_photo; st[2] = tr.n_mask; st[3] = p->lambda; }
-            if (op->solver == 0 || !p->have_cur || tr.cost < p->cur.cost) {
+            if (op->solver == 0 || !p->have_cur || (dec ? *dec != 0 : tr.cost < p->cur.cost)) {
                 if (op->solver == 1 && p->have_cur) p->lambda = fmax(p->lambda * op->lambda_down, op->lambda_min);
                 p->cur = tr; memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; p->have_cur = 1;
             } else {
@@ -853,6 +996,11 @@ void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *
         if (np == 7 && log_scale_io) log_scale_io[m] = ps[m].scur;
     }
     free(ps); free(ae); free(mask); free(Tf); free(lsf); free(pt);
+}
+
+void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, int argmin, double *pose_io, double *log_scale_io, double *stats) {
+    orc_refine_window_forced(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, pose_io, log_scale_io, stats, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -918,6 +1066,8 @@ static void linearize_dense_masked(int H, int W, const real *tgt, const real *sr
             real m = (real)P->valid;
             if (op->automask) m *= (e < ae[i]) ? (real)1 : (real)0;
             if (mask_in) m = mask_in[i];   /* window mode: min-over-sources selection */
+            if (g_force_bits) m = (real)(g_force_bits[i] & 1);
+            if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
             M[i] = m; nmask += m; num += (double)m * Wm[i] * e;
         }
     /* pass 2: exact gradient by scattering every residual's derivative onto the pixels of its window */
@@ -929,12 +1079,12 @@ static void linearize_dense_masked(int H, int W, const real *tgt, const real *sr
             if (am == 0) continue;
             real Wt = Wm[i];
             real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum;
-            real sg = (raw >= 0 && raw <= 1) ? (dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0)) : (real)0;
+            real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
             double lxx = 0, lxy = 0, lyy = 0;
             for (int ch = 0; ch < 3; ch++) {
                 const real *x = tgt + ch * n, *y = rec + ch * n;
                 real r = y[i] - x[i], ar = fabs(r);
-                real sgn = (ar <= 1) ? (r > 0 ? (real)1 : (r < 0 ? (real)-1 : (real)0)) : (real)0;
+                real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 5 + ch) : (real)0;
                 gx_adj[2 * i] += am * Wt * wl * sgn * P->gx[ch];
                 gx_adj[2 * i + 1] += am * Wt * wl * sgn * P->gy[ch];
                 if (ar <= 1) {
@@ -1047,10 +1197,10 @@ static void dense_state_free(dense_state *st) {
 }
 /* after a linearisation `tr` at (Ttry, dep_try) with records in st->gr/Dq/Bq: accept / reject, next trial */
 static void dense_state_step(dense_state *st, const orc_opts *op, const lin_t *tr, double lambda_depth, double min_depth, double max_depth,
-                             double *stats_row) {
+                             double *stats_row, const int *dec) {
     const int n = st->n;
     if (stats_row) { stats_row[0] = tr->cost; stats_row[1] = tr->cost_photo; stats_row[2] = tr->n_mask; stats_row[3] = st->lambda; }
-    if (op->solver == 0 || !st->have_cur || tr->cost < st->cur.cost) {
+    if (op->solver == 0 || !st->have_cur || (dec ? *dec != 0 : tr->cost < st->cur.cost)) {
         if (op->solver == 1 && st->have_cur) st->lambda = fmax(st->lambda * op->lambda_down, op->lambda_min);
         st->cur = *tr; memcpy(st->Tcur, st->Ttry, sizeof(st->Tcur)); st->have_cur = 1;
         memcpy(st->dep_acc, st->dep_try, sizeof(real) * n);
@@ -1074,11 +1224,11 @@ static void dense_state_step(dense_state *st, const orc_opts *op, const lin_t *t
     }
 }
 /* the end: GN keeps the last trial; LM keeps it only if its cost (tr_final) is lower */
-static void dense_state_finish(dense_state *st, const orc_opts *op, const lin_t *tr_final, double pose_out[6], double *stats_row) {
+static void dense_state_finish(dense_state *st, const orc_opts *op, const lin_t *tr_final, double pose_out[6], double *stats_row, const int *dec) {
     int keep = 1;
     if (op->solver == 1 && op->n_iters > 0) {
         if (stats_row) { stats_row[0] = tr_final->cost; stats_row[1] = tr_final->cost_photo; stats_row[2] = tr_final->n_mask; stats_row[3] = st->lambda; }
-        keep = tr_final->cost < st->cur.cost;
+        keep = dec ? *dec != 0 : tr_final->cost < st->cur.cost;
     }
     if (keep) memcpy(st->Tcur, st->Ttry, sizeof(st->Tcur));
     else memcpy(st->dep_try, st->dep_acc, sizeof(real) * st->n);
@@ -1116,10 +1266,11 @@ static void dense_window_select(int H, int W, int B, int S, const real **img, co
     }
 }
 
-void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_src,
+void orc_refine_dense_window_forced(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_src,
                              const real *K, const orc_opts *op, int argmin, double lambda_depth, double w_prior, double min_depth,
-                             double max_depth, double *pose_io /* [2SB][6] */, double *stats /* [2SB][n_iters+1][4] or NULL */) {
-    const int n = H * W, SB = S * B, N = 2 * SB, sel = argmin && S > 1;
+                             double max_depth, double *pose_io /* [2SB][6] */, double *stats /* [2SB][n_iters+1][4] or NULL */,
+                             const unsigned char *bits /* [n_lin][2SB][H*W] */, const int *decide /* [n_lin][2SB] */) {
+    const int n = H * W, SB = S * B, N = 2 * SB, sel = argmin && S > 1 && !bits;
     real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *d0 = (real *)malloc(sizeof(real) * (size_t)n * N);
     real *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
     real *diff = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL, *valid = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL;
@@ -1141,23 +1292,33 @@ void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const 
         for (int m = 0; m < N; m++) {
             const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
             lin_t L;
+            g_force_bits = bits ? bits + ((size_t)it * N + m) * n : NULL;
             linearize_dense_masked(H, W, img[2 * m], img[2 * m + 1], st[m].dep_try, depth_src + (size_t)m * n, st[m].Ttry, Km, op, ae + (size_t)m * n,
                                    (sel && m < SB) ? mask + (size_t)m * n : NULL, lambda_depth, w_prior, d0 + (size_t)m * n, &L, st[m].gr, st[m].Dq, st[m].Bq);
+            g_force_bits = NULL;
             double *row = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
-            if (final) dense_state_finish(&st[m], op, &L, pose_io + 6 * m, row);
-            else dense_state_step(&st[m], op, &L, lambda_depth, min_depth, max_depth, row);
+            const int *dec = decide ? decide + (size_t)it * N + m : NULL;
+            if (final) dense_state_finish(&st[m], op, &L, pose_io + 6 * m, row, dec);
+            else dense_state_step(&st[m], op, &L, lambda_depth, min_depth, max_depth, row, dec);
         }
     }
     for (int m = 0; m < N; m++) {
-        if (!lm_final) dense_state_finish(&st[m], op, NULL, pose_io + 6 * m, NULL);
+        if (!lm_final) dense_state_finish(&st[m], op, NULL, pose_io + 6 * m, NULL, NULL);
         dense_state_free(&st[m]);
     }
     free(ae); free(d0); free(mask); free(diff); free(valid); free(st); free(img);
 }
 
-void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
+void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_src,
+                             const real *K, const orc_opts *op, int argmin, double lambda_depth, double w_prior, double min_depth,
+                             double max_depth, double *pose_io, double *stats) {
+    orc_refine_dense_window_forced(H, W, B, S, tgt, srcs, depth_io, depth_src, K, op, argmin, lambda_depth, w_prior, min_depth, max_depth,
+                                   pose_io, stats, NULL, NULL);
+}
+
+void orc_refine_dense_forced(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
                       const orc_opts *op, double lambda_depth, double w_prior, double min_depth, double max_depth,
-                      double pose_io[6], double *stats) {
+                      double pose_io[6], double *stats, const unsigned char *bits /* [n_lin][H*W] */, const int *decide /* [n_lin] */) {
     int n = H * W;
     real *ae = (real *)malloc(sizeof(real) * n), *d0 = (real *)malloc(sizeof(real) * n);
     memcpy(d0, depth_io, sizeof(real) * n);
@@ -1169,13 +1330,22 @@ void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *dept
         const int final = it == op->n_iters;
         if (final && !lm_final) break;
         lin_t L;
+        g_force_bits = bits ? bits + (size_t)it * n : NULL;
         orc_linearize_dense(H, W, tgt, src, st.dep_try, depth_s, st.Ttry, K, op, ae, lambda_depth, w_prior, d0, &L, st.gr, st.Dq, st.Bq);
-        if (final) dense_state_finish(&st, op, &L, pose_io, stats ? stats + 4 * it : NULL);
-        else dense_state_step(&st, op, &L, lambda_depth, min_depth, max_depth, stats ? stats + 4 * it : NULL);
+        g_force_bits = NULL;
+        const int *dec = decide ? decide + it : NULL;
+        if (final) dense_state_finish(&st, op, &L, pose_io, stats ? stats + 4 * it : NULL, dec);
+        else dense_state_step(&st, op, &L, lambda_depth, min_depth, max_depth, stats ? stats + 4 * it : NULL, dec);
     }
-    if (!lm_final) dense_state_finish(&st, op, NULL, pose_io, NULL);
+    if (!lm_final) dense_state_finish(&st, op, NULL, pose_io, NULL, NULL);
     dense_state_free(&st);
     free(ae); free(d0);
+}
+
+void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
+                      const orc_opts *op, double lambda_depth, double w_prior, double min_depth, double max_depth,
+                      double pose_io[6], double *stats) {
+    orc_refine_dense_forced(H, W, tgt, src, depth_io, depth_s, K, op, lambda_depth, w_prior, min_depth, max_depth, pose_io, stats, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -34,5 +34,11 @@ if lin:
     with open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
     print(traffic)
+# per-kernel HBM traffic (same correction) for every kernel that has the counters: the mode profiles have other dominant kernels
+for k, v in pmc.items():
+    if "FETCH_SIZE" in v:
+        v["hbm_bytes_per_launch"] = int((2 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024)
+with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
+    json.dump(pmc, f, indent=1, sort_keys=True)
 for k, v in pmc.items():
     print(k, {c: round(x, 1) for c, x in sorted(v.items())})

@@ -48,7 +48,9 @@ _SIGNATURES = {
     "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),
     "tcsfm_profile_begin": (C.c_int, [_P]),
     "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
+    "tcsfm_profile_kernel_time": (C.c_int, [_P, _P, _P]),
     "tcsfm_debug_stamps": (C.c_int, [_P, _P]),
+    "tcsfm_debug_trace": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "tcsfm_pose_to_matrix": (None, [_P, _P]),
     "tcsfm_matrix_to_pose": (None, [_P, _P]),
     "tcsfm_se3_exp": (None, [_P, _P]),

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     const float4 *srcpack = P.srcpack + (size_t)n * (H + 2) * (W + 2);   // zero-bordered (tap4)
     const float *depth_t = P.depth_t + (size_t)n * hw;
     const int tid = threadIdx.x;
+    stamp_begin(P.stamp, tid);
 
     // own pixel (tile coordinates) and values carried from phase 1 to phase 2b
     const int oy = tid / TW, ox = tid - oy * TW;
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
             lds_write1(aux + S.ly * W2 + S.lx, Wt, oob ? 0.f : 1.f, S.tp.w, 0.f);
         }
         if (own) {
+            if (P.trace != nullptr && inimg)    // bilinear cell parity now, mask / validity bits in phase 2b
+                P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
+                    (unsigned char)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             geo_jac<7>(c, S.g, W, H, a, b, zc);
             // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
             a[6] *= -S.dep; b[6] *= -S.dep; zc[6] *= -S.dep;
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     __syncthreads();
 
     // ---------------- phase 2a: residual + adjoint coefficients for tile + 1-pixel halo ----------------
+    float o_valid = 0.f;
     float o_diff = 0.f, o_w = 0.f, o_m = 0.f, o_lxx = 0.f, o_lxy = 0.f, o_lyy = 0.f, o_l1x = 0.f, o_l1y = 0.f;
     float o_gx[3] = {0, 0, 0}, o_gy[3] = {0, 0, 0}, o_y[3] = {0, 0, 0}, o_x[3] = {0, 0, 0};
     constexpr int RA = (N1 + NT - 1) / NT;
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         lds_write1(cr + 1, w * cB[1], w * cB[2], w * cC[0], w * cC[1]);
         lds_write1(cr + 2, w * cC[2], 0.f, 0.f, 0.f);
         if (r == 0) {
+            o_valid = ax.y;
             o_diff = diff; o_w = w; o_m = m; o_lxx = lxx; o_lxy = lxy; o_lyy = lyy; o_l1x = l1x; o_l1y = l1y;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) { o_gx[ch] = gxc[ch]; o_gy[ch] = gyc[ch]; o_y[ch] = yc[ch]; o_x[ch] = xc[ch]; }
@@ -212,6 +218,11 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
 #pragma unroll
     for (int i = 0; i < L::NH + NP + 3; i++) v[i] = 0.f;
     if (inimg) {
+        if (P.trace != nullptr) {   // parity tests replay these decisions in the float64 oracle
+            unsigned char *tb = P.trace + (size_t)n * hw + gyo * W + gxo;     // (this thread's own phase-1 byte)
+            *tb = (unsigned char)(*tb | (o_m > 0.f ? 1 : 0) | (o_valid > 0.5f ? 2 : 0) | (o_cd > o_pd ? 16 : 0) | (o_y[0] > o_x[0] ? 32 : 0) |
+                                  (o_y[1] > o_x[1] ? 64 : 0) | (o_y[2] > o_x[2] ? 128 : 0));
+        }
         float lam[3] = {0, 0, 0};
 #pragma unroll 1
         for (int kk = 0; kk < 9; kk++) {
@@ -275,6 +286,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         reinterpret_cast<float4 *>(dr)[1] = make_float4(Bq[2], Bq[3], Bq[4], Bq[5]);
     }
     block_reduce_publish<NP, L::NH + NP + 3, true, false, NT>(P, v, red, n, bid, nblk, tid);
+    stamp_end(P.stamp, tid);
 }
 
 // back-substitution: drho_q = -(g_rho_q + B_q' dxi) / Dd_q ;  rho clamped to [1/max_depth, 1/min_depth]

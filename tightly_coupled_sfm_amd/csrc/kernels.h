@@ -70,7 +70,21 @@ struct LinParams {
     const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
     int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
+    unsigned char *trace;   // tcsfm_debug_trace: [N][H*W] decisions of THIS launch (bit 0 = pixel counts, bit 1 = warp valid,
+                            // bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy), bit 4 = cd > pd, bits 5..7 =
+                            // rec_c > tgt_c), or null
+    unsigned long long *stamp;  // tcsfm_profile_*: [2] = earliest workgroup start / latest workgroup end of THIS launch in
+                                // s_memrealtime ticks (100 MHz), or null.  The launch's duration as the GPU sees it, free of the
+                                // ~2-4 us a HIP event pair adds around a 10 us kernel.
 };
+
+// in-kernel launch bracket (see LinParams::stamp): one 64-bit atomic per workgroup at each end, only while profiling
+__device__ __forceinline__ void stamp_begin(unsigned long long *stamp, int tid) {
+    if (stamp != nullptr && tid == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_end(unsigned long long *stamp, int tid) {
+    if (stamp != nullptr && tid == 0) atomicMax(&stamp[1], (unsigned long long)wall_clock64());
+}
 
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
@@ -712,6 +726,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     const float4 *srcpack = P.srcpack + (size_t)img * (H + 2) * (W + 2);   // zero-bordered (tap4)
     const float *depth_t = P.depth_t + (size_t)img * hw;
     const int tid = threadIdx.x;
+    stamp_begin(P.stamp, tid);
 
     // centre-only values carried in registers from phase 1 to phase 2
     float c_pd[PPT], c_cd[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
@@ -815,6 +830,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
         if (centre) {
             c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
+            if (MODE != MODE_MAPS && P.trace != nullptr && c_in[0])    // bilinear cell parity now, mask / validity bits in phase 2
+                P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
+                    (unsigned char)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
             c_ae[0] = S.tp.w; c_valid[0] = !(S.g.oobx || S.g.ooby);
             if (MODE == MODE_LIN) {
@@ -956,6 +974,12 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             m = inimg && keep && (diff < sel_before) && (diff <= sel_after);
         }
 
+        if (MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
+            unsigned char *tb = P.trace + (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);   // (this thread's own phase-1 byte)
+            *tb = (unsigned char)(*tb | (m ? 1 : 0) | (c_valid[k] ? 2 : 0) | (dif > 0.f ? 16 : 0) | (yc[0] > xc[0] ? 32 : 0) |
+                                  (yc[1] > xc[1] ? 64 : 0) | (yc[2] > xc[2] ? 128 : 0));
+        }
+
         if (MODE == MODE_MAPS) {
             if (inimg) {
                 size_t o = (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
@@ -1040,7 +1064,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             }
         }
     }
-    if (MODE == MODE_MAPS) return;
+    if (MODE == MODE_MAPS) { stamp_end(P.stamp, tid); return; }
 
     // unpack the row-pair accumulators into the triangular layout the reduction / solve kernel use
     float aHP[L::NH], aGP[NP], aHD[DC ? L::NH : 1], aGD[DC ? NP : 1];
@@ -1089,6 +1113,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         v[NLIVE - 3] = sMWd; v[NLIVE - 2] = sM; v[NLIVE - 1] = sdd;
         block_reduce_publish<NP, NLIVE, (MODE == MODE_LIN), DC, NT>(P, v, red, n, bid, nblk, tid);
     }
+    stamp_end(P.stamp, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1110,6 +1135,7 @@ struct SolveParams {
     long long *dbg;                   // diagnostic builds only: s_memrealtime stamps of the solve phases (null in production)
     double *delta_out;                // dense mode: [N][8] pose increment of this iteration for k_dense_update (else null)
     int *accept_out;                  // dense LM: [N] 1 = this launch accepted the trial (mode 0) / kept the last step (mode 1)
+    int *trace_decide;                // tcsfm_debug_trace: [N] the same decision of THIS launch, or null
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -1222,6 +1248,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
         const bool keep = cost < Lc.cost_cur;
         if (P.accept_out && tid == 0) P.accept_out[n] = keep ? 1 : 0;
+        if (P.trace_decide && tid == 0) P.trace_decide[n] = keep ? 1 : 0;
         if (tid < 12) { const double v = keep ? Lc.Ttry[tid] : Lc.Tcur[tid]; Ts[24 + tid] = v; if (keep) S.Tcur[tid] = v; }
         sfin = keep ? Lc.stry : Lc.scur;
         if (tid == 0 && keep) S.scur = sfin;
@@ -1261,6 +1288,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         TC_STAMP(3)
         if (tid == 0) {   // serial part: bookkeeping and the exponential of the step
             if (P.accept_out) P.accept_out[n] = accept ? 1 : 0;
+            if (P.trace_decide) P.trace_decide[n] = accept ? 1 : 0;
             if (accept) { S.scur = sc; S.cost_cur = cost; S.have_cur = 1; }
             S.lambda = lambda;
             if (P.delta_out)

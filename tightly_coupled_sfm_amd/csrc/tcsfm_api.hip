@@ -53,8 +53,13 @@ struct tcsfm_ctx {
     // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
     const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
     int K_checked_n = 0;
+    unsigned char *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
+    int *trace_decide = nullptr;
+    long long trace_bits_cap = 0, trace_decide_cap = 0;
     bool tickets_dirty = false;        // a failed call may have left group tickets non-zero
     bool profiling = false;
+    unsigned long long *stamp_buf = nullptr;   // in-kernel launch brackets of the linearisation launches of a profile session: [cap][2]
+    int stamp_cap = 0, stamp_used = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;
     size_t ev_used = 0;
@@ -176,6 +181,12 @@ struct ProfScope {
     }
 };
 
+// while profiling, hand the next in-kernel stamp slot to a linearisation launch
+void take_stamp(tcsfm_ctx *h, LinParams &P) {
+    P.stamp = nullptr;
+    if (h->profiling && h->stamp_buf && h->stamp_used < h->stamp_cap) P.stamp = h->stamp_buf + 2 * (size_t)(h->stamp_used++);
+}
+
 template <int NP, bool DC, int MODE>
 void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
     dim3 grid(h->nblk, N), block(TILE_NT);
@@ -185,7 +196,9 @@ void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
         hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
 }
 
-void launch_lin(tcsfm_ctx *h, const LinParams &P, int N, int np, bool dc, int mode, int prof_class = 0) {
+void launch_lin(tcsfm_ctx *h, const LinParams &P_in, int N, int np, bool dc, int mode, int prof_class = 0) {
+    LinParams P = P_in;
+    if (prof_class == 0) take_stamp(h, P); else P.stamp = nullptr;
     ProfScope prof(h, prof_class);
     if (np == 6) {
         if (mode == MODE_MAPS) launch_lin_t<6, false, MODE_MAPS>(h, P, N);
@@ -204,6 +217,19 @@ void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
     if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
     else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
+}
+
+// decision trace (tcsfm_debug_trace) of linearisation `lin` of a call over N pairs: [lin][N][H*W] bits, [lin][N] decisions
+void trace_at(const tcsfm_ctx *h, int lin, int N, LinParams &P, SolveParams &S) {
+    const size_t hw = (size_t)h->H * h->W;
+    P.trace = h->trace_bits ? h->trace_bits + (size_t)lin * N * hw : nullptr;
+    S.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
+}
+int trace_check(tcsfm_ctx *h, const tcsfm_opts *o, int N) {
+    const long long n_lin = o->n_iters + (o->solver == TCSFM_SOLVER_LM && o->n_iters > 0 ? 1 : 0);
+    if (h->trace_bits && n_lin * N * (long long)h->H * h->W > h->trace_bits_cap) return fail(h, TCSFM_E_ARG, "tcsfm_debug_trace: bits buffer too small for this call");
+    if (h->trace_decide && n_lin * N > h->trace_decide_cap) return fail(h, TCSFM_E_ARG, "tcsfm_debug_trace: decide buffer too small for this call");
+    return TCSFM_OK;
 }
 
 int np_of(const tcsfm_opts *o) { return o->refine == TCSFM_REFINE_POSE_SCALE ? 7 : 6; }
@@ -357,7 +383,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    void *ptrs[] = {h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
+    void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -634,7 +660,9 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (n_sel) { P.sel_B = win_B; P.sel_S = win_S; }   // min over the sources: evaluated inside k_linearize<SEL>
+    if ((rc = trace_check(h, o, N))) return rc;
     for (int it = 0; it < o->n_iters; it++) {
+        trace_at(h, it, N, P, S);
         launch_lin(h, P, N, np, dc, MODE_LIN);
         S.it = it; S.mode = 0;
         const bool last = !lm && it == o->n_iters - 1;   // the last solve also emits the refined pose
@@ -642,6 +670,7 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         launch_solve(h, S, N, np);
     }
     if (lm && o->n_iters > 0) {  // cost-only pass deciding whether the last step is kept
+        trace_at(h, o->n_iters, N, P, S);
         launch_lin(h, P, N, np, dc, MODE_COST);
         S.it = o->n_iters; S.mode = 1;
         S.pose_out = d_pose_out; S.log_scale_out = d_ls_out;
@@ -798,6 +827,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     };
     auto linearize = [&]() {
         if (n_sel) select_pass();
+        take_stamp(h, P);
         ProfScope prof(h, 0);
         hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
     };
@@ -806,7 +836,9 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     Ul.accept = h->lm_accept; Ul.hw = (int)hw; Ul.rho_lo = U.rho_lo; Ul.rho_hi = U.rho_hi;
     S.accept_out = lm ? h->lm_accept : nullptr;
     const dim3 px_grid((unsigned)((hw + 255) / 256), N);
+    if ((rc = trace_check(h, o, N))) return rc;
     for (int it = 0; it < o->n_iters; it++) {
+        trace_at(h, it, N, P, S);
         linearize();
         S.it = it; S.mode = 0;
         const bool last = !lm && it == o->n_iters - 1;
@@ -816,6 +848,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         else hipLaunchKernelGGL(k_dense_update, px_grid, dim3(256), 0, h->stream, U);
     }
     if (lm && o->n_iters > 0) {   // evaluate the last trial once more; keep it only if it lowered the cost (pose and depth map)
+        trace_at(h, o->n_iters, N, P, S);
         linearize();
         S.it = o->n_iters; S.mode = 1;
         S.pose_out = d_pose_out; S.log_scale_out = nullptr;
@@ -850,6 +883,14 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
     return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
 }
 
+int tcsfm_debug_trace(tcsfm_handle h, uint8_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity) {
+    if (!h) return TCSFM_E_ARG;
+    if ((bits && bits_capacity < 1) || (decide && decide_capacity < 1)) return fail(h, TCSFM_E_ARG, "tcsfm_debug_trace: bad capacity");
+    h->trace_bits = bits; h->trace_bits_cap = bits ? bits_capacity : 0;
+    h->trace_decide = decide; h->trace_decide_cap = decide ? decide_capacity : 0;
+    return TCSFM_OK;
+}
+
 // diagnostic: copy the k_solve phase stamps to the host (8 values; zeros unless TCSFM_DEBUG_STAMPS was set at create)
 int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]) {
     if (!h || !out) return TCSFM_E_ARG;
@@ -862,6 +903,18 @@ int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]) {
 
 int tcsfm_profile_begin(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->stamp_buf) {
+        h->stamp_cap = 8192;
+        HIPCHK(h, hipMalloc((void **)&h->stamp_buf, (size_t)h->stamp_cap * 2 * sizeof(unsigned long long)));
+    }
+    {   // slot = (earliest start, latest end): start at (all ones, 0)
+        std::vector<unsigned long long> init((size_t)h->stamp_cap * 2);
+        for (int i = 0; i < h->stamp_cap; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+        HIPCHK(h, hipMemcpyAsync(h->stamp_buf, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->stamp_used = 0;
     h->profiling = true;
     h->ev_used = 0;
     h->ev_class.clear();
@@ -881,6 +934,18 @@ int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]) {
     }
     h->ev_used = 0;
     h->ev_class.clear();
+    return TCSFM_OK;
+}
+
+int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches) {
+    if (!h || !ms_sum || !launches) return TCSFM_E_ARG;
+    *ms_sum = 0.0; *launches = 0;
+    if (!h->stamp_buf || h->stamp_used == 0) return TCSFM_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> st((size_t)h->stamp_used * 2);
+    HIPCHK(h, hipMemcpy(st.data(), h->stamp_buf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->stamp_used; i++)
+        if (st[2 * i + 1] > st[2 * i]) { *ms_sum += (double)(st[2 * i + 1] - st[2 * i]) * 1e-5; (*launches)++; }   // 100 MHz ticks -> ms
     return TCSFM_OK;
 }
 

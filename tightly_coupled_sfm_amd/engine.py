@@ -97,10 +97,31 @@ class Engine:
         self._call(self.lib.tcsfm_profile_begin(self._h))
 
     def profile_end(self):
-        """-> {'linearize'|'solve'|'pack': (summed ms, launches)}"""
+        """-> {'linearize'|'solve'|'pack': (summed ms, launches) from HIP event pairs,
+               'linearize_kernel': (summed ms, launches) from the in-kernel s_memrealtime bracket of the linearisation launches}"""
         ms = (C.c_double * 3)(); cnt = (C.c_int64 * 3)()
         self._call(self.lib.tcsfm_profile_end(self._h, ms, cnt))
-        return {k: (ms[i], cnt[i]) for i, k in enumerate(("linearize", "solve", "pack"))}
+        out = {k: (ms[i], cnt[i]) for i, k in enumerate(("linearize", "solve", "pack"))}
+        kms = C.c_double(); kn = C.c_int64()
+        self._call(self.lib.tcsfm_profile_kernel_time(self._h, C.byref(kms), C.byref(kn)))
+        out["linearize_kernel"] = (kms.value, kn.value)
+        return out
+
+    def trace_begin(self, n_lin: int, n_pairs: int):
+        """parity-test hook (tcsfm_debug_trace): record the discrete decisions of the following refine* calls -- per
+        linearisation and pair the per-pixel bits (bit 0 mask, bit 1 warp validity) and the LM accept / keep decision"""
+        self._trace = (torch.zeros((n_lin, n_pairs, self.H, self.W), dtype=torch.uint8, device=self.dev),
+                       torch.ones((n_lin, n_pairs), dtype=torch.int32, device=self.dev))
+        b, d = self._trace
+        self._call(self.lib.tcsfm_debug_trace(self._h, self._p(b), b.numel(), self._p(d), d.numel()))
+
+    def trace_end(self):
+        """-> (bits [n_lin,N,H,W] uint8, decide [n_lin,N] int32) as numpy arrays; switches the trace off"""
+        torch.cuda.synchronize(self.device)
+        self._call(self.lib.tcsfm_debug_trace(self._h, None, 0, None, 0))
+        b, d = self._trace
+        self._trace = None
+        return b.cpu().numpy(), d.cpu().numpy()
 
     @property
     def dev(self) -> torch.device:
