@@ -194,21 +194,23 @@ int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]);
 /* The same session's linearisation launches (k_linearize / k_dense_linearize) as the GPU itself timed them: every workgroup
  * stamps s_memrealtime (100 MHz) at its start and end, duration of a launch = latest end - earliest start.  An event pair
  * around a ~10 us kernel reads 2-4 us high (dispatch latency + the event packets); this figure is the one that agrees with
- * rocprofv3's kernel duration.  Call after tcsfm_profile_end; up to 8192 launches per session. */
+ * rocprofv3's kernel duration.  Call after tcsfm_profile_end; launches beyond the stamp buffer (4 M workgroups per session)
+ * are not counted. */
 int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches);
 /* Parity-test hook.  The reference's masks are discontinuous (valid x [diff < auto_err], min over sources; helpers.py:17-19,
  * optimizer.py:47-69) and LM accepts / rejects on a cost comparison: near a tie the fp32 engine and a float64 checker may
  * decide differently.  While a trace is set, every linearisation `lin` of tcsfm_refine* / tcsfm_refine_dense* over N pairs
  * records the engine's decisions into caller-owned DEVICE buffers:
- *   bits   [lin][N][H*W] uint8   bit 0 = the pixel counts (final mask, incl. the min-over-sources selection), bit 1 = warp valid,
+ *   bits   [lin][N][H*W] uint16  bit 0 = the pixel counts (final mask, incl. the min-over-sources selection), bit 1 = warp valid,
  *                                bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy) (grid_sample's backward is
- *                                discontinuous across texel boundaries), bit 4 = [computed depth > projected depth] and
- *                                bits 5..7 = [rec_c > tgt_c] (the signs in the derivatives of |cd - pd| and |rec - tgt|)
+ *                                discontinuous across texel boundaries), bits 4-5 = sign of computed - projected depth,
+ *                                bits 6-7 / 8-9 / 10-11 = sign of rec_c - tgt_c per colour channel (the signs in the derivatives
+ *                                of |cd - pd| and |rec - tgt|; 2-bit codes: 0 exactly zero, 1 positive, 2 negative)
  *   decide [lin][N]      int32   LM: 1 = trial accepted (lin < n_iters) / last step kept (lin == n_iters); GN: 1
  * so that a checker can replay them and compare the continuous arithmetic at full tolerance (tests/test_gpu_parity.py).
  * Capacities in elements; a call that would overflow them returns TCSFM_E_ARG.  Either pointer may be NULL; (NULL, 0, NULL, 0)
  * switches the trace off.  Costs one wave-uniform branch per pixel when off. */
-int tcsfm_debug_trace(tcsfm_handle h, uint8_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity);
+int tcsfm_debug_trace(tcsfm_handle h, uint16_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity);
 /* Diagnostic builds: 100 MHz wall-clock stamps of the phases of the last k_solve launch of pair 0 (zeros unless the
  * handle was created with TCSFM_DEBUG_STAMPS set in the environment). */
 int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]);

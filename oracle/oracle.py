@@ -70,8 +70,8 @@ class Oracle:
 
     @staticmethod
     def _forced(bits, decide):
-        """the engine's decision trace (Engine.trace_*) as C arrays: bits uint8 (bit 0 mask, bit 1 warp validity), decide int32"""
-        b = None if bits is None else np.ascontiguousarray(bits, dtype=np.uint8)
+        """the engine's decision trace (Engine.trace_*) as C arrays: bits uint16 (bit 0 mask, bit 1 warp validity, 2-3 bilinear cell parity, 4-11 sign codes), decide int32"""
+        b = None if bits is None else np.ascontiguousarray(bits, dtype=np.uint16)
         d = None if decide is None else np.ascontiguousarray(decide, dtype=np.int32)
         return b, d
 
@@ -268,7 +268,7 @@ class Oracle:
 
     def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0, bits=None, decide=None):
         """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4]).
-        bits [n_lin,H,W] uint8 / decide [n_lin] int32 (n_lin = n_iters, +1 for LM): replay the engine's per-pixel mask / validity
+        bits [n_lin,H,W] uint16 / decide [n_lin] int32 (n_lin = n_iters, +1 for LM): replay the engine's per-pixel mask / validity
         and accept decisions instead of taking them here (tie-proof parity, see g_force_bits in tcsfm_oracle.c)."""
         opts = opts or default_opts()
         tgt, src, depth_t, depth_s, K = map(self._r, (tgt, src, depth_t, depth_s, K))
@@ -290,7 +290,7 @@ class Oracle:
         ls = C.c_double(log_scale)
         n_lin = opts.n_iters + (1 if opts.solver == 1 and opts.n_iters > 0 else 0)
         stats = np.zeros((opts.n_iters + 1, 4))
-        bits = np.zeros((n_lin, H, W), np.uint8); decide = np.zeros(n_lin, np.int32)
+        bits = np.zeros((n_lin, H, W), np.uint16); decide = np.zeros(n_lin, np.int32)
         self.lib.orc_refine_record(H, W, self._p(tgt), self._p(src), self._p(depth_t), self._p(depth_s), self._p(K),
                                    C.byref(opts), self._p(pose), C.byref(ls), self._p(stats), self._p(bits), self._p(decide))
         return pose, ls.value, stats, bits, decide

@@ -274,20 +274,22 @@ static void cam_setup(cam_t *c, int H, int W, const real *K, const double T[12],
  * HIP engine and by this float64 restatement.  The *_forced entry points below replay the ENGINE's decisions -- per pixel and
  * linearisation: bit 0 = the pixel counts (final mask M, including the min-over-sources selection), bit 1 = the warp is valid
  * (stn.py:268-269), bits 2 / 3 = parity of the bilinear cell (floor of the sample coordinate ix / iy: the sample VALUE is
- * continuous across a texel boundary, its derivative -- grid_sample's backward -- is not), bit 4 = [cd - pd > 0] (the sign in
- * the derivative of the depth-consistency weight, train_mono.py:91), bits 5..7 = [rec_c - tgt_c > 0] of the three colour
- * channels (the sign in the derivative of the L1 term, train_mono.py:87); per linearisation: the LM accept /
+ * continuous across a texel boundary, its derivative -- grid_sample's backward -- is not), bits 4-5 = sign code of cd - pd (the
+ * sign in the derivative of the depth-consistency weight, train_mono.py:91), bits 6-7 / 8-9 / 10-11 = sign codes of
+ * rec_c - tgt_c of the three colour channels (the sign in the derivative of the L1 term, train_mono.py:87), codes: 0 zero,
+ * 1 positive, 2 negative; per linearisation: the LM accept /
  * keep decision -- so that the continuous arithmetic can be compared at the north-star tolerance in every case, while the
  * number of flipped decisions is bounded by a separate assertion. */
-static __thread const unsigned char *g_force_bits = NULL; /* [H*W] of the linearisation being evaluated, or NULL: decide here */
-static __thread unsigned char *g_record_bits = NULL;      /* [H*W]: record the decisions taken here in the same format (CPU self-test) */
+static __thread const unsigned short *g_force_bits = NULL; /* [H*W] of the linearisation being evaluated, or NULL: decide here */
+static __thread unsigned short *g_record_bits = NULL;      /* [H*W]: record the decisions taken here in the same format (CPU self-test) */
 
-/* sign of a quantity whose sign is a discrete decision of the residual's derivative (L1 term: rec - tgt of a channel, bit 5 + c;
- * depth-consistency term: cd - pd, bit 4).  Replay: within `tie` of zero the engine's recorded sign wins. */
-static inline real forced_sign(real x, real tie, int i, int bit) {
+/* sign of a quantity whose sign is a discrete decision of the residual's derivative (L1 term: rec - tgt of a channel; depth-
+ * consistency term: cd - pd), kept as a 2-bit code at `shift`: 0 = exactly zero, 1 = positive, 2 = negative (an exact zero is not
+ * rare in fp32: consistent depth maps give cd == pd bit for bit).  Replay: within `tie` of zero the engine's recorded sign wins. */
+static inline real forced_sign(real x, real tie, int i, int shift) {
     real sgn = x > 0 ? (real)1 : (x < 0 ? (real)-1 : (real)0);
-    if (g_force_bits && fabs(x) < tie) sgn = ((g_force_bits[i] >> bit) & 1) ? (real)1 : (real)-1;
-    if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~(1 << bit)) | ((sgn > 0 ? 1 : 0) << bit));
+    if (g_force_bits && fabs(x) < tie) { const int c = (g_force_bits[i] >> shift) & 3; sgn = c == 1 ? (real)1 : (c == 2 ? (real)-1 : (real)0); }
+    if (g_record_bits) g_record_bits[i] = (unsigned short)((g_record_bits[i] & ~(3 << shift)) | ((sgn > 0 ? 1 : (sgn < 0 ? 2 : 0)) << shift));
     return sgn;
 }
 
@@ -314,7 +316,7 @@ static void warp_geo(const cam_t *c, int u, int v, real depth, geo_t *g) {
         if (valid) g->oobx = g->ooby = 0;
         else if (!(g->oobx || g->ooby)) g->oobx = g->ooby = 1;
     }
-    if (g_record_bits) g_record_bits[v * c->W + u] = (unsigned char)((g_record_bits[v * c->W + u] & ~2) | ((g->oobx || g->ooby) ? 0 : 2));
+    if (g_record_bits) g_record_bits[v * c->W + u] = (unsigned short)((g_record_bits[v * c->W + u] & ~2) | ((g->oobx || g->ooby) ? 0 : 2));
     if (g->oobx) xn = 2; /* stn.py:223-227: OOB sentinel, detached */
     if (g->ooby) yn = 2;
     g->ix = ((xn + 1) * (real)c->W - 1) / 2;
@@ -322,7 +324,7 @@ static void warp_geo(const cam_t *c, int u, int v, real depth, geo_t *g) {
     g->adjx = g->adjy = 0;
     if (!(g->oobx || g->ooby)) {
         const int cx = (int)floor(g->ix), cy = (int)floor(g->iy);
-        if (g_record_bits) g_record_bits[v * c->W + u] = (unsigned char)((g_record_bits[v * c->W + u] & ~12) | ((cx & 1) << 2) | ((cy & 1) << 3));
+        if (g_record_bits) g_record_bits[v * c->W + u] = (unsigned short)((g_record_bits[v * c->W + u] & ~12) | ((cx & 1) << 2) | ((cy & 1) << 3));
         if (g_force_bits) { /* a sample within 1e-4 px of a texel boundary follows the engine's side of it */
             const int b = g_force_bits[v * c->W + u];
             const real rx = g->ix - floor(g->ix + (real)0.5), ry = g->iy - floor(g->iy + (real)0.5);
@@ -619,7 +621,7 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
                 const real *x = tgt + ch * n, *y = rec + ch * n;
                 real r = y[i] - x[i], ar = fabs(r);
                 e1 += wl * clamp01(ar);
-                real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 5 + ch) : (real)0;
+                real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 6 + 2 * ch) : (real)0;
                 for (int j = 0; j < np; j++) de1[j] += wl * sgn * (P->gx[ch] * P->a[j] + P->gy[ch] * P->b[j]);
                 if (ar <= 1) { /* IRLS curvature of the L1 term */
                     real w1 = wl * Wt / (ar > reps ? ar : reps);
@@ -661,7 +663,7 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
             if (op->automask) m *= (diff < ae[i]) ? (real)1 : (real)0;
             if (mask_in) m = mask_in[i];   /* window mode: the per-pixel min-over-sources selection replaces the pair's own mask */
             if (g_force_bits) m = (real)(g_force_bits[i] & 1);
-            if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
+            if (g_record_bits) g_record_bits[i] = (unsigned short)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
             M[i] = m; nmask += m;
             E[3 * i] = Wt * e1; E[3 * i + 1] = Wt * e2; E[3 * i + 2] = dd;
             for (int j = 0; j < np; j++) {
@@ -719,7 +721,7 @@ double orc_cost(int H, int W, const real *tgt, const real *src, const real *dept
     double num = 0, den = 0, dc = 0;
     for (int i = 0; i < n; i++) {
         double m = va[i] * (op->automask ? am[i] : 1);
-        if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
+        if (g_record_bits) g_record_bits[i] = (unsigned short)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
         num += m * w[i] * d[i]; den += m; dc += 1 - w[i];
     }
     free(d); free(va); free(w); free(am);
@@ -790,9 +792,9 @@ static void apply_step(const orc_opts *op, const double *Hm, const double *g, do
 static double cost_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                           const double T[12], const real *K, double log_scale, const orc_opts *op, const real *mask);
 
-/* cost of one pair under the engine's decisions `bits` (see g_force_bits) */
+/* cost of one pair under the engine's decisions `bits` (uint16 per pixel, see g_force_bits) */
 static double cost_forced(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
-                          const double T[12], const real *K, double log_scale, const orc_opts *op, const unsigned char *bits) {
+                          const double T[12], const real *K, double log_scale, const orc_opts *op, const unsigned short *bits) {
     int n = H * W;
     real *mk = (real *)malloc(sizeof(real) * n);
     for (int i = 0; i < n; i++) mk[i] = (real)(bits[i] & 1);
@@ -805,7 +807,7 @@ static double cost_forced(int H, int W, const real *tgt, const real *src, const 
 
 static void refine_impl(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats,
-                       const unsigned char *bits, const int *decide, unsigned char *bits_out, int *decide_out) {
+                       const unsigned short *bits, const int *decide, unsigned short *bits_out, int *decide_out) {
     int n = H * W, np = op->nparam;
     real *ae = (real *)malloc(sizeof(real) * n);
     photo_err_map(H, W, tgt, src, op->w_l1, op->w_ssim, ae);
@@ -859,14 +861,14 @@ static void refine_impl(int H, int W, const real *tgt, const real *src, const re
  * (LM: 1 = trial accepted / last step kept), n_lin = n_iters (+1 for LM's final cost check); either may be NULL. */
 void orc_refine_forced(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats,
-                       const unsigned char *bits, const int *decide) {
+                       const unsigned short *bits, const int *decide) {
     refine_impl(H, W, tgt, src, depth_t, depth_s, K, op, pose_io, log_scale_io, stats, bits, decide, NULL, NULL);
 }
 
 /* free-running refinement that RECORDS its own decisions in the trace format (CPU self-test of the replay mechanism) */
 void orc_refine_record(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, double pose_io[6], double *log_scale_io, double *stats,
-                       unsigned char *bits_out, int *decide_out) {
+                       unsigned short *bits_out, int *decide_out) {
     refine_impl(H, W, tgt, src, depth_t, depth_s, K, op, pose_io, log_scale_io, stats, NULL, NULL, bits_out, decide_out);
 }
 
@@ -933,7 +935,7 @@ static double cost_masked(int H, int W, const real *tgt, const real *src, const 
 void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, int argmin, double *pose_io /* [2SB][6] */,
                        double *log_scale_io /* [2SB] or NULL */, double *stats /* [2SB][n_iters+1][4] or NULL */,
-                       const unsigned char *bits, const int *decide) {
+                       const unsigned short *bits, const int *decide) {
     const int n = H * W, np = op->nparam, SB = S * B, N = 2 * SB, sel = argmin && S > 1 && !bits;
     typedef struct { double Tcur[12], Ttry[12], scur, stry, s0, lambda; lin_t cur; int have_cur; } pstate;
     pstate *ps = (pstate *)calloc(N, sizeof(pstate));
@@ -964,7 +966,7 @@ void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const
             const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
             double *st = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
             const double prior = pw * (p->stry - p->s0) * (p->stry - p->s0);
-            const unsigned char *fb = bits ? bits + ((size_t)it * N + m) * n : NULL;
+            const unsigned short *fb = bits ? bits + ((size_t)it * N + m) * n : NULL;
             const int *dec = decide ? decide + (size_t)it * N + m : NULL;
             if (final) { /* LM: cost-only check of the last trial step */
                 double c = (fb ? cost_forced(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, fb)
@@ -1067,7 +1069,7 @@ static void linearize_dense_masked(int H, int W, const real *tgt, const real *sr
             if (op->automask) m *= (e < ae[i]) ? (real)1 : (real)0;
             if (mask_in) m = mask_in[i];   /* window mode: min-over-sources selection */
             if (g_force_bits) m = (real)(g_force_bits[i] & 1);
-            if (g_record_bits) g_record_bits[i] = (unsigned char)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
+            if (g_record_bits) g_record_bits[i] = (unsigned short)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
             M[i] = m; nmask += m; num += (double)m * Wm[i] * e;
         }
     /* pass 2: exact gradient by scattering every residual's derivative onto the pixels of its window */
@@ -1084,7 +1086,7 @@ static void linearize_dense_masked(int H, int W, const real *tgt, const real *sr
             for (int ch = 0; ch < 3; ch++) {
                 const real *x = tgt + ch * n, *y = rec + ch * n;
                 real r = y[i] - x[i], ar = fabs(r);
-                real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 5 + ch) : (real)0;
+                real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 6 + 2 * ch) : (real)0;
                 gx_adj[2 * i] += am * Wt * wl * sgn * P->gx[ch];
                 gx_adj[2 * i + 1] += am * Wt * wl * sgn * P->gy[ch];
                 if (ar <= 1) {
@@ -1269,7 +1271,7 @@ static void dense_window_select(int H, int W, int B, int S, const real **img, co
 void orc_refine_dense_window_forced(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_src,
                              const real *K, const orc_opts *op, int argmin, double lambda_depth, double w_prior, double min_depth,
                              double max_depth, double *pose_io /* [2SB][6] */, double *stats /* [2SB][n_iters+1][4] or NULL */,
-                             const unsigned char *bits /* [n_lin][2SB][H*W] */, const int *decide /* [n_lin][2SB] */) {
+                             const unsigned short *bits /* [n_lin][2SB][H*W] */, const int *decide /* [n_lin][2SB] */) {
     const int n = H * W, SB = S * B, N = 2 * SB, sel = argmin && S > 1 && !bits;
     real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *d0 = (real *)malloc(sizeof(real) * (size_t)n * N);
     real *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
@@ -1318,7 +1320,7 @@ void orc_refine_dense_window(int H, int W, int B, int S, const real *tgt, const 
 
 void orc_refine_dense_forced(int H, int W, const real *tgt, const real *src, real *depth_io, const real *depth_s, const real *K,
                       const orc_opts *op, double lambda_depth, double w_prior, double min_depth, double max_depth,
-                      double pose_io[6], double *stats, const unsigned char *bits /* [n_lin][H*W] */, const int *decide /* [n_lin] */) {
+                      double pose_io[6], double *stats, const unsigned short *bits /* [n_lin][H*W] */, const int *decide /* [n_lin] */) {
     int n = H * W;
     real *ae = (real *)malloc(sizeof(real) * n), *d0 = (real *)malloc(sizeof(real) * n);
     memcpy(d0, depth_io, sizeof(real) * n);

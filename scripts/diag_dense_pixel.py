@@ -42,6 +42,8 @@ for iters in (1, 2, 3, 4):
                 else:
                     pp, dd = b["pose_init"][n].astype(np.float64), d0[n, 0]
                 T = orc.pose_to_T(pp).reshape(12)
+                lin = orc.linearize_dense(b["tgt"][n], b["src"][n], dd, b["depth_s"][n, 0], pp, b["K"][n], oopts(), lambda_depth=1.0, w_prior=10.0, depth0=d0[n, 0])
+                print(f"      oracle: depth {dd[y, x]:.6f} (range {1/3.0:.3f}..{1/0.03:.1f}) g_rho {lin['g_rho'][y, x]:+.3e} D {lin['D'][y, x]:.3e} step {-lin['g_rho'][y, x] / (2 * lin['D'][y, x] + 1e-300):+.3e} rho {1 / dd[y, x]:.4f}")
                 for dy in (-1, 0, 1):
                     for dx in (-1, 0, 1):
                         yy, xx = min(max(y + dy, 0), H - 1), min(max(x + dx, 0), W - 1)

@@ -41,7 +41,7 @@ def test_replay_obeys_edited_decisions(oracle64):
     a = (b["tgt"][0], b["src"][0], b["depth_t"][0, 0], b["depth_s"][0, 0], b["pose_init"][0], b["K"][0])
     kw = dict(solver=1, lambda0=1e-3, n_iters=5)
     p1, _, s1, bits, dec = oracle64.refine_record(*a, default_opts(**kw))
-    drop = bits.copy(); drop[:, 5:12, 5:30] &= 2                                  # take a block of pixels out of every mask
+    drop = bits.copy(); drop[:, 5:12, 5:30] &= 0xFFFE                                  # take a block of pixels out of every mask
     p2, _, s2 = oracle64.refine(*a, default_opts(**kw), bits=drop, decide=dec)
     assert s2[0, 2] < s1[0, 2] and np.abs(p2 - p1).max() > 1e-6
     inval = bits.copy(); inval[:, 5:12, 5:30] = 0                                 # ... and declare them invalid: their samples become zero,

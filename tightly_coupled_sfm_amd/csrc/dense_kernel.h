@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         if (own) {
             if (P.trace != nullptr && inimg)    // bilinear cell parity now, mask / validity bits in phase 2b
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
-                    (unsigned char)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
+                    (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             geo_jac<7>(c, S.g, W, H, a, b, zc);
             // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
             a[6] *= -S.dep; b[6] *= -S.dep; zc[6] *= -S.dep;
@@ -219,9 +219,9 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     for (int i = 0; i < L::NH + NP + 3; i++) v[i] = 0.f;
     if (inimg) {
         if (P.trace != nullptr) {   // parity tests replay these decisions in the float64 oracle
-            unsigned char *tb = P.trace + (size_t)n * hw + gyo * W + gxo;     // (this thread's own phase-1 byte)
-            *tb = (unsigned char)(*tb | (o_m > 0.f ? 1 : 0) | (o_valid > 0.5f ? 2 : 0) | (o_cd > o_pd ? 16 : 0) | (o_y[0] > o_x[0] ? 32 : 0) |
-                                  (o_y[1] > o_x[1] ? 64 : 0) | (o_y[2] > o_x[2] ? 128 : 0));
+            unsigned short *tb = P.trace + (size_t)n * hw + gyo * W + gxo;     // (this thread's own phase-1 word)
+            *tb = (unsigned short)(*tb | (o_m > 0.f ? 1 : 0) | (o_valid > 0.5f ? 2 : 0) | (sign_code(o_cd - o_pd) << 4) | (sign_code(o_y[0] - o_x[0]) << 6) |
+                                   (sign_code(o_y[1] - o_x[1]) << 8) | (sign_code(o_y[2] - o_x[2]) << 10));
         }
         float lam[3] = {0, 0, 0};
 #pragma unroll 1

@@ -70,20 +70,23 @@ struct LinParams {
     const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
     int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
-    unsigned char *trace;   // tcsfm_debug_trace: [N][H*W] decisions of THIS launch (bit 0 = pixel counts, bit 1 = warp valid,
-                            // bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy), bit 4 = cd > pd, bits 5..7 =
-                            // rec_c > tgt_c), or null
-    unsigned long long *stamp;  // tcsfm_profile_*: [2] = earliest workgroup start / latest workgroup end of THIS launch in
-                                // s_memrealtime ticks (100 MHz), or null.  The launch's duration as the GPU sees it, free of the
-                                // ~2-4 us a HIP event pair adds around a 10 us kernel.
+    unsigned short *trace;  // tcsfm_debug_trace: [N][H*W] decisions of THIS launch (bit 0 = pixel counts, bit 1 = warp valid,
+                            // bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy), bits 4-5 = sign code of cd - pd,
+                            // bits 6-11 = sign codes of rec_c - tgt_c; codes 0 zero / 1 positive / 2 negative), or null
+    unsigned long long *stamp;  // tcsfm_profile_*: [workgroups of this launch][2] = start / end of every workgroup in
+                                // s_memrealtime ticks (100 MHz), or null.  Duration of the launch as the GPU sees it = latest end -
+                                // earliest start (taken on the host), free of the ~2-4 us a HIP event pair adds around a 10 us kernel.
 };
 
-// in-kernel launch bracket (see LinParams::stamp): one 64-bit atomic per workgroup at each end, only while profiling
+__device__ __forceinline__ unsigned sign_code(float x) { return x > 0.f ? 1u : (x < 0.f ? 2u : 0u); }
+
+// in-kernel launch bracket (see LinParams::stamp): one plain 8-byte store per workgroup at each end, only while profiling
+// (an atomic min / max on one word per launch was tried first: 480 workgroups x 2 same-address atomics x ~12 ns = +4 us per launch)
 __device__ __forceinline__ void stamp_begin(unsigned long long *stamp, int tid) {
-    if (stamp != nullptr && tid == 0) atomicMin(&stamp[0], (unsigned long long)wall_clock64());
+    if (stamp != nullptr && tid == 0) stamp[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)] = (unsigned long long)wall_clock64();
 }
 __device__ __forceinline__ void stamp_end(unsigned long long *stamp, int tid) {
-    if (stamp != nullptr && tid == 0) atomicMax(&stamp[1], (unsigned long long)wall_clock64());
+    if (stamp != nullptr && tid == 0) stamp[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = (unsigned long long)wall_clock64();
 }
 
 constexpr float SSIM_C1 = 0.01f * 0.01f;
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
             if (MODE != MODE_MAPS && P.trace != nullptr && c_in[0])    // bilinear cell parity now, mask / validity bits in phase 2
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
-                    (unsigned char)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
+                    (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
             c_ae[0] = S.tp.w; c_valid[0] = !(S.g.oobx || S.g.ooby);
             if (MODE == MODE_LIN) {
@@ -975,9 +978,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
 
         if (MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
-            unsigned char *tb = P.trace + (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);   // (this thread's own phase-1 byte)
-            *tb = (unsigned char)(*tb | (m ? 1 : 0) | (c_valid[k] ? 2 : 0) | (dif > 0.f ? 16 : 0) | (yc[0] > xc[0] ? 32 : 0) |
-                                  (yc[1] > xc[1] ? 64 : 0) | (yc[2] > xc[2] ? 128 : 0));
+            unsigned short *tb = P.trace + (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);   // (this thread's own phase-1 word)
+            *tb = (unsigned short)(*tb | (m ? 1 : 0) | (c_valid[k] ? 2 : 0) | (sign_code(dif) << 4) | (sign_code(yc[0] - xc[0]) << 6) |
+                                   (sign_code(yc[1] - xc[1]) << 8) | (sign_code(yc[2] - xc[2]) << 10));
         }
 
         if (MODE == MODE_MAPS) {

@@ -53,13 +53,14 @@ struct tcsfm_ctx {
     // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
     const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
     int K_checked_n = 0;
-    unsigned char *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
+    unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
     int *trace_decide = nullptr;
     long long trace_bits_cap = 0, trace_decide_cap = 0;
     bool tickets_dirty = false;        // a failed call may have left group tickets non-zero
     bool profiling = false;
-    unsigned long long *stamp_buf = nullptr;   // in-kernel launch brackets of the linearisation launches of a profile session: [cap][2]
-    int stamp_cap = 0, stamp_used = 0;
+    unsigned long long *stamp_buf = nullptr;   // in-kernel workgroup stamps of the linearisation launches of a profile session
+    size_t stamp_cap = 0, stamp_used = 0;      // capacity / use in (start, end) pairs
+    std::vector<std::pair<size_t, size_t>> stamp_launch;   // (first pair, workgroups) of every stamped launch
     std::vector<hipEvent_t> ev_pool;
     std::vector<int> ev_class;
     size_t ev_used = 0;
@@ -181,10 +182,14 @@ struct ProfScope {
     }
 };
 
-// while profiling, hand the next in-kernel stamp slot to a linearisation launch
-void take_stamp(tcsfm_ctx *h, LinParams &P) {
+// while profiling, hand the next in-kernel stamp slots (one (start, end) pair per workgroup) to a linearisation launch
+void take_stamp(tcsfm_ctx *h, LinParams &P, size_t workgroups) {
     P.stamp = nullptr;
-    if (h->profiling && h->stamp_buf && h->stamp_used < h->stamp_cap) P.stamp = h->stamp_buf + 2 * (size_t)(h->stamp_used++);
+    if (h->profiling && h->stamp_buf && h->stamp_used + workgroups <= h->stamp_cap) {
+        P.stamp = h->stamp_buf + 2 * h->stamp_used;
+        h->stamp_launch.emplace_back(h->stamp_used, workgroups);
+        h->stamp_used += workgroups;
+    }
 }
 
 template <int NP, bool DC, int MODE>
@@ -198,7 +203,7 @@ void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
 
 void launch_lin(tcsfm_ctx *h, const LinParams &P_in, int N, int np, bool dc, int mode, int prof_class = 0) {
     LinParams P = P_in;
-    if (prof_class == 0) take_stamp(h, P); else P.stamp = nullptr;
+    if (prof_class == 0) take_stamp(h, P, (size_t)h->nblk * N); else P.stamp = nullptr;
     ProfScope prof(h, prof_class);
     if (np == 6) {
         if (mode == MODE_MAPS) launch_lin_t<6, false, MODE_MAPS>(h, P, N);
@@ -827,7 +832,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     };
     auto linearize = [&]() {
         if (n_sel) select_pass();
-        take_stamp(h, P);
+        take_stamp(h, P, (size_t)nblk * N);
         ProfScope prof(h, 0);
         hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
     };
@@ -883,7 +888,7 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
     return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
 }
 
-int tcsfm_debug_trace(tcsfm_handle h, uint8_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity) {
+int tcsfm_debug_trace(tcsfm_handle h, uint16_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity) {
     if (!h) return TCSFM_E_ARG;
     if ((bits && bits_capacity < 1) || (decide && decide_capacity < 1)) return fail(h, TCSFM_E_ARG, "tcsfm_debug_trace: bad capacity");
     h->trace_bits = bits; h->trace_bits_cap = bits ? bits_capacity : 0;
@@ -905,16 +910,11 @@ int tcsfm_profile_begin(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->stamp_buf) {
-        h->stamp_cap = 8192;
-        HIPCHK(h, hipMalloc((void **)&h->stamp_buf, (size_t)h->stamp_cap * 2 * sizeof(unsigned long long)));
-    }
-    {   // slot = (earliest start, latest end): start at (all ones, 0)
-        std::vector<unsigned long long> init((size_t)h->stamp_cap * 2);
-        for (int i = 0; i < h->stamp_cap; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
-        HIPCHK(h, hipMemcpyAsync(h->stamp_buf, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->stamp_cap = (size_t)4 << 20;     // 4 M workgroup stamps = 64 MB: ~8000 launches of the BASELINE config
+        HIPCHK(h, hipMalloc((void **)&h->stamp_buf, h->stamp_cap * 2 * sizeof(unsigned long long)));
     }
     h->stamp_used = 0;
+    h->stamp_launch.clear();
     h->profiling = true;
     h->ev_used = 0;
     h->ev_class.clear();
@@ -942,10 +942,13 @@ int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches)
     *ms_sum = 0.0; *launches = 0;
     if (!h->stamp_buf || h->stamp_used == 0) return TCSFM_OK;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::vector<unsigned long long> st((size_t)h->stamp_used * 2);
+    std::vector<unsigned long long> st(h->stamp_used * 2);
     HIPCHK(h, hipMemcpy(st.data(), h->stamp_buf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int i = 0; i < h->stamp_used; i++)
-        if (st[2 * i + 1] > st[2 * i]) { *ms_sum += (double)(st[2 * i + 1] - st[2 * i]) * 1e-5; (*launches)++; }   // 100 MHz ticks -> ms
+    for (const auto &l : h->stamp_launch) {     // duration of a launch = latest workgroup end - earliest workgroup start
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (size_t w = l.first; w < l.first + l.second; w++) { t0 = st[2 * w] < t0 ? st[2 * w] : t0; t1 = st[2 * w + 1] > t1 ? st[2 * w + 1] : t1; }
+        if (t1 > t0) { *ms_sum += (double)(t1 - t0) * 1e-5; (*launches)++; }   // 100 MHz ticks -> ms
+    }
     return TCSFM_OK;
 }
 

@@ -109,19 +109,20 @@ class Engine:
 
     def trace_begin(self, n_lin: int, n_pairs: int):
         """parity-test hook (tcsfm_debug_trace): record the discrete decisions of the following refine* calls -- per
-        linearisation and pair the per-pixel bits (bit 0 mask, bit 1 warp validity) and the LM accept / keep decision"""
-        self._trace = (torch.zeros((n_lin, n_pairs, self.H, self.W), dtype=torch.uint8, device=self.dev),
+        linearisation and pair one uint16 per pixel (mask, warp validity, bilinear cell parity, L1 / depth-consistency sign codes:
+        include/tcsfm.h) and the LM accept / keep decision"""
+        self._trace = (torch.zeros((n_lin, n_pairs, self.H, self.W), dtype=torch.int16, device=self.dev),
                        torch.ones((n_lin, n_pairs), dtype=torch.int32, device=self.dev))
         b, d = self._trace
         self._call(self.lib.tcsfm_debug_trace(self._h, self._p(b), b.numel(), self._p(d), d.numel()))
 
     def trace_end(self):
-        """-> (bits [n_lin,N,H,W] uint8, decide [n_lin,N] int32) as numpy arrays; switches the trace off"""
+        """-> (bits [n_lin,N,H,W] uint16, decide [n_lin,N] int32) as numpy arrays; switches the trace off"""
         torch.cuda.synchronize(self.device)
         self._call(self.lib.tcsfm_debug_trace(self._h, None, 0, None, 0))
         b, d = self._trace
         self._trace = None
-        return b.cpu().numpy(), d.cpu().numpy()
+        return b.cpu().numpy().view(np.uint16), d.cpu().numpy()
 
     @property
     def dev(self) -> torch.device:
