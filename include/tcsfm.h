@@ -14,7 +14,11 @@
  *   - pose 6-vector = the reference's [tx,ty,tz,rx,ry,rz] (models/stn.py:143-158).  The warp uses
  *     pose_vec2mat(-pose) exactly like the reference call sites (train_mono.py:69, helpers.py:11).
  *   - intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1] (all of the reference's loaders produce
- *     this form); anything else returns TCSFM_E_INTRINSICS.
+ *     this form); anything else returns TCSFM_E_INTRINSICS: at once for host pointers and for the first use
+ *     of a device buffer (one small blocking copy), and -- when the CONTENTS of an already validated device
+ *     buffer change behind the library's back -- from a device-side guard: that call's results are NaN and
+ *     the error is returned by the next call on the handle or by tcsfm_synchronize().
+ *   - every entry point runs on the handle's device and restores the caller's current device on return.
  *   - pointers are DEVICE pointers unless tcsfm_opts.host_ptrs != 0, in which case the library stages
  *     them through its own device buffers (PCIe-inclusive path).
  *   - every call is asynchronous on the handle's HIP stream when given device pointers, except that

@@ -1,0 +1,30 @@
+"""dense mode timings (BASELINE config 5): per call and per k_dense_linearize launch (in-kernel bracket), B=1 and chip-full"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tightly_coupled_sfm_amd import synth
+from tightly_coupled_sfm_amd.engine import Engine, default_opts
+
+def run(H, W, npairs, steps):
+    b = synth.make_batch(2, H, W, seed0=0, both_directions=True)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    if npairs > 2:
+        d = {k: v.repeat((npairs // 2,) + (1,) * (v.dim() - 1)).contiguous() for k, v in d.items()}
+    e = Engine(H, W, npairs)
+    o = default_opts(n_iters=4, min_depth=0.03, max_depth=3.0)
+    step = lambda: e.refine_dense(d["tgt"], d["src"], d["depth_t"], d["depth_s"], d["K"], d["pose_init"], o)
+    for _ in range(max(3, steps // 10)): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    e.profile_begin()
+    for _ in range(min(steps, 50)): step()
+    pr = e.profile_end()
+    lin = pr["linearize_kernel"][0] / max(pr["linearize_kernel"][1], 1) * 1e3
+    print(json.dumps({"tile": os.environ.get("TCSFM_DENSE_TILE", "32"), "HxW": f"{H}x{W}", "pairs": npairs, "us_per_call": round(dt * 1e6, 1),
+                      "windows_per_s": round(npairs / 2 / dt, 1), "k_dense_linearize_us": round(lin, 2),
+                      "GBps_alg36": round(36 * H * W * npairs / lin / 1e3, 1), "Gpx_per_s": round(H * W * npairs / lin / 1e3, 2)}), flush=True)
+
+for H, W in ((240, 320), (256, 448)):
+    run(H, W, 2, 300)
+    run(H, W, 64, 30)

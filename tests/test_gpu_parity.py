@@ -560,6 +560,37 @@ def test_host_pointer_calls_match_device_pointer_calls():
     assert np.array_equal(out_h, out_d.cpu().numpy())
 
 
+def test_intrinsics_changed_in_place_are_caught_on_the_device():
+    """the host validates a device intrinsics buffer once per (pointer, count); when its CONTENTS later become non-pinhole the
+    device-side guard poisons that call's results with NaN and the next call / synchronize reports TCSFM_E_INTRINSICS -- for the
+    refinement (init_pair) and for the scale recovery (k_ground) alike"""
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W, N = 24, 40, 2
+    b = _pairs(N, H, W, seed0=1)
+    e = _eng(H, W, N)
+    d = _dev(b); p0 = _t(b["pose_init"])
+    K = d[4].clone()
+    good, _, _ = e.refine(d[0], d[1], d[2], d[3], K, p0, default_opts(n_iters=2))          # validates and caches this buffer
+    Kgood = K.clone()
+    K[:, 0, 1] = 0.5                                                                        # same address, skewed now
+    bad, _, _ = e.refine(d[0], d[1], d[2], d[3], K, p0, default_opts(n_iters=2))           # asynchronous: no error yet
+    with pytest.raises(RuntimeError, match="pinhole"):
+        e.synchronize()
+    assert torch.isnan(bad).all()
+    K.copy_(Kgood)
+    again, _, _ = e.refine(d[0], d[1], d[2], d[3], K, p0, default_opts(n_iters=2))         # the handle is healthy afterwards
+    e.synchronize()
+    assert torch.equal(again, good)
+    # scale recovery: k_ground consumes K directly
+    depth = d[2]
+    s0 = e.scale_recovery(depth, K, 0.055)
+    K[:, 1, 0] = 0.25
+    s1 = e.scale_recovery(depth, K, 0.055)
+    with pytest.raises(RuntimeError, match="pinhole"):
+        e.synchronize()
+    assert torch.isnan(s1).all() and torch.isfinite(s0).all()
+
+
 def test_argument_errors_are_codes_not_crashes():
     """errors never cross the ABI as exceptions or faults: negative return code + tcsfm_last_error (SURVEY 8b 'Errors')"""
     import ctypes as C

@@ -34,6 +34,26 @@ def test_metrics_properties():
     assert 3.5 < errs[2] < 5.5 and errs[3] < 0.02 and errs[0] > 1.0      # (curved path: chord error < arc-length scale error)
 
 
+def test_metric_definitions_on_a_hand_computed_case():
+    """mean_err is the MEAN of the per-frame error norms, rms_err their RMSE; numbers worked out by hand: ground truth at rest,
+    estimates displaced by 0, 3, 4 units along x and rotated by 0, 0.1, 0.2 rad about z"""
+    from tightly_coupled_sfm_amd.trajectory import TrajectoryMetrics, error_norms, mean_err, rms_err
+    def T(tx, rz):
+        M = np.eye(4); c, s = np.cos(rz), np.sin(rz)
+        M[:2, :2] = [[c, -s], [s, c]]; M[0, 3] = tx
+        return M
+    gt = [np.eye(4)] * 3
+    est = [T(0.0, 0.0), T(3.0, 0.1), T(4.0, 0.2)]
+    e = error_norms(gt, est)
+    assert np.allclose(e[:, 0], [0, 3, 4]) and np.allclose(e[:, 1], [0, 0.1, 0.2], atol=1e-12)
+    mt, mr = mean_err(gt, est)
+    assert abs(mt - 7.0 / 3.0) < 1e-12 and abs(mr - 0.1) < 1e-12
+    rt, rr = rms_err(gt, est)
+    assert abs(rt - np.sqrt(25.0 / 3.0)) < 1e-12 and abs(rr - np.sqrt(0.05 / 3.0)) < 1e-12
+    tm = TrajectoryMetrics(gt, est)
+    assert np.allclose(tm.mean_err(), (mt, mr)) and np.allclose(tm.rms_err(), (rt, rr)) and rt > mt
+
+
 def test_reference_style_trajectory_code_runs_on_the_stand_ins():
     """the body of the reference's compute_trajectory (validate.py:61-91) written against liegroups.SE3 and
     pyslam TrajectoryMetrics, executed with this package's stand-ins for both absent dependencies"""

@@ -21,7 +21,25 @@ struct DenseParams {
     const float *depth0;    // [N][H*W]     initial depth (prior centre)
     float lambda_depth;     // Marquardt damping of the depth block
     float w_prior;          // weight of the masked prior  w sum M ((rho - rho0)/rho0)^2 / sum M
+    // Fused back-substitution (Gauss-Newton, pair form): the depth map this linearisation works on is the PREVIOUS iteration's map
+    // (LinParams::depth_t) advanced on the fly by the previous iteration's per-pixel records and pose step -- the arithmetic of
+    // k_dense_update, evaluated for the tile and its halo -- and written once, for the tile's own pixels, to depth_next.  Saves
+    // one launch per iteration (5 us + a kernel boundary of a ~25 us iteration at B=1).  prev_rec == nullptr: first iteration.
+    const float *prev_rec;      // [N][H*W][8] records of the previous linearisation (a different buffer than dense_rec)
+    const double *prev_delta;   // [N][8] pose step of the previous iteration (written by k_solve)
+    float *depth_next;          // [N][H*W] the advanced depth map (a different buffer than LinParams::depth_t), or nullptr
+    float rho_lo, rho_hi;       // clamp of the inverse depth: 1/max_depth, 1/min_depth
 };
+
+// back-substitution of one pixel: drho = -(g_rho + B' dxi) / Dd ; rho clamped to [rho_lo, rho_hi]  (shared by the fused form in
+// k_dense_linearize and by k_dense_update, so that both produce the same bits)
+__device__ __forceinline__ float dense_advance(float dep, const float4 &r0, const float4 &r1, const float *d, float rho_lo, float rho_hi) {
+    if (!(r0.y > 0.f)) return dep;
+    float bd = r0.z * d[0] + r0.w * d[1] + r1.x * d[2] + r1.y * d[3] + r1.z * d[4] + r1.w * d[5];
+    float rho = 1.f / dep - (r0.x + bd) / r0.y;
+    rho = fminf(fmaxf(rho, rho_lo), rho_hi);
+    return 1.f / rho;
+}
 
 template <int TW, int TH, int NT>
 __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DenseParams Dn) {
@@ -67,13 +85,24 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     constexpr int NRING = N2 - NCEN;
     static_assert(NRING <= NT, "one ring round");
     constexpr int RING_THREADS = (NRING + 63) / 64 * 64;
-    struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
+    struct Stage { int lx, ly, px, py; float4 tp; float dep; float4 r0, r1; Geo g; Tap t; };
+    const bool fused = Dn.prev_rec != nullptr;      // wave-uniform
+    float dstep[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (fused) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) dstep[j] = (float)Dn.prev_delta[n * 8 + j];
+    }
     auto s_load = [&](Stage &S) {
         S.px = refl_idx(x00 + S.lx - 2, W); S.py = refl_idx(y00 + S.ly - 2, H);
         const int gi = S.py * W + S.px;
         S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+        if (fused) {
+            const float4 *r = reinterpret_cast<const float4 *>(Dn.prev_rec + ((size_t)n * hw + gi) * 8);
+            S.r0 = r[0]; S.r1 = r[1];
+        }
     };
     auto s_warp = [&](Stage &S) {
+        if (fused) S.dep = dense_advance(S.dep, S.r0, S.r1, dstep, Dn.rho_lo, Dn.rho_hi);
         warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
         tap4_fetch(srcpack, W, H, S.px, S.py, S.g.rx, S.g.ry, S.g.oobx || S.g.ooby, S.t);
     };
@@ -91,6 +120,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
             lds_write1(aux + S.ly * W2 + S.lx, Wt, oob ? 0.f : 1.f, S.tp.w, 0.f);
         }
         if (own) {
+            if (Dn.depth_next != nullptr && inimg) Dn.depth_next[(size_t)n * hw + (size_t)S.py * W + S.px] = S.dep;
             if (P.trace != nullptr && inimg)    // bilinear cell parity now, mask / validity bits in phase 2b
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
@@ -223,21 +253,30 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
             *tb = (unsigned short)(*tb | (o_m > 0.f ? 1 : 0) | (o_valid > 0.5f ? 2 : 0) | (sign_code(o_cd - o_pd) << 4) | (sign_code(o_y[0] - o_x[0]) << 6) |
                                    (sign_code(o_y[1] - o_x[1]) << 8) | (sign_code(o_y[2] - o_x[2]) << 10));
         }
-        float lam[3] = {0, 0, 0};
+        // reflect-pad multiplicity: how many window slots of residual pixel p map to this pixel q (losses.py:22).  It differs from 1
+        // only next to the image border and factorises into a column and a row factor: formed ONCE per pixel (the first version
+        // evaluated four compares and two selects per neighbour -- a third of the gather's instructions).
+        const float mxl = (gxo == 1) ? 2.f : 1.f, mxr = (gxo == W - 2) ? 2.f : 1.f;
+        const float myu = (gyo == 1) ? 2.f : 1.f, myd = (gyo == H - 2) ? 2.f : 1.f;
+        const float yq[3] = {o_y[0] - 0.5f, o_y[1] - 0.5f, o_y[2] - 0.5f}, xq[3] = {o_x[0] - 0.5f, o_x[1] - 0.5f, o_x[2] - 0.5f};
+        float sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0}, sC[3] = {0, 0, 0};     // multiplicity-weighted sums of the 9 coefficient records
 #pragma unroll 1
-        for (int kk = 0; kk < 9; kk++) {
-            const int dy = kk / 3 - 1, dx = kk - (kk / 3) * 3 - 1;
-            const int pxx = gxo + dx, pyy = gyo + dy;
-            // reflect-pad multiplicity: how many window slots of residual pixel p map to this pixel q (losses.py:22)
-            int mult = (1 + ((gxo == 1 && pxx == 0) || (gxo == W - 2 && pxx == W - 1) ? 1 : 0)) *
-                       (1 + ((gyo == 1 && pyy == 0) || (gyo == H - 2 && pyy == H - 1) ? 1 : 0));
-            float4 c0, c1, c2;
-            lds_read3(coef + ((oy + 1 + dy) * W1 + ox + 1 + dx) * 3, c0, c1, c2);
-            const float fm = (float)mult;
-            const float cA[3] = {c0.x, c0.y, c0.z}, cB[3] = {c0.w, c1.x, c1.y}, cC[3] = {c1.z, c1.w, c2.x};
+        for (int r = 0; r < 3; r++) {                      // rows rolled (a full unroll keeps all 27 LDS reads live: 172 VGPRs)
+            const float fy = r == 0 ? myu : (r == 2 ? myd : 1.f);
+            const float4 *row = coef + ((oy + r) * W1 + ox) * 3;
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) lam[ch] += fm * (cA[ch] + cB[ch] * (o_y[ch] - 0.5f) + cC[ch] * (o_x[ch] - 0.5f));
+            for (int cx = 0; cx < 3; cx++) {
+                float4 c0, c1, c2;
+                lds_read3(row + cx * 3, c0, c1, c2);
+                const float fm = (cx == 0 ? mxl : (cx == 2 ? mxr : 1.f)) * fy;
+                sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
+                sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
+                sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
+            }
         }
+        float lam[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) lam[ch] = sA[ch] + sB[ch] * yq[ch] + sC[ch] * xq[ch];
         // d C / d (ix, iy) of this pixel: SSIM adjoint + own L1 term (both carry M W of the residual pixel)
         float sx = o_w * o_l1x, sy = o_w * o_l1y;
 #pragma unroll
@@ -293,7 +332,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
 struct DenseUpdateParams {
     const float *dense_rec;   // [N][H*W][8]
     const double *delta;      // [N][8] pose increment of this iteration (written by k_solve)
-    float *depth;             // [N][H*W] in/out
+    const float *depth;       // [N][H*W] in
+    float *depth_out;         // [N][H*W] out (may be the same buffer)
     int hw;
     float rho_lo, rho_hi;
 };
@@ -303,14 +343,11 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdateParams P) {
     int n = blockIdx.y;
     if (idx >= P.hw) return;
     const float4 *r = reinterpret_cast<const float4 *>(P.dense_rec + ((size_t)n * P.hw + idx) * 8);
-    float4 r0 = r[0], r1 = r[1];
-    if (!(r0.y > 0.f)) return;
-    const double *d = P.delta + n * 8;
-    float bd = r0.z * (float)d[0] + r0.w * (float)d[1] + r1.x * (float)d[2] + r1.y * (float)d[3] + r1.z * (float)d[4] + r1.w * (float)d[5];
-    float dep = P.depth[(size_t)n * P.hw + idx];
-    float rho = 1.f / dep - (r0.x + bd) / r0.y;
-    rho = fminf(fmaxf(rho, P.rho_lo), P.rho_hi);
-    P.depth[(size_t)n * P.hw + idx] = 1.f / rho;
+    const float4 r0 = r[0], r1 = r[1];
+    float d[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) d[j] = (float)P.delta[n * 8 + j];
+    P.depth_out[(size_t)n * P.hw + idx] = dense_advance(P.depth[(size_t)n * P.hw + idx], r0, r1, d, P.rho_lo, P.rho_hi);
 }
 
 // LM variant of the back-substitution: an accepted trial first becomes the accepted state (depth map and per-pixel records),

@@ -275,6 +275,7 @@ struct InitParams {
     int N, shared_image;                // shared_image: all problems read image pair 0 (loss-surface sweep)
     float lambda0;
     int K_mod;                          // window form: pair n uses intrinsics K[n % K_mod] (0: one matrix per pair)
+    int *err;                           // host-mapped status word: set to 1 when a pair's intrinsics are not pinhole (or null)
 };
 
 __device__ inline void init_pair(const InitParams &P, int n) {
@@ -286,8 +287,10 @@ __device__ inline void init_pair(const InitParams &P, int n) {
     for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
     {   // device-side guard of the pinhole contract (the host validates a given intrinsics buffer only once)
         const double *K = S.K;
-        if (K[1] != 0.0 || K[3] != 0.0 || K[6] != 0.0 || K[7] != 0.0 || K[8] != 1.0 || K[0] == 0.0 || K[4] == 0.0)
-            for (int i = 0; i < 6; i++) pose[i] = __longlong_as_double(0x7ff8000000000000LL);  // NaN: fail loudly
+        if (K[1] != 0.0 || K[3] != 0.0 || K[6] != 0.0 || K[7] != 0.0 || K[8] != 1.0 || K[0] == 0.0 || K[4] == 0.0) {
+            for (int i = 0; i < 6; i++) pose[i] = __longlong_as_double(0x7ff8000000000000LL);  // NaN: fail loudly ...
+            if (P.err) *reinterpret_cast<volatile int *>(P.err) = 1;   // ... and report TCSFM_E_INTRINSICS at the next call / synchronize
+        }
     }
     pose_to_T(pose, S.Tcur);
     for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
@@ -309,6 +312,7 @@ struct PackParams {
     const float *tgt, *src, *depth_t, *depth_s;  // planar inputs [N,3,H,W] / [N,1,H,W]
     float4 *tgtpack, *srcpack;
     float *depth_out;                            // [N,H,W] depth_t (converted if depth_is_disp)
+    float *depth_out2;                           // optional second copy of the same (dense mode: the prior centre depth0), or null
     int H, W, N;
     float wl, ws;                                // w_l1/3, w_ssim/3
     int depth_is_disp;
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
         }
     }
     P.depth_out[(size_t)n * hw + idx] = dt;
+    if (P.depth_out2) P.depth_out2[(size_t)n * hw + idx] = dt;
 }
 
 // Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69): from the forward pairs'

@@ -15,6 +15,7 @@ struct GroundParams {
     float *height, *mask; // optional outputs [N][H*W]
     unsigned *keys;       // [N][H*W] float bits of the height where masked, 0xFFFFFFFF elsewhere
     int H, W;
+    int *err;             // host-mapped status word: set to 1 when an image's intrinsics are not pinhole (or null)
 };
 
 __device__ __forceinline__ void bp(const float *depth, int W, float ifx, float icx, float ify, float icy, int v, int u, float *p) {
@@ -34,6 +35,15 @@ __global__ __launch_bounds__(256) void k_ground(GroundParams P) {
     if (idx >= hw) return;
     int v = idx / W, u = idx - v * W;
     const float *K = P.K + n * 9, *depth = P.depth + (size_t)n * hw;
+    if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || K[0] == 0.f || K[4] == 0.f) {
+        // device-side guard of the pinhole contract (the host validates a given device buffer only once): no ground anywhere ->
+        // the median and the scale come out NaN, and the status word turns the next call / synchronize into TCSFM_E_INTRINSICS
+        if (P.err && idx == 0) *reinterpret_cast<volatile int *>(P.err) = 1;
+        if (P.height) P.height[(size_t)n * hw + idx] = __uint_as_float(0x7fc00000u);
+        if (P.mask) P.mask[(size_t)n * hw + idx] = 0.f;
+        P.keys[(size_t)n * hw + idx] = 0xFFFFFFFFu;
+        return;
+    }
     const float ifx = 1.f / K[0], icx = -K[2] / K[0], ify = 1.f / K[4], icy = -K[5] / K[4];
     // normal of the reflect-mapped interior pixel (dnet_layers.py:289-290)
     int rv = v == 0 ? 2 : (v == H - 1 ? H - 3 : v), ru = u == 0 ? 2 : (u == W - 1 ? W - 3 : u);

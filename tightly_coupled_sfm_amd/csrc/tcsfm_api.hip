@@ -42,6 +42,7 @@ struct tcsfm_ctx {
     int tiles_x = 0, tiles_y = 0, nblk = 0, ngrp = 0, ngrp_pad = 0, stats_cap_iters = 0;
     int nblk_alloc = 0, ngrp_alloc = 0;   // scratch capacity (covers the 32x8 tiling of the dense kernel too)
     float *dense_rec = nullptr, *depth0 = nullptr;   // dense mode scratch, allocated on first use
+    float *dense_rec2 = nullptr, *depth_alt = nullptr;   // ... second record / depth buffers of the fused back-substitution (ping-pong)
     float *dense_rec_acc = nullptr, *depth_acc = nullptr;   // dense LM: accepted per-pixel records / depth maps
     int *lm_accept = nullptr;
     double *delta = nullptr;
@@ -51,6 +52,7 @@ struct tcsfm_ctx {
     std::vector<HostStage> stage;
     std::string err;
     // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
+    int *err_host = nullptr, *err_dev = nullptr;   // host-mapped status word of the device-side guards (host / device address)
     const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
     int K_checked_n = 0;
     unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
@@ -68,6 +70,19 @@ struct tcsfm_ctx {
 
 namespace {
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it (a process driving several
+// GPUs from one thread keeps allocating on the device it selected).
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+
 #define HIPCHK(h, call)                                                                              \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
@@ -81,6 +96,17 @@ namespace {
 int fail(tcsfm_ctx *h, int code, const char *msg) {
     h->err = msg;
     return code;
+}
+
+// The device-side pinhole guards (init_pair, k_ground) raise a host-mapped status word; it is reported -- as the documented
+// TCSFM_E_INTRINSICS -- by the next call on the handle or by tcsfm_synchronize, without a device synchronisation of its own.
+int pending_error(tcsfm_ctx *h) {
+    if (h->err_host && *reinterpret_cast<volatile int *>(h->err_host)) {
+        *reinterpret_cast<volatile int *>(h->err_host) = 0;
+        h->K_checked = nullptr;
+        return fail(h, TCSFM_E_INTRINSICS, "an earlier asynchronous call was given non-pinhole intrinsics (detected on the device): its results are NaN");
+    }
+    return TCSFM_OK;
 }
 
 constexpr int kMaxAcc = AccLayout<7>::NACC;
@@ -170,7 +196,9 @@ struct ProfScope {
         if (h->ev_used + 2 > h->ev_pool.size()) {
             size_t old = h->ev_pool.size();
             h->ev_pool.resize(old + 64);
-            for (size_t i = old; i < h->ev_pool.size(); i++) (void)hipEventCreate(&h->ev_pool[i]);
+            for (size_t i = old; i < h->ev_pool.size(); i++)
+                if (hipEventCreate(&h->ev_pool[i]) != hipSuccess) { h->ev_pool.resize(i); break; }   // no event, no bracket
+            if (h->ev_used + 2 > h->ev_pool.size()) { on = false; return; }
         }
         h->ev_class.push_back(cls);
         (void)hipEventRecord(h->ev_pool[h->ev_used], h->stream);
@@ -245,13 +273,15 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
     I.pose = pose; I.log_scale = ls; I.K = K; I.st = h->state; I.pc = h->pconst; I.N = N; I.shared_image = shared;
     I.lambda0 = o->lambda0;
     I.K_mod = 0;
+    I.err = h->err_dev;
     return I;
 }
 
 // init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
 int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
-             const InitParams *init = nullptr, int win_B = 0, int win_S = 0) {
+             const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr) {
     PackParams P;
+    P.depth_out2 = depth_copy;
     memset(&P.init, 0, sizeof(P.init));
     P.win_B = win_B; P.win_S = win_S;
     if (init) {
@@ -349,13 +379,18 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     h->device = device; h->H = H; h->W = W; h->max_pairs = max_pairs;
     h->tiles_x = (W + TILE_W - 1) / TILE_W; h->tiles_y = (H + TILE_H - 1) / TILE_H; h->nblk = h->tiles_x * h->tiles_y;
     h->ngrp = (h->nblk + RG - 1) / RG;
-    h->nblk_alloc = ((W + 31) / 32) * ((H + 7) / 8);
+    h->nblk_alloc = ((W + 15) / 16) * ((H + 15) / 16);   // the finest tiling any kernel uses (dense mode, 16x16)
     if (h->nblk_alloc < h->nblk) h->nblk_alloc = h->nblk;
     h->ngrp_alloc = (h->nblk_alloc + RG - 1) / RG;
     h->ngrp_pad = (h->ngrp_alloc + 63) / 64 * 64;
     size_t hw = (size_t)H * W, n = max_pairs;
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard dev_guard(device);
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess && cur != device) e = hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->err_host, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { *h->err_host = 0; e = hipHostGetDevicePointer((void **)&h->err_dev, h->err_host, 0); }
     h->stream = h->own_stream;
     if (e == hipSuccess) e = hipMalloc((void **)&h->tgtpack, n * hw * sizeof(float4));
     if (e == hipSuccess) e = hipMalloc((void **)&h->srcpack, n * (size_t)(H + 2) * (W + 2) * sizeof(float4));   // zero-bordered
@@ -386,15 +421,16 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
 
 void tcsfm_destroy(tcsfm_handle h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept};
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
         if (s.p) (void)hipFree(s.p);
     for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -402,6 +438,7 @@ void tcsfm_destroy(tcsfm_handle h) {
 int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
     if (!h) return TCSFM_E_ARG;
     h->stream = (hipStream_t)hip_stream;  // NULL = legacy default stream
+    h->K_checked = nullptr;               // a new stream is a new producer of the caller's buffers: validate intrinsics again
     return TCSFM_OK;
 }
 
@@ -413,15 +450,17 @@ int tcsfm_use_own_stream(tcsfm_handle h) {
 
 int tcsfm_synchronize(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
+    DeviceGuard dev_guard(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return TCSFM_OK;
+    return pending_error(h);
 }
 
 int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const float *disp, float *scaled, float *depth) {
     if (!h) return TCSFM_E_ARG;
     if (!o || !disp || n < 1) return fail(h, TCSFM_E_ARG, "tcsfm_disp_to_depth: bad argument");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     const float *d_in; float *d_s, *d_d;
     int rc;
     if ((rc = to_dev(h, o, 0, disp, (size_t)n, &d_in))) return rc;
@@ -439,7 +478,8 @@ int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const fl
 int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, const float *y, float *out) {
     if (!h) return TCSFM_E_ARG;
     if (!o || !x || !y || !out || planes < 1) return fail(h, TCSFM_E_ARG, "tcsfm_ssim: bad argument");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     size_t hw = (size_t)h->H * h->W, n = hw * planes;
     const float *d_x, *d_y; float *d_o;
     int rc;
@@ -458,7 +498,8 @@ int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, con
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_warp: NULL input");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if ((rc = check_intrinsics(h, o, K, N))) return rc;
     size_t hw = (size_t)h->H * h->W;
     const float *d_src, *d_dt, *d_ds, *d_pose, *d_K;
@@ -494,7 +535,8 @@ int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const f
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose || !K || !posenet_in) return fail(h, TCSFM_E_ARG, "tcsfm_warp_posenet_input: NULL argument");
     if (o->depth_is_disp) return fail(h, TCSFM_E_ARG, "tcsfm_warp_posenet_input takes depth maps");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if ((rc = check_intrinsics(h, o, K, N))) return rc;
     size_t hw = (size_t)h->H * h->W;
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K;
@@ -525,7 +567,8 @@ int tcsfm_photometric(tcsfm_handle h, const tcsfm_opts *o, int N, const float *t
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_photometric: NULL input");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if ((rc = check_intrinsics(h, o, K, N))) return rc;
     size_t hw = (size_t)h->H * h->W;
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K;
@@ -578,7 +621,8 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_linearize: NULL input");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if ((rc = check_intrinsics(h, o, K, N))) return rc;
     size_t hw = (size_t)h->H * h->W;
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K, *d_ls;
@@ -606,7 +650,8 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
     int rc = check_common(h, o, P);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !poses || !K || !cost_out) return fail(h, TCSFM_E_ARG, "tcsfm_loss_surface: NULL argument");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if ((rc = check_intrinsics(h, o, K, 1))) return rc;
     size_t hw = (size_t)h->H * h->W;
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_pose, *d_K;
@@ -632,7 +677,8 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
     if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W;
@@ -715,7 +761,8 @@ int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float
     if (rc) return rc;
     if (!depth || !K || !scale_out) return fail(h, TCSFM_E_ARG, "tcsfm_scale_recovery: NULL argument");
     if (h->H < 5 || h->W < 5) return fail(h, TCSFM_E_ARG, "tcsfm_scale_recovery: image too small");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if ((rc = check_intrinsics(h, o, K, N))) return rc;
     const size_t hw = (size_t)h->H * h->W;
     if (!h->scale_keys) {
@@ -732,7 +779,7 @@ int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float
     if ((rc = out_dev(h, o, 5, mask_out, N * hw, &d_m))) return rc;
     HIPCHK(h, hipMemsetAsync(h->scale_hist, 0, 260 * sizeof(unsigned), h->stream));
     GroundParams G;
-    G.depth = d_depth; G.K = d_K; G.height = d_h; G.mask = d_m; G.keys = h->scale_keys; G.H = h->H; G.W = h->W;
+    G.depth = d_depth; G.K = d_K; G.height = d_h; G.mask = d_m; G.keys = h->scale_keys; G.H = h->H; G.W = h->W; G.err = h->err_dev;
     hipLaunchKernelGGL(k_ground, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, G);
     // the reference pads the batch to config['minibatch'] with copies of image 0 (dnet_layers.py:307-311): weight image 0
     const int w0 = 1 + (pad_to_batch > N ? pad_to_batch - N : 0);
@@ -762,7 +809,8 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (o->w_dc > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth)");
     if (o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: SE(3) chart only");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
     if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
@@ -798,9 +846,18 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     oo.refine = TCSFM_REFINE_POSE;
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
     I.K_mod = win_B;
-    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S))) return rc;   // every pair gets its OWN copy of its target's depth
-    HIPCHK(h, hipMemcpyAsync(h->depth0, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    // the dense kernel's own tile grid (same 32x16 / 512 threads as k_linearize today) and reduction-group count
+    // Gauss-Newton in the pair form: the back-substitution of iteration k is fused into the linearisation of iteration k+1 (depth
+    // maps and per-pixel records ping-pong between two buffers); LM rolls maps back and the min over sources needs the current map
+    // materialised before the linearisation, so those keep the separate update launch
+    const bool fuse = !lm && !n_sel && o->n_iters > 0;
+    if (fuse && !h->dense_rec2) {
+        HIPCHK(h, hipMalloc((void **)&h->dense_rec2, n * hw * 8 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->depth_alt, n * hw * sizeof(float)));
+    }
+    // every pair gets its OWN copy of its target's depth; the pack also leaves the prior centre depth0
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, h->depth0))) return rc;
+    // the dense kernel's own tile grid (32x16 tiles of 512 threads, as k_linearize; 16x16 / 256 threads measured slower except
+    // for 320x240 at B=1: 10.9 vs 11.8 us per launch there, 234 vs 200 us with the chip full) and reduction-group count
     constexpr int DTW = 32, DTH = 16, DNT = 512;
     LinParams P = lin_params(h, &oo, 6);
     P.tiles_x = (h->W + DTW - 1) / DTW; P.tiles_y = (h->H + DTH - 1) / DTH;
@@ -813,9 +870,12 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     S.stats = d_stats; S.delta_out = h->delta;
     DenseParams Dn;
     Dn.dense_rec = h->dense_rec; Dn.depth0 = h->depth0; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
+    Dn.prev_rec = nullptr; Dn.prev_delta = h->delta; Dn.depth_next = nullptr;
+    Dn.rho_lo = 1.f / o->max_depth; Dn.rho_hi = 1.f / o->min_depth;
     DenseUpdateParams U;
-    U.dense_rec = h->dense_rec; U.delta = h->delta; U.depth = h->depth_work; U.hw = (int)hw;
-    U.rho_lo = 1.f / o->max_depth; U.rho_hi = 1.f / o->min_depth;
+    U.dense_rec = h->dense_rec; U.delta = h->delta; U.depth = h->depth_work; U.depth_out = h->depth_work; U.hw = (int)hw;
+    U.rho_lo = Dn.rho_lo; U.rho_hi = Dn.rho_hi;
+    float *Dbuf[2] = {h->depth_work, h->depth_alt}, *Rbuf[2] = {h->dense_rec, h->dense_rec2};
     // min over the sources (window form): selection masks of the forward pairs from their residual maps at the current poses
     // AND current depth copies, rebuilt before every linearisation (same two launches as in the pose mode)
     float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
@@ -844,13 +904,22 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if ((rc = trace_check(h, o, N))) return rc;
     for (int it = 0; it < o->n_iters; it++) {
         trace_at(h, it, N, P, S);
+        if (fuse) {   // reads depth_{it-1} + the records / step of iteration it-1, leaves depth_it and the records of iteration it
+            P.depth_t = Dbuf[it & 1]; Dn.depth_next = Dbuf[(it + 1) & 1];
+            Dn.dense_rec = Rbuf[it & 1]; Dn.prev_rec = it > 0 ? Rbuf[(it - 1) & 1] : nullptr;
+        }
         linearize();
         S.it = it; S.mode = 0;
         const bool last = !lm && it == o->n_iters - 1;
         S.pose_out = last ? d_pose_out : nullptr; S.log_scale_out = nullptr;
         launch_solve(h, S, N, 6);
         if (lm) hipLaunchKernelGGL(k_dense_update_lm, px_grid, dim3(256), 0, h->stream, Ul);
-        else hipLaunchKernelGGL(k_dense_update, px_grid, dim3(256), 0, h->stream, U);
+        else if (!fuse) hipLaunchKernelGGL(k_dense_update, px_grid, dim3(256), 0, h->stream, U);
+    }
+    if (fuse) {   // the last back-substitution writes the caller's depth map directly
+        const int nit = o->n_iters;
+        U.dense_rec = Rbuf[(nit - 1) & 1]; U.depth = Dbuf[nit & 1]; U.depth_out = d_depth_out;
+        hipLaunchKernelGGL(k_dense_update, px_grid, dim3(256), 0, h->stream, U);
     }
     if (lm && o->n_iters > 0) {   // evaluate the last trial once more; keep it only if it lowered the cost (pose and depth map)
         trace_at(h, o->n_iters, N, P, S);
@@ -866,7 +935,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = nullptr; F.N = N;
         hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
     }
-    HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (!fuse) HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
     if ((rc = copy_back(h, o, depth_out, d_depth_out, N * hw))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
@@ -908,7 +977,8 @@ int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]) {
 
 int tcsfm_profile_begin(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
-    HIPCHK(h, hipSetDevice(h->device));
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
     if (!h->stamp_buf) {
         h->stamp_cap = (size_t)4 << 20;     // 4 M workgroup stamps = 64 MB: ~8000 launches of the BASELINE config
         HIPCHK(h, hipMalloc((void **)&h->stamp_buf, h->stamp_cap * 2 * sizeof(unsigned long long)));

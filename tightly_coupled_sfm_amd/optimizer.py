@@ -52,14 +52,27 @@ def process_sample_batch(data, config):
     return target, src, gt, vo, flows, K, target_img_aug, src_aug, gt_aug, vo_aug, K_aug
 
 
+_RAMPS = {}
+
+
+def _flip_ramp(w):
+    """blend weight of the flipped prediction along the image width: 1 on the left 5 %, linear down to 0 at 10 %, 0 beyond"""
+    if w not in _RAMPS:
+        x = np.arange(w, dtype=np.float64) / max(w - 1, 1)
+        _RAMPS[w] = np.clip(1.0 - 20.0 * (x - 0.05), 0.0, 1.0)
+    return _RAMPS[w]
+
+
 def batch_post_process_disparity(l_disp, r_disp):
-    """utils/learning_helpers.py:115-123 (Monodepth flip post-processing)."""
-    _, h, w = l_disp.shape
-    m_disp = 0.5 * (l_disp + r_disp)
-    l, _ = np.meshgrid(np.linspace(0, 1, w), np.linspace(0, 1, h))
-    l_mask = (1.0 - np.clip(20 * (l - 0.05), 0, 1))[None, ...]
-    r_mask = l_mask[:, :, ::-1]
-    return r_mask * l_disp + l_mask * r_disp + (1.0 - l_mask - r_mask) * m_disp
+    """Flip post-processing of Monodepth as the reference applies it (utils/learning_helpers.py:115-123): a prediction and the
+    un-flipped prediction of the mirrored image are averaged, except near the left / right border where only the one that saw
+    the scene content beyond that border is kept.  [B,H,W] arrays in, [B,H,W] out."""
+    left = _flip_ramp(l_disp.shape[-1])           # weight of r_disp
+    right = left[::-1]                            # weight of l_disp
+    out = 0.5 * (1.0 - left - right) * (l_disp + r_disp)
+    out += right * l_disp
+    out += left * r_disp
+    return out
 
 
 def avg_final_predictions(pred_list, num):
@@ -172,6 +185,10 @@ class DepthOptimizer:
         res["gt_poses"] = torch.cat(gt_lie_alg_list, 0).cpu() if gt_lie_alg_list[0] is not None else None
         res["gt_poses_inv"] = -res["gt_poses"] if res["gt_poses"] is not None else None
         res["depths_init"] = [d.clone() for d in depths]
+        unscaled = self.options.get("mode", "scaled") == "unscaled"
+        # DNet ground-plane rescaling of the INITIAL depths (the reference evaluates it at epoch 0, optimizer.py:254-261)
+        sf_init = (eng.scale_recovery(depths[0].contiguous(), intrinsics.float().contiguous(), cfg["camera_height"] / 30.0,
+                                      pad_to_batch=int(cfg.get("minibatch", B))).cpu() if unscaled else torch.FloatTensor([1]))
         res["stacked_poses_init"] = stacked0[:split].cpu()
         res["stacked_poses_inv_init"] = stacked0[split:].cpu()
 
@@ -196,7 +213,8 @@ class DepthOptimizer:
             stats = stats.clone(); stats[split:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6] = pose0[split:, None, :]
         res["poses_opt"] = pose[:split].cpu()
         res["poses_inv_opt"] = pose[split:].cpu()
-        traj = stats[:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6]      # [2SB, gn_iters+1, 6]: the iterates (cf. train_mono.py:71-79)
+        traj = stats[:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6].clone()   # [2SB, gn_iters+1, 6]: the iterates (cf. train_mono.py:71-79)
+        traj[:, -1] = pose            # LM: the last row is the TRIAL pose even when that step was rejected; report what was returned
         res["stacked_poses_opt"] = traj[:split]
         res["stacked_poses_inv_opt"] = traj[split:]
         res["gn_cost"] = stats[:, :, 0].cpu()          # per pair, per linearisation (extra key)
@@ -211,14 +229,14 @@ class DepthOptimizer:
             depths = [1.0 / inv_t] + [depth_ref[split + i * B: split + (i + 1) * B] for i in range(S)]
         res["depths_opt"] = depths
 
-        if self.options.get("mode", "scaled") == "unscaled":
-            # DNet ground-plane rescaling, optimizer.py:254-256 (self.dgc = ScaleRecovery(minibatch, 192, 640))
+        if unscaled:
+            # DNet ground-plane rescaling of the refined depths, optimizer.py:254-256 (self.dgc = ScaleRecovery(minibatch, 192, 640))
             sf = eng.scale_recovery(depths[0].contiguous(), intrinsics.float().contiguous(), cfg["camera_height"] / 30.0,
                                     pad_to_batch=int(cfg.get("minibatch", B))).cpu()
         else:
             sf = torch.FloatTensor([1])
         res["scale_factor"] = sf
-        res["scale_factor_init"] = sf.clone()
+        res["scale_factor_init"] = sf_init
 
         # disparity for depth evaluation: flip-averaged prediction (helpers.py:35-49)
         flipped = self._disparities(torch.cat((target_img, torch.flip(target_img, [3])), 0)).float().contiguous()

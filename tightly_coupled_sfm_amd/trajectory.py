@@ -6,7 +6,8 @@ exactly as the reference does -- est[i+1] = (exp(pose_i) est[i]^-1)^-1 -- using 
 
 The error metrics in the reference come from pyslam.metrics.TrajectoryMetrics (also absent, version unpinned, no
 fixtures in the reference): PARITY UNPINNED.  What is implemented here is the standard definition:
-  mean_err        RMSE over frames of |trans(T_gt^-1 T_est)| and of |log(rot(T_gt^-1 T_est))|
+  mean_err        MEAN over frames of the per-frame error norms |trans(T_gt^-1 T_est)| and |log(rot(T_gt^-1 T_est))| (what
+                  validate.compute_trajectory prints as "mean trans. / rot. error"); rms_err is the RMSE of the same norms
   segment_errors  KITTI devkit: for every start frame and every segment length L, the relative-motion error between
                   estimate and ground truth over the first sub-trajectory of (ground-truth) length >= L, divided by L.
 """
@@ -37,8 +38,19 @@ def _rel_err(Tg, Te):
     return float(np.linalg.norm(E[:, 3])), float(np.linalg.norm(se3_log(E)[3:]))
 
 
+def error_norms(gt_traj, est_traj):
+    """per-frame (translational, rotational [rad]) error norms of T_gt^-1 T_est -> array [n, 2]"""
+    return np.array([_rel_err(g, t) for g, t in zip(gt_traj, est_traj)])
+
+
 def mean_err(gt_traj, est_traj):
-    e = np.array([_rel_err(g, t) for g, t in zip(gt_traj, est_traj)])
+    """mean of the per-frame error norms (NOT their RMSE: that is rms_err)"""
+    e = error_norms(gt_traj, est_traj)
+    return float(np.mean(e[:, 0])), float(np.mean(e[:, 1]))
+
+
+def rms_err(gt_traj, est_traj):
+    e = error_norms(gt_traj, est_traj)
     return float(np.sqrt(np.mean(e[:, 0] ** 2))), float(np.sqrt(np.mean(e[:, 1] ** 2)))
 
 
@@ -95,6 +107,11 @@ class TrajectoryMetrics:
     def mean_err(self):
         """-> (mean translational error, mean rotational error [rad])"""
         t, r = mean_err(self.gt, self.est)
+        return np.float64(t), np.float64(r)
+
+    def rms_err(self):
+        """-> (RMS translational error, RMS rotational error [rad])"""
+        t, r = rms_err(self.gt, self.est)
         return np.float64(t), np.float64(r)
 
     def segment_errors(self, segment_lengths, rot_unit="rad"):
