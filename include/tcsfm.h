@@ -58,7 +58,8 @@ typedef struct tcsfm_opts {
     int32_t refine;        /* TCSFM_REFINE_*                                                             */
     int32_t automask;      /* mask = valid * (diff < auto_err), helpers.py:17-19; options['automasking'] */
     int32_t depth_is_disp; /* depth inputs are sigmoid disparities: disp_to_depth is fused (learning_helpers.py:77-86) */
-    int32_t host_ptrs;     /* array arguments are host pointers                                          */
+    int32_t host_ptrs;     /* 1: array arguments are host pointers (the call synchronises); 2: PINNED host pointers,
+                              asynchronous (tcsfm_refine_window_async only)                                 */
     int32_t argmin;        /* tcsfm_refine_window with S > 1: per-pixel min over the sources, options['diff_img_argmin'] */
     float w_l1, w_ssim;    /* 0.15 / 0.85, train_mono.py:87                                              */
     float w_dc;            /* options['l_depth_consist_weight'] if options['l_depth_consist'] else 0, optimizer.py:83-86 */
@@ -187,6 +188,31 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
  * scale_out [1]; optional: median_out [1], height_out / mask_out [N,1,H,W]. */
 int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,
                          int pad_to_batch, float *scale_out, float *median_out, float *height_out, float *mask_out);
+
+/* ---- lanes: several refinements in flight (streaming a sequence) ----------------------------------
+ * The reference's driver refines one window after another (run_sequential_optimization.py:186-247: DataLoader batch -> H2D ->
+ * optimize_window); consecutive windows do not depend on each other.  A B=1 refinement leaves the GPU idle between its short
+ * kernels, and a host-pointer call spends more time on PCIe than on the refinement, so the library can keep several calls in
+ * flight: lane k >= 1 owns a HIP stream and a full set of scratch buffers (lane 0 is the handle itself).
+ *   tcsfm_set_lanes          1..8 lanes (allocates / frees the lanes' scratch; default 1)
+ *   tcsfm_refine_window_async   tcsfm_refine_window on `lane`, asynchronously.  Device pointers (host_ptrs = 0): the lane first
+ *                            waits for the work queued on the handle's stream at call time (the producers of the inputs).
+ *                            Pinned host pointers (host_ptrs = 2): the copies run on the lane's stream -- they overlap the other
+ *                            lanes' kernels -- and the call does NOT synchronise; read the outputs after tcsfm_lane_synchronize.
+ *   tcsfm_lane_wait          the handle's stream waits (on the device, not the host) for the lane's last call
+ *   tcsfm_lane_synchronize   the host waits for the lane's last call; reports a pending TCSFM_E_INTRINSICS of that lane
+ *   tcsfm_lane_event         marks the current end of the lane's work with an event (owned by the library; one of a ring of 64
+ *                            per lane, so a mark stays valid until 64 later marks of that lane) -- for callers that recycle
+ *                            input buffers: tcsfm_stream_wait_event(stream, mark) makes e.g. their copy stream wait, on the
+ *                            device, until the lane has consumed the buffer */
+int tcsfm_set_lanes(tcsfm_handle h, int n_lanes);
+int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                              const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                              const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);
+int tcsfm_lane_wait(tcsfm_handle h, int lane);
+int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
+int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);
+int tcsfm_stream_wait_event(tcsfm_handle h, void *hip_stream, void *event);
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 

@@ -1,0 +1,75 @@
+"""PCIe-inclusive throughput of a streamed synthetic sequence: 200 frames of 640x192 in pinned host memory,
+window = (frame t, frame t+1) -> fwd + inv directed pairs, 4 GN iterations.  Compares
+  (a) the round-1 host-pointer path: one synchronous tcsfm_refine per window, both pairs' arrays handed over (7.9 MB / window)
+  (b) SequenceRefiner: every frame uploaded once, window form, 1 / 2 / 3 lanes"""
+import json, os, sys, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tightly_coupled_sfm_amd import synth
+from tightly_coupled_sfm_amd.engine import Engine, default_opts
+from tightly_coupled_sfm_amd.streaming import SequenceRefiner
+
+H, W, T = 192, 640, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seq = synth.make_sequence(T, H, W, seed=5)
+frames = torch.as_tensor(seq["frames"]).pin_memory(); depths = torch.as_tensor(seq["depths"]).pin_memory()
+K, init = seq["K"], seq["init"]            # init [T-1, 2, 6]
+opts = default_opts(n_iters=4)
+
+# (a) synchronous host-pointer calls, pinned arrays, pair form (what round 1 measured)
+e = Engine(H, W, 2)
+o = default_opts(n_iters=4, host_ptrs=1)
+ptr = lambda a: C.c_void_p(a.data_ptr())
+out = torch.zeros((2, 6)).pin_memory()
+Kh = torch.as_tensor(np.repeat(K[None], 2, 0).astype(np.float32)).pin_memory()
+def window_a(w):
+    tg = torch.stack([frames[w], frames[w + 1]]); sr = torch.stack([frames[w + 1], frames[w]])
+    dt = torch.stack([depths[w], depths[w + 1]]); ds = torch.stack([depths[w + 1], depths[w]])
+    return [x.pin_memory() for x in (tg, sr, dt, ds)]
+wins = [window_a(w) for w in range(min(T - 1, 40))]
+p_h = torch.as_tensor(init[:40]).pin_memory()
+for rep in range(2):
+    t0 = time.perf_counter()
+    for w, (tg, sr, dt, ds) in enumerate(wins):
+        e._call(e.lib.tcsfm_refine(e._h, C.byref(o), 2, ptr(tg), ptr(sr), ptr(dt), ptr(ds), ptr(Kh), ptr(p_h[w]), None, ptr(out), None, None))
+    dt_a = (time.perf_counter() - t0) / len(wins)
+print(json.dumps({"path": "r01 host-pointer call per window (pinned, synchronous, pair form: 7.9 MB in per window)", "us_per_window": round(dt_a * 1e6, 1),
+                  "windows_per_s": round(1 / dt_a, 1)}), flush=True)
+
+ref = None
+for lanes in (1, 2, 3, 4):
+    sr = SequenceRefiner(H, W, sources=1, lanes=lanes, opts=opts)
+    sr.run(frames[:20], depths[:20], K, init[:19])            # warm-up (allocations, clocks)
+    torch.cuda.synchronize()
+    times = []
+    for rep in range(7):
+        t0 = time.perf_counter()
+        res = sr.run(frames, depths, K, init)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    best = sorted(times)[len(times) // 2]              # median of 7 passes over the sequence
+    if ref is None:
+        ref = res.clone()
+    same = bool(torch.equal(res, ref))
+    print(json.dumps({"path": f"SequenceRefiner: each frame uploaded once ({(3 + 1) * H * W * 4 / 1e6:.2f} MB / window), window form, {lanes} lane(s)",
+                      "frames": T, "windows": T - 1, "ms_total": round(best * 1e3, 2), "windows_per_s": round((T - 1) / best, 1),
+                      "bit_identical_to_1_lane": same}), flush=True)
+# the same windows from DEVICE-resident frames (no PCIe in the loop): what the lanes alone buy at B=1
+dev_f, dev_d = frames.cuda(), depths.cuda()
+Kd = torch.as_tensor(K[None]).cuda(); p0 = torch.as_tensor(init).cuda(); outd = torch.empty_like(p0)
+for lanes in (1, 2, 3, 4):
+    e = Engine(H, W, 2, lanes=lanes)
+    tg = [dev_f[w][None] for w in range(T - 1)]; sc = [dev_f[w + 1][None, None] for w in range(T - 1)]
+    dt = [dev_d[w][None] for w in range(T - 1)]; ds = [dev_d[w + 1][None, None] for w in range(T - 1)]
+    pw, ow = list(p0.unbind(0)), list(outd.unbind(0))
+    def sweep():
+        for w in range(T - 1):
+            e.refine_window_async(w % lanes, tg[w], sc[w], dt[w], ds[w], Kd, pw[w], ow[w], opts)
+        for l in range(lanes):
+            e.lane_synchronize(l)
+    sweep(); torch.cuda.synchronize()
+    times = []
+    for rep in range(7):
+        t0 = time.perf_counter(); sweep(); torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    med = sorted(times)[3]
+    print(json.dumps({"path": f"device-resident frames, window form, {lanes} lane(s)", "windows_per_s": round((T - 1) / med, 1),
+                      "us_per_window": round(med / (T - 1) * 1e6, 1), "equal_to_streamed": bool(torch.equal(outd, ref))}), flush=True)

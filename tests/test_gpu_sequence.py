@@ -46,3 +46,60 @@ def test_refined_trajectory_beats_initial_trajectory():
     seg = trajectory.segment_errors(traj_opt, traj_ref, [0.1, 0.2])
     assert np.all(seg[:, 1] < 0.01)                                                 # < 1 % translation error on every segment length
     assert np.all(st.cpu().numpy()[:, 7, 0] < st.cpu().numpy()[:, 0, 0])
+
+
+def test_streamed_sequence_lanes_match_plain_calls():
+    """SequenceRefiner (frames uploaded once into a device ring, windows round-robin over the engine's lanes, copies on their own
+    stream): bit-identical to plain per-window refine_window calls for 1, 2 and 3 lanes, ring wrap-around included"""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd.streaming import SequenceRefiner
+    H, W, T = 48, 160, 26
+    seq = synth.make_sequence(T, H, W, seed=3)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    e = Engine(H, W, 2)
+    o = default_opts(n_iters=3)
+    K = t(seq["K"][None])
+    plain = torch.stack([e.refine_window(t(seq["frames"][w:w + 1]), t(seq["frames"][w + 1:w + 2])[None], t(seq["depths"][w:w + 1]),
+                                         t(seq["depths"][w + 1:w + 2])[None], K, t(seq["init"][w]), o)[0] for w in range(T - 1)])
+    for lanes in (1, 2, 3):
+        sr = SequenceRefiner(H, W, sources=1, lanes=lanes, opts=o)
+        assert sr.R < T                                        # the ring wraps around several times
+        out = sr.run(seq["frames"], seq["depths"], seq["K"], seq["init"])
+        assert torch.equal(out, plain), lanes
+        out2 = sr.run(seq["frames"], seq["depths"], seq["K"], seq["init"])     # reusable
+        assert torch.equal(out2, plain)
+    assert not torch.equal(plain, t(seq["init"]))             # (and something was refined)
+
+
+def test_lane_calls_from_pinned_host_memory():
+    """tcsfm_refine_window_async with host_ptrs = 2 (pinned host arrays, no synchronisation inside the call): results equal the
+    device-pointer call once the lane has been synchronised; host_ptrs = 1 is refused there"""
+    import ctypes as C
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 48, 160
+    seq = synth.make_sequence(4, H, W, seed=9)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    e = Engine(H, W, 2, lanes=3)
+    o = default_opts(n_iters=3)
+    ref = [e.refine_window(t(seq["frames"][w:w + 1]).cuda(), t(seq["frames"][w + 1:w + 2])[None].cuda(), t(seq["depths"][w:w + 1]).cuda(),
+                           t(seq["depths"][w + 1:w + 2])[None].cuda(), t(seq["K"][None]).cuda(), t(seq["init"][w]).cuda(), o)[0].cpu() for w in range(3)]
+    pin = lambda a: t(a).pin_memory()
+    host = [dict(tgt=pin(seq["frames"][w:w + 1]), src=pin(seq["frames"][w + 1:w + 2][None]), dt=pin(seq["depths"][w:w + 1]),
+                 ds=pin(seq["depths"][w + 1:w + 2][None]), K=pin(seq["K"][None]), p0=pin(seq["init"][w]), out=torch.zeros(2, 6).pin_memory()) for w in range(3)]
+    oh = default_opts(n_iters=3, host_ptrs=2)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    for w, hb in enumerate(host):                   # three calls in flight on three lanes, none of them blocks the host
+        rc = e.lib.tcsfm_refine_window_async(e._h, w, C.byref(oh), 1, 1, P(hb["tgt"]), P(hb["src"]), P(hb["dt"]), P(hb["ds"]), P(hb["K"]), P(hb["p0"]),
+                                             None, P(hb["out"]), None, None)
+        assert rc == 0, e.lib.tcsfm_last_error(e._h)
+    for w in range(3):
+        e.lane_synchronize(w)
+        assert torch.equal(host[w]["out"], ref[w]), w
+    bad = default_opts(n_iters=3, host_ptrs=1)
+    hb = host[0]
+    assert e.lib.tcsfm_refine_window_async(e._h, 1, C.byref(bad), 1, 1, P(hb["tgt"]), P(hb["src"]), P(hb["dt"]), P(hb["ds"]), P(hb["K"]), P(hb["p0"]),
+                                           None, P(hb["out"]), None, None) < 0
+    assert e.lib.tcsfm_refine_window_async(e._h, 7, C.byref(oh), 1, 1, P(hb["tgt"]), P(hb["src"]), P(hb["dt"]), P(hb["ds"]), P(hb["K"]), P(hb["p0"]),
+                                           None, P(hb["out"]), None, None) < 0          # no such lane

@@ -46,6 +46,12 @@ _SIGNATURES = {
     "tcsfm_refine_dense_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),
+    "tcsfm_set_lanes": (C.c_int, [_P, C.c_int]),
+    "tcsfm_refine_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
+    "tcsfm_lane_wait": (C.c_int, [_P, C.c_int]),
+    "tcsfm_lane_synchronize": (C.c_int, [_P, C.c_int]),
+    "tcsfm_lane_event": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "tcsfm_stream_wait_event": (C.c_int, [_P, _P, _P]),
     "tcsfm_profile_begin": (C.c_int, [_P]),
     "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
     "tcsfm_profile_kernel_time": (C.c_int, [_P, _P, _P]),

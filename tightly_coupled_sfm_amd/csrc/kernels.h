@@ -1149,7 +1149,8 @@ struct SolveParams {
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
 // inverse-trig keeps ~1e-7 relative accuracy and stays off the fp64 serial path
 __device__ inline void T_to_pose_f32(const double *T, float *pose) {
-    float sb = fminf(fmaxf((float)T[2], -1.f), 1.f);
+    const float sbr = (float)T[2];
+    float sb = sbr < -1.f ? -1.f : (sbr > 1.f ? 1.f : sbr);   // (comparisons, not fminf / fmaxf: a NaN pose must stay NaN in every component)
     pose[0] = (float)-T[3]; pose[1] = (float)-T[7]; pose[2] = (float)-T[11];
     pose[3] = -atan2f((float)-T[6], (float)T[10]);
     pose[4] = -asinf(sb);

@@ -53,6 +53,13 @@ struct tcsfm_ctx {
     std::string err;
     // event profiling (tcsfm_profile_*): one (start, stop, class) triple per bracketed launch
     int *err_host = nullptr, *err_dev = nullptr;   // host-mapped status word of the device-side guards (host / device address)
+    // lanes (tcsfm_set_lanes): lane k >= 1 is a child handle with its own stream and scratch, so that several refine calls are
+    // in flight at once; lane 0 is this handle.  in_ev orders a lane behind the work queued on the parent's stream at call time,
+    // done_ev is what tcsfm_lane_wait makes the parent's stream wait for.
+    std::vector<tcsfm_ctx *> lanes;
+    hipEvent_t in_ev = nullptr, done_ev = nullptr;
+    std::vector<hipEvent_t> marks;   // tcsfm_lane_event: a ring of events handed out to the caller
+    size_t mark_next = 0;
     const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
     int K_checked_n = 0;
     unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
@@ -421,7 +428,12 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
 
 void tcsfm_destroy(tcsfm_handle h) {
     if (!h) return;
+    for (tcsfm_ctx *c : h->lanes) tcsfm_destroy(c);
+    h->lanes.clear();
     DeviceGuard dev_guard(h->device);
+    if (h->in_ev) (void)hipEventDestroy(h->in_ev);
+    if (h->done_ev) (void)hipEventDestroy(h->done_ev);
+    for (auto &e : h->marks) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept};
@@ -737,7 +749,7 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
     if (d_ls_out && (rc = copy_back(h, o, log_scale_out, d_ls_out, (size_t)N))) return rc;
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
-    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (o->host_ptrs == 1) HIPCHK(h, hipStreamSynchronize(h->stream));   // host_ptrs == 2: pinned + asynchronous, the caller synchronises
     return TCSFM_OK;
 }
 
@@ -955,6 +967,90 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: need 1 <= 2*B*S <= max_pairs");
     return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+}
+
+int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
+    if (!h) return TCSFM_E_ARG;
+    if (n_lanes < 1 || n_lanes > 8) return fail(h, TCSFM_E_ARG, "tcsfm_set_lanes: 1 <= n_lanes <= 8");
+    DeviceGuard dev_guard(h->device);
+    while ((int)h->lanes.size() + 1 > n_lanes) { tcsfm_destroy(h->lanes.back()); h->lanes.pop_back(); }
+    while ((int)h->lanes.size() + 1 < n_lanes) {
+        tcsfm_ctx *c = nullptr;
+        int rc = tcsfm_create(&c, h->device, h->H, h->W, h->max_pairs);
+        if (rc) return fail(h, rc, "tcsfm_set_lanes: could not create a lane");
+        hipError_t e = hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming);
+        if (e != hipSuccess) { tcsfm_destroy(c); return fail(h, TCSFM_E_HIP, "tcsfm_set_lanes: hipEventCreate failed"); }
+        h->lanes.push_back(c);
+    }
+    return TCSFM_OK;
+}
+
+static tcsfm_ctx *lane_of(tcsfm_ctx *h, int lane) {
+    if (!h || lane < 0 || lane > (int)h->lanes.size()) return nullptr;
+    return lane == 0 ? h : h->lanes[lane - 1];
+}
+
+int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                              const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                              const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out) {
+    tcsfm_ctx *c = lane_of(h, lane);
+    if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_refine_window_async: no such lane (tcsfm_set_lanes)") : TCSFM_E_ARG;
+    if (o && o->host_ptrs == 1) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_async: host_ptrs must be 0 (device) or 2 (pinned host, asynchronous)");
+    if (c == h) return tcsfm_refine_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
+    DeviceGuard dev_guard(h->device);
+    // the lane starts behind everything queued on the parent's stream so far (the producers of the caller's device buffers) ...
+    HIPCHK(h, hipEventRecord(c->in_ev, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(c->own_stream, c->in_ev, 0));
+    c->stream = c->own_stream;
+    int rc = tcsfm_refine_window(c, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
+    if (rc) { h->err = c->err; return rc; }
+    // ... and marks its end for tcsfm_lane_wait / tcsfm_lane_synchronize
+    HIPCHK(h, hipEventRecord(c->done_ev, c->own_stream));
+    return TCSFM_OK;
+}
+
+int tcsfm_lane_wait(tcsfm_handle h, int lane) {
+    tcsfm_ctx *c = lane_of(h, lane);
+    if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_lane_wait: no such lane") : TCSFM_E_ARG;
+    if (c == h) return TCSFM_OK;
+    DeviceGuard dev_guard(h->device);
+    HIPCHK(h, hipStreamWaitEvent(h->stream, c->done_ev, 0));     // consumers on the parent's stream see the lane's outputs
+    return TCSFM_OK;
+}
+
+int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out) {
+    tcsfm_ctx *c = lane_of(h, lane);
+    if (!c || !event_out) return h ? fail(h, TCSFM_E_ARG, "tcsfm_lane_event: bad argument") : TCSFM_E_ARG;
+    DeviceGuard dev_guard(h->device);
+    constexpr size_t kMarks = 64;
+    if (c->marks.size() < kMarks) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->marks.push_back(e);
+        c->mark_next = c->marks.size() - 1;
+    }
+    hipEvent_t e = c->marks[c->mark_next];
+    c->mark_next = (c->mark_next + 1) % kMarks;
+    HIPCHK(h, hipEventRecord(e, c == h ? h->stream : c->own_stream));
+    *event_out = (void *)e;
+    return TCSFM_OK;
+}
+
+int tcsfm_stream_wait_event(tcsfm_handle h, void *hip_stream, void *event) {
+    if (!h || !event) return TCSFM_E_ARG;
+    DeviceGuard dev_guard(h->device);
+    HIPCHK(h, hipStreamWaitEvent((hipStream_t)hip_stream, (hipEvent_t)event, 0));
+    return TCSFM_OK;
+}
+
+int tcsfm_lane_synchronize(tcsfm_handle h, int lane) {
+    tcsfm_ctx *c = lane_of(h, lane);
+    if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_lane_synchronize: no such lane") : TCSFM_E_ARG;
+    DeviceGuard dev_guard(h->device);
+    HIPCHK(h, hipStreamSynchronize(c == h ? h->stream : c->own_stream));
+    if (int rc = pending_error(c)) { h->err = c->err; return rc; }
+    return TCSFM_OK;
 }
 
 int tcsfm_debug_trace(tcsfm_handle h, uint16_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity) {

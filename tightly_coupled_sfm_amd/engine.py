@@ -40,7 +40,7 @@ def _copy_opts(o: Opts) -> Opts:
 class Engine:
     """One handle = one GPU + one HIP stream (include/tcsfm.h).  ``max_pairs`` directed pairs of HxW."""
 
-    def __init__(self, H: int, W: int, max_pairs: int, device: Optional[int] = None):
+    def __init__(self, H: int, W: int, max_pairs: int, device: Optional[int] = None, lanes: int = 1):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("tightly_coupled_sfm_amd.Engine needs a ROCm GPU (torch.cuda.is_available() is False)")
@@ -51,7 +51,10 @@ class Engine:
         if rc != 0:
             raise RuntimeError(f"tcsfm_create failed ({rc}): {self.lib.tcsfm_last_error(None).decode()}")
         self._h = h
+        self.lanes = 1
         self.use_torch_stream()
+        if lanes > 1:
+            self.set_lanes(lanes)
 
     # -- lifetime ----------------------------------------------------------------------------
     def close(self):
@@ -338,6 +341,36 @@ class Engine:
         self._call(self.lib.tcsfm_scale_recovery(self._h, C.byref(o), N, self._p(depth), self._p(K), float(real_cam_height),
                                                  int(pad_to_batch), self._p(scale), self._p(med), self._p(hm), self._p(mm)))
         return (scale, med, hm, mm) if maps else scale
+
+    # -- lanes: several refinements in flight (include/tcsfm.h "lanes") -----------------------------------------
+    def set_lanes(self, n: int):
+        self._call(self.lib.tcsfm_set_lanes(self._h, int(n)))
+        self.lanes = int(n)
+
+    def refine_window_async(self, lane: int, tgt, srcs, depth_t, depth_s, K, pose, pose_out, opts: Opts, log_scale=None, log_scale_out=None):
+        """tcsfm_refine_window on `lane`, zero-allocation and asynchronous: tensors must be validated / contiguous float32 CUDA
+        tensors in the window layout (see refine_window); the lane waits for the work queued on this engine's stream so far.
+        Outputs are valid for consumers on this engine's stream after lane_wait(lane), for the host after lane_synchronize(lane)."""
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        self._call(self.lib.tcsfm_refine_window_async(self._h, int(lane), C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t),
+                                                      self._p(depth_s), self._p(K), self._p(pose), self._p(log_scale), self._p(pose_out),
+                                                      self._p(log_scale_out), None))
+
+    def lane_wait(self, lane: int):
+        self._call(self.lib.tcsfm_lane_wait(self._h, int(lane)))
+
+    def lane_event(self, lane: int):
+        """mark the current end of the lane's work -> opaque event handle for stream_wait_event"""
+        ev = C.c_void_p()
+        self._call(self.lib.tcsfm_lane_event(self._h, int(lane), C.byref(ev)))
+        return ev
+
+    def stream_wait_event(self, stream: "torch.cuda.Stream", event):
+        """make a torch stream wait (on the device) for a lane_event mark"""
+        self._call(self.lib.tcsfm_stream_wait_event(self._h, C.c_void_p(stream.cuda_stream), event))
+
+    def lane_synchronize(self, lane: int):
+        self._call(self.lib.tcsfm_lane_synchronize(self._h, int(lane)))
 
     def refine_into(self, tgt, src, depth_t, depth_s, K, pose_in, pose_out, opts: Opts, log_scale_in=None, log_scale_out=None,
                     stats_out=None):

@@ -190,3 +190,32 @@ def make_batch(N, H=192, W=640, seed0=0, noise=0.003, dtype=np.float32, both_dir
             out["pose_init"].append(invert_pose(init).astype(dtype) if flip else init)
         i += 1
     return {k: np.ascontiguousarray(np.stack(v)) for k, v in out.items()}
+
+
+def make_sequence(T, H=192, W=640, seed=0, noise=0.003, dtype=np.float32, room=(0.055, 12.0, 0.28, 0.33)):
+    """T frames of ONE textured corridor seen from a moving camera (frame t+1 is the source of frame t and the target of the next
+    window, as in the reference's sequence loaders).  Returns dict: frames [T,3,H,W], depths [T,1,H,W], K [3,3],
+    pose_gt [T-1,6] (frame t -> t+1, the convention of make_pair), init [T-1,2,6] = PoseNet-quality initial poses of the forward
+    and inverse directed pair of every window."""
+    K = scaled_K(H, W)
+    rng = np.random.default_rng(3000 + seed)
+    tex = _Texture(seed)
+    rays = _rays(H, W, K)
+    Rw, tw = np.eye(3), np.zeros(3)                       # world (= frame 0) -> camera t
+    frames, depths, rel, init = [], [], [], []
+    for t in range(T):
+        d = _room_depth(rays, Rw, tw, room)
+        Xw = (rays * d[..., None] - tw) @ Rw             # R^T (X_c - t)
+        img = tex(Xw)
+        if noise > 0:
+            img = np.clip(img + rng.normal(scale=noise, size=img.shape), 0, 1)
+        frames.append(img.astype(dtype)); depths.append(d[None].astype(dtype))
+        if t < T - 1:
+            p = np.array([0.002, -0.001, 0.033, 0.001, -0.003, 0.001]) + rng.normal(scale=[3e-4, 3e-4, 2e-3, 5e-4, 1e-3, 5e-4])
+            rel.append(p)
+            f0 = perturb_pose(p, seed * 1000 + t)
+            init.append(np.stack([f0, invert_pose(f0)]))
+            Tm = pose_to_T(p)
+            Rw, tw = Tm[:, :3] @ Rw, Tm[:, :3] @ tw + Tm[:, 3]
+    return dict(frames=np.stack(frames), depths=np.stack(depths), K=K.astype(dtype), pose_gt=np.stack(rel).astype(dtype),
+                init=np.stack(init).astype(dtype))
