@@ -270,7 +270,7 @@ def main():
         send = final.to(coll_dev)
         for k in range(2):
             gathered = [torch.empty_like(send) for _ in range(world)]
-            fence()
+            fence(lanes)
             t0 = time.perf_counter()
             dist.all_gather(gathered, send)
             if coll_dev == "cuda":
