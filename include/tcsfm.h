@@ -189,6 +189,29 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
 int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,
                          int pad_to_batch, float *scale_out, float *median_out, float *height_out, float *mask_out);
 
+/* ---- PoseNet and the coupled pose loop ----------------------------------------
+ * The reference's PoseNet (models/pose_models.py:88-147: seven weight-standardised stride-2 convolutions + GroupNorm(16) + ReLU,
+ * 1x1 head, spatial mean, x 0.01) is evaluated `iterations` times per window inside solve_pose_iteratively (train_mono.py:64,77).
+ * Here it runs as hand-written gfx950 kernels (fp32 matrix instructions, weight standardisation folded into the loaded weights,
+ * GroupNorm + ReLU applied by the consuming layer), so that the whole coupled loop stays inside the library.
+ *   tcsfm_posenet_create   activations for up to max_images samples of the handle's H x W
+ *   tcsfm_posenet_load     HOST pointers to the parameters of the reference module, in its own layouts: conv_w[l] = conv{l+1}.0.weight
+ *                          [cout,cin,k,k], conv_b[l] = conv{l+1}.0.bias [cout] (NULL: 0), gn_w / gn_b[l] = conv{l+1}.1.weight / .bias
+ *                          [cout] (NULL: 1 / 0), head_w = pose_pred.weight [6,256(,1,1)], head_b = pose_pred.bias [6]
+ *   tcsfm_posenet_forward  pose_model(imgs): imgs [N,6,H,W] (device) -> pose [N,6] (device)
+ *   tcsfm_solve_pose_iteratively   train_mono.py:41-81 for a window (layouts of tcsfm_refine_window): PoseNet on (tgt | src) /
+ *                          (src | tgt), then num_iter-1 rounds of { inverse_warp2 with -pose; PoseNet on (tgt * valid | img_rec);
+ *                          pose += correction }.  poses_out [2*S*B,6] = the last iterate; stacked_out [2*S*B,num_iter,6] optional
+ *                          (the reference's stacked_poses).  Asynchronous on the handle's stream. */
+typedef struct tcsfm_posenet tcsfm_posenet;
+int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out);
+void tcsfm_posenet_destroy(tcsfm_posenet *pn);
+int tcsfm_posenet_load(tcsfm_posenet *pn, const float *const conv_w[7], const float *const conv_b[7], const float *const gn_w[7],
+                       const float *const gn_b[7], const float *head_w, const float *head_b);
+int tcsfm_posenet_forward(tcsfm_posenet *pn, int N, const float *imgs, float *pose_out);
+int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, float *poses_out, float *stacked_out);
+
 /* ---- lanes: several refinements in flight (streaming a sequence) ----------------------------------
  * The reference's driver refines one window after another (run_sequential_optimization.py:186-247: DataLoader batch -> H2D ->
  * optimize_window); consecutive windows do not depend on each other.  A B=1 refinement leaves the GPU idle between its short

@@ -336,6 +336,40 @@ def main():
         est, gt_out, errors, cum = val.compute_trajectory(noisy, np.array(gt), method="odom", compute_seg_err=True)
     out["traj400"] = dict(pose_vec=noisy, gt_traj=np.array(gt), est_traj=est, errors=np.array(errors, dtype=np.float64), cum_dist=cum)
 
+    # ------------------------------------------------------------------ G12: the reference's PoseNet and coupled pose loop
+    # models/pose_models.py:88-147 with seeded parameters (tests/standins.posenet_params: the fixture carries the seed, not 6 MB of
+    # weights), float32 as the reference runs it, on (a) 4 six-channel inputs of 48x160 and (b) the fwd + inv pair of a 192x640
+    # window; then solve_pose_iteratively (train_mono.py:41-81) with that network, B=2 targets x S=2 sources, 4 iterations
+    import importlib
+    pm_mod = importlib.import_module("models.pose_models")
+    sdp = standins.posenet_params(0)
+    net = pm_mod.pose_model({'flow_type': 'none'})
+    net.load_state_dict({k: torch.tensor(v) for k, v in sdp.items()})
+    net.eval()
+    g12 = {"seed": np.array(0)}
+    with torch.no_grad():
+        for tag, (hh, ww, nimg) in (("a", (48, 160, 4)), ("b", (192, 640, 2))):
+            bb = synth.make_batch(nimg, hh, ww, seed0=40, both_directions=True)
+            x = torch.tensor(np.concatenate([bb["tgt"], bb["src"]], 1))
+            pose, feats = net(x, return_features=True)
+            g12[f"{tag}_pose"] = N(pose)
+            g12[f"{tag}_in_checksum"] = np.array([float(x.double().sum()), float(x.double().abs().max())])
+            for i, f in enumerate(feats):      # per layer: mean, mean |.|, and a strided sample of the activated features
+                g12[f"{tag}_feat{i + 1}_stats"] = np.array([float(f.double().mean()), float(f.double().abs().mean())])
+            g12[f"{tag}_feat1_sub"] = N(feats[0][:, :, ::9, ::13]); g12[f"{tag}_feat4_sub"] = N(feats[3][:, ::8])
+            g12[f"{tag}_feat7"] = N(feats[6])
+        w12 = standins.make_window(2, 2, 48, 160, seed0=90)
+        from oracle.oracle import Oracle as _O
+        o64 = _O("f64")
+        dts = [torch.tensor(o64.disp_to_depth(w12["disp_t"], 0.06, 2.67)[1].astype(np.float32))] + \
+              [torch.tensor(o64.disp_to_depth(w12["disp_s"][i], 0.06, 2.67)[1].astype(np.float32)) for i in range(2)]
+        reset_grid()
+        poses, poses_inv, outs = ref["train_mono"].solve_pose_iteratively(4, dts, net, torch.tensor(w12["target"]), [torch.tensor(w12["sources"][i]) for i in range(2)],
+                                                                        torch.tensor(w12["K"]), return_errors=True)
+        g12["loop_stacked"] = np.concatenate([N(outs["fwd"]["poses"]), N(outs["inv"]["poses"])])      # [2SB, 4, 6]
+        g12["loop_poses"] = np.concatenate([np.concatenate([N(p) for p in poses]), np.concatenate([N(p) for p in poses_inv])])
+    out["posenet"] = g12
+
     # ------------------------------------------------------------------ full-size summary (192x640, f32 as run by the reference)
     H, W, seed = 192, 640, 0
     p = synth.make_pair(H, W, seed=seed, dtype=np.float32)

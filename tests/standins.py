@@ -94,3 +94,58 @@ def window_models(w, iterations, device="cpu"):
     images = torch.cat([t(w["target"])] + [t(w["sources"][i]) for i in range(S)], 0)
     disps = torch.cat([t(w["disp_t"])] + [t(w["disp_s"][i]) for i in range(S)], 0)
     return LinearPose(t(w["first"]), iterations).to(device), LookupDepth(images, disps).to(device)
+
+
+def posenet_params(seed=0):
+    """Seeded parameters for the reference's pose_model (models/pose_models.py:88-147) under its state_dict names: He-scaled
+    convolution weights, NON-trivial convolution biases and GroupNorm affine parameters (the reference initialises those to
+    0 / 1 / 0; trained checkpoints do not keep them there), a head that yields poses of a few 1e-2.  Shared by
+    tests/golden/make_golden.py (loaded into the REFERENCE module) and the GPU tests (loaded into the HIP PoseNet), so the
+    fixture only has to carry the seed."""
+    rng = np.random.default_rng(7000 + seed)
+    chans, ks = [6, 16, 32, 64, 128, 256, 256, 256], [7, 5, 3, 3, 3, 3, 3]
+    sd = {}
+    for i in range(7):
+        cin, cout, k = chans[i], chans[i + 1], ks[i]
+        sd[f"conv{i + 1}.0.weight"] = (rng.normal(size=(cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k)) + 0.02).astype(np.float32)
+        sd[f"conv{i + 1}.0.bias"] = (0.1 * rng.normal(size=cout)).astype(np.float32)
+        sd[f"conv{i + 1}.1.weight"] = (1.0 + 0.2 * rng.normal(size=cout)).astype(np.float32)
+        sd[f"conv{i + 1}.1.bias"] = (0.1 * rng.normal(size=cout)).astype(np.float32)
+    # head scale: the coupled loop ADDS the network's output at every iteration (train_mono.py:78) and a random network has no
+    # notion of convergence; keep the accumulated pose of 4 iterations at the size of a real frame-to-frame motion (~0.03), where
+    # the warp is well conditioned (at 0.1 the near ground plane projects through the Z clamp and fp32 results are noise)
+    sd["pose_pred.weight"] = (0.05 * rng.normal(size=(6, 256, 1, 1))).astype(np.float32)
+    sd["pose_pred.bias"] = (0.08 * rng.normal(size=6)).astype(np.float32)
+    return sd
+
+
+class PoseNetTwin(nn.Module):
+    """Plain-PyTorch fp32 restatement of the reference's pose_model (models/pose_models.py:88-147) under the same state_dict
+    names -- the torch reference the HIP PoseNet is compared with on inputs the golden fixture does not cover, pinned itself on
+    the fixture (tests/test_oracle_vs_golden.py).  conv{i} = (weight-standardised stride-2 convolution, GroupNorm(16), ReLU)."""
+
+    class _WS(nn.Conv2d):
+        def forward(self, x):
+            w = self.weight
+            w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+            w = w / (w.flatten(1).std(dim=1).view(-1, 1, 1, 1) + 1e-5)          # unbiased std, pose_models.py:21
+            return nn.functional.conv2d(x, w, self.bias, self.stride, self.padding)
+
+    def __init__(self, params=None):
+        super().__init__()
+        chans, ks = [6, 16, 32, 64, 128, 256, 256, 256], [7, 5, 3, 3, 3, 3, 3]
+        for i in range(7):
+            setattr(self, f"conv{i + 1}", nn.Sequential(self._WS(chans[i], chans[i + 1], ks[i], stride=2, padding=(ks[i] - 1) // 2),
+                                                        nn.GroupNorm(16, chans[i + 1]), nn.ReLU()))
+        self.pose_pred = nn.Conv2d(256, 6, kernel_size=1)
+        if params is not None:
+            self.load_state_dict({k: torch.as_tensor(v) for k, v in params.items()})
+
+    def forward(self, imgs, return_features=False):
+        x = (imgs - 0.45) / 0.22
+        feats = []
+        for i in range(7):
+            x = getattr(self, f"conv{i + 1}")(x)
+            feats.append(x)
+        pose = 0.01 * self.pose_pred(x).mean(3).mean(2).view(-1, 6)
+        return (pose, feats) if return_features else pose

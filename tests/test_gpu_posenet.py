@@ -1,0 +1,112 @@
+"""GPU: the HIP PoseNet (csrc/posenet_kernel.h: fp32 matrix-core convolutions, weight standardisation folded into the loaded
+weights, GroupNorm + ReLU applied by the consumer) and the in-library coupled pose loop, against the golden G12 produced by the
+reference's own pose_model / solve_pose_iteratively, and against a plain-PyTorch fp32 twin on other sizes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _window(B, S, H, W):
+    import standins
+    from oracle.oracle import Oracle
+    w = standins.make_window(B, S, H, W, seed0=90)
+    o64 = Oracle("f64")
+    w["depth_t"] = o64.disp_to_depth(w["disp_t"], 0.06, 2.67)[1].astype(np.float32)
+    w["depth_s"] = o64.disp_to_depth(w["disp_s"], 0.06, 2.67)[1].astype(np.float32)
+    return w
+
+
+@pytest.mark.parametrize("tag,H,W,N", [("a", 48, 160, 4), ("b", 192, 640, 2)])
+def test_posenet_forward_vs_reference_golden(tag, H, W, N):
+    """pose_model(imgs) (pose_models.py:122-137) with seeded parameters: 1e-5 relative on the poses, features of the last layer"""
+    import standins
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+    g = load_golden("posenet")
+    b = synth.make_batch(N, H, W, seed0=40, both_directions=True)
+    x = np.concatenate([b["tgt"], b["src"]], 1)
+    assert np.allclose([float(x.astype(np.float64).sum()), float(np.abs(x).max())], g[f"{tag}_in_checksum"], rtol=0, atol=1e-6)
+    e = Engine(H, W, N)
+    net = PoseNetHIP(e, N, standins.posenet_params(int(g["seed"])))
+    pose = net(_t(x)).cpu().numpy()
+    ref = g[f"{tag}_pose"]
+    assert np.max(np.abs(pose - ref)) < 1e-5 * np.abs(ref).max(), (np.max(np.abs(pose - ref)) / np.abs(ref).max())
+    assert np.max(np.abs(pose - ref) / np.maximum(np.abs(ref), 1e-3)) < 1e-4       # and element-wise
+
+
+@pytest.mark.parametrize("H,W,N", [(64, 96, 3), (100, 333, 1), (192, 640, 5)])
+def test_posenet_forward_vs_torch_twin(H, W, N):
+    """odd sizes (ragged tiles, odd output extents) and a batch that is not a power of two, against the plain-PyTorch fp32 twin
+    run on the same GPU"""
+    import standins
+    from tightly_coupled_sfm_amd.engine import Engine
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP, is_reference_posenet
+    rng = np.random.default_rng(H * W + N)
+    x = _t(rng.uniform(0, 1, size=(N, 6, H, W)))
+    sd = standins.posenet_params(3)
+    twin = standins.PoseNetTwin(sd).cuda().eval()
+    assert is_reference_posenet(twin)
+    with torch.no_grad():
+        ref = twin(x).cpu().numpy()
+    net = PoseNetHIP(Engine(H, W, N), N, twin)                      # parameters taken from the module
+    pose = net(x).cpu().numpy()
+    assert np.max(np.abs(pose - ref)) < 1e-5 * np.abs(ref).max(), np.max(np.abs(pose - ref)) / np.abs(ref).max()
+    again = net(x).cpu().numpy()
+    assert np.array_equal(again, pose)                              # deterministic (fixed-order reductions, no atomics)
+    one = PoseNetHIP(Engine(H, W, 1), 1, sd)(x[N - 1:N].contiguous()).cpu().numpy()
+    assert np.array_equal(one[0], pose[N - 1])                      # batch independent
+
+
+def test_coupled_pose_loop_vs_reference_golden():
+    """solve_pose_iteratively (train_mono.py:41-81) with the reference's PoseNet in the loop, entirely inside the library:
+    B=2 targets x S=2 sources, 4 iterations -- the reference's stacked poses of all 8 directed pairs"""
+    import standins
+    from tightly_coupled_sfm_amd.engine import Engine
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+    g = load_golden("posenet")
+    B, S, H, W = 2, 2, 48, 160
+    w = _window(B, S, H, W)
+    e = Engine(H, W, 2 * S * B)
+    net = PoseNetHIP(e, 2 * S * B, standins.posenet_params(int(g["seed"])))
+    poses, stacked = net.solve_pose_iteratively(4, _t(w["target"]), _t(w["sources"]), _t(w["depth_t"]), _t(w["depth_s"]), _t(w["K"]))
+    poses, stacked = poses.cpu().numpy(), stacked.cpu().numpy()
+    ref = g["loop_stacked"]
+    assert stacked.shape == ref.shape == (2 * S * B, 4, 6)
+    for it in range(4):     # the loop feeds warped images back into the network: rounding differences grow slowly with the iterate
+        err = np.max(np.abs(stacked[:, it] - ref[:, it])) / np.abs(ref[:, it]).max()
+        assert err < (1e-5 if it == 0 else 2e-5), (it, err)
+    assert np.array_equal(poses, stacked[:, -1]) and np.max(np.abs(poses - g["loop_poses"])) < 2e-5 * np.abs(g["loop_poses"]).max()
+
+
+def test_solve_pose_iteratively_drop_in_uses_the_library_network():
+    """train_mono.solve_pose_iteratively handed a module with the reference PoseNet's parameters runs network AND warps in the
+    library (no torch convolution is executed) and returns the reference's structure"""
+    import standins
+    from tightly_coupled_sfm_amd import train_mono
+    g = load_golden("posenet")
+    B, S, H, W = 2, 2, 48, 160
+    w = _window(B, S, H, W)
+    twin = standins.PoseNetTwin(standins.posenet_params(int(g["seed"]))).cuda().eval()
+    calls = []
+    twin.register_forward_hook(lambda *a: calls.append(1))
+    depths = [_t(w["depth_t"])] + [_t(w["depth_s"][i]) for i in range(S)]
+    poses, poses_inv, out = train_mono.solve_pose_iteratively(4, depths, twin, _t(w["target"]), [_t(w["sources"][i]) for i in range(S)], _t(w["K"]),
+                                                              return_errors=True)
+    assert not calls                                                 # the torch module was not evaluated
+    got = np.concatenate([torch.cat(poses).cpu().numpy(), torch.cat(poses_inv).cpu().numpy()])
+    assert np.max(np.abs(got - g["loop_poses"])) < 2e-5 * np.abs(g["loop_poses"]).max()
+    assert set(out["fwd"]) == {"diff_img", "img_rec", "valid_mask", "weight_mask", "poses", "auto_mask_error", "auto_mask"}
+    assert np.max(np.abs(out["fwd"]["poses"].cpu().numpy() - g["loop_stacked"][:S * B])) < 2e-5 * np.abs(g["loop_stacked"]).max()

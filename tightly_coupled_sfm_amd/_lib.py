@@ -46,6 +46,11 @@ _SIGNATURES = {
     "tcsfm_refine_dense_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),
+    "tcsfm_posenet_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "tcsfm_posenet_destroy": (None, [_P]),
+    "tcsfm_posenet_load": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "tcsfm_posenet_forward": (C.c_int, [_P, C.c_int, _P, _P]),
+    "tcsfm_solve_pose_iteratively": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int] + [_P] * 7),
     "tcsfm_set_lanes": (C.c_int, [_P, C.c_int]),
     "tcsfm_refine_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
     "tcsfm_lane_wait": (C.c_int, [_P, C.c_int]),

@@ -462,6 +462,7 @@ struct WarpParams {
     const float *tgt;   // optional: with posenet_in, the target image to be masked by the warp validity
     float *posenet_in;  // optional [N,6,H,W]: (tgt * valid, img_rec) = the next PoseNet input of solve_pose_iteratively
     int H, W;           //                     (train_mono.py:74-76), written by the warp itself: no extra HBM round trip
+    int win_B, win_S;   // window form (win_B > 0): tgt [B,3,H,W], src [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W]; pair n as in k_pack
 };
 
 __device__ __forceinline__ float tap1(const float *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob) {
@@ -484,21 +485,29 @@ __global__ __launch_bounds__(256) void k_warp(WarpParams P) {
     if (idx >= hw) return;
     int v = idx / P.W, u = idx - v * P.W;
     const PairConst &c = P.pc[n];
+    const float *tgt = P.tgt ? P.tgt + (size_t)n * 3 * hw : nullptr, *src = P.src + (size_t)n * 3 * hw;
+    const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
+    if (P.win_B > 0) {   // the directed pairs of a window, formed by indexing (train_mono.py:54-62)
+        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
+        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)q * 3 * hw;
+        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)q * hw;
+        tgt = inv ? si : ti; src = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
+    }
     Geo g;
-    warp_geo(c, P.W, P.H, u, v, P.depth_t[(size_t)n * hw + idx], g);
+    warp_geo(c, P.W, P.H, u, v, dtp[idx], g);
     const bool oob = g.oobx || g.ooby;
     if (P.rec)
         for (int ch = 0; ch < 3; ch++)
-            P.rec[((size_t)n * 3 + ch) * hw + idx] = tap1(P.src + ((size_t)n * 3 + ch) * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+            P.rec[((size_t)n * 3 + ch) * hw + idx] = tap1(src + (size_t)ch * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
     if (P.valid) P.valid[(size_t)n * hw + idx] = oob ? 0.f : 1.f;
     if (P.posenet_in) {
         const float vm = oob ? 0.f : 1.f;
         for (int ch = 0; ch < 3; ch++) {
-            P.posenet_in[((size_t)n * 6 + ch) * hw + idx] = P.tgt[((size_t)n * 3 + ch) * hw + idx] * vm;
-            P.posenet_in[((size_t)n * 6 + 3 + ch) * hw + idx] = tap1(P.src + ((size_t)n * 3 + ch) * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+            P.posenet_in[((size_t)n * 6 + ch) * hw + idx] = tgt[(size_t)ch * hw + idx] * vm;
+            P.posenet_in[((size_t)n * 6 + 3 + ch) * hw + idx] = tap1(src + (size_t)ch * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
         }
     }
-    if (P.pd) P.pd[(size_t)n * hw + idx] = c.es * tap1(P.depth_s + (size_t)n * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+    if (P.pd) P.pd[(size_t)n * hw + idx] = c.es * tap1(dsp, P.W, P.H, u, v, g.rx, g.ry, oob);
     if (P.cd) P.cd[(size_t)n * hw + idx] = g.Z;
 }
 

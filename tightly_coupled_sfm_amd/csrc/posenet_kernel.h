@@ -1,0 +1,273 @@
+// posenet_kernel.h -- the reference's PoseNet (models/pose_models.py:88-147) on gfx950: seven weight-standardised stride-2
+// convolutions (conv2d_wn, :10-25) each followed by GroupNorm(16) + ReLU (conv_gn, :62-82), a 1x1 head, spatial mean, x 0.01.
+// It is called `iterations` times per window inside the coupled pose loop (train_mono.py:64,77), on the (tgt | src) /
+// (tgt * valid | img_rec) 6-channel inputs the warp kernel assembles.
+//
+// Design (MI355X, not a cuDNN/MIOpen call chain):
+//   * weights are frozen at test time: weight standardisation is done ONCE when the weights are loaded (k_pn_prep), which also
+//     lays them out for the matrix cores;
+//   * every convolution is an implicit GEMM  out[pixel][cout] = sum_k patch[pixel][k] w[k][cout]  on the fp32 matrix
+//     instruction v_mfma_f32_16x16x4_f32 (exact fp32: the bf16 forms would not hold the 1e-5 parity bar).  One wave owns 16
+//     output pixels x up to 64 output channels.  Operands go global -> registers with 16-byte loads and NO LDS staging: the A
+//     operand of four consecutive K-steps is ONE float4 per lane (four consecutive input channels of the lane's pixel at the
+//     current tap), the B operand one float4 per lane and 16-channel block from a weight image stored in exactly that order
+//     (K is summed in a permuted order; any fixed order is a valid GEMM).  Activations are NHWC so that those float4 are contiguous;
+//   * GroupNorm needs whole-image statistics, i.e. a grid-wide dependency between a convolution and its consumer: k_pn_stats
+//     (one workgroup per image and group) reduces them deterministically into per-channel scale / shift, and the CONSUMER applies
+//     normalisation + ReLU on the fly while loading its A operand -- the normalised activation is never written;
+//   * the last layers have 120 / 30 / 10 output pixels per image and K up to 2304: they are split over K across workgroups
+//     (partial sums reduced, in fixed order, by the same k_pn_stats pass);
+//   * the first layer reads the caller's planar NCHW images directly (two 3-channel pointers per image: no concatenated
+//     [N,6,H,W] tensor is needed for the first call of the loop), input normalisation (x - 0.45) / 0.22 fused.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tc {
+
+typedef float pn_f4 __attribute__((ext_vector_type(4)));
+
+struct PnLayer {           // geometry of one convolution layer (host-filled)
+    int cin, cout, ks, pad; // stride is 2 everywhere
+    int ih, iw, oh, ow;     // input / output spatial size
+    int ksplit;             // K-split factor (1 = none)
+    int kgroups;            // number of 16-wide K groups: layer 1: 21 (6 ch x 7 rows x 8 padded columns / 16), else ks*ks*cin/16
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight preparation: conv2d_wn's standardisation (pose_models.py:17-23: subtract the per-filter mean, divide by the UNBIASED
+// per-filter standard deviation + 1e-5) and the matrix-core layout.  One workgroup per output channel.
+//   generic layers (cin % 16 == 0): w4[((tap * cin/16 + c16) * 4 + kq) * cout + co] = float4 over t of w[co][ci = c16*16 + 4 kq + t][tap]
+//   first layer (cin = 6, 7x7):      w4[(grp * 4 + kq) * cout + co] = float4 over t of w[co][ci][ky][kx = 4 (kq & 1) + t], combo = 2 grp + (kq >> 1)
+//                                    = ci * 7 + ky, kx = 7 is the zero pad
+__global__ __launch_bounds__(256) void k_pn_prep(const float *w, pn_f4 *w4, int cin, int cout, int ks, int first, int standardize) {
+    const int co = blockIdx.x, tid = threadIdx.x, n = cin * ks * ks;
+    const float *wc = w + (size_t)co * n;
+    __shared__ double red[256];
+    __shared__ float s_mean, s_inv;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)wc[i];
+    red[tid] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float mean = (float)(red[0] / n);
+    __syncthreads();
+    double q = 0.0;
+    for (int i = tid; i < n; i += 256) { const double d = (double)(wc[i] - mean); q += d * d; }
+    red[tid] = q; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) { s_mean = standardize ? mean : 0.f; s_inv = standardize ? 1.f / ((float)sqrt(red[0] / (n - 1)) + 1e-5f) : 1.f; }
+    __syncthreads();
+    const float m = s_mean, inv = s_inv;
+    auto W = [&](int ci, int ky, int kx) { return (wc[(ci * ks + ky) * ks + kx] - m) * inv; };
+    if (first) {
+        const int ngrp = (cin * ks + 1) / 2;                       // 21 for 6 x 7
+        for (int e = tid; e < ngrp * 4; e += 256) {
+            const int grp = e >> 2, kq = e & 3, combo = 2 * grp + (kq >> 1);
+            pn_f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (combo < cin * ks) {
+                const int ci = combo / ks, ky = combo - ci * ks;
+                for (int t = 0; t < 4; t++) { const int kx = 4 * (kq & 1) + t; if (kx < ks) v[t] = W(ci, ky, kx); }
+            }
+            w4[(size_t)(grp * 4 + kq) * cout + co] = v;
+        }
+    } else {
+        const int c16n = cin / 16;
+        for (int e = tid; e < ks * ks * c16n * 4; e += 256) {
+            const int kq = e & 3, c16 = (e >> 2) % c16n, tap = (e >> 2) / c16n, ky = tap / ks, kx = tap - ky * ks;
+            pn_f4 v;
+            for (int t = 0; t < 4; t++) v[t] = W(c16 * 16 + 4 * kq + t, ky, kx);
+            w4[(size_t)((tap * c16n + c16) * 4 + kq) * cout + co] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct PnConvParams {
+    // first layer: two planar 3-channel images per sample.  Pair-stacked callers pass both with a per-sample stride; the window
+    // form (win_B > 0) indexes the B targets / S*B sources like k_pack: sample n = s B + b forward (tgt b | src (s,b)), inverse swapped
+    const float *imgA, *imgB;     // [*,3,IH,IW] planar
+    long long strideA, strideB;   // floats between consecutive samples
+    int win_B, win_S;
+    // generic layers: NHWC raw convolution output of the previous layer + its per-sample, per-channel GroupNorm scale / shift
+    const float *in;              // [N][IH][IW][CIN]
+    const float *scsh;            // [N][CIN][2]  (scale, shift): a = relu(x * scale + shift)
+    const pn_f4 *w4;              // prepared weights
+    const float *bias;            // [COUT] or null
+    float *out;                   // [ksplit][N][OH][OW][COUT] raw output (+ bias when ksplit == 1)
+    PnLayer L;
+    int N;
+};
+
+// One wave = 16 output pixels x (16 NB) output channels; a workgroup = 4 waves = 64 consecutive output pixels of ONE sample.
+// grid = (ceil(OH OW / 64), COUT / (16 NB), N * ksplit).
+template <int NB, bool FIRST>
+__global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
+    const PnLayer &L = P.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int ksp = blockIdx.z % L.ksplit, n = blockIdx.z / L.ksplit;
+    const int npix = L.oh * L.ow;
+    const int pix = (blockIdx.x * 4 + wave) * 16 + m;           // this lane's output pixel (A operand row)
+    const bool pvalid = pix < npix;
+    const int oy = pvalid ? pix / L.ow : 0, ox = pvalid ? pix - (pix / L.ow) * L.ow : 0;
+    const int cbase = blockIdx.y * 16 * NB;
+    pn_f4 acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = (pn_f4){0.f, 0.f, 0.f, 0.f};
+    // K groups of this split: contiguous ranges
+    const int g0 = (L.kgroups * ksp) / L.ksplit, g1 = (L.kgroups * (ksp + 1)) / L.ksplit;
+    if (FIRST) {
+        const int SB = P.win_S * P.win_B;
+        const float *pa, *pb;
+        if (P.win_B > 0) {
+            const int inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
+            const float *t = P.imgA + (size_t)b * P.strideA, *s = P.imgB + (size_t)q * P.strideB;
+            pa = inv ? s : t; pb = inv ? t : s;
+        } else { pa = P.imgA + (size_t)n * P.strideA; pb = P.imgB + (size_t)n * P.strideB; }
+        const int hw = L.ih * L.iw;
+        for (int g = g0; g < g1; g++) {
+            const int combo = 2 * g + (kq >> 1);                 // (ci, ky)
+            const int ci = combo / 7, ky = combo - ci * 7;
+            const int iy = oy * 2 + ky - 3, ix0 = ox * 2 - 3 + 4 * (kq & 1);
+            const bool rowok = pvalid && combo < 42 && iy >= 0 && iy < L.ih;
+            const float *row = (ci < 3 ? pa + (size_t)ci * hw : pb + (size_t)(ci - 3) * hw) + (size_t)(rowok ? iy : 0) * L.iw;
+            pn_f4 a;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int ix = ix0 + t;
+                const bool ok = rowok && ix >= 0 && ix < L.iw;
+                const float v = row[ok ? ix : 0];
+                a[t] = ok ? (v - 0.45f) * (1.f / 0.22f) : 0.f;   // (imgs - 0.45) / 0.22, pose_models.py:125; zero padding of the normalised image
+            }
+            pn_f4 b4[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) b4[b] = P.w4[(size_t)(g * 4 + kq) * L.cout + cbase + b * 16 + m];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[b][t], acc[b], 0, 0, 0);
+        }
+    } else {
+        const int c16n = L.cin / 16;
+        const float *in = P.in + (size_t)n * L.ih * L.iw * L.cin;
+        const pn_f4 *scsh = reinterpret_cast<const pn_f4 *>(P.scsh + (size_t)n * L.cin * 2);   // [(scale, shift) pairs]: 2 channels per float4
+        for (int g = g0; g < g1; g++) {
+            const int tap = g / c16n, c16 = g - tap * c16n;
+            const int ky = tap / L.ks, kx = tap - ky * L.ks;
+            const int iy = oy * 2 + ky - L.pad, ix = ox * 2 + kx - L.pad;
+            const bool ok = pvalid && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
+            const int c0 = c16 * 16 + 4 * kq;
+            pn_f4 a = *reinterpret_cast<const pn_f4 *>(in + ((size_t)(ok ? iy : 0) * L.iw + (ok ? ix : 0)) * L.cin + c0);
+            const pn_f4 s01 = scsh[c0 / 2], s23 = scsh[c0 / 2 + 1];              // (sc0, sh0, sc1, sh1), (sc2, sh2, sc3, sh3)
+            a[0] = ok ? fmaxf(a[0] * s01[0] + s01[1], 0.f) : 0.f;                 // GroupNorm + ReLU of the producer, zero padding after it
+            a[1] = ok ? fmaxf(a[1] * s01[2] + s01[3], 0.f) : 0.f;
+            a[2] = ok ? fmaxf(a[2] * s23[0] + s23[1], 0.f) : 0.f;
+            a[3] = ok ? fmaxf(a[3] * s23[2] + s23[3], 0.f) : 0.f;
+            pn_f4 b4[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) b4[b] = P.w4[(size_t)(g * 4 + kq) * L.cout + cbase + b * 16 + m];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[b][t], acc[b], 0, 0, 0);
+        }
+    }
+    // C/D layout of the 16x16 tile: column (output channel) = lane & 15, row (pixel) = 4 (lane >> 4) + reg
+    float *out = P.out + ((size_t)ksp * P.N + n) * npix * L.cout;
+    const int prow0 = (blockIdx.x * 4 + wave) * 16 + 4 * kq;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int co = cbase + b * 16 + m;
+        const float bs = (P.bias != nullptr && L.ksplit == 1) ? P.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (prow0 + r < npix) out[(size_t)(prow0 + r) * L.cout + co] = acc[b][r] + bs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics of one layer's raw output (+ the fixed-order reduction of its K-split partial sums, + bias for split
+// layers), one workgroup per (sample, group): mean and biased variance over the group's channels and all pixels (torch
+// GroupNorm), eps 1e-5, folded with the affine parameters into per-channel  scale = rstd gamma,  shift = beta - mean scale.
+struct PnStatsParams {
+    float *out;             // [ksplit][N][npix][cout] raw (reduced in place into split 0 when ksplit > 1)
+    const float *bias;      // [cout] or null (added here when ksplit > 1)
+    const float *gamma, *beta;   // [cout] GroupNorm affine, or null (1, 0)
+    float *scsh;            // [N][cout][2]
+    int N, npix, cout, ksplit;
+};
+
+__global__ __launch_bounds__(256) void k_pn_stats(PnStatsParams P) {
+    const int n = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int cg = P.cout / 16;                               // channels per group
+    const size_t plane = (size_t)P.N * P.npix * P.cout;
+    float *x = P.out + (size_t)n * P.npix * P.cout;
+    __shared__ double r1[256], r2[256];
+    double s = 0.0, q = 0.0;
+    const int total = P.npix * cg;
+    for (int e = tid; e < total; e += 256) {
+        const int p = e / cg, c = g * cg + (e - p * cg);
+        float v = x[(size_t)p * P.cout + c];
+        if (P.ksplit > 1) {
+            for (int k = 1; k < P.ksplit; k++) v += x[k * plane + (size_t)p * P.cout + c];      // fixed order
+            if (P.bias) v += P.bias[c];
+            x[(size_t)p * P.cout + c] = v;
+        }
+        s += (double)v; q += (double)v * (double)v;
+    }
+    r1[tid] = s; r2[tid] = q; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; } __syncthreads(); }
+    const double mean = r1[0] / total, var = fmax(r2[0] / total - mean * mean, 0.0);
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    if (tid < cg) {
+        const int c = g * cg + tid;
+        const float sc = rstd * (P.gamma ? P.gamma[c] : 1.f);
+        P.scsh[((size_t)n * P.cout + c) * 2] = sc;
+        P.scsh[((size_t)n * P.cout + c) * 2 + 1] = (P.beta ? P.beta[c] : 0.f) - (float)mean * sc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// head: GroupNorm + ReLU of conv7, 1x1 convolution 256 -> 6 (+ bias), spatial mean, x 0.01 (pose_models.py:135-137); optionally
+// accumulates into the running pose (full_poses += correction, train_mono.py:78) and records the iterate.  One workgroup per sample.
+struct PnHeadParams {
+    const float *x;         // [N][npix][256] raw conv7
+    const float *scsh;      // [N][256][2]
+    const float *w, *b;     // [6][256], [6]
+    float *pose;            // [N][6]
+    float *stacked;         // optional [N][iters][6] (row `it` receives the pose after this call), or null
+    int npix, accumulate, it, iters;
+};
+
+__global__ __launch_bounds__(256) void k_pn_head(PnHeadParams P) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    __shared__ float feat[256];
+    const float sc = P.scsh[((size_t)n * 256 + c) * 2], sh = P.scsh[((size_t)n * 256 + c) * 2 + 1];
+    float s = 0.f;
+    for (int p = 0; p < P.npix; p++) s += fmaxf(P.x[((size_t)n * P.npix + p) * 256 + c] * sc + sh, 0.f);
+    feat[c] = s / (float)P.npix;                              // the mean commutes with the 1x1 convolution
+    __syncthreads();
+    __shared__ float part[6][4];
+    const int o = c >> 6 < 4 ? c & 63 : 0;
+    // 6 outputs: wave w sums a quarter of the channels for every output, fixed order
+    const int wave = c >> 6, lane = c & 63;
+    float acc[6] = {0, 0, 0, 0, 0, 0};
+    const int ch = wave * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc[j] = feat[ch] * P.w[j * 256 + ch];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float v = acc[j];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+        if (lane == 0) part[j][wave] = v;
+    }
+    (void)o;
+    __syncthreads();
+    if (c < 6) {
+        float v = 0.01f * (part[c][0] + part[c][1] + part[c][2] + part[c][3] + P.b[c]);
+        if (P.accumulate) v += P.pose[n * 6 + c];
+        P.pose[n * 6 + c] = v;
+        if (P.stacked) P.stacked[((size_t)n * P.iters + P.it) * 6 + c] = v;
+    }
+}
+
+}  // namespace tc

@@ -6,11 +6,13 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/tcsfm.h"
 #include "kernels.h"
 #include "dense_kernel.h"
 #include "scale_kernel.h"
+#include "posenet_kernel.h"
 
 using namespace tc;
 
@@ -530,7 +532,7 @@ int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, con
     WarpParams P;
     P.src = d_src; P.depth_t = d_dt; P.depth_s = d_ds; P.pc = h->pconst;
     P.rec = d_rec; P.valid = d_valid; P.pd = d_pd; P.cd = d_cd; P.H = h->H; P.W = h->W;
-    P.tgt = nullptr; P.posenet_in = nullptr;
+    P.tgt = nullptr; P.posenet_in = nullptr; P.win_B = 0; P.win_S = 0;
     hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, P);
     HIPCHK(h, hipGetLastError());
     if ((rc = copy_back(h, o, img_rec, d_rec, N * 3 * hw))) return rc;
@@ -565,6 +567,7 @@ int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const f
     WarpParams P;
     P.src = d_src; P.depth_t = d_dt; P.depth_s = d_ds; P.pc = h->pconst;
     P.rec = nullptr; P.valid = d_valid; P.pd = nullptr; P.cd = nullptr; P.tgt = d_tgt; P.posenet_in = d_out; P.H = h->H; P.W = h->W;
+    P.win_B = 0; P.win_S = 0;
     hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, P);
     HIPCHK(h, hipGetLastError());
     if ((rc = copy_back(h, o, posenet_in, d_out, N * 6 * hw))) return rc;
@@ -1115,6 +1118,173 @@ int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches)
         for (size_t w = l.first; w < l.first + l.second; w++) { t0 = st[2 * w] < t0 ? st[2 * w] : t0; t1 = st[2 * w + 1] > t1 ? st[2 * w + 1] : t1; }
         if (t1 > t0) { *ms_sum += (double)(t1 - t0) * 1e-5; (*launches)++; }   // 100 MHz ticks -> ms
     }
+    return TCSFM_OK;
+}
+
+// ---- PoseNet (models/pose_models.py:88-147) and the coupled pose loop (train_mono.py:64-80) ---------------------------------
+struct tcsfm_posenet {
+    tcsfm_ctx *h = nullptr;
+    int max_images = 0, loaded = 0;
+    PnLayer L[7];
+    pn_f4 *w4[7] = {};
+    float *bias[7] = {}, *gamma[7] = {}, *beta[7] = {};
+    float *act[7] = {}, *scsh[7] = {};
+    float *head_w = nullptr, *head_b = nullptr, *raw = nullptr;
+    float *in_buf = nullptr;     // [max_images,6,H,W] (tgt * valid | img_rec) written by the warp kernel
+    float *pose = nullptr;       // [max_images,6] running pose of the coupled loop
+};
+
+void tcsfm_posenet_destroy(tcsfm_posenet *pn) {
+    if (!pn) return;
+    DeviceGuard dev_guard(pn->h->device);
+    for (int l = 0; l < 7; l++) {
+        void *ptrs[] = {pn->w4[l], pn->bias[l], pn->gamma[l], pn->beta[l], pn->act[l], pn->scsh[l]};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+    }
+    void *ptrs[] = {pn->head_w, pn->head_b, pn->raw, pn->in_buf, pn->pose};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete pn;
+}
+
+int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
+    if (!h || !out) return TCSFM_E_ARG;
+    *out = nullptr;
+    if (max_images < 1 || max_images > 4096) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_create: max_images out of range");
+    DeviceGuard dev_guard(h->device);
+    tcsfm_posenet *pn = new tcsfm_posenet();
+    pn->h = h; pn->max_images = max_images;
+    static const int chans[8] = {6, 16, 32, 64, 128, 256, 256, 256}, ksz[7] = {7, 5, 3, 3, 3, 3, 3};
+    int ih = h->H, iw = h->W;
+    hipError_t e = hipSuccess;
+    size_t wmax = 0;
+    for (int l = 0; l < 7; l++) {
+        PnLayer &L = pn->L[l];
+        L.cin = chans[l]; L.cout = chans[l + 1]; L.ks = ksz[l]; L.pad = (ksz[l] - 1) / 2;
+        L.ih = ih; L.iw = iw; L.oh = (ih + 2 * L.pad - L.ks) / 2 + 1; L.ow = (iw + 2 * L.pad - L.ks) / 2 + 1;
+        L.kgroups = l == 0 ? 21 : L.ks * L.ks * L.cin / 16;
+        const int nb = L.cout >= 64 ? 4 : L.cout / 16;
+        const long long wgs = (long long)((L.oh * L.ow + 63) / 64) * (L.cout / (16 * nb));
+        // small layers: split K so that a 2-image call still spreads over ~256 workgroups
+        int ks = (int)((256 + 2 * wgs - 1) / (2 * wgs));
+        L.ksplit = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+        if (L.ksplit > L.kgroups) L.ksplit = L.kgroups;
+        if (L.oh < 1 || L.ow < 1) { tcsfm_posenet_destroy(pn); return fail(h, TCSFM_E_ARG, "tcsfm_posenet_create: image too small for seven stride-2 layers"); }
+        const size_t nw4 = (size_t)L.kgroups * 4 * L.cout;
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->w4[l], nw4 * sizeof(pn_f4));
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->bias[l], L.cout * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->gamma[l], L.cout * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->beta[l], L.cout * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->act[l], (size_t)L.ksplit * max_images * L.oh * L.ow * L.cout * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->scsh[l], (size_t)max_images * L.cout * 2 * sizeof(float));
+        wmax = std::max(wmax, (size_t)L.cout * L.cin * L.ks * L.ks);
+        ih = L.oh; iw = L.ow;
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->head_w, 6 * 256 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->head_b, 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->raw, wmax * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->in_buf, (size_t)max_images * 6 * h->H * h->W * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->pose, (size_t)max_images * 6 * sizeof(float));
+    if (e != hipSuccess) { tcsfm_posenet_destroy(pn); return fail(h, e == hipErrorOutOfMemory ? TCSFM_E_NOMEM : TCSFM_E_HIP, "tcsfm_posenet_create: allocation failed"); }
+    *out = pn;
+    return TCSFM_OK;
+}
+
+int tcsfm_posenet_load(tcsfm_posenet *pn, const float *const conv_w[7], const float *const conv_b[7], const float *const gn_w[7],
+                       const float *const gn_b[7], const float *head_w, const float *head_b) {
+    if (!pn) return TCSFM_E_ARG;
+    tcsfm_ctx *h = pn->h;
+    if (!conv_w || !head_w || !head_b) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_load: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    for (int l = 0; l < 7; l++) {
+        const PnLayer &L = pn->L[l];
+        if (!conv_w[l]) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_load: NULL convolution weight");
+        const size_t nw = (size_t)L.cout * L.cin * L.ks * L.ks;
+        HIPCHK(h, hipMemcpyAsync(pn->raw, conv_w[l], nw * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_pn_prep, dim3(L.cout), dim3(256), 0, h->stream, (const float *)pn->raw, pn->w4[l], L.cin, L.cout, L.ks, l == 0 ? 1 : 0, 1);
+        HIPCHK(h, hipStreamSynchronize(h->stream));    // pn->raw is reused by the next layer; loading happens once per model
+        std::vector<float> ones(L.cout, 1.f), zeros(L.cout, 0.f);
+        HIPCHK(h, hipMemcpy(pn->bias[l], conv_b && conv_b[l] ? conv_b[l] : zeros.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(pn->gamma[l], gn_w && gn_w[l] ? gn_w[l] : ones.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(pn->beta[l], gn_b && gn_b[l] ? gn_b[l] : zeros.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIPCHK(h, hipMemcpy(pn->head_w, head_w, 6 * 256 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(pn->head_b, head_b, 6 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipGetLastError());
+    pn->loaded = 1;
+    return TCSFM_OK;
+}
+
+namespace {
+// the seven convolutions + statistics passes + head of one PoseNet evaluation on N samples; the first layer reads
+// (imgA | imgB) per sample (strides in floats; window indexing when win_B > 0)
+int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const float *imgB, long long strideB, int win_B, int win_S,
+           float *pose, int accumulate, float *stacked, int it, int iters) {
+    tcsfm_ctx *h = pn->h;
+    for (int l = 0; l < 7; l++) {
+        const PnLayer &L = pn->L[l];
+        PnConvParams P;
+        memset(&P, 0, sizeof(P));
+        P.imgA = imgA; P.imgB = imgB; P.strideA = strideA; P.strideB = strideB; P.win_B = win_B; P.win_S = win_S;
+        P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
+        P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.L = L; P.N = N;
+        const int nb = L.cout >= 64 ? 4 : L.cout / 16;
+        const dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
+        if (l == 0) hipLaunchKernelGGL((k_pn_conv<1, true>), grid, dim3(256), 0, h->stream, P);
+        else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
+        else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
+        PnStatsParams S;
+        S.out = pn->act[l]; S.bias = pn->bias[l]; S.gamma = pn->gamma[l]; S.beta = pn->beta[l]; S.scsh = pn->scsh[l];
+        S.N = N; S.npix = L.oh * L.ow; S.cout = L.cout; S.ksplit = L.ksplit;
+        hipLaunchKernelGGL(k_pn_stats, dim3(N, 16), dim3(256), 0, h->stream, S);
+    }
+    PnHeadParams Hd;
+    Hd.x = pn->act[6]; Hd.scsh = pn->scsh[6]; Hd.w = pn->head_w; Hd.b = pn->head_b; Hd.pose = pose; Hd.stacked = stacked;
+    Hd.npix = pn->L[6].oh * pn->L[6].ow; Hd.accumulate = accumulate; Hd.it = it; Hd.iters = iters;
+    hipLaunchKernelGGL(k_pn_head, dim3(N), dim3(256), 0, h->stream, Hd);
+    HIPCHK(h, hipGetLastError());
+    return TCSFM_OK;
+}
+}  // namespace
+
+int tcsfm_posenet_forward(tcsfm_posenet *pn, int N, const float *imgs, float *pose_out) {
+    if (!pn) return TCSFM_E_ARG;
+    tcsfm_ctx *h = pn->h;
+    if (!pn->loaded) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_forward: no weights loaded");
+    if (N < 1 || N > pn->max_images || !imgs || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_forward: bad argument");
+    DeviceGuard dev_guard(h->device);
+    const long long hw = (long long)h->H * h->W;
+    return pn_run(pn, N, imgs, 6 * hw, imgs + 3 * hw, 6 * hw, 0, 0, pose_out, 0, nullptr, 0, 1);
+}
+
+int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, float *poses_out, float *stacked_out) {
+    if (!h || !pn || pn->h != h) return TCSFM_E_ARG;
+    if (!pn->loaded) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: no weights loaded");
+    const int N = 2 * B * S;
+    if (num_iter < 1 || B < 1 || S < 1 || N > pn->max_images || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: sizes out of range");
+    if (!tgt || !srcs || !depth_t || !depth_s || !K || !poses_out) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
+    int rc;
+    tcsfm_opts o; tcsfm_default_opts(&o);
+    if ((rc = check_intrinsics(h, &o, K, B))) return rc;
+    const long long hw = (long long)h->H * h->W;
+    // full_poses = pose_model(cat(tgt | src ; src | tgt)), train_mono.py:54-64 -- the pairs are formed by indexing
+    if ((rc = pn_run(pn, N, tgt, 3 * hw, srcs, 3 * hw, B, S, pn->pose, 0, stacked_out, 0, num_iter))) return rc;
+    for (int it = 1; it < num_iter; it++) {
+        // inverse_warp2(src, d_t, d_s, -full_poses, K) with the next network input (tgt * valid | img_rec) written by the warp
+        // itself (train_mono.py:69-76), then full_poses += pose_model(new_imgs) (:77-78)
+        InitParams I = init_params(h, &o, N, pn->pose, nullptr, K, 0);
+        I.K_mod = B;
+        hipLaunchKernelGGL(k_init, dim3((N + 63) / 64), dim3(64), 0, h->stream, I);
+        WarpParams W;
+        memset(&W, 0, sizeof(W));
+        W.src = srcs; W.depth_t = depth_t; W.depth_s = depth_s; W.pc = h->pconst; W.tgt = tgt; W.posenet_in = pn->in_buf;
+        W.H = h->H; W.W = h->W; W.win_B = B; W.win_S = S;
+        hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, W);
+        if ((rc = pn_run(pn, N, pn->in_buf, 6 * hw, pn->in_buf + 3 * hw, 6 * hw, 0, 0, pn->pose, 1, stacked_out, it, num_iter))) return rc;
+    }
+    HIPCHK(h, hipMemcpyAsync(poses_out, pn->pose, (size_t)N * 6 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return TCSFM_OK;
 }
 
