@@ -93,6 +93,7 @@ struct PnConvParams {
     const pn_f4 *w4;              // prepared weights
     const float *bias;            // [COUT] or null
     float *out;                   // [ksplit][N][OH][OW][COUT] raw output (+ bias when ksplit == 1)
+    float *part;                  // ksplit == 1: [N][tiles][COUT][2] per-workgroup (sum, sum of squares) of the outputs, for GroupNorm
     PnLayer L;
     int N;
 };
@@ -115,7 +116,11 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
     for (int b = 0; b < NB; b++) acc[b] = (pn_f4){0.f, 0.f, 0.f, 0.f};
     // K groups of this split: contiguous ranges
     const int g0 = (L.kgroups * ksp) / L.ksplit, g1 = (L.kgroups * (ksp + 1)) / L.ksplit;
+    // The K loop is latency-bound, not matrix-bound (a layer has only a few hundred waves, far fewer than would hide a global load
+    // behind other waves' MFMAs): the loads of GC consecutive K groups are issued together, then their 16 GC MFMAs run -- the
+    // compiler keeps the whole batch of loads in flight (one wait per batch instead of one per group).
     if (FIRST) {
+        constexpr int GC = 7;                                    // 21 groups = 3 batches
         const int SB = P.win_S * P.win_B;
         const float *pa, *pb;
         if (P.win_B > 0) {
@@ -124,63 +129,103 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
             pa = inv ? s : t; pb = inv ? t : s;
         } else { pa = P.imgA + (size_t)n * P.strideA; pb = P.imgB + (size_t)n * P.strideB; }
         const int hw = L.ih * L.iw;
-        for (int g = g0; g < g1; g++) {
-            const int combo = 2 * g + (kq >> 1);                 // (ci, ky)
-            const int ci = combo / 7, ky = combo - ci * 7;
-            const int iy = oy * 2 + ky - 3, ix0 = ox * 2 - 3 + 4 * (kq & 1);
-            const bool rowok = pvalid && combo < 42 && iy >= 0 && iy < L.ih;
-            const float *row = (ci < 3 ? pa + (size_t)ci * hw : pb + (size_t)(ci - 3) * hw) + (size_t)(rowok ? iy : 0) * L.iw;
-            pn_f4 a;
+        for (int gb = g0; gb < g1; gb += GC) {
+            pn_f4 a[GC], b4[GC][NB];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int ix = ix0 + t;
-                const bool ok = rowok && ix >= 0 && ix < L.iw;
-                const float v = row[ok ? ix : 0];
-                a[t] = ok ? (v - 0.45f) * (1.f / 0.22f) : 0.f;   // (imgs - 0.45) / 0.22, pose_models.py:125; zero padding of the normalised image
+            for (int u = 0; u < GC; u++) {
+                const int g = gb + u;
+                const bool gok = g < g1;
+                const int combo = 2 * (gok ? g : g0) + (kq >> 1);    // (ci, ky)
+                const int ci = combo / 7, ky = combo - ci * 7;
+                const int iy = oy * 2 + ky - 3, ix0 = ox * 2 - 3 + 4 * (kq & 1);
+                const bool rowok = gok && pvalid && iy >= 0 && iy < L.ih;
+                const float *row = (ci < 3 ? pa + (size_t)ci * hw : pb + (size_t)(ci - 3) * hw) + (size_t)(rowok ? iy : 0) * L.iw;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int ix = ix0 + t;
+                    const bool ok = rowok && ix >= 0 && ix < L.iw;
+                    const float v = row[ok ? ix : 0];
+                    a[u][t] = ok ? (v - 0.45f) * (1.f / 0.22f) : 0.f;   // (imgs - 0.45) / 0.22, pose_models.py:125; zero padding of the normalised image
+                }
+#pragma unroll
+                for (int b = 0; b < NB; b++) b4[u][b] = P.w4[(size_t)((gok ? g : g0) * 4 + kq) * L.cout + cbase + b * 16 + m];
             }
-            pn_f4 b4[NB];
+            __builtin_amdgcn_sched_barrier(0);       // all loads of the batch are issued before the first MFMA (hipcc otherwise re-serialises them)
 #pragma unroll
-            for (int b = 0; b < NB; b++) b4[b] = P.w4[(size_t)(g * 4 + kq) * L.cout + cbase + b * 16 + m];
+            for (int u = 0; u < GC; u++)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[b][t], acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b4[u][b][t], acc[b], 0, 0, 0);
         }
     } else {
+        constexpr int GC = 4;
         const int c16n = L.cin / 16;
         const float *in = P.in + (size_t)n * L.ih * L.iw * L.cin;
         const pn_f4 *scsh = reinterpret_cast<const pn_f4 *>(P.scsh + (size_t)n * L.cin * 2);   // [(scale, shift) pairs]: 2 channels per float4
-        for (int g = g0; g < g1; g++) {
-            const int tap = g / c16n, c16 = g - tap * c16n;
-            const int ky = tap / L.ks, kx = tap - ky * L.ks;
-            const int iy = oy * 2 + ky - L.pad, ix = ox * 2 + kx - L.pad;
-            const bool ok = pvalid && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
-            const int c0 = c16 * 16 + 4 * kq;
-            pn_f4 a = *reinterpret_cast<const pn_f4 *>(in + ((size_t)(ok ? iy : 0) * L.iw + (ok ? ix : 0)) * L.cin + c0);
-            const pn_f4 s01 = scsh[c0 / 2], s23 = scsh[c0 / 2 + 1];              // (sc0, sh0, sc1, sh1), (sc2, sh2, sc3, sh3)
-            a[0] = ok ? fmaxf(a[0] * s01[0] + s01[1], 0.f) : 0.f;                 // GroupNorm + ReLU of the producer, zero padding after it
-            a[1] = ok ? fmaxf(a[1] * s01[2] + s01[3], 0.f) : 0.f;
-            a[2] = ok ? fmaxf(a[2] * s23[0] + s23[1], 0.f) : 0.f;
-            a[3] = ok ? fmaxf(a[3] * s23[2] + s23[3], 0.f) : 0.f;
-            pn_f4 b4[NB];
+        for (int gb = g0; gb < g1; gb += GC) {
+            pn_f4 a[GC], s01[GC], s23[GC], b4[GC][NB];
+            bool ok[GC];
 #pragma unroll
-            for (int b = 0; b < NB; b++) b4[b] = P.w4[(size_t)(g * 4 + kq) * L.cout + cbase + b * 16 + m];
+            for (int u = 0; u < GC; u++) {
+                const int g = gb + u < g1 ? gb + u : g0;
+                const int tap = g / c16n, c16 = g - tap * c16n;
+                const int ky = tap / L.ks, kx = tap - ky * L.ks;
+                const int iy = oy * 2 + ky - L.pad, ix = ox * 2 + kx - L.pad;
+                ok[u] = gb + u < g1 && pvalid && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
+                const int c0 = c16 * 16 + 4 * kq;
+                a[u] = *reinterpret_cast<const pn_f4 *>(in + ((size_t)(ok[u] ? iy : 0) * L.iw + (ok[u] ? ix : 0)) * L.cin + c0);
+                s01[u] = scsh[c0 / 2]; s23[u] = scsh[c0 / 2 + 1];            // (sc0, sh0, sc1, sh1), (sc2, sh2, sc3, sh3)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int b = 0; b < NB; b++) b4[u][b] = P.w4[(size_t)(g * 4 + kq) * L.cout + cbase + b * 16 + m];
+            }
+            __builtin_amdgcn_sched_barrier(0);       // all loads of the batch are issued before the first use
 #pragma unroll
-                for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[b][t], acc[b], 0, 0, 0);
+            for (int u = 0; u < GC; u++) {     // GroupNorm + ReLU of the producer, zero padding AFTER it; a group past the end contributes 0
+                a[u][0] = ok[u] ? fmaxf(a[u][0] * s01[u][0] + s01[u][1], 0.f) : 0.f;
+                a[u][1] = ok[u] ? fmaxf(a[u][1] * s01[u][2] + s01[u][3], 0.f) : 0.f;
+                a[u][2] = ok[u] ? fmaxf(a[u][2] * s23[u][0] + s23[u][1], 0.f) : 0.f;
+                a[u][3] = ok[u] ? fmaxf(a[u][3] * s23[u][2] + s23[u][3], 0.f) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < GC; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b4[u][b][t], acc[b], 0, 0, 0);
         }
     }
     // C/D layout of the 16x16 tile: column (output channel) = lane & 15, row (pixel) = 4 (lane >> 4) + reg
     float *out = P.out + ((size_t)ksp * P.N + n) * npix * L.cout;
     const int prow0 = (blockIdx.x * 4 + wave) * 16 + 4 * kq;
+    __shared__ float wsum[4][16 * NB][2];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int co = cbase + b * 16 + m;
         const float bs = (P.bias != nullptr && L.ksplit == 1) ? P.bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            if (prow0 + r < npix) out[(size_t)(prow0 + r) * L.cout + co] = acc[b][r] + bs;
+            if (prow0 + r < npix) {
+                const float v = acc[b][r] + bs;
+                out[(size_t)(prow0 + r) * L.cout + co] = v;
+                s1 += v; s2 += v * v;
+            }
+        // GroupNorm partial sums of this workgroup's 64 pixels, per channel: the 4 row groups of the wave (lanes m, m+16, m+32,
+        // m+48), then the 4 waves through LDS, both in fixed order
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (kq == 0) { wsum[wave][b * 16 + m][0] = s1; wsum[wave][b * 16 + m][1] = s2; }
+    }
+    if (L.ksplit == 1 && P.part != nullptr) {
+        __syncthreads();
+        const int c = threadIdx.x;
+        if (c < 16 * NB) {
+            const float t1 = (wsum[0][c][0] + wsum[1][c][0]) + (wsum[2][c][0] + wsum[3][c][0]);
+            const float t2 = (wsum[0][c][1] + wsum[1][c][1]) + (wsum[2][c][1] + wsum[3][c][1]);
+            float *pp = P.part + (((size_t)n * gridDim.x + blockIdx.x) * L.cout + cbase + c) * 2;
+            pp[0] = t1; pp[1] = t2;
+        }
     }
 }
 
@@ -189,6 +234,8 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
 // layers), one workgroup per (sample, group): mean and biased variance over the group's channels and all pixels (torch
 // GroupNorm), eps 1e-5, folded with the affine parameters into per-channel  scale = rstd gamma,  shift = beta - mean scale.
 struct PnStatsParams {
+    const float *part;      // ksplit == 1: [N][tiles][cout][2] partial sums written by the convolution's epilogue
+    int tiles;
     float *out;             // [ksplit][N][npix][cout] raw (reduced in place into split 0 when ksplit > 1)
     const float *bias;      // [cout] or null (added here when ksplit > 1)
     const float *gamma, *beta;   // [cout] GroupNorm affine, or null (1, 0)
@@ -204,6 +251,13 @@ __global__ __launch_bounds__(256) void k_pn_stats(PnStatsParams P) {
     __shared__ double r1[256], r2[256];
     double s = 0.0, q = 0.0;
     const int total = P.npix * cg;
+    if (P.ksplit == 1 && P.part != nullptr) {       // fixed-order sum of the workgroup partials of this group's channels
+        const float *pp = P.part + (size_t)n * P.tiles * P.cout * 2;
+        for (int e = tid; e < P.tiles * cg; e += 256) {
+            const int t = e / cg, c = g * cg + (e - t * cg);
+            s += (double)pp[((size_t)t * P.cout + c) * 2]; q += (double)pp[((size_t)t * P.cout + c) * 2 + 1];
+        }
+    } else
     for (int e = tid; e < total; e += 256) {
         const int p = e / cg, c = g * cg + (e - p * cg);
         float v = x[(size_t)p * P.cout + c];

@@ -1128,7 +1128,7 @@ struct tcsfm_posenet {
     PnLayer L[7];
     pn_f4 *w4[7] = {};
     float *bias[7] = {}, *gamma[7] = {}, *beta[7] = {};
-    float *act[7] = {}, *scsh[7] = {};
+    float *act[7] = {}, *scsh[7] = {}, *part[7] = {};
     float *head_w = nullptr, *head_b = nullptr, *raw = nullptr;
     float *in_buf = nullptr;     // [max_images,6,H,W] (tgt * valid | img_rec) written by the warp kernel
     float *pose = nullptr;       // [max_images,6] running pose of the coupled loop
@@ -1138,7 +1138,7 @@ void tcsfm_posenet_destroy(tcsfm_posenet *pn) {
     if (!pn) return;
     DeviceGuard dev_guard(pn->h->device);
     for (int l = 0; l < 7; l++) {
-        void *ptrs[] = {pn->w4[l], pn->bias[l], pn->gamma[l], pn->beta[l], pn->act[l], pn->scsh[l]};
+        void *ptrs[] = {pn->w4[l], pn->bias[l], pn->gamma[l], pn->beta[l], pn->act[l], pn->scsh[l], pn->part[l]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
     }
     void *ptrs[] = {pn->head_w, pn->head_b, pn->raw, pn->in_buf, pn->pose};
@@ -1162,12 +1162,10 @@ int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
         L.cin = chans[l]; L.cout = chans[l + 1]; L.ks = ksz[l]; L.pad = (ksz[l] - 1) / 2;
         L.ih = ih; L.iw = iw; L.oh = (ih + 2 * L.pad - L.ks) / 2 + 1; L.ow = (iw + 2 * L.pad - L.ks) / 2 + 1;
         L.kgroups = l == 0 ? 21 : L.ks * L.ks * L.cin / 16;
-        const int nb = L.cout >= 64 ? 4 : L.cout / 16;
-        const long long wgs = (long long)((L.oh * L.ow + 63) / 64) * (L.cout / (16 * nb));
-        // small layers: split K so that a 2-image call still spreads over ~256 workgroups
-        int ks = (int)((256 + 2 * wgs - 1) / (2 * wgs));
-        L.ksplit = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
-        if (L.ksplit > L.kgroups) L.ksplit = L.kgroups;
+        // K split: only the small late layers (few output pixels, K up to 2304), so that one wave's K loop stays around 24 groups
+        // of 16 MFMAs; the big early layers keep K whole and get their GroupNorm partial sums from the convolution's epilogue
+        L.ksplit = 1;
+        if (L.oh * L.ow <= 512) L.ksplit = std::min(16, (L.kgroups + 23) / 24);
         if (L.oh < 1 || L.ow < 1) { tcsfm_posenet_destroy(pn); return fail(h, TCSFM_E_ARG, "tcsfm_posenet_create: image too small for seven stride-2 layers"); }
         const size_t nw4 = (size_t)L.kgroups * 4 * L.cout;
         if (e == hipSuccess) e = hipMalloc((void **)&pn->w4[l], nw4 * sizeof(pn_f4));
@@ -1176,6 +1174,8 @@ int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
         if (e == hipSuccess) e = hipMalloc((void **)&pn->beta[l], L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->act[l], (size_t)L.ksplit * max_images * L.oh * L.ow * L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->scsh[l], (size_t)max_images * L.cout * 2 * sizeof(float));
+        if (e == hipSuccess && L.ksplit == 1)
+            e = hipMalloc((void **)&pn->part[l], (size_t)max_images * ((L.oh * L.ow + 63) / 64) * L.cout * 2 * sizeof(float));
         wmax = std::max(wmax, (size_t)L.cout * L.cin * L.ks * L.ks);
         ih = L.oh; iw = L.ow;
     }
@@ -1226,13 +1226,14 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         memset(&P, 0, sizeof(P));
         P.imgA = imgA; P.imgB = imgB; P.strideA = strideA; P.strideB = strideB; P.win_B = win_B; P.win_S = win_S;
         P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
-        P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.L = L; P.N = N;
+        P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = pn->part[l]; P.L = L; P.N = N;
         const int nb = L.cout >= 64 ? 4 : L.cout / 16;
         const dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
         if (l == 0) hipLaunchKernelGGL((k_pn_conv<1, true>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
         else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
         PnStatsParams S;
+        S.part = pn->part[l]; S.tiles = (L.oh * L.ow + 63) / 64;
         S.out = pn->act[l]; S.bias = pn->bias[l]; S.gamma = pn->gamma[l]; S.beta = pn->beta[l]; S.scsh = pn->scsh[l];
         S.N = N; S.npix = L.oh * L.ow; S.cout = L.cout; S.ksplit = L.ksplit;
         hipLaunchKernelGGL(k_pn_stats, dim3(N, 16), dim3(256), 0, h->stream, S);
