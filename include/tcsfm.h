@@ -105,6 +105,11 @@ int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const fl
 /* SSIM_Loss.forward(x, y), losses.py:27-41: `planes` = N*C images of H x W each (reflect pad 1, 3x3 means, clamp). */
 int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, const float *y, float *out);
 
+/* get_smooth_loss(disp, img), losses.py:43-61: edge-aware smoothness of the mean-normalised disparity, disp [N,1,H,W],
+ * img [N,3,H,W] -> one scalar (host double; the call synchronises the stream).  Off by default in the reference
+ * (options['l_smooth'], run_sequential_optimization.py:87); a logging quantity here, not a term of the Gauss-Newton cost. */
+int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *disp, const float *img, double *loss_out);
+
 /* inverse_warp2(src, depth_t, depth_s, -pose, K), models/stn.py:234-273.
  * Outputs (any may be NULL): img_rec [N,3,H,W], valid [N,1,H,W], proj_depth, comp_depth [N,1,H,W]. */
 int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,

@@ -147,6 +147,26 @@ def test_optimization_loss_vs_reference_golden():
     assert _maxabs(s, so) < 2e-6
 
 
+def test_smooth_loss_kernel_vs_reference_expression():
+    """get_smooth_loss (losses.py:43-61) as a HIP kernel against the reference's expression evaluated in float64 torch, and the
+    drop-in losses.get_smooth_loss routing GPU tensors through it (the expression itself is pinned on golden G5's `smooth` toggle)"""
+    from tightly_coupled_sfm_amd import losses
+    g = load_golden("batch24x40")
+    disp, img = g["loss_disp"], g["target"]
+    H, W = img.shape[2:]
+    d64, i64 = torch.tensor(disp, dtype=torch.float64), torch.tensor(img, dtype=torch.float64)
+    ref = float(losses.get_smooth_loss(d64, i64))
+    e = _eng(H, W, disp.shape[0])
+    got = e.smooth_loss(_t(disp), _t(img))
+    assert abs(got - ref) < 2e-6 * abs(ref), (got, ref)
+    assert abs(float(losses.get_smooth_loss(_t(disp), _t(img))) - ref) < 2e-6 * abs(ref)
+    rng = np.random.default_rng(5)                       # a size with ragged blocks, non-trivial values
+    e2 = _eng(37, 53, 3)
+    dd, ii = rng.uniform(0.05, 0.9, (3, 1, 37, 53)), rng.uniform(0, 1, (3, 3, 37, 53))
+    r2 = float(losses.get_smooth_loss(torch.tensor(dd), torch.tensor(ii)))
+    assert abs(e2.smooth_loss(_t(dd), _t(ii)) - r2) < 2e-6 * r2
+
+
 def test_loss_surface_vs_reference_golden():
     """generate_loss_surface (plot_loss_surface.py:11-87): both 50-point sweeps in one launch each"""
     g = load_golden("sweep48x160")

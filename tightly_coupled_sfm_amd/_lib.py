@@ -35,6 +35,7 @@ _SIGNATURES = {
     "tcsfm_default_opts": (None, [C.POINTER(Opts)]),
     "tcsfm_algorithmic_bytes_per_pixel": (C.c_int, [C.POINTER(Opts)]),
     "tcsfm_disp_to_depth": (C.c_int, [_P, C.POINTER(Opts), C.c_int64, _P, _P, _P]),
+    "tcsfm_smooth_loss": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, _P]),
     "tcsfm_ssim": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, _P]),
     "tcsfm_warp": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_warp_posenet_input": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),

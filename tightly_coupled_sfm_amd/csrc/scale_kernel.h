@@ -110,4 +110,42 @@ __global__ void k_sel_pick(unsigned *hist, unsigned *state, int shift, float rea
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// get_smooth_loss, losses.py:43-61: edge-aware smoothness of the mean-normalised disparity,
+//   mean |d_x (disp / mean disp)| exp(-mean_c |d_x img|)  +  the same in y.
+// k_smooth_mean: per-image mean of the disparity (one workgroup per image, fp64, fixed order);
+// k_smooth: per-pixel terms, one (sum_x, sum_y) partial per workgroup (fixed-order LDS tree); the host adds the partials in double.
+__global__ __launch_bounds__(1024) void k_smooth_mean(const float *disp, int hw, double *mean) {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int i = tid; i < hw; i += 1024) s += (double)disp[(size_t)n * hw + i];
+    red[tid] = s; __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) mean[n] = red[0] / hw;
+}
+
+__global__ __launch_bounds__(256) void k_smooth(const float *disp, const float *img, const double *mean, int H, int W, float *partial) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y, hw = H * W;
+    float sx = 0.f, sy = 0.f;
+    if (idx < hw) {
+        const int v = idx / W, u = idx - v * W;
+        const float inv = 1.f / ((float)mean[n] + 1e-7f);
+        const float *d = disp + (size_t)n * hw, *im = img + (size_t)n * 3 * hw;
+        const float d0 = d[idx] * inv;
+        if (u < W - 1) {
+            const float g = (fabsf(im[idx] - im[idx + 1]) + fabsf(im[hw + idx] - im[hw + idx + 1]) + fabsf(im[2 * hw + idx] - im[2 * hw + idx + 1])) * (1.f / 3.f);
+            sx = fabsf(d0 - d[idx + 1] * inv) * __expf(-g);
+        }
+        if (v < H - 1) {
+            const float g = (fabsf(im[idx] - im[idx + W]) + fabsf(im[hw + idx] - im[hw + idx + W]) + fabsf(im[2 * hw + idx] - im[2 * hw + idx + W])) * (1.f / 3.f);
+            sy = fabsf(d0 - d[idx + W] * inv) * __expf(-g);
+        }
+    }
+    __shared__ float rx[256], ry[256];
+    rx[threadIdx.x] = sx; ry[threadIdx.x] = sy; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { rx[threadIdx.x] += rx[threadIdx.x + o]; ry[threadIdx.x] += ry[threadIdx.x + o]; } __syncthreads(); }
+    if (threadIdx.x == 0) { partial[((size_t)n * gridDim.x + blockIdx.x) * 2] = rx[0]; partial[((size_t)n * gridDim.x + blockIdx.x) * 2 + 1] = ry[0]; }
+}
+
 }  // namespace tc

@@ -814,6 +814,38 @@ int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float
     return TCSFM_OK;
 }
 
+int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *disp, const float *img, double *loss_out) {
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!disp || !img || !loss_out) return fail(h, TCSFM_E_ARG, "tcsfm_smooth_loss: NULL argument");
+    if (h->H < 2 || h->W < 2) return fail(h, TCSFM_E_ARG, "tcsfm_smooth_loss: image too small");
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
+    const size_t hw = (size_t)h->H * h->W;
+    const int nb = (int)((hw + 255) / 256);
+    const float *d_disp, *d_img;
+    if ((rc = to_dev(h, o, 0, disp, N * hw, &d_disp))) return rc;
+    if ((rc = to_dev(h, o, 1, img, N * 3 * hw, &d_img))) return rc;
+    // scratch: N means (double) + N * nb * 2 partial sums, carved from the staging slot 2
+    float *scratch;
+    tcsfm_opts os = *o; os.host_ptrs = 1;
+    const size_t nfl = (size_t)N * 2 + (size_t)N * nb * 2;
+    float dummy;
+    if ((rc = out_dev(h, &os, 2, &dummy, nfl, &scratch))) return rc;
+    double *mean = reinterpret_cast<double *>(scratch);
+    float *partial = scratch + (size_t)N * 2;
+    hipLaunchKernelGGL(k_smooth_mean, dim3(N), dim3(1024), 0, h->stream, d_disp, (int)hw, mean);
+    hipLaunchKernelGGL(k_smooth, dim3(nb, N), dim3(256), 0, h->stream, d_disp, d_img, (const double *)mean, h->H, h->W, partial);
+    HIPCHK(h, hipGetLastError());
+    std::vector<float> hp((size_t)N * nb * 2);
+    HIPCHK(h, hipMemcpyAsync(hp.data(), partial, hp.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double sx = 0.0, sy = 0.0;
+    for (size_t i = 0; i < hp.size(); i += 2) { sx += hp[i]; sy += hp[i + 1]; }
+    *loss_out = sx / ((double)N * h->H * (h->W - 1)) + sy / ((double)N * (h->H - 1) * h->W);
+    return TCSFM_OK;
+}
+
 // shared body of tcsfm_refine_dense (win_B == 0) and tcsfm_refine_dense_window
 static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,

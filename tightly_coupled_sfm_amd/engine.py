@@ -160,6 +160,15 @@ class Engine:
         self._call(self.lib.tcsfm_ssim(self._h, C.byref(o), N * Cc, self._p(x), self._p(y), self._p(out)))
         return out
 
+    def smooth_loss(self, disp: torch.Tensor, img: torch.Tensor) -> float:
+        """get_smooth_loss (losses.py:43-61): disp [N,1,H,W], img [N,3,H,W] -> python float"""
+        self._bind()
+        N = disp.shape[0]
+        disp = _chk(disp, (N, 1, self.H, self.W), "disp"); img = _chk(img, (N, 3, self.H, self.W), "img")
+        out = C.c_double()
+        self._call(self.lib.tcsfm_smooth_loss(self._h, C.byref(default_opts()), N, self._p(disp), self._p(img), C.byref(out)))
+        return out.value
+
     def inverse_warp2(self, img, depth, ref_depth, pose, intrinsics):
         """models/stn.py:234-273 with the reference's argument order; ``pose`` here is what the reference
         passes, i.e. callers that wrote ``inverse_warp2(src, d_t, d_s, -poses, K)`` keep passing ``-poses``."""

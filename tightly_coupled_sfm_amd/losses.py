@@ -20,7 +20,14 @@ class SSIM_Loss:
 
 
 def get_smooth_loss(disp: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
-    """losses.py:43-61: edge-aware smoothness of the mean-normalised disparity."""
+    """losses.py:43-61: edge-aware smoothness of the mean-normalised disparity.  GPU tensors of the engine's image size go
+    through the HIP kernels (tcsfm_smooth_loss); anything else (CPU tensors: the golden tests of the scalar-loss mirror) through
+    the same expression in torch."""
+    if disp.is_cuda and disp.dim() == 4 and disp.shape[1] == 1 and img.shape[1] == 3:
+        from ._shared import get_engine
+        H, W = disp.shape[-2:]
+        v = get_engine(H, W, max(1, disp.shape[0])).smooth_loss(disp.float().contiguous(), img.float().contiguous())
+        return torch.tensor(v, device=disp.device, dtype=disp.dtype)
     mean_disp = disp.mean(2, True).mean(3, True)
     disp = disp / (mean_disp + 1e-7)
     gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
