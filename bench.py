@@ -284,8 +284,9 @@ def main():
         np.save(args.dump_poses, final_all.cpu().numpy())
 
     # instrumented pass on EVERY rank: in-kernel brackets + HIP events around every kernel launch, same steps
+    n_prof = min(max(args.steps, 300), 500)                 # enough launches for a stable average, whatever K the driver asked for
     eng.profile_begin()
-    for _ in range(min(args.steps, 500)):
+    for _ in range(n_prof):
         step()
     prof = eng.profile_end()
     alg_bytes = 32 * H * W * npairs                          # 32 B/pixel/pair/iteration x pixels x pairs/launch
