@@ -10,6 +10,9 @@ os.makedirs(dst, exist_ok=True)
 ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+ks1 = glob.glob(os.path.join(src, "trace_lanes1", "*", "*kernel_stats.csv"))
+if ks1:
+    shutil.copy(ks1[0], os.path.join(dst, f"{tag}_lanes1_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "bench.json")):
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 pmc = collections.defaultdict(dict)

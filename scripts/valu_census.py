@@ -85,7 +85,7 @@ def classify(op, operands, table, costs, prev_vcc_write):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="k_linearizeILi6ELb0ELi1ELi32ELi16ELi512ELb0E")
+    ap.add_argument("--kernel", default="k_linearizeILi6ELb0ELi1ELi32ELi16ELi512ELb0ELb0E")
     ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r02_valu_rate.jsonl"))
     ap.add_argument("--trips", default="8,9", help="trip counts of the loops in program order")
     ap.add_argument("--frac", default="", help="executing fraction of each skipped region in program order (see --list)")

@@ -41,7 +41,7 @@ __device__ __forceinline__ float dense_advance(float dep, const float4 &r0, cons
     return 1.f / rho;
 }
 
-template <int TW, int TH, int NT>
+template <int TW, int TH, int NT, bool TRACE = false>
 __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DenseParams Dn) {
     constexpr int NP = 6;
     using L = AccLayout<NP>;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         }
         if (own) {
             if (Dn.depth_next != nullptr && inimg) Dn.depth_next[(size_t)n * hw + (size_t)S.py * W + S.px] = S.dep;
-            if (P.trace != nullptr && inimg)    // bilinear cell parity now, mask / validity bits in phase 2b
+            if (TRACE && P.trace != nullptr && inimg)    // bilinear cell parity now, mask / validity bits in phase 2b
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             geo_jac<7>(c, S.g, W, H, a, b, zc);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
 #pragma unroll
     for (int i = 0; i < L::NH + NP + 3; i++) v[i] = 0.f;
     if (inimg) {
-        if (P.trace != nullptr) {   // parity tests replay these decisions in the float64 oracle
+        if (TRACE && P.trace != nullptr) {   // parity tests replay these decisions in the float64 oracle
             unsigned short *tb = P.trace + (size_t)n * hw + gyo * W + gxo;     // (this thread's own phase-1 word)
             *tb = (unsigned short)(*tb | (o_m > 0.f ? 1 : 0) | (o_valid > 0.5f ? 2 : 0) | (sign_code(o_cd - o_pd) << 4) | (sign_code(o_y[0] - o_x[0]) << 6) |
                                    (sign_code(o_y[1] - o_x[1]) << 8) | (sign_code(o_y[2] - o_x[2]) << 10));

@@ -716,7 +716,9 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
     if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
 }
 
-template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false>
+// TRACE: the parity-test build of the kernel that records its discrete decisions (tcsfm_debug_trace); a template parameter so that
+// the production instantiation carries none of it (not even the branches: the kernel sits at its 128-VGPR budget)
+template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
     constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
         if (centre) {
             c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
-            if (MODE != MODE_MAPS && P.trace != nullptr && c_in[0])    // bilinear cell parity now, mask / validity bits in phase 2
+            if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && c_in[0])    // bilinear cell parity now, mask / validity bits in phase 2
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             m = inimg && keep && (diff < sel_before) && (diff <= sel_after);
         }
 
-        if (MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
+        if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
             unsigned short *tb = P.trace + (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);   // (this thread's own phase-1 word)
             *tb = (unsigned short)(*tb | (m ? 1 : 0) | (c_valid[k] ? 2 : 0) | (sign_code(dif) << 4) | (sign_code(yc[0] - xc[0]) << 6) |
                                    (sign_code(yc[1] - xc[1]) << 8) | (sign_code(yc[2] - xc[2]) << 10));

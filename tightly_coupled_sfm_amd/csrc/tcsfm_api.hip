@@ -232,7 +232,11 @@ void take_stamp(tcsfm_ctx *h, LinParams &P, size_t workgroups) {
 template <int NP, bool DC, int MODE>
 void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
     dim3 grid(h->nblk, N), block(TILE_NT);
-    if (MODE != MODE_MAPS && P.sel_S > 1)   // window form with the min over sources: selection inside the kernel
+    const bool sel = MODE != MODE_MAPS && P.sel_S > 1;   // window form with the min over sources: selection inside the kernel
+    if (MODE != MODE_MAPS && P.trace != nullptr) {       // parity tests: the decision-recording build
+        if (sel) hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, true>), grid, block, 0, h->stream, P);
+        else hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, false, true>), grid, block, 0, h->stream, P);
+    } else if (sel)
         hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true>), grid, block, 0, h->stream, P);
     else
         hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
@@ -941,7 +945,8 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         if (n_sel) select_pass();
         take_stamp(h, P, (size_t)nblk * N);
         ProfScope prof(h, 0);
-        hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
+        if (P.trace != nullptr) hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT, true>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
+        else hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, N), dim3(DNT), 0, h->stream, P, Dn);
     };
     DenseLmParams Ul;
     Ul.rec_try = h->dense_rec; Ul.rec_acc = h->dense_rec_acc; Ul.depth_acc = h->depth_acc; Ul.depth = h->depth_work; Ul.delta = h->delta;
@@ -1116,6 +1121,8 @@ int tcsfm_profile_begin(tcsfm_handle h) {
     }
     h->stamp_used = 0;
     h->stamp_launch.clear();
+    for (tcsfm_ctx *c : h->lanes)                       // the lanes are bracketed too: their figures are added in profile_end
+        if (int rc = tcsfm_profile_begin(c)) { h->err = c->err; return rc; }
     h->profiling = true;
     h->ev_used = 0;
     h->ev_class.clear();
@@ -1135,20 +1142,32 @@ int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]) {
     }
     h->ev_used = 0;
     h->ev_class.clear();
+    for (tcsfm_ctx *c : h->lanes) {
+        double ms[3]; int64_t n[3];
+        if (int rc = tcsfm_profile_end(c, ms, n)) { h->err = c->err; return rc; }
+        for (int i = 0; i < 3; i++) { ms_sum[i] += ms[i]; launches[i] += n[i]; }
+    }
     return TCSFM_OK;
 }
 
 int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches) {
     if (!h || !ms_sum || !launches) return TCSFM_E_ARG;
     *ms_sum = 0.0; *launches = 0;
-    if (!h->stamp_buf || h->stamp_used == 0) return TCSFM_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    std::vector<unsigned long long> st(h->stamp_used * 2);
-    HIPCHK(h, hipMemcpy(st.data(), h->stamp_buf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (const auto &l : h->stamp_launch) {     // duration of a launch = latest workgroup end - earliest workgroup start
-        unsigned long long t0 = ~0ull, t1 = 0ull;
-        for (size_t w = l.first; w < l.first + l.second; w++) { t0 = st[2 * w] < t0 ? st[2 * w] : t0; t1 = st[2 * w + 1] > t1 ? st[2 * w + 1] : t1; }
-        if (t1 > t0) { *ms_sum += (double)(t1 - t0) * 1e-5; (*launches)++; }   // 100 MHz ticks -> ms
+    DeviceGuard dev_guard(h->device);
+    if (h->stamp_buf && h->stamp_used > 0) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> st(h->stamp_used * 2);
+        HIPCHK(h, hipMemcpy(st.data(), h->stamp_buf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (const auto &l : h->stamp_launch) {     // duration of a launch = latest workgroup end - earliest workgroup start
+            unsigned long long t0 = ~0ull, t1 = 0ull;
+            for (size_t w = l.first; w < l.first + l.second; w++) { t0 = st[2 * w] < t0 ? st[2 * w] : t0; t1 = st[2 * w + 1] > t1 ? st[2 * w + 1] : t1; }
+            if (t1 > t0) { *ms_sum += (double)(t1 - t0) * 1e-5; (*launches)++; }   // 100 MHz ticks -> ms
+        }
+    }
+    for (tcsfm_ctx *c : h->lanes) {
+        double ms = 0.0; int64_t n = 0;
+        if (int rc = tcsfm_profile_kernel_time(c, &ms, &n)) { h->err = c->err; return rc; }
+        *ms_sum += ms; *launches += n;
     }
     return TCSFM_OK;
 }
