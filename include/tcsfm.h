@@ -162,6 +162,12 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
  * With o->argmin and S > 1 the forward pairs of a target use the reference's per-pixel min over the sources
  * (compute_optimization_loss, optimizer.py:47-69): at every linearisation a pixel counts only for the source with the
  * smallest photometric error there, under the union validity mask and the auto-mask of the minima.
+ * Two deliberate differences from the reference's scalar loss (each directed pair is its own least-squares problem here): a pair
+ * is normalised by ITS OWN count of selected pixels, and every pair keeps ITS OWN depth-consistency weight map -- the reference
+ * multiplies the per-pixel minimum by the weight map of source 0 whichever source won the pixel (optimizer.py:69), which would
+ * couple the pose of source 0 into the other pairs' gradients.  The selection itself (which pixels count, for which source) is
+ * the reference's and is pinned on its own maps (golden G4); the scalar-loss mirror tightly_coupled_sfm_amd.losses reproduces
+ * the reference's formula, weight map of source 0 included, for logging (golden G5, all eight option toggles).
  * The handle must have been created with max_pairs >= 2*S*B. */
 int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                         const float *depth_t, const float *depth_s, const float *K, const float *pose_in,

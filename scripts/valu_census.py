@@ -16,6 +16,8 @@ Instruction classes and their cost in clocks per wave-instruction per SIMD come 
 (the kernel's occupancy).  Unmeasured opcodes are priced at the half-rate cost and listed.
 """
 import argparse, collections, json, os, re, subprocess, sys, tempfile
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tightly_coupled_sfm_amd.build import FLAGS
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def isa_of(kernel_substr):
     tmp = tempfile.mkdtemp(prefix="census_")
     src = os.path.join(ROOT, "tightly_coupled_sfm_amd", "csrc", "tcsfm_api.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", src, "-o",
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [src, "-o",
                            os.path.join(tmp, "lib.so"), "-save-temps=obj"], cwd=tmp, stderr=subprocess.DEVNULL)
     s = open(os.path.join(tmp, "tcsfm_api-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
     start = next(i for i, l in enumerate(s) if re.match(r"^_Z\w*" + re.escape(kernel_substr) + r"\w*:", l))
