@@ -12,7 +12,7 @@ frame-pair is counted per window (not per directed pair).  Inputs are synthetic 
 before the timed region.
 
 Calls in flight.  Steps are independent windows (as the windows of a sequence are), so the handle keeps --lanes of them (default
-2) in flight on its lanes (include/tcsfm.h: own HIP stream and scratch per lane): the kernels of one call fill the gaps between
+3) in flight on its lanes (include/tcsfm.h: own HIP stream and scratch per lane): the kernels of one call fill the gaps between
 the short kernels of the other.  Every step is still one B-window ``tcsfm_refine_window`` call; `single_stream` reports the same
 blocks with one call in flight (the round-1 protocol).
 
@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--windows-per-gpu", type=int, default=0, help="windows (B) per rank and step; default 1 on one GPU (config 2), 8 on several (config 3)")
     ap.add_argument("--sat-windows", type=int, default=32, help="windows per call of the chip-filling roofline leg (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of wall time given to the CPU baseline (0 = skip)")
-    ap.add_argument("--lanes", type=int, default=2, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
+    ap.add_argument("--lanes", type=int, default=3, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
     ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered refined poses [world, pairs, 6] to this .npy file (tests)")
     args = ap.parse_args()
 
@@ -212,6 +212,8 @@ def main():
     b = synth.make_batch(npairs, H, W, seed0=100 * rank, both_directions=True)
     dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
     eng = Engine(H, W, npairs, lanes=lanes)
+    eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
+    torch.cuda.synchronize()
     opts = default_opts(n_iters=ITERS)
     # the window form of the same batch (the library forms the fwd / inv pairs itself, bit-identical to the pair form): targets
     # [B], the S=1 source of each, initial poses in the stacked order [forward pairs | inverse pairs]
@@ -326,7 +328,7 @@ def main():
                 "launches": int(k_n), "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_us_hip_events": round(ev_s * 1e6, 3), "rocprof_avg_us": rocprof_avg_us() if B == 1 else None,
                 "rocprof_note": "profiles/*_kernel_stats.csv is rocprofv3 --kernel-trace --stats of this very command: its average covers the "
-                                "launches of the two-in-flight timed blocks, of the single-stream blocks and of both instrumented passes; "
+                                "launches of the timed blocks (`steps_in_flight` calls in flight), of the single-stream blocks and of both instrumented passes; "
                                 "profiles/*_lanes1_kernel_stats.csv is the same command with --lanes 1 (every launch has the chip)",
                 "other_kernels_avg_us_hip_events": {k: round(v[0] / max(v[1], 1) * 1e3, 3) for k, v in prof.items() if k in ("solve", "pack")},
                 "valu_bound": valu_bound(avg_s, npairs),
