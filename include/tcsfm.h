@@ -243,6 +243,10 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes);
 int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
                               const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);
+/* the dense mode (tcsfm_refine_dense_window) on a lane: same ordering rules */
+int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                    const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                                    float *depth_out, float *stats_out);
 int tcsfm_lane_wait(tcsfm_handle h, int lane);
 int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
 int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);

@@ -22,12 +22,15 @@ from tightly_coupled_sfm_amd.build import FLAGS
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def isa_of(kernel_substr):
+def isa_of(kernel_substr, line_tables=False):
     tmp = tempfile.mkdtemp(prefix="census_")
     src = os.path.join(ROOT, "tightly_coupled_sfm_amd", "csrc", "tcsfm_api.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [src, "-o",
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + (["-gline-tables-only"] if line_tables else []) + [src, "-o",
                            os.path.join(tmp, "lib.so"), "-save-temps=obj"], cwd=tmp, stderr=subprocess.DEVNULL)
     s = open(os.path.join(tmp, "tcsfm_api-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    if line_tables:
+        global FILES
+        FILES = {int(m.group(1)): m.group(2) for l in s for m in [re.match(r'\s+\.file\s+(\d+)\s+(?:"[^"]*"\s+)?"([^"]*)"', l)] if m}
     start = next(i for i, l in enumerate(s) if re.match(r"^_Z\w*" + re.escape(kernel_substr) + r"\w*:", l))
     end = next(i for i in range(start, len(s)) if s[i].startswith(".Lfunc_end"))
     return s[start:end + 1]
@@ -94,8 +97,9 @@ def main():
     ap.add_argument("--list", action="store_true", help="print loops / regions with their line ranges and exit")
     ap.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json"))
     ap.add_argument("--out", default="")
+    ap.add_argument("--lines", type=int, default=0, help="also print the N source lines that cost most VALU clocks (compiles with -gline-tables-only)")
     a = ap.parse_args()
-    isa = isa_of(a.kernel)
+    isa = isa_of(a.kernel, a.lines > 0)
     labels = {l.split(":")[0]: i for i, l in enumerate(isa) if re.match(r"^\.LBB\d+_\d+:", l)}
     loops, regions = [], []
     for i, l in enumerate(isa):
@@ -129,7 +133,13 @@ def main():
     table, costs = price_table(load_costs(a.rates))
     dyn, clk = collections.Counter(), collections.Counter()
     other = collections.Counter()
+    by_line, cur = collections.Counter(), None
+    by_line_n = collections.Counter()
     for i, l in enumerate(isa):
+        ml = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", l)
+        if ml:
+            cur = (int(ml.group(1)), int(ml.group(2)))
+            continue
         m = re.match(r"\s+([a-z_0-9]+)\s*(.*)", l)
         if not m or weight[i] == 0:
             continue
@@ -137,6 +147,7 @@ def main():
         if op.startswith("v_"):
             cls, c = classify(op, rest, table, costs, False)
             dyn[cls] += weight[i]; clk[cls] += weight[i] * c
+            by_line[cur] += weight[i] * c; by_line_n[cur] += weight[i]
         else:
             other[op.split("_")[0] + "_" + (op.split("_")[1] if "_" in op else "")] += weight[i]
     n_valu, busy = sum(dyn.values()), sum(clk.values())
@@ -158,6 +169,16 @@ def main():
             per_wave = k["SQ_INSTS_VALU"] / k["SQ_WAVES"]
             out["pmc"] = {"file": os.path.basename(a.pmc), "SQ_INSTS_VALU_per_wave": round(per_wave, 1), "census_over_pmc": round(n_valu / per_wave, 4),
                           "SQ_ACTIVE_INST_VALU_quadclk_per_wave": round(k["SQ_ACTIVE_INST_VALU"] / k["SQ_WAVES"], 1)}
+    if a.lines:
+        src_cache = {}
+        for (f, ln), c in by_line.most_common(a.lines):
+            name = FILES.get(f, "?")
+            path = name if os.path.isabs(name) else os.path.join(ROOT, "tightly_coupled_sfm_amd", "csrc", os.path.basename(name))
+            if path not in src_cache:
+                src_cache[path] = open(path).read().splitlines() if os.path.exists(path) else []
+            text = src_cache[path][ln - 1].strip()[:110] if 0 < ln <= len(src_cache[path]) else ""
+            print(f"{c:8.1f} clk {by_line_n[(f, ln)]:7.1f} inst  {os.path.basename(name)}:{ln}  {text}")
+        return
     print(json.dumps(out, indent=1))
     if a.out:
         json.dump(out, open(a.out, "w"), indent=1)

@@ -103,3 +103,31 @@ def test_lane_calls_from_pinned_host_memory():
                                            None, P(hb["out"]), None, None) < 0
     assert e.lib.tcsfm_refine_window_async(e._h, 7, C.byref(oh), 1, 1, P(hb["tgt"]), P(hb["src"]), P(hb["dt"]), P(hb["ds"]), P(hb["K"]), P(hb["p0"]),
                                            None, P(hb["out"]), None, None) < 0          # no such lane
+
+
+def test_dense_windows_on_lanes_match_synchronous_calls():
+    """tcsfm_refine_dense_window_async: different windows in flight on three lanes give, bit for bit, what one synchronous
+    tcsfm_refine_dense_window call per window gives (each lane owns its scratch; nothing is shared but the inputs)"""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W, NWIN = 96, 160, 7
+    o = default_opts(n_iters=3, min_depth=0.03, max_depth=3.0)
+    e = Engine(H, W, 2, lanes=3)
+    wins = []
+    for w in range(NWIN):
+        b = synth.make_batch(2, H, W, seed0=40 + w, both_directions=True)
+        d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+        wins.append(dict(tgt=d["tgt"][0:1].contiguous(), srcs=d["src"][0:1].contiguous()[None], dt=d["depth_t"][0:1].contiguous(),
+                         ds=d["depth_s"][0:1].contiguous()[None], K=d["K"][0:1].contiguous(),
+                         p0=torch.stack([d["pose_init"][0], d["pose_init"][1]]).contiguous()))
+    ref = [e.refine_dense_window(x["tgt"], x["srcs"], x["dt"], x["ds"], x["K"], x["p0"], o)[:2] for x in wins]
+    torch.cuda.synchronize()
+    po = [torch.empty(2, 6, device="cuda") for _ in range(NWIN)]
+    do = [torch.empty(2, 1, H, W, device="cuda") for _ in range(NWIN)]
+    for w, x in enumerate(wins):
+        e.refine_dense_window_async(w % 3, x["tgt"], x["srcs"], x["dt"], x["ds"], x["K"], x["p0"], po[w], do[w], o)
+    for l in range(3):
+        e.lane_synchronize(l)
+    for w in range(NWIN):
+        assert torch.equal(po[w], ref[w][0]) and torch.equal(do[w], ref[w][1]), w
+    assert not torch.equal(po[0], po[1])                      # the windows really differ

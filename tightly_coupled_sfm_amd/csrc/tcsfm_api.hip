@@ -1050,6 +1050,23 @@ int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int
     return TCSFM_OK;
 }
 
+int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                    const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                                    float *depth_out, float *stats_out) {
+    tcsfm_ctx *c = lane_of(h, lane);
+    if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_async: no such lane (tcsfm_set_lanes)") : TCSFM_E_ARG;
+    if (o && o->host_ptrs == 1) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_async: host_ptrs must be 0 (device) or 2 (pinned host, asynchronous)");
+    if (c == h) return tcsfm_refine_dense_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+    DeviceGuard dev_guard(h->device);
+    HIPCHK(h, hipEventRecord(c->in_ev, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(c->own_stream, c->in_ev, 0));
+    c->stream = c->own_stream;
+    int rc = tcsfm_refine_dense_window(c, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+    if (rc) { h->err = c->err; return rc; }
+    HIPCHK(h, hipEventRecord(c->done_ev, c->own_stream));
+    return TCSFM_OK;
+}
+
 int tcsfm_lane_wait(tcsfm_handle h, int lane) {
     tcsfm_ctx *c = lane_of(h, lane);
     if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_lane_wait: no such lane") : TCSFM_E_ARG;

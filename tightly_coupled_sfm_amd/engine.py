@@ -365,6 +365,13 @@ class Engine:
                                                       self._p(depth_s), self._p(K), self._p(pose), self._p(log_scale), self._p(pose_out),
                                                       self._p(log_scale_out), None))
 
+    def refine_dense_window_async(self, lane: int, tgt, srcs, depth_t, depth_s, K, pose, pose_out, depth_out, opts: Opts):
+        """tcsfm_refine_dense_window on `lane` (see refine_window_async: validated contiguous float32 CUDA tensors, no allocation;
+        pose_out [2SB,6], depth_out [2SB,1,H,W])"""
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        self._call(self.lib.tcsfm_refine_dense_window_async(self._h, int(lane), C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t),
+                                                            self._p(depth_s), self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out), None))
+
     def lane_wait(self, lane: int):
         self._call(self.lib.tcsfm_lane_wait(self._h, int(lane)))
 
