@@ -247,6 +247,20 @@ int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int
 int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                     const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                                     float *depth_out, float *stats_out);
+/* The reference's sequential driver loop as ONE call (run_sequential_optimization.py:186-247: for every window DataLoader batch ->
+ * H2D in process_sample_batch, data/kitti_loader.py:60-98 -> optimize_window, strictly one window after the other).
+ * Window w = (target frame w, source frames w+1 .. w+S) -> its 2*S directed pairs in the stacked order of train_mono.py:54-62
+ * (forward pairs, then inverse pairs), w = 0 .. T-S-1.  All array arguments are HOST pointers here (pinned memory makes the
+ * copies asynchronous; pageable memory works, slower), whatever opts.host_ptrs says:
+ *   frames [T,3,H,W], depths [T,1,H,W] (or disparities, opts.depth_is_disp), K [3,3] (one camera for the sequence),
+ *   pose_init / pose_out [T-S, 2*S, 6], log_scale_out [T-S, 2*S] or NULL (TCSFM_REFINE_POSE_SCALE; the scale starts at 0).
+ * Every frame crosses PCIe once, on a high-priority copy stream of the handle, four frames per copy, into a device ring of `ring`
+ * frames (0 = default: 32 + S; at least S + 2, chunked copies from S + 8 up); windows are refined round robin on the handle's lanes
+ * (tcsfm_set_lanes; 2-3 lanes: the GPU runs four hardware queues at once and the copy stream is one of them) from the ring by
+ * pointer; a slot is recycled -- on the device, by events -- once every window reading it has finished.  The call returns when all
+ * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window. */
+int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring);
 int tcsfm_lane_wait(tcsfm_handle h, int lane);
 int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
 int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);

@@ -34,6 +34,7 @@ for rep in range(2):
     dt_a = (time.perf_counter() - t0) / len(wins)
 print(json.dumps({"path": "r01 host-pointer call per window (pinned, synchronous, pair form: 7.9 MB in per window)", "us_per_window": round(dt_a * 1e6, 1),
                   "windows_per_s": round(1 / dt_a, 1)}), flush=True)
+e.close()
 
 ref = None
 for lanes in (1, 2, 3, 4):
@@ -53,6 +54,22 @@ for lanes in (1, 2, 3, 4):
     print(json.dumps({"path": f"SequenceRefiner: each frame uploaded once ({(3 + 1) * H * W * 4 / 1e6:.2f} MB / window), window form, {lanes} lane(s)",
                       "frames": T, "windows": T - 1, "ms_total": round(best * 1e3, 2), "windows_per_s": round((T - 1) / best, 1),
                       "bit_identical_to_1_lane": same}), flush=True)
+    sr.eng.close(); del sr                 # live handles keep their streams: the GPU runs four hardware queues at once
+# (c) the same loop inside the library: ONE tcsfm_refine_sequence call per pass (C++ drives copies, events and lanes)
+init_t = torch.as_tensor(init)
+for lanes in (1, 2, 3):
+    e = Engine(H, W, 2, lanes=lanes)
+    e.refine_sequence(frames[:60], depths[:60], K, init_t[:59], opts)
+    times = []
+    for rep in range(7):
+        t0 = time.perf_counter()
+        res = e.refine_sequence(frames, depths, K, init_t, opts)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[3]
+    print(json.dumps({"path": f"tcsfm_refine_sequence: the window loop inside the library, {lanes} lane(s)", "frames": T, "windows": T - 1,
+                      "ms_total": round(med * 1e3, 2), "windows_per_s": round((T - 1) / med, 1),
+                      "bit_identical_to_streamed": bool(torch.equal(res, ref.cpu()))}), flush=True)
+    e.close()
 # the same windows from DEVICE-resident frames (no PCIe in the loop): what the lanes alone buy at B=1
 dev_f, dev_d = frames.cuda(), depths.cuda()
 Kd = torch.as_tensor(K[None]).cuda(); p0 = torch.as_tensor(init).cuda(); outd = torch.empty_like(p0)
@@ -73,3 +90,4 @@ for lanes in (1, 2, 3, 4):
     med = sorted(times)[3]
     print(json.dumps({"path": f"device-resident frames, window form, {lanes} lane(s)", "windows_per_s": round((T - 1) / med, 1),
                       "us_per_window": round(med / (T - 1) * 1e6, 1), "equal_to_streamed": bool(torch.equal(outd, ref))}), flush=True)
+    e.close()

@@ -131,3 +131,43 @@ def test_dense_windows_on_lanes_match_synchronous_calls():
     for w in range(NWIN):
         assert torch.equal(po[w], ref[w][0]) and torch.equal(do[w], ref[w][1]), w
     assert not torch.equal(po[0], po[1])                      # the windows really differ
+
+
+@pytest.mark.parametrize("S,lanes,ring", [(1, 1, 0), (1, 3, 0), (1, 2, 4), (1, 3, 12), (2, 3, 0), (2, 2, 5), (2, 2, 12)])
+def test_native_sequence_loop_matches_per_window_calls(S, lanes, ring):
+    """tcsfm_refine_sequence (the reference's whole window loop inside the library: frames uploaded once into a device ring on a
+    copy stream, windows round robin on the lanes, slots recycled by events): bit-identical to one refine_window call per window,
+    for one and two sources per window, rings that wrap many times (single-frame copies down to the minimum S + 2 slots, four-frame
+    copies from S + 8 slots up), pinned and pageable memory"""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W, T = 48, 160, 23
+    seq = synth.make_sequence(T, H, W, seed=11)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    nwin = T - S
+    # initial poses [nwin, 2S, 6]: forward pairs (target -> source k), then inverse pairs; two frames ahead ~ the sum of the steps
+    fwd = [[seq["init"][w + k, 0] if k == 0 else seq["init"][w, 0] + seq["init"][w + 1, 0] for k in range(S)] for w in range(nwin)]
+    init = np.stack([np.stack(f + [synth.invert_pose(p) for p in f]) for f in fwd]).astype(np.float32)
+    o = default_opts(n_iters=3, argmin=1)
+    e = Engine(H, W, 2 * S, lanes=lanes)
+    K = t(seq["K"][None]).cuda()
+    plain = []
+    for w in range(nwin):
+        srcs = t(seq["frames"][w + 1:w + 1 + S])[:, None].cuda(); ds = t(seq["depths"][w + 1:w + 1 + S])[:, None].cuda()
+        plain.append(e.refine_window(t(seq["frames"][w:w + 1]).cuda(), srcs, t(seq["depths"][w:w + 1]).cuda(), ds, K, t(init[w]).cuda(), o)[0].cpu())
+    plain = torch.stack(plain)
+    frames, depths = t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory()
+    out = e.refine_sequence(frames, depths, seq["K"], init, o, sources=S, ring=ring)
+    assert out.shape == (nwin, 2 * S, 6) and torch.equal(out, plain)
+    out2 = e.refine_sequence(t(seq["frames"]), t(seq["depths"]), seq["K"], init, o, sources=S, ring=ring)      # pageable memory, scratch reused
+    assert torch.equal(out2, plain)
+    assert not torch.equal(plain, t(init))
+    # the handle is still good for ordinary calls afterwards, and errors are reported as codes
+    again = e.refine_window(t(seq["frames"][0:1]).cuda(), t(seq["frames"][1:1 + S])[:, None].cuda(), t(seq["depths"][0:1]).cuda(),
+                            t(seq["depths"][1:1 + S])[:, None].cuda(), K, t(init[0]).cuda(), o)[0].cpu()
+    assert torch.equal(again, plain[0])
+    with pytest.raises(RuntimeError):
+        e.refine_sequence(frames, depths, seq["K"], init, o, sources=S, ring=S + 1)        # ring too small
+    badK = seq["K"].copy(); badK[0, 1] = 0.1
+    with pytest.raises(RuntimeError, match="pinhole"):
+        e.refine_sequence(frames, depths, badK, init, o, sources=S)

@@ -62,6 +62,12 @@ struct tcsfm_ctx {
     hipEvent_t in_ev = nullptr, done_ev = nullptr;
     std::vector<hipEvent_t> marks;   // tcsfm_lane_event: a ring of events handed out to the caller
     size_t mark_next = 0;
+    // tcsfm_refine_sequence: device ring of frames, copy stream, per-slot / per-window events, pose staging (allocated on first use)
+    float *seq_img = nullptr, *seq_depth = nullptr, *seq_pose_in = nullptr, *seq_pose_out = nullptr, *seq_ls_out = nullptr, *seq_K = nullptr;
+    int seq_slots = 0;                 // ring slots + S mirror slots allocated
+    size_t seq_pose_cap = 0;           // windows x pairs the pose staging holds
+    hipStream_t seq_copy = nullptr;
+    std::vector<hipEvent_t> seq_copied, seq_done;
     const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
     int K_checked_n = 0;
     unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
@@ -440,9 +446,13 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (h->in_ev) (void)hipEventDestroy(h->in_ev);
     if (h->done_ev) (void)hipEventDestroy(h->done_ev);
     for (auto &e : h->marks) (void)hipEventDestroy(e);
+    if (h->seq_copy) { (void)hipStreamSynchronize(h->seq_copy); (void)hipStreamDestroy(h->seq_copy); }
+    for (auto &e : h->seq_copied) (void)hipEventDestroy(e);
+    for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept};
+                    h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
+                    h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -1064,6 +1074,122 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
     int rc = tcsfm_refine_dense_window(c, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
     if (rc) { h->err = c->err; return rc; }
     HIPCHK(h, hipEventRecord(c->done_ev, c->own_stream));
+    return TCSFM_OK;
+}
+
+// The reference's sequential driver (run_sequential_optimization.py:186-247) as ONE call: see include/tcsfm.h.
+int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring) {
+    if (!h) return TCSFM_E_ARG;
+    if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
+    const int N = 2 * S, L = (int)h->lanes.size() + 1;
+    if (S < 1 || T <= S || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: need S >= 1, T > S and 2*S <= max_pairs");
+    if (!frames || !depths || !K || !pose_init || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
+    tcsfm_opts o = *o_in;
+    o.host_ptrs = 0;                                   // the lanes work on the device ring; this call does the staging itself
+    int rc = check_common(h, &o, N);
+    if (rc) return rc;
+    if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || !(K[0] != 0.f) || !(K[4] != 0.f))
+        return fail(h, TCSFM_E_INTRINSICS, "intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1]");
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
+    const int nwin = T - S;
+    // frames go up in chunks of C (one copy for the images, one for the depths: PCIe runs at 55 GB/s on 8-frame copies, at 36 GB/s
+    // on single frames, and the host issues a quarter of the calls); the ring holds a whole number of chunks
+    const int C = ring > 0 ? (ring >= S + 8 ? 4 : 1) : 4;
+    const int R = ring > 0 ? (ring / C) * C : 32 + ((S + C - 1) / C) * C;     // frames resident at once (measured: 16 -> 32 slots is +13 % at 3 lanes)
+    if (R < S + 2 || R < S + C) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: ring must hold at least S + 2 frames");
+    const size_t hw = (size_t)h->H * h->W;
+    // ---- scratch: ring (+ S mirror slots so that the S+1 frames of a window are always contiguous), events, pose staging
+    if (h->seq_slots < R + S) {
+        if (h->seq_img) HIPCHK(h, hipFree(h->seq_img));
+        if (h->seq_depth) HIPCHK(h, hipFree(h->seq_depth));
+        h->seq_img = h->seq_depth = nullptr; h->seq_slots = 0;
+        HIPCHK(h, hipMalloc(&h->seq_img, (size_t)(R + S) * 3 * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->seq_depth, (size_t)(R + S) * hw * sizeof(float)));
+        h->seq_slots = R + S;
+    }
+    if (h->seq_pose_cap < (size_t)nwin * N) {
+        for (float **q : {&h->seq_pose_in, &h->seq_pose_out, &h->seq_ls_out})
+            if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
+        h->seq_pose_cap = 0;
+        HIPCHK(h, hipMalloc(&h->seq_pose_in, (size_t)nwin * N * 6 * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->seq_pose_out, (size_t)nwin * N * 6 * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->seq_ls_out, (size_t)nwin * N * sizeof(float)));
+        h->seq_pose_cap = (size_t)nwin * N;
+    }
+    if (!h->seq_K) HIPCHK(h, hipMalloc(&h->seq_K, 9 * sizeof(float)));
+    if (!h->seq_copy) {   // high priority: a hardware queue outside the pool the normal-priority streams share (a copy stream that lands in
+        int lo = 0, hi = 0;   // a lane's queue parks its slot-recycling waits in front of that lane's kernels), and copies go first anyway
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->seq_copy, hipStreamNonBlocking, hi));
+    }
+    const size_t n_done = (size_t)2 * R + 2;               // a window's event is re-recorded long after its slots were recycled
+    while (h->seq_copied.size() < (size_t)R) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_copied.push_back(e); }
+    while (h->seq_done.size() < n_done) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_done.push_back(e); }
+    // ---- small inputs: one copy each, on the copy stream; every lane waits for them once
+    hipStream_t cs = h->seq_copy;
+    HIPCHK(h, hipMemcpyAsync(h->seq_K, K, 9 * sizeof(float), hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(h->seq_pose_in, pose_init, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyHostToDevice, cs));
+    hipEvent_t small_ev = h->seq_done[n_done - 1];
+    HIPCHK(h, hipEventRecord(small_ev, cs));
+    std::vector<tcsfm_ctx *> lane(L);
+    std::vector<hipStream_t> ls(L);
+    for (int l = 0; l < L; l++) {
+        lane[l] = l == 0 ? h : h->lanes[l - 1];
+        ls[l] = l == 0 ? h->stream : lane[l]->own_stream;
+        lane[l]->stream = ls[l];
+        HIPCHK(h, hipStreamWaitEvent(ls[l], small_ev, 0));
+        lane[l]->K_checked = h->seq_K; lane[l]->K_checked_n = 1;     // validated on the host above
+    }
+    std::vector<long long> slot_reader(R, -1);             // last window that reads the frame in this slot (-1: none pending)
+    const int np = np_of(&o);
+    const int ahead = S + L + C;                           // frames kept in flight ahead of the window being issued
+    int nxt = 0;                                           // first frame of the next chunk to upload
+    const int depth = 16;
+    for (int w = 0; w < nwin; w++) {
+        // the host stays at most `depth` windows ahead of the GPU: a deeper backlog buys nothing, and with one the runtime was seen to
+        // block a single hipMemcpyAsync of the copy stream for 7 ms while the lanes ran dry behind it
+        if (w >= depth) HIPCHK(h, hipEventSynchronize(h->seq_done[(w - depth) % (n_done - 1)]));
+        // a chunk may go up once every window that reads the frames it overwrites has been ISSUED (their events exist): nxt - R + C - 1 < w
+        while (nxt < T && nxt <= w + ahead && nxt + C - 1 - R < w) {
+            const int slot = nxt % R, nf = T - nxt < C ? T - nxt : C;
+            long long last = -1;                           // the slots' previous frames may still be read: the copy waits for their readers --
+            for (int k = 0; k < nf; k++) { if (slot_reader[slot + k] > last) last = slot_reader[slot + k]; slot_reader[slot + k] = -1; }
+            for (long long r = last; r >= 0 && r > last - L; r--)     // -- the latest of them on every lane (a lane's stream is in order)
+                HIPCHK(h, hipStreamWaitEvent(cs, h->seq_done[r % (n_done - 1)], 0));
+            HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)slot * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nf * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
+            HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)slot * hw, depths + (size_t)nxt * hw, (size_t)nf * hw * sizeof(float), hipMemcpyHostToDevice, cs));
+            if (slot < S) {                                // mirror of the first S slots behind the ring: the frames of a window never wrap
+                const int nm = nf < S - slot ? nf : S - slot;
+                HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)(R + slot) * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nm * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
+                HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)(R + slot) * hw, depths + (size_t)nxt * hw, (size_t)nm * hw * sizeof(float), hipMemcpyHostToDevice, cs));
+            }
+            HIPCHK(h, hipEventRecord(h->seq_copied[slot / C], cs));
+            nxt += nf;
+        }
+        const int l = w % L, s0 = w % R;
+        for (int k = w / C; k <= (w + S) / C; k++) HIPCHK(h, hipStreamWaitEvent(ls[l], h->seq_copied[(k * C % R) / C], 0));
+        tcsfm_ctx *c = lane[l];
+        rc = refine_impl(c, &o, N, 1, S, h->seq_img + (size_t)s0 * 3 * hw, h->seq_img + (size_t)(s0 + 1) * 3 * hw, h->seq_depth + (size_t)s0 * hw,
+                         h->seq_depth + (size_t)(s0 + 1) * hw, h->seq_K, h->seq_pose_in + (size_t)w * N * 6, nullptr,
+                         h->seq_pose_out + (size_t)w * N * 6, np == 7 ? h->seq_ls_out + (size_t)w * N : nullptr, nullptr);
+        if (rc) { if (c != h) h->err = c->err; break; }
+        hipEvent_t done = h->seq_done[w % (n_done - 1)];
+        HIPCHK(h, hipEventRecord(done, ls[l]));
+        for (int k = 0; k <= S; k++) slot_reader[(w + k) % R] = w;
+    }
+    // ---- drain: every lane, then the results in one copy each
+    for (int l = 0; l < L; l++) {
+        hipError_t e = hipStreamSynchronize(ls[l]);
+        if (e != hipSuccess && !rc) { h->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = TCSFM_E_HIP; }
+    }
+    (void)hipStreamSynchronize(cs);
+    if (rc) return rc;
+    for (int l = 0; l < L; l++)
+        if (int rc_ = pending_error(lane[l])) { if (lane[l] != h) h->err = lane[l]->err; return rc_; }
+    HIPCHK(h, hipMemcpy(pose_out, h->seq_pose_out, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    if (log_scale_out && np == 7) HIPCHK(h, hipMemcpy(log_scale_out, h->seq_ls_out, (size_t)nwin * N * sizeof(float), hipMemcpyDeviceToHost));
     return TCSFM_OK;
 }
 

@@ -372,6 +372,33 @@ class Engine:
         self._call(self.lib.tcsfm_refine_dense_window_async(self._h, int(lane), C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t),
                                                             self._p(depth_s), self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out), None))
 
+    def refine_sequence(self, frames: torch.Tensor, depths: torch.Tensor, K, init_poses, opts: Optional[Opts] = None, sources: int = 1,
+                        ring: int = 0, log_scale: bool = False):
+        """tcsfm_refine_sequence: the whole window loop of a sequence inside the library (frames [T,3,H,W] / depths [T,1,H,W] CPU
+        tensors -- pinned for asynchronous copies --, K [3,3], init_poses [T-S, 2S, 6]) -> refined poses [T-S, 2S, 6] (CPU tensor;
+        with log_scale=True also the log depth scales [T-S, 2S]); windows run on the engine's lanes"""
+        self._bind()
+        o = opts or default_opts()
+        cpu = lambda a, shape, name: self._cpu(a, shape, name)
+        T, S = int(frames.shape[0]), int(sources)
+        frames = cpu(frames, (T, 3, self.H, self.W), "frames"); depths = cpu(depths, (T, 1, self.H, self.W), "depths")
+        Kc = cpu(torch.as_tensor(np.asarray(K, dtype=np.float32)), (3, 3), "K")
+        p0 = cpu(torch.as_tensor(np.asarray(init_poses, dtype=np.float32)), (T - S, 2 * S, 6), "init_poses")
+        out = torch.empty_like(p0)
+        ls = torch.zeros((T - S, 2 * S), dtype=torch.float32) if log_scale else None
+        hp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._call(self.lib.tcsfm_refine_sequence(self._h, C.byref(o), T, S, hp(frames), hp(depths), hp(Kc), hp(p0), hp(out), hp(ls), int(ring)))
+        return (out, ls) if log_scale else out
+
+    @staticmethod
+    def _cpu(t, shape, name):
+        t = torch.as_tensor(t)
+        if t.is_cuda or t.dtype != torch.float32:
+            raise TypeError(f"{name} must be a float32 CPU tensor (pinned for asynchronous copies)")
+        if tuple(t.shape) != tuple(shape):
+            raise AssertionError("wrong size for {}, expected {}, got  {}".format(name, "x".join(map(str, shape)), list(t.shape)))
+        return t.contiguous()
+
     def lane_wait(self, lane: int):
         self._call(self.lib.tcsfm_lane_wait(self._h, int(lane)))
 

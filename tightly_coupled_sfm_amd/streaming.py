@@ -22,6 +22,8 @@ from .engine import Engine, Opts, default_opts
 
 class SequenceRefiner:
     """Refines the windows (frame t = target, frames t+1 .. t+S = sources; forward + inverse directed pairs) of a sequence.
+    (Python-level loop, kept for callers that interleave their own torch work; `Engine.refine_sequence` runs the same loop inside
+    the library -- tcsfm_refine_sequence -- at about twice the rate.)
 
     frames / depths: pinned CPU tensors [T,3,H,W] / [T,1,H,W] (or anything torch.as_tensor takes; pinned on the fly),
     K [3,3], init_poses [T-S, 2*S, 6] in the stacked order of train_mono.py:54-62 (forward pairs, then inverse pairs).
@@ -39,7 +41,7 @@ class SequenceRefiner:
         self.ring_depth = torch.empty((self.R, 1, H, W), device=dev, dtype=torch.float32)
         self.copy_stream = torch.cuda.Stream(device=dev)
         self.copied = [torch.cuda.Event() for _ in range(self.R)]   # frame data has landed in this slot (re-recorded per use)
-        self.slot_mark = [None] * self.R       # lane_event of the last window that read this slot
+        self.slot_mark = [[] for _ in range(self.R)]   # lane_events of the windows that read this slot's current frame
         # per-slot views in the shapes the window form takes (target [1,3,H,W] / [1,1,H,W], single source [1,1,3,H,W] / [1,1,1,H,W])
         self.v_tgt = [self.ring_img[k][None] for k in range(self.R)]
         self.v_dt = [self.ring_depth[k][None] for k in range(self.R)]
@@ -48,9 +50,9 @@ class SequenceRefiner:
 
     def _upload(self, t: int, img: torch.Tensor, depth: torch.Tensor):
         slot = t % self.R
-        if self.slot_mark[slot] is not None:   # the slot's previous frame may still be read by a lane: the copy waits for THAT window
-            self.eng.stream_wait_event(self.copy_stream, self.slot_mark[slot])
-            self.slot_mark[slot] = None
+        for mark in self.slot_mark[slot]:      # the slot's previous frame may still be read by the lanes: the copy waits for its readers
+            self.eng.stream_wait_event(self.copy_stream, mark)
+        self.slot_mark[slot] = []
         with torch.cuda.stream(self.copy_stream):
             self.ring_img[slot].copy_(img, non_blocking=True)
             self.ring_depth[slot].copy_(depth, non_blocking=True)
@@ -87,7 +89,7 @@ class SequenceRefiner:
             eng.refine_window_async(lane, tgt, srcs, dt, ds, Kd, p0w[w], outw[w], self.opts)
             mark = eng.lane_event(lane)
             for s_ in slots:
-                self.slot_mark[s_] = mark
+                self.slot_mark[s_].append(mark)
         for lane in range(self.lanes):
             eng.lane_synchronize(lane)
         return out
