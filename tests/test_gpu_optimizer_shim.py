@@ -134,3 +134,40 @@ def test_tuple_form_dense_mode_and_legacy_switches():
         DepthOptimizer(dict(OPTIONS, optimize_depth_encoder=True), _config(B, iters), pose_model, depth_model, "09_02")
     with pytest.raises(NotImplementedError):
         DepthOptimizer(dict(OPTIONS, optimize_depth_encoder=True, strict_legacy=True), _config(B, iters), pose_model, depth_model, "09_02")
+
+
+def test_optimize_window_runs_a_reference_posenet_inside_the_library():
+    """A pose model with the reference PoseNet's parameters (models/pose_models.py:88-147) never executes in PyTorch inside
+    DepthOptimizer.optimize_window: its coupled loop (train_mono.py:64-80) runs in the library (tcsfm_solve_pose_iteratively), and
+    the initial poses equal the PyTorch module's own loop"""
+    import standins
+    from tightly_coupled_sfm_amd.optimizer import DepthOptimizer
+    from tightly_coupled_sfm_amd.engine import Engine
+    g, w, iters = _window()
+    B, S = w["target"].shape[0], w["sources"].shape[0]
+    _, depth_model = standins.window_models(w, iters, device="cuda")
+    twin = standins.PoseNetTwin(standins.posenet_params(11)).cuda().eval()
+    calls = []
+    hook = twin.register_forward_hook(lambda *a: calls.append(1))
+    opt = DepthOptimizer(dict(OPTIONS), _config(B, iters), twin, depth_model, "09_02")
+    r = opt.optimize_window(0, standins.loader_batch(w, device="cuda"))
+    assert not calls
+    hook.remove()
+    # the same loop with the torch module: PoseNet -> library warp -> PoseNet correction
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    H, W = w["target"].shape[2:]
+    e = Engine(H, W, 2 * S * B)
+    depths = [d.float() for d in r["depths_init"]]
+    tgt = t(w["target"]).repeat(S, 1, 1, 1); src = torch.cat([t(w["sources"][i]) for i in range(S)], 0)
+    imgs = torch.cat([torch.cat([tgt, src], 1), torch.cat([src, tgt], 1)], 0)
+    d_t = torch.cat([depths[0].repeat(S, 1, 1, 1), torch.cat(depths[1:], 0)], 0).contiguous()
+    d_s = torch.cat([torch.cat(depths[1:], 0), depths[0].repeat(S, 1, 1, 1)], 0).contiguous()
+    K = t(w["K"]).repeat(2 * S, 1, 1).contiguous()
+    with torch.no_grad():
+        full = twin(imgs)
+        for _ in range(iters - 1):
+            full = full + twin(e.posenet_input(imgs[:, 0:3].contiguous(), imgs[:, 3:6].contiguous(), d_t, d_s, full[:, :6].contiguous(), K))
+    ref = full[:, :6].cpu().numpy()
+    got = np.concatenate([r["poses_init"].numpy(), r["poses_inv_init"].numpy()])
+    assert np.max(np.abs(got - ref)) < 2e-5 * np.abs(ref).max()
+    assert r["stacked_poses_init"].shape == (S * B, iters, 6) and torch.isfinite(r["poses_opt"]).all()

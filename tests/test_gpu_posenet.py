@@ -110,3 +110,23 @@ def test_solve_pose_iteratively_drop_in_uses_the_library_network():
     assert np.max(np.abs(got - g["loop_poses"])) < 2e-5 * np.abs(g["loop_poses"]).max()
     assert set(out["fwd"]) == {"diff_img", "img_rec", "valid_mask", "weight_mask", "poses", "auto_mask_error", "auto_mask"}
     assert np.max(np.abs(out["fwd"]["poses"].cpu().numpy() - g["loop_stacked"][:S * B])) < 2e-5 * np.abs(g["loop_stacked"]).max()
+
+
+def test_posenet_from_a_reference_style_checkpoint(tmp_path):
+    """PoseNetHIP.load_checkpoint: the 'pose_state_dict' of a checkpoint written the way utils/learning_helpers.py:20-27 writes it
+    gives the golden poses of the reference's module with those parameters"""
+    import standins
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+    g = load_golden("posenet")
+    H, W, N = 48, 160, 4
+    (tmp_path / "best_model").mkdir()
+    torch.save({"pose_state_dict": standins.PoseNetTwin(standins.posenet_params(int(g["seed"]))).state_dict(), "depth_state_dict": {},
+                "best_val_loss": 0.0, "epoch": 1}, tmp_path / "best_model" / "best_model.pt")
+    e = Engine(H, W, N)
+    net = PoseNetHIP(e, N)
+    net.load_checkpoint(str(tmp_path))
+    b = synth.make_batch(N, H, W, seed0=40, both_directions=True)
+    pose = net(_t(np.concatenate([b["tgt"], b["src"]], 1))).cpu().numpy()
+    assert np.max(np.abs(pose - g["a_pose"])) < 1e-5 * np.abs(g["a_pose"]).max()

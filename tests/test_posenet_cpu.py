@@ -23,3 +23,24 @@ def test_posenet_twin_vs_reference_golden():
             assert np.max(np.abs(feats[6].numpy() - g[f"{tag}_feat7"])) < 1e-4
             for i, f in enumerate(feats):
                 assert np.allclose([float(f.double().mean()), float(f.double().abs().mean())], g[f"{tag}_feat{i + 1}_stats"], rtol=1e-5)
+
+
+def test_read_pose_state_dict_of_a_reference_style_checkpoint(tmp_path):
+    """utils/learning_helpers.py:20-48: save_ckp writes {'pose_state_dict', 'depth_state_dict', 'best_val_loss', 'epoch', 'optimizer'}
+    to <dir>/checkpoint.pt and copies the best one to <dir>/best_model/best_model.pt; load_ckp picks by `load_best`"""
+    import standins
+    from tightly_coupled_sfm_amd.posenet import read_pose_state_dict, is_reference_posenet
+    net = standins.PoseNetTwin(standins.posenet_params(3))
+    assert is_reference_posenet(net)
+    other = standins.PoseNetTwin(standins.posenet_params(4))
+    (tmp_path / "best_model").mkdir()
+    torch.save({"pose_state_dict": net.state_dict(), "depth_state_dict": {}, "best_val_loss": 0.1, "epoch": 7, "optimizer": {}}, tmp_path / "best_model" / "best_model.pt")
+    torch.save({"pose_state_dict": other.state_dict(), "depth_state_dict": {}, "best_val_loss": 0.2, "epoch": 9, "optimizer": {}}, tmp_path / "checkpoint.pt")
+    for path, ref in ((str(tmp_path), net), (str(tmp_path / "best_model" / "best_model.pt"), net)):
+        sd = read_pose_state_dict(path)
+        assert set(sd) == set(ref.state_dict()) and all(torch.equal(sd[k], v) for k, v in ref.state_dict().items())
+    sd = read_pose_state_dict(str(tmp_path), load_best=False)
+    assert all(torch.equal(sd[k], v) for k, v in other.state_dict().items())
+    torch.save({"depth_state_dict": {}}, tmp_path / "broken.pt")
+    with pytest.raises(KeyError, match="pose_state_dict"):
+        read_pose_state_dict(str(tmp_path / "broken.pt"))

@@ -151,6 +151,11 @@ class DepthOptimizer:
         imgs = torch.cat([torch.cat([target_imgs, source_imgs], 1), torch.cat([source_imgs, target_imgs], 1)], 0)
         d_t = torch.cat([target_depths, source_depths], 0).contiguous()
         d_s = torch.cat([source_depths, target_depths], 0).contiguous()
+        from .train_mono import _library_posenet
+        net = _library_posenet(self.pose_model, eng, 2 * S * B)
+        if net is not None:     # a PoseNet with the reference's parameters: network, warps and corrections all inside the library
+            full, stacked = net.solve_pose_iteratively(num_iter, target_img, list(source_img_list), depths[0], list(depths[1:]), intrinsics)
+            return full, stacked, imgs, d_t, d_s, K
         full = self.pose_model(imgs)
         stacked = [full.clone()]
         tgt, src = imgs[:, 0:3].contiguous(), imgs[:, 3:6].contiguous()

@@ -15,6 +15,17 @@ from .engine import Engine, _chk
 _CONV = ["conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7"]
 
 
+def read_pose_state_dict(path: str, load_best: bool = True) -> dict:
+    """'pose_state_dict' of a reference checkpoint (utils/learning_helpers.py:29-37 resolves the file the same way)"""
+    import os
+    if os.path.isdir(path):
+        path = os.path.join(path, "best_model", "best_model.pt") if load_best else os.path.join(path, "checkpoint.pt")
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    if "pose_state_dict" not in ck:
+        raise KeyError(f"{path}: no 'pose_state_dict' entry (keys: {sorted(ck)})")
+    return ck["pose_state_dict"]
+
+
 def is_reference_posenet(module) -> bool:
     """does `module` carry the parameters of the reference's pose_model (conv1..conv7 = (conv2d_wn, GroupNorm, ReLU), pose_pred)?"""
     try:
@@ -66,6 +77,11 @@ class PoseNetHIP:
         self.eng._bind()
         self.eng._call(self.lib.tcsfm_posenet_load(self._pn, cw, cb, gw, gb, hw.ctypes.data_as(C.c_void_p), hb.ctypes.data_as(C.c_void_p)))
         return self
+
+    def load_checkpoint(self, path: str, load_best: bool = True):
+        """The reference's checkpoint files (utils/learning_helpers.py:20-48: `torch.save` of a dict whose 'pose_state_dict' entry is
+        the PoseNet's state_dict; `<dir>/best_model/best_model.pt` or `<dir>/checkpoint.pt`).  `path` is such a file or the directory."""
+        self.load(read_pose_state_dict(path, load_best))
 
     def __call__(self, imgs: torch.Tensor) -> torch.Tensor:
         """pose_model(imgs): imgs [N,6,H,W] -> [N,6]"""
