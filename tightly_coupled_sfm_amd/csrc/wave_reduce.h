@@ -41,10 +41,17 @@ __device__ __forceinline__ void halve(float *v, int lane) {
             v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
         }
     } else {
-        const bool hi = (lane & XOR) != 0;
+        // lanes with the bit set keep the upper half.  The lane pattern is a compile-time constant, so the selects take it as a
+        // 64-bit scalar mask (v_cndmask_b32_e64 with an SGPR pair: half rate) instead of a compare into VCC + v_cndmask_b32_e32
+        // (measured 8.2 clocks per select behind a compare, scripts/valu_rate.hip).
+        constexpr unsigned long long HI = XOR == 1 ? 0xAAAAAAAAAAAAAAAAull : XOR == 2 ? 0xCCCCCCCCCCCCCCCCull
+                                        : XOR == 4 ? 0xF0F0F0F0F0F0F0F0ull : 0xFF00FF00FF00FF00ull;
+        (void)lane;
 #pragma unroll
         for (int i = 0; i < N / 2; i++) {
-            float keep = hi ? v[i + N / 2] : v[i], send = hi ? v[i] : v[i + N / 2];
+            float keep, send;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(keep) : "v"(v[i]), "v"(v[i + N / 2]), "s"(HI));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(send) : "v"(v[i + N / 2]), "v"(v[i]), "s"(HI));
             v[i] = keep + dpp_xor<XOR>(send);
         }
     }
