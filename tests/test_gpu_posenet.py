@@ -66,8 +66,16 @@ def test_posenet_forward_vs_torch_twin(H, W, N):
     assert np.max(np.abs(pose - ref)) < 1e-5 * np.abs(ref).max(), np.max(np.abs(pose - ref)) / np.abs(ref).max()
     again = net(x).cpu().numpy()
     assert np.array_equal(again, pose)                              # deterministic (fixed-order reductions, no atomics)
+    # batch independent: bit for bit among batches in the same work-split regime (up to 4 images / more: csrc tcsfm_posenet_create),
+    # to rounding (the K split changes the summation order) across the two
+    M = 3 if N <= 4 else 7
+    more = PoseNetHIP(Engine(H, W, M), M, sd)(torch.cat([x[N - 1:N], _t(rng.uniform(0, 1, size=(M - 1, 6, H, W)))]).contiguous()).cpu().numpy()
+    assert np.array_equal(more[0], pose[N - 1])
     one = PoseNetHIP(Engine(H, W, 1), 1, sd)(x[N - 1:N].contiguous()).cpu().numpy()
-    assert np.array_equal(one[0], pose[N - 1])                      # batch independent
+    if N <= 4:
+        assert np.array_equal(one[0], pose[N - 1])
+    else:
+        assert np.max(np.abs(one[0] - pose[N - 1])) < 3e-6 * np.abs(pose).max()
 
 
 def test_coupled_pose_loop_vs_reference_golden():

@@ -258,15 +258,37 @@ __global__ __launch_bounds__(256) void k_pn_stats(PnStatsParams P) {
             s += (double)pp[((size_t)t * P.cout + c) * 2]; q += (double)pp[((size_t)t * P.cout + c) * 2 + 1];
         }
     } else
-    for (int e = tid; e < total; e += 256) {
-        const int p = e / cg, c = g * cg + (e - p * cg);
-        float v = x[(size_t)p * P.cout + c];
-        if (P.ksplit > 1) {
-            for (int k = 1; k < P.ksplit; k++) v += x[k * plane + (size_t)p * P.cout + c];      // fixed order
-            if (P.bias) v += P.bias[c];
-            x[(size_t)p * P.cout + c] = v;
+    for (int e0 = tid; e0 < total; e0 += 1024) {       // 4 elements per trip: their loads (all K-split planes) are independent
+        float v[4];
+        float *xp[4];
+        int cc[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + 256 * u;
+            ok[u] = e < total;
+            const int p = ok[u] ? e / cg : 0, c = g * cg + (ok[u] ? e - p * cg : 0);
+            xp[u] = x + (size_t)p * P.cout + c;
+            cc[u] = c;
+            v[u] = xp[u][0];
         }
-        s += (double)v; q += (double)v * (double)v;
+        if (P.ksplit > 1) {          // partial sums of the K split, added in fixed order (k ascending)
+            for (int k = 1; k < P.ksplit; k++) {
+                float a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] = xp[u][k * plane];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] += a[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (P.bias) v[u] += P.bias[cc[u]];
+                if (ok[u]) xp[u][0] = v[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (ok[u]) { s += (double)v[u]; q += (double)v[u] * (double)v[u]; }
     }
     r1[tid] = s; r2[tid] = q; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; } __syncthreads(); }

@@ -1320,6 +1320,7 @@ struct tcsfm_posenet {
     tcsfm_ctx *h = nullptr;
     int max_images = 0, loaded = 0;
     PnLayer L[7];
+    int nb_cfg[2][7] = {}, ks_cfg[2][7] = {};   // (output-channel blocks per wave, K split) per layer: [0] few images (latency), [1] many
     pn_f4 *w4[7] = {};
     float *bias[7] = {}, *gamma[7] = {}, *beta[7] = {};
     float *act[7] = {}, *scsh[7] = {}, *part[7] = {};
@@ -1356,10 +1357,23 @@ int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
         L.cin = chans[l]; L.cout = chans[l + 1]; L.ks = ksz[l]; L.pad = (ksz[l] - 1) / 2;
         L.ih = ih; L.iw = iw; L.oh = (ih + 2 * L.pad - L.ks) / 2 + 1; L.ow = (iw + 2 * L.pad - L.ks) / 2 + 1;
         L.kgroups = l == 0 ? 21 : L.ks * L.ks * L.cin / 16;
-        // K split: only the small late layers (few output pixels, K up to 2304), so that one wave's K loop stays around 24 groups
-        // of 16 MFMAs; the big early layers keep K whole and get their GroupNorm partial sums from the convolution's epilogue
-        L.ksplit = 1;
-        if (L.oh * L.ow <= 512) L.ksplit = std::min(16, (L.kgroups + 23) / 24);
+        // Work split of a layer = (output-channel blocks of 16 per wave, K split).  A wave's K loop is a serial chain of loads and
+        // matrix-core steps, and a window's fwd + inv pair is only 2 images: with 4 channel blocks per wave and K whole the small
+        // layers ran on ~100 waves of ~300 dependent MFMAs each (15 us per layer whatever its size).  Two fixed regimes, chosen by
+        // the number of images only (results do not depend on anything else):
+        //   few images (N <= 4): as few channel blocks per wave as it takes to have ~800 waves for N = 2, then K split until they
+        //                        exist or a wave's loop is down to 8 groups;
+        //   many images:         up to 4 channel blocks per wave, K split only for the late layers (few output pixels).
+        {
+            const int pxb = (L.oh * L.ow + 15) / 16, cb = L.cout / 16;
+            int nb = std::min(cb, 4), ks = 1;
+            while (nb > 1 && pxb * (cb / nb) * 2 < 768) nb /= 2;
+            while (ks < 16 && pxb * (cb / nb) * 2 * ks < 768 && L.kgroups / (2 * ks) >= 8) ks *= 2;
+            pn->nb_cfg[0][l] = l == 0 ? 1 : nb; pn->ks_cfg[0][l] = l == 0 ? 1 : ks;
+            pn->nb_cfg[1][l] = L.cout >= 64 ? 4 : cb;
+            pn->ks_cfg[1][l] = L.oh * L.ow <= 512 ? std::min(16, (L.kgroups + 23) / 24) : 1;
+        }
+        L.ksplit = std::max(pn->ks_cfg[0][l], pn->ks_cfg[1][l]);     // allocation; the launch sets the split it uses
         if (L.oh < 1 || L.ow < 1) { tcsfm_posenet_destroy(pn); return fail(h, TCSFM_E_ARG, "tcsfm_posenet_create: image too small for seven stride-2 layers"); }
         const size_t nw4 = (size_t)L.kgroups * 4 * L.cout;
         if (e == hipSuccess) e = hipMalloc((void **)&pn->w4[l], nw4 * sizeof(pn_f4));
@@ -1368,7 +1382,7 @@ int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
         if (e == hipSuccess) e = hipMalloc((void **)&pn->beta[l], L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->act[l], (size_t)L.ksplit * max_images * L.oh * L.ow * L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->scsh[l], (size_t)max_images * L.cout * 2 * sizeof(float));
-        if (e == hipSuccess && L.ksplit == 1)
+        if (e == hipSuccess && (pn->ks_cfg[0][l] == 1 || pn->ks_cfg[1][l] == 1))
             e = hipMalloc((void **)&pn->part[l], (size_t)max_images * ((L.oh * L.ow + 63) / 64) * L.cout * 2 * sizeof(float));
         wmax = std::max(wmax, (size_t)L.cout * L.cin * L.ks * L.ks);
         ih = L.oh; iw = L.ow;
@@ -1414,20 +1428,23 @@ namespace {
 int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const float *imgB, long long strideB, int win_B, int win_S,
            float *pose, int accumulate, float *stacked, int it, int iters) {
     tcsfm_ctx *h = pn->h;
+    const int cfg = N <= 4 ? 0 : 1;
     for (int l = 0; l < 7; l++) {
-        const PnLayer &L = pn->L[l];
+        PnLayer L = pn->L[l];
+        L.ksplit = pn->ks_cfg[cfg][l];
+        const int nb = pn->nb_cfg[cfg][l];
         PnConvParams P;
         memset(&P, 0, sizeof(P));
         P.imgA = imgA; P.imgB = imgB; P.strideA = strideA; P.strideB = strideB; P.win_B = win_B; P.win_S = win_S;
         P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
-        P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = pn->part[l]; P.L = L; P.N = N;
-        const int nb = L.cout >= 64 ? 4 : L.cout / 16;
+        P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = L.ksplit == 1 ? pn->part[l] : nullptr; P.L = L; P.N = N;
         const dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
         if (l == 0) hipLaunchKernelGGL((k_pn_conv<1, true>), grid, dim3(256), 0, h->stream, P);
+        else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
         else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
         PnStatsParams S;
-        S.part = pn->part[l]; S.tiles = (L.oh * L.ow + 63) / 64;
+        S.part = P.part; S.tiles = (L.oh * L.ow + 63) / 64;
         S.out = pn->act[l]; S.bias = pn->bias[l]; S.gamma = pn->gamma[l]; S.beta = pn->beta[l]; S.scsh = pn->scsh[l];
         S.N = N; S.npix = L.oh * L.ow; S.cout = L.cout; S.ksplit = L.ksplit;
         hipLaunchKernelGGL(k_pn_stats, dim3(N, 16), dim3(256), 0, h->stream, S);
