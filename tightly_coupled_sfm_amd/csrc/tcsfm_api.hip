@@ -1383,7 +1383,7 @@ int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
         if (e == hipSuccess) e = hipMalloc((void **)&pn->act[l], (size_t)L.ksplit * max_images * L.oh * L.ow * L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->scsh[l], (size_t)max_images * L.cout * 2 * sizeof(float));
         if (e == hipSuccess && (pn->ks_cfg[0][l] == 1 || pn->ks_cfg[1][l] == 1))
-            e = hipMalloc((void **)&pn->part[l], (size_t)max_images * ((L.oh * L.ow + 63) / 64) * L.cout * 2 * sizeof(float));
+            e = hipMalloc((void **)&pn->part[l], (size_t)max_images * std::max((L.oh * L.ow + 63) / 64, L.oh * ((L.ow + 63) / 64)) * L.cout * 2 * sizeof(float));
         wmax = std::max(wmax, (size_t)L.cout * L.cin * L.ks * L.ks);
         ih = L.oh; iw = L.ow;
     }
@@ -1438,13 +1438,15 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         P.imgA = imgA; P.imgB = imgB; P.strideA = strideA; P.strideB = strideB; P.win_B = win_B; P.win_S = win_S;
         P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
         P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = L.ksplit == 1 ? pn->part[l] : nullptr; P.L = L; P.N = N;
-        const dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
-        if (l == 0) hipLaunchKernelGGL((k_pn_conv<1, true>), grid, dim3(256), 0, h->stream, P);
-        else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
+        dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
+        if (l == 0) {            // LDS-staged first layer: one workgroup per 64-pixel segment of an output row
+            grid = dim3(L.oh * ((L.ow + 63) / 64), 1, N);
+            hipLaunchKernelGGL(k_pn_conv1, grid, dim3(256), 0, h->stream, P);
+        } else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
         else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
         PnStatsParams S;
-        S.part = P.part; S.tiles = (L.oh * L.ow + 63) / 64;
+        S.part = P.part; S.tiles = (int)grid.x;
         S.out = pn->act[l]; S.bias = pn->bias[l]; S.gamma = pn->gamma[l]; S.beta = pn->beta[l]; S.scsh = pn->scsh[l];
         S.N = N; S.npix = L.oh * L.ow; S.cout = L.cout; S.ksplit = L.ksplit;
         hipLaunchKernelGGL(k_pn_stats, dim3(N, 16), dim3(256), 0, h->stream, S);
