@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--windows-per-gpu", type=int, default=0, help="windows (B) per rank and step; default 1 on one GPU (config 2), 8 on several (config 3)")
+    ap.add_argument("--total-windows", type=int, default=0, help="STRONG scaling instead of the default weak scaling: this many windows per step in "
+                    "the whole job (BASELINE config 3: 64), split evenly over the ranks (SURVEY 8e: report both)")
     ap.add_argument("--sat-windows", type=int, default=32, help="windows per call of the chip-filling roofline leg (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of wall time given to the CPU baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=3, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
@@ -205,6 +207,9 @@ def main():
     from tightly_coupled_sfm_amd.engine import Engine, default_opts
 
     B = args.windows_per_gpu or (8 if distributed else 1)
+    if args.total_windows:
+        assert args.total_windows % world == 0, "--total-windows must be a multiple of the number of ranks"
+        B = args.total_windows // world
     npairs = 2 * SOURCES * B
     lanes = max(1, args.lanes)
     # rank r owns windows r*B .. r*B+B-1 of the global minibatch (contiguous block split, tightly_coupled_sfm_amd/parallel.py);
@@ -385,7 +390,7 @@ def main():
             "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.total_windows else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
                        "global_batch_frame_pairs": B * world, "gn_iters": ITERS, "solver": "gn", "param": "se3",

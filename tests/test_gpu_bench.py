@@ -75,3 +75,13 @@ def test_bench_two_ranks_one_card(tmp_path):
         pose, _, _ = e.refine(t["tgt"], t["src"], t["depth_t"], t["depth_s"], t["K"], t["pose_init"], default_opts(n_iters=4))
         pose = pose.cpu().numpy()           # pair form: (fwd, inv) interleaved; the bench's window form: all fwd pairs, then all inv pairs
         assert np.array_equal(np.concatenate([pose[0::2], pose[1::2]]), got[rank])
+
+
+def test_bench_strong_scaling_option():
+    """--total-windows fixes the job's windows per step (split over the ranks) and reports "scaling": "strong" (SURVEY 8e asks for both)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--cpu-sample", "0", "--sat-windows", "0",
+                        "--total-windows", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["scaling"] == "strong" and d["config"]["windows_per_gpu"] == 4 and d["config"]["directed_pairs_per_step"] == 8
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
