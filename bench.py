@@ -232,12 +232,10 @@ def main():
     def step_on(lane):   # every step starts from the same initial poses and writes the refined poses to the lane's output
         eng.refine_window_async(lane, win["tgt"], win["srcs"], win["depth_t"], win["depth_s"], win["K"], win["pose"], outs[lane], opts)
 
-    def fence(nl):
-        for l in range(nl):
-            eng.lane_synchronize(l)
+    def fence(nl):     # the contract's bracket: device-wide synchronise (it covers the lanes' streams) + barrier
+        torch.cuda.synchronize()
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
 
     def block(nl):
         fence(nl)
@@ -267,6 +265,8 @@ def main():
         return med, blocks
 
     elapsed, blocks = timed(lanes)
+    for l in range(lanes):                   # a deferred device-side error of any lane surfaces here
+        eng.lane_synchronize(l)
     single = timed(1) if lanes > 1 else (elapsed, blocks)       # the same steps strictly one after the other
     pose_io = outs[0]
 
