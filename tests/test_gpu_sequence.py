@@ -69,6 +69,7 @@ def test_streamed_sequence_lanes_match_plain_calls():
         assert torch.equal(out, plain), lanes
         out2 = sr.run(seq["frames"], seq["depths"], seq["K"], seq["init"])     # reusable
         assert torch.equal(out2, plain)
+        assert torch.equal(sr.run_native(seq["frames"], seq["depths"], seq["K"], seq["init"]), plain.cpu())   # the C++ loop
     assert not torch.equal(plain, t(seq["init"]))             # (and something was refined)
 
 

@@ -58,6 +58,12 @@ class SequenceRefiner:
             self.ring_depth[slot].copy_(depth, non_blocking=True)
             self.copied[slot].record(self.copy_stream)
 
+    def run_native(self, frames, depths, K, init_poses, ring: int = 0) -> torch.Tensor:
+        """The same loop inside the library (tcsfm_refine_sequence: four-frame copies, events and lanes driven from C++) -> refined
+        poses [T-S, 2*S, 6] as a CPU tensor; bit-identical to run()"""
+        pin = lambda a: a if (isinstance(a, torch.Tensor) and not a.is_cuda) else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32)
+        return self.eng.refine_sequence(pin(frames), pin(depths), K, init_poses, self.opts, sources=self.S, ring=ring)
+
     def run(self, frames, depths, K, init_poses) -> torch.Tensor:
         """-> refined poses [T-S, 2*S, 6] (GPU tensor, complete on return)"""
         pin = lambda a: a if (isinstance(a, torch.Tensor) and a.is_pinned()) else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).pin_memory()
