@@ -993,3 +993,34 @@ def test_handles_release_their_memory():
     gc.collect(); torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, (free0, free1)          # 40 leaked handles would hold > 1 GB
+
+
+def test_degenerate_inputs_stay_contained():
+    """Garbage in one pair (NaN texels, non-positive depths, a NaN start pose, textureless images) never crashes or hangs, never
+    leaks into the other pairs of the call (their results are bit-identical to a clean call), and a textureless pair -- singular
+    normal equations -- comes back with its start pose"""
+    from tightly_coupled_sfm_amd.engine import default_opts
+    H, W = 48, 160
+    b = _pairs(3, H, W, seed0=21)
+    e = _eng(H, W, 3)
+    o = default_opts(n_iters=3)
+    clean = e.refine(*_dev(b), _t(b["pose_init"]), o)[0].cpu().numpy()
+
+    def run(mut):
+        bb = {k: v.copy() for k, v in b.items()}
+        mut(bb)
+        return e.refine(*_dev(bb), _t(bb["pose_init"]), o)[0].cpu().numpy()
+
+    def nan_texels(bb): bb["src"][1, :, 10:20, 30:60] = np.nan
+    def bad_depth(bb): bb["depth_t"][1, 0, ::3, ::5] = 0.0; bb["depth_s"][1, 0, 5:9] = -1.0
+    def nan_pose(bb): bb["pose_init"][1, 2] = np.nan
+    def flat(bb): bb["tgt"][1] = 0.5; bb["src"][1] = 0.5
+    for mut in (nan_texels, bad_depth, nan_pose, flat):
+        got = run(mut)
+        assert np.array_equal(got[0], clean[0]) and np.array_equal(got[2], clean[2]), mut.__name__     # the neighbours are untouched
+        if mut is flat:
+            assert np.allclose(got[1], b["pose_init"][1], atol=1e-6), got[1]                             # no information -> no step
+        if mut is nan_pose:
+            assert np.isnan(got[1][:3]).all()                                                             # a NaN start pose is not laundered into numbers
+    again = e.refine(*_dev(b), _t(b["pose_init"]), o)[0].cpu().numpy()
+    assert np.array_equal(again, clean)                                                                   # and the handle is none the worse
