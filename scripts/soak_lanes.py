@@ -1,0 +1,68 @@
+"""Soak of the round-2 concurrency code: for ~SECONDS, random interleavings of lane calls (pose windows, dense windows), whole-sequence
+calls with random lane counts / ring sizes / sources, PoseNet loops and plain calls on ONE handle; every result is compared bit for bit
+with the first result of the same work item, and device memory must not grow."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from tightly_coupled_sfm_amd import synth
+from tightly_coupled_sfm_amd.engine import Engine, default_opts
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 60
+H, W, T = 96, 320, 40
+rng = np.random.default_rng(0)
+seq = synth.make_sequence(T, H, W, seed=2)
+frames, depths = torch.as_tensor(seq["frames"]).pin_memory(), torch.as_tensor(seq["depths"]).pin_memory()
+fd, dd = frames.cuda(), depths.cuda()
+K = torch.as_tensor(seq["K"][None]).cuda()
+init = torch.as_tensor(seq["init"])
+initd = init.cuda()
+o = default_opts(n_iters=3)
+od = default_opts(n_iters=2, min_depth=0.03, max_depth=3.0)
+e = Engine(H, W, 4, lanes=3)
+ref = {}
+def check(key, val):
+    val = [v.clone().cpu() for v in val]
+    if key in ref:
+        assert all(torch.equal(a, b) for a, b in zip(ref[key], val)), key
+    else:
+        ref[key] = val
+po = [torch.empty(2, 6, device="cuda") for _ in range(3)]
+do = [torch.empty(2, 1, H, W, device="cuda") for _ in range(3)]
+torch.cuda.synchronize()
+mem0 = None
+t0 = time.time(); n = 0
+while time.time() - t0 < SECONDS:
+    kind = rng.integers(0, 4)
+    if kind == 0:      # three pose windows in flight
+        ws = rng.integers(0, T - 1, size=3)
+        for l, w in enumerate(ws):
+            e.refine_window_async(l, fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], po[l], o)
+        for l, w in enumerate(ws):
+            e.lane_synchronize(l); check(("pose", int(w)), [po[l]])
+    elif kind == 1:    # dense windows in flight, mixed with a pose window
+        ws = rng.integers(0, T - 1, size=3)
+        for l, w in enumerate(ws):
+            if l == 1:
+                e.refine_window_async(l, fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], po[l], o)
+            else:
+                e.refine_dense_window_async(l, fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], po[l], do[l], od)
+        for l, w in enumerate(ws):
+            e.lane_synchronize(l)
+            check(("pose", int(w)), [po[l]]) if l == 1 else check(("dense", int(w)), [po[l], do[l]])
+    elif kind == 2:    # a whole sequence in one call, random ring
+        ring = int(rng.choice([0, 3, 5, 12, 20]))
+        n0 = int(rng.integers(0, 10)); n1 = int(rng.integers(n0 + 6, T))
+        out = e.refine_sequence(frames[n0:n1], depths[n0:n1], seq["K"], init[n0:n1 - 1], o, ring=ring)
+        for w in range(n0, n1 - 1):
+            check(("pose", w), [out[w - n0].cuda()])
+    else:              # plain synchronous call on the handle itself
+        w = int(rng.integers(0, T - 1))
+        p = e.refine_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], o)[0]
+        check(("pose", w), [p])
+    n += 1
+    if n == 50:
+        torch.cuda.synchronize(); mem0 = torch.cuda.mem_get_info()[0]
+torch.cuda.synchronize()
+mem1 = torch.cuda.mem_get_info()[0]
+print(json.dumps({"seconds": round(time.time() - t0, 1), "rounds": n, "work_items_checked": len(ref), "free_memory_change_MB": None if mem0 is None else round((mem1 - mem0) / 2**20, 2)}))
+assert mem0 is None or mem0 - mem1 < 64 * 2**20
