@@ -33,3 +33,20 @@ def test_documented_ctypes_stub_runs_and_matches_engine():
     ref, _, _ = e.refine(tgt, src, dt, ds, K, p0, default_opts(n_iters=4))
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+def test_documented_sequence_stub_runs_and_matches_engine():
+    from tightly_coupled_sfm_amd import _lib, synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    _lib.load()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# tcsfm_sequence\.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("libtcsfm_hip.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:tcsfm_sequence", "exec"), ns)
+    H, W, T = 48, 160, 14
+    seq = synth.make_sequence(T, H, W, seed=4)
+    frames, depths = torch.as_tensor(seq["frames"]).pin_memory(), torch.as_tensor(seq["depths"]).pin_memory()
+    out = ns["refine_sequence"](frames, depths, seq["K"], seq["init"], sources=1, gn_iters=3, lanes=2)
+    ref = Engine(H, W, 2, lanes=2).refine_sequence(frames, depths, seq["K"], seq["init"], default_opts(n_iters=3))
+    assert out.shape == (T - 1, 2, 6) and np.array_equal(out, ref.numpy())
