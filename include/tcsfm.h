@@ -261,6 +261,15 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window. */
 int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
                           const float *pose_init, float *pose_out, float *log_scale_out, int ring);
+/* The same loop with the reference's pose initialisation inside it: for every window the coupled PoseNet loop of
+ * train_mono.py:64-80 (tcsfm_solve_pose_iteratively, `num_iter` network evaluations: config['iterations'], 4 in the reference's
+ * scripts) produces the initial poses on the window's lane, then the window is refined -- what optimize_window does per window
+ * (optimizer.py:136-297) minus the depth network, whose per-frame output is the `depths` argument (depths, not disparities).
+ * `pn`: a loaded PoseNet of this handle with max_images >= 2*S; the lanes run copies of it that share its weights.
+ * pose_init_out [T-S, 2*S, 6] (or NULL) receives the PoseNet poses, pose_out the refined ones.  Bit-identical to one
+ * tcsfm_solve_pose_iteratively + tcsfm_refine_window per window. */
+int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
+                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring);
 int tcsfm_lane_wait(tcsfm_handle h, int lane);
 int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
 int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);

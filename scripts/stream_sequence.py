@@ -70,6 +70,40 @@ for lanes in (1, 2, 3):
                       "ms_total": round(med * 1e3, 2), "windows_per_s": round((T - 1) / med, 1),
                       "bit_identical_to_streamed": bool(torch.equal(res, ref.cpu()))}), flush=True)
     e.close()
+# (d) with the reference's pose initialisation inside the loop: per window the coupled PoseNet loop (4 evaluations + 3 warps), then the
+#     refinement -- tcsfm_odometry_sequence against the same work issued window by window from Python (frames already on the device)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import standins
+from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+params = standins.posenet_params(0)
+e = Engine(H, W, 2)
+net = PoseNetHIP(e, 2, params)
+fd, dd = frames.cuda(), depths.cuda(); Kd1 = torch.as_tensor(K[None]).cuda()
+def per_window():
+    outs = []
+    for w in range(T - 1):
+        p0, _ = net.solve_pose_iteratively(4, fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], Kd1)
+        outs.append(e.refine_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], Kd1, p0, opts)[0])
+    torch.cuda.synchronize()
+    return torch.stack(outs)
+ref_o = per_window()
+ts = []
+for rep in range(3):
+    t0 = time.perf_counter(); per_window(); ts.append(time.perf_counter() - t0)
+print(json.dumps({"path": "PoseNet loop (4 its) + refinement per window, one window after the other, device-resident frames (Python loop over the library calls)",
+                  "windows_per_s": round((T - 1) / sorted(ts)[1], 1), "us_per_window": round(sorted(ts)[1] / (T - 1) * 1e6, 1)}), flush=True)
+e.close()
+for lanes in (1, 2, 3):
+    e = Engine(H, W, 2, lanes=lanes)
+    net = PoseNetHIP(e, 2, params)
+    net.odometry_sequence(frames[:40], depths[:40], K, opts, iterations=4)
+    ts = []
+    for rep in range(5):
+        t0 = time.perf_counter(); init_o, out_o = net.odometry_sequence(frames, depths, K, opts, iterations=4); ts.append(time.perf_counter() - t0)
+    print(json.dumps({"path": f"tcsfm_odometry_sequence: PoseNet loop (4 its) + refinement per window inside the library, frames streamed from pinned memory, {lanes} lane(s)",
+                      "windows_per_s": round((T - 1) / sorted(ts)[2], 1), "us_per_window": round(sorted(ts)[2] / (T - 1) * 1e6, 1),
+                      "bit_identical_to_per_window_calls": bool(torch.equal(out_o, ref_o.cpu()))}), flush=True)
+    net.close(); e.close()
 # the same windows from DEVICE-resident frames (no PCIe in the loop): what the lanes alone buy at B=1
 dev_f, dev_d = frames.cuda(), depths.cuda()
 Kd = torch.as_tensor(K[None]).cuda(); p0 = torch.as_tensor(init).cuda(); outd = torch.empty_like(p0)

@@ -138,3 +138,29 @@ def test_posenet_from_a_reference_style_checkpoint(tmp_path):
     b = synth.make_batch(N, H, W, seed0=40, both_directions=True)
     pose = net(_t(np.concatenate([b["tgt"], b["src"]], 1))).cpu().numpy()
     assert np.max(np.abs(pose - g["a_pose"])) < 1e-5 * np.abs(g["a_pose"]).max()
+
+
+@pytest.mark.parametrize("S,lanes", [(1, 1), (1, 3), (2, 2)])
+def test_odometry_sequence_matches_per_window_calls(S, lanes):
+    """tcsfm_odometry_sequence (per window: coupled PoseNet loop -> refinement, windows on the lanes, frames streamed once): the
+    PoseNet poses and the refined poses equal, bit for bit, one solve_pose_iteratively + one refine_window call per window"""
+    import standins
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+    H, W, T, IT = 48, 160, 12, 3
+    seq = synth.make_sequence(T, H, W, seed=6)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    e = Engine(H, W, 2 * S, lanes=lanes)
+    net = PoseNetHIP(e, 2 * S, standins.posenet_params(5))
+    o = default_opts(n_iters=3, argmin=1)
+    K = t(seq["K"][None]).cuda()
+    ref_init, ref_out = [], []
+    for w in range(T - S):
+        tg, dt_ = t(seq["frames"][w:w + 1]).cuda(), t(seq["depths"][w:w + 1]).cuda()
+        sr, ds_ = t(seq["frames"][w + 1:w + 1 + S])[:, None].cuda(), t(seq["depths"][w + 1:w + 1 + S])[:, None].cuda()
+        p0, _ = net.solve_pose_iteratively(IT, tg, sr, dt_, ds_, K)
+        ref_init.append(p0.cpu()); ref_out.append(e.refine_window(tg, sr, dt_, ds_, K, p0, o)[0].cpu())
+    init, out = net.odometry_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], o, sources=S, iterations=IT)
+    assert torch.equal(init, torch.stack(ref_init)) and torch.equal(out, torch.stack(ref_out))
+    assert not torch.equal(init, out)

@@ -1077,14 +1077,25 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
     return TCSFM_OK;
 }
 
-// The reference's sequential driver (run_sequential_optimization.py:186-247) as ONE call: see include/tcsfm.h.
-int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
-                          const float *pose_init, float *pose_out, float *log_scale_out, int ring) {
+// (the PoseNet section further down)
+struct tcsfm_posenet;
+static int pose_loop(tcsfm_ctx *h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
+                     const float *depth_s, const float *K, float *poses_out, float *stacked_out);
+static tcsfm_posenet *pn_for_lane(tcsfm_posenet *pn, tcsfm_ctx *c);
+static bool pn_usable(const tcsfm_posenet *pn, const tcsfm_ctx *h, int images);
+
+// The reference's sequential driver (run_sequential_optimization.py:186-247) as ONE call: see include/tcsfm.h.  With `pn` the initial
+// poses of every window come from the coupled PoseNet loop (train_mono.py:64-80) on the window's lane instead of from the caller.
+static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
+                         const float *pose_init, tcsfm_posenet *pn, int num_iter, float *pose_init_out, float *pose_out,
+                         float *log_scale_out, int ring) {
     if (!h) return TCSFM_E_ARG;
     if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
     const int N = 2 * S, L = (int)h->lanes.size() + 1;
     if (S < 1 || T <= S || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: need S >= 1, T > S and 2*S <= max_pairs");
-    if (!frames || !depths || !K || !pose_init || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
+    if (!frames || !depths || !K || (!pose_init && !pn) || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
+    if (pn && (num_iter < 1 || !pn_usable(pn, h, N) || o_in->depth_is_disp))
+        return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: needs a loaded PoseNet of this handle with max_images >= 2*S, num_iter >= 1 and depths (not disparities)");
     tcsfm_opts o = *o_in;
     o.host_ptrs = 0;                                   // the lanes work on the device ring; this call does the staging itself
     int rc = check_common(h, &o, N);
@@ -1130,13 +1141,15 @@ int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, 
     // ---- small inputs: one copy each, on the copy stream; every lane waits for them once
     hipStream_t cs = h->seq_copy;
     HIPCHK(h, hipMemcpyAsync(h->seq_K, K, 9 * sizeof(float), hipMemcpyHostToDevice, cs));
-    HIPCHK(h, hipMemcpyAsync(h->seq_pose_in, pose_init, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyHostToDevice, cs));
+    if (!pn) HIPCHK(h, hipMemcpyAsync(h->seq_pose_in, pose_init, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyHostToDevice, cs));
     hipEvent_t small_ev = h->seq_done[n_done - 1];
     HIPCHK(h, hipEventRecord(small_ev, cs));
     std::vector<tcsfm_ctx *> lane(L);
+    std::vector<tcsfm_posenet *> net(L, nullptr);
     std::vector<hipStream_t> ls(L);
     for (int l = 0; l < L; l++) {
         lane[l] = l == 0 ? h : h->lanes[l - 1];
+        if (pn && !(net[l] = pn_for_lane(pn, lane[l]))) return fail(h, TCSFM_E_NOMEM, "tcsfm_odometry_sequence: no memory for a lane's PoseNet activations");
         ls[l] = l == 0 ? h->stream : lane[l]->own_stream;
         lane[l]->stream = ls[l];
         HIPCHK(h, hipStreamWaitEvent(ls[l], small_ev, 0));
@@ -1171,6 +1184,11 @@ int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, 
         const int l = w % L, s0 = w % R;
         for (int k = w / C; k <= (w + S) / C; k++) HIPCHK(h, hipStreamWaitEvent(ls[l], h->seq_copied[(k * C % R) / C], 0));
         tcsfm_ctx *c = lane[l];
+        if (pn) {           // initial poses of this window: PoseNet -> warp -> PoseNet correction, num_iter times, on the lane
+            rc = pose_loop(c, net[l], num_iter, 1, S, h->seq_img + (size_t)s0 * 3 * hw, h->seq_img + (size_t)(s0 + 1) * 3 * hw,
+                           h->seq_depth + (size_t)s0 * hw, h->seq_depth + (size_t)(s0 + 1) * hw, h->seq_K, h->seq_pose_in + (size_t)w * N * 6, nullptr);
+            if (rc) { if (c != h) h->err = c->err; break; }
+        }
         rc = refine_impl(c, &o, N, 1, S, h->seq_img + (size_t)s0 * 3 * hw, h->seq_img + (size_t)(s0 + 1) * 3 * hw, h->seq_depth + (size_t)s0 * hw,
                          h->seq_depth + (size_t)(s0 + 1) * hw, h->seq_K, h->seq_pose_in + (size_t)w * N * 6, nullptr,
                          h->seq_pose_out + (size_t)w * N * 6, np == 7 ? h->seq_ls_out + (size_t)w * N : nullptr, nullptr);
@@ -1189,8 +1207,21 @@ int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, 
     for (int l = 0; l < L; l++)
         if (int rc_ = pending_error(lane[l])) { if (lane[l] != h) h->err = lane[l]->err; return rc_; }
     HIPCHK(h, hipMemcpy(pose_out, h->seq_pose_out, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    if (pose_init_out) HIPCHK(h, hipMemcpy(pose_init_out, h->seq_pose_in, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyDeviceToHost));
     if (log_scale_out && np == 7) HIPCHK(h, hipMemcpy(log_scale_out, h->seq_ls_out, (size_t)nwin * N * sizeof(float), hipMemcpyDeviceToHost));
     return TCSFM_OK;
+}
+
+int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring) {
+    if (h && !pose_init) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
+    return sequence_impl(h, o, T, S, frames, depths, K, pose_init, nullptr, 0, nullptr, pose_out, log_scale_out, ring);
+}
+
+int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
+                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring) {
+    if (h && !pn) return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: NULL PoseNet");
+    return sequence_impl(h, o, T, S, frames, depths, K, nullptr, pn, num_iter, pose_init_out, pose_out, log_scale_out, ring);
 }
 
 int tcsfm_lane_wait(tcsfm_handle h, int lane) {
@@ -1327,19 +1358,58 @@ struct tcsfm_posenet {
     float *head_w = nullptr, *head_b = nullptr, *raw = nullptr;
     float *in_buf = nullptr;     // [max_images,6,H,W] (tgt * valid | img_rec) written by the warp kernel
     float *pose = nullptr;       // [max_images,6] running pose of the coupled loop
+    // tcsfm_odometry_sequence runs the network on the handle's lanes: clone k works on lane k with its own activations and
+    // borrows this object's weights
+    bool owns_weights = true;
+    std::vector<tcsfm_posenet *> clones;
 };
 
 void tcsfm_posenet_destroy(tcsfm_posenet *pn) {
     if (!pn) return;
+    for (tcsfm_posenet *c : pn->clones) tcsfm_posenet_destroy(c);
     DeviceGuard dev_guard(pn->h->device);
     for (int l = 0; l < 7; l++) {
-        void *ptrs[] = {pn->w4[l], pn->bias[l], pn->gamma[l], pn->beta[l], pn->act[l], pn->scsh[l], pn->part[l]};
-        for (void *p : ptrs) if (p) (void)hipFree(p);
+        void *weights[] = {pn->w4[l], pn->bias[l], pn->gamma[l], pn->beta[l]}, *scratch[] = {pn->act[l], pn->scsh[l], pn->part[l]};
+        if (pn->owns_weights) for (void *p : weights) if (p) (void)hipFree(p);
+        for (void *p : scratch) if (p) (void)hipFree(p);
     }
-    void *ptrs[] = {pn->head_w, pn->head_b, pn->raw, pn->in_buf, pn->pose};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    void *weights[] = {pn->head_w, pn->head_b, pn->raw}, *scratch[] = {pn->in_buf, pn->pose};
+    if (pn->owns_weights) for (void *p : weights) if (p) (void)hipFree(p);
+    for (void *p : scratch) if (p) (void)hipFree(p);
     delete pn;
 }
+
+// activations, statistics and loop buffers of one PoseNet instance (layer geometry and work split already filled in)
+static hipError_t pn_alloc_scratch(tcsfm_posenet *pn) {
+    hipError_t e = hipSuccess;
+    const int max_images = pn->max_images;
+    for (int l = 0; l < 7 && e == hipSuccess; l++) {
+        const PnLayer &L = pn->L[l];
+        e = hipMalloc((void **)&pn->act[l], (size_t)L.ksplit * max_images * L.oh * L.ow * L.cout * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&pn->scsh[l], (size_t)max_images * L.cout * 2 * sizeof(float));
+        if (e == hipSuccess && (pn->ks_cfg[0][l] == 1 || pn->ks_cfg[1][l] == 1))
+            e = hipMalloc((void **)&pn->part[l], (size_t)max_images * std::max((L.oh * L.ow + 63) / 64, L.oh * ((L.ow + 63) / 64)) * L.cout * 2 * sizeof(float));
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->in_buf, (size_t)max_images * 6 * pn->h->H * pn->h->W * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&pn->pose, (size_t)max_images * 6 * sizeof(float));
+    return e;
+}
+
+// the instance that runs `pn`'s network on lane context `c` (lane 0 = pn itself)
+static tcsfm_posenet *pn_for_lane(tcsfm_posenet *pn, tcsfm_ctx *c) {
+    if (pn->h == c) return pn;
+    for (tcsfm_posenet *q : pn->clones)
+        if (q->h == c) return q;
+    tcsfm_posenet *q = new tcsfm_posenet(*pn);          // geometry, work split, weight pointers
+    q->h = c; q->owns_weights = false; q->clones.clear();
+    for (int l = 0; l < 7; l++) q->act[l] = q->scsh[l] = q->part[l] = nullptr;
+    q->in_buf = q->pose = nullptr;
+    if (pn_alloc_scratch(q) != hipSuccess) { tcsfm_posenet_destroy(q); return nullptr; }
+    pn->clones.push_back(q);
+    return q;
+}
+
+static bool pn_usable(const tcsfm_posenet *pn, const tcsfm_ctx *h, int images) { return pn && pn->h == h && pn->loaded && images <= pn->max_images; }
 
 int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
     if (!h || !out) return TCSFM_E_ARG;
@@ -1380,18 +1450,13 @@ int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
         if (e == hipSuccess) e = hipMalloc((void **)&pn->bias[l], L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->gamma[l], L.cout * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&pn->beta[l], L.cout * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&pn->act[l], (size_t)L.ksplit * max_images * L.oh * L.ow * L.cout * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc((void **)&pn->scsh[l], (size_t)max_images * L.cout * 2 * sizeof(float));
-        if (e == hipSuccess && (pn->ks_cfg[0][l] == 1 || pn->ks_cfg[1][l] == 1))
-            e = hipMalloc((void **)&pn->part[l], (size_t)max_images * std::max((L.oh * L.ow + 63) / 64, L.oh * ((L.ow + 63) / 64)) * L.cout * 2 * sizeof(float));
         wmax = std::max(wmax, (size_t)L.cout * L.cin * L.ks * L.ks);
         ih = L.oh; iw = L.ow;
     }
     if (e == hipSuccess) e = hipMalloc((void **)&pn->head_w, 6 * 256 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&pn->head_b, 6 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&pn->raw, wmax * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&pn->in_buf, (size_t)max_images * 6 * h->H * h->W * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&pn->pose, (size_t)max_images * 6 * sizeof(float));
+    if (e == hipSuccess) e = pn_alloc_scratch(pn);
     if (e != hipSuccess) { tcsfm_posenet_destroy(pn); return fail(h, e == hipErrorOutOfMemory ? TCSFM_E_NOMEM : TCSFM_E_HIP, "tcsfm_posenet_create: allocation failed"); }
     *out = pn;
     return TCSFM_OK;
@@ -1470,15 +1535,10 @@ int tcsfm_posenet_forward(tcsfm_posenet *pn, int N, const float *imgs, float *po
     return pn_run(pn, N, imgs, 6 * hw, imgs + 3 * hw, 6 * hw, 0, 0, pose_out, 0, nullptr, 0, 1);
 }
 
-int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs,
-                                 const float *depth_t, const float *depth_s, const float *K, float *poses_out, float *stacked_out) {
-    if (!h || !pn || pn->h != h) return TCSFM_E_ARG;
-    if (!pn->loaded) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: no weights loaded");
+// the coupled loop of train_mono.py:64-80 on context `h` (the handle or one of its lanes; pn->h == h): network, warps, corrections
+static int pose_loop(tcsfm_ctx *h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
+                     const float *depth_s, const float *K, float *poses_out, float *stacked_out) {
     const int N = 2 * B * S;
-    if (num_iter < 1 || B < 1 || S < 1 || N > pn->max_images || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: sizes out of range");
-    if (!tgt || !srcs || !depth_t || !depth_s || !K || !poses_out) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: NULL argument");
-    DeviceGuard dev_guard(h->device);
-    if (int rc_ = pending_error(h)) return rc_;
     int rc;
     tcsfm_opts o; tcsfm_default_opts(&o);
     if ((rc = check_intrinsics(h, &o, K, B))) return rc;
@@ -1502,7 +1562,18 @@ int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter
     return TCSFM_OK;
 }
 
-// ---- SE(3) host utilities ----------------------------------------------------------------------
+int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, float *poses_out, float *stacked_out) {
+    if (!h || !pn || pn->h != h) return TCSFM_E_ARG;
+    if (!pn->loaded) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: no weights loaded");
+    const int N = 2 * B * S;
+    if (num_iter < 1 || B < 1 || S < 1 || N > pn->max_images || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: sizes out of range");
+    if (!tgt || !srcs || !depth_t || !depth_s || !K || !poses_out) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: NULL argument");
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
+    return pose_loop(h, pn, num_iter, B, S, tgt, srcs, depth_t, depth_s, K, poses_out, stacked_out);
+}
+
 void tcsfm_pose_to_matrix(const double pose[6], double T[12]) { tc::pose_to_T(pose, T); }
 void tcsfm_matrix_to_pose(const double T[12], double pose[6]) { tc::T_to_pose(T, pose); }
 void tcsfm_se3_exp(const double xi[6], double T[12]) { tc::se3_exp(xi, T); }

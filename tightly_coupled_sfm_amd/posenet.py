@@ -93,6 +93,23 @@ class PoseNetHIP:
         e._call(self.lib.tcsfm_posenet_forward(self._pn, N, e._p(imgs), e._p(out)))
         return out
 
+    def odometry_sequence(self, frames, depths, K, opts=None, sources: int = 1, iterations: int = 4, ring: int = 0):
+        """tcsfm_odometry_sequence: for every window of a sequence (frames [T,3,H,W] / depths [T,1,H,W] CPU tensors, pinned for
+        asynchronous copies; K [3,3]) the coupled PoseNet loop gives the initial poses and the engine refines them, windows
+        running on the engine's lanes -> (initial poses, refined poses), each [T-S, 2S, 6] CPU tensors"""
+        e = self.eng
+        e._bind()
+        from .engine import default_opts
+        o = opts or default_opts()
+        T, S = int(frames.shape[0]), int(sources)
+        frames = e._cpu(frames, (T, 3, e.H, e.W), "frames"); depths = e._cpu(depths, (T, 1, e.H, e.W), "depths")
+        Kc = e._cpu(torch.as_tensor(np.asarray(K, dtype=np.float32)), (3, 3), "K")
+        init = torch.empty((T - S, 2 * S, 6), dtype=torch.float32); out = torch.empty_like(init)
+        hp = lambda t: C.c_void_p(t.data_ptr())
+        e._call(self.lib.tcsfm_odometry_sequence(e._h, self._pn, int(iterations), C.byref(o), T, S, hp(frames), hp(depths), hp(Kc), hp(init), hp(out),
+                                                 None, int(ring)))
+        return init, out
+
     def solve_pose_iteratively(self, num_iter: int, tgt, srcs, depth_t, depth_s, K):
         """the coupled loop of train_mono.py:41-81 for a window (layouts of Engine.refine_window) -> (poses [2SB,6], stacked [2SB,num_iter,6])"""
         e = self.eng
