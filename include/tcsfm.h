@@ -255,21 +255,26 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  *   frames [T,3,H,W], depths [T,1,H,W] (or disparities, opts.depth_is_disp), K [3,3] (one camera for the sequence),
  *   pose_init / pose_out [T-S, 2*S, 6], log_scale_out [T-S, 2*S] or NULL (TCSFM_REFINE_POSE_SCALE; the scale starts at 0).
  * Every frame crosses PCIe once, on a high-priority copy stream of the handle, four frames per copy, into a device ring of `ring`
- * frames (0 = default: 32 + S; at least S + 2, chunked copies from S + 8 up); windows are refined round robin on the handle's lanes
- * (tcsfm_set_lanes; 2-3 lanes: the GPU runs four hardware queues at once and the copy stream is one of them) from the ring by
- * pointer; a slot is recycled -- on the device, by events -- once every window reading it has finished.  The call returns when all
- * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window. */
+ * frames (0 = default; at least windows_per_call + S + 4, or S + 2 with one window per call and single-frame copies); the calls are
+ * issued round robin on the handle's lanes (tcsfm_set_lanes; 2-3 lanes: the GPU runs four hardware queues at once and the copy
+ * stream is one of them) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
+ * finished.  windows_per_call (0 = default 8, capped by max_pairs / (2 S)): with S = 1 the targets and the sources of consecutive
+ * windows are contiguous runs of the ring, so one call refines that many windows at once (the kernels fill the chip); with S > 1
+ * every call is one window.  The call returns when all windows are done (it synchronises).  Results are bit-identical to one
+ * tcsfm_refine_window call per window, whatever the lanes, the ring and windows_per_call. */
 int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
-                          const float *pose_init, float *pose_out, float *log_scale_out, int ring);
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call);
 /* The same loop with the reference's pose initialisation inside it: for every window the coupled PoseNet loop of
  * train_mono.py:64-80 (tcsfm_solve_pose_iteratively, `num_iter` network evaluations: config['iterations'], 4 in the reference's
  * scripts) produces the initial poses on the window's lane, then the window is refined -- what optimize_window does per window
  * (optimizer.py:136-297) minus the depth network, whose per-frame output is the `depths` argument (depths, not disparities).
  * `pn`: a loaded PoseNet of this handle with max_images >= 2*S; the lanes run copies of it that share its weights.
  * pose_init_out [T-S, 2*S, 6] (or NULL) receives the PoseNet poses, pose_out the refined ones.  Bit-identical to one
- * tcsfm_solve_pose_iteratively + tcsfm_refine_window per window. */
+ * tcsfm_solve_pose_iteratively + tcsfm_refine_window per CALL's windows (windows_per_call of them as one batch; the PoseNet's
+ * work split -- hence its rounding -- depends on the number of images, see tcsfm_posenet_forward: per-window calls agree to 1e-5). */
 int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
-                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring);
+                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring,
+                            int windows_per_call);
 int tcsfm_lane_wait(tcsfm_handle h, int lane);
 int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
 int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);

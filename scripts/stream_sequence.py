@@ -57,16 +57,16 @@ for lanes in (1, 2, 3, 4):
     sr.eng.close(); del sr                 # live handles keep their streams: the GPU runs four hardware queues at once
 # (c) the same loop inside the library: ONE tcsfm_refine_sequence call per pass (C++ drives copies, events and lanes)
 init_t = torch.as_tensor(init)
-for lanes in (1, 2, 3):
-    e = Engine(H, W, 2, lanes=lanes)
-    e.refine_sequence(frames[:60], depths[:60], K, init_t[:59], opts)
+for lanes, wpc in ((1, 1), (2, 1), (3, 1), (1, 8), (2, 8), (3, 8), (2, 16)):
+    e = Engine(H, W, 2 * wpc, lanes=lanes)
+    e.refine_sequence(frames[:60], depths[:60], K, init_t[:59], opts, windows_per_call=wpc)
     times = []
     for rep in range(7):
         t0 = time.perf_counter()
-        res = e.refine_sequence(frames, depths, K, init_t, opts)
+        res = e.refine_sequence(frames, depths, K, init_t, opts, windows_per_call=wpc)
         times.append(time.perf_counter() - t0)
     med = sorted(times)[3]
-    print(json.dumps({"path": f"tcsfm_refine_sequence: the window loop inside the library, {lanes} lane(s)", "frames": T, "windows": T - 1,
+    print(json.dumps({"path": f"tcsfm_refine_sequence: the window loop inside the library, {lanes} lane(s), {wpc} window(s) per call", "frames": T, "windows": T - 1,
                       "ms_total": round(med * 1e3, 2), "windows_per_s": round((T - 1) / med, 1),
                       "bit_identical_to_streamed": bool(torch.equal(res, ref.cpu()))}), flush=True)
     e.close()
@@ -80,29 +80,32 @@ e = Engine(H, W, 2)
 net = PoseNetHIP(e, 2, params)
 fd, dd = frames.cuda(), depths.cuda(); Kd1 = torch.as_tensor(K[None]).cuda()
 def per_window():
-    outs = []
+    outs, inits = [], []
     for w in range(T - 1):
         p0, _ = net.solve_pose_iteratively(4, fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], Kd1)
+        inits.append(p0)
         outs.append(e.refine_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], Kd1, p0, opts)[0])
     torch.cuda.synchronize()
-    return torch.stack(outs)
-ref_o = per_window()
+    return torch.stack(outs), torch.stack(inits)
+ref_o, ref_i = per_window()
 ts = []
 for rep in range(3):
     t0 = time.perf_counter(); per_window(); ts.append(time.perf_counter() - t0)
 print(json.dumps({"path": "PoseNet loop (4 its) + refinement per window, one window after the other, device-resident frames (Python loop over the library calls)",
                   "windows_per_s": round((T - 1) / sorted(ts)[1], 1), "us_per_window": round(sorted(ts)[1] / (T - 1) * 1e6, 1)}), flush=True)
 e.close()
-for lanes in (1, 2, 3):
-    e = Engine(H, W, 2, lanes=lanes)
-    net = PoseNetHIP(e, 2, params)
-    net.odometry_sequence(frames[:40], depths[:40], K, opts, iterations=4)
+for lanes, wpc in ((1, 1), (2, 1), (3, 1), (1, 8), (2, 8), (3, 8), (2, 16)):
+    e = Engine(H, W, 2 * wpc, lanes=lanes)
+    net = PoseNetHIP(e, 2 * wpc, params)
+    net.odometry_sequence(frames[:40], depths[:40], K, opts, iterations=4, windows_per_call=wpc)
     ts = []
     for rep in range(5):
-        t0 = time.perf_counter(); init_o, out_o = net.odometry_sequence(frames, depths, K, opts, iterations=4); ts.append(time.perf_counter() - t0)
-    print(json.dumps({"path": f"tcsfm_odometry_sequence: PoseNet loop (4 its) + refinement per window inside the library, frames streamed from pinned memory, {lanes} lane(s)",
+        t0 = time.perf_counter(); init_o, out_o = net.odometry_sequence(frames, depths, K, opts, iterations=4, windows_per_call=wpc); ts.append(time.perf_counter() - t0)
+    print(json.dumps({"path": f"tcsfm_odometry_sequence: PoseNet loop (4 its) + refinement inside the library, frames streamed from pinned memory, {lanes} lane(s), {wpc} window(s) per call",
                       "windows_per_s": round((T - 1) / sorted(ts)[2], 1), "us_per_window": round(sorted(ts)[2] / (T - 1) * 1e6, 1),
-                      "bit_identical_to_per_window_calls": bool(torch.equal(out_o, ref_o.cpu()))}), flush=True)
+                      "posenet_poses_max_rel_diff_to_per_window_calls": float((init_o - ref_i.cpu()).abs().max() / ref_i.abs().max()),
+                      "refined_poses_max_rel_diff": float((out_o - ref_o.cpu()).abs().max() / ref_o.abs().max()),
+                      "note": "the PoseNet's work split (hence its rounding, ~1e-6) depends on the number of images per call; the coupled loop has discrete decisions (warp validity), so with these RANDOM weights a few windows (3 of 199) amplify it to 1e-5..1e-2 -- all others agree to ~1e-6"}), flush=True)
     net.close(); e.close()
 # the same windows from DEVICE-resident frames (no PCIe in the loop): what the lanes alone buy at B=1
 dev_f, dev_d = frames.cuda(), depths.cuda()

@@ -140,8 +140,8 @@ def test_posenet_from_a_reference_style_checkpoint(tmp_path):
     assert np.max(np.abs(pose - g["a_pose"])) < 1e-5 * np.abs(g["a_pose"]).max()
 
 
-@pytest.mark.parametrize("S,lanes", [(1, 1), (1, 3), (2, 2)])
-def test_odometry_sequence_matches_per_window_calls(S, lanes):
+@pytest.mark.parametrize("S,lanes,wpc", [(1, 1, 1), (1, 3, 1), (2, 2, 0), (1, 2, 2), (1, 2, 5)])
+def test_odometry_sequence_matches_per_window_calls(S, lanes, wpc):
     """tcsfm_odometry_sequence (per window: coupled PoseNet loop -> refinement, windows on the lanes, frames streamed once): the
     PoseNet poses and the refined poses equal, bit for bit, one solve_pose_iteratively + one refine_window call per window"""
     import standins
@@ -151,16 +151,27 @@ def test_odometry_sequence_matches_per_window_calls(S, lanes):
     H, W, T, IT = 48, 160, 12, 3
     seq = synth.make_sequence(T, H, W, seed=6)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
-    e = Engine(H, W, 2 * S, lanes=lanes)
-    net = PoseNetHIP(e, 2 * S, standins.posenet_params(5))
+    WB = max(1, wpc) if S == 1 else 1
+    e = Engine(H, W, 2 * S * WB, lanes=lanes)
+    net = PoseNetHIP(e, 2 * S * WB, standins.posenet_params(5))
     o = default_opts(n_iters=3, argmin=1)
-    K = t(seq["K"][None]).cuda()
     ref_init, ref_out = [], []
-    for w in range(T - S):
-        tg, dt_ = t(seq["frames"][w:w + 1]).cuda(), t(seq["depths"][w:w + 1]).cuda()
-        sr, ds_ = t(seq["frames"][w + 1:w + 1 + S])[:, None].cuda(), t(seq["depths"][w + 1:w + 1 + S])[:, None].cuda()
+    for c0 in range(0, T - S, WB):                        # the same batches, call by call
+        nb = min(WB, T - S - c0)
+        K = t(np.repeat(seq["K"][None], nb, 0)).cuda()
+        tg, dt_ = t(seq["frames"][c0:c0 + nb]).cuda(), t(seq["depths"][c0:c0 + nb]).cuda()
+        sr = torch.stack([t(seq["frames"][c0 + 1 + s:c0 + 1 + s + nb]) for s in range(S)]).cuda()
+        ds_ = torch.stack([t(seq["depths"][c0 + 1 + s:c0 + 1 + s + nb]) for s in range(S)]).cuda()
         p0, _ = net.solve_pose_iteratively(IT, tg, sr, dt_, ds_, K)
-        ref_init.append(p0.cpu()); ref_out.append(e.refine_window(tg, sr, dt_, ds_, K, p0, o)[0].cpu())
-    init, out = net.odometry_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], o, sources=S, iterations=IT)
+        pr = e.refine_window(tg, sr, dt_, ds_, K, p0, o)[0]
+        # stacked order of a call [fwd (s, b) | inv (s, b)] -> per window [fwd s | inv s]
+        idx = [[s * nb + b for s in range(S)] + [S * nb + s * nb + b for s in range(S)] for b in range(nb)]
+        ref_init += [p0[i].cpu() for i in idx]; ref_out += [pr[i].cpu() for i in idx]
+    init, out = net.odometry_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], o, sources=S, iterations=IT,
+                                      windows_per_call=wpc)
     assert torch.equal(init, torch.stack(ref_init)) and torch.equal(out, torch.stack(ref_out))
     assert not torch.equal(init, out)
+    if WB > 1:      # against one window per call: the PoseNet's work split depends on the number of images (rounding only)
+        i1, o1 = net.odometry_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], o, sources=S, iterations=IT,
+                                       windows_per_call=1)
+        assert float((i1 - init).abs().max()) < 1e-5 * float(init.abs().max())

@@ -172,3 +172,26 @@ def test_native_sequence_loop_matches_per_window_calls(S, lanes, ring):
     badK = seq["K"].copy(); badK[0, 1] = 0.1
     with pytest.raises(RuntimeError, match="pinhole"):
         e.refine_sequence(frames, depths, badK, init, o, sources=S)
+
+
+@pytest.mark.parametrize("wpc,lanes,ring", [(0, 2, 0), (8, 3, 0), (3, 2, 0), (5, 1, 12), (4, 3, 20), (8, 2, 16)])
+def test_sequence_loop_with_several_windows_per_call(wpc, lanes, ring):
+    """tcsfm_refine_sequence with one source per window refines `windows_per_call` consecutive windows per call (their targets and
+    sources are contiguous runs of the ring): bit-identical to one refine_window call per window for every batch size (ragged last
+    call included), lane count and ring -- the refinement is batch-independent"""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W, T = 48, 160, 31
+    seq = synth.make_sequence(T, H, W, seed=12)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    o = default_opts(n_iters=3, refine=1)                               # pose + log depth scale: the scale array is permuted back too
+    e = Engine(H, W, 16, lanes=lanes)
+    K = t(seq["K"][None]).cuda()
+    plain, plain_ls = [], []
+    for w in range(T - 1):
+        p, ls, _ = e.refine_window(t(seq["frames"][w:w + 1]).cuda(), t(seq["frames"][w + 1:w + 2])[None].cuda(), t(seq["depths"][w:w + 1]).cuda(),
+                                   t(seq["depths"][w + 1:w + 2])[None].cuda(), K, t(seq["init"][w]).cuda(), o)
+        plain.append(p.cpu()); plain_ls.append(ls.cpu())
+    out, ls = e.refine_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], seq["init"], o, ring=ring,
+                                windows_per_call=wpc, log_scale=True)
+    assert torch.equal(out, torch.stack(plain)) and torch.equal(ls, torch.stack(plain_ls))

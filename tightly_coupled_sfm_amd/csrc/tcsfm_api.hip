@@ -64,7 +64,7 @@ struct tcsfm_ctx {
     size_t mark_next = 0;
     // tcsfm_refine_sequence: device ring of frames, copy stream, per-slot / per-window events, pose staging (allocated on first use)
     float *seq_img = nullptr, *seq_depth = nullptr, *seq_pose_in = nullptr, *seq_pose_out = nullptr, *seq_ls_out = nullptr, *seq_K = nullptr;
-    int seq_slots = 0;                 // ring slots + S mirror slots allocated
+    int seq_slots = 0, seq_K_n = 0;    // ring slots + mirror slots allocated; copies of K held by seq_K
     size_t seq_pose_cap = 0;           // windows x pairs the pose staging holds
     hipStream_t seq_copy = nullptr;
     std::vector<hipEvent_t> seq_copied, seq_done;
@@ -1083,42 +1083,52 @@ static int pose_loop(tcsfm_ctx *h, tcsfm_posenet *pn, int num_iter, int B, int S
                      const float *depth_s, const float *K, float *poses_out, float *stacked_out);
 static tcsfm_posenet *pn_for_lane(tcsfm_posenet *pn, tcsfm_ctx *c);
 static bool pn_usable(const tcsfm_posenet *pn, const tcsfm_ctx *h, int images);
+static int pn_max_images(const tcsfm_posenet *pn);
 
 // The reference's sequential driver (run_sequential_optimization.py:186-247) as ONE call: see include/tcsfm.h.  With `pn` the initial
 // poses of every window come from the coupled PoseNet loop (train_mono.py:64-80) on the window's lane instead of from the caller.
 static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
                          const float *pose_init, tcsfm_posenet *pn, int num_iter, float *pose_init_out, float *pose_out,
-                         float *log_scale_out, int ring) {
+                         float *log_scale_out, int ring, int windows_per_call) {
     if (!h) return TCSFM_E_ARG;
     if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
     const int N = 2 * S, L = (int)h->lanes.size() + 1;
     if (S < 1 || T <= S || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: need S >= 1, T > S and 2*S <= max_pairs");
     if (!frames || !depths || !K || (!pose_init && !pn) || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
+    if (windows_per_call < 0) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: windows_per_call < 0");
     if (pn && (num_iter < 1 || !pn_usable(pn, h, N) || o_in->depth_is_disp))
         return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: needs a loaded PoseNet of this handle with max_images >= 2*S, num_iter >= 1 and depths (not disparities)");
     tcsfm_opts o = *o_in;
     o.host_ptrs = 0;                                   // the lanes work on the device ring; this call does the staging itself
-    int rc = check_common(h, &o, N);
+    const int nwin = T - S;
+    // Windows per call: consecutive windows are independent, and with ONE source per window the targets (frames w ..) and the
+    // sources (frames w+1 ..) of WB consecutive windows are two contiguous runs of the ring -- exactly the window form's [B] / [S,B]
+    // layout -- so a lane refines WB windows per call: the kernels fill the chip (26 200 windows/s per call at WB = 8 against 13 900
+    // at WB = 1) and the PoseNet runs on 2 WB images at a third of the time per image.  With more sources the runs overlap: WB = 1.
+    int WB = S == 1 ? (windows_per_call > 0 ? windows_per_call : 8) : 1;
+    WB = std::min(WB, std::min(h->max_pairs / N, nwin));
+    if (pn) WB = std::min(WB, pn_max_images(pn) / N);
+    int rc = check_common(h, &o, N * WB);
     if (rc) return rc;
     if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || !(K[0] != 0.f) || !(K[4] != 0.f))
         return fail(h, TCSFM_E_INTRINSICS, "intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1]");
     DeviceGuard dev_guard(h->device);
     if (int rc_ = pending_error(h)) return rc_;
-    const int nwin = T - S;
     // frames go up in chunks of C (one copy for the images, one for the depths: PCIe runs at 55 GB/s on 8-frame copies, at 36 GB/s
     // on single frames, and the host issues a quarter of the calls); the ring holds a whole number of chunks
-    const int C = ring > 0 ? (ring >= S + 8 ? 4 : 1) : 4;
-    const int R = ring > 0 ? (ring / C) * C : 32 + ((S + C - 1) / C) * C;     // frames resident at once (measured: 16 -> 32 slots is +13 % at 3 lanes)
-    if (R < S + 2 || R < S + C) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: ring must hold at least S + 2 frames");
+    const int C = ring > 0 ? (ring >= WB + S + 8 ? 4 : 1) : 4;
+    const int R = ring > 0 ? (ring / C) * C : ((32 + (L + 1) * WB + S + C - 1) / C) * C;     // frames resident at once
+    const int M = WB + S - 1;                              // mirror slots behind the ring: the WB + S frames of a call never wrap
+    if (R < S + 2 || R < WB + S + C) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: ring must hold at least windows_per_call + S + 4 frames (S + 2 for one window per call)");
     const size_t hw = (size_t)h->H * h->W;
-    // ---- scratch: ring (+ S mirror slots so that the S+1 frames of a window are always contiguous), events, pose staging
-    if (h->seq_slots < R + S) {
+    // ---- scratch: ring + mirror slots, events, pose staging, WB copies of K
+    if (h->seq_slots < R + M) {
         if (h->seq_img) HIPCHK(h, hipFree(h->seq_img));
         if (h->seq_depth) HIPCHK(h, hipFree(h->seq_depth));
         h->seq_img = h->seq_depth = nullptr; h->seq_slots = 0;
-        HIPCHK(h, hipMalloc(&h->seq_img, (size_t)(R + S) * 3 * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc(&h->seq_depth, (size_t)(R + S) * hw * sizeof(float)));
-        h->seq_slots = R + S;
+        HIPCHK(h, hipMalloc(&h->seq_img, (size_t)(R + M) * 3 * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc(&h->seq_depth, (size_t)(R + M) * hw * sizeof(float)));
+        h->seq_slots = R + M;
     }
     if (h->seq_pose_cap < (size_t)nwin * N) {
         for (float **q : {&h->seq_pose_in, &h->seq_pose_out, &h->seq_ls_out})
@@ -1129,21 +1139,45 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         HIPCHK(h, hipMalloc(&h->seq_ls_out, (size_t)nwin * N * sizeof(float)));
         h->seq_pose_cap = (size_t)nwin * N;
     }
-    if (!h->seq_K) HIPCHK(h, hipMalloc(&h->seq_K, 9 * sizeof(float)));
+    if (h->seq_K_n < WB) {
+        if (h->seq_K) HIPCHK(h, hipFree(h->seq_K));
+        h->seq_K = nullptr; h->seq_K_n = 0;
+        HIPCHK(h, hipMalloc(&h->seq_K, (size_t)WB * 9 * sizeof(float)));
+        h->seq_K_n = WB;
+    }
     if (!h->seq_copy) {   // high priority: a hardware queue outside the pool the normal-priority streams share (a copy stream that lands in
         int lo = 0, hi = 0;   // a lane's queue parks its slot-recycling waits in front of that lane's kernels), and copies go first anyway
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(h, hipStreamCreateWithPriority(&h->seq_copy, hipStreamNonBlocking, hi));
     }
-    const size_t n_done = (size_t)2 * R + 2;               // a window's event is re-recorded long after its slots were recycled
+    const size_t n_done = (size_t)2 * R + 2;               // a call's event is re-recorded long after its slots were recycled
+    const size_t ND = n_done - 1;
     while (h->seq_copied.size() < (size_t)R) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_copied.push_back(e); }
     while (h->seq_done.size() < n_done) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_done.push_back(e); }
+    // Poses live on the device per CALL in the stacked order of the window form (forward pairs (s, b), then inverse pairs); the
+    // caller's arrays are per window.  at(): offset (in pairs) of pair j of window w inside the staging arrays.
+    auto at = [&](int w, int j) -> size_t {
+        const int c0 = (w / WB) * WB, nbw = std::min(WB, nwin - c0), b = w - c0;
+        return (size_t)c0 * N + (j < S ? (size_t)j * nbw + b : (size_t)S * nbw + (size_t)(j - S) * nbw + b);
+    };
     // ---- small inputs: one copy each, on the copy stream; every lane waits for them once
     hipStream_t cs = h->seq_copy;
-    HIPCHK(h, hipMemcpyAsync(h->seq_K, K, 9 * sizeof(float), hipMemcpyHostToDevice, cs));
-    if (!pn) HIPCHK(h, hipMemcpyAsync(h->seq_pose_in, pose_init, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyHostToDevice, cs));
+    std::vector<float> Kh((size_t)WB * 9), stage;
+    for (int b = 0; b < WB; b++) memcpy(&Kh[(size_t)b * 9], K, 9 * sizeof(float));
+    HIPCHK(h, hipMemcpyAsync(h->seq_K, Kh.data(), Kh.size() * sizeof(float), hipMemcpyHostToDevice, cs));
+    if (!pn) {
+        const float *src = pose_init;
+        if (WB > 1) {
+            stage.resize((size_t)nwin * N * 6);
+            for (int w = 0; w < nwin; w++)
+                for (int j = 0; j < N; j++) memcpy(&stage[at(w, j) * 6], pose_init + ((size_t)w * N + j) * 6, 6 * sizeof(float));
+            src = stage.data();
+        }
+        HIPCHK(h, hipMemcpyAsync(h->seq_pose_in, src, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyHostToDevice, cs));
+    }
     hipEvent_t small_ev = h->seq_done[n_done - 1];
     HIPCHK(h, hipEventRecord(small_ev, cs));
+    HIPCHK(h, hipEventSynchronize(small_ev));              // Kh / stage are host temporaries (pageable): gone from here on
     std::vector<tcsfm_ctx *> lane(L);
     std::vector<tcsfm_posenet *> net(L, nullptr);
     std::vector<hipStream_t> ls(L);
@@ -1152,50 +1186,51 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         if (pn && !(net[l] = pn_for_lane(pn, lane[l]))) return fail(h, TCSFM_E_NOMEM, "tcsfm_odometry_sequence: no memory for a lane's PoseNet activations");
         ls[l] = l == 0 ? h->stream : lane[l]->own_stream;
         lane[l]->stream = ls[l];
-        HIPCHK(h, hipStreamWaitEvent(ls[l], small_ev, 0));
-        lane[l]->K_checked = h->seq_K; lane[l]->K_checked_n = 1;     // validated on the host above
+        lane[l]->K_checked = h->seq_K; lane[l]->K_checked_n = WB;    // validated on the host above
     }
-    std::vector<long long> slot_reader(R, -1);             // last window that reads the frame in this slot (-1: none pending)
+    std::vector<long long> slot_reader(R, -1);             // last CALL that reads the frame in this slot (-1: none pending)
     const int np = np_of(&o);
-    const int ahead = S + L + C;                           // frames kept in flight ahead of the window being issued
-    int nxt = 0;                                           // first frame of the next chunk to upload
-    const int depth = 16;
-    for (int w = 0; w < nwin; w++) {
-        // the host stays at most `depth` windows ahead of the GPU: a deeper backlog buys nothing, and with one the runtime was seen to
+    const int ahead = S + L * WB + C;                      // frames kept in flight ahead of the first window of the call being issued
+    const long long depth = std::max(2 * L, 16 / WB);      // calls the host may run ahead of the GPU
+    int nxt = 0;                                           // first frame of the next copy chunk
+    long long ci = 0;                                      // call index
+    for (int c0 = 0; c0 < nwin; c0 += WB, ci++) {
+        const int nbw = std::min(WB, nwin - c0);
+        // the host stays a bounded number of calls ahead of the GPU: a deeper backlog buys nothing, and with one the runtime was seen to
         // block a single hipMemcpyAsync of the copy stream for 7 ms while the lanes ran dry behind it
-        if (w >= depth) HIPCHK(h, hipEventSynchronize(h->seq_done[(w - depth) % (n_done - 1)]));
-        // a chunk may go up once every window that reads the frames it overwrites has been ISSUED (their events exist): nxt - R + C - 1 < w
-        while (nxt < T && nxt <= w + ahead && nxt + C - 1 - R < w) {
+        if (ci >= depth) HIPCHK(h, hipEventSynchronize(h->seq_done[(ci - depth) % ND]));
+        // a chunk may go up once every window that reads the frames it overwrites has been ISSUED (their events exist): nxt - R + C - 1 < c0
+        while (nxt < T && nxt <= c0 + nbw - 1 + ahead && nxt + C - 1 - R < c0) {
             const int slot = nxt % R, nf = T - nxt < C ? T - nxt : C;
             long long last = -1;                           // the slots' previous frames may still be read: the copy waits for their readers --
             for (int k = 0; k < nf; k++) { if (slot_reader[slot + k] > last) last = slot_reader[slot + k]; slot_reader[slot + k] = -1; }
-            for (long long r = last; r >= 0 && r > last - L; r--)     // -- the latest of them on every lane (a lane's stream is in order)
-                HIPCHK(h, hipStreamWaitEvent(cs, h->seq_done[r % (n_done - 1)], 0));
+            for (long long r = last; r >= 0 && r > last - L; r--)     // -- the latest of those calls on every lane (a lane's stream is in order)
+                HIPCHK(h, hipStreamWaitEvent(cs, h->seq_done[r % ND], 0));
             HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)slot * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nf * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
             HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)slot * hw, depths + (size_t)nxt * hw, (size_t)nf * hw * sizeof(float), hipMemcpyHostToDevice, cs));
-            if (slot < S) {                                // mirror of the first S slots behind the ring: the frames of a window never wrap
-                const int nm = nf < S - slot ? nf : S - slot;
+            if (slot < M) {                                // mirror of the first M slots behind the ring: the frames of a call never wrap
+                const int nm = nf < M - slot ? nf : M - slot;
                 HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)(R + slot) * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nm * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
                 HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)(R + slot) * hw, depths + (size_t)nxt * hw, (size_t)nm * hw * sizeof(float), hipMemcpyHostToDevice, cs));
             }
             HIPCHK(h, hipEventRecord(h->seq_copied[slot / C], cs));
             nxt += nf;
         }
-        const int l = w % L, s0 = w % R;
-        for (int k = w / C; k <= (w + S) / C; k++) HIPCHK(h, hipStreamWaitEvent(ls[l], h->seq_copied[(k * C % R) / C], 0));
+        const int l = (int)(ci % L), s0 = c0 % R;
+        for (int k = c0 / C; k <= (c0 + nbw - 1 + S) / C; k++) HIPCHK(h, hipStreamWaitEvent(ls[l], h->seq_copied[(k * C % R) / C], 0));
         tcsfm_ctx *c = lane[l];
-        if (pn) {           // initial poses of this window: PoseNet -> warp -> PoseNet correction, num_iter times, on the lane
-            rc = pose_loop(c, net[l], num_iter, 1, S, h->seq_img + (size_t)s0 * 3 * hw, h->seq_img + (size_t)(s0 + 1) * 3 * hw,
-                           h->seq_depth + (size_t)s0 * hw, h->seq_depth + (size_t)(s0 + 1) * hw, h->seq_K, h->seq_pose_in + (size_t)w * N * 6, nullptr);
+        const float *tg = h->seq_img + (size_t)s0 * 3 * hw, *sr = h->seq_img + (size_t)(s0 + 1) * 3 * hw;
+        const float *dt = h->seq_depth + (size_t)s0 * hw, *ds = h->seq_depth + (size_t)(s0 + 1) * hw;
+        float *p_in = h->seq_pose_in + (size_t)c0 * N * 6, *p_out = h->seq_pose_out + (size_t)c0 * N * 6;
+        if (pn) {           // initial poses of these windows: PoseNet -> warp -> PoseNet correction, num_iter times, on the lane
+            rc = pose_loop(c, net[l], num_iter, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr);
             if (rc) { if (c != h) h->err = c->err; break; }
         }
-        rc = refine_impl(c, &o, N, 1, S, h->seq_img + (size_t)s0 * 3 * hw, h->seq_img + (size_t)(s0 + 1) * 3 * hw, h->seq_depth + (size_t)s0 * hw,
-                         h->seq_depth + (size_t)(s0 + 1) * hw, h->seq_K, h->seq_pose_in + (size_t)w * N * 6, nullptr,
-                         h->seq_pose_out + (size_t)w * N * 6, np == 7 ? h->seq_ls_out + (size_t)w * N : nullptr, nullptr);
+        rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
+                         np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr);
         if (rc) { if (c != h) h->err = c->err; break; }
-        hipEvent_t done = h->seq_done[w % (n_done - 1)];
-        HIPCHK(h, hipEventRecord(done, ls[l]));
-        for (int k = 0; k <= S; k++) slot_reader[(w + k) % R] = w;
+        HIPCHK(h, hipEventRecord(h->seq_done[ci % ND], ls[l]));
+        for (int k = 0; k < nbw + S; k++) slot_reader[(c0 + k) % R] = ci;
     }
     // ---- drain: every lane, then the results in one copy each
     for (int l = 0; l < L; l++) {
@@ -1206,22 +1241,31 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
     if (rc) return rc;
     for (int l = 0; l < L; l++)
         if (int rc_ = pending_error(lane[l])) { if (lane[l] != h) h->err = lane[l]->err; return rc_; }
-    HIPCHK(h, hipMemcpy(pose_out, h->seq_pose_out, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyDeviceToHost));
-    if (pose_init_out) HIPCHK(h, hipMemcpy(pose_init_out, h->seq_pose_in, (size_t)nwin * N * 6 * sizeof(float), hipMemcpyDeviceToHost));
-    if (log_scale_out && np == 7) HIPCHK(h, hipMemcpy(log_scale_out, h->seq_ls_out, (size_t)nwin * N * sizeof(float), hipMemcpyDeviceToHost));
+    auto fetch = [&](float *dst, const float *dev, int per_pair) -> int {     // device (per call, stacked) -> caller (per window)
+        if (WB == 1) { HIPCHK(h, hipMemcpy(dst, dev, (size_t)nwin * N * per_pair * sizeof(float), hipMemcpyDeviceToHost)); return TCSFM_OK; }
+        stage.resize((size_t)nwin * N * per_pair);
+        HIPCHK(h, hipMemcpy(stage.data(), dev, stage.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int w = 0; w < nwin; w++)
+            for (int j = 0; j < N; j++) memcpy(dst + ((size_t)w * N + j) * per_pair, &stage[at(w, j) * per_pair], per_pair * sizeof(float));
+        return TCSFM_OK;
+    };
+    if ((rc = fetch(pose_out, h->seq_pose_out, 6))) return rc;
+    if (pose_init_out && (rc = fetch(pose_init_out, h->seq_pose_in, 6))) return rc;
+    if (log_scale_out && np == 7 && (rc = fetch(log_scale_out, h->seq_ls_out, 1))) return rc;
     return TCSFM_OK;
 }
 
 int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
-                          const float *pose_init, float *pose_out, float *log_scale_out, int ring) {
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call) {
     if (h && !pose_init) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
-    return sequence_impl(h, o, T, S, frames, depths, K, pose_init, nullptr, 0, nullptr, pose_out, log_scale_out, ring);
+    return sequence_impl(h, o, T, S, frames, depths, K, pose_init, nullptr, 0, nullptr, pose_out, log_scale_out, ring, windows_per_call);
 }
 
 int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
-                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring) {
+                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring,
+                            int windows_per_call) {
     if (h && !pn) return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: NULL PoseNet");
-    return sequence_impl(h, o, T, S, frames, depths, K, nullptr, pn, num_iter, pose_init_out, pose_out, log_scale_out, ring);
+    return sequence_impl(h, o, T, S, frames, depths, K, nullptr, pn, num_iter, pose_init_out, pose_out, log_scale_out, ring, windows_per_call);
 }
 
 int tcsfm_lane_wait(tcsfm_handle h, int lane) {
@@ -1410,6 +1454,7 @@ static tcsfm_posenet *pn_for_lane(tcsfm_posenet *pn, tcsfm_ctx *c) {
 }
 
 static bool pn_usable(const tcsfm_posenet *pn, const tcsfm_ctx *h, int images) { return pn && pn->h == h && pn->loaded && images <= pn->max_images; }
+static int pn_max_images(const tcsfm_posenet *pn) { return pn->max_images; }
 
 int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out) {
     if (!h || !out) return TCSFM_E_ARG;
