@@ -52,7 +52,8 @@ while time.time() - t0 < SECONDS:
     elif kind == 2:    # a whole sequence in one call, random ring
         ring = int(rng.choice([0, 3, 5, 12, 20]))
         n0 = int(rng.integers(0, 10)); n1 = int(rng.integers(n0 + 6, T))
-        out = e.refine_sequence(frames[n0:n1], depths[n0:n1], seq["K"], init[n0:n1 - 1], o, ring=ring)
+        wpc = 1 if ring == 3 else int(rng.choice([0, 1, 2]))              # the handle holds 4 pairs: up to 2 windows per call
+        out = e.refine_sequence(frames[n0:n1], depths[n0:n1], seq["K"], init[n0:n1 - 1], o, ring=ring, windows_per_call=wpc)
         for w in range(n0, n1 - 1):
             check(("pose", w), [out[w - n0].cuda()])
     else:              # plain synchronous call on the handle itself
