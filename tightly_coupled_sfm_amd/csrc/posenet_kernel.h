@@ -236,20 +236,23 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
 // ---------------------------------------------------------------------------------------------------------------
 // First layer (6 -> 16 channels, 7x7, stride 2) with the input patch staged in LDS.  In the generic form every lane fetched its
 // 4 x 21 input values with bounds-checked scalar loads from global memory and each value was fetched ~12 times per workgroup: the
-// layer cost 24 us whatever the matrix cores did.  Here a workgroup owns 64 consecutive output pixels of ONE output row: the
-// 7 input rows x 134 columns x 6 channels behind them are loaded once, coalesced, normalised ((x - 0.45) / 0.22, zero outside the
-// image -- the padding of the NORMALISED image, pose_models.py:125) into LDS; the 21 weight float4 of a lane are loaded up front;
-// the K loop then runs on LDS reads and MFMAs only.  Same K order and the same arithmetic per output as k_pn_conv<1, true>.
-// grid = (OH * ceil(OW / 64), 1, N); GroupNorm partial sums per workgroup as in k_pn_conv (tiles = gridDim.x).
+// layer cost 24 us whatever the matrix cores did.  Here a workgroup owns 64 consecutive output pixels of TWO output rows: the
+// 9 input rows x 134 columns x 6 channels behind them are loaded once, coalesced, normalised ((x - 0.45) / 0.22, zero outside the
+// image -- the padding of the NORMALISED image, pose_models.py:125) into LDS; the 21 weight float4 of a lane are loaded up front and
+// serve both rows (two independent accumulator chains per wave); the K loop runs on LDS reads and MFMAs only.  Same K order and
+// the same arithmetic per output as k_pn_conv<1, true>.
+// grid = (ceil(OH / 2) * ceil(OW / 64), 1, N); GroupNorm partial sums per workgroup as in k_pn_conv (tiles = gridDim.x).
 constexpr int PN1_COLS = 136;      // 2 * 63 + 7 + 1 = 134 staged columns, padded (even: 8-byte aligned pairs)
+constexpr int PN1_ROWS = 9;        // two output rows per workgroup: input rows 2 oy0 - 3 .. 2 oy0 + 5
 __global__ __launch_bounds__(256) void k_pn_conv1(PnConvParams P) {
     const PnLayer &L = P.L;
-    __shared__ __attribute__((aligned(16))) float patch[6 * 7 * PN1_COLS];
+    __shared__ __attribute__((aligned(16))) float patch[6 * PN1_ROWS * PN1_COLS];
     __shared__ float wsum[4][16][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int chunks = (L.ow + 63) / 64;
-    const int oy = blockIdx.x / chunks, ox0 = (blockIdx.x - oy * chunks) * 64;
+    const int oyp = blockIdx.x / chunks, ox0 = (blockIdx.x - oyp * chunks) * 64;
+    const int oy0 = 2 * oyp;                             // output rows oy0 and oy0 + 1 (the second may be past the end)
     const int n = blockIdx.z;
     const int SB = P.win_S * P.win_B;
     const float *pa, *pb;
@@ -263,18 +266,18 @@ __global__ __launch_bounds__(256) void k_pn_conv1(PnConvParams P) {
     pn_f4 b4[21];
 #pragma unroll
     for (int g = 0; g < 21; g++) b4[g] = P.w4[(size_t)(g * 4 + kq) * L.cout + m];
-    // stage the patch: rows iy = 2 oy - 3 + ky, columns ix = 2 ox0 - 3 + col
-    const int iy0 = oy * 2 - 3, ix0 = ox0 * 2 - 3;
+    // stage the patch: rows iy = 2 oy0 - 3 + row, columns ix = 2 ox0 - 3 + col
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     {   // all of a thread's loads are issued before the first is used (a rolled loop would pay one memory latency per element)
-        constexpr int NE = 6 * 7 * PN1_COLS, NL = (NE + 255) / 256;
+        constexpr int NE = 6 * PN1_ROWS * PN1_COLS, NL = (NE + 255) / 256;
         float v[NL];
         bool ok[NL];
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             const int e = tid + 256 * j;
             const int rowi = e / PN1_COLS, col = e - rowi * PN1_COLS;
-            const int ci = rowi / 7, ky = rowi - ci * 7;
-            const int iy = iy0 + ky, ix = ix0 + col;
+            const int ci = rowi / PN1_ROWS, ry = rowi - ci * PN1_ROWS;
+            const int iy = iy0 + ry, ix = ix0 + col;
             ok[j] = e < NE && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
             const float *src = (ci < 3 ? pa + (size_t)ci * hw : pb + (size_t)(ci - 3) * hw);
             v[j] = (e < NE) ? src[ok[j] ? (size_t)iy * L.iw + ix : 0] : 0.f;
@@ -288,29 +291,35 @@ __global__ __launch_bounds__(256) void k_pn_conv1(PnConvParams P) {
     }
     __syncthreads();
     const int oxl = wave * 16 + m;                       // this lane's output pixel within the chunk (A operand row)
-    pn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    pn_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // output rows oy0 / oy0 + 1: two independent MFMA chains, one set of weights
 #pragma unroll
     for (int g = 0; g < 21; g++) {
-        const int combo = 2 * g + (kq >> 1);             // (ci, ky) = row of the patch
-        const float *row = patch + combo * PN1_COLS + 2 * oxl + 4 * (kq & 1);
-        const float2 lo = *reinterpret_cast<const float2 *>(row), hi = *reinterpret_cast<const float2 *>(row + 2);
-        const pn_f4 a = {lo.x, lo.y, hi.x, hi.y};
+        const int combo = 2 * g + (kq >> 1);             // (ci, ky)
+        const int ci = combo / 7, ky = combo - ci * 7;
+        const float *row = patch + (ci * PN1_ROWS + ky) * PN1_COLS + 2 * oxl + 4 * (kq & 1);
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[g][t], acc, 0, 0, 0);
+        for (int r = 0; r < 2; r++) {
+            const float2 lo = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS), hi = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS + 2);
+            const pn_f4 a = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[g][t], acc[r], 0, 0, 0);
+        }
     }
     // C/D layout: column (output channel) = lane & 15, row (pixel) = 4 (lane >> 4) + reg
     float *out = P.out + (size_t)n * L.oh * L.ow * L.cout;
     const float bs = P.bias != nullptr ? P.bias[m] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int ox = ox0 + wave * 16 + 4 * kq + r;
-        if (ox < L.ow) {
-            const float v = acc[r] + bs;
-            out[((size_t)oy * L.ow + ox) * L.cout + m] = v;
-            s1 += v; s2 += v * v;
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ox = ox0 + wave * 16 + 4 * kq + q, oy = oy0 + r;
+            if (ox < L.ow && oy < L.oh) {
+                const float v = acc[r][q] + bs;
+                out[((size_t)oy * L.ow + ox) * L.cout + m] = v;
+                s1 += v; s2 += v * v;
+            }
         }
-    }
     s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     if (kq == 0) { wsum[wave][m][0] = s1; wsum[wave][m][1] = s2; }

@@ -1549,8 +1549,8 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
         P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = L.ksplit == 1 ? pn->part[l] : nullptr; P.L = L; P.N = N;
         dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
-        if (l == 0) {            // LDS-staged first layer: one workgroup per 64-pixel segment of an output row
-            grid = dim3(L.oh * ((L.ow + 63) / 64), 1, N);
+        if (l == 0) {            // LDS-staged first layer: one workgroup per 64-pixel segment of two output rows
+            grid = dim3(((L.oh + 1) / 2) * ((L.ow + 63) / 64), 1, N);
             hipLaunchKernelGGL(k_pn_conv1, grid, dim3(256), 0, h->stream, P);
         } else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
