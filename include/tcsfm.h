@@ -249,8 +249,10 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
                                     float *depth_out, float *stats_out);
 /* The reference's sequential driver loop as ONE call (run_sequential_optimization.py:186-247: for every window DataLoader batch ->
  * H2D in process_sample_batch, data/kitti_loader.py:60-98 -> optimize_window, strictly one window after the other).
- * Window w = (target frame w, source frames w+1 .. w+S) -> its 2*S directed pairs in the stacked order of train_mono.py:54-62
- * (forward pairs, then inverse pairs), w = 0 .. T-S-1.  All array arguments are HOST pointers here (pinned memory makes the
+ * Window w = the S + 1 consecutive frames w .. w+S, w = 0 .. T-S-1: its target is frame w + target_pos (target_pos = -1: the middle
+ * one, (S+1)/2, as the reference's loaders choose it -- data/kitti_loader.py:271-273 -- i.e. the LATER frame of a two-frame window;
+ * 0: the first), its sources are the other frames in order -> its 2*S directed pairs in the stacked order of train_mono.py:54-62
+ * (forward pairs, then inverse pairs).  All array arguments are HOST pointers here (pinned memory makes the
  * copies asynchronous; pageable memory works, slower), whatever opts.host_ptrs says:
  *   frames [T,3,H,W], depths [T,1,H,W] (or disparities, opts.depth_is_disp), K [3,3] (one camera for the sequence),
  *   pose_init / pose_out [T-S, 2*S, 6], log_scale_out [T-S, 2*S] or NULL (TCSFM_REFINE_POSE_SCALE; the scale starts at 0).
@@ -258,12 +260,12 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  * frames (0 = default; at least windows_per_call + S + 4, or S + 2 with one window per call and single-frame copies); the calls are
  * issued round robin on the handle's lanes (tcsfm_set_lanes; 2-3 lanes: the GPU runs four hardware queues at once and the copy
  * stream is one of them) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
- * finished.  windows_per_call (0 = default 8, capped by max_pairs / (2 S)): with S = 1 the targets and the sources of consecutive
- * windows are contiguous runs of the ring, so one call refines that many windows at once (the kernels fill the chip); with S > 1
- * every call is one window.  The call returns when all windows are done (it synchronises).  Results are bit-identical to one
- * tcsfm_refine_window call per window, whatever the lanes, the ring and windows_per_call. */
+ * finished.  windows_per_call (0 = default 8, capped by max_pairs / (2 S)): the targets and every source of consecutive windows
+ * are runs of the ring, so one call refines that many windows at once (the kernels fill the chip).  The call returns when all
+ * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window, whatever the lanes,
+ * the ring and windows_per_call. */
 int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
-                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call);
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call, int target_pos);
 /* The same loop with the reference's pose initialisation inside it: for every window the coupled PoseNet loop of
  * train_mono.py:64-80 (tcsfm_solve_pose_iteratively, `num_iter` network evaluations: config['iterations'], 4 in the reference's
  * scripts) produces the initial poses on the window's lane, then the window is refined -- what optimize_window does per window
@@ -274,7 +276,7 @@ int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, con
  * work split -- hence its rounding -- depends on the number of images, see tcsfm_posenet_forward: per-window calls agree to 1e-5). */
 int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
                             const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring,
-                            int windows_per_call);
+                            int windows_per_call, int target_pos);
 int tcsfm_lane_wait(tcsfm_handle h, int lane);
 int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
 int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);

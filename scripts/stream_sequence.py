@@ -107,6 +107,19 @@ for lanes, wpc in ((1, 1), (2, 1), (3, 1), (1, 8), (2, 8), (3, 8), (2, 16)):
                       "refined_poses_max_rel_diff": float((out_o - ref_o.cpu()).abs().max() / ref_o.abs().max()),
                       "note": "the PoseNet's work split (hence its rounding, ~1e-6) depends on the number of images per call; the coupled loop has discrete decisions (warp validity), so with these RANDOM weights a few windows (3 of 199) amplify it to 1e-5..1e-2 -- all others agree to ~1e-6"}), flush=True)
     net.close(); e.close()
+# (e) the reference's KITTI windows: 3 frames, target in the middle, sources = previous and next frame (S = 2, 4 directed pairs, min over
+#     the sources, depth consistency), PoseNet loop + refinement
+o2 = default_opts(n_iters=4, argmin=1, w_dc=0.15)
+for lanes, wpc in ((1, 1), (2, 1), (3, 1), (1, 4), (2, 4), (2, 8)):
+    e = Engine(H, W, 4 * wpc, lanes=lanes)
+    net = PoseNetHIP(e, 4 * wpc, params)
+    net.odometry_sequence(frames[:40], depths[:40], K, o2, sources=2, iterations=4, windows_per_call=wpc, target_pos=-1)
+    ts = []
+    for rep in range(5):
+        t0 = time.perf_counter(); net.odometry_sequence(frames, depths, K, o2, sources=2, iterations=4, windows_per_call=wpc, target_pos=-1); ts.append(time.perf_counter() - t0)
+    print(json.dumps({"path": f"tcsfm_odometry_sequence, KITTI windows (S = 2, target in the middle, min over sources, depth consistency), {lanes} lane(s), {wpc} window(s) per call",
+                      "windows_per_s": round((T - 2) / sorted(ts)[2], 1), "us_per_window": round(sorted(ts)[2] / (T - 2) * 1e6, 1)}), flush=True)
+    net.close(); e.close()
 # the same windows from DEVICE-resident frames (no PCIe in the loop): what the lanes alone buy at B=1
 dev_f, dev_d = frames.cuda(), depths.cuda()
 Kd = torch.as_tensor(K[None]).cuda(); p0 = torch.as_tensor(init).cuda(); outd = torch.empty_like(p0)

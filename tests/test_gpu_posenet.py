@@ -140,7 +140,7 @@ def test_posenet_from_a_reference_style_checkpoint(tmp_path):
     assert np.max(np.abs(pose - g["a_pose"])) < 1e-5 * np.abs(g["a_pose"]).max()
 
 
-@pytest.mark.parametrize("S,lanes,wpc", [(1, 1, 1), (1, 3, 1), (2, 2, 0), (1, 2, 2), (1, 2, 5)])
+@pytest.mark.parametrize("S,lanes,wpc", [(1, 1, 1), (1, 3, 1), (2, 2, 1), (1, 2, 2), (1, 2, 5)])
 def test_odometry_sequence_matches_per_window_calls(S, lanes, wpc):
     """tcsfm_odometry_sequence (per window: coupled PoseNet loop -> refinement, windows on the lanes, frames streamed once): the
     PoseNet poses and the refined poses equal, bit for bit, one solve_pose_iteratively + one refine_window call per window"""
@@ -151,7 +151,7 @@ def test_odometry_sequence_matches_per_window_calls(S, lanes, wpc):
     H, W, T, IT = 48, 160, 12, 3
     seq = synth.make_sequence(T, H, W, seed=6)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
-    WB = max(1, wpc) if S == 1 else 1
+    WB = max(1, wpc)
     e = Engine(H, W, 2 * S * WB, lanes=lanes)
     net = PoseNetHIP(e, 2 * S * WB, standins.posenet_params(5))
     o = default_opts(n_iters=3, argmin=1)
@@ -175,3 +175,32 @@ def test_odometry_sequence_matches_per_window_calls(S, lanes, wpc):
         i1, o1 = net.odometry_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], o, sources=S, iterations=IT,
                                        windows_per_call=1)
         assert float((i1 - init).abs().max()) < 1e-5 * float(init.abs().max())
+
+
+def test_odometry_sequence_with_centred_windows_of_three_frames():
+    """the reference's KITTI windows (3 frames, target in the middle, sources = previous and next frame) through
+    tcsfm_odometry_sequence, two windows per call: equal to solve_pose_iteratively + refine_window on the hand-gathered batches"""
+    import standins
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+    H, W, T, IT, S, WB = 48, 160, 11, 3, 2, 2
+    seq = synth.make_sequence(T, H, W, seed=8)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    e = Engine(H, W, 2 * S * WB, lanes=2)
+    net = PoseNetHIP(e, 2 * S * WB, standins.posenet_params(5))
+    o = default_opts(n_iters=3, argmin=1)
+    ref_init, ref_out = [], []
+    for c0 in range(0, T - S, WB):
+        nb = min(WB, T - S - c0)
+        K = t(np.repeat(seq["K"][None], nb, 0)).cuda()
+        tg, dt_ = t(seq["frames"][c0 + 1:c0 + 1 + nb]).cuda(), t(seq["depths"][c0 + 1:c0 + 1 + nb]).cuda()
+        sr = torch.stack([t(seq["frames"][c0 + p:c0 + p + nb]) for p in (0, 2)]).cuda()
+        ds_ = torch.stack([t(seq["depths"][c0 + p:c0 + p + nb]) for p in (0, 2)]).cuda()
+        p0, _ = net.solve_pose_iteratively(IT, tg, sr, dt_, ds_, K)
+        pr = e.refine_window(tg, sr, dt_, ds_, K, p0, o)[0]
+        idx = [[s * nb + b for s in range(S)] + [S * nb + s * nb + b for s in range(S)] for b in range(nb)]
+        ref_init += [p0[i].cpu() for i in idx]; ref_out += [pr[i].cpu() for i in idx]
+    init, out = net.odometry_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], o, sources=S, iterations=IT,
+                                      windows_per_call=WB, target_pos=-1)
+    assert torch.equal(init, torch.stack(ref_init)) and torch.equal(out, torch.stack(ref_out))

@@ -195,3 +195,34 @@ def test_sequence_loop_with_several_windows_per_call(wpc, lanes, ring):
     out, ls = e.refine_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], seq["init"], o, ring=ring,
                                 windows_per_call=wpc, log_scale=True)
     assert torch.equal(out, torch.stack(plain)) and torch.equal(ls, torch.stack(plain_ls))
+
+
+@pytest.mark.parametrize("S,tp,wpc,lanes,ring", [(2, -1, 4, 2, 0), (2, -1, 1, 3, 5), (1, -1, 8, 2, 0), (3, 2, 2, 2, 12), (2, 0, 4, 1, 16), (2, 2, 3, 2, 0)])
+def test_sequence_windows_with_the_target_anywhere(S, tp, wpc, lanes, ring):
+    """Windows as the reference's loaders form them (data/kitti_loader.py:271-273: S + 1 consecutive frames, the target is the middle
+    one -- target_pos = -1 -- and the sources are the others in order), or with the target at any position; several windows per call
+    for any number of sources (the targets and every source of consecutive windows are runs of the frame ring, addressed by
+    position).  Bit-identical to one refine_window call per window with the frames gathered by hand."""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W, T = 48, 160, 21
+    seq = synth.make_sequence(T, H, W, seed=14)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    nwin = T - S
+    tpos = (S + 1) // 2 if tp < 0 else tp
+    src_pos = [k for k in range(S + 1) if k != tpos]
+    step = seq["init"][:, 0]                                            # PoseNet-quality pose of frame k -> k+1
+    def chain(a, b):                                                    # rough start for frame a -> frame b: sum of the steps (sign by direction)
+        return sum(step[k] for k in range(a, b)) if b > a else -sum(step[k] for k in range(b, a))
+    init = np.stack([np.stack([chain(w + tpos, w + p) for p in src_pos] + [chain(w + p, w + tpos) for p in src_pos]) for w in range(nwin)]).astype(np.float32)
+    o = default_opts(n_iters=3, argmin=1, w_dc=0.15)
+    e = Engine(H, W, 2 * S * max(wpc, 1), lanes=lanes)
+    K = t(seq["K"][None]).cuda()
+    plain = []
+    for w in range(nwin):
+        srcs = torch.stack([t(seq["frames"][w + p]) for p in src_pos])[:, None].cuda(); ds = torch.stack([t(seq["depths"][w + p]) for p in src_pos])[:, None].cuda()
+        plain.append(e.refine_window(t(seq["frames"][w + tpos][None]).cuda(), srcs, t(seq["depths"][w + tpos][None]).cuda(), ds, K, t(init[w]).cuda(), o)[0].cpu())
+    out = e.refine_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], init, o, sources=S, ring=ring,
+                            windows_per_call=wpc, target_pos=tp)
+    assert torch.equal(out, torch.stack(plain))
+    assert not torch.equal(out, t(init))

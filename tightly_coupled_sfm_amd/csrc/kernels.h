@@ -308,6 +308,16 @@ __global__ void k_init(InitParams P) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_pack
+// Window form with explicit source positions: source (s, b) is image win_off.off[s] + b of the `src` / `depth_s` arrays instead of the
+// standard s B + b.  The sequence calls use it: the targets and every source of consecutive windows are runs of ONE frame ring
+// (target = frame w + t0, source s = frame w + off[s]), so B windows with any number of sources are refined by pointer.
+constexpr int TC_MAX_SRC_OFF = 8;
+struct WinOff {
+    int on;                       // 0: standard layout
+    int off[TC_MAX_SRC_OFF];
+};
+__device__ __forceinline__ int win_src_image(const WinOff &w, int q, int B) { return w.on ? w.off[q / B] + (q - (q / B) * B) : q; }
+
 struct PackParams {
     const float *tgt, *src, *depth_t, *depth_s;  // planar inputs [N,3,H,W] / [N,1,H,W]
     float4 *tgtpack, *srcpack;
@@ -322,6 +332,7 @@ struct PackParams {
     // the stacked order of train_mono.py:54-62 -- n = s B + b forward (tgt b <- src s), S B + s B + b inverse -- are formed
     // here by indexing, the caller never materialises the repeated / concatenated tensors
     int win_B, win_S;
+    WinOff win_off;
 };
 
 // (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory.
@@ -367,9 +378,9 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
     const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
     if (P.win_B > 0) {
-        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
-        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)q * 3 * hw;
-        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)q * hw;
+        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, qi = win_src_image(P.win_off, q, P.win_B);
+        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)qi * 3 * hw;
+        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)qi * hw;
         t = inv ? si : ti; s = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
     }
     float ae = photo_err_planar(t, s, P.H, P.W, u, v, P.wl, P.ws);
@@ -463,6 +474,7 @@ struct WarpParams {
     float *posenet_in;  // optional [N,6,H,W]: (tgt * valid, img_rec) = the next PoseNet input of solve_pose_iteratively
     int H, W;           //                     (train_mono.py:74-76), written by the warp itself: no extra HBM round trip
     int win_B, win_S;   // window form (win_B > 0): tgt [B,3,H,W], src [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W]; pair n as in k_pack
+    WinOff win_off;
 };
 
 __device__ __forceinline__ float tap1(const float *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob) {
@@ -488,9 +500,9 @@ __global__ __launch_bounds__(256) void k_warp(WarpParams P) {
     const float *tgt = P.tgt ? P.tgt + (size_t)n * 3 * hw : nullptr, *src = P.src + (size_t)n * 3 * hw;
     const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
     if (P.win_B > 0) {   // the directed pairs of a window, formed by indexing (train_mono.py:54-62)
-        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
-        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)q * 3 * hw;
-        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)q * hw;
+        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, qi = win_src_image(P.win_off, q, P.win_B);
+        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)qi * 3 * hw;
+        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)qi * hw;
         tgt = inv ? si : ti; src = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
     }
     Geo g;

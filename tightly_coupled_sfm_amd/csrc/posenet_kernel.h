@@ -87,6 +87,7 @@ struct PnConvParams {
     const float *imgA, *imgB;     // [*,3,IH,IW] planar
     long long strideA, strideB;   // floats between consecutive samples
     int win_B, win_S;
+    WinOff win_off;
     // generic layers: NHWC raw convolution output of the previous layer + its per-sample, per-channel GroupNorm scale / shift
     const float *in;              // [N][IH][IW][CIN]
     const float *scsh;            // [N][CIN][2]  (scale, shift): a = relu(x * scale + shift)
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
         const float *pa, *pb;
         if (P.win_B > 0) {
             const int inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
-            const float *t = P.imgA + (size_t)b * P.strideA, *s = P.imgB + (size_t)q * P.strideB;
+            const float *t = P.imgA + (size_t)b * P.strideA, *s = P.imgB + (size_t)win_src_image(P.win_off, q, P.win_B) * P.strideB;
             pa = inv ? s : t; pb = inv ? t : s;
         } else { pa = P.imgA + (size_t)n * P.strideA; pb = P.imgB + (size_t)n * P.strideB; }
         const int hw = L.ih * L.iw;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_pn_conv1(PnConvParams P) {
     const float *pa, *pb;
     if (P.win_B > 0) {
         const int inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B;
-        const float *t = P.imgA + (size_t)b * P.strideA, *s_ = P.imgB + (size_t)q * P.strideB;
+        const float *t = P.imgA + (size_t)b * P.strideA, *s_ = P.imgB + (size_t)win_src_image(P.win_off, q, P.win_B) * P.strideB;
         pa = inv ? s_ : t; pb = inv ? t : s_;
     } else { pa = P.imgA + (size_t)n * P.strideA; pb = P.imgB + (size_t)n * P.strideB; }
     const int hw = L.ih * L.iw;

@@ -298,9 +298,10 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
 
 // init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
 int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
-             const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr) {
+             const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr, const WinOff *wo = nullptr) {
     PackParams P;
     P.depth_out2 = depth_copy;
+    if (wo) P.win_off = *wo; else P.win_off.on = 0;
     memset(&P.init, 0, sizeof(P.init));
     P.win_B = win_B; P.win_S = win_S;
     if (init) {
@@ -702,7 +703,7 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
 // shared body of tcsfm_refine (win_B == 0: one image set per pair) and tcsfm_refine_window (win_B x win_S window)
 static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
-                       float *pose_out, float *log_scale_out, float *stats_out) {
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
@@ -733,7 +734,7 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
 
     InitParams I = init_params(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0);
     I.K_mod = win_B;
-    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S))) return rc;
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo))) return rc;
     LinParams P = lin_params(h, o, np);
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
@@ -1080,7 +1081,7 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
 // (the PoseNet section further down)
 struct tcsfm_posenet;
 static int pose_loop(tcsfm_ctx *h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
-                     const float *depth_s, const float *K, float *poses_out, float *stacked_out);
+                     const float *depth_s, const float *K, float *poses_out, float *stacked_out, const WinOff *wo);
 static tcsfm_posenet *pn_for_lane(tcsfm_posenet *pn, tcsfm_ctx *c);
 static bool pn_usable(const tcsfm_posenet *pn, const tcsfm_ctx *h, int images);
 static int pn_max_images(const tcsfm_posenet *pn);
@@ -1089,23 +1090,30 @@ static int pn_max_images(const tcsfm_posenet *pn);
 // poses of every window come from the coupled PoseNet loop (train_mono.py:64-80) on the window's lane instead of from the caller.
 static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
                          const float *pose_init, tcsfm_posenet *pn, int num_iter, float *pose_init_out, float *pose_out,
-                         float *log_scale_out, int ring, int windows_per_call) {
+                         float *log_scale_out, int ring, int windows_per_call, int target_pos) {
     if (!h) return TCSFM_E_ARG;
     if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
     const int N = 2 * S, L = (int)h->lanes.size() + 1;
     if (S < 1 || T <= S || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: need S >= 1, T > S and 2*S <= max_pairs");
     if (!frames || !depths || !K || (!pose_init && !pn) || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
     if (windows_per_call < 0) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: windows_per_call < 0");
+    if (target_pos < -1 || target_pos > S || S > TC_MAX_SRC_OFF) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: target_pos must be -1 or 0..S, S at most 8");
+    // position of the target inside a window's S + 1 consecutive frames: the reference's loaders take the middle one
+    // (data/kitti_loader.py:271-273: target_idx = int(len / 2), the sources are the others in order)
+    const int tp = target_pos < 0 ? (S + 1) / 2 : target_pos;
+    WinOff wo;
+    wo.on = 1;
+    for (int s_ = 0; s_ < TC_MAX_SRC_OFF; s_++) wo.off[s_] = s_ < tp ? s_ : s_ + 1;     // source s = frame w + off[s], relative to the window's first frame
     if (pn && (num_iter < 1 || !pn_usable(pn, h, N) || o_in->depth_is_disp))
         return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: needs a loaded PoseNet of this handle with max_images >= 2*S, num_iter >= 1 and depths (not disparities)");
     tcsfm_opts o = *o_in;
     o.host_ptrs = 0;                                   // the lanes work on the device ring; this call does the staging itself
     const int nwin = T - S;
-    // Windows per call: consecutive windows are independent, and with ONE source per window the targets (frames w ..) and the
-    // sources (frames w+1 ..) of WB consecutive windows are two contiguous runs of the ring -- exactly the window form's [B] / [S,B]
-    // layout -- so a lane refines WB windows per call: the kernels fill the chip (26 200 windows/s per call at WB = 8 against 13 900
-    // at WB = 1) and the PoseNet runs on 2 WB images at a third of the time per image.  With more sources the runs overlap: WB = 1.
-    int WB = S == 1 ? (windows_per_call > 0 ? windows_per_call : 8) : 1;
+    // Windows per call: consecutive windows are independent, and the targets (frames w + tp ..) and every source (frames w + off[s] ..)
+    // of WB consecutive windows are runs of the ring -- the window form with explicit source positions (WinOff) -- so a lane refines
+    // WB windows per call: the kernels fill the chip (26 200 windows/s per call at WB = 8 against 13 900 at WB = 1) and the PoseNet
+    // runs on 2 S WB images at a third of the time per image.
+    int WB = windows_per_call > 0 ? windows_per_call : 8;
     WB = std::min(WB, std::min(h->max_pairs / N, nwin));
     if (pn) WB = std::min(WB, pn_max_images(pn) / N);
     int rc = check_common(h, &o, N * WB);
@@ -1219,15 +1227,15 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         const int l = (int)(ci % L), s0 = c0 % R;
         for (int k = c0 / C; k <= (c0 + nbw - 1 + S) / C; k++) HIPCHK(h, hipStreamWaitEvent(ls[l], h->seq_copied[(k * C % R) / C], 0));
         tcsfm_ctx *c = lane[l];
-        const float *tg = h->seq_img + (size_t)s0 * 3 * hw, *sr = h->seq_img + (size_t)(s0 + 1) * 3 * hw;
-        const float *dt = h->seq_depth + (size_t)s0 * hw, *ds = h->seq_depth + (size_t)(s0 + 1) * hw;
+        const float *tg = h->seq_img + (size_t)(s0 + tp) * 3 * hw, *sr = h->seq_img + (size_t)s0 * 3 * hw;      // sources: by position (wo)
+        const float *dt = h->seq_depth + (size_t)(s0 + tp) * hw, *ds = h->seq_depth + (size_t)s0 * hw;
         float *p_in = h->seq_pose_in + (size_t)c0 * N * 6, *p_out = h->seq_pose_out + (size_t)c0 * N * 6;
         if (pn) {           // initial poses of these windows: PoseNet -> warp -> PoseNet correction, num_iter times, on the lane
-            rc = pose_loop(c, net[l], num_iter, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr);
+            rc = pose_loop(c, net[l], num_iter, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, &wo);
             if (rc) { if (c != h) h->err = c->err; break; }
         }
         rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
-                         np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr);
+                         np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo);
         if (rc) { if (c != h) h->err = c->err; break; }
         HIPCHK(h, hipEventRecord(h->seq_done[ci % ND], ls[l]));
         for (int k = 0; k < nbw + S; k++) slot_reader[(c0 + k) % R] = ci;
@@ -1256,16 +1264,16 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
 }
 
 int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
-                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call) {
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call, int target_pos) {
     if (h && !pose_init) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
-    return sequence_impl(h, o, T, S, frames, depths, K, pose_init, nullptr, 0, nullptr, pose_out, log_scale_out, ring, windows_per_call);
+    return sequence_impl(h, o, T, S, frames, depths, K, pose_init, nullptr, 0, nullptr, pose_out, log_scale_out, ring, windows_per_call, target_pos);
 }
 
 int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
                             const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring,
-                            int windows_per_call) {
+                            int windows_per_call, int target_pos) {
     if (h && !pn) return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: NULL PoseNet");
-    return sequence_impl(h, o, T, S, frames, depths, K, nullptr, pn, num_iter, pose_init_out, pose_out, log_scale_out, ring, windows_per_call);
+    return sequence_impl(h, o, T, S, frames, depths, K, nullptr, pn, num_iter, pose_init_out, pose_out, log_scale_out, ring, windows_per_call, target_pos);
 }
 
 int tcsfm_lane_wait(tcsfm_handle h, int lane) {
@@ -1536,7 +1544,7 @@ namespace {
 // the seven convolutions + statistics passes + head of one PoseNet evaluation on N samples; the first layer reads
 // (imgA | imgB) per sample (strides in floats; window indexing when win_B > 0)
 int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const float *imgB, long long strideB, int win_B, int win_S,
-           float *pose, int accumulate, float *stacked, int it, int iters) {
+           float *pose, int accumulate, float *stacked, int it, int iters, const WinOff *wo = nullptr) {
     tcsfm_ctx *h = pn->h;
     const int cfg = N <= 4 ? 0 : 1;
     for (int l = 0; l < 7; l++) {
@@ -1546,6 +1554,7 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         PnConvParams P;
         memset(&P, 0, sizeof(P));
         P.imgA = imgA; P.imgB = imgB; P.strideA = strideA; P.strideB = strideB; P.win_B = win_B; P.win_S = win_S;
+        if (wo) P.win_off = *wo;
         P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
         P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = L.ksplit == 1 ? pn->part[l] : nullptr; P.L = L; P.N = N;
         dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
@@ -1582,14 +1591,14 @@ int tcsfm_posenet_forward(tcsfm_posenet *pn, int N, const float *imgs, float *po
 
 // the coupled loop of train_mono.py:64-80 on context `h` (the handle or one of its lanes; pn->h == h): network, warps, corrections
 static int pose_loop(tcsfm_ctx *h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
-                     const float *depth_s, const float *K, float *poses_out, float *stacked_out) {
+                     const float *depth_s, const float *K, float *poses_out, float *stacked_out, const WinOff *wo) {
     const int N = 2 * B * S;
     int rc;
     tcsfm_opts o; tcsfm_default_opts(&o);
     if ((rc = check_intrinsics(h, &o, K, B))) return rc;
     const long long hw = (long long)h->H * h->W;
     // full_poses = pose_model(cat(tgt | src ; src | tgt)), train_mono.py:54-64 -- the pairs are formed by indexing
-    if ((rc = pn_run(pn, N, tgt, 3 * hw, srcs, 3 * hw, B, S, pn->pose, 0, stacked_out, 0, num_iter))) return rc;
+    if ((rc = pn_run(pn, N, tgt, 3 * hw, srcs, 3 * hw, B, S, pn->pose, 0, stacked_out, 0, num_iter, wo))) return rc;
     for (int it = 1; it < num_iter; it++) {
         // inverse_warp2(src, d_t, d_s, -full_poses, K) with the next network input (tgt * valid | img_rec) written by the warp
         // itself (train_mono.py:69-76), then full_poses += pose_model(new_imgs) (:77-78)
@@ -1600,6 +1609,7 @@ static int pose_loop(tcsfm_ctx *h, tcsfm_posenet *pn, int num_iter, int B, int S
         memset(&W, 0, sizeof(W));
         W.src = srcs; W.depth_t = depth_t; W.depth_s = depth_s; W.pc = h->pconst; W.tgt = tgt; W.posenet_in = pn->in_buf;
         W.H = h->H; W.W = h->W; W.win_B = B; W.win_S = S;
+        if (wo) W.win_off = *wo;
         hipLaunchKernelGGL(k_warp, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, W);
         if ((rc = pn_run(pn, N, pn->in_buf, 6 * hw, pn->in_buf + 3 * hw, 6 * hw, 0, 0, pn->pose, 1, stacked_out, it, num_iter))) return rc;
     }
@@ -1616,7 +1626,7 @@ int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter
     if (!tgt || !srcs || !depth_t || !depth_s || !K || !poses_out) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: NULL argument");
     DeviceGuard dev_guard(h->device);
     if (int rc_ = pending_error(h)) return rc_;
-    return pose_loop(h, pn, num_iter, B, S, tgt, srcs, depth_t, depth_s, K, poses_out, stacked_out);
+    return pose_loop(h, pn, num_iter, B, S, tgt, srcs, depth_t, depth_s, K, poses_out, stacked_out, nullptr);
 }
 
 void tcsfm_pose_to_matrix(const double pose[6], double T[12]) { tc::pose_to_T(pose, T); }

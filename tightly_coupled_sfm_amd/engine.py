@@ -373,11 +373,12 @@ class Engine:
                                                             self._p(depth_s), self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out), None))
 
     def refine_sequence(self, frames: torch.Tensor, depths: torch.Tensor, K, init_poses, opts: Optional[Opts] = None, sources: int = 1,
-                        ring: int = 0, log_scale: bool = False, windows_per_call: int = 0):
+                        ring: int = 0, log_scale: bool = False, windows_per_call: int = 0, target_pos: int = 0):
         """tcsfm_refine_sequence: the whole window loop of a sequence inside the library (frames [T,3,H,W] / depths [T,1,H,W] CPU
         tensors -- pinned for asynchronous copies --, K [3,3], init_poses [T-S, 2S, 6]) -> refined poses [T-S, 2S, 6] (CPU tensor;
-        with log_scale=True also the log depth scales [T-S, 2S]); calls of `windows_per_call` windows (0 = default 8 with one source per window,
-        capped by max_pairs / 2S) run on the engine's lanes"""
+        with log_scale=True also the log depth scales [T-S, 2S]); calls of `windows_per_call` windows (0 = default 8, capped by max_pairs / 2S) run on
+        the engine's lanes.  Window w = frames w .. w+S; its target is frame w + target_pos (0: the first; -1: the middle one, (S+1)//2, as
+        the reference's loaders choose it), its sources the others in order"""
         self._bind()
         o = opts or default_opts()
         cpu = lambda a, shape, name: self._cpu(a, shape, name)
@@ -389,7 +390,7 @@ class Engine:
         ls = torch.zeros((T - S, 2 * S), dtype=torch.float32) if log_scale else None
         hp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         self._call(self.lib.tcsfm_refine_sequence(self._h, C.byref(o), T, S, hp(frames), hp(depths), hp(Kc), hp(p0), hp(out), hp(ls), int(ring),
-                                                  int(windows_per_call)))
+                                                  int(windows_per_call), int(target_pos)))
         return (out, ls) if log_scale else out
 
     @staticmethod

@@ -93,7 +93,8 @@ class PoseNetHIP:
         e._call(self.lib.tcsfm_posenet_forward(self._pn, N, e._p(imgs), e._p(out)))
         return out
 
-    def odometry_sequence(self, frames, depths, K, opts=None, sources: int = 1, iterations: int = 4, ring: int = 0, windows_per_call: int = 0):
+    def odometry_sequence(self, frames, depths, K, opts=None, sources: int = 1, iterations: int = 4, ring: int = 0, windows_per_call: int = 0,
+                          target_pos: int = 0):
         """tcsfm_odometry_sequence: for every window of a sequence (frames [T,3,H,W] / depths [T,1,H,W] CPU tensors, pinned for
         asynchronous copies; K [3,3]) the coupled PoseNet loop gives the initial poses and the engine refines them, windows
         running on the engine's lanes -> (initial poses, refined poses), each [T-S, 2S, 6] CPU tensors"""
@@ -107,7 +108,7 @@ class PoseNetHIP:
         init = torch.empty((T - S, 2 * S, 6), dtype=torch.float32); out = torch.empty_like(init)
         hp = lambda t: C.c_void_p(t.data_ptr())
         e._call(self.lib.tcsfm_odometry_sequence(e._h, self._pn, int(iterations), C.byref(o), T, S, hp(frames), hp(depths), hp(Kc), hp(init), hp(out),
-                                                 None, int(ring), int(windows_per_call)))
+                                                 None, int(ring), int(windows_per_call), int(target_pos)))
         return init, out
 
     def solve_pose_iteratively(self, num_iter: int, tgt, srcs, depth_t, depth_s, K):
