@@ -174,7 +174,7 @@ def test_native_sequence_loop_matches_per_window_calls(S, lanes, ring):
         e.refine_sequence(frames, depths, badK, init, o, sources=S)
 
 
-@pytest.mark.parametrize("wpc,lanes,ring", [(0, 2, 0), (8, 3, 0), (3, 2, 0), (5, 1, 12), (4, 3, 20), (8, 2, 16)])
+@pytest.mark.parametrize("wpc,lanes,ring", [(0, 2, 0), (8, 3, 0), (3, 2, 0), (5, 1, 12), (4, 3, 20), (8, 2, 16), (8, 2, 6), (0, 1, 3)])
 def test_sequence_loop_with_several_windows_per_call(wpc, lanes, ring):
     """tcsfm_refine_sequence with one source per window refines `windows_per_call` consecutive windows per call (their targets and
     sources are contiguous runs of the ring): bit-identical to one refine_window call per window for every batch size (ragged last

@@ -1116,6 +1116,7 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
     int WB = windows_per_call > 0 ? windows_per_call : 8;
     WB = std::min(WB, std::min(h->max_pairs / N, nwin));
     if (pn) WB = std::min(WB, pn_max_images(pn) / N);
+    while (ring > 0 && WB > 1 && ring < WB + S + (ring >= WB + S + 8 ? 4 : 1)) WB--;      // an explicit small ring bounds the windows per call
     int rc = check_common(h, &o, N * WB);
     if (rc) return rc;
     if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || !(K[0] != 0.f) || !(K[4] != 0.f))
