@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--min-blocks", type=int, default=5, help="timed K-step blocks at least (the median block is reported; short blocks are "
+                    "repeated until 50 ms anyway)")
     ap.add_argument("--windows-per-gpu", type=int, default=0, help="windows (B) per rank and step; default 1 on one GPU (config 2), 8 on several (config 3)")
     ap.add_argument("--total-windows", type=int, default=0, help="STRONG scaling instead of the default weak scaling: this many windows per step in "
                     "the whole job (BASELINE config 3: 64), split evenly over the ranks (SURVEY 8e: report both)")
@@ -250,7 +252,7 @@ def main():
         for k in range(args.warmup):
             step_on(k % nl)
         blocks = [block(nl)]
-        reps = int(min(64, max(1, np.ceil(0.05 / max(blocks[0], 1e-9)))))
+        reps = int(min(64, max(args.min_blocks, np.ceil(0.05 / max(blocks[0], 1e-9)))))
         if distributed:      # every rank runs the same number of blocks
             r = torch.tensor([reps], device=coll_dev, dtype=torch.int64)
             dist.all_reduce(r, op=dist.ReduceOp.MAX)
