@@ -5,6 +5,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# A refinement is a chain of short dependent kernels: kernel arguments must sit in device memory (this ROCm's default; with 0 every
+# launch fetches them over PCIe and a B=1 call takes 90 us instead of 72 us).  Only a default, and only effective when this module is
+# imported before the process's first HIP call.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtcsfm_hip.so")
 
