@@ -277,6 +277,11 @@ int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, con
 int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
                             const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring,
                             int windows_per_call, int target_pos);
+/* The dense mode (tcsfm_refine_dense_window: pose + per-pixel inverse depth with the Schur complement, BASELINE config 5) over a
+ * sequence, same streaming and batching: depth_out [T-S, 2*S, H, W] (host) receives every directed pair's refined depth map.
+ * Bit-identical to one tcsfm_refine_dense_window call per window. */
+int tcsfm_refine_dense_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
+                                const float *pose_init, float *pose_out, float *depth_out, int ring, int windows_per_call, int target_pos);
 int tcsfm_lane_wait(tcsfm_handle h, int lane);
 int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
 int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);

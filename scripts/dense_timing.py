@@ -57,3 +57,23 @@ for H, W in ((240, 320), (256, 448)):
     run(H, W, 64, 30)
     for lanes in (1, 2, 3):
         run_lanes(H, W, lanes, 600)
+
+
+def run_sequence(H, W, lanes, wpc, T=120):
+    """the dense mode over a streamed sequence (tcsfm_refine_dense_sequence): frames from pinned host memory, depth maps back to the host"""
+    seq = synth.make_sequence(T, H, W, seed=3)
+    frames, depths = torch.as_tensor(seq["frames"]).pin_memory(), torch.as_tensor(seq["depths"]).pin_memory()
+    init = torch.as_tensor(seq["init"])
+    e = Engine(H, W, 2 * wpc, lanes=lanes)
+    o = default_opts(n_iters=4, min_depth=0.03, max_depth=3.0)
+    e.refine_dense_sequence(frames[:40], depths[:40], seq["K"], init[:39], o, windows_per_call=wpc)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); e.refine_dense_sequence(frames, depths, seq["K"], init, o, windows_per_call=wpc); ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[2]
+    print(json.dumps({"HxW": f"{H}x{W}", "path": "tcsfm_refine_dense_sequence (PCIe-inclusive, depth maps back to the host)", "lanes": lanes, "windows_per_call": wpc,
+                      "us_per_window": round(t / (T - 1) * 1e6, 1), "windows_per_s": round((T - 1) / t, 1)}), flush=True)
+    e.close()
+
+for lanes, wpc in ((1, 1), (2, 1), (1, 8), (2, 8)):
+    run_sequence(240, 320, lanes, wpc)

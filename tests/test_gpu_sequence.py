@@ -226,3 +226,32 @@ def test_sequence_windows_with_the_target_anywhere(S, tp, wpc, lanes, ring):
                             windows_per_call=wpc, target_pos=tp)
     assert torch.equal(out, torch.stack(plain))
     assert not torch.equal(out, t(init))
+
+
+@pytest.mark.parametrize("S,tp,wpc,lanes", [(1, 0, 1, 2), (1, 0, 4, 2), (1, -1, 8, 1), (2, -1, 2, 2)])
+def test_dense_sequence_matches_per_window_calls(S, tp, wpc, lanes):
+    """tcsfm_refine_dense_sequence (pose + per-pixel inverse depth over a sequence, windows batched per call on the lanes): poses and
+    every pair's refined depth map equal, bit for bit, one refine_dense_window call per window"""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W, T = 48, 96, 14
+    seq = synth.make_sequence(T, H, W, seed=15)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32))
+    nwin = T - S
+    tpos = (S + 1) // 2 if tp < 0 else tp
+    src_pos = [k for k in range(S + 1) if k != tpos]
+    step = seq["init"][:, 0]
+    chain = lambda a, b: sum(step[k] for k in range(a, b)) if b > a else -sum(step[k] for k in range(b, a))
+    init = np.stack([np.stack([chain(w + tpos, w + p) for p in src_pos] + [chain(w + p, w + tpos) for p in src_pos]) for w in range(nwin)]).astype(np.float32)
+    o = default_opts(n_iters=3, min_depth=0.03, max_depth=3.0, argmin=1)
+    e = Engine(H, W, 2 * S * wpc, lanes=lanes)
+    K = t(seq["K"][None]).cuda()
+    ref_p, ref_d = [], []
+    for w in range(nwin):
+        srcs = torch.stack([t(seq["frames"][w + p]) for p in src_pos])[:, None].cuda(); ds = torch.stack([t(seq["depths"][w + p]) for p in src_pos])[:, None].cuda()
+        p, d, _ = e.refine_dense_window(t(seq["frames"][w + tpos][None]).cuda(), srcs, t(seq["depths"][w + tpos][None]).cuda(), ds, K, t(init[w]).cuda(), o)
+        ref_p.append(p.cpu()); ref_d.append(d.cpu())
+    out, dout = e.refine_dense_sequence(t(seq["frames"]).pin_memory(), t(seq["depths"]).pin_memory(), seq["K"], init, o, sources=S,
+                                        windows_per_call=wpc, target_pos=tp)
+    assert torch.equal(out, torch.stack(ref_p)) and torch.equal(dout, torch.stack(ref_d))
+    assert not torch.equal(dout[:, 0], t(seq["depths"][tpos:tpos + nwin]))          # the depth maps were refined

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "tcsfm_refine_dense_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_refine_sequence": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),
     "tcsfm_odometry_sequence": (C.c_int, [_P, _P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),
+    "tcsfm_refine_dense_sequence": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),
     "tcsfm_lane_wait": (C.c_int, [_P, C.c_int]),
     "tcsfm_lane_synchronize": (C.c_int, [_P, C.c_int]),
     "tcsfm_lane_event": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),

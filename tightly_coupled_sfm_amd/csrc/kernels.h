@@ -1375,6 +1375,15 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
 #undef TC_STAMP
 }
 
+// dense sequence calls: the refined depth maps of one call, stacked [pair index j][window b] by the window form, into the caller's
+// per-window order [window b][pair index j]
+__global__ __launch_bounds__(256) void k_maps_to_window_order(const float *__restrict__ src, float *__restrict__ dst, int nbw, int N, int hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;      // m = j * nbw + b
+    if (i >= hw) return;
+    const int j = m / nbw, b = m - j * nbw;
+    dst[((size_t)b * N + j) * hw + i] = src[(size_t)m * hw + i];
+}
+
 struct FinishParams {
     const PairState *st;
     float *pose_out, *log_scale_out;

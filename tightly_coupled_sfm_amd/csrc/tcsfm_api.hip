@@ -65,6 +65,10 @@ struct tcsfm_ctx {
     // tcsfm_refine_sequence: device ring of frames, copy stream, per-slot / per-window events, pose staging (allocated on first use)
     float *seq_img = nullptr, *seq_depth = nullptr, *seq_pose_in = nullptr, *seq_pose_out = nullptr, *seq_ls_out = nullptr, *seq_K = nullptr;
     int seq_slots = 0, seq_K_n = 0;    // ring slots + mirror slots allocated; copies of K held by seq_K
+    float *seq_dense = nullptr;        // tcsfm_refine_dense_sequence: refined depth maps of all windows, per-window order (on a lane: the
+    size_t seq_dense_cap = 0;          // lane's stacked maps of one call)
+    float *seq_dense_tmp = nullptr;    // ... the handle's own stacked maps of one call (lane 0)
+    size_t seq_dense_tmp_cap = 0;
     size_t seq_pose_cap = 0;           // windows x pairs the pose staging holds
     hipStream_t seq_copy = nullptr;
     std::vector<hipEvent_t> seq_copied, seq_done;
@@ -453,7 +457,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
-                    h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K};
+                    h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -864,7 +868,7 @@ int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *d
 // shared body of tcsfm_refine_dense (win_B == 0) and tcsfm_refine_dense_window
 static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
-                      float *depth_out, float *stats_out) {
+                      float *depth_out, float *stats_out, const WinOff *wo = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
@@ -917,7 +921,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         HIPCHK(h, hipMalloc((void **)&h->depth_alt, n * hw * sizeof(float)));
     }
     // every pair gets its OWN copy of its target's depth; the pack also leaves the prior centre depth0
-    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, h->depth0))) return rc;
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, h->depth0, wo))) return rc;
     // the dense kernel's own tile grid (32x16 tiles of 512 threads, as k_linearize; 16x16 / 256 threads measured slower except
     // for 320x240 at B=1: 10.9 vs 11.8 us per launch there, 234 vs 200 us with the chip full) and reduction-group count
     constexpr int DTW = 32, DTH = 16, DNT = 512;
@@ -1090,7 +1094,7 @@ static int pn_max_images(const tcsfm_posenet *pn);
 // poses of every window come from the coupled PoseNet loop (train_mono.py:64-80) on the window's lane instead of from the caller.
 static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
                          const float *pose_init, tcsfm_posenet *pn, int num_iter, float *pose_init_out, float *pose_out,
-                         float *log_scale_out, int ring, int windows_per_call, int target_pos) {
+                         float *log_scale_out, int ring, int windows_per_call, int target_pos, float *dense_depth_out = nullptr) {
     if (!h) return TCSFM_E_ARG;
     if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
     const int N = 2 * S, L = (int)h->lanes.size() + 1;
@@ -1147,6 +1151,19 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         HIPCHK(h, hipMalloc(&h->seq_pose_out, (size_t)nwin * N * 6 * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->seq_ls_out, (size_t)nwin * N * sizeof(float)));
         h->seq_pose_cap = (size_t)nwin * N;
+    }
+    const bool dense = dense_depth_out != nullptr;
+    if (dense && h->seq_dense_cap < (size_t)nwin * N * hw) {
+        if (h->seq_dense) HIPCHK(h, hipFree(h->seq_dense));
+        h->seq_dense = nullptr; h->seq_dense_cap = 0;
+        HIPCHK(h, hipMalloc(&h->seq_dense, (size_t)nwin * N * hw * sizeof(float)));
+        h->seq_dense_cap = (size_t)nwin * N * hw;
+    }
+    if (dense && h->seq_dense_tmp_cap < (size_t)WB * N * hw) {
+        if (h->seq_dense_tmp) HIPCHK(h, hipFree(h->seq_dense_tmp));
+        h->seq_dense_tmp = nullptr; h->seq_dense_tmp_cap = 0;
+        HIPCHK(h, hipMalloc(&h->seq_dense_tmp, (size_t)WB * N * hw * sizeof(float)));
+        h->seq_dense_tmp_cap = (size_t)WB * N * hw;
     }
     if (h->seq_K_n < WB) {
         if (h->seq_K) HIPCHK(h, hipFree(h->seq_K));
@@ -1235,8 +1252,22 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
             rc = pose_loop(c, net[l], num_iter, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, &wo);
             if (rc) { if (c != h) h->err = c->err; break; }
         }
-        rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
-                         np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo);
+        if (dense) {
+            // the call's maps come out stacked [pair index][window]; a small kernel puts them in the caller's per-window order, and ONE
+            // copy per call takes them to the host on the lane's stream (asynchronous when the destination is pinned)
+            if (c->seq_dense_cap < (size_t)WB * N * hw) {
+                if (c->seq_dense && c != h) HIPCHK(h, hipFree(c->seq_dense));
+                if (c != h) { c->seq_dense = nullptr; c->seq_dense_cap = 0; HIPCHK(h, hipMalloc(&c->seq_dense, (size_t)WB * N * hw * sizeof(float))); c->seq_dense_cap = (size_t)WB * N * hw; }
+            }
+            float *tmp = c == h ? h->seq_dense_tmp : c->seq_dense;
+            rc = dense_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, p_out, tmp, nullptr, &wo);
+            if (!rc) {
+                float *ordered = h->seq_dense + (size_t)c0 * N * hw;
+                hipLaunchKernelGGL(k_maps_to_window_order, dim3((unsigned)((hw + 255) / 256), N * nbw), dim3(256), 0, ls[l], (const float *)tmp, ordered, nbw, N, (int)hw);
+                HIPCHK(h, hipMemcpyAsync(dense_depth_out + (size_t)c0 * N * hw, ordered, (size_t)nbw * N * hw * sizeof(float), hipMemcpyDeviceToHost, ls[l]));
+            }
+        } else rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
+                              np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo);
         if (rc) { if (c != h) h->err = c->err; break; }
         HIPCHK(h, hipEventRecord(h->seq_done[ci % ND], ls[l]));
         for (int k = 0; k < nbw + S; k++) slot_reader[(c0 + k) % R] = ci;
@@ -1260,7 +1291,7 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
     };
     if ((rc = fetch(pose_out, h->seq_pose_out, 6))) return rc;
     if (pose_init_out && (rc = fetch(pose_init_out, h->seq_pose_in, 6))) return rc;
-    if (log_scale_out && np == 7 && (rc = fetch(log_scale_out, h->seq_ls_out, 1))) return rc;
+    if (log_scale_out && np == 7 && !dense && (rc = fetch(log_scale_out, h->seq_ls_out, 1))) return rc;
     return TCSFM_OK;
 }
 
@@ -1275,6 +1306,12 @@ int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, con
                             int windows_per_call, int target_pos) {
     if (h && !pn) return fail(h, TCSFM_E_ARG, "tcsfm_odometry_sequence: NULL PoseNet");
     return sequence_impl(h, o, T, S, frames, depths, K, nullptr, pn, num_iter, pose_init_out, pose_out, log_scale_out, ring, windows_per_call, target_pos);
+}
+
+int tcsfm_refine_dense_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
+                                const float *pose_init, float *pose_out, float *depth_out, int ring, int windows_per_call, int target_pos) {
+    if (h && (!pose_init || !depth_out)) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_sequence: NULL input");
+    return sequence_impl(h, o, T, S, frames, depths, K, pose_init, nullptr, 0, nullptr, pose_out, nullptr, ring, windows_per_call, target_pos, depth_out);
 }
 
 int tcsfm_lane_wait(tcsfm_handle h, int lane) {

@@ -393,6 +393,23 @@ class Engine:
                                                   int(windows_per_call), int(target_pos)))
         return (out, ls) if log_scale else out
 
+    def refine_dense_sequence(self, frames: torch.Tensor, depths: torch.Tensor, K, init_poses, opts: Optional[Opts] = None, sources: int = 1,
+                              ring: int = 0, windows_per_call: int = 0, target_pos: int = 0):
+        """tcsfm_refine_dense_sequence: the dense mode (pose + per-pixel inverse depth) over a sequence, arguments as refine_sequence
+        -> (poses [T-S, 2S, 6], refined depth maps [T-S, 2S, 1, H, W]) as CPU tensors"""
+        self._bind()
+        o = opts or default_opts()
+        T, S = int(frames.shape[0]), int(sources)
+        frames = self._cpu(frames, (T, 3, self.H, self.W), "frames"); depths = self._cpu(depths, (T, 1, self.H, self.W), "depths")
+        Kc = self._cpu(torch.as_tensor(np.asarray(K, dtype=np.float32)), (3, 3), "K")
+        p0 = self._cpu(torch.as_tensor(np.asarray(init_poses, dtype=np.float32)), (T - S, 2 * S, 6), "init_poses")
+        out = torch.empty_like(p0)
+        dout = torch.empty((T - S, 2 * S, 1, self.H, self.W), dtype=torch.float32).pin_memory()     # pinned: the copies back run beside the kernels
+        hp = lambda t: C.c_void_p(t.data_ptr())
+        self._call(self.lib.tcsfm_refine_dense_sequence(self._h, C.byref(o), T, S, hp(frames), hp(depths), hp(Kc), hp(p0), hp(out), hp(dout), int(ring),
+                                                        int(windows_per_call), int(target_pos)))
+        return out, dout
+
     @staticmethod
     def _cpu(t, shape, name):
         t = torch.as_tensor(t)
