@@ -251,9 +251,10 @@ class Oracle:
                                    C.byref(opts), self._p(T), None, self._p(mask))
         return mask
 
-    def refine_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, log_scale=None, bits=None, decide=None):
+    def refine_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, log_scale=None, bits=None, decide=None, rule=0):
         """window mode (forward + inverse pairs, optional min-over-sources selection): poses [2*S*B,6] in the stacked
-        order of train_mono.py:54-62 -> (poses [2SB,6], log_scale [2SB] or None, stats [2SB,n_iters+1,4])"""
+        order of train_mono.py:54-62 -> (poses [2SB,6], log_scale [2SB] or None, stats [2SB,n_iters+1,4]).
+        rule 0: every pair its own problem; 1: the reference's compute_optimization_loss (optimizer.py:47-86) is the scalar minimised"""
         opts = opts or default_opts()
         tgt, srcs, depth_t, depth_s, K = map(self._r, (tgt, srcs, depth_t, depth_s, K))
         S, B, _, H, W = srcs.shape
@@ -261,10 +262,35 @@ class Oracle:
         ls = None if log_scale is None else np.ascontiguousarray(np.asarray(log_scale, dtype=np.float64)).copy()
         stats = np.zeros((2 * S * B, opts.n_iters + 1, 4))
         bits, decide = self._forced(bits, decide)
-        self.lib.orc_refine_window_forced(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
-                                          C.byref(opts), int(bool(argmin)), self._p(pose), self._p(ls), self._p(stats),
-                                          self._p(bits), self._p(decide))
+        self.lib.orc_refine_window_rule(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
+                                        C.byref(opts), int(bool(argmin)), int(rule), self._p(pose), self._p(ls), self._p(stats),
+                                        self._p(bits), self._p(decide), None)
         return pose, ls, stats
+
+    def linearize_window(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, rule=0, log_scale=None):
+        """one linearisation of a whole window at `poses` [2SB,6] -> dict(H [2SB,np,np], g [2SB,np], cost, cost_photo, cost_dc, n_mask [2SB])"""
+        opts = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K = map(self._r, (tgt, srcs, depth_t, depth_s, K))
+        S, B, _, H, W = srcs.shape
+        N, n_p = 2 * S * B, opts.nparam
+        pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(N, 6))
+        ls = None if log_scale is None else np.ascontiguousarray(np.asarray(log_scale, dtype=np.float64))
+        out = (LinOut * N)()
+        self.lib.orc_linearize_window(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K),
+                                      C.byref(opts), int(bool(argmin)), int(rule), self._p(pose), self._p(ls), out)
+        return dict(H=np.stack([np.array(o.H[:n_p * n_p]).reshape(n_p, n_p) for o in out]), g=np.stack([np.array(o.g[:n_p]) for o in out]),
+                    cost=np.array([o.cost for o in out]), cost_photo=np.array([o.cost_photo for o in out]),
+                    cost_dc=np.array([o.cost_dc for o in out]), n_mask=np.array([o.n_mask for o in out]))
+
+    def flip_stats_reset(self):
+        self.lib.orc_flip_stats_reset()
+
+    def flip_stats(self, n_lin):
+        """flip statistics of the forced replays since the last reset (this thread): per linearisation (pixels the oracle would
+        have masked differently from the engine, those of them that are not near-ties) -> (n [n_lin], hard [n_lin])"""
+        n = (C.c_long * 64)(); h = (C.c_long * 64)()
+        self.lib.orc_flip_stats(n, h, 64)
+        return np.array(n[:n_lin]), np.array(h[:n_lin])
 
     def refine(self, tgt, src, depth_t, depth_s, pose, K, opts=None, log_scale=0.0, bits=None, decide=None):
         """GN/LM refinement of one directed pair -> (pose [6], log_scale, stats [n_iters+1,4]).

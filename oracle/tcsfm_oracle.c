@@ -244,6 +244,7 @@ typedef struct {
     real p[3];          /* K Xp                                                           */
     int oobx, ooby, zclamp;
     int adjx, adjy;     /* forced replay only: shift of the bilinear cell (-1, 0, +1) to the one the engine sampled */
+    int nat_valid;      /* validity as decided HERE, before a forced replay overrides it (flip statistics) */
 } geo_t;
 
 static void cam_setup(cam_t *c, int H, int W, const real *K, const double T[12], double log_scale) {
@@ -283,6 +284,28 @@ static void cam_setup(cam_t *c, int H, int W, const real *K, const double T[12],
 static __thread const unsigned short *g_force_bits = NULL; /* [H*W] of the linearisation being evaluated, or NULL: decide here */
 static __thread unsigned short *g_record_bits = NULL;      /* [H*W]: record the decisions taken here in the same format (CPU self-test) */
 
+/* Flip statistics of a forced replay (parity tests): while the engine's decisions are replayed, the mask this restatement
+ * would have chosen ITSELF at the same (replayed) iterate is compared with the engine's bit 0, per linearisation:
+ *   n    = pixels decided differently,
+ *   hard = those of them that are NOT explainable as a tie: a different warp validity (border of the valid region), an error
+ *          within ORC_TIE of its auto-mask threshold, or -- with the min over the sources -- two sources' errors / the minimum
+ *          and the smallest threshold within ORC_TIE of each other.
+ * A kernel bug that corrupts masks only after the first pose update shows up here at linearisations 1..n. */
+#define ORC_MAX_LIN 64
+#define ORC_TIE ((real)5e-5)
+static __thread int g_lin_idx = -1;                 /* linearisation being replayed, or -1: no statistics */
+static __thread long g_flip_n[ORC_MAX_LIN], g_flip_hard[ORC_MAX_LIN];
+static __thread const real *g_sel_margin = NULL;    /* [H*W] window mode: smallest gap among the selection's comparisons at the pixel */
+void orc_flip_stats_reset(void) { memset(g_flip_n, 0, sizeof(g_flip_n)); memset(g_flip_hard, 0, sizeof(g_flip_hard)); }
+void orc_flip_stats(long *n, long *hard, int count) {
+    for (int i = 0; i < count && i < ORC_MAX_LIN; i++) { n[i] = g_flip_n[i]; hard[i] = g_flip_hard[i]; }
+}
+static inline void flip_note(real m_nat, int forced, int is_tie) {
+    if (g_lin_idx < 0 || g_lin_idx >= ORC_MAX_LIN || (m_nat != 0) == (forced != 0)) return;
+    g_flip_n[g_lin_idx]++;
+    if (!is_tie) g_flip_hard[g_lin_idx]++;
+}
+
 /* sign of a quantity whose sign is a discrete decision of the residual's derivative (L1 term: rec - tgt of a channel; depth-
  * consistency term: cd - pd), kept as a 2-bit code at `shift`: 0 = exactly zero, 1 = positive, 2 = negative (an exact zero is not
  * rare in fp32: consistent depth maps give cd == pd bit for bit).  Replay: within `tie` of zero the engine's recorded sign wins. */
@@ -311,6 +334,7 @@ static void warp_geo(const cam_t *c, int u, int v, real depth, geo_t *g) {
     real yn = 2 * (g->p[1] / g->Z) / (real)(c->H - 1) - 1;
     g->oobx = (xn > 1) || (xn < -1);
     g->ooby = (yn > 1) || (yn < -1);
+    g->nat_valid = !(g->oobx || g->ooby);
     if (g_force_bits) { /* replay the engine's validity decision (the sample of an invalid pixel is zero as a whole) */
         const int valid = (g_force_bits[v * c->W + u] >> 1) & 1;
         if (valid) g->oobx = g->ooby = 0;
@@ -485,7 +509,7 @@ typedef struct {
     real rec[3], gx[3], gy[3]; /* warped source + d/d(ix,iy)                               */
     real pd, dgx, dgy, cd;     /* projected (sampled, scaled) / computed depth              */
     real a[MAXP], b[MAXP], zc[MAXP], dpd[MAXP]; /* d ix, d iy, d cd, d pd  w.r.t. parameters */
-    int valid;
+    int valid, nat_valid;
 } px_t;
 
 /* Parameters: xi = [rho, phi] left perturbation of T (T <- exp(xi^) T), optional 7th = log depth-scale
@@ -516,6 +540,7 @@ static void px_eval(const cam_t *c, const real *src, const real *depth_t, const 
     o->pd = c->es * dval; o->dgx *= c->es; o->dgy *= c->es;
     o->cd = g.Z;
     o->valid = !(g.oobx || g.ooby);
+    o->nat_valid = g.nat_valid;
     px_jac(c, &g, np, o);
     for (int j = 0; j < np; j++) o->dpd[j] = o->dgx * o->a[j] + o->dgy * o->b[j] + ((j == 6) ? o->pd : 0);
 }
@@ -580,9 +605,22 @@ typedef struct {
  *   Curvature of the W factor (e dW/dtheta) is neglected in H; it is present in g.
  * J1/J2/J3/E (optional, [H*W*np] / [H*W*3]) return the per-pixel rows for Jacobian pinning.
  */
+/* Coupling of one directed pair to the rest of its window under the REFERENCE window rule (compute_optimization_loss,
+ * optimizer.py:47-86 -- see orc_refine_window_rule): all fields optional. */
+typedef struct {
+    const real *w_map;  /* [H*W] weight map replacing the pair's OWN depth-consistency weight W in the photometric term, a constant
+                           of this pair's pose (optimizer.py:69: every source's minimum is multiplied by the weight map of source 0) */
+    const real *cross;  /* [H*W] extra gradient  -a cross(p) d dd_p/d theta : source 0's weight map also multiplies the pixels the
+                           OTHER sources won, cross(p) = sum_{s != 0} M_s(p) diff_s(p) */
+    double norm;        /* > 0: normaliser of the photometric sum (the batch-summed mask count) instead of the pair's own sum M */
+    double scale;       /* > 0: factor on the photometric term (0.25 for the inverse pairs, optimizer.py:79) */
+    double b_dc;        /* >= 0: per-pixel weight of the depth-consistency term instead of w_dc / (H W) */
+    int no_automask;    /* the pair's own mask is the warp validity alone (forward pairs without argmin, optimizer.py:71-73) */
+} lin_ext;
+
 static void linearize_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                    const double T[12], const real *K, double log_scale, const orc_opts *op, const real *auto_err_in,
-                   const real *mask_in, lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
+                   const real *mask_in, const lin_ext *x, lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
     int n = H * W, np = op->nparam;
     cam_t c;
     cam_setup(&c, H, W, K, T, log_scale);
@@ -611,7 +649,9 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
             /* depth consistency, train_mono.py:91-92 */
             real sum = P->cd + P->pd, dif = P->cd - P->pd;
             real raw = fabs(dif) / sum;
-            real dd = clamp01(raw), Wt = 1 - dd;
+            real dd = clamp01(raw), Wown = 1 - dd;
+            const int wext = x && x->w_map;
+            const real Wt = wext ? x->w_map[i] : Wown;   /* weight of the photometric term */
             real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
             real ddJ[MAXP];
             for (int j = 0; j < np; j++) ddJ[j] = sg * 2 * (P->pd * P->zc[j] - P->cd * P->dpd[j]) / (sum * sum);
@@ -659,24 +699,35 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
                 }
             }
             real diff = e1 + e2;
-            real m = (real)P->valid;
-            if (op->automask) m *= (diff < ae[i]) ? (real)1 : (real)0;
+            const int am_on = op->automask && !(x && x->no_automask);
+            real m = (real)P->nat_valid;
+            if (am_on) m *= (diff < ae[i]) ? (real)1 : (real)0;
             if (mask_in) m = mask_in[i];   /* window mode: the per-pixel min-over-sources selection replaces the pair's own mask */
-            if (g_force_bits) m = (real)(g_force_bits[i] & 1);
+            if (g_force_bits) {
+                const int fm = g_force_bits[i] & 1;
+                flip_note(m, fm, mask_in ? (g_sel_margin ? g_sel_margin[i] < ORC_TIE : 1)
+                                         : (P->nat_valid != P->valid) || (am_on && fabs(diff - ae[i]) < ORC_TIE));
+                m = (real)fm;
+            } else if (!mask_in) {
+                m = (real)P->valid * (am_on ? ((diff < ae[i]) ? (real)1 : (real)0) : (real)1);
+            }
             if (g_record_bits) g_record_bits[i] = (unsigned short)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
             M[i] = m; nmask += m;
             E[3 * i] = Wt * e1; E[3 * i + 1] = Wt * e2; E[3 * i + 2] = dd;
-            for (int j = 0; j < np; j++) {
-                J1[i * np + j] = Wt * de1[j] - e1 * ddJ[j];
-                J2[i * np + j] = Wt * de2[j] - e2 * ddJ[j];
+            for (int j = 0; j < np; j++) {   /* a foreign weight map does not depend on this pair's pose: no e dW term */
+                J1[i * np + j] = Wt * de1[j] - (wext ? 0 : e1 * ddJ[j]);
+                J2[i * np + j] = Wt * de2[j] - (wext ? 0 : e2 * ddJ[j]);
                 J3[i * np + j] = ddJ[j];
             }
         }
     memset(out, 0, sizeof(*out));
     out->n_mask = nmask;
-    double a = nmask > 0 ? 1.0 / nmask : 0.0, b = op->w_dc / (double)n, eps = op->irls_eps;
+    const double den = (x && x->norm > 0) ? x->norm : nmask, sc = (x && x->scale > 0) ? x->scale : 1.0;
+    double a = den > 0 ? sc / den : 0.0, b = (x && x->b_dc >= 0) ? x->b_dc : op->w_dc / (double)n, eps = op->irls_eps;
     for (int i = 0; i < n; i++) {
         double am = a * M[i];
+        if (x && x->cross)
+            for (int j = 0; j < np; j++) out->g[j] -= a * (double)x->cross[i] * J3[i * np + j];
         double E1 = E[3 * i], E2 = E[3 * i + 1], E3 = E[3 * i + 2];
         out->cost_photo += am * (E1 + E2);
         out->cost_dc += b * E3;
@@ -708,7 +759,7 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
 void orc_linearize(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
                    const double T[12], const real *K, double log_scale, const orc_opts *op, const real *auto_err_in,
                    lin_t *out, real *J1o, real *J2o, real *J3o, real *Eo, real *Mo) {
-    linearize_masked(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op, auto_err_in, NULL, out, J1o, J2o, J3o, Eo, Mo);
+    linearize_masked(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op, auto_err_in, NULL, NULL, out, J1o, J2o, J3o, Eo, Mo);
 }
 
 /* scalar cost only: the quantity generate_loss_surface sweeps, plot_loss_surface.py:31-33,45-47 */
@@ -822,8 +873,9 @@ static void refine_impl(int H, int W, const real *tgt, const real *src, const re
     for (int it = 0; it < op->n_iters; it++) {
         g_force_bits = bits ? bits + (size_t)it * n : NULL;
         g_record_bits = bits_out ? bits_out + (size_t)it * n : NULL;
+        g_lin_idx = bits ? it : -1;
         orc_linearize(H, W, tgt, src, depth_t, depth_s, Ttry, K, stry, op, ae, &tr, NULL, NULL, NULL, NULL, NULL);
-        g_force_bits = NULL; g_record_bits = NULL;
+        g_force_bits = NULL; g_record_bits = NULL; g_lin_idx = -1;
         if (np == 7) { /* scale prior: the photometric cost alone cannot separate depth scale from |t| */
             tr.cost += ps * (stry - s0) * (stry - s0);
             tr.g[6] += 2 * ps * (stry - s0);
@@ -886,12 +938,43 @@ void orc_refine(int H, int W, const real *tgt, const real *src, const real *dept
  *     s*(p)   = first argmin_s diff_s(p)                                          (torch.min over the source axis)
  *     keep(p) = max_s valid_s(p) > 0  and  (automask ? min_s diff_s(p) < min_s auto_err_s(p) : 1)
  *     M_s(p)  = keep(p) [s == s*(p)]
- * and pair s is linearised with M_s in place of its own valid x auto-mask.  Each pair keeps its own normaliser sum M_s
- * and its own weight map W_s (the reference multiplies every source by the weight map of source 0, optimizer.py:69 --
- * deliberately not reproduced: it would couple the pose of source 0 into the other pairs' gradients).
- * Inverse pairs are independent problems, exactly as in orc_refine.  Everything else (GN/LM, damping, retraction) is
- * per pair and identical to orc_refine.
+ * and pair s is linearised with M_s in place of its own valid x auto-mask.
+ *
+ * Two rules for how the pairs' costs are put together (tcsfm_opts.window_rule):
+ *   rule 0 (PAIR)       every directed pair is its own least-squares problem: own normaliser sum M_s, own weight map W_s.
+ *   rule 1 (REFERENCE)  the scalar that is minimised is compute_optimization_loss itself (optimizer.py:47-86, default options):
+ *         L = sum_b sum_p keep_b dmin_b W_{0,b} / sum_b sum_p keep_b                              forward term  (:69)
+ *           + 0.25 sum_{inv m} sum_p Minv_m W_m diff_m / sum_{inv m} sum_p Minv_m               inverse term  (:75-79)
+ *           + w_dc ( mean_{fwd m, p} dd_m + mean_{inv m, p} dd_m )                              depth consistency (:83-86)
+ *       i.e. batch-summed normalisers, and the weight map of SOURCE 0 on every forward pixel whichever source won it.  Without
+ *       argmin the forward term is 0.25 sum valid W diff / sum valid over all forward pairs, no auto-mask (:71-73).
+ *       Every pair takes a Gauss-Newton step on ITS pose with the gradient of L (exact, incl. the cross term: the pose of
+ *       source 0 moves the weight of the pixels the other sources won) and its own block of the curvature model.
+ * Everything else (GN/LM, damping, retraction) is per pair and identical to orc_refine.
  */
+static void window_select_maps(int H, int W, int S, const real *diff /* [S][n] */, const real *valid, const real *ae, int automask,
+                               real *mask /* [S] maps, stride */, size_t mstride, real *margin /* [n] or NULL */) {
+    const int n = H * W;
+    for (int i = 0; i < n; i++) {
+        int smin = 0;
+        real dmin = diff[i], amin = ae[i], vany = valid[i], gap = (real)1e30;
+        for (int s = 1; s < S; s++) {
+            const real d = diff[(size_t)s * n + i];
+            if (fabs(d - dmin) < gap) gap = fabs(d - dmin);
+            if (d < dmin) { dmin = d; smin = s; }
+            if (ae[(size_t)s * n + i] < amin) amin = ae[(size_t)s * n + i];
+            if (valid[(size_t)s * n + i] > vany) vany = valid[(size_t)s * n + i];
+        }
+        if (S > 2) { /* gap to the runner-up, whichever order they came in */
+            gap = (real)1e30;
+            for (int s = 0; s < S; s++) if (s != smin && fabs(diff[(size_t)s * n + i] - dmin) < gap) gap = fabs(diff[(size_t)s * n + i] - dmin);
+        }
+        int keep = vany > 0 && (!automask || dmin < amin);
+        if (margin) margin[i] = automask && fabs(dmin - amin) < gap ? fabs(dmin - amin) : gap;
+        for (int s = 0; s < S; s++) mask[(size_t)s * mstride + i] = (keep && s == smin) ? 1 : 0;
+    }
+}
+
 void orc_window_select(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, const double *T /* [S*B][12] */, const double *log_scale /* [S*B] or NULL */,
                        real *mask /* [S*B][H*W] */) {
@@ -904,44 +987,132 @@ void orc_window_select(int H, int W, int B, int S, const real *tgt, const real *
                             T + 12 * m, K + 9 * b, log_scale ? log_scale[m] : 0.0, op->w_l1, op->w_ssim, diff + (size_t)s * n,
                             valid + (size_t)s * n, NULL, ae + (size_t)s * n, NULL, NULL);
         }
-        for (int i = 0; i < n; i++) {
-            int smin = 0;
-            real dmin = diff[i], amin = ae[i], vany = valid[i];
-            for (int s = 1; s < S; s++) {
-                if (diff[(size_t)s * n + i] < dmin) { dmin = diff[(size_t)s * n + i]; smin = s; }
-                if (ae[(size_t)s * n + i] < amin) amin = ae[(size_t)s * n + i];
-                if (valid[(size_t)s * n + i] > vany) vany = valid[(size_t)s * n + i];
-            }
-            int keep = vany > 0 && (!op->automask || dmin < amin);
-            for (int s = 0; s < S; s++) mask[(size_t)(s * B + b) * n + i] = (keep && s == smin) ? 1 : 0;
-        }
+        window_select_maps(H, W, S, diff, valid, ae, op->automask, mask + (size_t)b * n, (size_t)B * n, NULL);
     }
     free(diff); free(valid); free(ae);
 }
 
-static double cost_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
-                          const double T[12], const real *K, double log_scale, const orc_opts *op, const real *mask) {
+static double cost_masked_x(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                            const double T[12], const real *K, double log_scale, const orc_opts *op, const real *mask, const lin_ext *x) {
     int n = H * W;
     real *d = (real *)malloc(sizeof(real) * n), *va = (real *)malloc(sizeof(real) * n), *w = (real *)malloc(sizeof(real) * n);
     orc_photometric(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op->w_l1, op->w_ssim, d, va, w, NULL, NULL, NULL);
     double num = 0, den = 0, dc = 0;
-    for (int i = 0; i < n; i++) { num += mask[i] * w[i] * d[i]; den += mask[i]; dc += 1 - w[i]; }
+    for (int i = 0; i < n; i++) { num += mask[i] * (x && x->w_map ? x->w_map[i] : w[i]) * d[i]; den += mask[i]; dc += 1 - w[i]; }
     free(d); free(va); free(w);
-    return (den > 0 ? num / den : 0.0) + op->w_dc * dc / n;
+    if (x && x->norm > 0) den = x->norm;
+    const double sc = (x && x->scale > 0) ? x->scale : 1.0, b = (x && x->b_dc >= 0) ? x->b_dc : op->w_dc / n;
+    return (den > 0 ? sc * num / den : 0.0) + b * dc;
+}
+static double cost_masked(int H, int W, const real *tgt, const real *src, const real *depth_t, const real *depth_s,
+                          const double T[12], const real *K, double log_scale, const orc_opts *op, const real *mask) {
+    return cost_masked_x(H, W, tgt, src, depth_t, depth_s, T, K, log_scale, op, mask, NULL);
 }
 
-/* bits [n_lin][2SB][H*W], decide [n_lin][2SB] (layout of the engine's trace): see orc_refine_forced.  With bits the
- * min-over-sources selection is not evaluated here -- bit 0 IS the selected mask. */
-void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
-                       const real *K, const orc_opts *op, int argmin, double *pose_io /* [2SB][6] */,
+/* One evaluation of a whole window at the pairs' current transforms: the shared state the pairs' linearisations need
+ * (selection masks, and under the REFERENCE rule the batch normalisers, source 0's weight maps and the cross terms). */
+typedef struct {
+    int H, W, B, S, argmin, rule;
+    const orc_opts *op;
+    const real **pt;        /* [2SB][4] tgt, src, depth_t, depth_s of every directed pair */
+    const real *K;          /* [B][9] */
+    const real *ae;         /* [2SB][n] */
+    real *mask;             /* [2SB][n] the masks the pairs are linearised with (forward pairs: selection) -- or NULL entries unused */
+    int use_mask;           /* forward pairs are given `mask` (selection / forced) */
+    real *margin;           /* [B][n] gaps of the selection's comparisons (flip statistics) */
+    real *w0, *cross;       /* [B][n] REFERENCE rule: weight map of source 0, sum_{s != 0} M_s diff_s */
+    double Kfwd, Kinv;      /* REFERENCE rule: batch-summed mask counts of the forward / inverse pairs */
+} win_ctx;
+
+static const real *win_K(const win_ctx *c, int m) { const int SB = c->S * c->B; return c->K + 9 * ((m >= SB ? m - SB : m) % c->B); }
+
+/* masks and couplings at transforms T [2SB][12] (log scales ls [2SB]); bits: the engine's decisions of this linearisation
+ * ([2SB][n]) or NULL */
+static void window_prepare(win_ctx *c, const double *T, const double *ls, const unsigned short *bits) {
+    const int n = c->H * c->W, B = c->B, S = c->S, SB = S * B, N = 2 * SB;
+    const orc_opts *op = c->op;
+    const int sel = c->argmin && S > 1;
+    c->use_mask = sel || (bits != NULL);
+    c->Kfwd = c->Kinv = 0;
+    if (!sel && !c->rule && !bits) return;
+    real *diff = (real *)malloc(sizeof(real) * (size_t)n * S), *valid = (real *)malloc(sizeof(real) * (size_t)n * S), *wt = (real *)malloc(sizeof(real) * (size_t)n * S);
+    for (int b = 0; b < B; b++) {
+        for (int s = 0; s < S; s++) {
+            const int m = s * B + b;
+            orc_photometric(c->H, c->W, c->pt[4 * m], c->pt[4 * m + 1], c->pt[4 * m + 2], c->pt[4 * m + 3], T + 12 * m, win_K(c, m), ls[m],
+                            op->w_l1, op->w_ssim, diff + (size_t)s * n, valid + (size_t)s * n, wt + (size_t)s * n, NULL, NULL, NULL);
+        }
+        if (sel) {   /* the selection as this restatement takes it (also during a forced replay: flip statistics) */
+            real *ae_b = (real *)malloc(sizeof(real) * (size_t)n * S);
+            for (int s = 0; s < S; s++) memcpy(ae_b + (size_t)s * n, c->ae + (size_t)(s * B + b) * n, sizeof(real) * n);
+            window_select_maps(c->H, c->W, S, diff, valid, ae_b, op->automask, c->mask + (size_t)b * n, (size_t)B * n, c->margin + (size_t)b * n);
+            free(ae_b);
+        } else if (c->rule || bits) {   /* own masks of the forward pairs: validity (x auto-mask unless REFERENCE without argmin) */
+            for (int s = 0; s < S; s++)
+                for (int i = 0; i < n; i++) {
+                    const int am = op->automask && !(c->rule && !c->argmin);
+                    c->mask[(size_t)(s * B + b) * n + i] = (valid[(size_t)s * n + i] > 0 && (!am || diff[(size_t)s * n + i] < c->ae[(size_t)(s * B + b) * n + i])) ? 1 : 0;
+                    if (c->margin) c->margin[(size_t)b * n + i] = (real)1e30;
+                }
+        }
+        if (c->rule) {
+            memcpy(c->w0 + (size_t)b * n, wt, sizeof(real) * n);
+            for (int i = 0; i < n; i++) {
+                double cr = 0;
+                for (int s = 0; s < S; s++) {
+                    const int mk = bits ? (bits[(size_t)(s * B + b) * n + i] & 1) : (c->mask[(size_t)(s * B + b) * n + i] != 0);
+                    c->Kfwd += mk;
+                    if (s > 0 && mk) cr += diff[(size_t)s * n + i];
+                }
+                c->cross[(size_t)b * n + i] = (real)cr;
+            }
+        }
+    }
+    if (c->rule) {   /* inverse pairs: own masks, batch-summed */
+        for (int m = SB; m < N; m++) {
+            if (bits) { for (int i = 0; i < n; i++) c->Kinv += bits[(size_t)m * n + i] & 1; continue; }
+            orc_photometric(c->H, c->W, c->pt[4 * m], c->pt[4 * m + 1], c->pt[4 * m + 2], c->pt[4 * m + 3], T + 12 * m, win_K(c, m), ls[m],
+                            op->w_l1, op->w_ssim, diff, valid, NULL, NULL, NULL, NULL);
+            for (int i = 0; i < n; i++) c->Kinv += (valid[i] > 0 && (!op->automask || diff[i] < c->ae[(size_t)m * n + i])) ? 1 : 0;
+        }
+    }
+    free(diff); free(valid); free(wt);
+}
+
+/* the coupling of pair m to its window (REFERENCE rule), or NULL */
+static const lin_ext *window_ext(const win_ctx *c, int m, lin_ext *x) {
+    if (!c->rule) return NULL;
+    const int n = c->H * c->W, B = c->B, SB = c->S * B, fwd = m < SB, b = (fwd ? m : m - SB) % B, s = (fwd ? m : m - SB) / B;
+    memset(x, 0, sizeof(*x));
+    x->b_dc = c->op->w_dc / ((double)SB * n);
+    if (fwd) {
+        x->norm = c->Kfwd;
+        if (c->argmin) {   /* optimizer.py:69 (with S == 1 the minimum is the pair itself and source 0's weight its own) */
+            x->scale = 1.0;
+            if (s > 0) x->w_map = c->w0 + (size_t)b * n; else if (c->S > 1) x->cross = c->cross + (size_t)b * n;
+        } else { x->scale = 0.25; x->no_automask = 1; }
+    } else { x->norm = c->Kinv; x->scale = 0.25; }
+    if (!(x->norm > 0)) x->norm = 1;   /* nothing selected anywhere: the sums are zero too */
+    return x;
+}
+
+/* bits [n_lin][2SB][H*W], decide [n_lin][2SB] (layout of the engine's trace): see orc_refine_forced.  With bits bit 0 IS the
+ * mask every pair is linearised with; the selection is still evaluated here, for the flip statistics only. */
+void orc_refine_window_rule(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, int argmin, int rule, double *pose_io /* [2SB][6] */,
                        double *log_scale_io /* [2SB] or NULL */, double *stats /* [2SB][n_iters+1][4] or NULL */,
-                       const unsigned short *bits, const int *decide) {
-    const int n = H * W, np = op->nparam, SB = S * B, N = 2 * SB, sel = argmin && S > 1 && !bits;
+                       const unsigned short *bits, const int *decide, lin_t *lin_out /* [2SB] or NULL: export the FIRST linearisation and return */) {
+    const int n = H * W, np = op->nparam, SB = S * B, N = 2 * SB;
     typedef struct { double Tcur[12], Ttry[12], scur, stry, s0, lambda; lin_t cur; int have_cur; } pstate;
     pstate *ps = (pstate *)calloc(N, sizeof(pstate));
-    real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
-    double *Tf = (double *)malloc(sizeof(double) * 12 * SB), *lsf = (double *)malloc(sizeof(double) * SB);
+    real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *mask = (real *)malloc(sizeof(real) * (size_t)n * SB);
+    double *Tf = (double *)malloc(sizeof(double) * 12 * N), *lsf = (double *)malloc(sizeof(double) * N);
     const real **pt = (const real **)malloc(sizeof(real *) * N * 4);
+    win_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.H = H; c.W = W; c.B = B; c.S = S; c.argmin = argmin; c.rule = rule; c.op = op; c.pt = pt; c.K = K; c.ae = ae; c.mask = mask;
+    c.margin = (real *)malloc(sizeof(real) * (size_t)n * B);
+    c.w0 = (real *)malloc(sizeof(real) * (size_t)n * B); c.cross = (real *)malloc(sizeof(real) * (size_t)n * B);
     for (int m = 0; m < N; m++) {
         int inv = m >= SB, q = inv ? m - SB : m, b = q % B;
         const real *ti = tgt + (size_t)b * 3 * n, *si = srcs + (size_t)q * 3 * n, *td = depth_t + (size_t)b * n, *sd = depth_s + (size_t)q * n;
@@ -956,32 +1127,54 @@ void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const
     for (int it = 0; it <= op->n_iters; it++) {
         const int final = it == op->n_iters;
         if (final && !(op->solver == 1 && op->n_iters > 0)) break;
-        if (sel) {
-            for (int m = 0; m < SB; m++) { memcpy(Tf + 12 * m, ps[m].Ttry, sizeof(double) * 12); lsf[m] = ps[m].stry; }
-            orc_window_select(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, Tf, lsf, mask);
-        }
+        for (int m = 0; m < N; m++) { memcpy(Tf + 12 * m, ps[m].Ttry, sizeof(double) * 12); lsf[m] = ps[m].stry; }
+        window_prepare(&c, Tf, lsf, bits ? bits + (size_t)it * N * n : NULL);
         for (int m = 0; m < N; m++) {
             pstate *p = &ps[m];
-            const real *mk = (sel && m < SB) ? mask + (size_t)m * n : NULL;
-            const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
+            const real *mk = (c.use_mask && m < SB && (argmin && S > 1)) ? mask + (size_t)m * n : NULL;
+            const real *Km = win_K(&c, m);
+            lin_ext xs;
+            const lin_ext *x = window_ext(&c, m, &xs);
             double *st = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
             const double prior = pw * (p->stry - p->s0) * (p->stry - p->s0);
             const unsigned short *fb = bits ? bits + ((size_t)it * N + m) * n : NULL;
             const int *dec = decide ? decide + (size_t)it * N + m : NULL;
             if (final) { /* LM: cost-only check of the last trial step */
-                double c = (fb ? cost_forced(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, fb)
-                            : mk ? cost_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, mk)
-                               : orc_cost(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op)) + prior;
-                if (st) { st[0] = c; st[1] = c; st[2] = 0; st[3] = p->lambda; }
-                if (dec ? *dec != 0 : c < p->cur.cost) { memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; }
+                double cst;
+                if (fb) {
+                    real *fm = (real *)malloc(sizeof(real) * n);
+                    for (int i = 0; i < n; i++) fm[i] = (real)(fb[i] & 1);
+                    g_force_bits = fb;
+                    cst = cost_masked_x(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, fm, x);
+                    g_force_bits = NULL;
+                    free(fm);
+                } else if (mk || x) {
+                    real *om = NULL;
+                    if (!mk) {   /* REFERENCE rule, own mask: evaluate it */
+                        om = (real *)malloc(sizeof(real) * n);
+                        real *d = (real *)malloc(sizeof(real) * n), *va = (real *)malloc(sizeof(real) * n);
+                        orc_photometric(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op->w_l1, op->w_ssim, d, va, NULL, NULL, NULL, NULL);
+                        const int am = op->automask && !(x && x->no_automask);
+                        for (int i = 0; i < n; i++) om[i] = (va[i] > 0 && (!am || d[i] < ae[(size_t)m * n + i])) ? 1 : 0;
+                        free(d); free(va);
+                    }
+                    cst = cost_masked_x(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, mk ? mk : om, x);
+                    free(om);
+                } else cst = orc_cost(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op);
+                cst += prior;
+                if (st) { st[0] = cst; st[1] = cst; st[2] = 0; st[3] = p->lambda; }
+                if (dec ? *dec != 0 : cst < p->cur.cost) { memcpy(p->Tcur, p->Ttry, sizeof(p->Tcur)); p->scur = p->stry; }
                 continue;
             }
             lin_t tr;
             g_force_bits = fb;
-            linearize_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, ae + (size_t)m * n, mk,
+            g_lin_idx = fb ? it : -1;
+            g_sel_margin = (mk && fb) ? c.margin + (size_t)(m % B) * n : NULL;
+            linearize_masked(H, W, pt[4 * m], pt[4 * m + 1], pt[4 * m + 2], pt[4 * m + 3], p->Ttry, Km, p->stry, op, ae + (size_t)m * n, mk, x,
                              &tr, NULL, NULL, NULL, NULL, NULL);
-            g_force_bits = NULL;
+            g_force_bits = NULL; g_lin_idx = -1; g_sel_margin = NULL;
             if (np == 7) { tr.cost += prior; tr.g[6] += 2 * pw * (p->stry - p->s0); tr.H[6 * np + 6] += 2 * pw; }
+            if (lin_out) lin_out[m] = tr;
             if (st) { st[0] = tr.cost; st[1] = tr.cost_photo; st[2] = tr.n_mask; st[3] = p->lambda; }
             if (op->solver == 0 || !p->have_cur || (dec ? *dec != 0 : tr.cost < p->cur.cost)) {
                 if (op->solver == 1 && p->have_cur) p->lambda = fmax(p->lambda * op->lambda_down, op->lambda_min);
@@ -991,18 +1184,40 @@ void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const
             }
             apply_step(op, p->cur.H, p->cur.g, p->lambda, p->Tcur, p->scur, p->Ttry, &p->stry);
         }
+        if (lin_out) break;
     }
-    for (int m = 0; m < N; m++) {
-        if (!(op->solver == 1 && op->n_iters > 0)) { memcpy(ps[m].Tcur, ps[m].Ttry, sizeof(ps[m].Tcur)); ps[m].scur = ps[m].stry; }
-        orc_T_to_pose(ps[m].Tcur, pose_io + 6 * m);
-        if (np == 7 && log_scale_io) log_scale_io[m] = ps[m].scur;
-    }
-    free(ps); free(ae); free(mask); free(Tf); free(lsf); free(pt);
+    if (!lin_out)
+        for (int m = 0; m < N; m++) {
+            if (!(op->solver == 1 && op->n_iters > 0)) { memcpy(ps[m].Tcur, ps[m].Ttry, sizeof(ps[m].Tcur)); ps[m].scur = ps[m].stry; }
+            orc_T_to_pose(ps[m].Tcur, pose_io + 6 * m);
+            if (np == 7 && log_scale_io) log_scale_io[m] = ps[m].scur;
+        }
+    free(ps); free(ae); free(mask); free(Tf); free(lsf); free(pt); free(c.margin); free(c.w0); free(c.cross);
+}
+
+void orc_refine_window_forced(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                       const real *K, const orc_opts *op, int argmin, double *pose_io, double *log_scale_io, double *stats,
+                       const unsigned short *bits, const int *decide) {
+    orc_refine_window_rule(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, 0, pose_io, log_scale_io, stats, bits, decide, NULL);
 }
 
 void orc_refine_window(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
                        const real *K, const orc_opts *op, int argmin, double *pose_io, double *log_scale_io, double *stats) {
-    orc_refine_window_forced(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, pose_io, log_scale_io, stats, NULL, NULL);
+    orc_refine_window_rule(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, 0, pose_io, log_scale_io, stats, NULL, NULL, NULL);
+}
+
+/* one linearisation of a whole window at the given poses: normal equations, cost and mask count of every directed pair */
+void orc_linearize_window(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                          const real *K, const orc_opts *op, int argmin, int rule, const double *pose /* [2SB][6] */,
+                          const double *log_scale /* [2SB] or NULL */, lin_t *out /* [2SB] */) {
+    const int N = 2 * S * B;
+    double *p = (double *)malloc(sizeof(double) * 6 * N), *ls = log_scale ? (double *)malloc(sizeof(double) * N) : NULL;
+    memcpy(p, pose, sizeof(double) * 6 * N);
+    if (ls) memcpy(ls, log_scale, sizeof(double) * N);
+    orc_opts o1 = *op;
+    if (o1.n_iters < 1) o1.n_iters = 1;
+    orc_refine_window_rule(H, W, B, S, tgt, srcs, depth_t, depth_s, K, &o1, argmin, rule, p, ls, NULL, NULL, NULL, out);
+    free(p); free(ls);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1065,10 +1280,15 @@ static void linearize_dense_masked(int H, int W, const real *tgt, const real *sr
             }
             real sum = P->cd + P->pd, raw = fabs(P->cd - P->pd) / sum;
             diffm[i] = e; Wm[i] = 1 - clamp01(raw);
-            real m = (real)P->valid;
+            real m = (real)P->nat_valid;
             if (op->automask) m *= (e < ae[i]) ? (real)1 : (real)0;
             if (mask_in) m = mask_in[i];   /* window mode: min-over-sources selection */
-            if (g_force_bits) m = (real)(g_force_bits[i] & 1);
+            if (g_force_bits) {
+                const int fm = g_force_bits[i] & 1;
+                flip_note(m, fm, mask_in ? (g_sel_margin ? g_sel_margin[i] < ORC_TIE : 1)
+                                         : (P->nat_valid != P->valid) || (op->automask && fabs(e - ae[i]) < ORC_TIE));
+                m = (real)fm;
+            } else if (!mask_in) m = (real)P->valid * (op->automask ? ((e < ae[i]) ? (real)1 : (real)0) : (real)1);
             if (g_record_bits) g_record_bits[i] = (unsigned short)((g_record_bits[i] & ~1) | (m != 0 ? 1 : 0));
             M[i] = m; nmask += m; num += (double)m * Wm[i] * e;
         }
@@ -1272,7 +1492,7 @@ void orc_refine_dense_window_forced(int H, int W, int B, int S, const real *tgt,
                              const real *K, const orc_opts *op, int argmin, double lambda_depth, double w_prior, double min_depth,
                              double max_depth, double *pose_io /* [2SB][6] */, double *stats /* [2SB][n_iters+1][4] or NULL */,
                              const unsigned short *bits /* [n_lin][2SB][H*W] */, const int *decide /* [n_lin][2SB] */) {
-    const int n = H * W, SB = S * B, N = 2 * SB, sel = argmin && S > 1 && !bits;
+    const int n = H * W, SB = S * B, N = 2 * SB, sel = argmin && S > 1;   /* (forced replay: evaluated for the flip statistics only) */
     real *ae = (real *)malloc(sizeof(real) * (size_t)n * N), *d0 = (real *)malloc(sizeof(real) * (size_t)n * N);
     real *mask = sel ? (real *)malloc(sizeof(real) * (size_t)n * SB) : NULL;
     real *diff = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL, *valid = sel ? (real *)malloc(sizeof(real) * (size_t)n * S) : NULL;
@@ -1295,9 +1515,10 @@ void orc_refine_dense_window_forced(int H, int W, int B, int S, const real *tgt,
             const real *Km = K + 9 * ((m >= SB ? m - SB : m) % B);
             lin_t L;
             g_force_bits = bits ? bits + ((size_t)it * N + m) * n : NULL;
+            g_lin_idx = bits ? it : -1;
             linearize_dense_masked(H, W, img[2 * m], img[2 * m + 1], st[m].dep_try, depth_src + (size_t)m * n, st[m].Ttry, Km, op, ae + (size_t)m * n,
                                    (sel && m < SB) ? mask + (size_t)m * n : NULL, lambda_depth, w_prior, d0 + (size_t)m * n, &L, st[m].gr, st[m].Dq, st[m].Bq);
-            g_force_bits = NULL;
+            g_force_bits = NULL; g_lin_idx = -1;
             double *row = stats ? stats + ((size_t)m * (op->n_iters + 1) + it) * 4 : NULL;
             const int *dec = decide ? decide + (size_t)it * N + m : NULL;
             if (final) dense_state_finish(&st[m], op, &L, pose_io + 6 * m, row, dec);
@@ -1333,8 +1554,9 @@ void orc_refine_dense_forced(int H, int W, const real *tgt, const real *src, rea
         if (final && !lm_final) break;
         lin_t L;
         g_force_bits = bits ? bits + (size_t)it * n : NULL;
+        g_lin_idx = bits ? it : -1;
         orc_linearize_dense(H, W, tgt, src, st.dep_try, depth_s, st.Ttry, K, op, ae, lambda_depth, w_prior, d0, &L, st.gr, st.Dq, st.Bq);
-        g_force_bits = NULL;
+        g_force_bits = NULL; g_lin_idx = -1;
         const int *dec = decide ? decide + it : NULL;
         if (final) dense_state_finish(&st, op, &L, pose_io, stats ? stats + 4 * it : NULL, dec);
         else dense_state_step(&st, op, &L, lambda_depth, min_depth, max_depth, stats ? stats + 4 * it : NULL, dec);

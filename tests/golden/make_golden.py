@@ -23,6 +23,8 @@ Goldens (SURVEY.md section 8c naming):
   G9 one DepthOptimizer.optimize_window (optimize_depth_pred, 5 epochs, stand-in nets): result-dict schema + the values
      that do not depend on the optimiser (initial poses, depths, flip-averaged disparity)   optimizer.py:136-297
   G10 ScaleRecovery                                                   models/dnet_layers.py:249-327
+  G13 compute_optimization_loss with S = 2 sources and its autograd gradients w.r.t. the poses of all directed pairs, the SHARED
+      target depth and the source depths; term by term (forward / + inverse / + depth consistency / without argmin)   optimizer.py:29-134
   G11 validate.compute_trajectory run on this package's stand-ins for the absent liegroups / pyslam (pins the
       composition order, the error bookkeeping and the rounding of the reference code; the SE(3) and metric arithmetic
       itself stays unpinned)                                          validate.py:61-103
@@ -225,6 +227,66 @@ def main():
         g4["loss_disp"] = N(disp); g4["loss_disp0"] = N(o.target_disparity)
     out["batch24x40"] = g4
 
+    # ------------------------------------------------------------------ G13: the window loss and its autograd gradients (S = 2)
+    # compute_optimization_loss (optimizer.py:29-134) on the outputs of solve_pose_iteratively (train_mono.py:41-120) with a stand-in
+    # PoseNet whose output IS a leaf tensor: loss.backward() gives d loss / d pose of all 2 S B directed pairs, and -- the depth
+    # maps being leaves too -- d loss / d depth of the SHARED target depth (it feeds every forward pair, train_mono.py:56) and of
+    # the source depths.  Variants isolate the terms: forward term alone (:47-69), + inverse (:75-81), + depth consistency (:83-86),
+    # and the same without the min over the sources (:71-73).
+    class LeafPose(nn.Module):
+        def __init__(self, first):
+            super().__init__(); self.first = first
+        def forward(self, x):
+            return self.first
+
+    for tagsz, (B13, S13, H13, W13) in (("24x40", (2, 2, 24, 40)), ("48x160", (1, 2, 48, 160))):
+        reset_grid()
+        tg, srcs, dts, dss, Ks, pgt = [], [[] for _ in range(S13)], [], [[] for _ in range(S13)], [], [[] for _ in range(S13)]
+        for b in range(B13):
+            for si in range(S13):
+                sign = 1.0 if si == 0 else -1.0
+                base = np.array([0.003, -0.002, 0.033, 0.002, -0.004, 0.0015]) * sign
+                p = synth.make_pair(H13, W13, seed=130 + b, pose_gt=base, dtype=np.float64)
+                if si == 0:
+                    tg.append(p["tgt"]); dts.append(p["depth_t"]); Ks.append(p["K"])
+                # the source depth maps are made mildly inconsistent with the geometry so that the depth-consistency weights
+                # (train_mono.py:91-92) are non-trivial and differ between the sources
+                srcs[si].append(p["src"]); dss[si].append(p["depth_s"] * (1.0 + 0.06 * (si + 1) * np.sin(np.arange(W13) / (5.0 + 2 * si))[None, :])); pgt[si].append(p["pose_gt"])
+        rng13 = np.random.default_rng(13)
+        gt_f = np.concatenate([np.stack(x) for x in pgt])
+        first = np.concatenate([gt_f, -gt_f]) + rng13.normal(scale=1.5e-3, size=(2 * S13 * B13, 6))
+        g13 = dict(target=np.stack(tg), sources=np.stack([np.stack(x) for x in srcs]), depth_t=np.stack(dts)[:, None],
+                   depth_s=np.stack([np.stack(x) for x in dss])[:, :, None], K=np.stack(Ks), first=first)
+        dt = torch.float64
+        base_opts = {'epochs': 20, 'diff_img_argmin': True, 'automasking': True, 'l_depth_consist': False,
+                     'l_depth_consist_weight': 0.15, 'l_depth_init': False, 'l_depth_init_weight': 0.1,
+                     'l_inverse_reconstruction': False, 'l_smooth': False, 'l_smooth_weight': 2,
+                     'l_pose_consist': False, 'num_source_imgs': S13, 'plotting': False}
+        DO = ref["optimizer"].DepthOptimizer
+        for tag, upd in (("fwd", {}), ("fwd_inv", {'l_inverse_reconstruction': True}),
+                         ("full", {'l_inverse_reconstruction': True, 'l_depth_consist': True}),
+                         ("noargmin_full", {'diff_img_argmin': False, 'l_inverse_reconstruction': True, 'l_depth_consist': True}),
+                         ("noauto_fwd", {'automasking': False})):
+            fp = T(first, dt).clone().requires_grad_()
+            d_t = T(g13["depth_t"], dt).clone().requires_grad_()
+            d_s = [T(g13["depth_s"][i], dt).clone().requires_grad_() for i in range(S13)]
+            poses, poses_inv, outputs = ref["train_mono"].solve_pose_iteratively(1, [d_t] + d_s, LeafPose(fp), T(g13["target"], dt),
+                                                                                [T(g13["sources"][i], dt) for i in range(S13)], T(g13["K"], dt), return_errors=True)
+            o = object.__new__(DO)
+            o.options = dict(base_opts, **upd); o.ssim_loss = losses.SSIM_Loss()
+            loss = DO.compute_optimization_loss(o, 0, 0, T(g13["target"], dt), None, outputs['fwd'], outputs['inv']).reshape(-1)[0]
+            loss.backward()
+            g13[f"{tag}_loss"] = np.array(loss.item())
+            g13[f"{tag}_grad_pose"] = N(fp.grad)
+            if tag in ("fwd", "full"):
+                g13[f"{tag}_grad_depth_t"] = N(d_t.grad[:, 0])
+                g13[f"{tag}_grad_depth_s"] = np.stack([N(x.grad[:, 0]) for x in d_s])
+            if tag == "full":
+                for d in ("fwd", "inv"):
+                    for k in ("diff_img", "valid_mask", "weight_mask", "auto_mask_error"):
+                        g13[f"{d}_{k}"] = N(outputs[d][k][:, 0])
+        out[f"winloss{tagsz}"] = g13
+
     # ------------------------------------------------------------------ G7: loss-surface sweeps (f32, as the reference runs it)
     H, W, seed = 48, 160, 5
     p = synth.make_pair(H, W, seed=seed, dtype=np.float32)
@@ -394,7 +456,10 @@ def main():
         full[f"{dtn}_mask_sub"] = N(r["valid_mask"][0, 0, ::7, ::7]); full[f"{dtn}_rec_sub"] = N(r["img_rec"][0, :, ::7, ::7])
     out["full192x640"] = full
 
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]      # `make_golden.py winloss24x40 ...`: write only these fixtures
     for name, d in out.items():
+        if only and name not in only:
+            continue
         path = os.path.join(HERE, f"golden_{name}.npz")
         np.savez_compressed(path, **d)
         print(f"{name:14s} {os.path.getsize(path) / 1024:8.1f} KiB  keys={len(d)}")

@@ -12,9 +12,13 @@ problems.  Instead of loosening the tolerance in such cases, every iterate-level
       relative on translation, rotation, depth scale, per-pixel depth) in EVERY case.  Measured effect of NOT replaying: three
       texel-boundary ties in 4 iterations of a 96x320 pair move the weakest rotation component by 3.5e-4 (reproduced on the CPU
       by flipping those three bits in the oracle's own trace);
-  (2) DECISIONS: the engine's decisions themselves are checked against the oracle's own: at the first linearisation (same pose on
-      both sides) every flipped pixel must be a near-tie and their number is bounded; every LM decision that differs from what the
-      oracle's costs imply must be a near-tie of the two costs.
+  (2) DECISIONS: the engine's decisions themselves are checked against the oracle's own AT EVERY LINEARISATION: while it replays, the
+      oracle also takes every mask decision itself at its (replayed) iterate and counts the pixels it would have decided
+      differently, and those of them that are not near-ties (Oracle.flip_stats; the iterates agree to ~1e-6, so beyond ties the
+      decisions must agree -- a kernel bug that corrupts masks only after the first pose update, e.g. a stale PairConst or a
+      wrong ping-pong buffer, fails here at linearisation >= 1): none may be hard, and their number is bounded; at the first
+      linearisation additionally against Oracle.photometric; every LM decision that differs from what the oracle's costs imply
+      must be a near-tie of the two costs.
 """
 import numpy as np
 
@@ -84,6 +88,15 @@ def check_first_masks(bits0, ph, automask, tag=None, max_frac=1e-3):
     return int(flip.sum())
 
 
+def check_flips_every_linearisation(orc, nit, pixels, tag=None, max_frac=1e-3):
+    """after forced replays covering `pixels` mask decisions per linearisation: per linearisation, no hard (non-tie) flip and at
+    most 2 + max_frac * pixels flips in all -> total number of flips"""
+    fn, fh = orc.flip_stats(nit)
+    assert not fh.any(), (tag, "non-tie mask flips per linearisation", fh.tolist(), fn.tolist())
+    assert np.all(fn <= 2 + max_frac * pixels), (tag, fn.tolist(), pixels)
+    return int(fn.sum())
+
+
 def replay_pairs(e, orc, b, o, oopts, tdev, log_scale=None, pose_key="pose_init", first_masks=True):
     """N directed pairs through Engine.refine with the decision trace on, then the oracle replay per pair.
     b: synth batch (numpy); o: engine opts; oopts: oracle opts; tdev: numpy -> cuda tensor.  -> dict of results"""
@@ -97,6 +110,7 @@ def replay_pairs(e, orc, b, o, oopts, tdev, log_scale=None, pose_key="pose_init"
     pose, st = pose.cpu().numpy().astype(np.float64), st.cpu().numpy()
     ls = ls.cpu().numpy() if refine else None
     out = dict(pose=pose, stats=st, bits=bits, decide=dec, log_scale=ls, ref_pose=[], ref_stats=[], mask_flips=0, lm_flips=0)
+    orc.flip_stats_reset()
     for n in range(N):
         a = (b["tgt"][n], b["src"][n], b["depth_t"][n, 0], b["depth_s"][n, 0], b[pose_key][n], b["K"][n])
         s0 = float(log_scale[n]) if refine else 0.0
@@ -113,6 +127,7 @@ def replay_pairs(e, orc, b, o, oopts, tdev, log_scale=None, pose_key="pose_init"
             ph = orc.photometric(*a[:4], a[4], a[5], log_scale=s0, w_l1=float(o.w_l1), w_ssim=float(o.w_ssim))
             out["mask_flips"] += check_first_masks(bits[0, n], ph, int(o.automask), ("pair", n))
         out["ref_pose"].append(rp); out["ref_stats"].append(rst)
+    out["flips_all_lin"] = check_flips_every_linearisation(orc, nit, N * bits.shape[-1] * bits.shape[-2], "pairs")
     return out
 
 
@@ -128,7 +143,7 @@ def window_pair_views(w):
     return out
 
 
-def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale=None, max_flip_frac=2e-3):
+def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale=None, max_flip_frac=2e-3, rule=0):
     """a window (B targets x S sources -> 2*S*B directed pairs) through Engine.refine_window / refine_dense_window with the
     decision trace on, then ONE oracle replay of the whole window.  w: dict(target, sources, depth_t, depth_s, K, first)."""
     S, B = w["sources"].shape[:2]
@@ -148,14 +163,16 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
         ls = ls.cpu().numpy() if refine else None
     bits, dec = e.trace_end()
     pose, st = pose.cpu().numpy().astype(np.float64), st.cpu().numpy()
+    orc.flip_stats_reset()
     if dense:
         rp, rd, rst = orc.refine_dense_window(*oargs, oopts, argmin=argmin, lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth),
                                               min_depth=float(o.min_depth), max_depth=float(o.max_depth), bits=bits, decide=dec)
         rls = None
     else:
         rp, rls, rst = orc.refine_window(*oargs, oopts, argmin=argmin, log_scale=np.asarray(log_scale, np.float64) if refine else None,
-                                         bits=bits, decide=dec)
+                                         bits=bits, decide=dec, rule=rule)
         rd = None
+    flips_all = check_flips_every_linearisation(orc, nit, N * H * W, "window", max_frac=max_flip_frac)
     rows = nit + (1 if int(o.solver) == 1 and nit > 0 else 0)
     lm_flips = 0
     for n in range(N):
@@ -188,7 +205,7 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
         flips = int(flip.sum())
         assert flips <= 2 * N + max_flip_frac * flip.size, (flips, flip.sum((1, 2)))
     return dict(pose=pose, stats=st, bits=bits, decide=dec, depth=depth, ref_pose=rp, ref_stats=rst, ref_depth=rd, log_scale=ls,
-                mask_flips=flips, lm_flips=lm_flips)
+                mask_flips=flips, lm_flips=lm_flips, flips_all_lin=flips_all)
 
 
 def replay_dense_pairs(e, orc, b, d0, o, oopts, tdev, pose_key="pose_init", poses=None):
@@ -202,6 +219,7 @@ def replay_dense_pairs(e, orc, b, d0, o, oopts, tdev, pose_key="pose_init", pose
     pose, depth, st = pose.cpu().numpy().astype(np.float64), depth.cpu().numpy()[:, 0], st.cpu().numpy()
     rows = nit + (1 if int(o.solver) == 1 and nit > 0 else 0)
     out = dict(pose=pose, depth=depth, stats=st, bits=bits, decide=dec, ref_pose=[], ref_depth=[], ref_stats=[], mask_flips=0, lm_flips=0)
+    orc.flip_stats_reset()
     for n in range(N):
         rp, rd, rst = orc.refine_dense(b["tgt"][n], b["src"][n], d0[n, 0], b["depth_s"][n, 0], p0[n], b["K"][n], oopts,
                                        lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth), min_depth=float(o.min_depth),
@@ -215,4 +233,5 @@ def replay_dense_pairs(e, orc, b, d0, o, oopts, tdev, pose_key="pose_init", pose
             ph = orc.photometric(b["tgt"][n], b["src"][n], d0[n, 0], b["depth_s"][n, 0], p0[n], b["K"][n], w_l1=float(o.w_l1), w_ssim=float(o.w_ssim))
             out["mask_flips"] += check_first_masks(bits[0, n], ph, int(o.automask), ("dense pair", n))
         out["ref_pose"].append(rp); out["ref_depth"].append(rd); out["ref_stats"].append(rst)
+    out["flips_all_lin"] = check_flips_every_linearisation(orc, nit, N * bits.shape[-1] * bits.shape[-2], "dense pairs")
     return out

@@ -18,8 +18,11 @@ def test_replay_of_own_decisions_is_the_identity(oracle64, kw):
     p0, l0, s0 = oracle64.refine(*a, default_opts(**kw), log_scale=0.02)
     p1, l1, s1, bits, dec = oracle64.refine_record(*a, default_opts(**kw), log_scale=0.02)
     assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+    oracle64.flip_stats_reset()
     p2, l2, s2 = oracle64.refine(*a, default_opts(**kw), log_scale=0.02, bits=bits, decide=dec)
     assert np.array_equal(p0, p2) and l0 == l2 and np.array_equal(s0, s2)
+    fn, fh = oracle64.flip_stats(kw["n_iters"])
+    assert not fn.any() and not fh.any()          # replaying its own decisions, the oracle would have decided the same at EVERY linearisation
     n_it = kw["n_iters"]
     assert np.array_equal((bits[:n_it] & 1).sum((1, 2)), s0[:n_it, 2])           # bit 0 is the mask the cost was taken over
     assert bits.shape[0] == n_it + (1 if kw.get("solver") == 1 else 0)
@@ -42,8 +45,12 @@ def test_replay_obeys_edited_decisions(oracle64):
     kw = dict(solver=1, lambda0=1e-3, n_iters=5)
     p1, _, s1, bits, dec = oracle64.refine_record(*a, default_opts(**kw))
     drop = bits.copy(); drop[:, 5:12, 5:30] &= 0xFFFE                                  # take a block of pixels out of every mask
+    oracle64.flip_stats_reset()
     p2, _, s2 = oracle64.refine(*a, default_opts(**kw), bits=drop, decide=dec)
     assert s2[0, 2] < s1[0, 2] and np.abs(p2 - p1).max() > 1e-6
+    fn, fh = oracle64.flip_stats(5)               # ... which the flip statistics report at every linearisation, as hard (non-tie) flips:
+    assert np.all(fn == s1[0, 2] - s2[0, 2]) or np.all(fn > 0.5 * (s1[0, 2] - s2[0, 2]))      # (later iterates: the masks have moved a little)
+    assert np.all(fh > 0.8 * fn)                  # what a kernel that corrupts masks after the first pose update would look like
     inval = bits.copy(); inval[:, 5:12, 5:30] = 0                                 # ... and declare them invalid: their samples become zero,
     p3, _, s3 = oracle64.refine(*a, default_opts(**kw), bits=inval, decide=dec)   # which the SSIM windows of their neighbours see
     assert s3[0, 2] == s2[0, 2] and abs(s3[0, 0] - s2[0, 0]) > 1e-9

@@ -278,6 +278,60 @@ def test_window_mode_reduces_to_pair_mode(oracle64):
     assert _maxabs(pa[:S * B], pw[:S * B]) > 1e-7
 
 
+G13_VARIANTS = (("fwd", dict(w_dc=0.0), True, "fwd"), ("fwd_inv", dict(w_dc=0.0), True, "all"), ("full", dict(w_dc=0.15), True, "all"),
+                ("noargmin_full", dict(w_dc=0.15), False, "all"), ("noauto_fwd", dict(w_dc=0.0, automask=0), True, "fwd"))
+
+
+@pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
+def test_window_reference_rule_vs_reference_loss_G13(name, oracle64):
+    """The REFERENCE window rule (tcsfm_opts.window_rule = 1): the scalar the window refinement minimises IS the reference's
+    compute_optimization_loss (optimizer.py:47-86; batch-summed normalisers, source 0's weight map on every forward pixel,
+    0.25 x inverse term, depth consistency averaged over all pairs) and every pair's gradient is the reference's autograd
+    gradient w.r.t. that pair's pose -- golden G13: S = 2 sources, term by term, with and without the min over the sources."""
+    g = load_golden(name)
+    S, B = g["sources"].shape[:2]
+    SB = S * B
+    for tag, kw, argmin, which in G13_VARIANTS:
+        # irls_eps -> 0: the Huberisation of the depth-consistency gradient (a documented deviation) is switched off for the pin
+        op = default_opts(n_iters=1, irls_eps=1e-12, **kw)
+        L = oracle64.linearize_window(g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"], op,
+                                      argmin=argmin, rule=1)
+        nn = SB if which == "fwd" else 2 * SB
+        ref_loss, ref_grad = float(g[f"{tag}_loss"]), g[f"{tag}_grad_pose"]
+        assert abs(L["cost"][:nn].sum() - ref_loss) < 1e-12 * ref_loss, (tag, L["cost"][:nn].sum(), ref_loss)
+        gp = np.stack([oracle64.euler_left_jacobian(g["first"][m]).T @ L["g"][m] for m in range(2 * SB)])
+        assert _maxabs(gp[:nn], ref_grad[:nn]) < 1e-11 * np.abs(ref_grad).max(), (tag, _maxabs(gp[:nn], ref_grad[:nn]))
+        if which == "fwd":
+            assert _maxabs(ref_grad[SB:], 0) == 0           # (the forward term does not see the inverse poses)
+    # the fixture exercises what the rule is about: the two sources' weight maps differ, and both sources win pixels
+    w = g["fwd_weight_mask"].reshape(S, B, *g["target"].shape[2:])
+    assert np.abs(w[0] - w[1]).mean() > 1e-3
+    # ... and the per-pair rule (0) minimises a DIFFERENT scalar: its costs do not add up to the reference's loss
+    op = default_opts(n_iters=1, irls_eps=1e-12, w_dc=0.15)
+    L0 = oracle64.linearize_window(g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"], op, argmin=True, rule=0)
+    assert abs(L0["cost"].sum() - float(g["full_loss"])) > 1e-3
+
+
+def test_window_reference_rule_refines_and_reduces(oracle64):
+    """rule 1 with one source and one target is the per-pair problem up to the constant factors of the reference's loss (they
+    cancel in a Marquardt-damped step); with S = 2 it lowers the reference's loss"""
+    g = load_golden("winloss24x40")
+    S, B = g["sources"].shape[:2]
+    SB = S * B
+    a = (g["target"][:1], g["sources"][:1, :1], g["depth_t"][:1, 0], g["depth_s"][:1, :1, 0], g["K"][:1], g["first"][[0, SB]])
+    o = default_opts(n_iters=3)
+    p0, _, _ = oracle64.refine_window(*a, o, argmin=True, rule=0)
+    p1, _, _ = oracle64.refine_window(*a, o, argmin=True, rule=1)
+    assert _maxabs(p0, p1) < 1e-9
+    full = (g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"])
+    o = default_opts(n_iters=4, w_dc=0.15)
+    p, _, st = oracle64.refine_window(*full, g["first"], o, argmin=True, rule=1)
+    before = oracle64.linearize_window(*full, g["first"], o, argmin=True, rule=1)["cost"].sum()
+    after = oracle64.linearize_window(*full, p, o, argmin=True, rule=1)["cost"].sum()
+    assert after < 0.9 * before, (before, after)
+    assert abs(st[:, 0, 0].sum() - before) < 1e-12
+
+
 def test_torch_twin_vs_reference_golden():
     """oracle/torch_twin.py (the reference-style Adam/autograd step that bench.py times on the host cores) against the
     reference's own float64 outputs: maps, cost and autograd gradient (goldens G1-G3, G6)"""
