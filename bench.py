@@ -191,7 +191,7 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("TCSFM_BENCH_FORCE_DIST"))     # (forced: the RCCL path on ONE rank, tests/test_gpu_bench.py)
     # rehearsal switches (tests/test_gpu_bench.py): several ranks sharing ONE card over gloo -- RCCL refuses duplicate devices
     backend = os.environ.get("TCSFM_BENCH_BACKEND", "nccl")
     if os.environ.get("TCSFM_BENCH_ONE_DEVICE"):
@@ -208,7 +208,7 @@ def main():
     from tightly_coupled_sfm_amd import synth
     from tightly_coupled_sfm_amd.engine import Engine, default_opts
 
-    B = args.windows_per_gpu or (8 if distributed else 1)
+    B = args.windows_per_gpu or (8 if world > 1 else 1)
     if args.total_windows:
         assert args.total_windows % world == 0, "--total-windows must be a multiple of the number of ranks"
         B = args.total_windows // world
@@ -396,7 +396,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
                        "global_batch_frame_pairs": B * world, "gn_iters": ITERS, "solver": "gn", "param": "se3",
-                       "steps_in_flight": lanes,
+                       "steps_in_flight": lanes, "collective_backend": backend if distributed else None,
                        "parallelism": f"{world} independent shards, no data-path collective; one all_gather of the poses after the timed region"},
             "timed_blocks": len(blocks),
             "ms_per_step_blocks": {"min": round(blocks[0] / args.steps * 1e3, 5), "median": round(elapsed / args.steps * 1e3, 5),

@@ -51,6 +51,22 @@ enum { TCSFM_PARAM_SE3 = 0,    /* T <- exp(delta^) T, delta = [rho, phi] (liegro
 enum { TCSFM_REFINE_POSE = 0,        /* 6 DoF                                                  */
        TCSFM_REFINE_POSE_SCALE = 1   /* 6 DoF + log depth-scale shared by both depth maps (7x7) */ };
 
+/* How tcsfm_refine_window / tcsfm_linearize_window combine the 2*S*B directed pairs of a call:
+ *   PAIR       every directed pair is its own least-squares problem: normalised by ITS OWN mask count, weighted by ITS OWN
+ *              depth-consistency weight map, depth-consistency term w_dc * mean over its own pixels.
+ *   REFERENCE  the scalar that is minimised is the reference's compute_optimization_loss itself (optimizer.py:47-86, default
+ *              options; pinned by golden G13 = the reference's loss and autograd gradients):
+ *                forward term   sum_b sum_p keep dmin W_{source 0} / sum_b sum_p keep   (batch-summed normaliser; the weight map
+ *                               of SOURCE 0 multiplies every forward pixel whichever source won it, optimizer.py:69);
+ *                               without argmin: 0.25 sum valid W diff / sum valid over all forward pairs, no auto-mask (:71-73)
+ *                inverse term   0.25 sum M W diff / sum M over all inverse pairs of the call (:75-79)
+ *                depth consist. w_dc * (mean over all forward pairs and pixels + mean over all inverse pairs and pixels) (:83-86)
+ *              Every pair still takes its own 6x6 / 7x7 step, with the exact gradient of that scalar w.r.t. its pose (the pose of
+ *              source 0 also moves the weight of the pixels the other sources won) and its own block of the curvature model.
+ *              The batch is the call's B targets: results depend on how windows are grouped into calls, exactly as the
+ *              reference's loss depends on config['minibatch']. */
+enum { TCSFM_WINDOW_PAIR = 0, TCSFM_WINDOW_REFERENCE = 1 };
+
 typedef struct tcsfm_opts {
     int32_t n_iters;       /* linearisations per refine call (BASELINE.json: 4)                         */
     int32_t solver;        /* TCSFM_SOLVER_*                                                             */
@@ -70,7 +86,7 @@ typedef struct tcsfm_opts {
                               depth scale from |t| (exact gauge); this prior makes the 7-DoF problem well posed.   */
     float lambda_depth;    /* dense mode: Marquardt damping of the per-pixel depth block (default 1.0)                */
     float prior_depth;     /* dense mode: weight of the masked prior sum M ((rho-rho0)/rho0)^2 / sum M (default 10)   */
-    float reserved1;
+    int32_t window_rule;   /* TCSFM_WINDOW_*: how the window forms put the directed pairs' costs together (default PAIR) */
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.
@@ -143,6 +159,14 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
                     const float *depth_s, const float *pose, const float *log_scale, const float *K,
                     double *Hmat, double *g, double *stats);
 
+/* Window form of tcsfm_linearize: ONE linearisation of the 2*S*B directed pairs of a window (layouts of tcsfm_refine_window)
+ * at the given poses, under o->argmin / o->window_rule.  Host outputs (doubles): Hmat [2SB,np,np], g [2SB,np],
+ * stats [2SB,4] = cost, cost_photo, cost_dc, n_mask -- under TCSFM_WINDOW_REFERENCE the pairs' costs add up to
+ * compute_optimization_loss (optimizer.py:47-86) and g is its gradient w.r.t. each pair's left SE(3) perturbation. */
+int tcsfm_linearize_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                           const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *log_scale,
+                           double *Hmat, double *g, double *stats);
+
 /* Refine N directed pairs: replaces the epoch loop of DepthOptimizer.optimize_window
  * (optimization_experiments/optimizer.py:217-274) for the pose / pose+scale unknowns with
  * o->n_iters Gauss-Newton (or LM) iterations on the reference's residual.
@@ -162,12 +186,11 @@ int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, c
  * With o->argmin and S > 1 the forward pairs of a target use the reference's per-pixel min over the sources
  * (compute_optimization_loss, optimizer.py:47-69): at every linearisation a pixel counts only for the source with the
  * smallest photometric error there, under the union validity mask and the auto-mask of the minima.
- * Two deliberate differences from the reference's scalar loss (each directed pair is its own least-squares problem here): a pair
- * is normalised by ITS OWN count of selected pixels, and every pair keeps ITS OWN depth-consistency weight map -- the reference
- * multiplies the per-pixel minimum by the weight map of source 0 whichever source won the pixel (optimizer.py:69), which would
- * couple the pose of source 0 into the other pairs' gradients.  The selection itself (which pixels count, for which source) is
- * the reference's and is pinned on its own maps (golden G4); the scalar-loss mirror tightly_coupled_sfm_amd.losses reproduces
- * the reference's formula, weight map of source 0 included, for logging (golden G5, all eight option toggles).
+ * With the default o->window_rule = TCSFM_WINDOW_PAIR each directed pair is its own least-squares problem: normalised by ITS OWN
+ * count of selected pixels, with ITS OWN depth-consistency weight map; TCSFM_WINDOW_REFERENCE minimises the reference's scalar
+ * loss itself -- batch-summed normalisers, the weight map of source 0 on every forward pixel (optimizer.py:69), 0.25 x the
+ * inverse term -- see the enum above (golden G13).  The selection (which pixels count, for which source) is the reference's
+ * under both rules and is pinned on its own maps (golden G4).
  * The handle must have been created with max_pairs >= 2*S*B. */
 int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                         const float *depth_t, const float *depth_s, const float *K, const float *pose_in,

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_BUILD = os.path.join(_DIR, "_build")
+# TCSFM_ORACLE_BUILD_DIR: load the libraries from another build directory (the sanitizer leg, scripts/run_asan.sh: _build_asan)
+_BUILD = os.environ.get("TCSFM_ORACLE_BUILD_DIR") or os.path.join(_DIR, "_build")
 MAXP = 7
 
 
@@ -40,6 +41,8 @@ def default_opts(**kw) -> OrcOpts:
 
 def build(force: bool = False) -> None:
     """Compile both oracle libraries with gcc (seconds)."""
+    if os.environ.get("TCSFM_ORACLE_BUILD_DIR"):
+        return          # a pre-built alternative (sanitizer build): use it as it is
     if force or not all(os.path.exists(os.path.join(_BUILD, f"liboracle_{p}.so")) for p in ("f32", "f64")) or \
             os.path.getmtime(os.path.join(_DIR, "tcsfm_oracle.c")) > os.path.getmtime(os.path.join(_BUILD, "liboracle_f64.so")):
         subprocess.check_call(["make", "-C", _DIR, "-s"] + (["-B"] if force else []))

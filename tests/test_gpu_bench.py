@@ -85,3 +85,48 @@ def test_bench_strong_scaling_option():
     d = _line(r.stdout)
     assert d["scaling"] == "strong" and d["config"]["windows_per_gpu"] == 4 and d["config"]["directed_pairs_per_step"] == 8
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 0.01 * d["value"]
+
+
+def test_bench_world_size_one_over_rccl():
+    """the RCCL code path of bench.py on hardware: one rank, backend nccl (= RCCL) -- init_process_group, the all_reduce of the
+    block count / block times, the final all_gather of the poses and the barriers all run on the card (the 8-GPU run itself is
+    the driver's: only one-GPU boxes exist here)"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               TCSFM_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-sample", "0",
+                        "--sat-windows", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 100 and d["final_gather_us"] is not None and d["final_gather_us"] > 0
+    assert d["config"]["collective_backend"] == "nccl"
+
+
+def test_sequence_sharded_two_ranks_one_card(tmp_path):
+    """the window loop of ONE sequence over two ranks (gloo rehearsal on one card) = the single-process sequence, bit for bit;
+    and parallel.refine_sharded wired to the real Engine.refine"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    env = dict(os.environ, TCSFM_BENCH_BACKEND="gloo", TCSFM_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    dump = str(tmp_path / "seq.npy")
+    common = [os.path.join(ROOT, "examples", "run_sequence_sharded.py"), "--frames", "37", "--sources", "2", "--height", "96", "--width", "320",
+              "--windows-per-call", "4", "--dump", dump]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + common, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(dump)
+    import run_sequence_sharded as RS
+    from tightly_coupled_sfm_amd import parallel
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    frames, depths, K, init = RS.make_sequence(37, 96, 320, 2)
+    e = Engine(96, 320, 16, lanes=2)
+    one = e.refine_sequence(frames, depths, K, init, default_opts(n_iters=4), sources=2, windows_per_call=4)
+    assert got.shape == (35, 4, 6) and np.array_equal(got, one.numpy())
+    # the pair-form helper on the real engine (single process: the gather is the identity)
+    from tightly_coupled_sfm_amd import synth
+    b = synth.make_batch(6, 96, 320, seed0=5, both_directions=True)
+    t = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    e2 = Engine(96, 320, 6)
+    fn = lambda tgt, src, depth_t, depth_s, K, pose: e2.refine(tgt, src, depth_t, depth_s, K, pose, default_opts(n_iters=2))[0]
+    out = parallel.refine_sharded(fn, dict(tgt=t["tgt"], src=t["src"], depth_t=t["depth_t"], depth_s=t["depth_s"], K=t["K"], pose=t["pose_init"]), 6)
+    assert torch.equal(out, fn(t["tgt"], t["src"], t["depth_t"], t["depth_s"], t["K"], t["pose_init"]))

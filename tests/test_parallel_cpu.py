@@ -55,3 +55,39 @@ def test_shard_range_properties():
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _seq_worker(rank, world, port, T, S, wpc, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tightly_coupled_sfm_amd import parallel as P
+    g = torch.Generator().manual_seed(0)
+    frames = torch.rand((T, 3, 4, 6), generator=g); depths = torch.rand((T, 1, 4, 6), generator=g) + 0.5
+    init = torch.rand((T - S, 2 * S, 6), generator=g)
+    seen = []
+
+    def fake_sequence(fr, dp, K, p0, opts, sources, windows_per_call, target_pos):
+        # a window's result depends on exactly its own S + 1 frames and its initial poses -- like the real loop
+        seen.append((fr.shape[0], p0.shape[0]))
+        w = torch.stack([fr[i:i + sources + 1].sum() + dp[i:i + sources + 1].sum() for i in range(p0.shape[0])])
+        return p0 * 2 + w[:, None, None]
+
+    out = P.refine_sequence_sharded(None, frames, depths, None, init, None, sources=S, windows_per_call=wpc, refine_fn=fake_sequence)
+    full = fake_sequence(frames, depths, None, init, None, S, wpc, 0)
+    lo, hi = P.sequence_block(T - S, rank, world, wpc)
+    ok = torch.equal(out, full) and (seen[0] == (hi - lo + S, hi - lo) if hi > lo else len(seen) == 1)
+    ret[rank] = (bool(ok), lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,S,wpc", [(21, 1, 8), (12, 2, 4), (4, 2, 8), (30, 1, 1)])
+def test_sequence_sharded_gloo_world2(T, S, wpc):
+    """the window loop of ONE sequence split over two ranks: contiguous blocks in whole calls, S overlap frames at the seam, one
+    all_gather -- equal to the single-process loop"""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_seq_worker, args=(world, port, T, S, wpc, ret), nprocs=world, join=True)
+        assert all(ret[r][0] for r in range(world)), dict(ret)
+        assert ret[0][1] == 0 and ret[0][2] == ret[1][1] and ret[1][2] == T - S and (ret[0][2] % wpc == 0 or ret[0][2] == T - S)

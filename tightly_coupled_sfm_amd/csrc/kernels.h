@@ -70,6 +70,9 @@ struct LinParams {
     const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
     int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
+    int rule;               // TCSFM_WINDOW_REFERENCE: the forward pairs of sources s > 0 weigh their pixels with source 0's depth-
+                            // consistency weight map, source 0 carries the cross term (optimizer.py:69; normalisers: k_solve)
+    int fwd_noauto;         // pairs n < fwd_noauto take no auto-mask (REFERENCE rule without argmin, optimizer.py:71-73)
     unsigned short *trace;  // tcsfm_debug_trace: [N][H*W] decisions of THIS launch (bit 0 = pixel counts, bit 1 = warp valid,
                             // bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy), bits 4-5 = sign code of cd - pd,
                             // bits 6-11 = sign codes of rec_c - tgt_c; codes 0 zero / 1 positive / 2 negative), or null
@@ -769,9 +772,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     // error among the sources before / after s (torch.min keeps the FIRST minimum), the union of their validity and the
     // smallest auto-mask threshold.  Same arithmetic as the maps pass + k_select pair it replaces, without the two launches.
     float sel_before = 3.0e38f, sel_after = 3.0e38f, sel_valid = 0.f, sel_ae = 3.0e38f;
+    float sel_w0 = 1.f;      // REFERENCE rule: depth-consistency weight of SOURCE 0 at this pixel (pairs of the other sources)
     const bool sel_pair = SEL && n < P.sel_B * P.sel_S;
+    const int s_own = (SEL && sel_pair) ? n / P.sel_B : 0;
     if (SEL && sel_pair) {
-        const int b_ = n % P.sel_B, s_own = n / P.sel_B;
+        const int b_ = n % P.sel_B;
         for (int so = 0; so < P.sel_S; so++) {
             if (so == s_own) continue;
             const int no = so * P.sel_B + b_;
@@ -789,6 +794,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 float4 *rec = lds + ci * (LDS_REC / 4);
                 lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
                 lds_write1(rec + 2, val.z, tp.z, (g.oobx || g.ooby) ? 0.f : 1.f, tp.w);
+                if (P.rule && so == 0) {   // that source's depth-consistency weight (train_mono.py:91-92), with its depth sample
+                    const float pdo = co.es * val.w;
+                    lds_write1(rec + 1, 1.f - clamp01(fabsf(g.Z - pdo) * frcp(g.Z + pdo)), 0.f, 0.f, 0.f);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
@@ -815,6 +824,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 if (so < s_own) sel_before = fminf(sel_before, d_o); else sel_after = fminf(sel_after, d_o);
                 sel_valid = fmaxf(sel_valid, q2.z);
                 sel_ae = fminf(sel_ae, q2.w);
+                if (P.rule && so == 0) sel_w0 = lds_read1(ctr + 1).x;
             }
             __syncthreads();   // the records are overwritten by the next source / by phase 1
         }
@@ -997,12 +1007,21 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float raw = fabsf(dif) * isum;
         float dd = clamp01(raw), Wt = 1.f - dd;
         bool inimg = c_in[k];
-        bool m = inimg && c_valid[k] && (!P.automask || diff < c_ae[k]);
+        bool m = inimg && c_valid[k] && (!(P.automask && n >= P.fwd_noauto) || diff < c_ae[k]);
+        // REFERENCE window rule (optimizer.py:69): Wp = the weight on the photometric term -- source 0's map for every forward
+        // pair; wext: it is not this pair's own (no e dW/d theta term); crossf: source 0's weight also multiplies the pixels the
+        // other sources won, their error times d W_0 / d theta enters source 0's gradient
+        float Wp = Wt, crossf = 0.f;
+        bool wext = false;
         if (SEL && sel_pair) {   // keep the pixel for the source with the smallest error (first minimum), under the union
                                  // validity and the auto-mask of the minima
-            const float dmin = fminf(diff, fminf(sel_before, sel_after));
+            const float dothers = fminf(sel_before, sel_after), dmin = fminf(diff, dothers);
             const bool keep = (c_valid[k] || sel_valid > 0.f) && (!P.automask || dmin < fminf(c_ae[k], sel_ae));
             m = inimg && keep && (diff < sel_before) && (diff <= sel_after);
+            if (P.rule) {
+                if (s_own != 0) { Wp = sel_w0; wext = true; }
+                else crossf = (inimg && keep && !m) ? dothers : 0.f;
+            }
         }
 
         if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
@@ -1028,7 +1047,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
 
         if (inimg) sdd += dd;
-        if (m) { sMWd += Wt * diff; sM += 1.f; }
+        if (m) { sMWd += Wp * diff; sM += 1.f; }
         if (MODE == MODE_LIN) {
             // own geometric Jacobian (centre record), as column pairs
             f32x4 q3, q4, q5;
@@ -1039,15 +1058,17 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
             float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;
-            const float wxx = mf * Wt * lxx, wxy = mf * Wt * lxy, wyy = mf * Wt * lyy;
+            const float wxx = mf * Wp * lxx, wxy = mf * Wp * lxy, wyy = mf * Wp * lyy;
+            const float dsub = (SEL && wext) ? 0.f : diff;
             f2 ddJ2[3], la2[3], lb2[3];
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const f2 zc2 = {c_zc[k][2 * p], c_zc[k][2 * p + 1]};
                 f2 dpd = c_dgx[k] * a2[p] + c_dgy[k] * b2[p];
                 ddJ2[p] = kdd * (pd * zc2 - cd * dpd);
-                f2 row = Wt * (de2[p] + l1x * a2[p] + l1y * b2[p]) - diff * ddJ2[p];   // d(W (e1+e2))/d theta
+                f2 row = Wp * (de2[p] + l1x * a2[p] + l1y * b2[p]) - dsub * ddJ2[p];   // d(W (e1+e2))/d theta
                 aG2[p] += mf * row;
+                if (SEL) aG2[p] -= crossf * ddJ2[p];
                 la2[p] = wxx * a2[p] + wxy * b2[p];
                 lb2[p] = wxy * a2[p] + wyy * b2[p];
             }
@@ -1055,7 +1076,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (NP == 7) {
                 float dpd = c_dgx[k] * a6 + c_dgy[k] * b6 + pd;
                 ddJ6 = kdd * (pd * c_zc[k][NP - 1] - cd * dpd);
-                aG6 += mf * (Wt * (de6 + l1x * a6 + l1y * b6) - diff * ddJ6);
+                aG6 += mf * (Wp * (de6 + l1x * a6 + l1y * b6) - dsub * ddJ6);
+                if (SEL) aG6 -= crossf * ddJ6;
                 la6 = wxx * a6 + wxy * b6; lb6 = wxy * a6 + wyy * b6;
             }
             // H row j (scalar la_j, lb_j) x column pairs p <= j/2
@@ -1167,6 +1189,10 @@ struct SolveParams {
     double *delta_out;                // dense mode: [N][8] pose increment of this iteration for k_dense_update (else null)
     int *accept_out;                  // dense LM: [N] 1 = this launch accepted the trial (mode 0) / kept the last step (mode 1)
     int *trace_decide;                // tcsfm_debug_trace: [N] the same decision of THIS launch, or null
+    // TCSFM_WINDOW_REFERENCE (compute_optimization_loss, optimizer.py:47-86): the photometric sums of a pair are normalised by the
+    // mask count summed over ALL forward (n < grp_fwd) or ALL inverse (grp_fwd <= n < n_pairs) pairs of the call, times `scale`
+    int rule, grp_fwd, n_pairs;
+    double scale_fwd, scale_inv;      // 1 (argmin) or 0.25 (no argmin, :73) / 0.25 (:79)
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -1205,6 +1231,14 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     // the pair's optimiser state is fetched NOW, together with the partial records, so that the serial phases below never
     // wait on a global load (each first touch used to cost a miss in the middle of the dependent chain)
     if (tid < NST) sst[tid] = reinterpret_cast<const double *>(&P.st[n])[tid];
+    __shared__ double kpart[256];
+    if (P.rule) {   // batch-summed mask count of this pair's group: every record of every pair of the group, fixed order
+        const int g0 = n < P.grp_fwd ? 0 : P.grp_fwd, g1 = n < P.grp_fwd ? P.grp_fwd : P.n_pairs, cnt = (g1 - g0) * P.ngrp;
+        const float *p = P.partials + (size_t)g0 * P.ngrp * L::NACC + L::OFF_S + 1;
+        double s = 0.0;
+        for (int i = tid; i < cnt; i += 256) s += (double)p[(size_t)i * L::NACC];
+        kpart[tid] = s;
+    }
     {
         // Deterministic fp64 reduction of the pair's P.ngrp partial records (group records, or one record per workgroup in
         // direct mode).  Only the live accumulators are read; they are spread over 256 threads as (accumulator, record
@@ -1242,7 +1276,12 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     const PairState &Lc = *reinterpret_cast<const PairState *>(sst);  // LDS copy taken at kernel start: reads
     const int r = tid >> 3, c = tid & 7;
     const double nmask = tot[L::OFF_S + 1];
-    const double an = nmask > 0 ? rcp64(nmask) : 0.0;
+    double an = nmask > 0 ? rcp64(nmask) : 0.0;
+    if (P.rule) {
+        double kn = 0.0;
+        for (int i = 0; i < 256; i++) kn += kpart[i];   // (every lane the same fixed-order sum: LDS broadcast reads)
+        an = kn > 0 ? (n < P.grp_fwd ? P.scale_fwd : P.scale_inv) * rcp64(kn) : 0.0;
+    }
     const double cost_photo = an * tot[L::OFF_S], cost_dc = P.b_dc * tot[L::OFF_S + 2];
     double cost = cost_photo + cost_dc;
     const double bdc = P.has_dc ? P.b_dc : 0.0;

@@ -85,19 +85,42 @@ TC_HD void se3_exp(const double *xi, double *T) {
 }
 
 TC_HD void se3_log(const double *T, double *xi) {
-    double c = 0.5 * (T[0] + T[5] + T[10] - 1);
-    c = c > 1 ? 1 : (c < -1 ? -1 : c);
-    double t = acos(c), t2 = t * t;
-    double f = (t < 1e-6) ? 0.5 + t2 / 12 : t / (2 * sin(t));
-    double phi[3] = {f * (T[9] - T[6]), f * (T[2] - T[8]), f * (T[4] - T[1])};
-    double D = (t < 1e-4) ? 1.0 / 12 + t2 / 720 : 1.0 / t2 - (1 + cos(t)) / (2 * t * sin(t));
+    // rotation angle from BOTH its sine (antisymmetric part) and cosine (trace): atan2 is well conditioned on all of [0, pi],
+    // acos(trace) alone loses half the digits near 0 and near pi
+    const double v[3] = {T[9] - T[6], T[2] - T[8], T[4] - T[1]};        // (R - R')^vee = 2 sin(t) n
+    const double s = 0.5 * sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double c = 0.5 * (T[0] + T[5] + T[10] - 1);
+    const double t = atan2(s, c), t2 = t * t;
+    double phi[3];
+    if (t < 1e-6) {
+        const double f = 0.5 + t2 / 12;
+        for (int i = 0; i < 3; i++) phi[i] = f * v[i];
+    } else if (c > -0.99) {
+        const double f = t / (2 * s);
+        for (int i = 0; i < 3; i++) phi[i] = f * v[i];
+    } else {
+        // near pi the antisymmetric part vanishes: take the axis from the symmetric part, R + R' = 2 c I + 2 (1 - c) n n',
+        // and only its overall sign from the antisymmetric one
+        const double omc = 1 - c, d[3] = {T[0], T[5], T[10]};
+        int k = d[0] >= d[1] ? (d[0] >= d[2] ? 0 : 2) : (d[1] >= d[2] ? 1 : 2);
+        double n[3], nk2 = (d[k] - c) / omc;
+        n[k] = sqrt(nk2 > 0 ? nk2 : 0);
+        for (int j = 0; j < 3; j++)
+            if (j != k) n[j] = (T[4 * k + j] + T[4 * j + k]) / (2 * omc * n[k]);
+        const double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        const double sg = (v[0] * n[0] + v[1] * n[1] + v[2] * n[2]) < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < 3; i++) phi[i] = sg * t * n[i] / nn;
+    }
+    // V^-1 = I - K/2 + D K^2,  D = 1/t^2 - (1 + cos t)/(2 t sin t) = 1/t^2 - cot(t/2)/(2 t)   (second form: finite at pi; the
+    // difference cancels for small t, hence the series below 1e-2: truncation t^6/1209600 < 1e-18)
+    double D = (t < 1e-2) ? 1.0 / 12 + t2 / 720 + t2 * t2 / 30240 : 1.0 / t2 - cos(0.5 * t) / (2 * t * sin(0.5 * t));
     double K[9], K2[9];
     hat(phi, K);
     mat3_mul(K, K, K2);
     for (int i = 0; i < 3; i++) {
-        double v = 0;
-        for (int j = 0; j < 3; j++) v += (((i == j) ? 1.0 : 0.0) - 0.5 * K[3 * i + j] + D * K2[3 * i + j]) * T[4 * j + 3];
-        xi[i] = v;
+        double v3 = 0;
+        for (int j = 0; j < 3; j++) v3 += (((i == j) ? 1.0 : 0.0) - 0.5 * K[3 * i + j] + D * K2[3 * i + j]) * T[4 * j + 3];
+        xi[i] = v3;
         xi[3 + i] = phi[i];
     }
 }

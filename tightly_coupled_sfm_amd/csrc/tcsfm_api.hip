@@ -140,7 +140,18 @@ int check_common(tcsfm_ctx *h, const tcsfm_opts *o, int N) {
     if (o->param != TCSFM_PARAM_SE3 && o->param != TCSFM_PARAM_EULER) return fail(h, TCSFM_E_ARG, "opts.param unsupported");
     if (o->n_iters < 0 || o->n_iters > 1000) return fail(h, TCSFM_E_ARG, "opts.n_iters out of range");
     if (o->depth_is_disp && !(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
+    if (o->window_rule != TCSFM_WINDOW_PAIR && o->window_rule != TCSFM_WINDOW_REFERENCE) return fail(h, TCSFM_E_ARG, "opts.window_rule unsupported");
     return TCSFM_OK;
+}
+
+// TCSFM_WINDOW_REFERENCE (window forms only): the coupling of the pairs' costs, see include/tcsfm.h
+void apply_window_rule(const tcsfm_ctx *h, const tcsfm_opts *o, int win_B, int win_S, int N, LinParams &P, SolveParams &S) {
+    if (!win_B || o->window_rule != TCSFM_WINDOW_REFERENCE) return;
+    P.rule = 1;
+    P.fwd_noauto = o->argmin ? 0 : win_B * win_S;      // optimizer.py:71-73: without argmin the forward term has no auto-mask
+    S.rule = 1; S.grp_fwd = win_B * win_S; S.n_pairs = N;
+    S.scale_fwd = o->argmin ? 1.0 : 0.25; S.scale_inv = 0.25;
+    S.b_dc = (double)o->w_dc / ((double)win_B * win_S * (double)h->H * (double)h->W);   // :83-86: mean over all S*B maps
 }
 
 // Stage a host array on the device (slot-indexed scratch that grows on demand) or pass a device pointer through.
@@ -679,6 +690,52 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
     return TCSFM_OK;
 }
 
+int tcsfm_linearize_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                           const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *log_scale,
+                           double *Hmat, double *g, double *stats) {
+    if (!h) return TCSFM_E_ARG;
+    if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_window: need 1 <= 2*B*S <= max_pairs");
+    const int N = 2 * B * S;
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !srcs || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_window: NULL input");
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
+    if ((rc = check_intrinsics(h, o, K, B))) return rc;
+    const size_t hw = (size_t)h->H * h->W;
+    const int np = np_of(o);
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose, *d_ls;
+    if ((rc = to_dev(h, o, 0, tgt, B * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, srcs, (size_t)B * S * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, B * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, (size_t)B * S * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)B * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 5, pose, (size_t)N * 6, &d_pose))) return rc;
+    if ((rc = to_dev(h, o, 6, log_scale, (size_t)N, &d_ls))) return rc;
+    InitParams I = init_params(h, o, N, d_pose, np == 7 ? d_ls : nullptr, d_K, 0);
+    I.K_mod = B;
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, B, S))) return rc;
+    LinParams P = lin_params(h, o, np);
+    SolveParams Sv = solve_params(h, o, np, 0);
+    if (S > 1 && o->argmin) { P.sel_B = B; P.sel_S = S; }
+    apply_window_rule(h, o, B, S, N, P, Sv);
+    launch_lin(h, P, N, np, o->w_dc > 0.f, MODE_LIN);
+    Sv.mode = 2;
+    launch_solve(h, Sv, N, np);
+    HIPCHK(h, hipGetLastError());
+    const int rec = np * np + np + 4;
+    std::vector<double> host((size_t)N * rec);
+    HIPCHK(h, hipMemcpyAsync(host.data(), h->lin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int n = 0; n < N; n++) {
+        const double *r = &host[(size_t)n * rec];
+        if (Hmat) memcpy(Hmat + (size_t)n * np * np, r, sizeof(double) * np * np);
+        if (g) memcpy(g + (size_t)n * np, r + np * np, sizeof(double) * np);
+        if (stats) memcpy(stats + (size_t)n * 4, r + np * np + np, sizeof(double) * 4);
+    }
+    return TCSFM_OK;
+}
+
 int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, const float *src, const float *depth_t,
                        const float *depth_s, const float *K, int P, const float *poses, double *cost_out) {
     int rc = check_common(h, o, P);
@@ -745,6 +802,7 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (n_sel) { P.sel_B = win_B; P.sel_S = win_S; }   // min over the sources: evaluated inside k_linearize<SEL>
+    apply_window_rule(h, o, win_B, win_S, N, P, S);
     if ((rc = trace_check(h, o, N))) return rc;
     for (int it = 0; it < o->n_iters; it++) {
         trace_at(h, it, N, P, S);
@@ -910,6 +968,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     }
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
+    oo.window_rule = TCSFM_WINDOW_PAIR;
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
     I.K_mod = win_B;
     // Gauss-Newton in the pair form: the back-substitution of iteration k is fused into the linearisation of iteration k+1 (depth

@@ -4,6 +4,13 @@ Windows / directed pairs are independent least-squares problems, so the path sha
 GPU (torch.distributed, backend "nccl" = RCCL on ROCm), a contiguous block of pairs per rank, NO collective on the data
 path, and one all_gather of the refined poses (N x 6 floats: bytes-scale, latency only) at the end.  On CPU the same
 code runs over "gloo" (tests/test_parallel_cpu.py, world size 2) with a stand-in refine function.
+
+The reference's actual unit of work is a SEQUENCE (run_sequential_optimization.py:186-247: one window after the other over a
+KITTI sequence): `refine_sequence_sharded` splits the windows of one sequence contiguously over the ranks -- rank r uploads
+only the frames of its block plus the S frames its last window reaches into (the overlap at the seam) -- every rank runs the
+library's own window loop (tcsfm_refine_sequence) on its block, and ONE all_gather of [windows, 2S, 6] puts the trajectory
+together.  Under the default window rule the result is bit-identical to the single-process sequence whatever the number of
+ranks (windows are independent problems and a block is a whole number of calls of `windows_per_call` windows).
 """
 from __future__ import annotations
 
@@ -49,3 +56,54 @@ def refine_sharded(refine_fn: Callable[..., torch.Tensor], tensors: dict, n_tota
     block = {k: v[lo:hi].contiguous() for k, v in tensors.items()}
     local = refine_fn(**block) if hi > lo else torch.zeros((0, 6), dtype=torch.float32, device=next(iter(tensors.values())).device)
     return gather_rows(local, n_total, group)
+
+
+def sequence_block(n_windows: int, rank: int, world: int, windows_per_call: int = 1) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of a sequence's windows for `rank`, in whole CALLS of `windows_per_call` windows (the library
+    refines that many windows per launch sequence; keeping call boundaries where the single-process loop has them makes the
+    sharded run bit-identical to it under every window rule)."""
+    wpc = max(1, int(windows_per_call))
+    lo_c, hi_c = shard_range((n_windows + wpc - 1) // wpc, rank, world)
+    return min(lo_c * wpc, n_windows), min(hi_c * wpc, n_windows)
+
+
+def refine_sequence_sharded(engine, frames: torch.Tensor, depths: torch.Tensor, K, init_poses: torch.Tensor, opts=None, sources: int = 1,
+                            windows_per_call: int = 8, target_pos: int = 0, group=None, gather_device: Optional[torch.device] = None,
+                            refine_fn: Optional[Callable[..., torch.Tensor]] = None) -> torch.Tensor:
+    """The window loop of ONE sequence over all ranks of `group` (run_sequential_optimization.py:186-247 on N GPUs).
+
+    frames [T,3,H,W], depths [T,1,H,W] (CPU, pinned for asynchronous uploads), K [3,3], init_poses [T-S, 2S, 6]; every rank
+    passes the same arguments (or at least its own block of them: only rows lo .. hi+S of frames / depths and lo .. hi of
+    init_poses are read).  -> refined poses [T-S, 2S, 6] on every rank (CPU tensor).
+    gather_device: where the collective runs -- the GPU for RCCL (default when the backend is nccl), the CPU for gloo.
+    refine_fn: stand-in for engine.refine_sequence (CPU tests)."""
+    T, S = int(frames.shape[0]), int(sources)
+    n_win = T - S
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = sequence_block(n_win, rank, world, windows_per_call)
+    if hi > lo:
+        run = refine_fn or engine.refine_sequence
+        local = run(frames[lo:hi + S], depths[lo:hi + S], K, init_poses[lo:hi], opts, sources=S, windows_per_call=windows_per_call,
+                    target_pos=target_pos)
+        local = torch.as_tensor(local).reshape(hi - lo, 2 * S * 6)
+    else:
+        local = torch.zeros((0, 2 * S * 6), dtype=torch.float32)
+    if world == 1:
+        return local.reshape(n_win, 2 * S, 6)
+    if gather_device is None:
+        gather_device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    wpc = max(1, int(windows_per_call))
+    n_calls = (n_win + wpc - 1) // wpc
+    nmax = ((n_calls + world - 1) // world) * wpc                       # the largest block, in windows
+    pad = torch.zeros((nmax, 2 * S * 6), dtype=torch.float32, device=gather_device)
+    pad[: hi - lo] = local.to(gather_device)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)                            # the ONE collective of the job: world x nmax x 2S x 6 floats
+    out = []
+    for r in range(world):
+        rlo, rhi = sequence_block(n_win, r, world, windows_per_call)
+        out.append(parts[r][: rhi - rlo].cpu())
+    return torch.cat(out, 0).reshape(n_win, 2 * S, 6)
