@@ -510,6 +510,7 @@ typedef struct {
     real pd, dgx, dgy, cd;     /* projected (sampled, scaled) / computed depth              */
     real a[MAXP], b[MAXP], zc[MAXP], dpd[MAXP]; /* d ix, d iy, d cd, d pd  w.r.t. parameters */
     int valid, nat_valid;
+    int dc_in;                 /* the four taps of the projected-depth sample are real source pixels (none is zero padding) */
 } px_t;
 
 /* Parameters: xi = [rho, phi] left perturbation of T (T <- exp(xi^) T), optional 7th = log depth-scale
@@ -538,6 +539,10 @@ static void px_eval(const cam_t *c, const real *src, const real *depth_t, const 
     real dval;
     bilinear_cell(depth_s, H, W, g.ix, g.iy, g.adjx, g.adjy, &dval, &o->dgx, &o->dgy);
     o->pd = c->es * dval; o->dgx *= c->es; o->dgy *= c->es;
+    {   /* (the cell the sample was actually taken from: a forced replay may have moved it across a texel boundary) */
+        const real fx = floor(g.ix) + (real)g.adjx, fy = floor(g.iy) + (real)g.adjy;
+        o->dc_in = !(g.oobx || g.ooby) && fx >= 0 && fx + 1 <= (real)(W - 1) && fy >= 0 && fy + 1 <= (real)(H - 1);
+    }
     o->cd = g.Z;
     o->valid = !(g.oobx || g.ooby);
     o->nat_valid = g.nat_valid;
@@ -731,7 +736,12 @@ static void linearize_masked(int H, int W, const real *tgt, const real *src, con
         double E1 = E[3 * i], E2 = E[3 * i + 1], E3 = E[3 * i + 2];
         out->cost_photo += am * (E1 + E2);
         out->cost_dc += b * E3;
-        double k3 = b / fmax(E3, eps);
+        /* IRLS curvature of the depth-consistency term -- over the pixels whose projected depth is a REAL depth sample only:
+         * where the bilinear footprint touches grid_sample's zero padding (stn.py:271, valid stays 1 up to half a pixel outside)
+         * the "projected depth" is a blend with 0, dd jumps from ~0 to 1 within one pixel of sample position and 1/max(dd,eps) x
+         * (depth / 1 px)^2 from a handful of such border pixels would make up 90 % of this term's curvature (measured), at the
+         * mercy of the fifth digit of their sample positions.  The GRADIENT keeps every pixel (it is the reference's autograd). */
+        double k3 = px[i].dc_in ? b / fmax(E3, eps) : 0.0;
         double lxx = am * Lam[3 * i], lxy = am * Lam[3 * i + 1], lyy = am * Lam[3 * i + 2];
         const px_t *P = &px[i];
         for (int j = 0; j < np; j++) {

@@ -194,7 +194,8 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
         for n in range(N):
             t, sr, dt, ds, K = views[n]
             ph = orc.photometric(t, sr, dt, ds, w["first"][n], K, log_scale=float(ls0[n]), w_l1=float(o.w_l1), w_ssim=float(o.w_ssim))
-            own[n] = (ph["valid"] > 0.5) & ((ph["diff"] < ph["auto_err"]) if int(o.automask) else True)
+            am = int(o.automask) and not (rule == 1 and not argmin and n < S * B)     # REFERENCE rule without argmin: no auto-mask on the forward term
+            own[n] = (ph["valid"] > 0.5) & ((ph["diff"] < ph["auto_err"]) if am else True)
         if argmin and S > 1:
             if refine and np.any(ls0 != 0):
                 own[:S * B] = (bits[0, :S * B] & 1) > 0      # (the select helper has no depth-scale argument)

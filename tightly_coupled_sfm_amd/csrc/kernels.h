@@ -110,6 +110,7 @@ struct Geo {
     float Z, iz;         // computed depth (clamped at 1e-3, stn.py:215) and 1/Z
     float uz, vz;        // projected pixel coordinates p0/Z, p1/Z
     float X0, X1, X2;    // point in the source camera frame
+    float q2;            // Z - D before the clamp (D = scaled target depth): the small part of the computed depth (see dc_diff)
     bool oobx, ooby, zcl;
 };
 
@@ -127,6 +128,7 @@ __device__ __forceinline__ void warp_geo(const PairConst &c, int W, int H, int u
     float a2 = c.A[6] * u + c.A[7] * v + c.A[8];
     float q0 = D * a0 + c.kt[0], q1 = D * a1 + c.kt[1], q2 = D * a2 + c.kt[2];
     float p2 = D + q2;
+    g.q2 = q2;
     g.zcl = p2 < 1e-3f;
     g.Z = g.zcl ? 1e-3f : p2;
     g.iz = frcp(g.Z);
@@ -158,12 +160,14 @@ __device__ __forceinline__ void warp_geo(const PairConst &c, int W, int H, int u
 struct Tap {
     float4 v00, v01, v10, v11;
     float wx, wy;
+    bool inside;     // all four taps are real source pixels (none comes from the zero border)
 };
 // address computation + the four 16-byte gathers (asynchronous: nothing here waits for them)
 __device__ __forceinline__ void tap4_fetch(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob, Tap &t) {
     float fx = floorf(rx), fy = floorf(ry);
     t.wx = rx - fx; t.wy = ry - fy;
     int xi = ui + (int)fx, yi = vi + (int)fy;
+    t.inside = !oob && xi >= 0 && xi < W - 1 && yi >= 0 && yi < H - 1;
     xi = oob ? -2 : xi;                                         // both columns clamp to the left border: all four taps are zero
     const int x0 = min(max(xi, -1), W) + 1, x1 = min(max(xi + 1, -1), W) + 1;   // bordered coordinates 0 .. W+1
     const int y0 = min(max(yi, -1), H) + 1, y1 = min(max(yi + 1, -1), H) + 1;
@@ -180,6 +184,19 @@ __device__ __forceinline__ void tap4_lerp(const Tap &t, float4 &val, float4 &gx,
     TC_LERP(x) TC_LERP(y) TC_LERP(z) TC_LERP(w)
 #undef TC_LERP
 }
+// computed - projected depth (train_mono.py:91) WITHOUT cancellation: both are O(1) numbers that agree to 1e-2 .. 1e-4 on consistent
+// depth maps, so their fp32 difference would carry 1e-4 .. 1e-3 relative error -- which the depth-consistency term's IRLS weight
+// 1 / max(dd, eps) turns into 1e-5 on the normal equations (measured; GN iterations under a strong depth-consistency weight
+// amplify it past the 1e-4 parity bar).  With Z = D + q2, D = es d_t and pd = es (v00 + delta), delta = the bilinear
+// interpolation of the taps' differences to tap 00:   cd - pd = es ((d_t - v00) - delta) + q2   -- every term small and exact
+// to its own ulp (d_t - v00 is exact by Sterbenz when the two depths are within a factor of two).
+__device__ __forceinline__ float dc_diff(const PairConst &c, const Geo &g, const Tap &t, float depth_t, float pd) {
+    const float wx = t.wx, wy = t.wy;
+    const float e01 = t.v01.w - t.v00.w, e10 = t.v10.w - t.v00.w, e11 = t.v11.w - t.v00.w;
+    const float dlt = wx * ((1.f - wy) * e01) + wy * ((1.f - wx) * e10) + (wx * wy) * e11;
+    return g.zcl ? g.Z - pd : c.es * ((depth_t - t.v00.w) - dlt) + g.q2;
+}
+
 __device__ __forceinline__ void tap4(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob,
                                      float4 &val, float4 &gx, float4 &gy) {
     Tap t;
@@ -763,8 +780,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     stamp_begin(P.stamp, tid);
 
     // centre-only values carried in registers from phase 1 to phase 2
-    float c_pd[PPT], c_cd[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
-    bool c_valid[PPT], c_in[PPT];
+    float c_pd[PPT], c_cd[PPT], c_dif[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
+    bool c_valid[PPT], c_in[PPT], c_dcin[PPT];
 
     // ---------------- window mode: the residual of the OTHER sources at this tile (min over sources, optimizer.py:47-69) -------
     // For a forward pair n = s B + b the other sources of target b are warped with THEIR poses (and their copy of the target
@@ -875,6 +892,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
+            c_dif[0] = dc_diff(c, S.g, S.t, S.dep, c_pd[0]);
+            c_dcin[0] = S.t.inside;
             c_ae[0] = S.tp.w; c_valid[0] = !(S.g.oobx || S.g.ooby);
             if (MODE == MODE_LIN) {
 #pragma unroll
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 
         // depth consistency, train_mono.py:91-92
         float cd = c_cd[k], pd = c_pd[k];
-        float sum = cd + pd, dif = cd - pd, isum = frcp(sum);
+        float sum = cd + pd, dif = c_dif[k], isum = frcp(sum);
         float raw = fabsf(dif) * isum;
         float dd = clamp01(raw), Wt = 1.f - dd;
         bool inimg = c_in[k];
@@ -1096,8 +1115,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 }
             }
             if (DC) {
-                // IRLS curvature 1/max(dd,eps); the gradient is Huberised inside dd < eps (sign(cd-pd) is rounding noise there)
-                float k3 = inimg ? frcp(fmaxf(dd, P.eps)) : 0.f, inf = inimg ? fminf(1.f, dd * frcp(P.eps)) : 0.f;
+                // IRLS curvature 1/max(dd,eps) -- over pixels whose projected depth is a real depth sample only (a footprint that
+                // touches the zero padding gives a blend with 0: a handful of such border pixels would be 90 % of this curvature, see
+                // the oracle); the gradient keeps every pixel and is Huberised inside dd < eps (sign(cd-pd) is rounding noise there)
+                float k3 = (inimg && c_dcin[k]) ? frcp(fmaxf(dd, P.eps)) : 0.f, inf = inimg ? fminf(1.f, dd * frcp(P.eps)) : 0.f;
                 int h = 0;
 #pragma unroll
                 for (int p = 0; p < 3; p++) dG2[p] += inf * ddJ2[p];
