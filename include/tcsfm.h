@@ -87,6 +87,10 @@ typedef struct tcsfm_opts {
     float lambda_depth;    /* dense mode: Marquardt damping of the per-pixel depth block (default 1.0)                */
     float prior_depth;     /* dense mode: weight of the masked prior sum M ((rho-rho0)/rho0)^2 / sum M (default 10)   */
     int32_t window_rule;   /* TCSFM_WINDOW_*: how the window forms put the directed pairs' costs together (default PAIR) */
+    int32_t dense_joint;   /* tcsfm_refine_dense_window with S > 1 (default 1): the S forward pairs of a target share ONE inverse-
+                              depth map and are solved JOINTLY (6S x 6S reduced camera system); 0: every forward pair refines its own
+                              copy of the target depth (the round-2 behaviour)                                                  */
+    int32_t reserved2;
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.
@@ -207,10 +211,20 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
                        float *stats_out);
 
 /* Window form of tcsfm_refine_dense (the `optimize_depth_pred` mode of optimize_window with its default options,
- * optimizer.py:194-198 + 47-69): B targets x S sources given once as in tcsfm_refine_window; every one of the 2*S*B directed
- * pairs refines its pose and ITS OWN copy of its target's depth (forward pairs: one copy of target b's depth per source,
- * inverse pairs: the depth of source (s,b)); depth_out [2*S*B,1,H,W] in the stacked pair order.  With o->argmin and S > 1
- * the forward pairs use the per-pixel min over the sources, evaluated at the current poses and depth copies. */
+ * optimizer.py:194-198 + 47-69): B targets x S sources given once as in tcsfm_refine_window; depth_out [2*S*B,1,H,W] in the
+ * stacked pair order.
+ *   JOINT (o->dense_joint, the default, S = 2 or 3): the reference optimises ONE disparity per frame that every term of the loss
+ *     sees (optimizer.py:235-247).  The S forward pairs of target b share one inverse-depth map; unknowns per target = S poses +
+ *     the map; cost = the forward term of the reference's loss (min over the sources under o->argmin -- weight map per
+ *     o->window_rule: the winning source's own, or source 0's as optimizer.py:69 has it -- or every valid source without argmin,
+ *     :71-73) + the depth prior; exact gradient (= reference autograd w.r.t. the poses AND the shared depth, golden G13);
+ *     per-pixel Schur elimination of the depth -> ONE reduced camera system of 6S x 6S per target (12 x 12 for the KITTI
+ *     window; its off-diagonal blocks vanish identically under argmin, where every pixel counts for exactly one source),
+ *     back-substitution once per target pixel.  LM accepts / rejects all S poses and the map together.  The S forward slots of
+ *     depth_out hold the same refined map; stats rows of the forward pairs: [joint cost of the target, own share, own mask
+ *     count, lambda, iterate].  The inverse pairs refine their pose and the depth of THEIR target (source frame (s,b)) as before.
+ *   PER-PAIR COPIES (o->dense_joint = 0, or S = 1 where the two coincide): every directed pair refines ITS OWN copy of its
+ *     target's depth; with o->argmin the forward pairs use the min over the sources at the current poses and depth copies. */
 int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                               float *depth_out, float *stats_out);

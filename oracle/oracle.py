@@ -226,6 +226,40 @@ class Oracle:
                                                 self._p(bits), self._p(decide))
         return pose, dt_pairs, stats
 
+    def linearize_dense_joint(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, lambda_depth=0.0, w_prior=0.0, depth0=None, rule=1):
+        """joint dense mode, ONE target: tgt [3,H,W], srcs [S,3,H,W], depth_t [H,W] (shared by the S forward pairs), depth_s [S,H,W],
+        poses [S,6] -> dict(H [6S,6S] reduced system, g [6S], cost, cost_photo, cost_prior, K, share [S], n_mask [S], g_rho [H,W],
+        D [H,W], B [H,W,S,6])"""
+        opts = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K = map(self._r, (tgt, srcs, depth_t, depth_s, K))
+        S, _, H, W = srcs.shape
+        pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(S, 6))
+        NP = 6 * S
+        Hm, g, sc = np.zeros((NP, NP)), np.zeros(NP), np.zeros(4 + 2 * S)
+        gr, D, B = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W, S, 6))
+        self.lib.orc_linearize_dense_joint(H, W, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s), self._p(K), C.byref(opts),
+                                           int(bool(argmin)), int(rule), self._p(pose), C.c_double(lambda_depth), C.c_double(w_prior),
+                                           self._p(None if depth0 is None else self._r(depth0)), self._p(Hm), self._p(g), self._p(sc),
+                                           self._p(gr), self._p(D), self._p(B))
+        return dict(H=Hm, g=g, cost=sc[0], cost_photo=sc[1], cost_prior=sc[2], K=sc[3], share=sc[4:4 + S], n_mask=sc[4 + S:], g_rho=gr, D=D, B=B)
+
+    def refine_dense_joint(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, lambda_depth=1.0, w_prior=10.0,
+                           min_depth=0.06, max_depth=2.67, bits=None, decide=None, rule=0):
+        """joint dense mode over the FORWARD group of a window: tgt [B,3,H,W], srcs [S,B,3,H,W], depth_t [B,H,W] (one map per
+        target, shared by its S forward pairs), depth_s [S,B,H,W] (fixed), poses [S*B,6] (stacked forward pairs) ->
+        (poses [SB,6], refined target depths [B,H,W], stats [SB,n_iters+1,4]); bits [n_lin,SB,H,W] / decide [n_lin,SB]: replay"""
+        opts = opts or default_opts()
+        tgt, srcs, depth_s, K = map(self._r, (tgt, srcs, depth_s, K))
+        S, B, _, H, W = srcs.shape
+        depth = self._r(depth_t).copy()
+        pose = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(S * B, 6)).copy()
+        stats = np.zeros((S * B, opts.n_iters + 1, 4))
+        bits, decide = self._forced(bits, decide)
+        self.lib.orc_refine_dense_joint(H, W, B, S, self._p(tgt), self._p(srcs), self._p(depth), self._p(depth_s), self._p(K), C.byref(opts),
+                                        int(bool(argmin)), int(rule), C.c_double(lambda_depth), C.c_double(w_prior), C.c_double(min_depth),
+                                        C.c_double(max_depth), self._p(pose), self._p(stats), self._p(bits), self._p(decide))
+        return pose, depth, stats
+
     def ground_height(self, depth, K):
         """DNet camera-height map and ground mask of one image (dnet_layers.py:259-304,319-322)"""
         depth, K = self._r(depth), self._r(K)

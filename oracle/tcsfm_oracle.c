@@ -1583,6 +1583,326 @@ void orc_refine_dense(int H, int W, const real *tgt, const real *src, real *dept
 }
 
 /* ------------------------------------------------------------------------- */
+/* JOINT dense mode: the S forward pairs of a target share ONE inverse-depth map (optimize_depth_pred, optimizer.py:194-198,     */
+/* 235-247: one disparity per frame that every term of the loss sees)                                                           */
+/*
+ * Unknowns of target b: the left SE(3) perturbations xi_0 .. xi_{S-1} of its S forward warps and rho_q = 1 / depth_t(q).
+ * Cost: the forward term of the reference's loss (optimizer.py:47-73) plus the masked depth prior of the dense mode,
+ *     argmin:      C = [ sum_p sum_s M_s(p) W_x(p) diff_s(p)  +  w sum_p m(p) ((rho - rho0)/rho0)^2 ] / K,   K = sum_p sum_s M_s(p)
+ *                  M_s = the min-over-sources selection (orc_window_select), m = sum_s M_s; W_x: under the REFERENCE window rule
+ *                  (rule 1) the weight map of SOURCE 0 on every pixel (:69), under the PAIR rule (rule 0) the winning source's own
+ *     no argmin:   the same with M_s = valid_s (no auto-mask, :71-73) and every source's own weight map W_s
+ * (the constant factors of the reference's loss -- 0.25, batch normaliser -- multiply C as a whole and cancel in every step).
+ * Gradient: exact (equal to reference autograd of the forward term w.r.t. the poses and the SHARED target depth, golden G13),
+ *   adjoint form per source as in linearize_dense_masked, plus the weight terms: -M_s diff_s d dd_x/d(xi_x, rho), x = 0 or s.
+ * Curvature: the dense mode's model per (pixel, source) with the window geometry frozen at the pixel, so residual (p, s) sees
+ *   xi_s and rho_p only:   H_ss += a Jg_s' Lam_s Jg_s,  B_s(p) = a Jg_s' Lam_s alpha_s,  D(p) = sum_s a alpha_s' Lam_s alpha_s (+ prior)
+ * Schur complement on the 6S pose unknowns:
+ *     S_ss' = [s == s'] H_ss - sum_p B_s(p) B_s'(p)' / Dd(p),   gS_s = g_s - sum_p B_s(p) g_rho(p) / Dd(p),   Dd = (1 + lambda_depth) D
+ *   -- a full 6S x 6S system (12 x 12 for the KITTI window) wherever a pixel counts for more than one source (no argmin); under
+ *   the min over the sources every pixel counts for exactly one source and the off-diagonal blocks vanish identically.
+ *     (S + lambda diag S) dxi = -gS ;  drho_p = -(g_rho_p + sum_s B_s(p)' dxi_s) / Dd_p ;  rho clamped to [1/max_depth, 1/min_depth]
+ * LM (solver 1): accept / reject on C, all S poses and the depth map together (as dense_state_step).
+ */
+#define JMAXS 4
+typedef struct {
+    double H[6 * JMAXS * 6 * JMAXS], g[6 * JMAXS];   /* reduced system (np = 6 S, row-major np x np) */
+    double cost, cost_photo, cost_prior, K;
+    double share[JMAXS], n_mask[JMAXS];               /* per source: sum M_s W diff / K, sum M_s */
+} jlin_t;
+
+static void linearize_joint(int H, int W, int S, const real *tgt, const real *const *src, const real *depth_t, const real *const *depth_s,
+                            const double *T /* [S][12] */, const real *K, const orc_opts *op, const real *const *ae, int argmin, int rule,
+                            const unsigned short *const *bits /* [S] or NULL */, double lambda_depth, double w_prior, const real *depth0,
+                            jlin_t *out, double *g_rho /* [n] */, double *Dq /* [n] */, double *Bq /* [n][S][6] */) {
+    const int n = H * W, np = 7, NP = 6 * S;
+    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3), reps = (real)op->irls_eps;
+    px_t **px = (px_t **)malloc(sizeof(px_t *) * S);
+    real **rec = (real **)malloc(sizeof(real *) * S);
+    real *diff = (real *)malloc(sizeof(real) * (size_t)n * S), *valid = (real *)malloc(sizeof(real) * (size_t)n * S), *Wm = (real *)malloc(sizeof(real) * (size_t)n * S);
+    real *aeb = (real *)malloc(sizeof(real) * (size_t)n * S), *mask = (real *)malloc(sizeof(real) * (size_t)n * S), *margin = (real *)malloc(sizeof(real) * n);
+    for (int s = 0; s < S; s++) {
+        cam_t c;
+        cam_setup(&c, H, W, K, T + 12 * s, 0.0);
+        px[s] = (px_t *)malloc(sizeof(px_t) * n);
+        rec[s] = (real *)malloc(sizeof(real) * 3 * n);
+        g_force_bits = bits ? bits[s] : NULL;
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                px_t *P = &px[s][v * W + u];
+                px_eval(&c, src[s], depth_t, depth_s[s], u, v, np, P);
+                real D = depth_t[v * W + u];          /* scale column -> inverse-depth column (as linearize_dense_masked) */
+                P->a[6] *= -D; P->b[6] *= -D; P->zc[6] *= -D;
+                P->dpd[6] = P->dgx * P->a[6] + P->dgy * P->b[6];
+            }
+        for (int i = 0; i < n; i++)
+            for (int ch = 0; ch < 3; ch++) rec[s][ch * n + i] = px[s][i].rec[ch];
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                int i = v * W + u;
+                const px_t *P = &px[s][i];
+                real e = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    ssim_t q;
+                    ssim_at(tgt + ch * n, rec[s] + ch * n, H, W, u, v, &q);
+                    e += wl * clamp01(fabs(rec[s][ch * n + i] - tgt[ch * n + i])) + ws * q.s;
+                }
+                real sum = P->cd + P->pd;
+                diff[(size_t)s * n + i] = e; Wm[(size_t)s * n + i] = 1 - clamp01(fabs(P->cd - P->pd) / sum);
+                valid[(size_t)s * n + i] = (real)P->nat_valid;
+            }
+        memcpy(aeb + (size_t)s * n, ae[s], sizeof(real) * n);
+    }
+    g_force_bits = NULL;
+    /* masks as this restatement takes them; a forced replay overrides them below (flip statistics per source) */
+    if (argmin && S > 1) window_select_maps(H, W, S, diff, valid, aeb, op->automask, mask, (size_t)n, margin);
+    else
+        for (int s = 0; s < S; s++)
+            for (int i = 0; i < n; i++) {
+                const int am = op->automask && (argmin || S == 1);   /* no argmin: optimizer.py:71-73 has no auto-mask */
+                mask[(size_t)s * n + i] = (valid[(size_t)s * n + i] > 0 && (!am || diff[(size_t)s * n + i] < aeb[(size_t)s * n + i])) ? 1 : 0;
+                margin[i] = (real)1e30;
+            }
+    for (int s = 0; s < S; s++)
+        for (int i = 0; i < n; i++) {
+            real *m = &mask[(size_t)s * n + i];
+            if (bits) {
+                const int fm = bits[s][i] & 1;
+                const int am = op->automask && (argmin || S == 1);
+                flip_note(*m, fm, (argmin && S > 1) ? margin[i] < ORC_TIE
+                                                    : (px[s][i].nat_valid != px[s][i].valid) || (am && fabs(diff[(size_t)s * n + i] - aeb[(size_t)s * n + i]) < ORC_TIE));
+                *m = (real)fm;
+            } else if (!(argmin && S > 1)) {
+                const int am = op->automask && (argmin || S == 1);
+                *m = (px[s][i].valid && (!am || diff[(size_t)s * n + i] < aeb[(size_t)s * n + i])) ? 1 : 0;
+            }
+        }
+    memset(out, 0, sizeof(*out));
+    double Kn = 0;
+    for (int s = 0; s < S; s++)
+        for (int i = 0; i < n; i++) { Kn += mask[(size_t)s * n + i]; out->n_mask[s] += mask[(size_t)s * n + i]; }
+    out->K = Kn;
+    const double a = Kn > 0 ? 1.0 / Kn : 0.0;
+    double *gx_adj = (double *)calloc((size_t)n * 2 * S, sizeof(double));   /* per source: adjoint wrt the sample position of q */
+    double *gxi = (double *)calloc(NP, sizeof(double)), *Hxx = (double *)calloc((size_t)NP * NP, sizeof(double));
+    double *own = (double *)calloc(n, sizeof(double));                       /* weight terms of the depth gradient */
+    double *Lam = (double *)calloc((size_t)n * 3 * S, sizeof(double));
+    for (int s = 0; s < S; s++) {
+        const int x = (argmin && rule) ? 0 : s;             /* whose weight map multiplies this source's pixels: source 0's under the
+                                                               REFERENCE rule with argmin (optimizer.py:69), else the source's own */
+        g_force_bits = bits ? bits[s] : NULL;                /* sign ties of source s follow the engine's codes of pair s */
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                const int i = v * W + u;
+                const double am = mask[(size_t)s * n + i];
+                if (am == 0) continue;
+                const px_t *P = &px[s][i];
+                const real Wt = Wm[(size_t)x * n + i];
+                out->share[s] += am * Wt * diff[(size_t)s * n + i];
+                double lxx = 0, lxy = 0, lyy = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    const real *xx = tgt + ch * n, *y = rec[s] + ch * n;
+                    real r = y[i] - xx[i], ar = fabs(r);
+                    real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 6 + 2 * ch) : (real)0;
+                    gx_adj[((size_t)s * n + i) * 2] += am * Wt * wl * sgn * P->gx[ch];
+                    gx_adj[((size_t)s * n + i) * 2 + 1] += am * Wt * wl * sgn * P->gy[ch];
+                    if (ar <= 1) {
+                        real w1 = wl * Wt / (ar > reps ? ar : reps);
+                        lxx += w1 * P->gx[ch] * P->gx[ch]; lxy += w1 * P->gx[ch] * P->gy[ch]; lyy += w1 * P->gy[ch] * P->gy[ch];
+                    }
+                    ssim_t q;
+                    ssim_at(xx, y, H, W, u, v, &q);
+                    if (!q.clamped) {
+                        real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
+                        real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
+                        real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);
+                        real Sx = 0, Sy = 0;
+                        for (int dv = -1; dv <= 1; dv++)
+                            for (int du = -1; du <= 1; du++) {
+                                int qi = refl(v + dv, H) * W + refl(u + du, W);
+                                real cf = ws * (cA + cB * y[qi] + cC * xx[qi]);
+                                gx_adj[((size_t)s * n + qi) * 2] += am * Wt * cf * px[s][qi].gx[ch];
+                                gx_adj[((size_t)s * n + qi) * 2 + 1] += am * Wt * cf * px[s][qi].gy[ch];
+                                Sx += px[s][qi].gx[ch]; Sy += px[s][qi].gy[ch];
+                            }
+                        const real ninth = (real)1 / 9;
+                        real mx = Sx * ninth, my = Sy * ninth, ex = P->gx[ch] - mx, ey = P->gy[ch] - my;
+                        real w2 = ws * Wt / q.d2 * (real)1.125, w3 = ws * Wt / q.d1;
+                        lxx += w2 * ex * ex + w3 * mx * mx; lxy += w2 * ex * ey + w3 * mx * my; lyy += w2 * ey * ey + w3 * my * my;
+                    }
+                }
+                Lam[((size_t)s * n + i) * 3] = lxx; Lam[((size_t)s * n + i) * 3 + 1] = lxy; Lam[((size_t)s * n + i) * 3 + 2] = lyy;
+            }
+        /* weight terms: -M_s diff_s d dd_x / d theta at the pixel itself (sign of cd_x - pd_x: pair x's code) */
+        g_force_bits = bits ? bits[x] : NULL;
+        for (int i = 0; i < n; i++) {
+            const double am = mask[(size_t)s * n + i];
+            if (am == 0) continue;
+            const px_t *X = &px[x][i];
+            real sum = X->cd + X->pd, dif = X->cd - X->pd, raw = fabs(dif) / sum;
+            real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
+            double kdd = sg * 2.0 / ((double)sum * sum), e = diff[(size_t)s * n + i];
+            for (int j = 0; j < 6; j++) gxi[6 * x + j] -= am * e * kdd * (X->pd * X->zc[j] - X->cd * X->dpd[j]);
+            own[i] -= am * e * kdd * (X->pd * X->zc[6] - X->cd * X->dpd[6]);
+        }
+    }
+    g_force_bits = NULL;
+    /* assemble: pose gradients and the depth gradient from the adjoints; curvature blocks; Schur complement */
+    double *Sm = (double *)calloc((size_t)NP * NP, sizeof(double)), *gs = (double *)calloc(NP, sizeof(double));
+    for (int i = 0; i < n; i++) {
+        double gr = a * own[i], D = 0, B[6 * JMAXS], mcnt = 0;
+        for (int s = 0; s < S; s++) {
+            const px_t *P = &px[s][i];
+            const double ax = gx_adj[((size_t)s * n + i) * 2], ay = gx_adj[((size_t)s * n + i) * 2 + 1];
+            for (int j = 0; j < 6; j++) gxi[6 * s + j] += ax * P->a[j] + ay * P->b[j];
+            gr += a * (ax * P->a[6] + ay * P->b[6]);
+            const double am = a * mask[(size_t)s * n + i];
+            mcnt += mask[(size_t)s * n + i];
+            const double lxx = am * Lam[((size_t)s * n + i) * 3], lxy = am * Lam[((size_t)s * n + i) * 3 + 1], lyy = am * Lam[((size_t)s * n + i) * 3 + 2];
+            const double la6 = lxx * P->a[6] + lxy * P->b[6], lb6 = lxy * P->a[6] + lyy * P->b[6];
+            D += la6 * P->a[6] + lb6 * P->b[6];
+            for (int j = 0; j < 6; j++) {
+                const double la = lxx * P->a[j] + lxy * P->b[j], lb = lxy * P->a[j] + lyy * P->b[j];
+                B[6 * s + j] = la * P->a[6] + lb * P->b[6];
+                for (int k = 0; k <= j; k++) Hxx[(size_t)(6 * s + j) * NP + 6 * s + k] += la * P->a[k] + lb * P->b[k];
+            }
+        }
+        if (w_prior > 0 && depth0) {
+            const double rho = 1.0 / (double)depth_t[i], rho0 = 1.0 / (double)depth0[i], am = a * mcnt;
+            gr += am * 2.0 * w_prior * (rho - rho0) / (rho0 * rho0);
+            D += am * 2.0 * w_prior / (rho0 * rho0);
+            out->cost_prior += am * w_prior * (rho - rho0) * (rho - rho0) / (rho0 * rho0);
+        }
+        if (g_rho) g_rho[i] = gr;
+        if (Dq) Dq[i] = D;
+        if (Bq) memcpy(Bq + (size_t)i * 6 * S, B, sizeof(double) * 6 * S);
+        const double Dd = (1.0 + lambda_depth) * D;
+        if (Dd > 1e-30)
+            for (int j = 0; j < NP; j++) {
+                gs[j] -= B[j] * gr / Dd;
+                for (int k = 0; k <= j; k++) Sm[(size_t)j * NP + k] -= B[j] * B[k] / Dd;
+            }
+    }
+    for (int j = 0; j < NP; j++) {
+        out->g[j] = a * gxi[j] + gs[j];
+        for (int k = 0; k <= j; k++) { const double v = Hxx[(size_t)j * NP + k] + Sm[(size_t)j * NP + k]; out->H[j * NP + k] = v; out->H[k * NP + j] = v; }
+    }
+    for (int s = 0; s < S; s++) { out->share[s] *= a; out->cost_photo += out->share[s]; }
+    out->cost = out->cost_photo + out->cost_prior;
+    for (int s = 0; s < S; s++) { free(px[s]); free(rec[s]); }
+    free(px); free(rec); free(diff); free(valid); free(Wm); free(aeb); free(mask); free(margin);
+    free(gx_adj); free(gxi); free(Hxx); free(own); free(Lam); free(Sm); free(gs);
+}
+
+/* one joint linearisation of ONE target at given poses: the reduced system and the per-pixel records (tests: autograd pin) */
+void orc_linearize_dense_joint(int H, int W, int S, const real *tgt, const real *srcs /* [S][3][n] */, const real *depth_t,
+                               const real *depth_s /* [S][n] */, const real *K, const orc_opts *op, int argmin, int rule, const double *pose /* [S][6] */,
+                               double lambda_depth, double w_prior, const real *depth0, double *Hout /* [6S][6S] */, double *gout /* [6S] */,
+                               double *scal /* cost, cost_photo, cost_prior, K, share[S], n_mask[S] */, double *g_rho, double *Dq, double *Bq) {
+    const int n = H * W;
+    const real *src[JMAXS], *ds[JMAXS], *aep[JMAXS];
+    real *ae = (real *)malloc(sizeof(real) * (size_t)n * S);
+    double T[12 * JMAXS];
+    for (int s = 0; s < S; s++) {
+        src[s] = srcs + (size_t)s * 3 * n; ds[s] = depth_s + (size_t)s * n;
+        photo_err_map(H, W, tgt, src[s], op->w_l1, op->w_ssim, ae + (size_t)s * n);
+        aep[s] = ae + (size_t)s * n;
+        orc_pose_to_T(pose + 6 * s, T + 12 * s);
+    }
+    jlin_t L;
+    linearize_joint(H, W, S, tgt, src, depth_t, ds, T, K, op, aep, argmin, rule, NULL, lambda_depth, w_prior, depth0, &L, g_rho, Dq, Bq);
+    const int NP = 6 * S;
+    memcpy(Hout, L.H, sizeof(double) * NP * NP); memcpy(gout, L.g, sizeof(double) * NP);
+    scal[0] = L.cost; scal[1] = L.cost_photo; scal[2] = L.cost_prior; scal[3] = L.K;
+    for (int s = 0; s < S; s++) { scal[4 + s] = L.share[s]; scal[4 + S + s] = L.n_mask[s]; }
+    free(ae);
+}
+
+/* The forward group of a window, jointly: B targets x S sources, ONE depth map per target (depth_io [B][n], in / out), the
+ * source depths fixed (depth_s [S*B][n], stacked (s, b) as everywhere).  pose_io [S*B][6] in the stacked order of the forward
+ * pairs.  stats [S*B][n_iters+1][4] or NULL: row of pair (s, b) = joint cost of target b, its own share, its own mask count,
+ * lambda.  bits [n_lin][S*B][n] / decide [n_lin][S*B] (decide of pair (0, b) is the target's decision): forced replay. */
+void orc_refine_dense_joint(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
+                            const orc_opts *op, int argmin, int rule, double lambda_depth, double w_prior, double min_depth, double max_depth,
+                            double *pose_io, double *stats, const unsigned short *bits, const int *decide) {
+    const int n = H * W, SB = S * B, NP = 6 * S;
+    const int lm_final = op->solver == 1 && op->n_iters > 0;
+    const double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
+    for (int b = 0; b < B; b++) {
+        const real *src[JMAXS], *ds[JMAXS], *aep[JMAXS];
+        real *ae = (real *)malloc(sizeof(real) * (size_t)n * S), *d0 = (real *)malloc(sizeof(real) * n);
+        real *dep_try = depth_io + (size_t)b * n, *dep_acc = (real *)malloc(sizeof(real) * n);
+        double Tcur[12 * JMAXS], Ttry[12 * JMAXS], lambda = op->lambda0;
+        double *gr = (double *)malloc(sizeof(double) * n), *Dq = (double *)malloc(sizeof(double) * n), *Bq = (double *)malloc(sizeof(double) * (size_t)n * 6 * S);
+        double *gr_a = (double *)malloc(sizeof(double) * n), *Dq_a = (double *)malloc(sizeof(double) * n), *Bq_a = (double *)malloc(sizeof(double) * (size_t)n * 6 * S);
+        jlin_t cur, tr;
+        int have_cur = 0;
+        memset(&cur, 0, sizeof(cur));
+        memcpy(d0, dep_try, sizeof(real) * n);
+        for (int s = 0; s < S; s++) {
+            const int m = s * B + b;
+            src[s] = srcs + (size_t)m * 3 * n; ds[s] = depth_s + (size_t)m * n;
+            photo_err_map(H, W, tgt + (size_t)b * 3 * n, src[s], op->w_l1, op->w_ssim, ae + (size_t)s * n);
+            aep[s] = ae + (size_t)s * n;
+            orc_pose_to_T(pose_io + 6 * m, Tcur + 12 * s);
+        }
+        memcpy(Ttry, Tcur, sizeof(double) * 12 * S);
+        for (int it = 0; it <= op->n_iters; it++) {
+            const int final = it == op->n_iters;
+            if (final && !lm_final) break;
+            const unsigned short *fb[JMAXS];
+            for (int s = 0; s < S; s++) fb[s] = bits ? bits + ((size_t)it * SB + s * B + b) * n : NULL;
+            g_lin_idx = bits ? it : -1;
+            linearize_joint(H, W, S, tgt + (size_t)b * 3 * n, src, dep_try, ds, Ttry, K + 9 * b, op, aep, argmin, rule, bits ? fb : NULL, lambda_depth, w_prior, d0,
+                            &tr, gr, Dq, Bq);
+            g_lin_idx = -1;
+            if (stats)
+                for (int s = 0; s < S; s++) {
+                    double *row = stats + ((size_t)(s * B + b) * (op->n_iters + 1) + it) * 4;
+                    row[0] = tr.cost; row[1] = tr.share[s]; row[2] = tr.n_mask[s]; row[3] = lambda;
+                }
+            const int *dec = decide ? decide + (size_t)it * SB + b : NULL;
+            if (final) {
+                if (dec ? *dec != 0 : tr.cost < cur.cost) memcpy(Tcur, Ttry, sizeof(double) * 12 * S);
+                else memcpy(dep_try, dep_acc, sizeof(real) * n);
+                break;
+            }
+            if (op->solver == 0 || !have_cur || (dec ? *dec != 0 : tr.cost < cur.cost)) {
+                if (op->solver == 1 && have_cur) lambda = fmax(lambda * op->lambda_down, op->lambda_min);
+                cur = tr; memcpy(Tcur, Ttry, sizeof(double) * 12 * S); have_cur = 1;
+                memcpy(dep_acc, dep_try, sizeof(real) * n);
+                memcpy(gr_a, gr, sizeof(double) * n); memcpy(Dq_a, Dq, sizeof(double) * n); memcpy(Bq_a, Bq, sizeof(double) * (size_t)n * 6 * S);
+            } else lambda *= op->lambda_up;
+            /* (S + lambda diag S + 1e-12 I) d = -gS */
+            double A[36 * JMAXS * JMAXS], dl[6 * JMAXS];
+            for (int i = 0; i < NP; i++) {
+                for (int j = 0; j < NP; j++) A[i * NP + j] = cur.H[i * NP + j];
+                A[i * NP + i] += lambda * cur.H[i * NP + i] + 1e-12;
+                dl[i] = -cur.g[i];
+            }
+            if (chol_solve(NP, A, dl)) memset(dl, 0, sizeof(dl));
+            for (int s = 0; s < S; s++) {
+                double E[12];
+                orc_se3_exp(dl + 6 * s, E);
+                orc_se3_mul(E, Tcur + 12 * s, Ttry + 12 * s);
+            }
+            for (int i = 0; i < n; i++) {
+                const double Dd = (1.0 + lambda_depth) * Dq_a[i];
+                if (!(Dd > 1e-30)) { dep_try[i] = dep_acc[i]; continue; }
+                double bd = 0;
+                for (int j = 0; j < NP; j++) bd += Bq_a[(size_t)i * NP + j] * dl[j];
+                double rho = 1.0 / (double)dep_acc[i] - (gr_a[i] + bd) / Dd;
+                rho = rho < lo ? lo : (rho > hi ? hi : rho);
+                dep_try[i] = (real)(1.0 / rho);
+            }
+        }
+        if (!lm_final) memcpy(Tcur, Ttry, sizeof(double) * 12 * S);
+        for (int s = 0; s < S; s++) orc_T_to_pose(Tcur + 12 * s, pose_io + 6 * (s * B + b));
+        free(ae); free(d0); free(dep_acc); free(gr); free(Dq); free(Bq); free(gr_a); free(Dq_a); free(Bq_a);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* DNet ground-plane scale recovery, models/dnet_layers.py:249-327                            */
 
 static void v3_norm(real *v) { /* F.normalize: v / max(|v|, 1e-12) */

@@ -266,7 +266,7 @@ def main():
         for tag, upd in (("fwd", {}), ("fwd_inv", {'l_inverse_reconstruction': True}),
                          ("full", {'l_inverse_reconstruction': True, 'l_depth_consist': True}),
                          ("noargmin_full", {'diff_img_argmin': False, 'l_inverse_reconstruction': True, 'l_depth_consist': True}),
-                         ("noauto_fwd", {'automasking': False})):
+                         ("noauto_fwd", {'automasking': False}), ("noargmin_fwd", {'diff_img_argmin': False})):
             fp = T(first, dt).clone().requires_grad_()
             d_t = T(g13["depth_t"], dt).clone().requires_grad_()
             d_s = [T(g13["depth_s"][i], dt).clone().requires_grad_() for i in range(S13)]
@@ -278,7 +278,7 @@ def main():
             loss.backward()
             g13[f"{tag}_loss"] = np.array(loss.item())
             g13[f"{tag}_grad_pose"] = N(fp.grad)
-            if tag in ("fwd", "full"):
+            if tag in ("fwd", "full", "noargmin_fwd"):
                 g13[f"{tag}_grad_depth_t"] = N(d_t.grad[:, 0])
                 g13[f"{tag}_grad_depth_s"] = np.stack([N(x.grad[:, 0]) for x in d_s])
             if tag == "full":

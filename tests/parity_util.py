@@ -143,7 +143,7 @@ def window_pair_views(w):
     return out
 
 
-def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale=None, max_flip_frac=2e-3, rule=0):
+def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale=None, max_flip_frac=2e-3, rule=0, joint=False):
     """a window (B targets x S sources -> 2*S*B directed pairs) through Engine.refine_window / refine_dense_window with the
     decision trace on, then ONE oracle replay of the whole window.  w: dict(target, sources, depth_t, depth_s, K, first)."""
     S, B = w["sources"].shape[:2]
@@ -156,6 +156,10 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
     e.trace_begin(nl, N)
     depth = ls = None
     if dense:
+        import ctypes as _C
+        o2 = type(o)(); _C.memmove(_C.byref(o2), _C.byref(o), _C.sizeof(o2)); o = o2
+        o.dense_joint = 1 if joint else 0            # joint: one depth map per target shared by its S forward pairs (tcsfm.h)
+        o.window_rule = rule if joint else 0
         pose, depth, st = e.refine_dense_window(*args, o, stats=True, argmin=argmin)
         depth = depth.cpu().numpy()[:, 0]
     else:
@@ -164,7 +168,23 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
     bits, dec = e.trace_end()
     pose, st = pose.cpu().numpy().astype(np.float64), st.cpu().numpy()
     orc.flip_stats_reset()
-    if dense:
+    if dense and joint:
+        # forward group: the joint oracle (shared depth, 6S x 6S reduced system); inverse pairs: the pair-form dense oracle
+        SB = S * B
+        kwj = dict(lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth), min_depth=float(o.min_depth), max_depth=float(o.max_depth))
+        pf, df, sf = orc.refine_dense_joint(w["target"], w["sources"], w["depth_t"][:, 0], w["depth_s"][:, :, 0], w["K"], w["first"][:SB], oopts,
+                                            argmin=argmin, rule=rule, bits=bits[:, :SB], decide=dec[:, :SB], **kwj)
+        rp, rd, rst = np.zeros((N, 6)), np.zeros((N, H, W)), np.zeros((N, nit + 1, 4))
+        rp[:SB], rst[:SB] = pf, sf
+        for m in range(SB):
+            rd[m] = df[m % B]
+        views = window_pair_views(w)
+        for m in range(SB, N):
+            t, sr, dt, ds, K = views[m]
+            rp[m], rd[m], rst[m] = orc.refine_dense(t, sr, dt, ds, w["first"][m], K, oopts, bits=bits[:, m], decide=dec[:, m], **kwj)
+        rls = None
+        assert all(np.array_equal(depth[s_ * B + b_], depth[b_]) for s_ in range(S) for b_ in range(B))     # the S forward slots hold ONE map
+    elif dense:
         rp, rd, rst = orc.refine_dense_window(*oargs, oopts, argmin=argmin, lambda_depth=float(o.lambda_depth), w_prior=float(o.prior_depth),
                                               min_depth=float(o.min_depth), max_depth=float(o.max_depth), bits=bits, decide=dec)
         rls = None
@@ -194,7 +214,8 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
         for n in range(N):
             t, sr, dt, ds, K = views[n]
             ph = orc.photometric(t, sr, dt, ds, w["first"][n], K, log_scale=float(ls0[n]), w_l1=float(o.w_l1), w_ssim=float(o.w_ssim))
-            am = int(o.automask) and not (rule == 1 and not argmin and n < S * B)     # REFERENCE rule without argmin: no auto-mask on the forward term
+            # REFERENCE rule / joint dense mode without argmin: no auto-mask on the forward term (optimizer.py:71-73)
+            am = int(o.automask) and not ((rule == 1 or (dense and joint)) and not argmin and n < S * B)
             own[n] = (ph["valid"] > 0.5) & ((ph["diff"] < ph["auto_err"]) if am else True)
         if argmin and S > 1:
             if refine and np.any(ls0 != 0):

@@ -773,7 +773,7 @@ def test_dense_window_mode_vs_oracle(oracle64):
     w = _window(B, S, H, W)
     e = _eng(H, W, 2 * S * B)
     tg, sr, dt, ds, K, p0 = (_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first"))
-    o = default_opts(n_iters=3, w_dc=0.0, min_depth=0.06, max_depth=2.67)
+    o = default_opts(n_iters=3, w_dc=0.0, min_depth=0.06, max_depth=2.67, dense_joint=0)       # the per-pair-copy mode (joint: test_gpu_joint_dense.py)
     # without the selection it is the pair form on the stacked tensors
     pw, dw, _ = e.refine_dense_window(tg, sr, dt, ds, K, p0, o, argmin=False)
     T = tg.repeat(S, 1, 1, 1); Sx = sr.reshape(S * B, 3, H, W); Dt = dt.repeat(S, 1, 1, 1); Ds = ds.reshape(S * B, 1, H, W)

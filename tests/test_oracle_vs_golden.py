@@ -332,6 +332,69 @@ def test_window_reference_rule_refines_and_reduces(oracle64):
     assert abs(st[:, 0, 0].sum() - before) < 1e-12
 
 
+@pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
+def test_joint_dense_gradients_vs_reference_autograd_G13(name, oracle64):
+    """joint dense mode (ONE inverse-depth map per target frame, shared by its S forward pairs -- optimizer.py:194-198,235-247):
+    the gradient of the forward term of the reference's loss w.r.t. the SHARED target depth and w.r.t. the S poses equals reference
+    autograd (golden G13), with the min over the sources (weight map of source 0, optimizer.py:69) and without it (:71-73);
+    with one source the joint linearisation IS the pair-form dense linearisation"""
+    g = load_golden(name)
+    S, B = g["sources"].shape[:2]
+    op = default_opts(n_iters=1)
+    for tag, argmin, factor in (("fwd", True, 1.0), ("noargmin_fwd", False, 0.25)):
+        parts = [oracle64.linearize_dense_joint(g["target"][b], g["sources"][:, b], g["depth_t"][b, 0], g["depth_s"][:, b, 0], g["K"][b],
+                                                g["first"][[s * B + b for s in range(S)]], op, argmin=argmin) for b in range(B)]
+        Ktot = sum(L["K"] for L in parts)                     # the reference normalises over the batch; the joint problem per target
+        loss = factor * sum(L["cost_photo"] * L["K"] for L in parts) / Ktot
+        assert abs(loss - float(g[f"{tag}_loss"])) < 1e-12 * loss
+        for b in range(B):
+            gd = -factor * parts[b]["g_rho"] * parts[b]["K"] / Ktot / g["depth_t"][b, 0] ** 2          # d / d depth = -rho^2 d / d rho
+            ref = g[f"{tag}_grad_depth_t"][b]
+            assert _maxabs(gd, ref) < 1e-11 * np.abs(ref).max(), (tag, b, _maxabs(gd, ref))
+            # pose gradients: with the depth block frozen (lambda_depth -> infinity) the reduced system is the pose system itself
+            Lf = oracle64.linearize_dense_joint(g["target"][b], g["sources"][:, b], g["depth_t"][b, 0], g["depth_s"][:, b, 0], g["K"][b],
+                                                g["first"][[s * B + b for s in range(S)]], op, argmin=argmin, lambda_depth=1e30)
+            for s in range(S):
+                m = s * B + b
+                gp = factor * Lf["K"] / Ktot * (oracle64.euler_left_jacobian(g["first"][m]).T @ Lf["g"][6 * s:6 * s + 6])
+                assert _maxabs(gp, g[f"{tag}_grad_pose"][m]) < 1e-11 * np.abs(g[f"{tag}_grad_pose"]).max(), (tag, m)
+        # the reduced camera system: 6S x 6S.  Under the min over the sources every pixel counts for exactly one source and the
+        # off-diagonal blocks vanish identically; without it the shared depth couples the poses
+        off = np.abs(parts[0]["H"][:6, 6:]).max() / np.abs(parts[0]["H"]).max()
+        assert (off == 0.0) if argmin else (off > 0.05), (tag, off)
+    b = 0
+    kw = dict(lambda_depth=0.3, w_prior=10.0, depth0=g["depth_t"][b, 0] * 1.01)
+    L1 = oracle64.linearize_dense_joint(g["target"][b], g["sources"][:1, b], g["depth_t"][b, 0], g["depth_s"][:1, b, 0], g["K"][b], g["first"][[b]], op, **kw)
+    Lp = oracle64.linearize_dense(g["target"][b], g["sources"][0, b], g["depth_t"][b, 0], g["depth_s"][0, b, 0], g["first"][b], g["K"][b], op, **kw)
+    assert _maxabs(L1["H"], Lp["H"]) < 1e-13 * np.abs(Lp["H"]).max() and _maxabs(L1["g"], Lp["g"]) < 1e-15 and _maxabs(L1["g_rho"], Lp["g_rho"]) < 1e-16
+    assert _maxabs(L1["D"], Lp["D"]) < 1e-16 and abs(L1["cost"] - Lp["cost"]) < 1e-15
+
+
+@pytest.mark.parametrize("rule,nit", [(0, 4), (0, 8), (1, 16)])
+def test_joint_dense_refinement_beats_per_pair_copies(rule, nit, oracle64):
+    """the joint problem (one shared depth map, 6S x 6S reduced system) ends at a lower value of ITS cost than the per-pair-copy mode
+    (every forward pair refines its own copy of the target depth; inverse depths averaged afterwards) from the same start.
+    With the winning source's own weight map (window rule PAIR, the default) already after 4 Gauss-Newton iterations; with the
+    reference's weighting (source 0's map on every pixel, optimizer.py:69) the pose of source 0 carries a gradient term from the
+    pixels the other source won that the Gauss-Newton curvature cannot model (the weight 1 - dd is concave in the pose), the
+    iteration is slower and overtakes the copies only towards convergence -- numbers: DESIGN.md section 2."""
+    g = load_golden("winloss48x160")
+    S, B = g["sources"].shape[:2]
+    n_fwd = S * B
+    d_t, d_s = g["depth_t"][:, 0] * 1.03, g["depth_s"][:, :, 0]                 # start from a biased target depth
+    a = (g["target"], g["sources"], d_t, d_s, g["K"])
+    o = default_opts(n_iters=nit)
+    kw = dict(lambda_depth=1.0, w_prior=10.0, min_depth=0.06, max_depth=2.67)
+    pj, dj, st = oracle64.refine_dense_joint(*a, g["first"][:n_fwd], o, argmin=True, rule=rule, **kw)
+    assert st[0, nit - 1, 0] < st[0, 0, 0]
+    pw, dw, _ = oracle64.refine_dense_window(*a, g["first"], o, argmin=True, **kw)
+    avg = 1.0 / (1.0 / dw[:n_fwd]).reshape(S, B, *d_t.shape[1:]).mean(0)        # what optimizer.py did with the copies (r02)
+    cost = lambda poses, depth: oracle64.linearize_dense_joint(g["target"][0], g["sources"][:, 0], depth[0], d_s[:, 0], g["K"][0], poses[[s * B for s in range(S)]],
+                                                               default_opts(n_iters=1), argmin=True, w_prior=10.0, depth0=d_t[0], rule=rule)["cost"]
+    c0, cj, cw = cost(g["first"], d_t), cost(pj, dj), cost(pw, avg)
+    assert cj < c0 and cj < cw, (c0, cj, cw)
+
+
 def test_torch_twin_vs_reference_golden():
     """oracle/torch_twin.py (the reference-style Adam/autograd step that bench.py times on the host cores) against the
     reference's own float64 outputs: maps, cost and autograd gradient (goldens G1-G3, G6)"""

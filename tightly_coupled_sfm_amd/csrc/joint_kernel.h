@@ -1,0 +1,607 @@
+// joint_kernel.h -- JOINT dense mode: the S forward pairs of a target share ONE inverse-depth map (the reference's
+// `optimize_depth_pred`: one disparity per frame that every term of the loss sees, optimizer.py:194-198,235-247).
+// Mirrors linearize_joint / orc_refine_dense_joint of the oracle.
+//
+// Unknowns of target b: the S left SE(3) perturbations of its forward warps and rho_q = 1 / depth_t(q).  Cost: the forward term of
+// the reference's loss (optimizer.py:47-73) + the masked depth prior of the dense mode.  Per pixel the depth block is a scalar and is
+// eliminated; what is left is ONE reduced camera system of 6S x 6S per target (12 x 12 for the KITTI window):
+//     S_ss' = [s == s'] H_ss - sum_p B_s(p) B_s'(p)' / Dd(p),   gS_s = g_s - sum_p B_s(p) g_rho(p) / Dd(p)
+// Under the min over the sources every pixel counts for exactly one source, so the off-diagonal blocks vanish identically and are
+// not accumulated (JointParams::argmin); without it the shared depth couples the poses.
+//
+// k_dense_joint        one workgroup = one 32x16 tile of ONE TARGET, looping over its S sources with the LDS staging of
+//                      k_dense_linearize reused per source (phase 1: tile + 2-pixel halo warped with the SHARED depth map; phase 2a:
+//                      residuals + adjoint coefficients on tile + 1-pixel halo; phase 2b: adjoint gather, this source's pose gradient
+//                      and curvature block, its share of the depth gradient / curvature).  Per-pixel cross-source state (g_rho, D,
+//                      mask count, weight terms) stays in registers, B_s goes straight into the pixel's back-substitution record;
+//                      every source's sums are reduced over the workgroup inside the loop, the Schur terms after it.
+// k_solve_joint        one workgroup per target: fp64 sum of the workgroup records, LM bookkeeping, (6S+1)-column Gauss-Jordan in
+//                      LDS, SE(3) retraction of every source's transform, next PairConst of every forward pair.
+// k_dense_joint_update back-substitution drho = -(g_rho + sum_s B_s' dxi_s) / Dd of the shared map, written to every forward pair's
+//                      depth slot (the selection pass reads them per pair) and, at the end, to the caller.
+#pragma once
+#include "dense_kernel.h"
+
+namespace tc {
+
+constexpr int JMAXS = 3;                       // sources per target the joint kernels are instantiated for (2 .. JMAXS)
+template <int NS> struct JointLayout {
+    static constexpr int NP = 6 * NS;
+    static constexpr int NHJ = NP * (NP + 1) / 2;
+    static constexpr int OFF_G = NHJ, OFF_S = NHJ + NP, OFF_SHARE = OFF_S + 3, OFF_NM = OFF_SHARE + NS, NACC = OFF_NM + NS;
+    static constexpr int JREC = (2 + 6 * NS + 3) / 4 * 4;     // floats per pixel record: g_rho, Dd, B[NS][6], padded to float4s
+    __host__ __device__ static constexpr int tri(int r, int c) { return r >= c ? r * (r + 1) / 2 + c : c * (c + 1) / 2 + r; }
+};
+
+struct JointParams {
+    float *jrec;             // [B][H*W][JREC]
+    const float *depth0;     // [.][H*W] prior centre of target b at index b (the slot of forward pair (0, b))
+    float *jblockrec;        // [B][nblk][NACC] one record per workgroup
+    float lambda_depth, w_prior;
+    int B, S, argmin, rule;  // rule: TCSFM_WINDOW_REFERENCE -> with argmin, source 0's weight map on every pixel (optimizer.py:69)
+    int automask;            // own masks (no argmin): optimizer.py:71-73 has no auto-mask there -> 0 from the host when S > 1
+};
+
+// reduce N (<= 32) per-thread values over the workgroup and ADD them to LDS accumulators acc[slot(k)], k = 0..N-1
+template <int N, int NT, class SlotFn>
+__device__ __forceinline__ void joint_reduce_add(const float *v, float *red, float *acc, SlotFn slot, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    wave_reduce_store<N>(v, red + wave * 32, lane);
+    __syncthreads();
+    if (tid < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) s += red[w * 32 + tid];
+        acc[slot(tid)] += s;
+    }
+    __syncthreads();
+}
+
+template <int NS, int TW, int TH, int NT, bool TRACE = false>
+__global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams J) {
+    using JL = JointLayout<NS>;
+    constexpr int NP = 6;
+    constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;
+    constexpr int W1 = TW + 2, H1 = TH + 2, N1 = W1 * H1;
+    constexpr int NCEN = TW * TH;
+    static_assert(NCEN == NT, "one tile pixel per thread");
+    __shared__ float4 rec1[N2 * 3];
+    __shared__ float4 aux[N2];
+    __shared__ float4 coef[N1 * 3];
+    __shared__ float w0map[N2];          // REFERENCE rule: source 0's depth-consistency weight over the staged region
+    __shared__ float red[(NT / 64) * 32];
+    __shared__ float acc[JL::NACC];
+
+    const int nblk = P.tiles_x * P.tiles_y;
+    int bid = blockIdx.x;
+    {
+        int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int b = blockIdx.y;
+    const int H = P.H, W = P.W, hw = H * W;
+    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const int x00 = txi * TW, y00 = tyi * TH;
+    const float *depth_t = P.depth_t + (size_t)b * hw;          // the SHARED map: slot of forward pair (0, b)
+    const int tid = threadIdx.x;
+    stamp_begin(P.stamp, tid);
+    for (int i = tid; i < JL::NACC; i += NT) acc[i] = 0.f;
+
+    const int oy = tid / TW, ox = tid - oy * TW;
+    const int gxo = x00 + ox, gyo = y00 + oy;
+    const bool inimg = gxo < W && gyo < H;
+    const bool ref_w = J.argmin && J.rule;                       // source 0's weight map everywhere
+    float *jr = J.jrec + ((size_t)b * hw + (inimg ? gyo * W + gxo : 0)) * JL::JREC;
+
+    // per-pixel state across the sources
+    float o_depth = 1.f, g_rho = 0.f, Dsum = 0.f, mcnt = 0.f, esum = 0.f;
+    float ddJ0[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // REFERENCE rule: d dd_0 / d (xi_0, rho) at this pixel
+
+    constexpr int NRING = N2 - NCEN;
+    static_assert(NRING <= NT, "one ring round");
+    constexpr int RING_THREADS = (NRING + 63) / 64 * 64;
+    struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
+
+#pragma unroll 1
+    for (int s = 0; s < NS; s++) {
+        const int n = s * J.B + b;
+        const PairConst &c = P.pc[n];
+        const float4 *tgtpack = P.tgtpack + (size_t)n * hw;
+        const float4 *srcpack = P.srcpack + (size_t)n * (H + 2) * (W + 2);
+        float a[7], bb[7], zc[7];
+        float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f;
+
+        // ---------------- phase 1: tile + 2-pixel halo, warped with the shared depth ----------------
+        auto s_load = [&](Stage &S) {
+            S.px = refl_idx(x00 + S.lx - 2, W); S.py = refl_idx(y00 + S.ly - 2, H);
+            const int gi = S.py * W + S.px;
+            S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+        };
+        auto s_warp = [&](Stage &S) {
+            warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
+            tap4_fetch(srcpack, W, H, S.px, S.py, S.g.rx, S.g.ry, S.g.oobx || S.g.ooby, S.t);
+        };
+        auto s_store = [&](Stage &S, bool write, bool own) {
+            float4 val, gx, gy;
+            tap4_lerp(S.t, val, gx, gy);
+            const bool oob = S.g.oobx || S.g.ooby;
+            float pd = c.es * val.w, cd = S.g.Z;
+            float Wt = 1.f - clamp01(fabsf(cd - pd) * frcp(cd + pd));
+            if (write) {
+                float4 *rec = rec1 + (S.ly * W2 + S.lx) * 3;
+                lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
+                lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+                lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
+                lds_write1(aux + S.ly * W2 + S.lx, Wt, oob ? 0.f : 1.f, S.tp.w, 0.f);
+                if (ref_w && s == 0) w0map[S.ly * W2 + S.lx] = Wt;
+            }
+            if (own) {
+                if (TRACE && P.trace != nullptr && inimg)
+                    P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
+                        (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
+                geo_jac<7>(c, S.g, W, H, a, bb, zc);
+                a[6] *= -S.dep; bb[6] *= -S.dep; zc[6] *= -S.dep;      // scale column -> inverse-depth column
+                o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
+            }
+        };
+        {
+            Stage A;
+            A.lx = ox + 2; A.ly = oy + 2;
+            if (tid < RING_THREADS) {
+                Stage B;
+                const int hi = min(tid, NRING - 1);
+                if (hi < 2 * W2) { B.ly = hi / W2; B.lx = hi - B.ly * W2; }
+                else if (hi < 4 * W2) { const int k = hi - 2 * W2; B.ly = H2 - 2 + k / W2; B.lx = k - (k / W2) * W2; }
+                else { const int k = hi - 4 * W2; B.ly = 2 + (k >> 2); const int q = k & 3; B.lx = q < 2 ? q : W2 - 4 + q; }
+                s_load(A); s_load(B);
+                s_warp(A); s_warp(B);
+                s_store(A, true, true); s_store(B, tid < NRING, false);
+            } else {
+                s_load(A); s_warp(A); s_store(A, true, true);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---------------- phase 2a: residual + adjoint coefficients for tile + 1-pixel halo ----------------
+        float o_valid = 0.f, o_diff = 0.f, o_w = 0.f, o_m = 0.f, o_lxx = 0.f, o_lxy = 0.f, o_lyy = 0.f, o_l1x = 0.f, o_l1y = 0.f;
+        float o_gx[3] = {0, 0, 0}, o_gy[3] = {0, 0, 0}, o_y[3] = {0, 0, 0}, o_x[3] = {0, 0, 0};
+        constexpr int RA = (N1 + NT - 1) / NT;
+#pragma unroll
+        for (int r = 0; r < RA; r++) {
+            int lx, ly;
+            bool active = true;
+            if (r == 0) { lx = ox + 1; ly = oy + 1; }
+            else {
+                int hi = tid + (r - 1) * NT;
+                active = hi < N1 - NCEN;
+                if (hi < W1) { ly = 0; lx = hi; }
+                else if (hi < 2 * W1) { ly = H1 - 1; lx = hi - W1; }
+                else { int k = hi - 2 * W1; ly = 1 + (k >> 1); lx = (k & 1) ? W1 - 1 : 0; }
+            }
+            if (!active) continue;
+            const int gx_ = x00 + lx - 1, gy_ = y00 + ly - 1;
+            const bool real = gx_ >= 0 && gx_ < W && gy_ >= 0 && gy_ < H;
+            const float4 *ctr = rec1 + ((ly + 1) * W2 + lx + 1) * 3;
+            f32x4 q0, q1, q2;
+            lds_read3v(ctr, q0, q1, q2);
+            const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = q1.lo, gyc01 = q1.hi, yx2c = q2.lo, g2c = q2.hi;
+            const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
+            const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
+            float4 ax = lds_read1(aux + (ly + 1) * W2 + lx + 1);
+            f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, Gx01, Gy01, S2, SS2, G2;
+            float Sxy2;
+            const float4 *nbA = ctr - (W2 + 1) * 3;
+            {
+                f32x4 n0, n1, n2;
+                lds_read3v(nbA, n0, n1, n2);
+                nbA += 3;
+                Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
+                Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
+                Gx01 = n1.lo; Gy01 = n1.hi;
+                S2 = pk_sub(n2.lo, yx2c);
+                SS2 = S2 * S2; Sxy2 = S2.x * S2.y; G2 = n2.hi;
+            }
+#pragma unroll 1
+            for (int kk = 1; kk < 9; kk++) {
+                f32x4 n0, n1, n2;
+                lds_read3v(nbA, n0, n1, n2);
+                nbA += (kk == 2 || kk == 5) ? (W2 - 2) * 3 : 3;
+                f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+                Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+                Gx01 += n1.lo; Gy01 += n1.hi;
+                f2 e2v = pk_sub(n2.lo, yx2c);
+                S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
+            }
+            ChanTerms<f2> t01;
+            ChanTerms<float> t2;
+            ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
+            ssim_l1_channel<float>(yx2c.y, yx2c.x, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+            const float cB[3] = {t01.cB.x, t01.cB.y, t2.cB}, cC[3] = {t01.cC.x, t01.cC.y, t2.cC};
+            float cA[3] = {t01.cA.x, t01.cA.y, t2.cA};
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) cA[ch] += cB[ch] * (0.5f - yc[ch]) + cC[ch] * (0.5f - xc[ch]);
+            const float e1 = t01.e1.x + t01.e1.y + t2.e1, e2 = t01.e2.x + t01.e2.y + t2.e2;
+            const float l1x = t01.l1x.x + t01.l1x.y + t2.l1x, l1y = t01.l1y.x + t01.l1y.y + t2.l1y;
+            float lxx = t01.lxx.x + t01.lxx.y + t2.lxx, lxy = t01.lxy.x + t01.lxy.y + t2.lxy, lyy = t01.lyy.x + t01.lyy.y + t2.lyy;
+            {
+                const float n9 = 1.f / 9.f;
+                const f2 mx = Gx01 * n9, my = Gy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+                const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
+                         qyy = t01.id2 * ey * ey + t01.id1 * my * my;
+                const float mx2 = G2.x * n9, my2 = G2.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
+                lxx += qxx.x + qxx.y + t2.id2 * ex2 * ex2 + t2.id1 * mx2 * mx2;
+                lxy += qxy.x + qxy.y + t2.id2 * ex2 * ey2 + t2.id1 * mx2 * my2;
+                lyy += qyy.x + qyy.y + t2.id2 * ey2 * ey2 + t2.id1 * my2 * my2;
+            }
+            float diff = e1 + e2;
+            float m = (real && ax.y > 0.5f && (!J.automask || diff < ax.z)) ? 1.f : 0.f;
+            if (P.ext_mask != nullptr)      // min over the sources: the selection mask of forward pair n
+                m = (real && P.ext_mask[(size_t)n * hw + (size_t)(real ? gy_ * W + gx_ : 0)] != 0.f) ? 1.f : 0.f;
+            const float Wx = (ref_w && s > 0) ? w0map[(ly + 1) * W2 + lx + 1] : ax.x;      // whose weight multiplies the pixel
+            float w = m * Wx;
+            float4 *cr = coef + (ly * W1 + lx) * 3;
+            lds_write1(cr + 0, w * cA[0], w * cA[1], w * cA[2], w * cB[0]);
+            lds_write1(cr + 1, w * cB[1], w * cB[2], w * cC[0], w * cC[1]);
+            lds_write1(cr + 2, w * cC[2], 0.f, 0.f, 0.f);
+            if (r == 0) {
+                o_valid = ax.y;
+                o_diff = diff; o_w = w; o_m = m; o_lxx = lxx; o_lxy = lxy; o_lyy = lyy; o_l1x = l1x; o_l1y = l1y;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) { o_gx[ch] = gxc[ch]; o_gy[ch] = gyc[ch]; o_y[ch] = yc[ch]; o_x[ch] = xc[ch]; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // ---------------- phase 2b: adjoint gather; this source's gradient, curvature block and depth terms ----------------
+        float v[29];      // H_ss (21, pre-Schur) | g_s (6) | share_s | n_mask_s
+#pragma unroll
+        for (int i = 0; i < 29; i++) v[i] = 0.f;
+        if (inimg) {
+            float sg;
+            {
+                float sum = o_cd + o_pd, dif = o_cd - o_pd, isum = frcp(sum), raw = fabsf(dif) * isum;
+                sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
+                if (TRACE && P.trace != nullptr) {
+                    unsigned short *tb = P.trace + (size_t)n * hw + gyo * W + gxo;
+                    *tb = (unsigned short)(*tb | (o_m > 0.f ? 1 : 0) | (o_valid > 0.5f ? 2 : 0) | (sign_code(dif) << 4) | (sign_code(o_y[0] - o_x[0]) << 6) |
+                                           (sign_code(o_y[1] - o_x[1]) << 8) | (sign_code(o_y[2] - o_x[2]) << 10));
+                }
+                sg *= 2.f * isum * isum;                     // d dd / d theta = sg (pd zc - cd dpd)
+            }
+            const float mxl = (gxo == 1) ? 2.f : 1.f, mxr = (gxo == W - 2) ? 2.f : 1.f;
+            const float myu = (gyo == 1) ? 2.f : 1.f, myd = (gyo == H - 2) ? 2.f : 1.f;
+            const float yq[3] = {o_y[0] - 0.5f, o_y[1] - 0.5f, o_y[2] - 0.5f}, xq[3] = {o_x[0] - 0.5f, o_x[1] - 0.5f, o_x[2] - 0.5f};
+            float sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0}, sC[3] = {0, 0, 0};
+#pragma unroll 1
+            for (int r = 0; r < 3; r++) {
+                const float fy = r == 0 ? myu : (r == 2 ? myd : 1.f);
+                const float4 *row = coef + ((oy + r) * W1 + ox) * 3;
+#pragma unroll
+                for (int cx = 0; cx < 3; cx++) {
+                    float4 c0, c1, c2;
+                    lds_read3(row + cx * 3, c0, c1, c2);
+                    const float fm = (cx == 0 ? mxl : (cx == 2 ? mxr : 1.f)) * fy;
+                    sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
+                    sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
+                    sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
+                }
+            }
+            float sx = o_w * o_l1x, sy = o_w * o_l1y;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float lam = sA[ch] + sB[ch] * yq[ch] + sC[ch] * xq[ch];
+                sx += lam * o_gx[ch]; sy += lam * o_gy[ch];
+            }
+            // weight term -M_s diff_s d dd_x/d theta: x = s (own weight: here) or x = 0 (REFERENCE rule: after the loop)
+            const float e_s = o_m * o_diff;
+            const float kdd = ref_w ? 0.f : e_s * sg;
+            float grow[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const float ddj = o_pd * zc[j] - o_cd * (o_dgx * a[j] + o_dgy * bb[j]);
+                grow[j] = sx * a[j] + sy * bb[j] - kdd * ddj;
+                if (ref_w && s == 0) ddJ0[j] = sg * ddj;
+            }
+            esum += e_s;
+            const float wxx = o_w * o_lxx, wxy = o_w * o_lxy, wyy = o_w * o_lyy;
+            float la[7], lb[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) { la[j] = wxx * a[j] + wxy * bb[j]; lb[j] = wxy * a[j] + wyy * bb[j]; }
+            Dsum += la[6] * a[6] + lb[6] * bb[6];
+            g_rho += grow[6];
+            mcnt += o_m;
+            float Bq[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) Bq[j] = la[j] * a[6] + lb[j] * bb[6];
+            // B_s goes straight into the pixel's record (read back for the Schur terms below and by the back-substitution)
+            jr[2 + 6 * s + 0] = Bq[0]; jr[2 + 6 * s + 1] = Bq[1]; jr[2 + 6 * s + 2] = Bq[2];
+            jr[2 + 6 * s + 3] = Bq[3]; jr[2 + 6 * s + 4] = Bq[4]; jr[2 + 6 * s + 5] = Bq[5];
+            int h = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                v[21 + j] = grow[j];
+#pragma unroll
+                for (int i = 0; i <= j; i++) { v[h] = la[j] * a[i] + lb[j] * bb[i]; h++; }
+            }
+            v[27] = o_w * o_diff;
+            v[28] = o_m;
+        }
+        joint_reduce_add<29, NT>(v, red, acc, [&](int k) {
+            if (k >= 27) return k == 27 ? JL::OFF_SHARE + s : JL::OFF_NM + s;
+            if (k >= 21) return JL::OFF_G + 6 * s + (k - 21);
+            int j = 0;                                       // k = j (j + 1) / 2 + i
+            while ((j + 1) * (j + 2) / 2 <= k) j++;
+            return JL::tri(6 * s + j, 6 * s + (k - j * (j + 1) / 2));
+        }, tid);          // (its barriers also protect rec1 / aux / coef for the next source)
+    }
+
+    // ---------------- after the sources: prior, per-pixel Schur elimination of the shared depth ----------------
+    float iD = 0.f, Bv[NS][6];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) Bv[s][j] = 0.f;
+    float prior_cost = 0.f;
+    if (inimg) {
+        if (ref_w) g_rho -= esum * ddJ0[6];
+        float D = Dsum;
+        if (J.w_prior > 0.f) {
+            float rho = frcp(o_depth), rho0 = frcp(J.depth0[(size_t)b * hw + gyo * W + gxo]);
+            float ir2 = frcp(rho0 * rho0), dr = rho - rho0;
+            g_rho += mcnt * 2.f * J.w_prior * dr * ir2;
+            D += mcnt * 2.f * J.w_prior * ir2;
+            prior_cost = mcnt * J.w_prior * dr * dr * ir2;
+        }
+        const float Dd = (1.f + J.lambda_depth) * D;
+        const bool elim = Dd > 1e-30f;
+        iD = elim ? frcp(Dd) : 0.f;
+        jr[0] = g_rho; jr[1] = elim ? Dd : 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) Bv[s][j] = jr[2 + 6 * s + j];          // (this thread's own stores: L1 / L2 hits)
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {       // diagonal blocks and right-hand sides
+        float v[28];
+        int h = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            v[21 + j] = -Bv[s][j] * g_rho * iD - ((ref_w && s == 0) ? esum * ddJ0[j] : 0.f);
+#pragma unroll
+            for (int i = 0; i <= j; i++) { v[h] = -Bv[s][j] * Bv[s][i] * iD; h++; }
+        }
+        v[27] = (s == 0) ? prior_cost : 0.f;
+        joint_reduce_add<28, NT>(v, red, acc, [&](int k) {
+            if (k == 27) return JL::OFF_S;                       // the prior's cost rides in the sum(M W diff) slot
+            if (k >= 21) return JL::OFF_G + 6 * s + (k - 21);
+            int j = 0;
+            while ((j + 1) * (j + 2) / 2 <= k) j++;
+            return JL::tri(6 * s + j, 6 * s + (k - j * (j + 1) / 2));
+        }, tid);
+    }
+    if (!J.argmin) {                     // off-diagonal blocks: the shared depth couples the poses (18 values per reduction)
+#pragma unroll
+        for (int s = 1; s < NS; s++)
+#pragma unroll
+            for (int t = 0; t < s; t++)
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    float v[18];
+#pragma unroll
+                    for (int k = 0; k < 18; k++) v[k] = -Bv[s][half * 3 + k / 6] * Bv[t][k % 6] * iD;
+                    joint_reduce_add<18, NT>(v, red, acc, [&](int k) { return JL::tri(6 * s + half * 3 + k / 6, 6 * t + k % 6); }, tid);
+                }
+    }
+    // share of source 0 carries the whole photometric numerator's slot layout of k_solve: OFF_S = sum M W diff (+ prior), OFF_S+1 = K
+    if (tid == 0) {
+        float num = 0.f, kk = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; s++) { num += acc[JL::OFF_SHARE + s]; kk += acc[JL::OFF_NM + s]; }
+        acc[JL::OFF_S] += num; acc[JL::OFF_S + 1] = kk;
+    }
+    __syncthreads();
+    float *myrec = J.jblockrec + ((size_t)b * nblk + bid) * JL::NACC;
+    for (int i = tid; i < JL::NACC; i += NT) myrec[i] = acc[i];
+    stamp_end(P.stamp, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct JointState {                 // per target (fp64): LM bookkeeping + the accepted reduced system [S | -gS] (NP x (NP+1))
+    double lambda, cost_cur;
+    int have_cur, pad;
+    double M[6 * JMAXS * (6 * JMAXS + 1)];
+};
+
+struct JointSolveParams {
+    const float *jblockrec;   // [B][nblk][NACC]
+    JointState *js;           // [B]
+    PairState *st;            // [N] (forward pairs n = s B + b hold their transforms)
+    PairConst *pc;
+    float *stats;             // [Ntot][n_iters+1][TCSFM_NSTAT] or null (rows of the forward pairs)
+    int nblk, B, it, n_iters, solver, mode;       // mode 0: step, 1: final LM check
+    double lambda_up, lambda_down, lambda_min, lambda0;
+    float *pose_out;          // [Ntot][6] or null: written by the last launch
+    double *delta_out;        // [B][6 JMAXS] pose step of this iteration (back-substitution)
+    int *accept_out;          // [B] LM decision (or null)
+    int *trace_decide;        // [N] slot of every forward pair of the target, or null
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_solve_joint(JointSolveParams P) {
+    using JL = JointLayout<NS>;
+    constexpr int NP = JL::NP, NC = NP + 1;
+    __shared__ double tot[JL::NACC];
+    __shared__ double M[NP * NC];
+    __shared__ double dl[NP];
+    __shared__ double Ts[NS][40];
+    __shared__ int s_flag[2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    // deterministic fp64 sum of the target's workgroup records: thread t owns accumulators t, t + 256, ...; records in index order
+    for (int i = tid; i < JL::NACC; i += 256) {
+        const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + i;
+        double s = 0.0;
+        int r = 0;
+        for (; r + 8 <= P.nblk; r += 8) {
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) w[k] = p[(size_t)(r + k) * JL::NACC];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += (double)w[k];
+        }
+        for (; r < P.nblk; r++) s += (double)p[(size_t)r * JL::NACC];
+        tot[i] = s;
+    }
+    __syncthreads();
+    JointState &S = P.js[b];
+    const double Kn = tot[JL::OFF_S + 1], an = Kn > 0 ? 1.0 / Kn : 0.0;
+    const double cost = an * tot[JL::OFF_S];
+    double lambda = P.it == 0 && P.mode == 0 ? P.lambda0 : S.lambda;
+    const bool have_cur = !(P.it == 0 && P.mode == 0) && S.have_cur;
+    const double cost_cur = S.cost_cur;
+    if (P.stats && tid < NS) {      // row of forward pair (tid, b): joint cost, own share, own mask count, lambda, the iterate
+        const int n = tid * P.B + b;
+        float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * TCSFM_NSTAT;
+        st[0] = (float)cost; st[1] = (float)(an * tot[JL::OFF_SHARE + tid]); st[2] = (float)tot[JL::OFF_NM + tid]; st[3] = (float)lambda;
+        T_to_pose_f32(P.st[n].Ttry, st + TCSFM_STAT_POSE);
+    }
+    if (P.mode == 1) {              // LM: keep the last trial (all S poses; the depth map follows accept_out) only if it lowered the cost
+        const bool keep = cost < cost_cur;
+        if (tid == 0 && P.accept_out) P.accept_out[b] = keep ? 1 : 0;
+        if (tid < NS) {
+            const int n = tid * P.B + b;
+            if (P.trace_decide) P.trace_decide[n] = keep ? 1 : 0;
+            PairState &ps = P.st[n];
+            if (keep) for (int i = 0; i < 12; i++) ps.Tcur[i] = ps.Ttry[i];
+            if (P.pose_out) {
+                float pose[6];
+                T_to_pose_f32(keep ? ps.Ttry : ps.Tcur, pose);
+                for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
+            }
+        }
+        return;
+    }
+    const bool accept = (P.solver == 0) || !have_cur || (cost < cost_cur);
+    if (accept && P.solver == 1 && have_cur) lambda = fmax(lambda * P.lambda_down, P.lambda_min);
+    if (!accept) lambda *= P.lambda_up;
+    // [S | -gS] of the accepted linearisation
+    for (int i = tid; i < NP * NC; i += 256) {
+        const int r = i / NC, c = i - r * NC;
+        double v;
+        if (accept) { v = (c < NP) ? an * tot[JL::tri(r, c)] : -an * tot[JL::OFF_G + r]; S.M[i] = v; }
+        else v = S.M[i];
+        M[i] = v;
+    }
+    __syncthreads();
+    if (tid < NP) M[tid * NC + tid] += lambda * M[tid * NC + tid] + 1e-12;     // Marquardt damping
+    if (tid == 0) { s_flag[0] = 1; }
+    __syncthreads();
+    for (int k = 0; k < NP; k++) {      // Gauss-Jordan, one thread per entry (unpivoted: the system is SPD)
+        const double piv = M[k * NC + k];
+        if (tid == 0 && !(piv > 0.0)) s_flag[0] = 0;
+        double upd = 0.0;
+        bool mine = false;
+        if (tid < NP * NC) {
+            const int r = tid / NC, c = tid - r * NC;
+            if (r != k) { upd = M[r * NC + c] - M[r * NC + k] / piv * M[k * NC + c]; mine = true; }
+        }
+        __syncthreads();
+        if (mine) M[tid] = upd;
+        __syncthreads();
+    }
+    if (tid < NP) dl[tid] = s_flag[0] ? M[tid * NC + NP] / M[tid * NC + tid] : 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        S.lambda = lambda;
+        if (accept) { S.cost_cur = cost; S.have_cur = 1; }
+        if (P.accept_out) P.accept_out[b] = accept ? 1 : 0;
+        if (P.delta_out) for (int i = 0; i < NP; i++) P.delta_out[b * 6 * JMAXS + i] = dl[i];
+    }
+    if (tid < NS) {                     // per source: T_try = exp(d_s) T_accepted, next constants
+        const int n = tid * P.B + b;
+        if (P.trace_decide) P.trace_decide[n] = accept ? 1 : 0;
+        PairState &ps = P.st[n];
+        double *T = Ts[tid];
+        for (int i = 0; i < 12; i++) { T[12 + i] = accept ? ps.Ttry[i] : ps.Tcur[i]; }
+        if (accept) for (int i = 0; i < 12; i++) ps.Tcur[i] = T[12 + i];
+        double d6[6];
+        for (int i = 0; i < 6; i++) d6[i] = dl[6 * tid + i];
+        se3_exp(d6, T);
+        se3_mul(T, T + 12, T + 24);
+        const bool last_gn = (P.solver == 0 && P.it == P.n_iters - 1);
+        for (int i = 0; i < 12; i++) { ps.Ttry[i] = T[24 + i]; if (last_gn) ps.Tcur[i] = T[24 + i]; }
+        write_const(ps, T + 24, 0.0, n, P.pc[n]);
+        if (last_gn && P.pose_out) {
+            float pose[6];
+            T_to_pose_f32(T + 24, pose);
+            for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
+            if (P.stats) {
+                float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;
+                for (int i = 0; i < 6; i++) st[i] = pose[i];
+            }
+        }
+    }
+}
+
+// back-substitution of the shared map; LM: promote / roll back first (as k_dense_update_lm)
+struct JointUpdateParams {
+    const float *jrec;        // [B][H*W][JREC] records of the linearisation just evaluated
+    float *jrec_acc;          // LM: accepted records (or null)
+    float *depth_acc;         // LM: accepted depth [B][H*W] (or null)
+    const double *delta;      // [B][6 JMAXS]
+    const int *accept;        // LM: [B] (or null)
+    float *depth;             // [.][H*W]: slots of the forward pairs n = s B + b, all S written
+    float *depth_out;         // optional: [.][H*W] same layout (the caller's buffer), or null
+    int hw, B, S, mode;       // mode 0: step; 1: final LM decision (keep the trial or fall back to the accepted map), no step
+    float rho_lo, rho_hi;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P) {
+    using JL = JointLayout<NS>;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (idx >= P.hw) return;
+    const size_t o = (size_t)b * P.hw + idx;
+    float dep;
+    if (P.mode == 1) {
+        dep = P.accept[b] ? P.depth[o] : P.depth_acc[o];
+    } else {
+        float r[JL::JREC];
+        float base;
+        const bool lm = P.jrec_acc != nullptr;
+        if (!lm || P.accept[b]) {
+            const float4 *rt = reinterpret_cast<const float4 *>(P.jrec + o * JL::JREC);
+#pragma unroll
+            for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = rt[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
+            base = P.depth[o];
+            if (lm) {
+                float4 *ra = reinterpret_cast<float4 *>(P.jrec_acc + o * JL::JREC);
+#pragma unroll
+                for (int k = 0; k < JL::JREC / 4; k++) ra[k] = make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]);
+                P.depth_acc[o] = base;
+            }
+        } else {
+            const float4 *ra = reinterpret_cast<const float4 *>(P.jrec_acc + o * JL::JREC);
+#pragma unroll
+            for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = ra[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
+            base = P.depth_acc[o];
+        }
+        dep = base;
+        if (r[1] > 0.f) {
+            float bd = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6 * NS; j++) bd += r[2 + j] * (float)P.delta[b * 6 * JMAXS + j];
+            float rho = 1.f / base - (r[0] + bd) / r[1];
+            rho = fminf(fmaxf(rho, P.rho_lo), P.rho_hi);
+            dep = 1.f / rho;
+        }
+    }
+    for (int s = 0; s < P.S; s++) {
+        P.depth[(size_t)(s * P.B + b) * P.hw + idx] = dep;
+        if (P.depth_out) P.depth_out[(size_t)(s * P.B + b) * P.hw + idx] = dep;
+    }
+}
+
+}  // namespace tc

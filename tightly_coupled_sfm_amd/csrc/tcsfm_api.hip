@@ -11,6 +11,7 @@
 #include "../../include/tcsfm.h"
 #include "kernels.h"
 #include "dense_kernel.h"
+#include "joint_kernel.h"
 #include "scale_kernel.h"
 #include "posenet_kernel.h"
 
@@ -48,6 +49,11 @@ struct tcsfm_ctx {
     float *dense_rec_acc = nullptr, *depth_acc = nullptr;   // dense LM: accepted per-pixel records / depth maps
     int *lm_accept = nullptr;
     double *delta = nullptr;
+    // joint dense mode (one depth map per target shared by its S forward pairs): per-pixel records, workgroup records, per-target state
+    float *jrec = nullptr, *jrec_acc = nullptr, *jblockrec = nullptr, *jdepth_acc = nullptr;
+    JointState *jstate = nullptr;
+    double *jdelta = nullptr;
+    int jrec_S = 0;
     float *sel_maps = nullptr;   // window mode scratch: diff | valid | selection mask, [3][max_pairs][H*W], allocated on first use
     unsigned *scale_keys = nullptr, *scale_hist = nullptr;   // scale recovery scratch (keys, 256 bins + 4 state words)
     long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
@@ -385,6 +391,152 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
 
 }  // namespace
 
+namespace {
+// JOINT dense mode of a window (include/tcsfm.h, tcsfm_refine_dense_window): the S forward pairs of every target share one depth map
+// and are solved together (k_dense_joint / k_solve_joint / k_dense_joint_update); the inverse pairs run the pair-form dense kernels on
+// offset views of the same scratch.  Inputs already on the device.
+template <int NS>
+int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, const float *d_src, const float *d_dt, const float *d_ds,
+                           const float *d_K, const float *d_pose_in, float *d_pose_out, float *d_depth_out, float *d_stats, const WinOff *wo) {
+    using JL = JointLayout<NS>;
+    constexpr int S = NS;
+    const int SB = S * B, N = 2 * SB;
+    const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
+    const bool lm = o->solver == TCSFM_SOLVER_LM;
+    const int n_sel = (o->argmin) ? SB : 0;
+    int rc;
+    constexpr int DTW = 32, DTH = 16, DNT = 512;
+    const int tiles_x = (h->W + DTW - 1) / DTW, tiles_y = (h->H + DTH - 1) / DTH, nblk = tiles_x * tiles_y;
+    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
+    if (!h->dense_rec) {
+        HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->delta, n * 8 * sizeof(double)));
+    }
+    if (lm && !h->dense_rec_acc) {
+        HIPCHK(h, hipMalloc((void **)&h->dense_rec_acc, n * hw * 8 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->depth_acc, n * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
+    }
+    if (!h->jrec || h->jrec_S < S) {      // targets <= max_pairs / (2 S) <= max_pairs / 4
+        for (void **q : {(void **)&h->jrec, (void **)&h->jrec_acc, (void **)&h->jblockrec, (void **)&h->jdepth_acc, (void **)&h->jstate, (void **)&h->jdelta})
+            if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
+        const size_t nb = (n + 3) / 4;
+        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JL::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JL::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JL::NACC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
+        HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
+        h->jrec_S = S;
+    }
+    if (lm && !h->lm_accept) HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
+    if ((size_t)nblk > (size_t)h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
+    tcsfm_opts oo = *o;
+    oo.refine = TCSFM_REFINE_POSE;
+    oo.window_rule = TCSFM_WINDOW_PAIR;          // (the pose-mode coupling; the joint kernel takes the rule through JointParams)
+    InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
+    I.K_mod = B;
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, B, S, h->depth0, wo))) return rc;
+    // ---- forward group: joint
+    LinParams Pj = lin_params(h, &oo, 6);
+    Pj.tiles_x = tiles_x; Pj.tiles_y = tiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
+    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
+          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
+    if (n_sel) { Pj.ext_mask = sel_mask; Pj.n_ext = n_sel; }
+    JointParams J;
+    J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = o->lambda_depth; J.w_prior = o->prior_depth;
+    J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0; J.rule = o->window_rule == TCSFM_WINDOW_REFERENCE ? 1 : 0;
+    J.automask = 0;                             // own masks only without argmin, where the reference's forward term has no auto-mask (:71-73)
+    JointSolveParams Sj;
+    memset(&Sj, 0, sizeof(Sj));
+    Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
+    Sj.n_iters = o->n_iters; Sj.solver = o->solver; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
+    Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = lm ? h->lm_accept : nullptr;
+    JointUpdateParams Uj;
+    Uj.jrec = h->jrec; Uj.jrec_acc = lm ? h->jrec_acc : nullptr; Uj.depth_acc = lm ? h->jdepth_acc : nullptr; Uj.delta = h->jdelta;
+    Uj.accept = lm ? h->lm_accept : nullptr; Uj.depth = h->depth_work; Uj.depth_out = nullptr; Uj.hw = (int)hw; Uj.B = B; Uj.S = S; Uj.mode = 0;
+    Uj.rho_lo = 1.f / o->max_depth; Uj.rho_hi = 1.f / o->min_depth;
+    // ---- inverse pairs: the pair-form dense kernels on views offset by S B pairs
+    LinParams Pi = lin_params(h, &oo, 6);
+    Pi.tiles_x = tiles_x; Pi.tiles_y = tiles_y; Pi.ngrp = (nblk + RG - 1) / RG; Pi.direct = 1;
+    Pi.tgtpack += (size_t)SB * hw; Pi.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pi.depth_t += (size_t)SB * hw; Pi.pc += SB;
+    Pi.blockrec += (size_t)SB * nblk * AccLayout<6>::NACC;
+    SolveParams Si = solve_params(h, &oo, 6, 0);
+    Si.partials = Pi.blockrec; Si.ngrp = nblk; Si.st = h->state + SB; Si.pc = h->pconst + SB;
+    Si.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
+    Si.delta_out = h->delta + (size_t)SB * 8; Si.accept_out = lm ? h->lm_accept + SB : nullptr;
+    DenseParams Dn;
+    Dn.dense_rec = h->dense_rec + (size_t)SB * hw * 8; Dn.depth0 = h->depth0 + (size_t)SB * hw; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
+    Dn.prev_rec = nullptr; Dn.prev_delta = h->delta; Dn.depth_next = nullptr; Dn.rho_lo = Uj.rho_lo; Dn.rho_hi = Uj.rho_hi;
+    DenseUpdateParams Ui;
+    Ui.dense_rec = Dn.dense_rec; Ui.delta = Si.delta_out; Ui.depth = h->depth_work + (size_t)SB * hw; Ui.depth_out = h->depth_work + (size_t)SB * hw; Ui.hw = (int)hw;
+    Ui.rho_lo = Uj.rho_lo; Ui.rho_hi = Uj.rho_hi;
+    DenseLmParams Ul;
+    Ul.rec_try = Dn.dense_rec; Ul.rec_acc = lm ? h->dense_rec_acc + (size_t)SB * hw * 8 : nullptr; Ul.depth_acc = lm ? h->depth_acc + (size_t)SB * hw : nullptr;
+    Ul.depth = h->depth_work + (size_t)SB * hw; Ul.delta = Si.delta_out; Ul.accept = lm ? h->lm_accept + SB : nullptr; Ul.hw = (int)hw; Ul.rho_lo = Uj.rho_lo; Ul.rho_hi = Uj.rho_hi;
+    const dim3 px_t((unsigned)((hw + 255) / 256), B), px_i((unsigned)((hw + 255) / 256), SB);
+    auto linearize = [&](int lin) {
+        const bool tr = h->trace_bits != nullptr;
+        Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
+        Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
+        Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
+        Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
+        if (n_sel) {       // selection masks of the forward pairs at the current poses and the current SHARED depth
+            LinParams M = lin_params(h, &oo, 6);
+            M.o_diff = sel_diff; M.o_valid = sel_valid;
+            launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
+            SelectParams Q;
+            Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
+            Q.B = B; Q.S = S; Q.hw = (int)hw; Q.automask = o->automask;
+            hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), B), dim3(256), 0, h->stream, Q);
+        }
+        {
+            take_stamp(h, Pj, (size_t)nblk * B);
+            ProfScope prof(h, 0);
+            if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true>), dim3(nblk, B), dim3(DNT), 0, h->stream, Pj, J);
+            else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT>), dim3(nblk, B), dim3(DNT), 0, h->stream, Pj, J);
+        }
+        Pi.stamp = nullptr;
+        if (tr) hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT, true>), dim3(nblk, SB), dim3(DNT), 0, h->stream, Pi, Dn);
+        else hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, SB), dim3(DNT), 0, h->stream, Pi, Dn);
+    };
+    constexpr int SOLVE_NT = (JL::NP * (JL::NP + 1) <= 256) ? 256 : 512;
+    if ((rc = trace_check(h, o, N))) return rc;
+    for (int it = 0; it < o->n_iters; it++) {
+        linearize(it);
+        const bool last = !lm && it == o->n_iters - 1;
+        Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
+        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(SOLVE_NT), 0, h->stream, Sj);
+        Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
+        launch_solve(h, Si, SB, 6);
+        hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, h->stream, Uj);
+        if (lm) hipLaunchKernelGGL(k_dense_update_lm, px_i, dim3(256), 0, h->stream, Ul);
+        else hipLaunchKernelGGL(k_dense_update, px_i, dim3(256), 0, h->stream, Ui);
+    }
+    if (lm && o->n_iters > 0) {
+        linearize(o->n_iters);
+        Sj.it = o->n_iters; Sj.mode = 1; Sj.pose_out = d_pose_out;
+        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(SOLVE_NT), 0, h->stream, Sj);
+        Si.it = o->n_iters; Si.mode = 1; Si.pose_out = d_pose_out + (size_t)SB * 6; Si.log_scale_out = nullptr;
+        launch_solve(h, Si, SB, 6);
+        Uj.mode = 1;
+        hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, h->stream, Uj);
+        hipLaunchKernelGGL(k_dense_final_lm, px_i, dim3(256), 0, h->stream, (const int *)(h->lm_accept + SB), (const float *)(h->depth_acc + (size_t)SB * hw),
+                           h->depth_work + (size_t)SB * hw, (int)hw);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (o->n_iters == 0) {
+        FinishParams F;
+        F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = nullptr; F.N = N;
+        hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
+    }
+    HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return TCSFM_OK;
+}
+
+}  // namespace
+
 // =================================================================================================
 extern "C" {
 
@@ -397,6 +549,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->min_depth = 0.06f; o->max_depth = 2.67f;
     o->prior_scale = 1.0f;
     o->lambda_depth = 1.0f; o->prior_depth = 10.0f;
+    o->window_rule = TCSFM_WINDOW_PAIR; o->dense_joint = 1;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -467,6 +620,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
@@ -965,6 +1119,16 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (stats_out) {
         if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
+    }
+    if (win_B && o->dense_joint && win_S >= 2 && win_S <= JMAXS) {   // one depth map per target, 6S x 6S reduced system (joint_kernel.h)
+        rc = win_S == 2 ? dense_joint_run<2>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo)
+                        : dense_joint_run<3>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo);
+        if (rc) return rc;
+        if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
+        if ((rc = copy_back(h, o, depth_out, d_depth_out, N * hw))) return rc;
+        if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
+        if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+        return TCSFM_OK;
     }
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
