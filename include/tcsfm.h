@@ -215,9 +215,12 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
  * stacked pair order.
  *   JOINT (o->dense_joint, the default, S = 2 or 3): the reference optimises ONE disparity per frame that every term of the loss
  *     sees (optimizer.py:235-247).  The S forward pairs of target b share one inverse-depth map; unknowns per target = S poses +
- *     the map; cost = the forward term of the reference's loss (min over the sources under o->argmin -- weight map per
- *     o->window_rule: the winning source's own, or source 0's as optimizer.py:69 has it -- or every valid source without argmin,
- *     :71-73) + the depth prior; exact gradient (= reference autograd w.r.t. the poses AND the shared depth, golden G13);
+ *     the map; cost = the forward term of the reference's loss (min over the sources under o->argmin, or every valid source
+ *     without it, :71-73) with every pixel weighted by the depth-consistency map of the source it counts for, + the depth prior.
+ *     (optimizer.py:69 multiplies every pixel by the map of source 0; with the depth as an unknown that makes the depth of a pixel
+ *     whose SOURCE-0 sample touches the zero padding depend chaotically on the fifth digit of source 0's pose although another
+ *     source won it -- measured, DESIGN.md section 2 -- so o->window_rule does not apply here; the pose modes offer it.)
+ *     Exact gradient (= reference autograd of that cost w.r.t. the poses AND the shared depth, golden G13 `fwd_ownw`);
  *     per-pixel Schur elimination of the depth -> ONE reduced camera system of 6S x 6S per target (12 x 12 for the KITTI
  *     window; its off-diagonal blocks vanish identically under argmin, where every pixel counts for exactly one source),
  *     back-substitution once per target pixel.  LM accepts / rejects all S poses and the map together.  The S forward slots of

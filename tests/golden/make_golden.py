@@ -281,6 +281,24 @@ def main():
             if tag in ("fwd", "full", "noargmin_fwd"):
                 g13[f"{tag}_grad_depth_t"] = N(d_t.grad[:, 0])
                 g13[f"{tag}_grad_depth_s"] = np.stack([N(x.grad[:, 0]) for x in d_s])
+            if tag == "fwd":
+                # the same forward term with every pixel weighted by the map of the source that WON it (instead of source 0's,
+                # optimizer.py:69) -- composed from the reference's own maps (diff_img, valid_mask, weight_mask, auto_mask_error of
+                # solve_pose_iteratively, train_mono.py:82-100) exactly as optimizer.py:47-69 composes its version: the cost of the
+                # joint dense mode, whose weight terms must not reach across sources
+                fp2 = T(first, dt).clone().requires_grad_()
+                d_t2 = T(g13["depth_t"], dt).clone().requires_grad_()
+                d_s2 = [T(g13["depth_s"][i], dt).clone() for i in range(S13)]
+                _, _, out2 = ref["train_mono"].solve_pose_iteratively(1, [d_t2] + d_s2, LeafPose(fp2), T(g13["target"], dt),
+                                                                      [T(g13["sources"][i], dt) for i in range(S13)], T(g13["K"], dt), return_errors=True)
+                f = out2['fwd']
+                stack = lambda k: torch.cat([f[k][i * B13:(i + 1) * B13] for i in range(S13)], 1)          # [B, S, H, W]
+                dmin, idx = torch.min(stack('diff_img'), 1, keepdim=True)
+                keep = stack('valid_mask').sum(1, keepdim=True).clamp(0, 1) * (dmin < torch.min(stack('auto_mask_error'), 1, keepdim=True)[0]).float()
+                w_own = torch.gather(stack('weight_mask'), 1, idx)
+                loss2 = (dmin * keep * w_own).sum() / keep.sum()
+                loss2.backward()
+                g13["fwd_ownw_loss"] = np.array(loss2.item()); g13["fwd_ownw_grad_pose"] = N(fp2.grad); g13["fwd_ownw_grad_depth_t"] = N(d_t2.grad[:, 0])
             if tag == "full":
                 for d in ("fwd", "inv"):
                     for k in ("diff_img", "valid_mask", "weight_mask", "auto_mask_error"):

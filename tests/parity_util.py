@@ -159,7 +159,7 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
         import ctypes as _C
         o2 = type(o)(); _C.memmove(_C.byref(o2), _C.byref(o), _C.sizeof(o2)); o = o2
         o.dense_joint = 1 if joint else 0            # joint: one depth map per target shared by its S forward pairs (tcsfm.h)
-        o.window_rule = rule if joint else 0
+        o.window_rule = 0
         pose, depth, st = e.refine_dense_window(*args, o, stats=True, argmin=argmin)
         depth = depth.cpu().numpy()[:, 0]
     else:

@@ -41,12 +41,12 @@ def _window(B, S, H, W, seed0=90, bias=True):
 
 @pytest.mark.parametrize("shape,kw,argmin,rule", [
     ((1, 2, 96, 320), dict(n_iters=4), True, 0),                 # the KITTI window: target + 2 sources, min over the sources
-    ((2, 2, 96, 320), dict(n_iters=4), True, 1),                 # the reference's weights (source 0's map on every pixel)
+    ((2, 2, 96, 320), dict(n_iters=4), True, 0),                 # two targets in one call
     ((2, 2, 96, 320), dict(n_iters=3), False, 0),                # no argmin: the shared depth couples the two poses (full 12 x 12)
     ((1, 2, 192, 640), dict(n_iters=4), True, 0),                # full KITTI size
     ((1, 3, 48, 160), dict(n_iters=3), True, 0),                 # three sources: 18 x 18
     ((2, 2, 96, 320), dict(n_iters=5, solver=1, lambda0=1e-3), True, 0),      # LM: all poses and the map accepted / rolled back together
-], ids=["kitti-96x320", "reference-weights", "no-argmin-coupled", "kitti-192x640", "three-sources", "lm"])
+], ids=["kitti-96x320", "two-targets", "no-argmin-coupled", "kitti-192x640", "three-sources", "lm"])
 def test_joint_dense_vs_oracle(shape, kw, argmin, rule, oracle64):
     from oracle.oracle import default_opts as oopts
     from tightly_coupled_sfm_amd.engine import default_opts

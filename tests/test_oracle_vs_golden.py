@@ -336,14 +336,17 @@ def test_window_reference_rule_refines_and_reduces(oracle64):
 def test_joint_dense_gradients_vs_reference_autograd_G13(name, oracle64):
     """joint dense mode (ONE inverse-depth map per target frame, shared by its S forward pairs -- optimizer.py:194-198,235-247):
     the gradient of the forward term of the reference's loss w.r.t. the SHARED target depth and w.r.t. the S poses equals reference
-    autograd (golden G13), with the min over the sources (weight map of source 0, optimizer.py:69) and without it (:71-73);
+    autograd (golden G13), with the min over the sources (weight map of source 0 as optimizer.py:69 has it, or of the winning
+    source: the two window rules) and without it (:71-73);
     with one source the joint linearisation IS the pair-form dense linearisation"""
     g = load_golden(name)
     S, B = g["sources"].shape[:2]
     op = default_opts(n_iters=1)
-    for tag, argmin, factor in (("fwd", True, 1.0), ("noargmin_fwd", False, 0.25)):
+    # fwd: the reference's forward term as written (weight map of source 0 on every pixel); fwd_ownw: the same with every pixel
+    # weighted by the map of the source that won it -- the cost of the HIP joint mode; noargmin_fwd: without the min over the sources
+    for tag, argmin, factor, rule in (("fwd", True, 1.0, 1), ("fwd_ownw", True, 1.0, 0), ("noargmin_fwd", False, 0.25, 0)):
         parts = [oracle64.linearize_dense_joint(g["target"][b], g["sources"][:, b], g["depth_t"][b, 0], g["depth_s"][:, b, 0], g["K"][b],
-                                                g["first"][[s * B + b for s in range(S)]], op, argmin=argmin) for b in range(B)]
+                                                g["first"][[s * B + b for s in range(S)]], op, argmin=argmin, rule=rule) for b in range(B)]
         Ktot = sum(L["K"] for L in parts)                     # the reference normalises over the batch; the joint problem per target
         loss = factor * sum(L["cost_photo"] * L["K"] for L in parts) / Ktot
         assert abs(loss - float(g[f"{tag}_loss"])) < 1e-12 * loss
@@ -353,7 +356,7 @@ def test_joint_dense_gradients_vs_reference_autograd_G13(name, oracle64):
             assert _maxabs(gd, ref) < 1e-11 * np.abs(ref).max(), (tag, b, _maxabs(gd, ref))
             # pose gradients: with the depth block frozen (lambda_depth -> infinity) the reduced system is the pose system itself
             Lf = oracle64.linearize_dense_joint(g["target"][b], g["sources"][:, b], g["depth_t"][b, 0], g["depth_s"][:, b, 0], g["K"][b],
-                                                g["first"][[s * B + b for s in range(S)]], op, argmin=argmin, lambda_depth=1e30)
+                                                g["first"][[s * B + b for s in range(S)]], op, argmin=argmin, lambda_depth=1e30, rule=rule)
             for s in range(S):
                 m = s * B + b
                 gp = factor * Lf["K"] / Ktot * (oracle64.euler_left_jacobian(g["first"][m]).T @ Lf["g"][6 * s:6 * s + 6])

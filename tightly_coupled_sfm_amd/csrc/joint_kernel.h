@@ -38,7 +38,7 @@ struct JointParams {
     const float *depth0;     // [.][H*W] prior centre of target b at index b (the slot of forward pair (0, b))
     float *jblockrec;        // [B][nblk][NACC] one record per workgroup
     float lambda_depth, w_prior;
-    int B, S, argmin, rule;  // rule: TCSFM_WINDOW_REFERENCE -> with argmin, source 0's weight map on every pixel (optimizer.py:69)
+    int B, S, argmin;        // every pixel is weighted by the depth-consistency map of the source it counts for (see tcsfm.h)
     int automask;            // own masks (no argmin): optimizer.py:71-73 has no auto-mask there -> 0 from the host when S > 1
 };
 
@@ -68,7 +68,6 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     __shared__ float4 rec1[N2 * 3];
     __shared__ float4 aux[N2];
     __shared__ float4 coef[N1 * 3];
-    __shared__ float w0map[N2];          // REFERENCE rule: source 0's depth-consistency weight over the staged region
     __shared__ float red[(NT / 64) * 32];
     __shared__ float acc[JL::NACC];
 
@@ -90,12 +89,10 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     const int oy = tid / TW, ox = tid - oy * TW;
     const int gxo = x00 + ox, gyo = y00 + oy;
     const bool inimg = gxo < W && gyo < H;
-    const bool ref_w = J.argmin && J.rule;                       // source 0's weight map everywhere
     float *jr = J.jrec + ((size_t)b * hw + (inimg ? gyo * W + gxo : 0)) * JL::JREC;
 
     // per-pixel state across the sources
-    float o_depth = 1.f, g_rho = 0.f, Dsum = 0.f, mcnt = 0.f, esum = 0.f;
-    float ddJ0[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // REFERENCE rule: d dd_0 / d (xi_0, rho) at this pixel
+    float o_depth = 1.f, g_rho = 0.f, Dsum = 0.f, mcnt = 0.f;
 
     constexpr int NRING = N2 - NCEN;
     static_assert(NRING <= NT, "one ring round");
@@ -133,7 +130,6 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
                 lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
                 lds_write1(aux + S.ly * W2 + S.lx, Wt, oob ? 0.f : 1.f, S.tp.w, 0.f);
-                if (ref_w && s == 0) w0map[S.ly * W2 + S.lx] = Wt;
             }
             if (own) {
                 if (TRACE && P.trace != nullptr && inimg)
@@ -238,8 +234,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             float m = (real && ax.y > 0.5f && (!J.automask || diff < ax.z)) ? 1.f : 0.f;
             if (P.ext_mask != nullptr)      // min over the sources: the selection mask of forward pair n
                 m = (real && P.ext_mask[(size_t)n * hw + (size_t)(real ? gy_ * W + gx_ : 0)] != 0.f) ? 1.f : 0.f;
-            const float Wx = (ref_w && s > 0) ? w0map[(ly + 1) * W2 + lx + 1] : ax.x;      // whose weight multiplies the pixel
-            float w = m * Wx;
+            float w = m * ax.x;    // M_s W_s
             float4 *cr = coef + (ly * W1 + lx) * 3;
             lds_write1(cr + 0, w * cA[0], w * cA[1], w * cA[2], w * cB[0]);
             lds_write1(cr + 1, w * cB[1], w * cB[2], w * cC[0], w * cC[1]);
@@ -294,17 +289,11 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 const float lam = sA[ch] + sB[ch] * yq[ch] + sC[ch] * xq[ch];
                 sx += lam * o_gx[ch]; sy += lam * o_gy[ch];
             }
-            // weight term -M_s diff_s d dd_x/d theta: x = s (own weight: here) or x = 0 (REFERENCE rule: after the loop)
-            const float e_s = o_m * o_diff;
-            const float kdd = ref_w ? 0.f : e_s * sg;
+            // weight term -M_s diff_s d dd_s / d theta (own pixel, own source)
+            const float kdd = o_m * o_diff * sg;
             float grow[7];
 #pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const float ddj = o_pd * zc[j] - o_cd * (o_dgx * a[j] + o_dgy * bb[j]);
-                grow[j] = sx * a[j] + sy * bb[j] - kdd * ddj;
-                if (ref_w && s == 0) ddJ0[j] = sg * ddj;
-            }
-            esum += e_s;
+            for (int j = 0; j < 7; j++) grow[j] = sx * a[j] + sy * bb[j] - kdd * (o_pd * zc[j] - o_cd * (o_dgx * a[j] + o_dgy * bb[j]));
             const float wxx = o_w * o_lxx, wxy = o_w * o_lxy, wyy = o_w * o_lyy;
             float la[7], lb[7];
 #pragma unroll
@@ -345,7 +334,6 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         for (int j = 0; j < 6; j++) Bv[s][j] = 0.f;
     float prior_cost = 0.f;
     if (inimg) {
-        if (ref_w) g_rho -= esum * ddJ0[6];
         float D = Dsum;
         if (J.w_prior > 0.f) {
             float rho = frcp(o_depth), rho0 = frcp(J.depth0[(size_t)b * hw + gyo * W + gxo]);
@@ -369,7 +357,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         int h = 0;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            v[21 + j] = -Bv[s][j] * g_rho * iD - ((ref_w && s == 0) ? esum * ddJ0[j] : 0.f);
+            v[21 + j] = -Bv[s][j] * g_rho * iD;
 #pragma unroll
             for (int i = 0; i <= j; i++) { v[h] = -Bv[s][j] * Bv[s][i] * iD; h++; }
         }

@@ -446,7 +446,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     if (n_sel) { Pj.ext_mask = sel_mask; Pj.n_ext = n_sel; }
     JointParams J;
     J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = o->lambda_depth; J.w_prior = o->prior_depth;
-    J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0; J.rule = o->window_rule == TCSFM_WINDOW_REFERENCE ? 1 : 0;
+    J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
     J.automask = 0;                             // own masks only without argmin, where the reference's forward term has no auto-mask (:71-73)
     JointSolveParams Sj;
     memset(&Sj, 0, sizeof(Sj));
