@@ -1376,6 +1376,9 @@ static void linearize_dense_masked(int H, int W, const real *tgt, const real *sr
         if (g_rho) g_rho[i] = gr;
         if (Dq) Dq[i] = D;
         if (Bq) for (int j = 0; j < 6; j++) Bq[i * 6 + j] = B[j];
+        /* a pixel whose own sample is valid but blends with grid_sample's zero padding keeps its depth (not eliminated, not
+         * updated): its image gradients are (colour / 1 px), its Gauss-Newton depth step is noise (see dense_kernel.h) */
+        if (P->valid && !P->dc_in) { D = 0; if (Dq) Dq[i] = 0; }
         double Dd = (1.0 + lambda_depth) * D;
         if (Dd > 1e-30) {
             for (int j = 0; j < 6; j++) {
@@ -1399,6 +1402,17 @@ void orc_linearize_dense(int H, int W, const real *tgt, const real *src, const r
                          const double T[12], const real *K, const orc_opts *op, const real *auto_err_in, double lambda_depth,
                          double w_prior, const real *depth0, lin_t *out, double *g_rho, double *Dq, double *Bq) {
     linearize_dense_masked(H, W, tgt, src, depth_t, depth_s, T, K, op, auto_err_in, NULL, lambda_depth, w_prior, depth0, out, g_rho, Dq, Bq);
+}
+
+/* Per-pixel trust region of the depth step, |drho| <= 0.25 rho, then the clamp to the depth range.  Where a sample (or a
+ * neighbour's, through the 3x3 SSIM window) touches grid_sample's zero padding the photometric gradient is (colour / 1 px)
+ * against an ordinary pixel's curvature: raw Gauss-Newton steps of 30-60 % of the inverse depth at a few dozen pixels per frame
+ * (measured), where the linearisation means nothing. */
+#define DEPTH_STEP_MAX 0.25
+static inline double depth_step(double rho0, double drho, double lo, double hi) {
+    const double lim = DEPTH_STEP_MAX * rho0;
+    double rho = rho0 + (drho < -lim ? -lim : (drho > lim ? lim : drho));
+    return rho < lo ? lo : (rho > hi ? hi : rho);
 }
 
 /* Per-pair state of the dense refinement (shared by the pair form and the window form).
@@ -1450,9 +1464,7 @@ static void dense_state_step(dense_state *st, const orc_opts *op, const lin_t *t
         if (!(Dd > 1e-30)) { st->dep_try[i] = st->dep_acc[i]; continue; }
         double bd = 0;
         for (int j = 0; j < 6; j++) bd += st->Bq_a[i * 6 + j] * delta[j];
-        double rho = 1.0 / (double)st->dep_acc[i] - (st->gr_a[i] + bd) / Dd;
-        rho = rho < lo ? lo : (rho > hi ? hi : rho);
-        st->dep_try[i] = (real)(1.0 / rho);
+        st->dep_try[i] = (real)(1.0 / depth_step(1.0 / (double)st->dep_acc[i], -(st->gr_a[i] + bd) / Dd, lo, hi));
     }
 }
 /* the end: GN keeps the last trial; LM keeps it only if its cost (tr_final) is lower */
@@ -1773,6 +1785,8 @@ static void linearize_joint(int H, int W, int S, const real *tgt, const real *co
             D += am * 2.0 * w_prior / (rho0 * rho0);
             out->cost_prior += am * w_prior * (rho - rho0) * (rho - rho0) / (rho0 * rho0);
         }
+        for (int s = 0; s < S; s++)
+            if (px[s][i].valid && !px[s][i].dc_in) D = 0;    /* sampled across the zero padding: the pixel keeps its depth */
         if (g_rho) g_rho[i] = gr;
         if (Dq) Dq[i] = D;
         if (Bq) memcpy(Bq + (size_t)i * 6 * S, B, sizeof(double) * 6 * S);
@@ -1891,9 +1905,7 @@ void orc_refine_dense_joint(int H, int W, int B, int S, const real *tgt, const r
                 if (!(Dd > 1e-30)) { dep_try[i] = dep_acc[i]; continue; }
                 double bd = 0;
                 for (int j = 0; j < NP; j++) bd += Bq_a[(size_t)i * NP + j] * dl[j];
-                double rho = 1.0 / (double)dep_acc[i] - (gr_a[i] + bd) / Dd;
-                rho = rho < lo ? lo : (rho > hi ? hi : rho);
-                dep_try[i] = (real)(1.0 / rho);
+                dep_try[i] = (real)(1.0 / depth_step(1.0 / (double)dep_acc[i], -(gr_a[i] + bd) / Dd, lo, hi));
             }
         }
         if (!lm_final) memcpy(Tcur, Ttry, sizeof(double) * 12 * S);

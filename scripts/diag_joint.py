@@ -8,13 +8,13 @@ from oracle.oracle import Oracle, default_opts as oopts
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 from test_gpu_joint_dense import _window, _t
 orc = Oracle("f64")
-B, S, H, W = 2, 2, 96, 320
-rule, argmin = int(sys.argv[1]) if len(sys.argv) > 1 else 1, True
+B, S, H, W = 1, 2, 192, 640
+rule, argmin = 0, True
 w = _window(B, S, H, W)
 N = 2 * S * B; SB = S * B
 for nit in (1, 2, 3, 4):
     e = Engine(H, W, N)
-    o = default_opts(n_iters=nit, w_dc=0.0, min_depth=0.06, max_depth=2.67, window_rule=rule)
+    o = default_opts(n_iters=nit, w_dc=0.0, min_depth=0.06, max_depth=2.67, window_rule=0)
     e.trace_begin(nit, N)
     pose, depth, st = e.refine_dense_window(*(_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first")), o, stats=True, argmin=argmin)
     bits, dec = e.trace_end()
@@ -28,5 +28,6 @@ for nit in (1, 2, 3, 4):
         for (v, u) in bad[:3]:
             for s in range(S):
                 m = s * B + b
-                T = orc.pose_to_T(w["first"][m])
-                print(f"    px ({v},{u}) pair {m}: bits per lin", [hex(int(bits[k, m, v, u])) for k in range(nit)], "rel", rel[v, u])
+                ix, iy = orc.sample_positions(df[b], pf[m], w["K"][b])
+                print(f"    px ({v},{u}) pair {m}: bits per lin", [hex(int(bits[k, m, v, u])) for k in range(nit)], "rel", rel[v, u], "final sample pos", ix[v, u], iy[v, u])
+

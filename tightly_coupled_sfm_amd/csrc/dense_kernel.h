@@ -33,12 +33,20 @@ struct DenseParams {
 
 // back-substitution of one pixel: drho = -(g_rho + B' dxi) / Dd ; rho clamped to [rho_lo, rho_hi]  (shared by the fused form in
 // k_dense_linearize and by k_dense_update, so that both produce the same bits)
+// Per-pixel trust region of the depth step: |drho| <= DEPTH_STEP_MAX * rho.  A pixel whose sample -- or whose neighbours' samples,
+// through the 3x3 SSIM window -- touch grid_sample's zero padding gets a photometric gradient of (colour / 1 px) against the
+// curvature of an ordinary pixel: raw Gauss-Newton steps of 30-60 % of the inverse depth were measured at such pixels (a few dozen
+// per 640x192 frame), i.e. outside the range in which the linearisation means anything, and 1e-4 of such a step is 1e-4 of the depth.
+constexpr float DEPTH_STEP_MAX = 0.25f;
+__device__ __forceinline__ float depth_step(float rho0, float drho, float rho_lo, float rho_hi) {
+    const float lim = DEPTH_STEP_MAX * rho0;
+    float rho = rho0 + fminf(fmaxf(drho, -lim), lim);
+    return fminf(fmaxf(rho, rho_lo), rho_hi);
+}
 __device__ __forceinline__ float dense_advance(float dep, const float4 &r0, const float4 &r1, const float *d, float rho_lo, float rho_hi) {
     if (!(r0.y > 0.f)) return dep;
     float bd = r0.z * d[0] + r0.w * d[1] + r1.x * d[2] + r1.y * d[3] + r1.z * d[4] + r1.w * d[5];
-    float rho = 1.f / dep - (r0.x + bd) / r0.y;
-    rho = fminf(fmaxf(rho, rho_lo), rho_hi);
-    return 1.f / rho;
+    return 1.f / depth_step(1.f / dep, -(r0.x + bd) / r0.y, rho_lo, rho_hi);
 }
 
 template <int TW, int TH, int NT, bool TRACE = false>
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     const bool inimg = gxo < W && gyo < H;
     float a[7], b[7], zc[7];
     float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f, o_depth = 1.f;
+    bool o_pad = false;      // the pixel's own sample is valid but its bilinear footprint touches the zero padding (see `elim` below)
 
     // ---------------- phase 1 ----------------
     // Own pixel for every thread; the N2 - NCEN pixels of the 2-pixel ring are a second pixel for the first threads.  As in
@@ -128,6 +137,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
             // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
             a[6] *= -S.dep; b[6] *= -S.dep; zc[6] *= -S.dep;
             o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
+            o_pad = !oob && !S.t.inside;
         }
     };
     {
@@ -309,7 +319,11 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
 #pragma unroll
         for (int j = 0; j < 6; j++) Bq[j] = la[j] * a[6] + lb[j] * b[6];
         const float Dd = (1.f + Dn.lambda_depth) * D;
-        const bool elim = Dd > 1e-30f;
+        // A pixel whose own sample is a blend with grid_sample's zero padding (valid up to half a pixel outside the source image,
+        // stn.py:268-271) has image gradients of (colour / 1 px): its depth gradient is 50x an ordinary pixel's against ordinary
+        // curvature, and the Gauss-Newton step there is noise (measured: 30-60 % of rho per iteration, chaotic from one iteration to
+        // the next).  Such pixels keep their depth: no elimination, no back-substitution; their photometric terms stay in the pose system.
+        const bool elim = Dd > 1e-30f && !o_pad;
         const float iD = elim ? frcp(Dd) : 0.f;
         int h = 0;
 #pragma unroll
@@ -381,9 +395,7 @@ __global__ __launch_bounds__(256) void k_dense_update_lm(DenseLmParams P) {
     if (r0.y > 0.f) {
         const double *d = P.delta + n * 8;
         float bd = r0.z * (float)d[0] + r0.w * (float)d[1] + r1.x * (float)d[2] + r1.y * (float)d[3] + r1.z * (float)d[4] + r1.w * (float)d[5];
-        float rho = 1.f / base - (r0.x + bd) / r0.y;
-        rho = fminf(fmaxf(rho, P.rho_lo), P.rho_hi);
-        dep = 1.f / rho;
+        dep = 1.f / depth_step(1.f / base, -(r0.x + bd) / r0.y, P.rho_lo, P.rho_hi);
     }
     P.depth[o] = dep;
 }

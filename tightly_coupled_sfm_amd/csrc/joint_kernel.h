@@ -93,6 +93,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
 
     // per-pixel state across the sources
     float o_depth = 1.f, g_rho = 0.f, Dsum = 0.f, mcnt = 0.f;
+    bool o_pad = false;      // some source's sample at this pixel is valid but blends with the zero padding: the pixel keeps its depth
 
     constexpr int NRING = N2 - NCEN;
     static_assert(NRING <= NT, "one ring round");
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 geo_jac<7>(c, S.g, W, H, a, bb, zc);
                 a[6] *= -S.dep; bb[6] *= -S.dep; zc[6] *= -S.dep;      // scale column -> inverse-depth column
                 o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
+                o_pad = o_pad || (!oob && !S.t.inside);
             }
         };
         {
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             prior_cost = mcnt * J.w_prior * dr * dr * ir2;
         }
         const float Dd = (1.f + J.lambda_depth) * D;
-        const bool elim = Dd > 1e-30f;
+        const bool elim = Dd > 1e-30f && !o_pad;         // (dense_kernel.h: pixels sampled across the zero padding keep their depth)
         iD = elim ? frcp(Dd) : 0.f;
         jr[0] = g_rho; jr[1] = elim ? Dd : 0.f;
 #pragma unroll
@@ -418,7 +420,7 @@ struct JointSolveParams {
 };
 
 template <int NS>
-__global__ __launch_bounds__(256) void k_solve_joint(JointSolveParams P) {
+__global__ __launch_bounds__((6 * NS * (6 * NS + 1) <= 256) ? 256 : 512) void k_solve_joint(JointSolveParams P) {
     using JL = JointLayout<NS>;
     constexpr int NP = JL::NP, NC = NP + 1;
     __shared__ double tot[JL::NACC];
@@ -428,7 +430,8 @@ __global__ __launch_bounds__(256) void k_solve_joint(JointSolveParams P) {
     __shared__ int s_flag[2];
     const int b = blockIdx.x, tid = threadIdx.x;
     // deterministic fp64 sum of the target's workgroup records: thread t owns accumulators t, t + 256, ...; records in index order
-    for (int i = tid; i < JL::NACC; i += 256) {
+    const int NTS = blockDim.x;
+    for (int i = tid; i < JL::NACC; i += NTS) {
         const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + i;
         double s = 0.0;
         int r = 0;
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(256) void k_solve_joint(JointSolveParams P) {
     if (accept && P.solver == 1 && have_cur) lambda = fmax(lambda * P.lambda_down, P.lambda_min);
     if (!accept) lambda *= P.lambda_up;
     // [S | -gS] of the accepted linearisation
-    for (int i = tid; i < NP * NC; i += 256) {
+    for (int i = tid; i < NP * NC; i += NTS) {
         const int r = i / NC, c = i - r * NC;
         double v;
         if (accept) { v = (c < NP) ? an * tot[JL::tri(r, c)] : -an * tot[JL::OFF_G + r]; S.M[i] = v; }
@@ -581,9 +584,7 @@ __global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P)
             float bd = 0.f;
 #pragma unroll
             for (int j = 0; j < 6 * NS; j++) bd += r[2 + j] * (float)P.delta[b * 6 * JMAXS + j];
-            float rho = 1.f / base - (r[0] + bd) / r[1];
-            rho = fminf(fmaxf(rho, P.rho_lo), P.rho_hi);
-            dep = 1.f / rho;
+            dep = 1.f / depth_step(1.f / base, -(r[0] + bd) / r[1], P.rho_lo, P.rho_hi);
         }
     }
     for (int s = 0; s < P.S; s++) {
