@@ -1825,6 +1825,10 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         } else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
         else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
+        // GroupNorm statistics (+ K-split combination) as their own launch.  Round 3 measured the alternative -- statistics, K-split
+        // combination and the head in the convolutions' tails by the last-arriver ticket protocol, 7 launches instead of 15: every
+        // convolution became 6-8 us SLOWER (ticket round trips, acquire, serial tail of the last workgroup), 127.5 vs 119 us per
+        // evaluation (profiles/r03_posenet_fused_tail_kernel_stats.csv, _timing.jsonl) -- a separate 16 N-workgroup pass is faster.
         PnStatsParams S;
         S.part = P.part; S.tiles = (int)grid.x;
         S.out = pn->act[l]; S.bias = pn->bias[l]; S.gamma = pn->gamma[l]; S.beta = pn->beta[l]; S.scsh = pn->scsh[l];

@@ -120,7 +120,7 @@ class DepthOptimizer:
             return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0, w_dc=0.0,
                                 solver=_lib.SOLVER_LM if o.get("solver", "gn") == "lm" else _lib.SOLVER_GN,
                                 lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
-                                max_depth=float(self.config["max_depth"]), **kw)
+                                max_depth=float(self.config["max_depth"]), dense_joint=1 if o.get("dense_joint", True) else 0, **kw)
         return default_opts(
             n_iters=int(o.get("gn_iters", 4)),
             solver=_lib.SOLVER_LM if o.get("solver", "gn") == "lm" else _lib.SOLVER_GN,
@@ -128,7 +128,10 @@ class DepthOptimizer:
             refine=_lib.REFINE_POSE_SCALE if self._refine_mode() == "pose+scale" else _lib.REFINE_POSE,
             automask=1 if o.get("automasking", True) else 0,
             w_dc=float(o.get("l_depth_consist_weight", 0.15)) if o.get("l_depth_consist", False) else 0.0,
-            lambda0=float(o.get("lambda0", 1e-4)))
+            lambda0=float(o.get("lambda0", 1e-4)),
+            # this class stands in for the reference's optimiser: by default the scalar it minimises is the reference's
+            # compute_optimization_loss itself (optimizer.py:47-86; golden G13); 'pair' = the library's batch-independent default
+            window_rule=_lib.WINDOW_PAIR if o.get("window_rule", "reference") == "pair" else _lib.WINDOW_REFERENCE)
 
     def _disparities(self, imgs):
         """depth net forward in the reference's two call forms (optimizer.py:146-147) or a plain callable"""
@@ -228,8 +231,9 @@ class DepthOptimizer:
             s = torch.exp(log_scale[:split].reshape(S, B).mean(0)).reshape(B, 1, 1, 1)
             depths = [d * s for d in depths]
         if dense:
-            # every directed pair refined the depth of ITS target: the window's target frame was refined once per source
-            # (forward pairs; fused by averaging inverse depths), source frame s by its inverse pair
+            # joint mode (default): the S forward slots hold ONE refined map of the target frame, shared by its S forward pairs
+            # (the mean below is then the identity); options['dense_joint'] = False: every forward pair refined its own copy and
+            # the copies are fused by averaging inverse depths.  Source frame s was refined by its inverse pair
             inv_t = (1.0 / depth_ref[:split]).reshape(S, B, 1, H, W).mean(0)
             depths = [1.0 / inv_t] + [depth_ref[split + i * B: split + (i + 1) * B] for i in range(S)]
         res["depths_opt"] = depths
