@@ -70,6 +70,10 @@ struct LinParams {
     const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
     int n_ext;
     int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
+    // Frame-level pack cache (sequence calls, tcsfm_refine_sequence): the packed source image (rgb + depth, zero border) and the
+    // converted depth plane exist ONCE per frame of the ring (k_frame_pack, when the frame's copy lands) instead of once per
+    // directed pair and call; pair n reads the slots k_pack_cached noted for it.  Null: per-pair srcpack / depth_t as before.
+    const int *pair_src, *pair_dep;     // [N] ring slot of pair n's source pack / of its target's depth plane
     int rule;               // TCSFM_WINDOW_REFERENCE: the forward pairs of sources s > 0 weigh their pixels with source 0's depth-
                             // consistency weight map, source 0 carries the cross term (optimizer.py:69; normalisers: k_solve)
     int fwd_noauto;         // pairs n < fwd_noauto take no auto-mask (REFERENCE rule without argmin, optimizer.py:71-73)
@@ -428,6 +432,100 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     if (P.depth_out2) P.depth_out2[(size_t)n * hw + idx] = dt;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Frame-level pack cache of the sequence calls (run_sequential_optimization.py:186-247 streams a sequence; every frame belongs to
+// S + 1 windows, as a target once and as a source S times).  k_frame_pack runs ONCE per frame, on the copy stream right behind
+// the frame's H2D copy: planar rgb + depth -> the bordered (rgb, depth) float4 image the warp gathers from + the (converted)
+// depth plane.  k_pack_cached then forms, per window call, only what is pair-specific: tgtpack = (target rgb, auto_err of THIS
+// (target, source) pair) and the pair's slots -- 16 B/pixel/pair written instead of 36.  Same values, bit for bit, as k_pack.
+struct FramePackParams {
+    const float *img, *depth;     // [F][3][H][W], [F][1][H][W] planar (ring slots)
+    float4 *fpack;                // [F][H+2][W+2]
+    float *fdepth;                // [F][H][W]
+    int H, W, depth_is_disp;
+    float min_disp, max_disp;
+};
+__global__ __launch_bounds__(256) void k_frame_pack(FramePackParams P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    const int hw = P.H * P.W;
+    if (idx >= hw) return;
+    const int v = idx / P.W, u = idx - v * P.W;
+    const float *s = P.img + (size_t)f * 3 * hw;
+    float d = P.depth[(size_t)f * hw + idx];
+    if (P.depth_is_disp) d = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * d);       // disp_to_depth, learning_helpers.py:77-86
+    const int WB = P.W + 2;
+    float4 *sp = P.fpack + (size_t)f * (P.H + 2) * WB;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    sp[(v + 1) * WB + u + 1] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], d);
+    if (u == 0) sp[(v + 1) * WB] = zero;
+    if (u == P.W - 1) sp[(v + 1) * WB + P.W + 1] = zero;
+    if (v == 0) { sp[u + 1] = zero; if (u == 0) sp[0] = zero; if (u == P.W - 1) sp[P.W + 1] = zero; }
+    if (v == P.H - 1) {
+        sp[(P.H + 1) * WB + u + 1] = zero;
+        if (u == 0) sp[(P.H + 1) * WB] = zero;
+        if (u == P.W - 1) sp[(P.H + 1) * WB + P.W + 1] = zero;
+    }
+    P.fdepth[(size_t)f * hw + idx] = d;
+}
+
+struct PackCachedParams {
+    const float4 *fpack;          // [F][H+2][W+2] frame packs (ring)
+    float4 *tgtpack;              // [N][H][W] out
+    int *pair_src, *pair_dep;     // [N] out
+    int H, W, N, win_B, win_S;
+    int slot0, tpos;              // ring slot of the call's first frame; position of the target inside a window
+    WinOff win_off;               // source s of window b = frame slot0 + off[s] + b
+    float wl, ws;
+    InitParams init;
+};
+// photo_err_planar on two bordered frame packs: same loads (values), same operation order -> the same bits
+__device__ inline float photo_err_packs(const float4 *__restrict__ x, const float4 *__restrict__ y, int H, int W, int u, int v, float wl, float ws) {
+    const int WB = W + 2;
+    const int r0 = (refl_idx(v - 1, H) + 1) * WB, r1 = (v + 1) * WB, r2 = (refl_idx(v + 1, H) + 1) * WB;
+    const int c0 = refl_idx(u - 1, W) + 1, c1 = u + 1, c2 = refl_idx(u + 1, W) + 1;
+    const int off[9] = {r0 + c0, r0 + c1, r0 + c2, r1 + c0, r1 + c1, r1 + c2, r2 + c0, r2 + c1, r2 + c2};
+    float4 xv[9], yv[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { xv[k] = x[off[k]]; yv[k] = y[off[k]]; }
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        auto ch = [&](const float4 &q) { return c == 0 ? q.x : (c == 1 ? q.y : q.z); };
+        const float x0 = ch(xv[4]), y0 = ch(yv[4]);
+        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float a = ch(xv[k]) - x0, b = ch(yv[k]) - y0;
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+        const float n9 = 1.f / 9.f;
+        float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
+        float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
+        float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
+        float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+        acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n * frcp(d)) * 0.5f);
+    }
+    return acc;
+}
+__global__ __launch_bounds__(256) void k_pack_cached(PackCachedParams P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    const int hw = P.H * P.W;
+    const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, s = q / P.win_B;
+    const int ts = P.slot0 + P.tpos + b, ss = P.slot0 + P.win_off.off[s] + b;     // window b: its target / its source s
+    const int tslot = inv ? ss : ts, sslot = inv ? ts : ss;                       // THIS pair's target / source frame
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.pair_src[n] = sslot; P.pair_dep[n] = tslot;
+        if (n < P.init.N) init_pair(P.init, n);
+    }
+    if (idx >= hw) return;
+    const int v = idx / P.W, u = idx - v * P.W;
+    const size_t fs = (size_t)(P.H + 2) * (P.W + 2);
+    const float4 *t = P.fpack + (size_t)tslot * fs, *sp = P.fpack + (size_t)sslot * fs;
+    const float ae = photo_err_packs(t, sp, P.H, P.W, u, v, P.wl, P.ws);
+    const float4 tc = t[(v + 1) * (P.W + 2) + u + 1];
+    P.tgtpack[(size_t)n * hw + idx] = make_float4(tc.x, tc.y, tc.z, ae);
+}
+
 // Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69): from the forward pairs'
 // diff / valid maps at the current poses -> one 0/1 selection mask per forward pair (see oracle orc_window_select).
 struct SelectParams {
@@ -774,8 +872,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     const int x00 = txi * TW, y00 = tyi * TH;
     const int img = P.shared_image ? 0 : n;
     const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
-    const float4 *srcpack = P.srcpack + (size_t)img * (H + 2) * (W + 2);   // zero-bordered (tap4)
-    const float *depth_t = P.depth_t + (size_t)img * hw;
+    const bool cached = P.pair_src != nullptr;                               // wave-uniform
+    const float4 *srcpack = P.srcpack + (size_t)(cached ? P.pair_src[n] : img) * (H + 2) * (W + 2);   // zero-bordered (tap4)
+    const float *depth_t = P.depth_t + (size_t)(cached ? P.pair_dep[n] : img) * hw;
     const int tid = threadIdx.x;
     stamp_begin(P.stamp, tid);
 
@@ -798,8 +897,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (so == s_own) continue;
             const int no = so * P.sel_B + b_;
             const PairConst &co = P.pc[no];
-            const float4 *tpo = P.tgtpack + (size_t)no * hw, *spo = P.srcpack + (size_t)no * (H + 2) * (W + 2);
-            const float *dto = P.depth_t + (size_t)no * hw;
+            const float4 *tpo = P.tgtpack + (size_t)no * hw, *spo = P.srcpack + (size_t)(cached ? P.pair_src[no] : no) * (H + 2) * (W + 2);
+            const float *dto = P.depth_t + (size_t)(cached ? P.pair_dep[no] : no) * hw;
             for (int ci = tid; ci < NCOMP; ci += NT) {       // tile + ring, colours only (+ validity and auto-mask threshold)
                 const int ly = ci / CW, lx = ci - ly * CW;
                 const int px = refl_idx(x00 + lx - 1, W), py = refl_idx(y00 + ly - 1, H), gi = py * W + px;

@@ -71,6 +71,9 @@ struct tcsfm_ctx {
     // tcsfm_refine_sequence: device ring of frames, copy stream, per-slot / per-window events, pose staging (allocated on first use)
     float *seq_img = nullptr, *seq_depth = nullptr, *seq_pose_in = nullptr, *seq_pose_out = nullptr, *seq_ls_out = nullptr, *seq_K = nullptr;
     int seq_slots = 0, seq_K_n = 0;    // ring slots + mirror slots allocated; copies of K held by seq_K
+    float4 *seq_fpack = nullptr;       // frame-level pack cache of the ring: [slots][H+2][W+2] (rgb, depth) + [slots][H][W] depth planes
+    float *seq_fdepth = nullptr;
+    int *pair_idx = nullptr;           // [2][max_pairs] ring slots of every pair's source pack / target depth plane (k_pack_cached)
     float *seq_dense = nullptr;        // tcsfm_refine_dense_sequence: refined depth maps of all windows, per-window order (on a lane: the
     size_t seq_dense_cap = 0;          // lane's stacked maps of one call)
     float *seq_dense_tmp = nullptr;    // ... the handle's own stacked maps of one call (lane 0)
@@ -594,6 +597,7 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->pose_dev, n * 6 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->ls_dev, n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->K_dev, n * 9 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->pair_idx, 2 * n * sizeof(int));
     if (e != hipSuccess) {
         g_create_error = std::string("tcsfm_create: ") + hipGetErrorString(e);
         tcsfm_destroy(h);
@@ -622,7 +626,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
                     h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
-                    h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
+                    h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -916,9 +920,12 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
 }
 
 // shared body of tcsfm_refine (win_B == 0: one image set per pair) and tcsfm_refine_window (win_B x win_S window)
+// frame-level pack cache of a sequence call (kernels.h k_frame_pack / k_pack_cached): the ring's packed frames, and where this call's windows start
+struct FrameCache { const float4 *fpack; const float *fdepth; int slot0, tpos; };
+
 static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
-                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr) {
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr, const FrameCache *fc = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
@@ -949,8 +956,23 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
 
     InitParams I = init_params(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0);
     I.K_mod = win_B;
-    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo))) return rc;
     LinParams P = lin_params(h, o, np);
+    if (fc) {      // sequence call: rgb + depth were packed once per frame when they landed; only the pair-specific part is formed here
+        if (h->tickets_dirty) {
+            HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp_alloc * sizeof(int), h->stream));
+            h->tickets_dirty = false;
+        }
+        PackCachedParams C;
+        C.fpack = fc->fpack; C.tgtpack = h->tgtpack; C.pair_src = h->pair_idx; C.pair_dep = h->pair_idx + h->max_pairs;
+        C.H = h->H; C.W = h->W; C.N = N; C.win_B = win_B; C.win_S = win_S; C.slot0 = fc->slot0; C.tpos = fc->tpos; C.win_off = *wo;
+        C.wl = o->w_l1 / 3.f; C.ws = o->w_ssim / 3.f; C.init = I;
+        {
+            ProfScope prof(h, 2);
+            hipLaunchKernelGGL(k_pack_cached, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, C);
+        }
+        HIPCHK(h, hipGetLastError());
+        P.srcpack = fc->fpack; P.depth_t = fc->fdepth; P.pair_src = C.pair_src; P.pair_dep = C.pair_dep;
+    } else if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo))) return rc;
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
     const bool dc = o->w_dc > 0.f;
@@ -1364,7 +1386,14 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         h->seq_img = h->seq_depth = nullptr; h->seq_slots = 0;
         HIPCHK(h, hipMalloc(&h->seq_img, (size_t)(R + M) * 3 * hw * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->seq_depth, (size_t)(R + M) * hw * sizeof(float)));
+        if (h->seq_fpack) { HIPCHK(h, hipFree(h->seq_fpack)); h->seq_fpack = nullptr; }       // (re-allocated below for the new slot count)
+        if (h->seq_fdepth) { HIPCHK(h, hipFree(h->seq_fdepth)); h->seq_fdepth = nullptr; }
         h->seq_slots = R + M;
+    }
+    const bool use_cache = dense_depth_out == nullptr;      // (the dense modes rewrite per-pair depth planes: they keep the per-pair pack)
+    if (use_cache && !h->seq_fpack) {
+        HIPCHK(h, hipMalloc((void **)&h->seq_fpack, (size_t)h->seq_slots * (h->H + 2) * (h->W + 2) * sizeof(float4)));
+        HIPCHK(h, hipMalloc((void **)&h->seq_fdepth, (size_t)h->seq_slots * hw * sizeof(float)));
     }
     if (h->seq_pose_cap < (size_t)nwin * N) {
         for (float **q : {&h->seq_pose_in, &h->seq_pose_out, &h->seq_ls_out})
@@ -1462,6 +1491,18 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
                 HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)(R + slot) * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nm * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
                 HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)(R + slot) * hw, depths + (size_t)nxt * hw, (size_t)nm * hw * sizeof(float), hipMemcpyHostToDevice, cs));
             }
+            if (use_cache) {      // pack the frames that just landed (and their mirror copies), once, on the copy stream
+                FramePackParams Fp;
+                Fp.H = h->H; Fp.W = h->W; Fp.depth_is_disp = o.depth_is_disp;
+                Fp.min_disp = o.depth_is_disp ? 1.f / o.max_depth : 0.f; Fp.max_disp = o.depth_is_disp ? 1.f / o.min_depth : 0.f;
+                auto pack = [&](int first, int count) {
+                    Fp.img = h->seq_img + (size_t)first * 3 * hw; Fp.depth = h->seq_depth + (size_t)first * hw;
+                    Fp.fpack = h->seq_fpack + (size_t)first * (h->H + 2) * (h->W + 2); Fp.fdepth = h->seq_fdepth + (size_t)first * hw;
+                    hipLaunchKernelGGL(k_frame_pack, dim3((unsigned)((hw + 255) / 256), count), dim3(256), 0, cs, Fp);
+                };
+                pack(slot, nf);
+                if (slot < M) pack(R + slot, nf < M - slot ? nf : M - slot);
+            }
             HIPCHK(h, hipEventRecord(h->seq_copied[slot / C], cs));
             nxt += nf;
         }
@@ -1489,8 +1530,11 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
                 hipLaunchKernelGGL(k_maps_to_window_order, dim3((unsigned)((hw + 255) / 256), N * nbw), dim3(256), 0, ls[l], (const float *)tmp, ordered, nbw, N, (int)hw);
                 HIPCHK(h, hipMemcpyAsync(dense_depth_out + (size_t)c0 * N * hw, ordered, (size_t)nbw * N * hw * sizeof(float), hipMemcpyDeviceToHost, ls[l]));
             }
-        } else rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
-                              np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo);
+        } else {
+            FrameCache fcache = {h->seq_fpack, h->seq_fdepth, s0, tp};
+            rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
+                             np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo, use_cache ? &fcache : nullptr);
+        }
         if (rc) { if (c != h) h->err = c->err; break; }
         HIPCHK(h, hipEventRecord(h->seq_done[ci % ND], ls[l]));
         for (int k = 0; k < nbw + S; k++) slot_reader[(c0 + k) % R] = ci;
