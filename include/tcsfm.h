@@ -249,7 +249,13 @@ int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float
  *   tcsfm_posenet_load     HOST pointers to the parameters of the reference module, in its own layouts: conv_w[l] = conv{l+1}.0.weight
  *                          [cout,cin,k,k], conv_b[l] = conv{l+1}.0.bias [cout] (NULL: 0), gn_w / gn_b[l] = conv{l+1}.1.weight / .bias
  *                          [cout] (NULL: 1 / 0), head_w = pose_pred.weight [6,256(,1,1)], head_b = pose_pred.bias [6]
- *   tcsfm_posenet_forward  pose_model(imgs): imgs [N,6,H,W] (device) -> pose [N,6] (device)
+ *   tcsfm_posenet_forward  pose_model(imgs): imgs [N,6,H,W] (device) -> pose [N,6] (device).  The work split of the layers (K split,
+ *                          channel blocks per wave) is chosen from the NUMBER OF IMAGES of the call -- two fixed regimes, N <= 4 and N > 4
+ *                          -- and the K split fixes the summation order: results are bit-identical for every N within a regime and
+ *                          agree to ~1e-6 relative across the two.  Consequence for the sequence calls below: the PoseNet poses of a
+ *                          window depend, at the 1e-6 level, on whether its call holds up to 4 or more images (windows_per_call), and the
+ *                          coupled loop's discrete warp-validity decisions can amplify that on individual windows (measured with random
+ *                          weights: 3 of 199 windows at 1e-5 .. 1e-2, all others ~1e-6).
  *   tcsfm_solve_pose_iteratively   train_mono.py:41-81 for a window (layouts of tcsfm_refine_window): PoseNet on (tgt | src) /
  *                          (src | tgt), then num_iter-1 rounds of { inverse_warp2 with -pose; PoseNet on (tgt * valid | img_rec);
  *                          pose += correction }.  poses_out [2*S*B,6] = the last iterate; stacked_out [2*S*B,num_iter,6] optional

@@ -13,6 +13,8 @@ tail -1 $OUT/bench.json | cut -c1-200
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 300 --warmup 50 --cpu-sample 0 --sat-windows 0 > $OUT/trace.log 2>&1
 # the same with one call in flight: every k_linearize launch has the chip to itself (what bench.py's `roofline` block measures)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes1 -- python $ROOT/bench.py --lanes 1 --steps 300 --warmup 50 --cpu-sample 0 --sat-windows 0 > $OUT/trace_lanes1.log 2>&1
+# the chip-filling launch (32 windows = 64 directed pairs per call): what bench.py's `roofline_saturated` cites
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sat -- python $ROOT/scripts/sat_workload.py > $OUT/trace_sat.log 2>&1
 for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY" \
          "FETCH_SIZE" "WRITE_SIZE"; do

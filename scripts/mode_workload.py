@@ -3,7 +3,9 @@
    dense_sat           : the same kernel with the chip full (64 directed pairs at 320x240)
    scale7              : BASELINE config 4 (pose + depth scale, 8 its, 640x192)                 -> k_linearize<7>, k_solve<7>
    window_sel          : the reference's KITTI default window B=1, S=2, min over sources, w_dc  -> k_linearize<6,true,..,SEL>
-   shard8              : BASELINE config 3's per-GPU shard, 8 windows = 16 directed pairs"""
+   shard8              : BASELINE config 3's per-GPU shard, 8 windows = 16 directed pairs
+   window_ref          : the KITTI window under the REFERENCE window rule                       -> k_linearize<..SEL> + k_solve group normalisers
+   joint_kitti / copies_kitti : the KITTI window in the dense mode, joint (shared depth, 12x12) / per-pair copies"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,6 +47,20 @@ elif mode == "window_sel":
     e = Engine(H, W, 2 * S * B)
     for _ in range(calls):
         out = e.refine_window(tgt, srcs, dt, ds, d["K"][:1], pose, default_opts(n_iters=4, w_dc=0.15), argmin=True)
+elif mode in ("window_ref", "joint_kitti", "copies_kitti"):
+    # the KITTI window (B=1, S=2, min over sources): pose mode under the REFERENCE window rule / dense mode joint / dense per-pair copies
+    H, W, B, S = 192, 640, 1, 2
+    b = synth.make_batch(2 * S, H, W, seed0=0)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    tgt, srcs = d["tgt"][:1], d["src"][:S].reshape(S, B, 3, H, W)
+    dt, ds = d["depth_t"][:1], d["depth_s"][:S].reshape(S, B, 1, H, W)
+    pose = torch.cat([d["pose_init"][:S], -d["pose_init"][:S]]).contiguous()
+    e = Engine(H, W, 2 * S * B)
+    for _ in range(calls):
+        if mode == "window_ref":
+            out = e.refine_window(tgt, srcs, dt, ds, d["K"][:1], pose, default_opts(n_iters=4, w_dc=0.15, window_rule=1), argmin=True)
+        else:
+            out = e.refine_dense_window(tgt, srcs, dt, ds, d["K"][:1], pose, default_opts(n_iters=4, dense_joint=1 if mode == "joint_kitti" else 0), argmin=True)
 elif mode == "shard8":
     H, W = 192, 640
     d = dev_batch(16, H, W)

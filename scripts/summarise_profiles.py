@@ -13,6 +13,9 @@ if ks:
 ks1 = glob.glob(os.path.join(src, "trace_lanes1", "*", "*kernel_stats.csv"))
 if ks1:
     shutil.copy(ks1[0], os.path.join(dst, f"{tag}_lanes1_kernel_stats.csv"))
+kss = glob.glob(os.path.join(src, "trace_sat", "*", "*kernel_stats.csv"))
+if kss:
+    shutil.copy(kss[0], os.path.join(dst, f"{tag}_sat_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "bench.json")):
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 pmc = collections.defaultdict(dict)

@@ -419,31 +419,43 @@ struct JointSolveParams {
     int *trace_decide;        // [N] slot of every forward pair of the target, or null
 };
 
+constexpr int JSOLVE_NT = 1024;
 template <int NS>
-__global__ __launch_bounds__((6 * NS * (6 * NS + 1) <= 256) ? 256 : 512) void k_solve_joint(JointSolveParams P) {
+__global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
     using JL = JointLayout<NS>;
     constexpr int NP = JL::NP, NC = NP + 1;
+    constexpr int APAD = JL::NACC <= 128 ? 128 : 256, PARTS = JSOLVE_NT / APAD;
+    static_assert(JL::NACC <= 256 && NP * NC <= JSOLVE_NT, "k_solve_joint: one thread per accumulator column and per matrix entry");
     __shared__ double tot[JL::NACC];
+    __shared__ double part[JSOLVE_NT];
     __shared__ double M[NP * NC];
     __shared__ double dl[NP];
     __shared__ double Ts[NS][40];
     __shared__ int s_flag[2];
     const int b = blockIdx.x, tid = threadIdx.x;
-    // deterministic fp64 sum of the target's workgroup records: thread t owns accumulators t, t + 256, ...; records in index order
-    const int NTS = blockDim.x;
-    for (int i = tid; i < JL::NACC; i += NTS) {
-        const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + i;
+    const int NTS = JSOLVE_NT;
+    {
+        // deterministic fp64 sum of the target's workgroup records, as in k_solve: thread = (accumulator, record subset), every
+        // subset's loads issued in batches of 8 so that they are all in flight, subsets combined in fixed order
+        const int c = tid & (APAD - 1), q = tid / APAD;
         double s = 0.0;
-        int r = 0;
-        for (; r + 8 <= P.nblk; r += 8) {
-            float w[8];
+        if (c < JL::NACC) {
+            const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + c;
+            for (int r0 = q; r0 < P.nblk; r0 += 8 * PARTS) {
+                float w[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) w[k] = p[(size_t)(r + k) * JL::NACC];
+                for (int k = 0; k < 8; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < P.nblk ? r : q) * JL::NACC]; }
 #pragma unroll
-            for (int k = 0; k < 8; k++) s += (double)w[k];
+                for (int k = 0; k < 8; k++) s += (r0 + k * PARTS < P.nblk) ? (double)w[k] : 0.0;
+            }
         }
-        for (; r < P.nblk; r++) s += (double)p[(size_t)r * JL::NACC];
-        tot[i] = s;
+        part[tid] = s;
+        __syncthreads();
+        if (q == 0 && c < JL::NACC) {
+            double t = 0.0;
+            for (int k = 0; k < PARTS; k++) t += part[k * APAD + c];
+            tot[c] = t;
+        }
     }
     __syncthreads();
     JointState &S = P.js[b];
