@@ -1083,9 +1083,25 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float lxx = t01.lxx.x + t01.lxx.y + t2.lxx, lxy = t01.lxy.x + t01.lxy.y + t2.lxy, lyy = t01.lyy.x + t01.lyy.y + t2.lyy;
         float diff = e1 + e2;
 
+        // the pixel's mask, known before the expensive part: valid x auto-mask, or the min-over-sources selection
+        const bool inimg = c_in[k];
+        bool m = inimg && c_valid[k] && (!(P.automask && n >= P.fwd_noauto) || diff < c_ae[k]);
+        bool sel_keep = false;
+        float sel_dothers = 0.f;
+        if (SEL && sel_pair) {   // keep the pixel for the source with the smallest error (first minimum), under the union
+                                 // validity and the auto-mask of the minima
+            sel_dothers = fminf(sel_before, sel_after);
+            const float dmin = fminf(diff, sel_dothers);
+            sel_keep = (c_valid[k] || sel_valid > 0.f) && (!P.automask || dmin < fminf(c_ae[k], sel_ae));
+            m = inimg && sel_keep && (diff < sel_before) && (diff <= sel_after);
+        }
+
         f2 de2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // d(e2)/d theta, column pairs (01)(23)(45)
         float de6 = 0.f;
-        if (MODE == MODE_LIN) {
+        // Pass B only serves masked-in pixels (its results are multiplied by the mask): a wave whose 64 pixels are ALL masked out --
+        // the other source won them (min over the sources: the sources win in coherent regions), the auto-mask or the warp's
+        // validity dropped them -- skips it (wave-uniform branch; the skipped terms would have been multiplied by zero).
+        if (MODE == MODE_LIN && __builtin_amdgcn_ballot_w64(m) != 0ull) {
             // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
             const f2 cA01 = {cA[0], cA[1]}, cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
             f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, G2 = {0.f, 0.f};   // 3x3 sums of the image gradients (curvature model)
@@ -1124,22 +1140,14 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float sum = cd + pd, dif = c_dif[k], isum = frcp(sum);
         float raw = fabsf(dif) * isum;
         float dd = clamp01(raw), Wt = 1.f - dd;
-        bool inimg = c_in[k];
-        bool m = inimg && c_valid[k] && (!(P.automask && n >= P.fwd_noauto) || diff < c_ae[k]);
         // REFERENCE window rule (optimizer.py:69): Wp = the weight on the photometric term -- source 0's map for every forward
         // pair; wext: it is not this pair's own (no e dW/d theta term); crossf: source 0's weight also multiplies the pixels the
         // other sources won, their error times d W_0 / d theta enters source 0's gradient
         float Wp = Wt, crossf = 0.f;
         bool wext = false;
-        if (SEL && sel_pair) {   // keep the pixel for the source with the smallest error (first minimum), under the union
-                                 // validity and the auto-mask of the minima
-            const float dothers = fminf(sel_before, sel_after), dmin = fminf(diff, dothers);
-            const bool keep = (c_valid[k] || sel_valid > 0.f) && (!P.automask || dmin < fminf(c_ae[k], sel_ae));
-            m = inimg && keep && (diff < sel_before) && (diff <= sel_after);
-            if (P.rule) {
-                if (s_own != 0) { Wp = sel_w0; wext = true; }
-                else crossf = (inimg && keep && !m) ? dothers : 0.f;
-            }
+        if (SEL && sel_pair && P.rule) {
+            if (s_own != 0) { Wp = sel_w0; wext = true; }
+            else crossf = (inimg && sel_keep && !m) ? sel_dothers : 0.f;
         }
 
         if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
