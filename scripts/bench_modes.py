@@ -40,6 +40,31 @@ run("#5 dense 448x256", 256, 448, 2, default_opts(n_iters=4, min_depth=0.03, max
 run("dense 640x192", 192, 640, 2, default_opts(n_iters=4), dense=True)
 
 
+def run_window(name, opts, dense=False, steps=300, warm=30):
+    """the reference's KITTI window as ONE call: B=1 target, S=2 sources (4 directed pairs), min over the sources"""
+    H, W, B, S = 192, 640, 1, 2
+    b = synth.make_batch(2 * S, H, W, seed0=0)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    tgt, srcs = d["tgt"][:1], d["src"][:S].reshape(S, B, 3, H, W)
+    dt, ds = d["depth_t"][:1], d["depth_s"][:S].reshape(S, B, 1, H, W)
+    pose = torch.cat([d["pose_init"][:S], -d["pose_init"][:S]]).contiguous()
+    e = Engine(H, W, 2 * S * B)
+    f = (lambda: e.refine_dense_window(tgt, srcs, dt, ds, d["K"][:1], pose, opts, argmin=True)) if dense else \
+        (lambda: e.refine_window(tgt, srcs, dt, ds, d["K"][:1], pose, opts, argmin=True))
+    for _ in range(warm): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): f()
+    torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": name, "HxW": f"{H}x{W}", "directed_pairs": 4, "iters": opts.n_iters, "us_per_call": round(dt_ * 1e6, 1), "windows_per_s": round(1 / dt_, 1)}))
+
+
+run_window("KITTI window B=1 S=2, depth consistency, min over sources (window rule PAIR)", default_opts(n_iters=4, w_dc=0.15))
+run_window("KITTI window B=1 S=2, depth consistency, min over sources (window rule REFERENCE)", default_opts(n_iters=4, w_dc=0.15, window_rule=1))
+run_window("KITTI window B=1 S=2 without the depth-consistency term", default_opts(n_iters=4))
+run_window("KITTI window dense JOINT (shared depth, 12x12)", default_opts(n_iters=4, dense_joint=1), dense=True)
+run_window("KITTI window dense per-pair copies", default_opts(n_iters=4, dense_joint=0), dense=True)
+
+
 def run_host(steps=200, warm=20):
     """PCIe-inclusive variant of #2: the caller hands over HOST arrays (opts.host_ptrs = 1); never the bench.py metric"""
     import ctypes as C
