@@ -1,0 +1,333 @@
+/*
+ * tcsfm.h -- C ABI of libtcsfm_hip.so, the MI355X (gfx950) photometric pose/depth refinement engine.
+ *
+ * This is the drop-in boundary for the hot path of utiasSTARS/tightly-coupled-SfM
+ * (SURVEY.md section 8a/8b).  The reference is pure Python/PyTorch and has no FFI; every entry
+ * point below names the reference function (file:line under /root/reference) it replaces.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch types.  All array arguments are fp32, contiguous, NCHW like the reference:
+ *       images [N,3,H,W], depth maps [N,1,H,W] (== [N,H,W]), intrinsics [N,3,3] row-major, poses [N,6].
+ *   - a "pair" is one DIRECTED frame pair (target, source); the reference stacks forward and inverse
+ *     pairs along N the same way (train_mono.py:54-62).
+ *   - pose 6-vector = the reference's [tx,ty,tz,rx,ry,rz] (models/stn.py:143-158).  The warp uses
+ *     pose_vec2mat(-pose) exactly like the reference call sites (train_mono.py:69, helpers.py:11).
+ *   - intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1] (all of the reference's loaders produce
+ *     this form); anything else returns TCSFM_E_INTRINSICS: at once for host pointers and for the first use
+ *     of a device buffer (one small blocking copy), and -- when the CONTENTS of an already validated device
+ *     buffer change behind the library's back -- from a device-side guard: that call's results are NaN and
+ *     the error is returned by the next call on the handle or by tcsfm_synchronize().
+ *   - every entry point runs on the handle's device and restores the caller's current device on return.
+ *   - pointers are DEVICE pointers unless tcsfm_opts.host_ptrs != 0, in which case the library stages
+ *     them through its own device buffers (PCIe-inclusive path).
+ *   - every call is asynchronous on the handle's HIP stream when given device pointers, except that
+ *     host-pointer calls and calls returning host scalars synchronise that stream before returning.
+ *   - return value: 0 = ok, negative = error; tcsfm_last_error() gives the message.  Nothing throws.
+ *   - one handle = one device + one stream; calls on a handle are not re-entrant.
+ */
+#ifndef TCSFM_H
+#define TCSFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tcsfm_ctx *tcsfm_handle;
+
+enum {
+    TCSFM_OK = 0,
+    TCSFM_E_ARG = -1,        /* bad argument (null pointer, size out of range, ...)   */
+    TCSFM_E_HIP = -2,        /* a HIP runtime call failed                              */
+    TCSFM_E_INTRINSICS = -3, /* non-pinhole intrinsics                                 */
+    TCSFM_E_NOMEM = -4
+};
+
+enum { TCSFM_SOLVER_GN = 0, TCSFM_SOLVER_LM = 1 };
+enum { TCSFM_PARAM_SE3 = 0,    /* T <- exp(delta^) T, delta = [rho, phi] (liegroups ordering, validate.py:65) */
+       TCSFM_PARAM_EULER = 1   /* pose <- pose + delta on the reference's [t, euler] vector                    */ };
+enum { TCSFM_REFINE_POSE = 0,        /* 6 DoF                                                  */
+       TCSFM_REFINE_POSE_SCALE = 1   /* 6 DoF + log depth-scale shared by both depth maps (7x7) */ };
+
+typedef struct tcsfm_opts {
+    int32_t n_iters;       /* linearisations per refine call (BASELINE.json: 4)                         */
+    int32_t solver;        /* TCSFM_SOLVER_*                                                             */
+    int32_t param;         /* TCSFM_PARAM_*                                                              */
+    int32_t refine;        /* TCSFM_REFINE_*                                                             */
+    int32_t automask;      /* mask = valid * (diff < auto_err), helpers.py:17-19; options['automasking'] */
+    int32_t depth_is_disp; /* depth inputs are sigmoid disparities: disp_to_depth is fused (learning_helpers.py:77-86) */
+    int32_t host_ptrs;     /* 1: array arguments are host pointers (the call synchronises); 2: PINNED host pointers,
+                              asynchronous (tcsfm_refine_window_async only)                                 */
+    int32_t argmin;        /* tcsfm_refine_window with S > 1: per-pixel min over the sources, options['diff_img_argmin'] */
+    float w_l1, w_ssim;    /* 0.15 / 0.85, train_mono.py:87                                              */
+    float w_dc;            /* options['l_depth_consist_weight'] if options['l_depth_consist'] else 0, optimizer.py:83-86 */
+    float irls_eps;        /* floor of the IRLS denominators                                             */
+    float lambda0, lambda_up, lambda_down, lambda_min; /* Marquardt damping (relative to diag H)        */
+    float min_depth, max_depth; /* config['min_depth'], config['max_depth'] (depth_is_disp only)       */
+    float prior_scale;     /* POSE_SCALE only: weight of (log_scale - initial)^2.  The photometric cost cannot separate
+                              depth scale from |t| (exact gauge); this prior makes the 7-DoF problem well posed.   */
+    float lambda_depth;    /* dense mode: Marquardt damping of the per-pixel depth block (default 1.0)                */
+    float prior_depth;     /* dense mode: weight of the masked prior sum M ((rho-rho0)/rho0)^2 / sum M (default 10)   */
+    float reserved1;
+} tcsfm_opts;
+
+/* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.
+ * Row i < n_iters: the i-th linearisation (cost, photometric part, mask count, damping) and the pose it was evaluated at,
+ * i.e. the trajectory of iterates (the analogue of the reference's stacked poses, train_mono.py:71-79).  Row n_iters:
+ * Gauss-Newton -- the final pose, cost fields 0 (not evaluated); LM -- the cost check of the last trial step. */
+enum { TCSFM_STAT_COST = 0, TCSFM_STAT_COST_PHOTO = 1, TCSFM_STAT_NMASK = 2, TCSFM_STAT_LAMBDA = 3,
+       TCSFM_STAT_POSE = 4 /* ..9: the 6-vector the row was evaluated at */, TCSFM_NSTAT = 10 };
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Allocates all device scratch for up to max_pairs directed pairs of H x W images on `device`.
+ * Nothing in the reference corresponds to this: PyTorch owns memory there (optimizer.py:15-27). */
+int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs);
+void tcsfm_destroy(tcsfm_handle h);
+const char *tcsfm_last_error(tcsfm_handle h); /* h may be NULL: last create() error */
+/* Run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is HIP's legacy default
+ * stream (stream 0), which is what PyTorch's default stream is.  A fresh handle runs on its own non-blocking stream;
+ * tcsfm_use_own_stream() switches back to it. */
+int tcsfm_set_stream(tcsfm_handle h, void *hip_stream);
+int tcsfm_use_own_stream(tcsfm_handle h);
+int tcsfm_synchronize(tcsfm_handle h);
+void tcsfm_default_opts(tcsfm_opts *o);
+/* bytes of HBM traffic the algorithm must move per pixel per pair per linearisation: 32 */
+int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *o);
+
+/* ---- reference-function drop-ins (a1, a5, a7, a12) -------------------------------------------- */
+
+/* disp_to_depth, utils/learning_helpers.py:77-86.  n elements; scaled/depth may be NULL. */
+int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const float *disp, float *scaled_disp, float *depth);
+
+/* SSIM_Loss.forward(x, y), losses.py:27-41: `planes` = N*C images of H x W each (reflect pad 1, 3x3 means, clamp). */
+int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, const float *y, float *out);
+
+/* get_smooth_loss(disp, img), losses.py:43-61: edge-aware smoothness of the mean-normalised disparity, disp [N,1,H,W],
+ * img [N,3,H,W] -> one scalar (host double; the call synchronises the stream).  Off by default in the reference
+ * (options['l_smooth'], run_sequential_optimization.py:87); a logging quantity here, not a term of the Gauss-Newton cost. */
+int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *disp, const float *img, double *loss_out);
+
+/* inverse_warp2(src, depth_t, depth_s, -pose, K), models/stn.py:234-273.
+ * Outputs (any may be NULL): img_rec [N,3,H,W], valid [N,1,H,W], proj_depth, comp_depth [N,1,H,W]. */
+int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,
+               const float *pose, const float *K, float *img_rec, float *valid, float *proj_depth, float *comp_depth);
+
+/* The coupled-iteration input assembly of solve_pose_iteratively, train_mono.py:73-77, fused into the warp:
+ * posenet_in [N,6,H,W] = (tgt * valid_mask, img_rec) for the next PoseNet call; valid [N,1,H,W] optional. */
+int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                             const float *depth_s, const float *pose, const float *K, float *posenet_in, float *valid);
+
+/* compute_photometric_error, optimization_experiments/helpers.py:8-23 == per-pair residual assembly of
+ * solve_pose_iteratively, train_mono.py:82-100.  Outputs (any may be NULL), all [N,1,H,W] except img_rec:
+ * diff (diff_img), valid (warp validity, stn.py:268-269), weight (weight_mask), auto_err (auto_mask_error),
+ * auto_mask (diff < auto_err), img_rec [N,3,H,W]. */
+int tcsfm_photometric(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                      const float *depth_s, const float *pose, const float *K, float *diff, float *valid, float *weight,
+                      float *auto_err, float *auto_mask, float *img_rec);
+
+/* The scalar generate_loss_surface sweeps, optimization_experiments/plot_loss_surface.py:31-33,45-47:
+ * cost[i] = sum(diff*mask*weight)/sum(mask) (+ w_dc*mean(1-weight)) of ONE pair (first pair of the arrays)
+ * under P candidate poses [P,6].  cost_out: P doubles (host pointer always). */
+int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, int P, const float *poses, double *cost_out);
+
+/* ---- the Gauss-Newton / LM engine (new functionality; north star) ------------------------------ */
+
+/* One linearisation of N pairs at the given poses (and log depth-scales, may be NULL): normal equations
+ * for parity tests.  np = 6 or 7 per o->refine.  Host outputs (doubles): Hmat [N,np,np], g [N,np],
+ * stats [N,4] = cost, cost_photo, cost_dc, n_mask. */
+int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                    const float *depth_s, const float *pose, const float *log_scale, const float *K,
+                    double *Hmat, double *g, double *stats);
+
+/* Refine N directed pairs: replaces the epoch loop of DepthOptimizer.optimize_window
+ * (optimization_experiments/optimizer.py:217-274) for the pose / pose+scale unknowns with
+ * o->n_iters Gauss-Newton (or LM) iterations on the reference's residual.
+ *   pose_in       [N,6] initial pose (e.g. PoseNet output);  pose_out [N,6] refined pose (may alias pose_in)
+ *   log_scale_in  [N] or NULL (start at 0), log_scale_out [N] or NULL: only read/written when refine == POSE_SCALE
+ *   stats_out     [N,n_iters+1,TCSFM_NSTAT] or NULL */
+int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                 const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
+                 float *log_scale_out, float *stats_out);
+
+/* Window form of tcsfm_refine: the call surface of solve_pose_iteratively / optimize_window (train_mono.py:41-62,
+ * optimizer.py:136-160): B target frames with S source frames each, given ONCE --
+ *   tgt [B,3,H,W], srcs [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W], K [B,3,3] --
+ * and refined as 2*S*B directed pairs in the reference's stacked order (train_mono.py:54-62): pair s*B+b reconstructs
+ * target b from source s (forward), pair S*B+s*B+b the reverse (inverse).  pose_in / pose_out [2*S*B,6],
+ * log_scale_* [2*S*B] or NULL, stats_out [2*S*B,n_iters+1,TCSFM_NSTAT] or NULL, as in tcsfm_refine.
+ * With o->argmin and S > 1 the forward pairs of a target use the reference's per-pixel min over the sources
+ * (compute_optimization_loss, optimizer.py:47-69): at every linearisation a pixel counts only for the source with the
+ * smallest photometric error there, under the union validity mask and the auto-mask of the minima.
+ * Two deliberate differences from the reference's scalar loss (each directed pair is its own least-squares problem here): a pair
+ * is normalised by ITS OWN count of selected pixels, and every pair keeps ITS OWN depth-consistency weight map -- the reference
+ * multiplies the per-pixel minimum by the weight map of source 0 whichever source won the pixel (optimizer.py:69), which would
+ * couple the pose of source 0 into the other pairs' gradients.  The selection itself (which pixels count, for which source) is
+ * the reference's and is pinned on its own maps (golden G4); the scalar-loss mirror tightly_coupled_sfm_amd.losses reproduces
+ * the reference's formula, weight map of source 0 included, for logging (golden G5, all eight option toggles).
+ * The handle must have been created with max_pairs >= 2*S*B. */
+int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                        const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);
+
+/* Dense mode (BASELINE config 5): refine the 6-DoF pose AND the per-pixel inverse depth of the target of N directed
+ * pairs: o->n_iters Gauss-Newton iterations, exact depth gradient (equal to reference autograd d loss / d depth), per-pixel
+ * Schur elimination of the depth block, 6x6 reduced pose system, back-substitution.  depth_t is the initial target depth
+ * (or sigmoid disparity with depth_is_disp); depth_out [N,1,H,W] receives the refined DEPTH.  w_dc must be 0 (the depth prior of
+ * opts.prior_depth regularises instead).  With TCSFM_SOLVER_LM the pose block is Marquardt-damped and a trial that does not
+ * lower the cost is rolled back -- pose AND depth map -- before the step is recomputed from the accepted linearisation. */
+int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
+                       const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
+                       float *stats_out);
+
+/* Window form of tcsfm_refine_dense (the `optimize_depth_pred` mode of optimize_window with its default options,
+ * optimizer.py:194-198 + 47-69): B targets x S sources given once as in tcsfm_refine_window; every one of the 2*S*B directed
+ * pairs refines its pose and ITS OWN copy of its target's depth (forward pairs: one copy of target b's depth per source,
+ * inverse pairs: the depth of source (s,b)); depth_out [2*S*B,1,H,W] in the stacked pair order.  With o->argmin and S > 1
+ * the forward pairs use the per-pixel min over the sources, evaluated at the current poses and depth copies. */
+int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                              const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                              float *depth_out, float *stats_out);
+
+/* ScaleRecovery.forward, models/dnet_layers.py:249-327 (the step right after the path in optimize_window,
+ * optimizer.py:254-258): camera-height map |P.n| from 8-neighbour surface normals, ground mask, exact lower median of the
+ * masked heights over the batch, scale = real_cam_height / median.  pad_to_batch mirrors the reference's padding of a short
+ * batch with copies of image 0 (dnet_layers.py:307-311; pass config['minibatch'], or 0 for none).
+ * scale_out [1]; optional: median_out [1], height_out / mask_out [N,1,H,W]. */
+int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,
+                         int pad_to_batch, float *scale_out, float *median_out, float *height_out, float *mask_out);
+
+/* ---- PoseNet and the coupled pose loop ----------------------------------------
+ * The reference's PoseNet (models/pose_models.py:88-147: seven weight-standardised stride-2 convolutions + GroupNorm(16) + ReLU,
+ * 1x1 head, spatial mean, x 0.01) is evaluated `iterations` times per window inside solve_pose_iteratively (train_mono.py:64,77).
+ * Here it runs as hand-written gfx950 kernels (fp32 matrix instructions, weight standardisation folded into the loaded weights,
+ * GroupNorm + ReLU applied by the consuming layer), so that the whole coupled loop stays inside the library.
+ *   tcsfm_posenet_create   activations for up to max_images samples of the handle's H x W
+ *   tcsfm_posenet_load     HOST pointers to the parameters of the reference module, in its own layouts: conv_w[l] = conv{l+1}.0.weight
+ *                          [cout,cin,k,k], conv_b[l] = conv{l+1}.0.bias [cout] (NULL: 0), gn_w / gn_b[l] = conv{l+1}.1.weight / .bias
+ *                          [cout] (NULL: 1 / 0), head_w = pose_pred.weight [6,256(,1,1)], head_b = pose_pred.bias [6]
+ *   tcsfm_posenet_forward  pose_model(imgs): imgs [N,6,H,W] (device) -> pose [N,6] (device)
+ *   tcsfm_solve_pose_iteratively   train_mono.py:41-81 for a window (layouts of tcsfm_refine_window): PoseNet on (tgt | src) /
+ *                          (src | tgt), then num_iter-1 rounds of { inverse_warp2 with -pose; PoseNet on (tgt * valid | img_rec);
+ *                          pose += correction }.  poses_out [2*S*B,6] = the last iterate; stacked_out [2*S*B,num_iter,6] optional
+ *                          (the reference's stacked_poses).  Asynchronous on the handle's stream. */
+typedef struct tcsfm_posenet tcsfm_posenet;
+int tcsfm_posenet_create(tcsfm_handle h, int max_images, tcsfm_posenet **out);
+void tcsfm_posenet_destroy(tcsfm_posenet *pn);
+int tcsfm_posenet_load(tcsfm_posenet *pn, const float *const conv_w[7], const float *const conv_b[7], const float *const gn_w[7],
+                       const float *const gn_b[7], const float *head_w, const float *head_b);
+int tcsfm_posenet_forward(tcsfm_posenet *pn, int N, const float *imgs, float *pose_out);
+int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, float *poses_out, float *stacked_out);
+
+/* ---- lanes: several refinements in flight (streaming a sequence) ----------------------------------
+ * The reference's driver refines one window after another (run_sequential_optimization.py:186-247: DataLoader batch -> H2D ->
+ * optimize_window); consecutive windows do not depend on each other.  A B=1 refinement leaves the GPU idle between its short
+ * kernels, and a host-pointer call spends more time on PCIe than on the refinement, so the library can keep several calls in
+ * flight: lane k >= 1 owns a HIP stream and a full set of scratch buffers (lane 0 is the handle itself).
+ *   tcsfm_set_lanes          1..8 lanes (allocates / frees the lanes' scratch; default 1)
+ *   tcsfm_refine_window_async   tcsfm_refine_window on `lane`, asynchronously.  Device pointers (host_ptrs = 0): the lane first
+ *                            waits for the work queued on the handle's stream at call time (the producers of the inputs).
+ *                            Pinned host pointers (host_ptrs = 2): the copies run on the lane's stream -- they overlap the other
+ *                            lanes' kernels -- and the call does NOT synchronise; read the outputs after tcsfm_lane_synchronize.
+ *   tcsfm_lane_wait          the handle's stream waits (on the device, not the host) for the lane's last call
+ *   tcsfm_lane_synchronize   the host waits for the lane's last call; reports a pending TCSFM_E_INTRINSICS of that lane
+ *   tcsfm_lane_event         marks the current end of the lane's work with an event (owned by the library; one of a ring of 64
+ *                            per lane, so a mark stays valid until 64 later marks of that lane) -- for callers that recycle
+ *                            input buffers: tcsfm_stream_wait_event(stream, mark) makes e.g. their copy stream wait, on the
+ *                            device, until the lane has consumed the buffer */
+int tcsfm_set_lanes(tcsfm_handle h, int n_lanes);
+int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                              const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                              const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);
+/* the dense mode (tcsfm_refine_dense_window) on a lane: same ordering rules */
+int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                    const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                                    float *depth_out, float *stats_out);
+/* The reference's sequential driver loop as ONE call (run_sequential_optimization.py:186-247: for every window DataLoader batch ->
+ * H2D in process_sample_batch, data/kitti_loader.py:60-98 -> optimize_window, strictly one window after the other).
+ * Window w = the S + 1 consecutive frames w .. w+S, w = 0 .. T-S-1: its target is frame w + target_pos (target_pos = -1: the middle
+ * one, (S+1)/2, as the reference's loaders choose it -- data/kitti_loader.py:271-273 -- i.e. the LATER frame of a two-frame window;
+ * 0: the first), its sources are the other frames in order -> its 2*S directed pairs in the stacked order of train_mono.py:54-62
+ * (forward pairs, then inverse pairs).  All array arguments are HOST pointers here (pinned memory makes the
+ * copies asynchronous; pageable memory works, slower), whatever opts.host_ptrs says:
+ *   frames [T,3,H,W], depths [T,1,H,W] (or disparities, opts.depth_is_disp), K [3,3] (one camera for the sequence),
+ *   pose_init / pose_out [T-S, 2*S, 6], log_scale_out [T-S, 2*S] or NULL (TCSFM_REFINE_POSE_SCALE; the scale starts at 0).
+ * Every frame crosses PCIe once, on a high-priority copy stream of the handle, four frames per copy, into a device ring of `ring`
+ * frames (0 = default; at least windows_per_call + S + 4, or S + 2 with one window per call and single-frame copies); the calls are
+ * issued round robin on the handle's lanes (tcsfm_set_lanes; 2-3 lanes: the GPU runs four hardware queues at once and the copy
+ * stream is one of them) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
+ * finished.  windows_per_call (0 = default 8, capped by max_pairs / (2 S)): the targets and every source of consecutive windows
+ * are runs of the ring, so one call refines that many windows at once (the kernels fill the chip).  The call returns when all
+ * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window, whatever the lanes,
+ * the ring and windows_per_call. */
+int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
+                          const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call, int target_pos);
+/* The same loop with the reference's pose initialisation inside it: for every window the coupled PoseNet loop of
+ * train_mono.py:64-80 (tcsfm_solve_pose_iteratively, `num_iter` network evaluations: config['iterations'], 4 in the reference's
+ * scripts) produces the initial poses on the window's lane, then the window is refined -- what optimize_window does per window
+ * (optimizer.py:136-297) minus the depth network, whose per-frame output is the `depths` argument (depths, not disparities).
+ * `pn`: a loaded PoseNet of this handle with max_images >= 2*S; the lanes run copies of it that share its weights.
+ * pose_init_out [T-S, 2*S, 6] (or NULL) receives the PoseNet poses, pose_out the refined ones.  Bit-identical to one
+ * tcsfm_solve_pose_iteratively + tcsfm_refine_window per CALL's windows (windows_per_call of them as one batch; the PoseNet's
+ * work split -- hence its rounding -- depends on the number of images, see tcsfm_posenet_forward: per-window calls agree to 1e-5). */
+int tcsfm_odometry_sequence(tcsfm_handle h, tcsfm_posenet *pn, int num_iter, const tcsfm_opts *o, int T, int S, const float *frames,
+                            const float *depths, const float *K, float *pose_init_out, float *pose_out, float *log_scale_out, int ring,
+                            int windows_per_call, int target_pos);
+/* The dense mode (tcsfm_refine_dense_window: pose + per-pixel inverse depth with the Schur complement, BASELINE config 5) over a
+ * sequence, same streaming and batching: depth_out [T-S, 2*S, H, W] (host) receives every directed pair's refined depth map.
+ * Bit-identical to one tcsfm_refine_dense_window call per window. */
+int tcsfm_refine_dense_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
+                                const float *pose_init, float *pose_out, float *depth_out, int ring, int windows_per_call, int target_pos);
+int tcsfm_lane_wait(tcsfm_handle h, int lane);
+int tcsfm_lane_synchronize(tcsfm_handle h, int lane);
+int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out);
+int tcsfm_stream_wait_event(tcsfm_handle h, void *hip_stream, void *event);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
+
+/* While profiling is on, every launch of the three kernel classes is bracketed by a pair of HIP events recorded on the
+ * handle's stream.  tcsfm_profile_end() synchronises the stream and returns summed elapsed milliseconds and launch
+ * counts per class: index 0 = k_linearize (the hot kernel), 1 = k_solve, 2 = k_pack. */
+int tcsfm_profile_begin(tcsfm_handle h);
+int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]);
+/* The same session's linearisation launches (k_linearize / k_dense_linearize) as the GPU itself timed them: every workgroup
+ * stamps s_memrealtime (100 MHz) at its start and end, duration of a launch = latest end - earliest start.  An event pair
+ * around a ~10 us kernel reads 2-4 us high (dispatch latency + the event packets); this figure is the one that agrees with
+ * rocprofv3's kernel duration.  Call after tcsfm_profile_end; launches beyond the stamp buffer (4 M workgroups per session)
+ * are not counted. */
+int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches);
+/* Parity-test hook.  The reference's masks are discontinuous (valid x [diff < auto_err], min over sources; helpers.py:17-19,
+ * optimizer.py:47-69) and LM accepts / rejects on a cost comparison: near a tie the fp32 engine and a float64 checker may
+ * decide differently.  While a trace is set, every linearisation `lin` of tcsfm_refine* / tcsfm_refine_dense* over N pairs
+ * records the engine's decisions into caller-owned DEVICE buffers:
+ *   bits   [lin][N][H*W] uint16  bit 0 = the pixel counts (final mask, incl. the min-over-sources selection), bit 1 = warp valid,
+ *                                bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy) (grid_sample's backward is
+ *                                discontinuous across texel boundaries), bits 4-5 = sign of computed - projected depth,
+ *                                bits 6-7 / 8-9 / 10-11 = sign of rec_c - tgt_c per colour channel (the signs in the derivatives
+ *                                of |cd - pd| and |rec - tgt|; 2-bit codes: 0 exactly zero, 1 positive, 2 negative)
+ *   decide [lin][N]      int32   LM: 1 = trial accepted (lin < n_iters) / last step kept (lin == n_iters); GN: 1
+ * so that a checker can replay them and compare the continuous arithmetic at full tolerance (tests/test_gpu_parity.py).
+ * Capacities in elements; a call that would overflow them returns TCSFM_E_ARG.  Either pointer may be NULL; (NULL, 0, NULL, 0)
+ * switches the trace off.  Costs one wave-uniform branch per pixel when off. */
+int tcsfm_debug_trace(tcsfm_handle h, uint16_t *bits, int64_t bits_capacity, int32_t *decide, int64_t decide_capacity);
+/* Diagnostic builds: 100 MHz wall-clock stamps of the phases of the last k_solve launch of pair 0 (zeros unless the
+ * handle was created with TCSFM_DEBUG_STAMPS set in the environment). */
+int tcsfm_debug_stamps(tcsfm_handle h, long long out[8]);
+
+/* ---- SE(3) utilities, host, double (replace liegroups.SE3 at data/kitti_loader_stereo.py:129-147,
+ *      validate.py:65-71; liegroups is an absent third-party dependency, version unpinned) ---------- */
+void tcsfm_pose_to_matrix(const double pose[6], double T[12]);   /* pose_vec2mat(-pose), 3x4 row-major  */
+void tcsfm_matrix_to_pose(const double T[12], double pose[6]);
+void tcsfm_se3_exp(const double xi[6], double T[12]);            /* xi = [rho, phi]                     */
+void tcsfm_se3_log(const double T[12], double xi[6]);
+void tcsfm_se3_mul(const double A[12], const double B[12], double C[12]);
+void tcsfm_se3_inv(const double A[12], double B[12]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCSFM_H */

@@ -67,11 +67,10 @@ def run_sequence(H, W, lanes, wpc, T=120):
     e = Engine(H, W, 2 * wpc, lanes=lanes)
     o = default_opts(n_iters=4, min_depth=0.03, max_depth=3.0)
     e.refine_dense_sequence(frames[:40], depths[:40], seq["K"], init[:39], o, windows_per_call=wpc)
-    dout = torch.empty((T - 1, 2, 1, H, W), dtype=torch.float32, pin_memory=True)      # the caller's result buffer, reused (pinning 70 MB per call costs 10x the refinement)
     ts = []
-    for _ in range(7):
-        t0 = time.perf_counter(); e.refine_dense_sequence(frames, depths, seq["K"], init, o, windows_per_call=wpc, out_depths=dout); ts.append(time.perf_counter() - t0)
-    t = sorted(ts)[3]
+    for _ in range(5):
+        t0 = time.perf_counter(); e.refine_dense_sequence(frames, depths, seq["K"], init, o, windows_per_call=wpc); ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[2]
     print(json.dumps({"HxW": f"{H}x{W}", "path": "tcsfm_refine_dense_sequence (PCIe-inclusive, depth maps back to the host)", "lanes": lanes, "windows_per_call": wpc,
                       "us_per_window": round(t / (T - 1) * 1e6, 1), "windows_per_s": round((T - 1) / t, 1)}), flush=True)
     e.close()

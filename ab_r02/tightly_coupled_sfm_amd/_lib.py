@@ -1,0 +1,113 @@
+"""ctypes binding of libtcsfm_hip.so (include/tcsfm.h).  There is NO fallback: if the HIP library is
+missing or fails to load, importing the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# A refinement is a chain of short dependent kernels: kernel arguments must sit in device memory (this ROCm's default; with 0 every
+# launch fetches them over PCIe and a B=1 call takes 90 us instead of 72 us).  Only a default, and only effective when this module is
+# imported before the process's first HIP call.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtcsfm_hip.so")
+
+
+class Opts(C.Structure):
+    """mirror of struct tcsfm_opts"""
+    _fields_ = [("n_iters", C.c_int32), ("solver", C.c_int32), ("param", C.c_int32), ("refine", C.c_int32),
+                ("automask", C.c_int32), ("depth_is_disp", C.c_int32), ("host_ptrs", C.c_int32), ("argmin", C.c_int32),
+                ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_dc", C.c_float), ("irls_eps", C.c_float),
+                ("lambda0", C.c_float), ("lambda_up", C.c_float), ("lambda_down", C.c_float), ("lambda_min", C.c_float),
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prior_scale", C.c_float), ("lambda_depth", C.c_float), ("prior_depth", C.c_float), ("reserved1", C.c_float)]
+
+
+SOLVER_GN, SOLVER_LM = 0, 1
+PARAM_SE3, PARAM_EULER = 0, 1
+REFINE_POSE, REFINE_POSE_SCALE = 0, 1
+STAT_POSE = 4
+NSTAT = 10        # cost, cost_photo, n_mask, lambda, pose[6]  (include/tcsfm.h TCSFM_STAT_*)
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "tcsfm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tcsfm_destroy": (None, [_P]),
+    "tcsfm_last_error": (C.c_char_p, [_P]),
+    "tcsfm_set_stream": (C.c_int, [_P, _P]),
+    "tcsfm_use_own_stream": (C.c_int, [_P]),
+    "tcsfm_synchronize": (C.c_int, [_P]),
+    "tcsfm_default_opts": (None, [C.POINTER(Opts)]),
+    "tcsfm_algorithmic_bytes_per_pixel": (C.c_int, [C.POINTER(Opts)]),
+    "tcsfm_disp_to_depth": (C.c_int, [_P, C.POINTER(Opts), C.c_int64, _P, _P, _P]),
+    "tcsfm_smooth_loss": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, _P]),
+    "tcsfm_ssim": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, _P]),
+    "tcsfm_warp": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
+    "tcsfm_warp_posenet_input": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 8),
+    "tcsfm_photometric": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 12),
+    "tcsfm_loss_surface": (C.c_int, [_P, C.POINTER(Opts)] + [_P] * 5 + [C.c_int, _P, _P]),
+    "tcsfm_linearize": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
+    "tcsfm_refine_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
+    "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
+    "tcsfm_refine_dense_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
+    "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
+    "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),
+    "tcsfm_posenet_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "tcsfm_posenet_destroy": (None, [_P]),
+    "tcsfm_posenet_load": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "tcsfm_posenet_forward": (C.c_int, [_P, C.c_int, _P, _P]),
+    "tcsfm_solve_pose_iteratively": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int] + [_P] * 7),
+    "tcsfm_set_lanes": (C.c_int, [_P, C.c_int]),
+    "tcsfm_refine_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
+    "tcsfm_refine_dense_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
+    "tcsfm_refine_sequence": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),
+    "tcsfm_odometry_sequence": (C.c_int, [_P, _P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),
+    "tcsfm_refine_dense_sequence": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),
+    "tcsfm_lane_wait": (C.c_int, [_P, C.c_int]),
+    "tcsfm_lane_synchronize": (C.c_int, [_P, C.c_int]),
+    "tcsfm_lane_event": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "tcsfm_stream_wait_event": (C.c_int, [_P, _P, _P]),
+    "tcsfm_profile_begin": (C.c_int, [_P]),
+    "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
+    "tcsfm_profile_kernel_time": (C.c_int, [_P, _P, _P]),
+    "tcsfm_debug_stamps": (C.c_int, [_P, _P]),
+    "tcsfm_debug_trace": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
+    "tcsfm_pose_to_matrix": (None, [_P, _P]),
+    "tcsfm_matrix_to_pose": (None, [_P, _P]),
+    "tcsfm_se3_exp": (None, [_P, _P]),
+    "tcsfm_se3_log": (None, [_P, _P]),
+    "tcsfm_se3_mul": (None, [_P, _P, _P]),
+    "tcsfm_se3_inv": (None, [_P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises RuntimeError when it is absent: build it with
+    ``python -m tightly_coupled_sfm_amd.build`` or ``__graft_entry__.build()``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own ROCm runtime: import it first so that this library binds to the SAME libamdhip64 the
+    # process's tensors live in (loading ours first leaves two runtimes and hipSetDevice then reports "no device").
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    load().tcsfm_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(f"tcsfm_opts has no field {k!r}")
+        setattr(o, k, v)
+    return o

@@ -1,0 +1,1402 @@
+// kernels.h -- gfx950 device code of the photometric refinement engine.
+//
+// Kernels (one HIP stream, no host sync between them):
+//   k_pack        once per refine call: planar fp32 inputs -> two float4 images per pair
+//                   tgtpack = (tgt r,g,b, auto_err)   auto_err = iteration-invariant auto-mask error (train_mono.py:84)
+//                   srcpack = (src r,g,b, depth_s)    one 16-B gather per bilinear tap instead of four 4-B gathers;
+//                                                     stored with a 1-texel zero border so that taps need no masks
+//                 (window form: the fwd / inv directed pairs of train_mono.py:54-62 are formed here by indexing)
+//   k_linearize   THE hot kernel, once per Gauss-Newton iteration: fused
+//                   backproject (stn.py:33-48) -> rigid transform + project (stn.py:198-231) -> bilinear warp of
+//                   RGB+depth with d/d(ix,iy) (stn.py:266,271) -> L1 + 3x3 SSIM (losses.py:27-41, train_mono.py:87)
+//                   -> masks / depth-consistency weight (train_mono.py:89-92) -> exact gradient rows, structure-tensor
+//                   curvature -> per-workgroup J'J / J'r partial sums.  Reads 36 B/pixel, writes one partial-sum record
+//                   per workgroup; measured VALU-issue bound (~1050 instructions per 64-pixel wave), see DESIGN.md.
+//                   MODE_COST / MODE_MAPS variants: scalar cost only / the reference's residual maps.
+//   k_select      window form with the min over sources (optimizer.py:47-69): per-pixel selection masks of the forward pairs
+//   k_solve       once per iteration, one workgroup per pair: deterministic fp64 reduction of the partial sums,
+//                   LM/GN logic, lane-parallel Gauss-Jordan on the 6x6 / 7x7 system, SE(3) retraction, emits the fp32
+//                   constants of the next iteration.
+//   k_warp        inverse_warp2 drop-in (stn.py:234-273), planar in / planar out (+ the next PoseNet input, train_mono.py:73-77).
+//   k_ssim, k_disp_to_depth: SSIM_Loss / disp_to_depth drop-ins.  dense_kernel.h, scale_kernel.h: dense mode, DNet scale.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "se3_math.h"
+#include "wave_reduce.h"
+
+namespace tc {
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-pair constants of one linearisation (fp32, written by k_init / k_solve, read through the scalar cache)
+struct PairConst {
+    float A[9], kt[3];         // A = K (R - I) K^-1 and K t, both formed in fp64: K[R|t] K^-1 pix = pix + A pix, so the
+                               // projection OFFSET (flow) is computed without cancellation (see warp_geo)
+    float R[9], t[3];          // [R|t] = pose_vec2mat(-pose) (left-multiplied by the GN updates)
+    float fx, fy, cx, cy;      // pinhole intrinsics
+    float ki0, ki2, ki4, ki5;  // K^-1 = [ki0 0 ki2; 0 ki4 ki5; 0 0 1]
+    float es;                  // exp(log depth-scale)
+    int img;                   // which packed image pair this problem reads (loss-surface sweeps share one)
+    int pad[2];
+};
+
+// per-pair optimiser state (fp64)
+struct PairState {
+    double Tcur[12], Ttry[12];
+    double scur, stry, s0;   // log depth-scale: accepted, trial, initial (prior centre)
+    double lambda, cost_cur;
+    double M8[64];             // accepted linearisation as the augmented 8x8 system [H | -g] (undamped), one entry per lane
+    double K[9];
+    int have_cur, pad;
+};
+
+struct LinParams {
+    const float4 *tgtpack;  // [Nimg][H][W]  rgb + auto_err
+    const float4 *srcpack;  // [Nimg][H+2][W+2]  rgb + depth_s, 1-texel zero border
+    const float *depth_t;   // [Nimg][H][W]
+    const PairConst *pc;    // [N]
+    float *blockrec;        // [N][nblk][nacc]   one partial-sum record per workgroup (write-through stores)
+    int *tickets;           // [N][ngrp]         arrival counters of the 16-workgroup reduction groups (zero between launches)
+    float *partials;        // [N][ngrp][nacc] group records (a few dozen per pair): what the solve kernel reads
+    // maps mode outputs (may be null)
+    float *o_diff, *o_valid, *o_weight, *o_auto_err, *o_auto_mask, *o_rec;
+    int H, W, tiles_x, tiles_y, nacc;
+    int ngrp, ngrp_pad;     // reduction groups per pair, and that rounded up to a multiple of 64
+    float wl, ws;           // w_l1/3, w_ssim/3
+    float eps;              // irls_eps
+    int automask;
+    int shared_image;       // all problems read packed image pair 0 (loss-surface sweeps); kept OUT of PairConst so that the
+                            // first image loads do not wait for the scalar loads of the pair constants
+    int direct;             // 1: no in-launch group reduction -- k_solve sums the workgroup records itself (small grids)
+    const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
+    int n_ext;
+    int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
+    unsigned short *trace;  // tcsfm_debug_trace: [N][H*W] decisions of THIS launch (bit 0 = pixel counts, bit 1 = warp valid,
+                            // bits 2 / 3 = parity of the bilinear cell floor(ix) / floor(iy), bits 4-5 = sign code of cd - pd,
+                            // bits 6-11 = sign codes of rec_c - tgt_c; codes 0 zero / 1 positive / 2 negative), or null
+    unsigned long long *stamp;  // tcsfm_profile_*: [workgroups of this launch][2] = start / end of every workgroup in
+                                // s_memrealtime ticks (100 MHz), or null.  Duration of the launch as the GPU sees it = latest end -
+                                // earliest start (taken on the host), free of the ~2-4 us a HIP event pair adds around a 10 us kernel.
+};
+
+__device__ __forceinline__ unsigned sign_code(float x) { return x > 0.f ? 1u : (x < 0.f ? 2u : 0u); }
+
+// in-kernel launch bracket (see LinParams::stamp): one plain 8-byte store per workgroup at each end, only while profiling
+// (an atomic min / max on one word per launch was tried first: 480 workgroups x 2 same-address atomics x ~12 ns = +4 us per launch)
+__device__ __forceinline__ void stamp_begin(unsigned long long *stamp, int tid) {
+    if (stamp != nullptr && tid == 0) stamp[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x)] = (unsigned long long)wall_clock64();
+}
+__device__ __forceinline__ void stamp_end(unsigned long long *stamp, int tid) {
+    if (stamp != nullptr && tid == 0) stamp[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = (unsigned long long)wall_clock64();
+}
+
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+
+__device__ __forceinline__ int refl_idx(int i, int n) {  // ReflectionPad2d(1), losses.py:22 (clamped for safety)
+    i = i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+    return min(max(i, 0), n - 1);
+}
+__device__ __forceinline__ float clamp01(float a) { return fminf(fmaxf(a, 0.f), 1.f); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: the kernel is VALU-bound
+__device__ __forceinline__ float frcp(float a) { return __builtin_amdgcn_rcpf(a); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// warp geometry of one target pixel
+struct Geo {
+    float rx, ry;        // sample position RELATIVE to the pixel's own integer coordinates: ix = u + rx, iy = v + ry
+    float Z, iz;         // computed depth (clamped at 1e-3, stn.py:215) and 1/Z
+    float uz, vz;        // projected pixel coordinates p0/Z, p1/Z
+    float X0, X1, X2;    // point in the source camera frame
+    bool oobx, ooby, zcl;
+};
+
+// pixel2cam (stn.py:33-48) -> [R|t] -> cam2pixel2 (stn.py:198-231) -> grid_sample un-normalisation (stn.py:266).
+// Same mathematics as the reference, evaluated in a cancellation-free order for fp32:
+//   p = K[R|t](D K^-1 pix) = D (pix + A pix) + K t     =>  p0 - u p2 = D((A pix)_0 - u (A pix)_2) + kt_0 - u kt_2
+// so the flow u_proj - u = (p0 - u Z)/Z is formed from small quantities only, and the bilinear weights come from
+// the fractional part of a small number instead of from ix ~ 10^2..10^3 (ulp 3e-5 px).  Agreement with the float64
+// oracle improves ~300x; versus the reference's own fp32 evaluation only exact ties can differ.
+__device__ __forceinline__ void warp_geo(const PairConst &c, int W, int H, int ui, int vi, float depth, Geo &g) {
+    const float u = (float)ui, v = (float)vi;
+    float D = c.es * depth;
+    float a0 = c.A[0] * u + c.A[1] * v + c.A[2];
+    float a1 = c.A[3] * u + c.A[4] * v + c.A[5];
+    float a2 = c.A[6] * u + c.A[7] * v + c.A[8];
+    float q0 = D * a0 + c.kt[0], q1 = D * a1 + c.kt[1], q2 = D * a2 + c.kt[2];
+    float p2 = D + q2;
+    g.zcl = p2 < 1e-3f;
+    g.Z = g.zcl ? 1e-3f : p2;
+    g.iz = frcp(g.Z);
+    // numerators of the flow: p0 - u Z, p1 - v Z
+    float fu = g.zcl ? (u * D + q0) - u * g.Z : q0 - u * q2;
+    float fv = g.zcl ? (v * D + q1) - v * g.Z : q1 - v * q2;
+    float flx = fu * g.iz, fly = fv * g.iz;
+    g.uz = u + flx;
+    g.vz = v + fly;
+    // |x_norm| > 1  <=>  u_proj outside [0, W-1]   (stn.py:223-227; detached sentinel -> zero sample, zero gradient)
+    g.oobx = (flx > (float)(W - 1 - ui)) || (flx < -u);
+    g.ooby = (fly > (float)(H - 1 - vi)) || (fly < -v);
+    // ix = u_proj W/(W-1) - 0.5 = u + [u/(W-1) - 0.5 + flow W/(W-1)]
+    const float iw = frcp((float)(W - 1)), ih = frcp((float)(H - 1));
+    g.rx = (u * iw - 0.5f) + flx * ((float)W * iw);
+    g.ry = (v * ih - 0.5f) + fly * ((float)H * ih);
+    // point in the source camera frame (Jacobians only)
+    float r0 = c.ki0 * u + c.ki2, r1 = c.ki4 * v + c.ki5;
+    float x0 = r0 * D, x1 = r1 * D, x2 = D;
+    g.X0 = c.R[0] * x0 + c.R[1] * x1 + c.R[2] * x2 + c.t[0];
+    g.X1 = c.R[3] * x0 + c.R[4] * x1 + c.R[5] * x2 + c.t[1];
+    g.X2 = c.R[6] * x0 + c.R[7] * x1 + c.R[8] * x2 + c.t[2];
+}
+
+// bilinear sample of a float4 image at (ui + rx, vi + ry) with zero padding; also d/dix and d/diy
+// (grid_sampler_2d forward/backward semantics).  oob => the reference's sentinel: everything is zero.
+// The image is stored with a 1-texel ZERO BORDER ((H+2) x (W+2), k_pack): taps are clamped into the border instead of being
+// masked one by one, and an out-of-bounds sample is sent there as a whole -- 1 select instead of 16 selects + 8 compares.
+struct Tap {
+    float4 v00, v01, v10, v11;
+    float wx, wy;
+};
+// address computation + the four 16-byte gathers (asynchronous: nothing here waits for them)
+__device__ __forceinline__ void tap4_fetch(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob, Tap &t) {
+    float fx = floorf(rx), fy = floorf(ry);
+    t.wx = rx - fx; t.wy = ry - fy;
+    int xi = ui + (int)fx, yi = vi + (int)fy;
+    xi = oob ? -2 : xi;                                         // both columns clamp to the left border: all four taps are zero
+    const int x0 = min(max(xi, -1), W) + 1, x1 = min(max(xi + 1, -1), W) + 1;   // bordered coordinates 0 .. W+1
+    const int y0 = min(max(yi, -1), H) + 1, y1 = min(max(yi + 1, -1), H) + 1;
+    const int WB = W + 2;
+    t.v00 = img[y0 * WB + x0]; t.v01 = img[y0 * WB + x1]; t.v10 = img[y1 * WB + x0]; t.v11 = img[y1 * WB + x1];
+}
+// bilinear value and d/dix, d/diy of the four channels
+__device__ __forceinline__ void tap4_lerp(const Tap &t, float4 &val, float4 &gx, float4 &gy) {
+    const float wx = t.wx, wy = t.wy, ax = 1.f - wx, ay = 1.f - wy;
+#define TC_LERP(f)                                                                             \
+    val.f = ax * ay * t.v00.f + wx * ay * t.v01.f + ax * wy * t.v10.f + wx * wy * t.v11.f;     \
+    gx.f = ay * (t.v01.f - t.v00.f) + wy * (t.v11.f - t.v10.f);                                \
+    gy.f = ax * (t.v10.f - t.v00.f) + wx * (t.v11.f - t.v01.f);
+    TC_LERP(x) TC_LERP(y) TC_LERP(z) TC_LERP(w)
+#undef TC_LERP
+}
+__device__ __forceinline__ void tap4(const float4 *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob,
+                                     float4 &val, float4 &gx, float4 &gy) {
+    Tap t;
+    tap4_fetch(img, W, H, ui, vi, rx, ry, oob, t);
+    tap4_lerp(t, val, gx, gy);
+}
+
+// Jacobian of the sample position and of Z w.r.t. the left SE(3) perturbation [rho, phi] (+ log depth-scale)
+//   dXp/drho_j = e_j ; dXp/dphi_j = e_j x Xp ; dXp/dsigma = Xp - t   ; pinhole K
+template <int NP>
+__device__ __forceinline__ void geo_jac(const PairConst &c, const Geo &g, int W, int H, float *a, float *b, float *zc) {
+    const float cw = (float)W * frcp((float)(W - 1)), ch = (float)H * frcp((float)(H - 1));
+    float dp0[TC_MAXP], dp1[TC_MAXP], dp2[TC_MAXP];
+    dp0[0] = c.fx;  dp1[0] = 0.f;   dp2[0] = 0.f;
+    dp0[1] = 0.f;   dp1[1] = c.fy;  dp2[1] = 0.f;
+    dp0[2] = c.cx;  dp1[2] = c.cy;  dp2[2] = 1.f;
+    dp0[3] = c.cx * g.X1;               dp1[3] = -c.fy * g.X2 + c.cy * g.X1; dp2[3] = g.X1;
+    dp0[4] = c.fx * g.X2 - c.cx * g.X0; dp1[4] = -c.cy * g.X0;               dp2[4] = -g.X0;
+    dp0[5] = -c.fx * g.X1;              dp1[5] = c.fy * g.X0;                dp2[5] = 0.f;
+    if (NP == 7) {
+        float q0 = g.X0 - c.t[0], q1 = g.X1 - c.t[1], q2 = g.X2 - c.t[2];
+        dp0[6] = c.fx * q0 + c.cx * q2; dp1[6] = c.fy * q1 + c.cy * q2; dp2[6] = q2;
+    }
+    float sa = g.oobx ? 0.f : cw * g.iz, sb = g.ooby ? 0.f : ch * g.iz, zf = g.zcl ? 0.f : 1.f;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        float dz = zf * dp2[j];
+        zc[j] = dz;
+        a[j] = sa * (dp0[j] - g.uz * dz);
+        b[j] = sb * (dp1[j] - g.vz * dz);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-pair fp64 state -> fp32 constants of one linearisation; pair initialisation
+
+__device__ inline void write_const(const PairState &S, const double *T, double s, int img, PairConst &c) {
+    const double *K = S.K;
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double Ki[9] = {1.0 / fx, 0, -cx / fx, 0, 1.0 / fy, -cy / fy, 0, 0, 1};
+    double RmI[9], KR[9], A[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) RmI[3 * i + j] = T[4 * i + j] - (i == j ? 1.0 : 0.0);
+    mat3_mul(K, RmI, KR);
+    mat3_mul(KR, Ki, A);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            c.A[3 * i + j] = (float)A[3 * i + j];
+            c.R[3 * i + j] = (float)T[4 * i + j];
+        }
+        c.kt[i] = (float)(K[3 * i] * T[3] + K[3 * i + 1] * T[7] + K[3 * i + 2] * T[11]);
+        c.t[i] = (float)T[4 * i + 3];
+    }
+    c.fx = (float)fx; c.fy = (float)fy; c.cx = (float)cx; c.cy = (float)cy;
+    c.ki0 = (float)(1.0 / fx); c.ki2 = (float)(-cx / fx); c.ki4 = (float)(1.0 / fy); c.ki5 = (float)(-cy / fy);
+    c.es = (s == 0.0) ? 1.f : (float)exp(s);
+    c.img = img;
+}
+
+// Lane-parallel form of write_const for the solve kernel: lanes 0..8 one entry of A and R each, lanes 0..2 kt and t.
+// Intrinsics and image index never change after init_pair and are not rewritten.  T: 3x4 transform in LDS.
+// 1/x in double precision without the ~35-instruction IEEE division sequence: v_rcp_f64 seed + two Newton steps
+// (quadratic: 2^-26 -> 2^-52).  The solve kernel is one long dependent fp64 chain; every division on it costs ~0.1 us.
+__device__ __forceinline__ double rcp64(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+template <int NP>
+__device__ __forceinline__ void write_const_lanes(int lane, const double *K, const double *T, double s, PairConst &c) {
+    if (lane < 9) {
+        const int i = lane / 3, j = lane - 3 * i;
+        const double ifx = rcp64(K[0]), ify = rcp64(K[4]), cx = K[2], cy = K[5];
+        const double Ki[9] = {ifx, 0, -cx * ifx, 0, ify, -cy * ify, 0, 0, 1};
+        double KR[3];   // row i of K (R - I)
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+            KR[m] = K[3 * i] * (T[m] - (m == 0 ? 1.0 : 0.0)) + K[3 * i + 1] * (T[4 + m] - (m == 1 ? 1.0 : 0.0)) +
+                    K[3 * i + 2] * (T[8 + m] - (m == 2 ? 1.0 : 0.0));
+        c.A[lane] = (float)(KR[0] * Ki[j] + KR[1] * Ki[3 + j] + KR[2] * Ki[6 + j]);
+        c.R[lane] = (float)T[4 * i + j];
+    }
+    if (lane < 3) {
+        c.kt[lane] = (float)(K[3 * lane] * T[3] + K[3 * lane + 1] * T[7] + K[3 * lane + 2] * T[11]);
+        c.t[lane] = (float)T[4 * lane + 3];
+    }
+    if (NP == 7 && lane == 0) c.es = (s == 0.0) ? 1.f : (float)exp(s);
+}
+
+struct InitParams {
+    const float *pose, *log_scale, *K;  // [N,6], [N] or null, [Nimg,3,3]
+    PairState *st;
+    PairConst *pc;
+    int N, shared_image;                // shared_image: all problems read image pair 0 (loss-surface sweep)
+    float lambda0;
+    int K_mod;                          // window form: pair n uses intrinsics K[n % K_mod] (0: one matrix per pair)
+    int *err;                           // host-mapped status word: set to 1 when a pair's intrinsics are not pinhole (or null)
+};
+
+__device__ inline void init_pair(const InitParams &P, int n) {
+    PairState &S = P.st[n];
+    int img = P.shared_image ? 0 : n;
+    const int kidx = P.K_mod > 0 ? n % P.K_mod : img;
+    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[kidx * 9 + i];
+    double pose[6];
+    for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
+    {   // device-side guard of the pinhole contract (the host validates a given intrinsics buffer only once)
+        const double *K = S.K;
+        if (K[1] != 0.0 || K[3] != 0.0 || K[6] != 0.0 || K[7] != 0.0 || K[8] != 1.0 || K[0] == 0.0 || K[4] == 0.0) {
+            for (int i = 0; i < 6; i++) pose[i] = __longlong_as_double(0x7ff8000000000000LL);  // NaN: fail loudly ...
+            if (P.err) *reinterpret_cast<volatile int *>(P.err) = 1;   // ... and report TCSFM_E_INTRINSICS at the next call / synchronize
+        }
+    }
+    pose_to_T(pose, S.Tcur);
+    for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
+    S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
+    S.lambda = (double)P.lambda0;
+    S.cost_cur = 0.0;
+    S.have_cur = 0;
+    write_const(S, S.Ttry, S.stry, img, P.pc[n]);
+}
+
+__global__ void k_init(InitParams P) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < P.N) init_pair(P, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_pack
+// Window form with explicit source positions: source (s, b) is image win_off.off[s] + b of the `src` / `depth_s` arrays instead of the
+// standard s B + b.  The sequence calls use it: the targets and every source of consecutive windows are runs of ONE frame ring
+// (target = frame w + t0, source s = frame w + off[s]), so B windows with any number of sources are refined by pointer.
+constexpr int TC_MAX_SRC_OFF = 8;
+struct WinOff {
+    int on;                       // 0: standard layout
+    int off[TC_MAX_SRC_OFF];
+};
+__device__ __forceinline__ int win_src_image(const WinOff &w, int q, int B) { return w.on ? w.off[q / B] + (q - (q / B) * B) : q; }
+
+struct PackParams {
+    const float *tgt, *src, *depth_t, *depth_s;  // planar inputs [N,3,H,W] / [N,1,H,W]
+    float4 *tgtpack, *srcpack;
+    float *depth_out;                            // [N,H,W] depth_t (converted if depth_is_disp)
+    float *depth_out2;                           // optional second copy of the same (dense mode: the prior centre depth0), or null
+    int H, W, N;
+    float wl, ws;                                // w_l1/3, w_ssim/3
+    int depth_is_disp;
+    float min_disp, max_disp;
+    InitParams init;                             // init.N > 0: pair initialisation fused into this launch (one thread per pair)
+    // window form (win_B > 0): tgt [B,3,H,W], src [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W]; directed pairs in
+    // the stacked order of train_mono.py:54-62 -- n = s B + b forward (tgt b <- src s), S B + s B + b inverse -- are formed
+    // here by indexing, the caller never materialises the repeated / concatenated tensors
+    int win_B, win_S;
+    WinOff win_off;
+};
+
+// (w_l1 |y-x|.clamp + w_ssim SSIM(x,y)).mean(C) at one pixel straight from planar global memory.
+// The 9 reflect-padded neighbour offsets are formed once (3 row + 3 column indices) and shared by the 6 planes: the first
+// version recomputed refl_idx per load and spent most of its instructions on addresses.
+__device__ inline float photo_err_planar(const float *__restrict__ x, const float *__restrict__ y, int H, int W, int u, int v,
+                                         float wl, float ws) {
+    float acc = 0.f;
+    const int hw = H * W;
+    const int r0 = refl_idx(v - 1, H) * W, r1 = v * W, r2 = refl_idx(v + 1, H) * W;
+    const int c0 = refl_idx(u - 1, W), c1 = u, c2 = refl_idx(u + 1, W);
+    const int off[9] = {r0 + c0, r0 + c1, r0 + c2, r1 + c0, r1 + c1, r1 + c2, r2 + c0, r2 + c1, r2 + c2};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float *xc = x + c * hw, *yc = y + c * hw;
+        float xv[9], yv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { xv[k] = xc[off[k]]; yv[k] = yc[off[k]]; }
+        const float x0 = xv[4], y0 = yv[4];
+        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float a = xv[k] - x0, b = yv[k] - y0;  // shifted by the centre value: fp32-safe variances
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+        const float n9 = 1.f / 9.f;
+        float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
+        float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
+        float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
+        float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+        acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n * frcp(d)) * 0.5f);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_pack(PackParams P) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.y;
+    const int hw = P.H * P.W;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n < P.init.N) init_pair(P.init, n);  // independent of the packing below
+    if (idx >= hw) return;
+    int v = idx / P.W, u = idx - v * P.W;
+    const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
+    const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
+    if (P.win_B > 0) {
+        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, qi = win_src_image(P.win_off, q, P.win_B);
+        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)qi * 3 * hw;
+        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)qi * hw;
+        t = inv ? si : ti; s = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
+    }
+    float ae = photo_err_planar(t, s, P.H, P.W, u, v, P.wl, P.ws);
+    float dt = dtp[idx], ds = dsp[idx];
+    if (P.depth_is_disp) {  // disp_to_depth, learning_helpers.py:77-86
+        dt = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * dt);
+        ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
+    }
+    P.tgtpack[(size_t)n * hw + idx] = make_float4(t[idx], t[hw + idx], t[2 * hw + idx], ae);
+    {   // source image with its 1-texel zero border (see tap4); edge pixels also write the border texels next to them
+        const int WB = P.W + 2;
+        float4 *sp = P.srcpack + (size_t)n * (P.H + 2) * WB;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        sp[(v + 1) * WB + u + 1] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], ds);
+        if (u == 0) sp[(v + 1) * WB] = zero;
+        if (u == P.W - 1) sp[(v + 1) * WB + P.W + 1] = zero;
+        if (v == 0) { sp[u + 1] = zero; if (u == 0) sp[0] = zero; if (u == P.W - 1) sp[P.W + 1] = zero; }
+        if (v == P.H - 1) {
+            sp[(P.H + 1) * WB + u + 1] = zero;
+            if (u == 0) sp[(P.H + 1) * WB] = zero;
+            if (u == P.W - 1) sp[(P.H + 1) * WB + P.W + 1] = zero;
+        }
+    }
+    P.depth_out[(size_t)n * hw + idx] = dt;
+    if (P.depth_out2) P.depth_out2[(size_t)n * hw + idx] = dt;
+}
+
+// Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69): from the forward pairs'
+// diff / valid maps at the current poses -> one 0/1 selection mask per forward pair (see oracle orc_window_select).
+struct SelectParams {
+    const float *diff, *valid;   // [S*B][H*W] written by k_linearize<MODE_MAPS>
+    const float4 *tgtpack;       // .w = auto_err of the pair
+    float *mask;                 // [S*B][H*W]
+    int B, S, hw, automask;
+};
+
+__global__ __launch_bounds__(256) void k_select(SelectParams P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (idx >= P.hw) return;
+    int smin = 0;
+    float dmin = 0.f, amin = 0.f, vany = 0.f;
+    for (int s = 0; s < P.S; s++) {
+        const size_t o = (size_t)(s * P.B + b) * P.hw + idx;
+        const float d = P.diff[o], a = P.tgtpack[o].w, v = P.valid[o];
+        if (s == 0 || d < dmin) { dmin = d; smin = s; }      // first minimum, like torch.min
+        amin = (s == 0) ? a : fminf(amin, a);
+        vany = fmaxf(vany, v);
+    }
+    const bool keep = vany > 0.f && (!P.automask || dmin < amin);
+    for (int s = 0; s < P.S; s++) P.mask[(size_t)(s * P.B + b) * P.hw + idx] = (keep && s == smin) ? 1.f : 0.f;
+}
+
+// SSIM_Loss.forward, losses.py:27-41, on C planes of N images: x, y [N*C, H, W] -> out (same shape)
+__global__ __launch_bounds__(256) void k_ssim(const float *x, const float *y, float *out, int H, int W) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int hw = H * W;
+    if (idx >= hw) return;
+    int v = idx / W, u = idx - v * W;
+    const float *xc = x + (size_t)blockIdx.y * hw, *yc = y + (size_t)blockIdx.y * hw;
+    float x0 = xc[idx], y0 = yc[idx];
+    float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+    for (int dv = -1; dv <= 1; dv++)
+        for (int du = -1; du <= 1; du++) {
+            int j = refl_idx(v + dv, H) * W + refl_idx(u + du, W);
+            float a = xc[j] - x0, b = yc[j] - y0;
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+    const float n9 = 1.f / 9.f;
+    float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
+    float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
+    float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
+    float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+    out[(size_t)blockIdx.y * hw + idx] = clamp01((1.f - n / d) * 0.5f);
+}
+
+__global__ void k_disp_to_depth(const float *disp, float *scaled, float *depth, long long n, float min_disp, float max_disp) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = min_disp + (max_disp - min_disp) * disp[i];
+    if (scaled) scaled[i] = s;
+    if (depth) depth[i] = 1.f / s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_warp: inverse_warp2 drop-in on planar inputs
+struct WarpParams {
+    const float *src, *depth_t, *depth_s;
+    const PairConst *pc;
+    float *rec, *valid, *pd, *cd;
+    const float *tgt;   // optional: with posenet_in, the target image to be masked by the warp validity
+    float *posenet_in;  // optional [N,6,H,W]: (tgt * valid, img_rec) = the next PoseNet input of solve_pose_iteratively
+    int H, W;           //                     (train_mono.py:74-76), written by the warp itself: no extra HBM round trip
+    int win_B, win_S;   // window form (win_B > 0): tgt [B,3,H,W], src [S,B,3,H,W], depth_t [B,1,H,W], depth_s [S,B,1,H,W]; pair n as in k_pack
+    WinOff win_off;
+};
+
+__device__ __forceinline__ float tap1(const float *__restrict__ img, int W, int H, int ui, int vi, float rx, float ry, bool oob) {
+    float fx = floorf(rx), fy = floorf(ry);
+    float wx = rx - fx, wy = ry - fy;
+    int xi = ui + (int)fx, yi = vi + (int)fy;
+    bool x0in = (xi >= 0) && (xi < W), x1in = (xi >= -1) && (xi < W - 1);
+    bool y0in = (yi >= 0) && (yi < H), y1in = (yi >= -1) && (yi < H - 1);
+    int x0 = min(max(xi, 0), W - 1), x1 = min(max(xi + 1, 0), W - 1);
+    int y0 = min(max(yi, 0), H - 1), y1 = min(max(yi + 1, 0), H - 1);
+    float v00 = (x0in && y0in && !oob) ? img[y0 * W + x0] : 0.f, v01 = (x1in && y0in && !oob) ? img[y0 * W + x1] : 0.f;
+    float v10 = (x0in && y1in && !oob) ? img[y1 * W + x0] : 0.f, v11 = (x1in && y1in && !oob) ? img[y1 * W + x1] : 0.f;
+    return (1.f - wx) * (1.f - wy) * v00 + wx * (1.f - wy) * v01 + (1.f - wx) * wy * v10 + wx * wy * v11;
+}
+
+__global__ __launch_bounds__(256) void k_warp(WarpParams P) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = blockIdx.y;
+    const int hw = P.H * P.W;
+    if (idx >= hw) return;
+    int v = idx / P.W, u = idx - v * P.W;
+    const PairConst &c = P.pc[n];
+    const float *tgt = P.tgt ? P.tgt + (size_t)n * 3 * hw : nullptr, *src = P.src + (size_t)n * 3 * hw;
+    const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
+    if (P.win_B > 0) {   // the directed pairs of a window, formed by indexing (train_mono.py:54-62)
+        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, qi = win_src_image(P.win_off, q, P.win_B);
+        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)qi * 3 * hw;
+        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)qi * hw;
+        tgt = inv ? si : ti; src = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
+    }
+    Geo g;
+    warp_geo(c, P.W, P.H, u, v, dtp[idx], g);
+    const bool oob = g.oobx || g.ooby;
+    if (P.rec)
+        for (int ch = 0; ch < 3; ch++)
+            P.rec[((size_t)n * 3 + ch) * hw + idx] = tap1(src + (size_t)ch * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+    if (P.valid) P.valid[(size_t)n * hw + idx] = oob ? 0.f : 1.f;
+    if (P.posenet_in) {
+        const float vm = oob ? 0.f : 1.f;
+        for (int ch = 0; ch < 3; ch++) {
+            P.posenet_in[((size_t)n * 6 + ch) * hw + idx] = tgt[(size_t)ch * hw + idx] * vm;
+            P.posenet_in[((size_t)n * 6 + 3 + ch) * hw + idx] = tap1(src + (size_t)ch * hw, P.W, P.H, u, v, g.rx, g.ry, oob);
+        }
+    }
+    if (P.pd) P.pd[(size_t)n * hw + idx] = c.es * tap1(dsp, P.W, P.H, u, v, g.rx, g.ry, oob);
+    if (P.cd) P.cd[(size_t)n * hw + idx] = g.Z;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_linearize
+//
+// Workgroup = one TW x TH tile of target pixels of one pair.  Phase 1 warps the tile plus a 1-pixel halo
+// (reflect-mapped at the image border, so the halo IS the ReflectionPad2d of losses.py:22) and stages per pixel
+//   y[3] (warped source), x[3] (target), gx[3], gy[3] (d rec/d ix,iy), a[NP], b[NP] (d ix, d iy / d theta)
+// in LDS as an array of 112-byte records (7 x float4: conflict-free ds_read_b128 for consecutive lanes).
+// Phase 2 evaluates SSIM / L1 / masks and the exact gradient rows for the tile's own pixels from the 3x3 LDS
+// neighbourhood and accumulates J'J and J'r in registers; one wave-reduce + LDS reduce per workgroup, one
+// partial-sum record per workgroup to HBM (deterministic: no atomics).
+
+constexpr int RG = 16;       // workgroups per in-launch reduction group
+constexpr int LDS_REC = 28;  // floats per staged pixel (12 + 2*NP <= 26, padded to 28 for bank spread)
+
+template <int NP>
+struct AccLayout {
+    static constexpr int NH = NP * (NP + 1) / 2;
+    static constexpr int OFF_HP = 0, OFF_GP = NH, OFF_HD = NH + NP, OFF_GD = 2 * NH + NP, OFF_S = 2 * NH + 2 * NP;
+    static constexpr int NACC = 2 * NH + 2 * NP + 3;  // + sum(M W diff), sum(M), sum(dd)
+};
+
+enum { MODE_COST = 0, MODE_LIN = 1, MODE_MAPS = 2 };
+
+// Forced 128-bit LDS accesses.  Left to itself hipcc splits partially-used or register-scattered float4 accesses of the
+// 112-byte records into ds_read2_b64 / ds_write2_b32 / ds_read_b96, whose banking conflicts 2- to 4-way on that stride
+// (PMC: 49 % of LDS cycles were bank-conflict cycles); ds_read_b128 / ds_write_b128 are conflict-free on it.
+// The waits are inside the asm statements because hipcc does not track asm loads (cdna_hip_programming.md section 5.7).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ void lds_read3(const float4 *p, float4 &a, float4 &b, float4 &c) {
+    f32x4 x, y, z;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(lds_addr(p)) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
+__device__ __forceinline__ void lds_read3b(const float4 *p, float4 &a, float4 &b, float4 &c) {  // record floats 12..23
+    f32x4 x, y, z;
+    asm volatile("ds_read_b128 %0, %3 offset:48\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(lds_addr(p)) : "memory");
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_read3v(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c) {   // record floats 0..11
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
+__device__ __forceinline__ void lds_read3bv(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c) {  // record floats 12..23
+    asm volatile("ds_read_b128 %0, %3 offset:48\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
+// a - b on both halves in ONE instruction (hipcc lowers a float2 subtraction to two v_sub_f32)
+__device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void lds_read02v(const float4 *p, f32x4 &a, f32x4 &c) {   // record floats 0..3 and 8..11
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
+__device__ __forceinline__ void lds_read6v(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f) {  // floats 0..23
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                 "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f) : "v"(lds_addr(p)) : "memory");
+}
+__device__ __forceinline__ float4 lds_read1(const float4 *p) {
+    f32x4 x;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(lds_addr(p)) : "memory");
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void lds_write1(float4 *p, float a, float b, float c, float d) {
+    f32x4 x = {a, b, c, d};
+    asm volatile("ds_write_b128 %0, %1" : : "v"(lds_addr(p)), "v"(x) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-channel photometric terms of one pixel from its 3x3 window statistics (centre-shifted sums), written once for
+// T = float and T = float2 (two channels per VALU instruction).
+typedef int i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vsel(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ f2 vsel(i2 c, f2 a, f2 b) { return c ? a : b; }
+__device__ __forceinline__ float vrcp(float a) { return frcp(a); }
+__device__ __forceinline__ f2 vrcp(f2 a) { return (f2){frcp(a.x), frcp(a.y)}; }
+__device__ __forceinline__ float vabs(float a) { return fabsf(a); }
+__device__ __forceinline__ f2 vabs(f2 a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ f2 vmin(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return __builtin_elementwise_max(a, b); }
+template <class T> __device__ __forceinline__ T vsplat(float a);
+template <> __device__ __forceinline__ float vsplat<float>(float a) { return a; }
+template <> __device__ __forceinline__ f2 vsplat<f2>(float a) { return (f2){a, a}; }
+
+template <class T>
+struct ChanTerms {
+    T e1, e2;          // w_l1/3 |y-x|.clamp(0,1),  w_ssim/3 SSIM            (train_mono.py:87, losses.py:27-41)
+    T cA, cB, cC;      // d e2 / d y_q = cA + cB (y_q - y_c) + cC (x_q - x_c)  for the 9 window pixels q
+    T id1, id2;        // curvature weights of the mean / covariance parts of SSIM
+    T l1x, l1y;        // d e1 / d(ix, iy) of the centre sample
+    T lxx, lxy, lyy;   // L1 part of the 2x2 curvature
+};
+
+template <class T>
+__device__ __forceinline__ void ssim_l1_channel(T xc, T yc, T gxc, T gyc, T Sx, T Sy, T Sxx, T Syy, T Sxy, float ws, float wl,
+                                                float eps, ChanTerms<T> &o) {
+    const float n9 = 1.f / 9.f;
+    const T zero = vsplat<T>(0.f), one = vsplat<T>(1.f);
+    T mdx = Sx * n9, mdy = Sy * n9;
+    T mux = xc + mdx, muy = yc + mdy;
+    T sigx = Sxx * n9 - mdx * mdx, sigy = Syy * n9 - mdy * mdy, sigxy = Sxy * n9 - mdx * mdy;
+    T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+    T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+    T idn = vrcp(d1 * d2), ratio = n1 * n2 * idn;
+    T raw = (one - ratio) * 0.5f;
+    auto cl = (raw < zero) || (raw > one);
+    o.e2 = ws * vmin(vmax(raw, zero), one);
+    T pre = vsel(cl, zero, idn * (-0.5f * n9 * ws));
+    o.cB = pre * (ratio * d1) * -2.f;
+    o.cC = pre * n1 * 2.f;
+    o.cA = pre * 2.f * (mux * n2 - ratio * muy * d2) - o.cB * mdy - o.cC * mdx;
+    T wi = vsel(cl, zero, idn * ws);
+    o.id1 = wi * d2; o.id2 = 1.125f * wi * d1;
+    // L1 term
+    T rr = yc - xc, ar = vabs(rr);
+    auto inr = ar <= one;
+    o.e1 = wl * vmin(ar, one);
+    T sgn = vsel(inr, vsel(rr > zero, one, vsel(rr < zero, -one, zero)), zero) * wl;
+    o.l1x = sgn * gxc; o.l1y = sgn * gyc;
+    T w1 = vsel(inr, wl * vrcp(vmax(ar, vsplat<T>(eps))), zero);
+    o.lxx = w1 * gxc * gxc; o.lxy = w1 * gxc * gyc; o.lyy = w1 * gyc * gyc;
+}
+
+// value of the per-channel photometric error only (no gradient coefficients): the residual of ANOTHER source, for the
+// min-over-sources selection
+template <class T>
+__device__ __forceinline__ T ssim_l1_value(T xc, T yc, T Sx, T Sy, T Sxx, T Syy, T Sxy, float ws, float wl) {
+    const float n9 = 1.f / 9.f;
+    const T zero = vsplat<T>(0.f), one = vsplat<T>(1.f);
+    T mdx = Sx * n9, mdy = Sy * n9, mux = xc + mdx, muy = yc + mdy;
+    T sigx = Sxx * n9 - mdx * mdx, sigy = Syy * n9 - mdy * mdy, sigxy = Sxy * n9 - mdx * mdy;
+    T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+    T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+    T raw = (one - n1 * n2 * vrcp(d1 * d2)) * 0.5f;
+    return ws * vmin(vmax(raw, zero), one) + wl * vmin(vabs(yc - xc), one);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup reduction of NLIVE per-thread values -> one record per workgroup -> deterministic in-launch group reduction.
+//   v[]: compacted live values [H photo | g photo | (H dc | g dc) | 3 scalars]; dead accumulators are stored as 0.
+template <int NP, int NLIVE, bool LIN, bool DC, int NT>
+__device__ __forceinline__ void block_reduce_publish(const LinParams &P, const float *v, float *red, int n, int bid, int nblk, int tid) {
+    using L = AccLayout<NP>;
+    constexpr int NPH = L::NH + NP;
+    const int wave = tid >> 6, lane = tid & 63;
+    wave_reduce_store<NLIVE>(v, red + wave * L::NACC, lane);
+    __syncthreads();
+    // A single workgroup can only pull ~6 GB/s of freshly written records (measured: 110 KB = 480 records in 19 us), so the
+    // solve kernel must not read one record per workgroup.  Groups of RG consecutive workgroups reduce themselves: every
+    // workgroup publishes its record, takes a ticket, and the LAST arriver of the group sums the group's records in index
+    // order (fixed order => bit-reproducible, no float atomics) into one group record.
+    // Protocol (cdna_hip_programming.md Guideline 16, counter form): write-through (sc1) record stores -> every storing
+    // wave drains vmcnt -> workgroup barrier -> one relaxed agent-scope ticket; reducer: agent-scope acquire -> drain ->
+    // barrier -> plain loads.  The reducer zeroes the ticket for the next launch (tickets are also zeroed at create
+    // and after a failed call).
+    float *myrec = P.blockrec + ((size_t)n * nblk + bid) * L::NACC;
+    for (int i = tid; i < L::NACC; i += NT) {
+        // accumulator index -> compacted live index (or -1 for a dead accumulator, stored as 0)
+        int li = -1;
+        if (i >= L::OFF_S) li = NLIVE - 3 + (i - L::OFF_S);
+        else if (LIN && (DC || i < NPH)) li = i;
+        float s = 0.f;
+        if (li >= 0)
+            for (int w = 0; w < NT / 64; w++) s += red[w * L::NACC + li];
+        if (P.direct) myrec[i] = s;   // plain store: the kernel boundary publishes it
+        else __hip_atomic_store(&myrec[i], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (P.direct) return;             // wave-uniform: k_solve reads one record per workgroup (a few hundred at most)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    const int grp = bid / RG, gfirst = grp * RG, gcount = min(RG, nblk - gfirst);
+    if (tid == 0) {
+        int t = __hip_atomic_fetch_add(&P.tickets[n * P.ngrp + grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gcount - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const float *grec = P.blockrec + ((size_t)n * nblk + gfirst) * L::NACC;
+    for (int i = tid; i < L::NACC; i += NT) {
+        float w[RG];
+#pragma unroll
+        for (int b = 0; b < RG; b++) w[b] = grec[(size_t)(b < gcount ? b : 0) * L::NACC + i];  // RG UNCONDITIONAL loads in flight
+        float s = 0.f;                                         // (a predicated load makes hipcc branch + vmcnt(0) per element)
+#pragma unroll
+        for (int b = 0; b < RG; b++) s += (b < gcount) ? w[b] : 0.f;   // fixed-order sum
+        P.partials[((size_t)n * P.ngrp + grp) * L::NACC + i] = s;
+    }
+    if (tid == 0) P.tickets[n * P.ngrp + grp] = 0;
+}
+
+// TRACE: the parity-test build of the kernel that records its discrete decisions (tcsfm_debug_trace); a template parameter so that
+// the production instantiation carries none of it (not even the branches: the kernel sits at its 128-VGPR budget)
+template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false>
+__global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
+    constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
+    constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
+    static_assert(NCEN % NT == 0, "tile must be a multiple of the workgroup");
+    using L = AccLayout<NP>;
+    __shared__ float4 lds[NCOMP * (LDS_REC / 4)];
+    __shared__ float red[(NT / 64) * L::NACC];
+
+    // XCD-aware tile order: consecutive workgroups land on different XCDs (round-robin dispatch), so give each
+    // of the 8 XCDs a contiguous band of tiles -> halo / source-texel reuse stays inside one XCD's L2.
+    const int nblk = P.tiles_x * P.tiles_y;
+    int bid = blockIdx.x;
+    {
+        int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = blockIdx.y;
+    const PairConst &c = P.pc[n];
+    const int H = P.H, W = P.W, hw = H * W;
+    const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
+    const int x00 = txi * TW, y00 = tyi * TH;
+    const int img = P.shared_image ? 0 : n;
+    const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
+    const float4 *srcpack = P.srcpack + (size_t)img * (H + 2) * (W + 2);   // zero-bordered (tap4)
+    const float *depth_t = P.depth_t + (size_t)img * hw;
+    const int tid = threadIdx.x;
+    stamp_begin(P.stamp, tid);
+
+    // centre-only values carried in registers from phase 1 to phase 2
+    float c_pd[PPT], c_cd[PPT], c_dgx[PPT], c_dgy[PPT], c_ae[PPT], c_zc[PPT][NP];
+    bool c_valid[PPT], c_in[PPT];
+
+    // ---------------- window mode: the residual of the OTHER sources at this tile (min over sources, optimizer.py:47-69) -------
+    // For a forward pair n = s B + b the other sources of target b are warped with THEIR poses (and their copy of the target
+    // depth), colours only, and their photometric error at the tile's pixels is reduced to four numbers per pixel: the smallest
+    // error among the sources before / after s (torch.min keeps the FIRST minimum), the union of their validity and the
+    // smallest auto-mask threshold.  Same arithmetic as the maps pass + k_select pair it replaces, without the two launches.
+    float sel_before = 3.0e38f, sel_after = 3.0e38f, sel_valid = 0.f, sel_ae = 3.0e38f;
+    const bool sel_pair = SEL && n < P.sel_B * P.sel_S;
+    if (SEL && sel_pair) {
+        const int b_ = n % P.sel_B, s_own = n / P.sel_B;
+        for (int so = 0; so < P.sel_S; so++) {
+            if (so == s_own) continue;
+            const int no = so * P.sel_B + b_;
+            const PairConst &co = P.pc[no];
+            const float4 *tpo = P.tgtpack + (size_t)no * hw, *spo = P.srcpack + (size_t)no * (H + 2) * (W + 2);
+            const float *dto = P.depth_t + (size_t)no * hw;
+            for (int ci = tid; ci < NCOMP; ci += NT) {       // tile + ring, colours only (+ validity and auto-mask threshold)
+                const int ly = ci / CW, lx = ci - ly * CW;
+                const int px = refl_idx(x00 + lx - 1, W), py = refl_idx(y00 + ly - 1, H), gi = py * W + px;
+                const float4 tp = tpo[gi];
+                Geo g;
+                warp_geo(co, W, H, px, py, dto[gi], g);
+                float4 val, gx, gy;
+                tap4(spo, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, val, gx, gy);
+                float4 *rec = lds + ci * (LDS_REC / 4);
+                lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
+                lds_write1(rec + 2, val.z, tp.z, (g.oobx || g.ooby) ? 0.f : 1.f, tp.w);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            {
+                const int cy = tid / TW + 1, cx = tid - (tid / TW) * TW + 1;
+                const float4 *ctr = lds + (cy * CW + cx) * (LDS_REC / 4);
+                f32x4 q0, q2;
+                lds_read02v(ctr, q0, q2);
+                const f2 yc01 = q0.lo, xc01 = q0.hi, yx2c = q2.lo;
+                const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
+                f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f};
+                float Sxy2 = 0.f;
+#pragma unroll 1
+                for (int kk = 0; kk < 9; kk++) {
+                    f32x4 n0, n2;
+                    lds_read02v(nb, n0, n2);
+                    nb += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
+                    f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01), e2v = pk_sub(n2.lo, yx2c);
+                    Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+                    S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
+                }
+                const f2 e01 = ssim_l1_value<f2>(xc01, yc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl);
+                const float d_o = e01.x + e01.y + ssim_l1_value<float>(yx2c.y, yx2c.x, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl);
+                if (so < s_own) sel_before = fminf(sel_before, d_o); else sel_after = fminf(sel_after, d_o);
+                sel_valid = fmaxf(sel_valid, q2.z);
+                sel_ae = fminf(sel_ae, q2.w);
+            }
+            __syncthreads();   // the records are overwritten by the next source / by phase 1
+        }
+    }
+
+    // ---------------- phase 1: warp + stage (centres, and the halo ring on the first waves) ----------------
+    // The NHALO ring pixels are a second pixel for the first NHALO threads.  Those waves run BOTH pixels as one software-
+    // pipelined sequence -- loads of both, then both warps and gather issues, then both interpolations -- so the dependent
+    // load chain (pixel data -> warp -> source gather) of the ring pixel overlaps the centre pixel's instead of following it
+    // while the rest of the workgroup waits at the barrier.
+    constexpr int NHALO = NCOMP - NCEN;
+    static_assert(PPT == 1 && NHALO <= NT, "one centre pixel per thread, one ring round");
+    constexpr int HALO_THREADS = (NHALO + 63) / 64 * 64;   // wave-uniform split
+    struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
+    auto s_load = [&](Stage &S) {
+        S.px = refl_idx(x00 + S.lx - 1, W); S.py = refl_idx(y00 + S.ly - 1, H);
+        const int gi = S.py * W + S.px;
+        S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+    };
+    auto s_warp = [&](Stage &S) {
+        warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
+        tap4_fetch(srcpack, W, H, S.px, S.py, S.g.rx, S.g.ry, S.g.oobx || S.g.ooby, S.t);
+    };
+    auto s_store = [&](Stage &S, bool write, bool centre) {
+        float4 val, gx, gy;
+        tap4_lerp(S.t, val, gx, gy);
+        float a[NP], b[NP], zc[NP];
+        if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
+        float4 *rec = lds + (S.ly * CW + S.lx) * (LDS_REC / 4);
+        // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0..a3][a4 a5 b0 b1][b2..b5]([a6 b6 - -]) : channel pairs and
+        // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles
+        if (write) {
+            lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
+            if (MODE == MODE_LIN) {
+                lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+                lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
+                lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
+                lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
+                lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
+                if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
+            } else {
+                lds_write1(rec + 2, val.z, S.tp.z, 0.f, 0.f);
+            }
+        }
+        if (centre) {
+            c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
+            if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && c_in[0])    // bilinear cell parity now, mask / validity bits in phase 2
+                P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
+                    (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
+            c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
+            c_ae[0] = S.tp.w; c_valid[0] = !(S.g.oobx || S.g.ooby);
+            if (MODE == MODE_LIN) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) c_zc[0][j] = zc[j];
+            }
+        }
+    };
+    {
+        Stage A;
+        A.ly = tid / TW + 1; A.lx = tid - (tid / TW) * TW + 1;
+        if (tid < HALO_THREADS) {
+            Stage B;
+            const int hi = min(tid, NHALO - 1);   // ring enumeration: top row, bottom row, then left/right columns
+            if (hi < CW) { B.ly = 0; B.lx = hi; }
+            else if (hi < 2 * CW) { B.ly = CH - 1; B.lx = hi - CW; }
+            else { const int k = hi - 2 * CW; B.ly = 1 + (k >> 1); B.lx = (k & 1) ? CW - 1 : 0; }
+            s_load(A); s_load(B);
+            s_warp(A); s_warp(B);
+            s_store(A, true, true); s_store(B, tid < NHALO, false);
+        } else {
+            s_load(A); s_warp(A); s_store(A, true, true);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm LDS writes above are invisible to hipcc's own waitcnt tracking
+    __syncthreads();
+
+    // ---------------- phase 2: residuals, gradient rows, curvature, accumulation ----------------
+    // Packed fp32 throughout: channels (0,1) travel as one f2, channel 2 shares an f2 with its partner quantity, Jacobian
+    // columns travel as pairs (01)(23)(45).  H is accumulated as 12 (+4 for NP=7) row-pair f2's: rows j, column pairs p <= j/2.
+    constexpr int NHP = (NP == 6) ? 12 : 16;     // f2 accumulators of the lower triangle (some upper entries ride along)
+    f2 aH2[NHP], aG2[3], dH2[DC ? NHP : 1], dG2[DC ? 3 : 1];
+    float aH66 = 0.f, aG6 = 0.f, dH66 = 0.f, dG6 = 0.f;   // NP == 7: the (6,6) entry and g[6]
+    float sMWd = 0.f, sM = 0.f, sdd = 0.f;
+#pragma unroll
+    for (int i = 0; i < NHP; i++) { aH2[i] = (f2){0.f, 0.f}; if (DC) dH2[i] = (f2){0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { aG2[i] = (f2){0.f, 0.f}; if (DC) dG2[i] = (f2){0.f, 0.f}; }
+
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        int ci = tid + k * NT;
+        int ly = ci / TW + 1, lx = ci - (ci / TW) * TW + 1;
+        const float4 *ctr = lds + (ly * CW + lx) * (LDS_REC / 4);
+        f32x4 q0, q1 = {0.f, 0.f, 0.f, 0.f}, q2;
+        if (MODE == MODE_LIN) lds_read3v(ctr, q0, q1, q2);
+        else lds_read02v(ctr, q0, q2);               // the gradient part of the records is only staged for linearisations
+        const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = q1.lo, gyc01 = q1.hi, yx2c = q2.lo, g2c = q2.hi;
+        const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
+        const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
+
+        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances) + gradient window
+        // sums.  Rolled (one neighbour live at a time); 14 packed instructions per neighbour.
+        // neighbour pointer walks the 3x3 window with ONE vector add per step (the step is wave-uniform).  The first neighbour
+        // is peeled: it INITIALISES the accumulators (no zero-fill instructions), the loop adds the other eight.  Only the
+        // colour part of the records is read here (32 of their 112 bytes): the neighbour passes are LDS-bandwidth limited, and
+        // the gradient window sums the curvature needs are gathered in pass B, which reads the gradients anyway.
+        const float4 *nbA = ctr - (CW + 1) * (LDS_REC / 4);
+        f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, S2, SS2;
+        float Sxy2;
+        {
+            f32x4 n0, n2;
+            lds_read02v(nbA, n0, n2);
+            nbA += LDS_REC / 4;
+            Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
+            Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
+            S2 = pk_sub(n2.lo, yx2c);            // (y2 - y2c, x2 - x2c)
+            SS2 = S2 * S2; Sxy2 = S2.x * S2.y;
+        }
+#pragma unroll 1
+        for (int kk = 1; kk < 9; kk++) {
+            f32x4 n0, n2;
+            lds_read02v(nbA, n0, n2);
+            nbA += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
+            f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+            Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+            f2 e2v = pk_sub(n2.lo, yx2c);
+            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
+        }
+        // per-channel SSIM value / gradient coefficients / curvature weights and the L1 term: channels (0,1) as one packed
+        // evaluation, channel 2 as a scalar one (same code, ssim_l1_channel<T>)
+        ChanTerms<f2> t01;
+        ChanTerms<float> t2;
+        ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
+        ssim_l1_channel<float>(yx2c.y, yx2c.x, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+        const float cA[3] = {t01.cA.x, t01.cA.y, t2.cA}, cB[3] = {t01.cB.x, t01.cB.y, t2.cB}, cC[3] = {t01.cC.x, t01.cC.y, t2.cC};
+        const float e1 = t01.e1.x + t01.e1.y + t2.e1, e2 = t01.e2.x + t01.e2.y + t2.e2;
+        const float l1x = t01.l1x.x + t01.l1x.y + t2.l1x, l1y = t01.l1y.x + t01.l1y.y + t2.l1y;
+        float lxx = t01.lxx.x + t01.lxx.y + t2.lxx, lxy = t01.lxy.x + t01.lxy.y + t2.lxy, lyy = t01.lyy.x + t01.lyy.y + t2.lyy;
+        float diff = e1 + e2;
+
+        f2 de2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // d(e2)/d theta, column pairs (01)(23)(45)
+        float de6 = 0.f;
+        if (MODE == MODE_LIN) {
+            // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
+            const f2 cA01 = {cA[0], cA[1]}, cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
+            f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, G2 = {0.f, 0.f};   // 3x3 sums of the image gradients (curvature model)
+            const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
+#pragma unroll 1
+            for (int kk = 0; kk < 9; kk++) {
+                f32x4 n0, n1, n2, n3, n4, n5;
+                lds_read6v(nb, n0, n1, n2, n3, n4, n5);   // one LDS round trip per neighbour
+                Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
+                f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+                f2 cf = cA01 + cB01 * ey + cC01 * ex;
+                f2 e2v = pk_sub(n2.lo, yx2c);
+                float cf2 = cA[2] + cB[2] * e2v.x + cC[2] * e2v.y;
+                f2 tx = cf * n1.lo, ty = cf * n1.hi;
+                float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
+                de2[0] += sx * n3.lo; de2[0] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
+                de2[1] += sx * n3.hi; de2[1] += sy * n5.lo;
+                de2[2] += sx * n4.lo; de2[2] += sy * n5.hi;
+                if (NP == 7) { float4 n6 = lds_read1(nb + 6); de6 += sx * n6.x + sy * n6.y; }
+                nb += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
+            }
+            {   // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1, Cov ~ 9/8 (g - mean)(g - mean)' (centre sample)
+                const float n9 = 1.f / 9.f;
+                const f2 mx = Gx01 * n9, my = Gy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+                const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
+                         qyy = t01.id2 * ey * ey + t01.id1 * my * my;
+                const float mx2 = G2.x * n9, my2 = G2.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
+                lxx += qxx.x + qxx.y + t2.id2 * ex2 * ex2 + t2.id1 * mx2 * mx2;
+                lxy += qxy.x + qxy.y + t2.id2 * ex2 * ey2 + t2.id1 * mx2 * my2;
+                lyy += qyy.x + qyy.y + t2.id2 * ey2 * ey2 + t2.id1 * my2 * my2;
+            }
+        }
+
+        // depth consistency, train_mono.py:91-92
+        float cd = c_cd[k], pd = c_pd[k];
+        float sum = cd + pd, dif = cd - pd, isum = frcp(sum);
+        float raw = fabsf(dif) * isum;
+        float dd = clamp01(raw), Wt = 1.f - dd;
+        bool inimg = c_in[k];
+        bool m = inimg && c_valid[k] && (!P.automask || diff < c_ae[k]);
+        if (SEL && sel_pair) {   // keep the pixel for the source with the smallest error (first minimum), under the union
+                                 // validity and the auto-mask of the minima
+            const float dmin = fminf(diff, fminf(sel_before, sel_after));
+            const bool keep = (c_valid[k] || sel_valid > 0.f) && (!P.automask || dmin < fminf(c_ae[k], sel_ae));
+            m = inimg && keep && (diff < sel_before) && (diff <= sel_after);
+        }
+
+        if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
+            unsigned short *tb = P.trace + (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);   // (this thread's own phase-1 word)
+            *tb = (unsigned short)(*tb | (m ? 1 : 0) | (c_valid[k] ? 2 : 0) | (sign_code(dif) << 4) | (sign_code(yc[0] - xc[0]) << 6) |
+                                   (sign_code(yc[1] - xc[1]) << 8) | (sign_code(yc[2] - xc[2]) << 10));
+        }
+
+        if (MODE == MODE_MAPS) {
+            if (inimg) {
+                size_t o = (size_t)n * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
+                if (P.o_diff) P.o_diff[o] = diff;
+                if (P.o_valid) P.o_valid[o] = c_valid[k] ? 1.f : 0.f;
+                if (P.o_weight) P.o_weight[o] = Wt;
+                if (P.o_auto_err) P.o_auto_err[o] = c_ae[k];
+                if (P.o_auto_mask) P.o_auto_mask[o] = diff < c_ae[k] ? 1.f : 0.f;
+                if (P.o_rec) {
+                    size_t o3 = (size_t)n * 3 * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
+                    P.o_rec[o3] = yc[0]; P.o_rec[o3 + hw] = yc[1]; P.o_rec[o3 + 2 * hw] = yc[2];
+                }
+            }
+            continue;
+        }
+
+        if (inimg) sdd += dd;
+        if (m) { sMWd += Wt * diff; sM += 1.f; }
+        if (MODE == MODE_LIN) {
+            // own geometric Jacobian (centre record), as column pairs
+            f32x4 q3, q4, q5;
+            lds_read3bv(ctr, q3, q4, q5);
+            const f2 a2[3] = {q3.lo, q3.hi, q4.lo}, b2[3] = {q4.hi, q5.lo, q5.hi};
+            float a6 = 0.f, b6 = 0.f;
+            if (NP == 7) { float4 q6 = lds_read1(ctr + 6); a6 = q6.x; b6 = q6.y; }
+            float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
+            float kdd = sg * 2.f * isum * isum;
+            float mf = m ? 1.f : 0.f;
+            const float wxx = mf * Wt * lxx, wxy = mf * Wt * lxy, wyy = mf * Wt * lyy;
+            f2 ddJ2[3], la2[3], lb2[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const f2 zc2 = {c_zc[k][2 * p], c_zc[k][2 * p + 1]};
+                f2 dpd = c_dgx[k] * a2[p] + c_dgy[k] * b2[p];
+                ddJ2[p] = kdd * (pd * zc2 - cd * dpd);
+                f2 row = Wt * (de2[p] + l1x * a2[p] + l1y * b2[p]) - diff * ddJ2[p];   // d(W (e1+e2))/d theta
+                aG2[p] += mf * row;
+                la2[p] = wxx * a2[p] + wxy * b2[p];
+                lb2[p] = wxy * a2[p] + wyy * b2[p];
+            }
+            float ddJ6 = 0.f, la6 = 0.f, lb6 = 0.f;
+            if (NP == 7) {
+                float dpd = c_dgx[k] * a6 + c_dgy[k] * b6 + pd;
+                ddJ6 = kdd * (pd * c_zc[k][NP - 1] - cd * dpd);
+                aG6 += mf * (Wt * (de6 + l1x * a6 + l1y * b6) - diff * ddJ6);
+                la6 = wxx * a6 + wxy * b6; lb6 = wxy * a6 + wyy * b6;
+            }
+            // H row j (scalar la_j, lb_j) x column pairs p <= j/2
+            {
+                int h = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const float la = (j & 1) ? la2[j >> 1].y : la2[j >> 1].x, lb = (j & 1) ? lb2[j >> 1].y : lb2[j >> 1].x;
+#pragma unroll
+                    for (int p = 0; p <= (j >> 1); p++) { aH2[h] += la * a2[p]; aH2[h] += lb * b2[p]; h++; }
+                }
+                if (NP == 7) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { aH2[h] += la6 * a2[p]; aH2[h] += lb6 * b2[p]; h++; }
+                    aH66 += la6 * a6 + lb6 * b6;
+                }
+            }
+            if (DC) {
+                // IRLS curvature 1/max(dd,eps); the gradient is Huberised inside dd < eps (sign(cd-pd) is rounding noise there)
+                float k3 = inimg ? frcp(fmaxf(dd, P.eps)) : 0.f, inf = inimg ? fminf(1.f, dd * frcp(P.eps)) : 0.f;
+                int h = 0;
+#pragma unroll
+                for (int p = 0; p < 3; p++) dG2[p] += inf * ddJ2[p];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const float kj = k3 * ((j & 1) ? ddJ2[j >> 1].y : ddJ2[j >> 1].x);
+#pragma unroll
+                    for (int p = 0; p <= (j >> 1); p++) { dH2[h] += kj * ddJ2[p]; h++; }
+                }
+                if (NP == 7) {
+                    dG6 += inf * ddJ6;
+                    const float kj = k3 * ddJ6;
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { dH2[h] += kj * ddJ2[p]; h++; }
+                    dH66 += kj * ddJ6;
+                }
+            }
+        }
+    }
+    if (MODE == MODE_MAPS) { stamp_end(P.stamp, tid); return; }
+
+    // unpack the row-pair accumulators into the triangular layout the reduction / solve kernel use
+    float aHP[L::NH], aGP[NP], aHD[DC ? L::NH : 1], aGD[DC ? NP : 1];
+    {
+        int h2 = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int npair = (j == 6) ? 3 : (j >> 1) + 1;
+#pragma unroll
+            for (int i = 0; i <= j; i++) {
+                float vp = 0.f, vd = 0.f;
+                if (i < 6) {
+                    vp = (i & 1) ? aH2[h2 + (i >> 1)].y : aH2[h2 + (i >> 1)].x;
+                    if (DC) vd = (i & 1) ? dH2[h2 + (i >> 1)].y : dH2[h2 + (i >> 1)].x;
+                } else { vp = aH66; vd = dH66; }
+                aHP[j * (j + 1) / 2 + i] = vp;
+                if (DC) aHD[j * (j + 1) / 2 + i] = vd;
+            }
+            h2 += npair;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            aGP[j] = (j & 1) ? aG2[j >> 1].y : aG2[j >> 1].x;
+            if (DC) aGD[j] = (j & 1) ? dG2[j >> 1].y : dG2[j >> 1].x;
+        }
+        if (NP == 7) { aGP[NP - 1] = aG6; if (DC) aGD[NP - 1] = dG6; }
+    }
+
+    // ---------------- workgroup reduction -> group record (shared with the dense kernel) ----------------
+    {
+        constexpr int NPH = L::NH + NP;
+        constexpr int NLIVE = (MODE == MODE_LIN) ? (DC ? L::NACC : NPH + 3) : 3;
+        float v[NLIVE];
+        if (MODE == MODE_LIN) {
+#pragma unroll
+            for (int i = 0; i < L::NH; i++) v[i] = aHP[i];
+#pragma unroll
+            for (int i = 0; i < NP; i++) v[L::NH + i] = aGP[i];
+            if (DC) {
+#pragma unroll
+                for (int i = 0; i < L::NH; i++) v[NPH + i] = aHD[i];
+#pragma unroll
+                for (int i = 0; i < NP; i++) v[NPH + L::NH + i] = aGD[i];
+            }
+        }
+        v[NLIVE - 3] = sMWd; v[NLIVE - 2] = sM; v[NLIVE - 1] = sdd;
+        block_reduce_publish<NP, NLIVE, (MODE == MODE_LIN), DC, NT>(P, v, red, n, bid, nblk, tid);
+    }
+    stamp_end(P.stamp, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_init / k_solve / k_finish (fp64 per-pair logic; mirrors oracle/tcsfm_oracle.c orc_refine)
+
+struct SolveParams {
+    const float *partials;  // [N][ngrp][nacc] group records
+    PairState *st;
+    PairConst *pc;
+    float *stats;           // [N][n_iters+1][TCSFM_NSTAT] or null
+    double *lin_out;        // linearize debug: [N][np*np + np + 4] or null
+    int ngrp, nacc, np, has_dc;
+    int it, n_iters, solver, param, mode;  // mode 0: iteration step, 1: final LM cost check, 2: export only
+    double b_dc;            // w_dc / (H W)
+    double lambda_up, lambda_down, lambda_min;
+    double prior_scale;     // weight of (log_scale - s0)^2 (np == 7)
+    int shared_image;
+    float *pose_out, *log_scale_out;  // written by the last launch of a refine call (null otherwise)
+    long long *dbg;                   // diagnostic builds only: s_memrealtime stamps of the solve phases (null in production)
+    double *delta_out;                // dense mode: [N][8] pose increment of this iteration for k_dense_update (else null)
+    int *accept_out;                  // dense LM: [N] 1 = this launch accepted the trial (mode 0) / kept the last step (mode 1)
+    int *trace_decide;                // tcsfm_debug_trace: [N] the same decision of THIS launch, or null
+};
+
+// fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
+// inverse-trig keeps ~1e-7 relative accuracy and stays off the fp64 serial path
+__device__ inline void T_to_pose_f32(const double *T, float *pose) {
+    const float sbr = (float)T[2];
+    float sb = sbr < -1.f ? -1.f : (sbr > 1.f ? 1.f : sbr);   // (comparisons, not fminf / fmaxf: a NaN pose must stay NaN in every component)
+    pose[0] = (float)-T[3]; pose[1] = (float)-T[7]; pose[2] = (float)-T[11];
+    pose[3] = -atan2f((float)-T[6], (float)T[10]);
+    pose[4] = -asinf(sb);
+    pose[5] = -atan2f((float)-T[1], (float)T[0]);
+}
+
+// One workgroup per pair.
+//   1. all 256 threads: deterministic fp64 reduction of the workgroup partial records -> tot[] (LDS)
+//   2. wave 0, one lane per entry of the augmented 8x8 system [H | -g]: assembly, LM accept/reject bookkeeping,
+//      Marquardt damping and an unpivoted Gauss-Jordan elimination (SPD system) with 3 cross-lane reads per pivot
+//   3. lane 0: SE(3) retraction (series exp, no trig), next iteration's fp32 constants, pose output
+// The per-pair logic mirrors orc_refine() of the CPU oracle (which factorises with Cholesky instead).
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
+    using L = AccLayout<NP>;
+    constexpr int NPH = L::NH + NP;
+    __shared__ double tot[L::NACC];
+    __shared__ double part[256];
+    __shared__ double ws[3 * NP * NP];
+    __shared__ double dl[8];
+    __shared__ double eul[NP * NP + NP];
+    __shared__ double Ts[40];
+    constexpr int NST = (int)(sizeof(PairState) / sizeof(double));
+    static_assert(sizeof(PairState) % sizeof(double) == 0 && NST <= 256, "PairState must be a whole number of doubles");
+    __shared__ double sst[NST];
+    const int n = blockIdx.x, tid = threadIdx.x;
+#define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
+    TC_STAMP(0)
+    // the pair's optimiser state is fetched NOW, together with the partial records, so that the serial phases below never
+    // wait on a global load (each first touch used to cost a miss in the middle of the dependent chain)
+    if (tid < NST) sst[tid] = reinterpret_cast<const double *>(&P.st[n])[tid];
+    {
+        // Deterministic fp64 reduction of the pair's P.ngrp partial records (group records, or one record per workgroup in
+        // direct mode).  Only the live accumulators are read; they are spread over 256 threads as (accumulator, record
+        // subset) so that ALL loads of a thread are in flight before its first add -- the records were written by other CUs,
+        // every load is a miss (~0.4 us each if serialised; a predicated load compiles to branch + vmcnt(0) per element).
+        const int nlive = P.has_dc ? L::NACC : NPH + 3;
+        const int apad = nlive <= 32 ? 32 : (nlive <= 64 ? 64 : 128), parts = 256 / apad;
+        const int c = tid & (apad - 1), q = tid / apad;
+        const int acc = (P.has_dc || c < NPH) ? c : L::OFF_S + (c - NPH);   // compact live index -> accumulator
+        if (tid < L::NACC) tot[tid] = 0.0;
+        double s = 0.0;
+        if (c < nlive) {
+            const float *p = P.partials + (size_t)n * P.ngrp * L::NACC + acc;
+            for (int r0 = q; r0 < P.ngrp; r0 += 32 * parts) {
+                float v[32];
+#pragma unroll
+                for (int j = 0; j < 32; j++) { const int r = r0 + j * parts; v[j] = p[(size_t)(r < P.ngrp ? r : 0) * L::NACC]; }
+#pragma unroll
+                for (int j = 0; j < 32; j++) s += (r0 + j * parts < P.ngrp) ? (double)v[j] : 0.0;
+            }
+        }
+        part[tid] = s;
+        __syncthreads();
+        if (q == 0 && c < nlive) {
+            double t = 0.0;
+            for (int k = 0; k < parts; k++) t += part[k * apad + c];   // fixed order
+            tot[acc] = t;
+        }
+    }
+    __syncthreads();
+    TC_STAMP(1)
+    if (tid >= 64) return;  // wave 0 only from here: no workgroup barriers below
+
+    PairState &S = P.st[n];                                        // global: writes (the next launch reads them)
+    const PairState &Lc = *reinterpret_cast<const PairState *>(sst);  // LDS copy taken at kernel start: reads
+    const int r = tid >> 3, c = tid & 7;
+    const double nmask = tot[L::OFF_S + 1];
+    const double an = nmask > 0 ? rcp64(nmask) : 0.0;
+    const double cost_photo = an * tot[L::OFF_S], cost_dc = P.b_dc * tot[L::OFF_S + 2];
+    double cost = cost_photo + cost_dc;
+    const double bdc = P.has_dc ? P.b_dc : 0.0;
+    // this lane's entry of [H | -g]
+    double M = 0.0;
+    if (r < NP && c < NP) {
+        const int hi = r > c ? r : c, lo = r > c ? c : r, h = hi * (hi + 1) / 2 + lo;
+        M = an * tot[L::OFF_HP + h] + bdc * tot[L::OFF_HD + h];
+    } else if (r < NP && c == 7) {
+        M = -(an * tot[L::OFF_GP + r] + bdc * tot[L::OFF_GD + r]);
+    }
+    if (NP == 7 && P.mode != 2) {  // scale prior (not part of the exported raw normal equations)
+        const double ds = Lc.stry - Lc.s0;
+        cost += P.prior_scale * ds * ds;
+        if (r == 6 && c == 6) M += 2.0 * P.prior_scale;
+        if (r == 6 && c == 7) M -= 2.0 * P.prior_scale * ds;
+    }
+    if (P.mode == 2) {  // export for tcsfm_linearize / tcsfm_loss_surface
+        double *o = P.lin_out + (size_t)n * (NP * NP + NP + 4);
+        if (r < NP && c < NP) o[r * NP + c] = M;
+        if (r < NP && c == 7) o[NP * NP + r] = -M;
+        if (tid == 0) { o[NP * NP + NP] = cost; o[NP * NP + NP + 1] = cost_photo; o[NP * NP + NP + 2] = cost_dc; o[NP * NP + NP + 3] = nmask; }
+        return;
+    }
+    double lambda = Lc.lambda;
+    if (P.stats && tid == 0) {
+        float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * TCSFM_NSTAT;
+        st[0] = (float)cost; st[1] = (float)cost_photo; st[2] = (float)nmask; st[3] = (float)lambda;
+        T_to_pose_f32(Lc.Ttry, st + TCSFM_STAT_POSE);   // the iterate this linearisation was evaluated at
+    }
+    // Ts (LDS): [0..11] exp(delta), [12..23] the accepted transform, [24..35] the new trial transform, [36] its log scale
+    bool final_pose = false;
+    const double *Tfin = Ts + 24;
+    double sfin = 0.0;
+    if (P.mode == 1) {  // LM: keep the last step only if it lowered the cost
+        const bool keep = cost < Lc.cost_cur;
+        if (P.accept_out && tid == 0) P.accept_out[n] = keep ? 1 : 0;
+        if (P.trace_decide && tid == 0) P.trace_decide[n] = keep ? 1 : 0;
+        if (tid < 12) { const double v = keep ? Lc.Ttry[tid] : Lc.Tcur[tid]; Ts[24 + tid] = v; if (keep) S.Tcur[tid] = v; }
+        sfin = keep ? Lc.stry : Lc.scur;
+        if (tid == 0 && keep) S.scur = sfin;
+        final_pose = true;
+    } else {
+        const bool accept = (P.solver == 0) || !Lc.have_cur || (cost < Lc.cost_cur);  // wave-uniform
+        if (accept) {
+            if (P.solver == 1 && Lc.have_cur) lambda = fmax(lambda * P.lambda_down, P.lambda_min);
+            S.M8[tid] = M;
+        } else {
+            lambda *= P.lambda_up;
+            M = Lc.M8[tid];
+        }
+        if (P.param != 0) {   // undamped system in dense NP x NP form for the additive-Euler branch below
+            if (r < NP && c < NP) eul[r * NP + c] = M;
+            if (r < NP && c == 7) eul[NP * NP + r] = -M;
+        }
+        TC_STAMP(2)
+        // Marquardt damping, then Gauss-Jordan on [H + lambda diag(H) + 1e-12 I | -g]
+        if (r == c && r < NP) M += lambda * M + 1e-12;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const double piv = __shfl(M, k * 8 + k, 64);
+            const double rowv = __shfl(M, k * 8 + c, 64);
+            const double colv = __shfl(M, r * 8 + k, 64);
+            ok = ok && (piv > 0.0);
+            const double f = colv * rcp64(piv);
+            if (r != k) M -= f * rowv;
+        }
+        const double diag = __shfl(M, r * 8 + r, 64);
+        if (c == 7 && r < NP) dl[r] = ok ? M * rcp64(diag) : 0.0;
+        const double sc = accept ? Lc.stry : Lc.scur;
+        if (tid < 12) { const double v = accept ? Lc.Ttry[tid] : Lc.Tcur[tid]; Ts[12 + tid] = v; if (accept) S.Tcur[tid] = v; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): dl[] / Ts[] written before they are read (single wave)
+        __builtin_amdgcn_wave_barrier();
+        TC_STAMP(3)
+        if (tid == 0) {   // serial part: bookkeeping and the exponential of the step
+            if (P.accept_out) P.accept_out[n] = accept ? 1 : 0;
+            if (P.trace_decide) P.trace_decide[n] = accept ? 1 : 0;
+            if (accept) { S.scur = sc; S.cost_cur = cost; S.have_cur = 1; }
+            S.lambda = lambda;
+            if (P.delta_out)
+                for (int i = 0; i < NP; i++) P.delta_out[n * 8 + i] = dl[i];
+            if (P.param == 0) {
+                double d6[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) d6[i] = dl[i];
+                se3_exp(d6, Ts);
+                Ts[36] = sc + (NP == 7 ? dl[NP - 1] : 0.0);
+            } else {
+                // additive Euler parameterisation: re-solve in pose coordinates from the undamped system (rare path, serial;
+                // everything stays in LDS so that this branch does not set the register budget of the kernel)
+                double stry;
+                apply_step<NP>(1, eul, eul + NP * NP, lambda, Ts + 12, sc, Ts + 24, &stry, ws);
+                Ts[36] = stry;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (P.param == 0 && tid < 12) {   // T_try = exp(delta) T_accepted, one entry per lane (se3_mul's operation order)
+            const int i = tid >> 2, j = tid & 3;
+            double v = Ts[4 * i] * Ts[12 + j] + Ts[4 * i + 1] * Ts[16 + j] + Ts[4 * i + 2] * Ts[20 + j];
+            if (j == 3) v += Ts[4 * i + 3];
+            Ts[24 + tid] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        TC_STAMP(4)
+        const double stry = Ts[36];
+        const bool last_gn = (P.solver == 0 && P.it == P.n_iters - 1);   // GN: the last step is always taken
+        if (tid < 12) { const double v = Ts[24 + tid]; S.Ttry[tid] = v; if (last_gn) S.Tcur[tid] = v; }
+        if (tid == 0) { S.stry = stry; if (last_gn) S.scur = stry; }
+        write_const_lanes<NP>(tid, Lc.K, Ts + 24, stry, P.pc[n]);
+        TC_STAMP(5)
+        final_pose = last_gn;
+        sfin = stry;
+    }
+    if (final_pose && P.pose_out && tid == 0) {  // last launch of a refine call: emit the reference 6-vector
+        float pose[6];
+        T_to_pose_f32(Tfin, pose);
+#pragma unroll
+        for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
+        if (P.log_scale_out) P.log_scale_out[n] = (float)sfin;
+        if (P.stats && P.mode == 0) {                  // GN: last row = final iterate (its cost is not evaluated)
+            float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;
+#pragma unroll
+            for (int i = 0; i < 6; i++) st[i] = pose[i];
+        }
+    }
+    TC_STAMP(6)
+#undef TC_STAMP
+}
+
+// dense sequence calls: the refined depth maps of one call, stacked [pair index j][window b] by the window form, into the caller's
+// per-window order [window b][pair index j]
+__global__ __launch_bounds__(256) void k_maps_to_window_order(const float *__restrict__ src, float *__restrict__ dst, int nbw, int N, int hw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;      // m = j * nbw + b
+    if (i >= hw) return;
+    const int j = m / nbw, b = m - j * nbw;
+    dst[((size_t)b * N + j) * hw + i] = src[(size_t)m * hw + i];
+}
+
+struct FinishParams {
+    const PairState *st;
+    float *pose_out, *log_scale_out;
+    int N;
+};
+
+__global__ void k_finish(FinishParams P) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= P.N) return;
+    double pose[6];
+    T_to_pose(P.st[n].Tcur, pose);
+    for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = (float)pose[i];
+    if (P.log_scale_out) P.log_scale_out[n] = (float)P.st[n].scur;
+}
+
+}  // namespace tc

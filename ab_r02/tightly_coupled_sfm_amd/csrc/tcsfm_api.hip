@@ -11,7 +11,6 @@
 #include "../../include/tcsfm.h"
 #include "kernels.h"
 #include "dense_kernel.h"
-#include "joint_kernel.h"
 #include "scale_kernel.h"
 #include "posenet_kernel.h"
 
@@ -49,13 +48,6 @@ struct tcsfm_ctx {
     float *dense_rec_acc = nullptr, *depth_acc = nullptr;   // dense LM: accepted per-pixel records / depth maps
     int *lm_accept = nullptr;
     double *delta = nullptr;
-    // joint dense mode (one depth map per target shared by its S forward pairs): per-pixel records, workgroup records, per-target state
-    float *jrec = nullptr, *jrec_acc = nullptr, *jblockrec = nullptr, *jdepth_acc = nullptr;
-    JointState *jstate = nullptr;
-    double *jdelta = nullptr;
-    int jrec_S = 0;
-    hipStream_t aux_stream = nullptr;  // joint dense mode: the inverse pairs' refinement runs beside the forward group's (fork / join by events)
-    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     float *sel_maps = nullptr;   // window mode scratch: diff | valid | selection mask, [3][max_pairs][H*W], allocated on first use
     unsigned *scale_keys = nullptr, *scale_hist = nullptr;   // scale recovery scratch (keys, 256 bins + 4 state words)
     long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
@@ -73,17 +65,13 @@ struct tcsfm_ctx {
     // tcsfm_refine_sequence: device ring of frames, copy stream, per-slot / per-window events, pose staging (allocated on first use)
     float *seq_img = nullptr, *seq_depth = nullptr, *seq_pose_in = nullptr, *seq_pose_out = nullptr, *seq_ls_out = nullptr, *seq_K = nullptr;
     int seq_slots = 0, seq_K_n = 0;    // ring slots + mirror slots allocated; copies of K held by seq_K
-    float4 *seq_fpack = nullptr;       // frame-level pack cache of the ring: [slots][H+2][W+2] (rgb, depth) + [slots][H][W] depth planes
-    float *seq_fdepth = nullptr;
-    int *pair_idx = nullptr;           // [2][max_pairs] ring slots of every pair's source pack / target depth plane (k_pack_cached)
     float *seq_dense = nullptr;        // tcsfm_refine_dense_sequence: refined depth maps of all windows, per-window order (on a lane: the
     size_t seq_dense_cap = 0;          // lane's stacked maps of one call)
     float *seq_dense_tmp = nullptr;    // ... the handle's own stacked maps of one call (lane 0)
     size_t seq_dense_tmp_cap = 0;
     size_t seq_pose_cap = 0;           // windows x pairs the pose staging holds
     hipStream_t seq_copy = nullptr;
-    std::vector<hipEvent_t> seq_copied, seq_done, seq_raw;      // per chunk: frames usable by the lanes / per call: done / per chunk: raw frames landed
-    hipStream_t seq_pack = nullptr;    // k_frame_pack runs here, behind the chunk's copy (event), beside the next chunk's copy
+    std::vector<hipEvent_t> seq_copied, seq_done;
     const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
     int K_checked_n = 0;
     unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
@@ -152,18 +140,7 @@ int check_common(tcsfm_ctx *h, const tcsfm_opts *o, int N) {
     if (o->param != TCSFM_PARAM_SE3 && o->param != TCSFM_PARAM_EULER) return fail(h, TCSFM_E_ARG, "opts.param unsupported");
     if (o->n_iters < 0 || o->n_iters > 1000) return fail(h, TCSFM_E_ARG, "opts.n_iters out of range");
     if (o->depth_is_disp && !(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
-    if (o->window_rule != TCSFM_WINDOW_PAIR && o->window_rule != TCSFM_WINDOW_REFERENCE) return fail(h, TCSFM_E_ARG, "opts.window_rule unsupported");
     return TCSFM_OK;
-}
-
-// TCSFM_WINDOW_REFERENCE (window forms only): the coupling of the pairs' costs, see include/tcsfm.h
-void apply_window_rule(const tcsfm_ctx *h, const tcsfm_opts *o, int win_B, int win_S, int N, LinParams &P, SolveParams &S) {
-    if (!win_B || o->window_rule != TCSFM_WINDOW_REFERENCE) return;
-    P.rule = 1;
-    P.fwd_noauto = o->argmin ? 0 : win_B * win_S;      // optimizer.py:71-73: without argmin the forward term has no auto-mask
-    S.rule = 1; S.grp_fwd = win_B * win_S; S.n_pairs = N;
-    S.scale_fwd = o->argmin ? 1.0 : 0.25; S.scale_inv = 0.25;
-    S.b_dc = (double)o->w_dc / ((double)win_B * win_S * (double)h->H * (double)h->W);   // :83-86: mean over all S*B maps
 }
 
 // Stage a host array on the device (slot-indexed scratch that grows on demand) or pass a device pointer through.
@@ -397,174 +374,6 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
 
 }  // namespace
 
-namespace {
-// JOINT dense mode of a window (include/tcsfm.h, tcsfm_refine_dense_window): the S forward pairs of every target share one depth map
-// and are solved together (k_dense_joint / k_solve_joint / k_dense_joint_update); the inverse pairs run the pair-form dense kernels on
-// offset views of the same scratch.  Inputs already on the device.
-template <int NS>
-int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, const float *d_src, const float *d_dt, const float *d_ds,
-                           const float *d_K, const float *d_pose_in, float *d_pose_out, float *d_depth_out, float *d_stats, const WinOff *wo) {
-    using JL = JointLayout<NS>;
-    constexpr int S = NS;
-    const int SB = S * B, N = 2 * SB;
-    const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
-    const bool lm = o->solver == TCSFM_SOLVER_LM;
-    const int n_sel = (o->argmin) ? SB : 0;
-    int rc;
-    constexpr int DTW = 32, DTH = 16, DNT = 512;
-    const int tiles_x = (h->W + DTW - 1) / DTW, tiles_y = (h->H + DTH - 1) / DTH, nblk = tiles_x * tiles_y;
-    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
-    if (!h->dense_rec) {
-        HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->delta, n * 8 * sizeof(double)));
-    }
-    if (lm && !h->dense_rec_acc) {
-        HIPCHK(h, hipMalloc((void **)&h->dense_rec_acc, n * hw * 8 * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->depth_acc, n * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
-    }
-    if (!h->jrec || h->jrec_S < S) {      // targets <= max_pairs / (2 S) <= max_pairs / 4
-        for (void **q : {(void **)&h->jrec, (void **)&h->jrec_acc, (void **)&h->jblockrec, (void **)&h->jdepth_acc, (void **)&h->jstate, (void **)&h->jdelta})
-            if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
-        const size_t nb = (n + 3) / 4;
-        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JL::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JL::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JL::NACC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
-        HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
-        h->jrec_S = S;
-    }
-    if (lm && !h->lm_accept) HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
-    if ((size_t)nblk > (size_t)h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
-    tcsfm_opts oo = *o;
-    oo.refine = TCSFM_REFINE_POSE;
-    oo.window_rule = TCSFM_WINDOW_PAIR;          // (the pose-mode coupling; the joint kernel takes the rule through JointParams)
-    InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
-    I.K_mod = B;
-    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, B, S, h->depth0, wo))) return rc;
-    // ---- forward group: joint
-    LinParams Pj = lin_params(h, &oo, 6);
-    Pj.tiles_x = tiles_x; Pj.tiles_y = tiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
-    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
-          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
-    if (n_sel) { Pj.ext_mask = sel_mask; Pj.n_ext = n_sel; }
-    JointParams J;
-    J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = o->lambda_depth; J.w_prior = o->prior_depth;
-    J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
-    J.automask = 0;                             // own masks only without argmin, where the reference's forward term has no auto-mask (:71-73)
-    JointSolveParams Sj;
-    memset(&Sj, 0, sizeof(Sj));
-    Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
-    Sj.n_iters = o->n_iters; Sj.solver = o->solver; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
-    Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = lm ? h->lm_accept : nullptr;
-    JointUpdateParams Uj;
-    Uj.jrec = h->jrec; Uj.jrec_acc = lm ? h->jrec_acc : nullptr; Uj.depth_acc = lm ? h->jdepth_acc : nullptr; Uj.delta = h->jdelta;
-    Uj.accept = lm ? h->lm_accept : nullptr; Uj.depth = h->depth_work; Uj.depth_out = nullptr; Uj.hw = (int)hw; Uj.B = B; Uj.S = S; Uj.mode = 0;
-    Uj.rho_lo = 1.f / o->max_depth; Uj.rho_hi = 1.f / o->min_depth;
-    // ---- inverse pairs: the pair-form dense kernels on views offset by S B pairs
-    LinParams Pi = lin_params(h, &oo, 6);
-    Pi.tiles_x = tiles_x; Pi.tiles_y = tiles_y; Pi.ngrp = (nblk + RG - 1) / RG; Pi.direct = 1;
-    Pi.tgtpack += (size_t)SB * hw; Pi.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pi.depth_t += (size_t)SB * hw; Pi.pc += SB;
-    Pi.blockrec += (size_t)SB * nblk * AccLayout<6>::NACC;
-    SolveParams Si = solve_params(h, &oo, 6, 0);
-    Si.partials = Pi.blockrec; Si.ngrp = nblk; Si.st = h->state + SB; Si.pc = h->pconst + SB;
-    Si.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
-    Si.delta_out = h->delta + (size_t)SB * 8; Si.accept_out = lm ? h->lm_accept + SB : nullptr;
-    DenseParams Dn;
-    Dn.dense_rec = h->dense_rec + (size_t)SB * hw * 8; Dn.depth0 = h->depth0 + (size_t)SB * hw; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
-    Dn.prev_rec = nullptr; Dn.prev_delta = h->delta; Dn.depth_next = nullptr; Dn.rho_lo = Uj.rho_lo; Dn.rho_hi = Uj.rho_hi;
-    DenseUpdateParams Ui;
-    Ui.dense_rec = Dn.dense_rec; Ui.delta = Si.delta_out; Ui.depth = h->depth_work + (size_t)SB * hw; Ui.depth_out = h->depth_work + (size_t)SB * hw; Ui.hw = (int)hw;
-    Ui.rho_lo = Uj.rho_lo; Ui.rho_hi = Uj.rho_hi;
-    DenseLmParams Ul;
-    Ul.rec_try = Dn.dense_rec; Ul.rec_acc = lm ? h->dense_rec_acc + (size_t)SB * hw * 8 : nullptr; Ul.depth_acc = lm ? h->depth_acc + (size_t)SB * hw : nullptr;
-    Ul.depth = h->depth_work + (size_t)SB * hw; Ul.delta = Si.delta_out; Ul.accept = lm ? h->lm_accept + SB : nullptr; Ul.hw = (int)hw; Ul.rho_lo = Uj.rho_lo; Ul.rho_hi = Uj.rho_hi;
-    const dim3 px_t((unsigned)((hw + 255) / 256), B), px_i((unsigned)((hw + 255) / 256), SB);
-    // The inverse pairs' refinement never meets the forward group's (different pairs, different scratch views): it runs on a second
-    // stream beside it -- fork after the pack, join before the results are copied out -- so a call costs max(forward chain, inverse
-    // chain) per iteration instead of their sum (80 -> ~50 us per iteration for the KITTI window at 640x192).
-    if (!h->aux_stream) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-        HIPCHK(h, hipEventCreateWithFlags(&h->aux_fork, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->aux_join, hipEventDisableTiming));
-    }
-    hipStream_t fs = h->stream, is = h->aux_stream;
-    const bool tr = h->trace_bits != nullptr;
-    if ((rc = trace_check(h, o, N))) return rc;
-    HIPCHK(h, hipEventRecord(h->aux_fork, fs));
-    HIPCHK(h, hipStreamWaitEvent(is, h->aux_fork, 0));
-    // ---- inverse pairs, all iterations, on the second stream
-    auto lin_inv = [&](int lin) {
-        Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
-        Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
-        Pi.stamp = nullptr;
-        if (tr) hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT, true>), dim3(nblk, SB), dim3(DNT), 0, is, Pi, Dn);
-        else hipLaunchKernelGGL((k_dense_linearize<DTW, DTH, DNT>), dim3(nblk, SB), dim3(DNT), 0, is, Pi, Dn);
-    };
-    for (int it = 0; it < o->n_iters; it++) {
-        lin_inv(it);
-        const bool last = !lm && it == o->n_iters - 1;
-        Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
-        hipLaunchKernelGGL((k_solve<6>), dim3(SB), dim3(256), 0, is, Si);
-        if (lm) hipLaunchKernelGGL(k_dense_update_lm, px_i, dim3(256), 0, is, Ul);
-        else hipLaunchKernelGGL(k_dense_update, px_i, dim3(256), 0, is, Ui);
-    }
-    if (lm && o->n_iters > 0) {
-        lin_inv(o->n_iters);
-        Si.it = o->n_iters; Si.mode = 1; Si.pose_out = d_pose_out + (size_t)SB * 6; Si.log_scale_out = nullptr;
-        hipLaunchKernelGGL((k_solve<6>), dim3(SB), dim3(256), 0, is, Si);
-        hipLaunchKernelGGL(k_dense_final_lm, px_i, dim3(256), 0, is, (const int *)(h->lm_accept + SB), (const float *)(h->depth_acc + (size_t)SB * hw),
-                           h->depth_work + (size_t)SB * hw, (int)hw);
-    }
-    HIPCHK(h, hipEventRecord(h->aux_join, is));
-    // ---- forward group, jointly, on the handle's stream
-    auto lin_fwd = [&](int lin) {
-        Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
-        Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
-        if (n_sel) {       // selection masks of the forward pairs at the current poses and the current SHARED depth
-            LinParams M = lin_params(h, &oo, 6);
-            M.o_diff = sel_diff; M.o_valid = sel_valid;
-            launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
-            SelectParams Q;
-            Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
-            Q.B = B; Q.S = S; Q.hw = (int)hw; Q.automask = o->automask;
-            hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), B), dim3(256), 0, fs, Q);
-        }
-        take_stamp(h, Pj, (size_t)nblk * B);
-        ProfScope prof(h, 0);
-        if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true>), dim3(nblk, B), dim3(DNT), 0, fs, Pj, J);
-        else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT>), dim3(nblk, B), dim3(DNT), 0, fs, Pj, J);
-    };
-    constexpr int SOLVE_NT = JSOLVE_NT;
-    for (int it = 0; it < o->n_iters; it++) {
-        lin_fwd(it);
-        const bool last = !lm && it == o->n_iters - 1;
-        Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
-        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(SOLVE_NT), 0, fs, Sj);
-        hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, fs, Uj);
-    }
-    if (lm && o->n_iters > 0) {
-        lin_fwd(o->n_iters);
-        Sj.it = o->n_iters; Sj.mode = 1; Sj.pose_out = d_pose_out;
-        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(SOLVE_NT), 0, fs, Sj);
-        Uj.mode = 1;
-        hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, fs, Uj);
-    }
-    HIPCHK(h, hipStreamWaitEvent(fs, h->aux_join, 0));
-    HIPCHK(h, hipGetLastError());
-    if (o->n_iters == 0) {
-        FinishParams F;
-        F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = nullptr; F.N = N;
-        hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, h->stream, F);
-    }
-    HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    return TCSFM_OK;
-}
-
-}  // namespace
-
 // =================================================================================================
 extern "C" {
 
@@ -577,7 +386,6 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->min_depth = 0.06f; o->max_depth = 2.67f;
     o->prior_scale = 1.0f;
     o->lambda_depth = 1.0f; o->prior_depth = 10.0f;
-    o->window_rule = TCSFM_WINDOW_PAIR; o->dense_joint = 1;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -622,7 +430,6 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->pose_dev, n * 6 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->ls_dev, n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->K_dev, n * 9 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->pair_idx, 2 * n * sizeof(int));
     if (e != hipSuccess) {
         g_create_error = std::string("tcsfm_create: ") + hipGetErrorString(e);
         tcsfm_destroy(h);
@@ -645,18 +452,12 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (h->done_ev) (void)hipEventDestroy(h->done_ev);
     for (auto &e : h->marks) (void)hipEventDestroy(e);
     if (h->seq_copy) { (void)hipStreamSynchronize(h->seq_copy); (void)hipStreamDestroy(h->seq_copy); }
-    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
-    if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
-    if (h->aux_join) (void)hipEventDestroy(h->aux_join);
-    if (h->seq_pack) { (void)hipStreamSynchronize(h->seq_pack); (void)hipStreamDestroy(h->seq_pack); }
     for (auto &e : h->seq_copied) (void)hipEventDestroy(e);
-    for (auto &e : h->seq_raw) (void)hipEventDestroy(e);
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
-                    h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
+                    h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &s : h->stage)
@@ -878,52 +679,6 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
     return TCSFM_OK;
 }
 
-int tcsfm_linearize_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
-                           const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *log_scale,
-                           double *Hmat, double *g, double *stats) {
-    if (!h) return TCSFM_E_ARG;
-    if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_window: need 1 <= 2*B*S <= max_pairs");
-    const int N = 2 * B * S;
-    int rc = check_common(h, o, N);
-    if (rc) return rc;
-    if (!tgt || !srcs || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_window: NULL input");
-    DeviceGuard dev_guard(h->device);
-    if (int rc_ = pending_error(h)) return rc_;
-    if ((rc = check_intrinsics(h, o, K, B))) return rc;
-    const size_t hw = (size_t)h->H * h->W;
-    const int np = np_of(o);
-    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose, *d_ls;
-    if ((rc = to_dev(h, o, 0, tgt, B * 3 * hw, &d_tgt))) return rc;
-    if ((rc = to_dev(h, o, 1, srcs, (size_t)B * S * 3 * hw, &d_src))) return rc;
-    if ((rc = to_dev(h, o, 2, depth_t, B * hw, &d_dt))) return rc;
-    if ((rc = to_dev(h, o, 3, depth_s, (size_t)B * S * hw, &d_ds))) return rc;
-    if ((rc = to_dev(h, o, 4, K, (size_t)B * 9, &d_K))) return rc;
-    if ((rc = to_dev(h, o, 5, pose, (size_t)N * 6, &d_pose))) return rc;
-    if ((rc = to_dev(h, o, 6, log_scale, (size_t)N, &d_ls))) return rc;
-    InitParams I = init_params(h, o, N, d_pose, np == 7 ? d_ls : nullptr, d_K, 0);
-    I.K_mod = B;
-    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, B, S))) return rc;
-    LinParams P = lin_params(h, o, np);
-    SolveParams Sv = solve_params(h, o, np, 0);
-    if (S > 1 && o->argmin) { P.sel_B = B; P.sel_S = S; }
-    apply_window_rule(h, o, B, S, N, P, Sv);
-    launch_lin(h, P, N, np, o->w_dc > 0.f, MODE_LIN);
-    Sv.mode = 2;
-    launch_solve(h, Sv, N, np);
-    HIPCHK(h, hipGetLastError());
-    const int rec = np * np + np + 4;
-    std::vector<double> host((size_t)N * rec);
-    HIPCHK(h, hipMemcpyAsync(host.data(), h->lin_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int n = 0; n < N; n++) {
-        const double *r = &host[(size_t)n * rec];
-        if (Hmat) memcpy(Hmat + (size_t)n * np * np, r, sizeof(double) * np * np);
-        if (g) memcpy(g + (size_t)n * np, r + np * np, sizeof(double) * np);
-        if (stats) memcpy(stats + (size_t)n * 4, r + np * np + np, sizeof(double) * 4);
-    }
-    return TCSFM_OK;
-}
-
 int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, const float *src, const float *depth_t,
                        const float *depth_s, const float *K, int P, const float *poses, double *cost_out) {
     int rc = check_common(h, o, P);
@@ -950,12 +705,9 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
 }
 
 // shared body of tcsfm_refine (win_B == 0: one image set per pair) and tcsfm_refine_window (win_B x win_S window)
-// frame-level pack cache of a sequence call (kernels.h k_frame_pack / k_pack_cached): the ring's packed frames, and where this call's windows start
-struct FrameCache { const float4 *fpack; const float *fdepth; int slot0, tpos; };
-
 static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
-                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr, const FrameCache *fc = nullptr) {
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
@@ -986,29 +738,13 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
 
     InitParams I = init_params(h, o, N, d_pose_in, np == 7 ? d_ls_in : nullptr, d_K, 0);
     I.K_mod = win_B;
+    if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo))) return rc;
     LinParams P = lin_params(h, o, np);
-    if (fc) {      // sequence call: rgb + depth were packed once per frame when they landed; only the pair-specific part is formed here
-        if (h->tickets_dirty) {
-            HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp_alloc * sizeof(int), h->stream));
-            h->tickets_dirty = false;
-        }
-        PackCachedParams C;
-        C.fpack = fc->fpack; C.tgtpack = h->tgtpack; C.pair_src = h->pair_idx; C.pair_dep = h->pair_idx + h->max_pairs;
-        C.H = h->H; C.W = h->W; C.N = N; C.win_B = win_B; C.win_S = win_S; C.slot0 = fc->slot0; C.tpos = fc->tpos; C.win_off = *wo;
-        C.wl = o->w_l1 / 3.f; C.ws = o->w_ssim / 3.f; C.init = I;
-        {
-            ProfScope prof(h, 2);
-            hipLaunchKernelGGL(k_pack_cached, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, C);
-        }
-        HIPCHK(h, hipGetLastError());
-        P.srcpack = fc->fpack; P.depth_t = fc->fdepth; P.pair_src = C.pair_src; P.pair_dep = C.pair_dep;
-    } else if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo))) return rc;
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (n_sel) { P.sel_B = win_B; P.sel_S = win_S; }   // min over the sources: evaluated inside k_linearize<SEL>
-    apply_window_rule(h, o, win_B, win_S, N, P, S);
     if ((rc = trace_check(h, o, N))) return rc;
     for (int it = 0; it < o->n_iters; it++) {
         trace_at(h, it, N, P, S);
@@ -1172,19 +908,8 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
     }
-    if (win_B && o->dense_joint && win_S >= 2 && win_S <= JMAXS) {   // one depth map per target, 6S x 6S reduced system (joint_kernel.h)
-        rc = win_S == 2 ? dense_joint_run<2>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo)
-                        : dense_joint_run<3>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo);
-        if (rc) return rc;
-        if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
-        if ((rc = copy_back(h, o, depth_out, d_depth_out, N * hw))) return rc;
-        if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
-        if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
-        return TCSFM_OK;
-    }
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
-    oo.window_rule = TCSFM_WINDOW_PAIR;
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
     I.K_mod = win_B;
     // Gauss-Newton in the pair form: the back-substitution of iteration k is fused into the linearisation of iteration k+1 (depth
@@ -1404,8 +1129,7 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
     if (int rc_ = pending_error(h)) return rc_;
     // frames go up in chunks of C (one copy for the images, one for the depths: PCIe runs at 55 GB/s on 8-frame copies, at 36 GB/s
     // on single frames, and the host issues a quarter of the calls); the ring holds a whole number of chunks
-    static const int chunk_default = getenv("TCSFM_SEQ_CHUNK") ? std::max(1, atoi(getenv("TCSFM_SEQ_CHUNK"))) : 4;      // (measurement hook)
-    const int C = ring > 0 ? (ring >= WB + S + 8 ? 4 : 1) : chunk_default;
+    const int C = ring > 0 ? (ring >= WB + S + 8 ? 4 : 1) : 4;
     const int R = ring > 0 ? (ring / C) * C : ((32 + (L + 1) * WB + S + C - 1) / C) * C;     // frames resident at once
     const int M = WB + S - 1;                              // mirror slots behind the ring: the WB + S frames of a call never wrap
     if (R < S + 2 || R < WB + S + C) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: ring must hold at least windows_per_call + S + 4 frames (S + 2 for one window per call)");
@@ -1417,14 +1141,7 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         h->seq_img = h->seq_depth = nullptr; h->seq_slots = 0;
         HIPCHK(h, hipMalloc(&h->seq_img, (size_t)(R + M) * 3 * hw * sizeof(float)));
         HIPCHK(h, hipMalloc(&h->seq_depth, (size_t)(R + M) * hw * sizeof(float)));
-        if (h->seq_fpack) { HIPCHK(h, hipFree(h->seq_fpack)); h->seq_fpack = nullptr; }       // (re-allocated below for the new slot count)
-        if (h->seq_fdepth) { HIPCHK(h, hipFree(h->seq_fdepth)); h->seq_fdepth = nullptr; }
         h->seq_slots = R + M;
-    }
-    const bool use_cache = dense_depth_out == nullptr;      // (the dense modes rewrite per-pair depth planes: they keep the per-pair pack)
-    if (use_cache && !h->seq_fpack) {
-        HIPCHK(h, hipMalloc((void **)&h->seq_fpack, (size_t)h->seq_slots * (h->H + 2) * (h->W + 2) * sizeof(float4)));
-        HIPCHK(h, hipMalloc((void **)&h->seq_fdepth, (size_t)h->seq_slots * hw * sizeof(float)));
     }
     if (h->seq_pose_cap < (size_t)nwin * N) {
         for (float **q : {&h->seq_pose_in, &h->seq_pose_out, &h->seq_ls_out})
@@ -1462,8 +1179,6 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
     const size_t n_done = (size_t)2 * R + 2;               // a call's event is re-recorded long after its slots were recycled
     const size_t ND = n_done - 1;
     while (h->seq_copied.size() < (size_t)R) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_copied.push_back(e); }
-    while (use_cache && h->seq_raw.size() < (size_t)R) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_raw.push_back(e); }
-    if (use_cache && !h->seq_pack) HIPCHK(h, hipStreamCreateWithFlags(&h->seq_pack, hipStreamNonBlocking));
     while (h->seq_done.size() < n_done) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->seq_done.push_back(e); }
     // Poses live on the device per CALL in the stacked order of the window form (forward pairs (s, b), then inverse pairs); the
     // caller's arrays are per window.  at(): offset (in pairs) of pair j of window w inside the staging arrays.
@@ -1519,31 +1234,12 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
                 HIPCHK(h, hipStreamWaitEvent(cs, h->seq_done[r % ND], 0));
             HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)slot * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nf * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
             HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)slot * hw, depths + (size_t)nxt * hw, (size_t)nf * hw * sizeof(float), hipMemcpyHostToDevice, cs));
-            // mirror of the first M slots behind the ring (the frames of a call never wrap).  The frames cross PCIe ONCE: raw mirrors are
-            // device-to-device copies, and with the pack cache only the PoseNet reads raw frames -- otherwise the mirror exists as packs only
-            const int nm = slot < M ? (nf < M - slot ? nf : M - slot) : 0;
-            if (nm > 0 && (!use_cache || pn)) {
-                HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)(R + slot) * 3 * hw, h->seq_img + (size_t)slot * 3 * hw, (size_t)nm * 3 * hw * sizeof(float), hipMemcpyDeviceToDevice, cs));
-                HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)(R + slot) * hw, h->seq_depth + (size_t)slot * hw, (size_t)nm * hw * sizeof(float), hipMemcpyDeviceToDevice, cs));
+            if (slot < M) {                                // mirror of the first M slots behind the ring: the frames of a call never wrap
+                const int nm = nf < M - slot ? nf : M - slot;
+                HIPCHK(h, hipMemcpyAsync(h->seq_img + (size_t)(R + slot) * 3 * hw, frames + (size_t)nxt * 3 * hw, (size_t)nm * 3 * hw * sizeof(float), hipMemcpyHostToDevice, cs));
+                HIPCHK(h, hipMemcpyAsync(h->seq_depth + (size_t)(R + slot) * hw, depths + (size_t)nxt * hw, (size_t)nm * hw * sizeof(float), hipMemcpyHostToDevice, cs));
             }
-            if (use_cache) {      // pack the frames that just landed (and their mirrors), once -- on the PACK stream, so that the next chunk's
-                                  // copy does not queue behind the kernel (a sequence with S = 1 is PCIe-bound: the copy stream is its critical path)
-                HIPCHK(h, hipEventRecord(h->seq_raw[slot / C], cs));
-                HIPCHK(h, hipStreamWaitEvent(h->seq_pack, h->seq_raw[slot / C], 0));
-                FramePackParams Fp;
-                Fp.H = h->H; Fp.W = h->W; Fp.depth_is_disp = o.depth_is_disp;
-                Fp.min_disp = o.depth_is_disp ? 1.f / o.max_depth : 0.f; Fp.max_disp = o.depth_is_disp ? 1.f / o.min_depth : 0.f;
-                auto pack = [&](int from, int to, int count) {
-                    Fp.img = h->seq_img + (size_t)from * 3 * hw; Fp.depth = h->seq_depth + (size_t)from * hw;
-                    Fp.fpack = h->seq_fpack + (size_t)to * (h->H + 2) * (h->W + 2); Fp.fdepth = h->seq_fdepth + (size_t)to * hw;
-                    hipLaunchKernelGGL(k_frame_pack, dim3((unsigned)((hw + 255) / 256), count), dim3(256), 0, h->seq_pack, Fp);
-                };
-                pack(slot, slot, nf);
-                if (nm > 0) pack(slot, R + slot, nm);
-                HIPCHK(h, hipEventRecord(h->seq_copied[slot / C], h->seq_pack));
-            } else {
-                HIPCHK(h, hipEventRecord(h->seq_copied[slot / C], cs));
-            }
+            HIPCHK(h, hipEventRecord(h->seq_copied[slot / C], cs));
             nxt += nf;
         }
         const int l = (int)(ci % L), s0 = c0 % R;
@@ -1570,11 +1266,8 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
                 hipLaunchKernelGGL(k_maps_to_window_order, dim3((unsigned)((hw + 255) / 256), N * nbw), dim3(256), 0, ls[l], (const float *)tmp, ordered, nbw, N, (int)hw);
                 HIPCHK(h, hipMemcpyAsync(dense_depth_out + (size_t)c0 * N * hw, ordered, (size_t)nbw * N * hw * sizeof(float), hipMemcpyDeviceToHost, ls[l]));
             }
-        } else {
-            FrameCache fcache = {h->seq_fpack, h->seq_fdepth, s0, tp};
-            rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
-                             np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo, use_cache ? &fcache : nullptr);
-        }
+        } else rc = refine_impl(c, &o, N * nbw, nbw, S, tg, sr, dt, ds, h->seq_K, p_in, nullptr, p_out,
+                              np == 7 ? h->seq_ls_out + (size_t)c0 * N : nullptr, nullptr, &wo);
         if (rc) { if (c != h) h->err = c->err; break; }
         HIPCHK(h, hipEventRecord(h->seq_done[ci % ND], ls[l]));
         for (int k = 0; k < nbw + S; k++) slot_reader[(c0 + k) % R] = ci;
@@ -1585,7 +1278,6 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         if (e != hipSuccess && !rc) { h->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = TCSFM_E_HIP; }
     }
     (void)hipStreamSynchronize(cs);
-    if (h->seq_pack) (void)hipStreamSynchronize(h->seq_pack);
     if (rc) return rc;
     for (int l = 0; l < L; l++)
         if (int rc_ = pending_error(lane[l])) { if (lane[l] != h) h->err = lane[l]->err; return rc_; }
@@ -1910,10 +1602,6 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         } else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
         else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
-        // GroupNorm statistics (+ K-split combination) as their own launch.  Round 3 measured the alternative -- statistics, K-split
-        // combination and the head in the convolutions' tails by the last-arriver ticket protocol, 7 launches instead of 15: every
-        // convolution became 6-8 us SLOWER (ticket round trips, acquire, serial tail of the last workgroup), 127.5 vs 119 us per
-        // evaluation (profiles/r03_posenet_fused_tail_kernel_stats.csv, _timing.jsonl) -- a separate 16 N-workgroup pass is faster.
         PnStatsParams S;
         S.part = P.part; S.tiles = (int)grid.x;
         S.out = pn->act[l]; S.bias = pn->bias[l]; S.gamma = pn->gamma[l]; S.beta = pn->beta[l]; S.scsh = pn->scsh[l];

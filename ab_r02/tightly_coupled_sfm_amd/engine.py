@@ -269,27 +269,6 @@ class Engine:
                                          self._p(K), self._p(pose), self._p(ls_in), self._p(pose_out), self._p(ls_out), self._p(st)))
         return pose_out, ls_out, st
 
-    def linearize_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None, argmin: Optional[bool] = None):
-        """ONE linearisation of a window's 2*S*B directed pairs (layouts of refine_window) at ``pose`` under opts.argmin /
-        opts.window_rule -> dict(H [2SB,np,np], g [2SB,np], cost, cost_photo, cost_dc, n_mask [2SB]) (numpy f64).  With
-        window_rule = WINDOW_REFERENCE the costs add up to the reference's compute_optimization_loss (optimizer.py:47-86)."""
-        self._bind()
-        o = opts or default_opts()
-        if argmin is not None:
-            o = _copy_opts(o); o.argmin = 1 if argmin else 0
-        S, B = int(srcs.shape[0]), int(srcs.shape[1])
-        N = 2 * S * B
-        tgt = _chk(tgt, (B, 3, self.H, self.W), "tgt"); srcs = _chk(srcs, (S, B, 3, self.H, self.W), "srcs")
-        depth_t = _chk(depth_t, (B, 1, self.H, self.W), "depth_t"); depth_s = _chk(depth_s, (S, B, 1, self.H, self.W), "depth_s")
-        K = _chk(K, (B, 3, 3), "K"); pose = _chk(pose, (N, 6), "pose")
-        n_p = 7 if o.refine == _lib.REFINE_POSE_SCALE else 6
-        ls = None if log_scale is None else _chk(log_scale, (N,), "log_scale")
-        Hm = np.zeros((N, n_p, n_p)); g = np.zeros((N, n_p)); st = np.zeros((N, 4))
-        self._call(self.lib.tcsfm_linearize_window(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
-                                                   self._p(K), self._p(pose), self._p(ls), Hm.ctypes.data_as(C.c_void_p),
-                                                   g.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
-        return dict(H=Hm, g=g, cost=st[:, 0], cost_photo=st[:, 1], cost_dc=st[:, 2], n_mask=st[:, 3])
-
     def refine_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, log_scale=None, stats: bool = False,
                       argmin: Optional[bool] = None):
         """Window form (the call surface of solve_pose_iteratively, train_mono.py:41-62): tgt [B,3,H,W], srcs [S,B,3,H,W] (or a
@@ -415,11 +394,9 @@ class Engine:
         return (out, ls) if log_scale else out
 
     def refine_dense_sequence(self, frames: torch.Tensor, depths: torch.Tensor, K, init_poses, opts: Optional[Opts] = None, sources: int = 1,
-                              ring: int = 0, windows_per_call: int = 0, target_pos: int = 0, out_depths: Optional[torch.Tensor] = None):
+                              ring: int = 0, windows_per_call: int = 0, target_pos: int = 0):
         """tcsfm_refine_dense_sequence: the dense mode (pose + per-pixel inverse depth) over a sequence, arguments as refine_sequence
-        -> (poses [T-S, 2S, 6], refined depth maps [T-S, 2S, 1, H, W]) as CPU tensors.
-        out_depths: a caller-owned (pinned) CPU tensor of that shape to receive the depth maps; a caller that runs sequence after
-        sequence should pass one -- pinning a fresh 70 MB result buffer costs ten times the refinement of a 120-frame sequence."""
+        -> (poses [T-S, 2S, 6], refined depth maps [T-S, 2S, 1, H, W]) as CPU tensors"""
         self._bind()
         o = opts or default_opts()
         T, S = int(frames.shape[0]), int(sources)
@@ -427,12 +404,7 @@ class Engine:
         Kc = self._cpu(torch.as_tensor(np.asarray(K, dtype=np.float32)), (3, 3), "K")
         p0 = self._cpu(torch.as_tensor(np.asarray(init_poses, dtype=np.float32)), (T - S, 2 * S, 6), "init_poses")
         out = torch.empty_like(p0)
-        if out_depths is None:      # pinned: the copies back run beside the kernels
-            dout = torch.empty((T - S, 2 * S, 1, self.H, self.W), dtype=torch.float32, pin_memory=True)
-        else:
-            dout = out_depths
-            if dout.is_cuda or dout.dtype != torch.float32 or not dout.is_contiguous() or tuple(dout.shape) != (T - S, 2 * S, 1, self.H, self.W):
-                raise TypeError("out_depths must be a contiguous float32 CPU tensor [T-S, 2S, 1, H, W]")
+        dout = torch.empty((T - S, 2 * S, 1, self.H, self.W), dtype=torch.float32).pin_memory()     # pinned: the copies back run beside the kernels
         hp = lambda t: C.c_void_p(t.data_ptr())
         self._call(self.lib.tcsfm_refine_dense_sequence(self._h, C.byref(o), T, S, hp(frames), hp(depths), hp(Kc), hp(p0), hp(out), hp(dout), int(ring),
                                                         int(windows_per_call), int(target_pos)))
