@@ -7,8 +7,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "tcsfm_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("kernels.h", "dense_kernel.h", "scale_kernel.h", "se3_math.h", "wave_reduce.h", "posenet_kernel.h")] + \
-       [os.path.join(os.path.dirname(HERE), "include", "tcsfm.h")]
+DEPS = [SRC] + sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")) + \
+       [os.path.join(os.path.dirname(HERE), "include", "tcsfm.h")]          # every header of csrc/ (a fixed list once missed joint_kernel.h)
 OUT = os.path.join(HERE, "libtcsfm_hip.so")
 # -ffp-contract=on: a*b+c is fused only where the source writes it in one expression (hipcc's default, "fast", lets the backend fuse
 # across statements depending on how many uses a product has -- which made the decision-recording instantiations of the kernels

@@ -434,6 +434,18 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
     __shared__ int s_flag[2];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int NTS = JSOLVE_NT;
+    // the optimiser state is fetched NOW, beside the records: the serial phases below never wait on a global load (as in k_solve)
+    __shared__ double Ks[NS][12];
+    JointState &S = P.js[b];
+    const double S_lambda = S.lambda, S_cost_cur = S.cost_cur;
+    const int S_have_cur = S.have_cur;
+    double pre_try = 0.0, pre_cur = 0.0;
+    if (tid < 64 && (tid >> 4) < NS) {
+        const PairState &ps0 = P.st[(tid >> 4) * P.B + b];
+        const int sub = tid & 15;
+        if (sub < 12) { pre_try = ps0.Ttry[sub]; pre_cur = ps0.Tcur[sub]; }
+        if (sub < 9) Ks[tid >> 4][sub] = ps0.K[sub];
+    }
     {
         // deterministic fp64 sum of the target's workgroup records, as in k_solve: thread = (accumulator, record subset), every
         // subset's loads issued in batches of 8 so that they are all in flight, subsets combined in fixed order
@@ -441,12 +453,12 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
         double s = 0.0;
         if (c < JL::NACC) {
             const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + c;
-            for (int r0 = q; r0 < P.nblk; r0 += 8 * PARTS) {
-                float w[8];
+            for (int r0 = q; r0 < P.nblk; r0 += 32 * PARTS) {      // 32 loads per thread in flight (240 records of 192x640: one batch)
+                float w[32];
 #pragma unroll
-                for (int k = 0; k < 8; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < P.nblk ? r : q) * JL::NACC]; }
+                for (int k = 0; k < 32; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < P.nblk ? r : q) * JL::NACC]; }
 #pragma unroll
-                for (int k = 0; k < 8; k++) s += (r0 + k * PARTS < P.nblk) ? (double)w[k] : 0.0;
+                for (int k = 0; k < 32; k++) s += (r0 + k * PARTS < P.nblk) ? (double)w[k] : 0.0;
             }
         }
         part[tid] = s;
@@ -458,12 +470,11 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
         }
     }
     __syncthreads();
-    JointState &S = P.js[b];
     const double Kn = tot[JL::OFF_S + 1], an = Kn > 0 ? 1.0 / Kn : 0.0;
     const double cost = an * tot[JL::OFF_S];
-    double lambda = P.it == 0 && P.mode == 0 ? P.lambda0 : S.lambda;
-    const bool have_cur = !(P.it == 0 && P.mode == 0) && S.have_cur;
-    const double cost_cur = S.cost_cur;
+    double lambda = P.it == 0 && P.mode == 0 ? P.lambda0 : S_lambda;
+    const bool have_cur = !(P.it == 0 && P.mode == 0) && S_have_cur;
+    const double cost_cur = S_cost_cur;
     if (P.stats && tid < NS) {      // row of forward pair (tid, b): joint cost, own share, own mask count, lambda, the iterate
         const int n = tid * P.B + b;
         float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.it) * TCSFM_NSTAT;
@@ -501,19 +512,33 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
     if (tid < NP) M[tid * NC + tid] += lambda * M[tid * NC + tid] + 1e-12;     // Marquardt damping
     if (tid == 0) { s_flag[0] = 1; }
     __syncthreads();
-    for (int k = 0; k < NP; k++) {      // Gauss-Jordan, one thread per entry (unpivoted: the system is SPD)
-        const double piv = M[k * NC + k];
-        if (tid == 0 && !(piv > 0.0)) s_flag[0] = 0;
-        double upd = 0.0;
-        bool mine = false;
-        if (tid < NP * NC) {
-            const int r = tid / NC, c = tid - r * NC;
-            if (r != k) { upd = M[r * NC + c] - M[r * NC + k] / piv * M[k * NC + c]; mine = true; }
+    // Gauss-Jordan (unpivoted: the system is SPD) by wave 0 alone: a wave's LDS accesses execute in program order, so the pivots
+    // need no workgroup barrier (12-18 pivots x 2 barriers of 16 waves cost more than the arithmetic); lane = entries lane, lane + 64, ..
+    if (tid < 64) {
+        constexpr int EPL = (NP * NC + 63) / 64;
+        double *Mv = M;      // (not volatile: the memory legaliser waits after every volatile access; the fences below order the wave's LDS traffic)
+        for (int k = 0; k < NP; k++) {
+            const double piv = Mv[k * NC + k];
+            if (tid == 0 && !(piv > 0.0)) s_flag[0] = 0;
+            const double ipiv = rcp64(piv);
+            double upd[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int i = tid + 64 * e, r = i / NC, c = i - r * NC;
+                upd[e] = (i < NP * NC && r != k) ? Mv[i] - Mv[r * NC + k] * ipiv * Mv[k * NC + c] : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                const int i = tid + 64 * e, r = i / NC;
+                if (i < NP * NC && r != k) Mv[i] = upd[e];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
-        if (mine) M[tid] = upd;
-        __syncthreads();
     }
+    __syncthreads();
     if (tid < NP) dl[tid] = s_flag[0] ? M[tid * NC + NP] / M[tid * NC + tid] : 0.0;
     __syncthreads();
     if (tid == 0) {
@@ -522,21 +547,41 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
         if (P.accept_out) P.accept_out[b] = accept ? 1 : 0;
         if (P.delta_out) for (int i = 0; i < NP; i++) P.delta_out[b * 6 * JMAXS + i] = dl[i];
     }
-    if (tid < NS) {                     // per source: T_try = exp(d_s) T_accepted, next constants
-        const int n = tid * P.B + b;
-        if (P.trace_decide) P.trace_decide[n] = accept ? 1 : 0;
+    // per source: T_try = exp(d_s) T_accepted and the next constants, on 16 lanes of wave 0 each (as k_solve: the exponential is
+    // serial on one lane, the product and the constants one entry per lane)
+    if (tid < 64) {
+        const int g = tid >> 4, sub = tid & 15;
+        const bool on = g < NS;
+        const int n = (on ? g : 0) * P.B + b;
         PairState &ps = P.st[n];
-        double *T = Ts[tid];
-        for (int i = 0; i < 12; i++) { T[12 + i] = accept ? ps.Ttry[i] : ps.Tcur[i]; }
-        if (accept) for (int i = 0; i < 12; i++) ps.Tcur[i] = T[12 + i];
-        double d6[6];
-        for (int i = 0; i < 6; i++) d6[i] = dl[6 * tid + i];
-        se3_exp(d6, T);
-        se3_mul(T, T + 12, T + 24);
+        double *T = Ts[on ? g : 0];
+        if (on && sub < 12) {
+            const double v = accept ? pre_try : pre_cur;
+            T[12 + sub] = v;
+            if (accept) ps.Tcur[sub] = v;
+        }
+        if (on && sub == 0) {
+            if (P.trace_decide) P.trace_decide[n] = accept ? 1 : 0;
+            double d6[6], E[12];
+            for (int i = 0; i < 6; i++) d6[i] = dl[6 * g + i];
+            se3_exp(d6, E);
+            for (int i = 0; i < 12; i++) T[i] = E[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const bool last_gn = (P.solver == 0 && P.it == P.n_iters - 1);
-        for (int i = 0; i < 12; i++) { ps.Ttry[i] = T[24 + i]; if (last_gn) ps.Tcur[i] = T[24 + i]; }
-        write_const(ps, T + 24, 0.0, n, P.pc[n]);
-        if (last_gn && P.pose_out) {
+        if (on && sub < 12) {           // se3_mul's operation order
+            const int i = sub >> 2, j = sub & 3;
+            double v = T[4 * i] * T[12 + j] + T[4 * i + 1] * T[16 + j] + T[4 * i + 2] * T[20 + j];
+            if (j == 3) v += T[4 * i + 3];
+            T[24 + sub] = v;
+            ps.Ttry[sub] = v;
+            if (last_gn) ps.Tcur[sub] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (on) write_const_lanes<6>(sub, Ks[g], T + 24, 0.0, P.pc[n]);
+        if (on && sub == 0 && last_gn && P.pose_out) {
             float pose[6];
             T_to_pose_f32(T + 24, pose);
             for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
