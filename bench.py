@@ -34,7 +34,7 @@ The JSON line also carries
                 latest end - earliest start, tcsfm_profile_kernel_time; ~1.4 us below rocprof's duration, which includes dispatch and
                 completion) and the HIP event pair around the same launches on the launch stream (2-4 us high on a ~10 us kernel).
                 `traffic` = HBM bytes per launch of THIS workload from the committed PMC passes (profiles/<tag>_pmc_traffic.json).  `valu_bound`: the bound the kernel actually runs into (see
-                profiles/r02_valu_census.json): VALU issue time of its instruction stream priced with measured per-class costs.
+                profiles/r03_valu_census.json): VALU issue time of its instruction stream priced with measured per-class costs.
   cpu_baseline  the float64 CPU oracle (a scalar C port of the same algorithm, oracle/tcsfm_oracle.c) timed on this box's host
                 cores on a bounded sample of the same workload: all cores of the box's share (`value`) and one core (`one_thread`),
                 plus the reference's own style of step (PyTorch autograd + Adam, oracle/torch_twin.py).
@@ -161,8 +161,8 @@ def rocprof_avg_us(kernel_substr=KERNEL):
 
 def valu_bound(avg_s, pairs_per_launch):
     """VALU issue time of one launch: waves per SIMD x (instructions of one wave priced with the measured per-class issue costs,
-    profiles/r02_valu_census.json) / shader clock.  The kernel cannot run faster than this whatever the memory system does."""
-    f = os.path.join(ROOT, "profiles", "r02_valu_census.json")
+    profiles/r03_valu_census.json) / shader clock.  The kernel cannot run faster than this whatever the memory system does."""
+    f = os.path.join(ROOT, "profiles", "r03_valu_census.json")
     if not os.path.exists(f):
         return None
     c = json.load(open(f))
@@ -171,7 +171,7 @@ def valu_bound(avg_s, pairs_per_launch):
     ghz = c.get("shader_clock_GHz", 2.4)
     t = clk / (ghz * 1e9)
     return {"valu_insts_per_wave": c["valu_insts_per_wave_census"], "busy_clk_per_wave": c["predicted_valu_busy_clk_per_wave"],
-            "bound_us": round(t * 1e6, 3), "frac_of_bound": round(t / avg_s, 4), "clock_GHz": ghz, "census": "profiles/r02_valu_census.json"}
+            "bound_us": round(t * 1e6, 3), "frac_of_bound": round(t / avg_s, 4), "clock_GHz": ghz, "census": "profiles/r03_valu_census.json"}
 
 
 def main():
