@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--gn-iters", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--dump", default="")
+    ap.add_argument("--odometry", type=int, default=0, metavar="ITERS",
+                    help="initial poses from the coupled PoseNet loop (ITERS network evaluations per window, seeded stand-in weights) instead of --init")
     args = ap.parse_args()
     world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("TCSFM_BENCH_BACKEND", "nccl")
@@ -61,12 +63,21 @@ def main():
     frames, depths, K, init = make_sequence(args.frames, H, W, S)
     eng = Engine(H, W, 2 * S * args.windows_per_call, lanes=args.lanes)
     o = default_opts(n_iters=args.gn_iters)
-    parallel.refine_sequence_sharded(eng, frames, depths, K, init, o, sources=S, windows_per_call=args.windows_per_call)      # warm-up
+    if args.odometry:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import standins                                                           # seeded PoseNet parameters (a real run loads a checkpoint)
+        from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+        net = PoseNetHIP(eng, 2 * S * args.windows_per_call, standins.posenet_params(0))
+        run = lambda: parallel.odometry_sequence_sharded(net, frames, depths, K, o, sources=S, iterations=args.odometry,
+                                                         windows_per_call=args.windows_per_call)[1]
+    else:
+        run = lambda: parallel.refine_sequence_sharded(eng, frames, depths, K, init, o, sources=S, windows_per_call=args.windows_per_call)
+    run()      # warm-up
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
-    poses = parallel.refine_sequence_sharded(eng, frames, depths, K, init, o, sources=S, windows_per_call=args.windows_per_call)
+    poses = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

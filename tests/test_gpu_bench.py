@@ -129,6 +129,17 @@ def test_sequence_sharded_two_ranks_one_card(tmp_path):
     e = Engine(96, 320, 16, lanes=2)
     one = e.refine_sequence(frames, depths, K, init, default_opts(n_iters=4), sources=2, windows_per_call=4)
     assert got.shape == (35, 4, 6) and np.array_equal(got, one.numpy())
+    # the same with the PoseNet loop inside (tcsfm_odometry_sequence per rank): equal to the single-process run, bit for bit
+    dump2 = str(tmp_path / "odo.npy")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + common[:-1] + [dump2, "--odometry", "2"], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import standins
+    from tightly_coupled_sfm_amd.posenet import PoseNetHIP
+    net = PoseNetHIP(e, 16, standins.posenet_params(0))
+    _, one_odo = net.odometry_sequence(frames, depths, K, default_opts(n_iters=4), sources=2, iterations=2, windows_per_call=4)
+    assert np.array_equal(np.load(dump2), one_odo.numpy())
     # the pair-form helper on the real engine (single process: the gather is the identity)
     from tightly_coupled_sfm_amd import synth
     b = synth.make_batch(6, 96, 320, seed0=5, both_directions=True)

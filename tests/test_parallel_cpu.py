@@ -76,6 +76,16 @@ def _seq_worker(rank, world, port, T, S, wpc, ret):
     full = fake_sequence(frames, depths, None, init, None, S, wpc, 0)
     lo, hi = P.sequence_block(T - S, rank, world, wpc)
     ok = torch.equal(out, full) and (seen[0] == (hi - lo + S, hi - lo) if hi > lo else len(seen) == 1)
+
+    def fake_odometry(fr, dp, K, opts, sources, iterations, windows_per_call, target_pos):       # (initial, refined) per window
+        n = fr.shape[0] - sources
+        w = torch.stack([fr[i:i + sources + 1].sum() * iterations + dp[i:i + sources + 1].sum() for i in range(n)])
+        i0 = w[:, None, None] * torch.ones((n, 2 * sources, 6))
+        return i0, i0 * 3 + 1
+
+    i_sh, o_sh = P.odometry_sequence_sharded(None, frames, depths, None, None, sources=S, iterations=3, windows_per_call=wpc, run_fn=fake_odometry)
+    i_1, o_1 = fake_odometry(frames, depths, None, None, S, 3, wpc, 0)
+    ok = ok and torch.equal(i_sh, i_1) and torch.equal(o_sh, o_1)
     ret[rank] = (bool(ok), lo, hi)
     dist.barrier()
     dist.destroy_process_group()

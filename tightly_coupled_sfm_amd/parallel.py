@@ -91,19 +91,51 @@ def refine_sequence_sharded(engine, frames: torch.Tensor, depths: torch.Tensor, 
         local = torch.as_tensor(local).reshape(hi - lo, 2 * S * 6)
     else:
         local = torch.zeros((0, 2 * S * 6), dtype=torch.float32)
+    return _gather_window_blocks(local, n_win, 2 * S * 6, windows_per_call, world, group, gather_device).reshape(n_win, 2 * S, 6)
+
+
+def _gather_window_blocks(local: torch.Tensor, n_win: int, width: int, windows_per_call: int, world: int, group, gather_device) -> torch.Tensor:
+    """all_gather of per-rank blocks [hi - lo, width] (blocks from sequence_block) -> [n_win, width] on every rank (CPU)"""
     if world == 1:
-        return local.reshape(n_win, 2 * S, 6)
+        return local
     if gather_device is None:
         gather_device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     wpc = max(1, int(windows_per_call))
     n_calls = (n_win + wpc - 1) // wpc
     nmax = ((n_calls + world - 1) // world) * wpc                       # the largest block, in windows
-    pad = torch.zeros((nmax, 2 * S * 6), dtype=torch.float32, device=gather_device)
-    pad[: hi - lo] = local.to(gather_device)
+    pad = torch.zeros((nmax, width), dtype=torch.float32, device=gather_device)
+    pad[: local.shape[0]] = local.to(gather_device)
     parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)                            # the ONE collective of the job: world x nmax x 2S x 6 floats
+    dist.all_gather(parts, pad, group=group)                            # the ONE collective of the job: world x nmax x width floats
     out = []
     for r in range(world):
         rlo, rhi = sequence_block(n_win, r, world, windows_per_call)
         out.append(parts[r][: rhi - rlo].cpu())
-    return torch.cat(out, 0).reshape(n_win, 2 * S, 6)
+    return torch.cat(out, 0)
+
+
+def odometry_sequence_sharded(net, frames: torch.Tensor, depths: torch.Tensor, K, opts=None, sources: int = 1, iterations: int = 4,
+                              windows_per_call: int = 8, target_pos: int = 0, group=None, gather_device: Optional[torch.device] = None,
+                              run_fn: Optional[Callable[..., Tuple[torch.Tensor, torch.Tensor]]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """tcsfm_odometry_sequence (PoseNet loop + refinement per window, run_sequential_optimization.py:186-247 with
+    train_mono.py:64-80 inside) over all ranks of `group`: blocks of whole calls + S overlap frames per rank, as
+    refine_sequence_sharded; ONE all_gather carries initial and refined poses together.
+    net: posenet.PoseNetHIP of this rank's engine (run_fn: stand-in for net.odometry_sequence in CPU tests).
+    -> (initial poses, refined poses), each [T-S, 2S, 6] on every rank (CPU tensors).  The PoseNet's work split depends on the
+    images per call only, and a block is a whole number of calls: bit-identical to the single-process run."""
+    T, S = int(frames.shape[0]), int(sources)
+    n_win = T - S
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = sequence_block(n_win, rank, world, windows_per_call)
+    if hi > lo:
+        run = run_fn or net.odometry_sequence
+        init, out = run(frames[lo:hi + S], depths[lo:hi + S], K, opts, sources=S, iterations=iterations, windows_per_call=windows_per_call,
+                        target_pos=target_pos)
+        local = torch.cat([torch.as_tensor(init).reshape(hi - lo, 2 * S * 6), torch.as_tensor(out).reshape(hi - lo, 2 * S * 6)], 1)
+    else:
+        local = torch.zeros((0, 4 * S * 6), dtype=torch.float32)
+    both = _gather_window_blocks(local, n_win, 4 * S * 6, windows_per_call, world, group, gather_device)
+    return both[:, : 2 * S * 6].reshape(n_win, 2 * S, 6), both[:, 2 * S * 6:].reshape(n_win, 2 * S, 6)
