@@ -11,7 +11,7 @@ for r in $(seq 1 $R); do
     cp $ROOT/tightly_coupled_sfm_amd/variants/$V $ROOT/tightly_coupled_sfm_amd/libtcsfm_hip.so
     python $ROOT/bench.py --cpu-sample 0 --sat-windows 32 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('$V', 'lin_us', d['roofline']['avg_launch_us'], 'sat_us', d['roofline_saturated']['avg_launch_us'], 'value', d['value'], 'single', d['single_stream']['value'])"
+d=json.loads(sys.stdin.readline()); print('$V', 'lin_us', d['roofline']['live']['avg_launch_us_in_kernel'], 'sat_us', d['roofline_saturated']['live']['avg_launch_us_in_kernel'], 'value', d['value'], 'single', d['single_stream']['value'])"
   done
 done
 cp /tmp/lib_keep.so $ROOT/tightly_coupled_sfm_amd/libtcsfm_hip.so
