@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--sat-windows", type=int, default=32, help="windows per call of the chip-filling roofline leg (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of wall time given to the CPU baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=3, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
+    ap.add_argument("--graph-replay", type=int, default=1, help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph "
+                    "(tcsfm_set_graph_replay: one host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches")
     ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered refined poses [world, pairs, 6] to this .npy file (tests)")
     args = ap.parse_args()
 
@@ -229,6 +231,8 @@ def main():
     dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
     eng = Engine(H, W, npairs, lanes=lanes)
     eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
+    if args.graph_replay:
+        eng.set_graph_replay(4)
     torch.cuda.synchronize()
     opts = default_opts(n_iters=ITERS)
     # the window form of the same batch (the library forms the fwd / inv pairs itself, bit-identical to the pair form): targets
@@ -248,12 +252,16 @@ def main():
         if distributed:
             dist.barrier()
 
+    enqueue_s = []       # host time spent enqueueing the K steps of a block (inside the block's wall time)
+
     def block(nl):
         fence(nl)
         t0 = time.perf_counter()
         for k in range(args.steps):
             step_on(k % nl)
+        t1 = time.perf_counter()
         fence(nl)
+        enqueue_s.append(t1 - t0)
         return time.perf_counter() - t0
 
     def timed(nl):
@@ -276,8 +284,22 @@ def main():
         return med, blocks
 
     elapsed, blocks = timed(lanes)
+    host_enqueue_us = float(np.median(enqueue_s)) / args.steps * 1e6
     for l in range(lanes):                   # a deferred device-side error of any lane surfaces here
         eng.lane_synchronize(l)
+    plain = None
+    if args.graph_replay:                    # the same blocks with plain launches (nine per call), for comparison; bit-identical poses
+        replayed = [o_.clone() for o_ in outs]
+        counts = eng.graph_replay_counts()
+        eng.set_graph_replay(0)
+        del enqueue_s[:]
+        p_el, p_blocks = timed(lanes)
+        plain = {"value": None, "ms_per_step": round(p_el / args.steps * 1e3, 5), "host_enqueue_us_per_step": round(float(np.median(enqueue_s)) / args.steps * 1e6, 2),
+                 "same_poses": bool(all(torch.equal(a_, b_) for a_, b_ in zip(replayed, outs))), "captures": counts[0], "replays": counts[1]}
+        for l in range(lanes):
+            eng.lane_synchronize(l)
+    # one call in flight: the host is not what binds (74 us of GPU time against 42 us of launches per call) and a graph launch adds
+    # ~4 us of GPU time to the call -- the latency figure uses plain launches
     single = timed(1) if lanes > 1 else (elapsed, blocks)       # the same steps strictly one after the other
     pose_io = outs[0]
 
@@ -429,9 +451,13 @@ def main():
             "ms_per_step_blocks": {"min": round(blocks[0] / args.steps * 1e3, 5), "median": round(elapsed / args.steps * 1e3, 5),
                                    "max": round(blocks[-1] / args.steps * 1e3, 5)},
             "single_stream": {"value": round(windows_per_block / single[0], 2), "ms_per_step": round(single[0] / args.steps * 1e3, 5),
-                              "what": "the same K-step blocks with ONE call in flight (steps_in_flight = 1): the per-call latency figure; "
+                              "what": "the same K-step blocks with ONE call in flight (steps_in_flight = 1), plain launches: the per-call latency figure; "
                                       "the headline keeps `steps_in_flight` independent calls in flight on the handle's lanes, which fills "
                                       "the idle time between the short kernels of a B=1 call"},
+            "host_enqueue_us_per_step": round(host_enqueue_us, 2),
+            "launch_mode": ("graph replay: every lane's call (same buffers every step) is captured once and launched as ONE HIP graph "
+                            "(tcsfm_set_graph_replay); same kernels, bit-identical poses" if args.graph_replay else "plain launches (9 per call)"),
+            "plain_launches": None if plain is None else dict(plain, value=round(windows_per_block / (plain["ms_per_step"] * args.steps * 1e-3), 2)),
             "final_gather_us": None if gather_us is None else round(gather_us, 1),
             "roofline": roof,
             "roofline_saturated": roof_sat,

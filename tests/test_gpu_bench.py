@@ -45,6 +45,10 @@ def test_bench_single_process():
     assert cb["one_thread"]["value"] > 0 and cb["one_thread"]["cores"] == 1
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert "workload" in d["config"] and d["roofline_saturated"]["achieved"] > rf["achieved"]
+    # the timed steps are graph replays of the lanes' calls (one capture per lane), checked against plain launches in the same run
+    pl = d["plain_launches"]
+    assert "graph replay" in d["launch_mode"] and pl["same_poses"] is True and pl["captures"] == 3 and pl["replays"] >= 60 - 6
+    assert pl["value"] > 100 and d["host_enqueue_us_per_step"] < pl["host_enqueue_us_per_step"]
 
 
 def _free_port():

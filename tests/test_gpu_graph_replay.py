@@ -1,0 +1,104 @@
+"""tcsfm_set_graph_replay: a repeated device-pointer refine call is captured once and replayed as one HIP graph -- same kernels,
+bit-identical results, whatever the buffers hold at replay time; everything else falls back to plain launches."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(H, W, seed):
+    from tightly_coupled_sfm_amd import synth
+    b = synth.make_batch(2, H, W, seed0=seed, both_directions=True)
+    return {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+
+
+def test_replay_is_bit_identical_and_counts():
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    d = _batch(H, W, 3)
+    o = default_opts(n_iters=4)
+    plain = Engine(H, W, 2)
+    want, _, _ = plain.refine(d["tgt"], d["src"], d["depth_t"], d["depth_s"], d["K"], d["pose_init"], o)
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2, lanes=2)
+    e.use_own_stream()
+    e.set_graph_replay(2)
+    win = dict(tgt=d["tgt"][0:1].contiguous(), srcs=d["src"][0:1].contiguous()[None], depth_t=d["depth_t"][0:1].contiguous(),
+               depth_s=d["depth_s"][0:1].contiguous()[None], K=d["K"][0:1].contiguous(), pose=d["pose_init"].clone())
+    outs = [torch.zeros_like(win["pose"]) for _ in range(2)]
+    for rep in range(5):
+        for lane in range(2):
+            outs[lane].zero_()
+        torch.cuda.synchronize()                        # (the engine runs on its own non-blocking streams: order torch's work by hand)
+        for lane in range(2):
+            e.refine_window_async(lane, win["tgt"], win["srcs"], win["depth_t"], win["depth_s"], win["K"], win["pose"], outs[lane], o)
+        for lane in range(2):
+            e.lane_synchronize(lane)
+            assert torch.equal(outs[lane], want), (rep, lane)
+    assert e.graph_replay_counts() == (2, 6)            # per lane: plain, capture (+ launch), then three replays
+    # the graph reads the buffers, not a snapshot: new contents in the same tensors give the new problem's result
+    d2 = _batch(H, W, 11)
+    want2, _, _ = plain.refine(d2["tgt"], d2["src"], d2["depth_t"], d2["depth_s"], d2["K"], d2["pose_init"], o)
+    win["tgt"].copy_(d2["tgt"][0:1]); win["srcs"].copy_(d2["src"][0:1][None]); win["depth_t"].copy_(d2["depth_t"][0:1])
+    win["depth_s"].copy_(d2["depth_s"][0:1][None]); win["pose"].copy_(d2["pose_init"])
+    torch.cuda.synchronize()
+    e.refine_window_async(1, win["tgt"], win["srcs"], win["depth_t"], win["depth_s"], win["K"], win["pose"], outs[1], o)
+    e.lane_synchronize(1)
+    assert torch.equal(outs[1], want2) and e.graph_replay_counts() == (2, 7)
+    # other options = another call: seen for the first time, launched plainly
+    o8 = default_opts(n_iters=2)
+    w8, _, _ = plain.refine(d2["tgt"], d2["src"], d2["depth_t"], d2["depth_s"], d2["K"], d2["pose_init"], o8)
+    e.refine_window_async(1, win["tgt"], win["srcs"], win["depth_t"], win["depth_s"], win["K"], win["pose"], outs[1], o8)
+    e.lane_synchronize(1)
+    assert torch.equal(outs[1], w8) and e.graph_replay_counts() == (2, 7)
+    # switched off: captures dropped, plain launches, same bits
+    e.set_graph_replay(0)
+    e.refine_window_async(0, win["tgt"], win["srcs"], win["depth_t"], win["depth_s"], win["K"], win["pose"], outs[0], o)
+    e.lane_synchronize(0)
+    assert torch.equal(outs[0], want2) and e.graph_replay_counts() == (2, 7)
+
+
+def test_replay_eviction_pair_form_lm_and_bypasses():
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 48, 160
+    a, b = _batch(H, W, 1), _batch(H, W, 2)
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2)
+    e.use_own_stream()
+    e.set_graph_replay(1)                               # one slot: two alternating calls evict each other, never replayed
+    o = default_opts(n_iters=3, solver=1, lambda0=1e-3, w_dc=0.15)
+    ref = Engine(H, W, 2)
+    wa, _, _ = ref.refine(a["tgt"], a["src"], a["depth_t"], a["depth_s"], a["K"], a["pose_init"], o)
+    wb, _, _ = ref.refine(b["tgt"], b["src"], b["depth_t"], b["depth_s"], b["K"], b["pose_init"], o)
+    oa, ob = torch.empty_like(wa), torch.empty_like(wb)
+    for _ in range(3):
+        e.refine_into(a["tgt"], a["src"], a["depth_t"], a["depth_s"], a["K"], a["pose_init"], oa, o)
+        e.refine_into(b["tgt"], b["src"], b["depth_t"], b["depth_s"], b["K"], b["pose_init"], ob, o)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, wa) and torch.equal(ob, wb) and e.graph_replay_counts() == (0, 0)
+    e.set_graph_replay(2)                               # two slots: both captured (LM: six launches + the cost-only pass), both replayed
+    for _ in range(4):
+        e.refine_into(a["tgt"], a["src"], a["depth_t"], a["depth_s"], a["K"], a["pose_init"], oa, o)
+        e.refine_into(b["tgt"], b["src"], b["depth_t"], b["depth_s"], b["K"], b["pose_init"], ob, o)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, wa) and torch.equal(ob, wb) and e.graph_replay_counts() == (2, 5)      # (b was already seen once above)
+    # profiling brackets need their own launches: bypass while profiling, replay again afterwards
+    e.profile_begin()
+    e.refine_into(a["tgt"], a["src"], a["depth_t"], a["depth_s"], a["K"], a["pose_init"], oa, o)
+    pr = e.profile_end()
+    assert pr["linearize"][1] == 4 and e.graph_replay_counts() == (2, 5)            # 3 linearisations + the cost-only pass, bracketed one by one
+    e.refine_into(a["tgt"], a["src"], a["depth_t"], a["depth_s"], a["K"], a["pose_init"], oa, o)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, wa) and e.graph_replay_counts() == (2, 6)
+    # host pointers are never captured
+    oh = default_opts(n_iters=3, solver=1, lambda0=1e-3, w_dc=0.15, host_ptrs=1)
+    hp = {k: v.cpu().numpy() for k, v in a.items()}
+    out = np.empty((2, 6), np.float32)
+    import ctypes as C
+    P = lambda x: x.ctypes.data_as(C.c_void_p)
+    for _ in range(3):
+        rc = e.lib.tcsfm_refine(e._h, C.byref(oh), 2, P(hp["tgt"]), P(hp["src"]), P(hp["depth_t"]), P(hp["depth_s"]), P(hp["K"]), P(hp["pose_init"]), None,
+                                P(out), None, None)
+        assert rc == 0
+    assert np.array_equal(out, wa.cpu().numpy()) and e.graph_replay_counts() == (2, 6)

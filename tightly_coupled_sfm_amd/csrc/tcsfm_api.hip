@@ -84,8 +84,17 @@ struct tcsfm_ctx {
     hipStream_t seq_copy = nullptr;
     std::vector<hipEvent_t> seq_copied, seq_done, seq_raw;      // per chunk: frames usable by the lanes / per call: done / per chunk: raw frames landed
     hipStream_t seq_pack = nullptr;    // k_frame_pack runs here, behind the chunk's copy (event), beside the next chunk's copy
-    const float *K_checked = nullptr;  // device intrinsics pointer (and count) that already passed the pinhole check
-    int K_checked_n = 0;
+    struct KOk { const float *p; int n; };
+    KOk K_ok[4] = {{nullptr, 0}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};   // device intrinsics pointers (and counts) that already passed the pinhole check
+    int K_ok_next = 0;
+    // tcsfm_set_graph_replay: repeated device-pointer refine calls (same arguments) replayed as ONE captured HIP graph
+    struct CallKey { tcsfm_opts o; int N, win_B, win_S, pad; const void *p[10]; };
+    struct CallGraph { CallKey key; hipGraphExec_t exec; int seen; unsigned long long used; };
+    int graph_slots = 0;               // 0: off
+    std::vector<CallGraph> graphs;
+    unsigned long long graph_clock = 0;
+    int graph_captures = 0, graph_replays = 0;
+    bool capturing = false;
     unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
     int *trace_decide = nullptr;
     long long trace_bits_cap = 0, trace_decide_cap = 0;
@@ -131,10 +140,21 @@ int fail(tcsfm_ctx *h, int code, const char *msg) {
 
 // The device-side pinhole guards (init_pair, k_ground) raise a host-mapped status word; it is reported -- as the documented
 // TCSFM_E_INTRINSICS -- by the next call on the handle or by tcsfm_synchronize, without a device synchronisation of its own.
+static bool k_known(const tcsfm_ctx *h, const float *K, int n) {
+    for (const auto &k : h->K_ok) if (k.p == K && K && n <= k.n) return true;
+    return false;
+}
+static void k_add(tcsfm_ctx *h, const float *K, int n) {
+    for (auto &k : h->K_ok) if (k.p == K) { if (n > k.n) k.n = n; return; }
+    h->K_ok[h->K_ok_next] = {K, n};
+    h->K_ok_next = (h->K_ok_next + 1) % 4;
+}
+static void k_forget(tcsfm_ctx *h) { for (auto &k : h->K_ok) k = {nullptr, 0}; }
+
 int pending_error(tcsfm_ctx *h) {
     if (h->err_host && *reinterpret_cast<volatile int *>(h->err_host)) {
         *reinterpret_cast<volatile int *>(h->err_host) = 0;
-        h->K_checked = nullptr;
+        k_forget(h);
         return fail(h, TCSFM_E_INTRINSICS, "an earlier asynchronous call was given non-pinhole intrinsics (detected on the device): its results are NaN");
     }
     return TCSFM_OK;
@@ -213,7 +233,7 @@ int check_intrinsics(tcsfm_ctx *h, const tcsfm_opts *o, const float *K_host_or_d
     // Device intrinsics are validated with one blocking D2H copy the FIRST time a (pointer, count) is seen; repeated calls
     // on the same buffer (a sequence, the bench loop) stay fully asynchronous.  The device side guards independently:
     // init_pair() poisons the pose with NaN when K is not pinhole, so a buffer mutated behind our back still fails loudly.
-    if (!o->host_ptrs && K_host_or_dev == h->K_checked && n <= h->K_checked_n) return TCSFM_OK;
+    if (!o->host_ptrs && k_known(h, K_host_or_dev, n)) return TCSFM_OK;
     std::vector<float> k((size_t)n * 9);
     if (o->host_ptrs) memcpy(k.data(), K_host_or_dev, k.size() * sizeof(float));
     else {
@@ -225,7 +245,7 @@ int check_intrinsics(tcsfm_ctx *h, const tcsfm_opts *o, const float *K_host_or_d
         if (K[1] != 0.f || K[3] != 0.f || K[6] != 0.f || K[7] != 0.f || K[8] != 1.f || !(K[0] != 0.f) || !(K[4] != 0.f))
             return fail(h, TCSFM_E_INTRINSICS, "intrinsics must be pinhole [fx 0 cx; 0 fy cy; 0 0 1]");
     }
-    if (!o->host_ptrs) { h->K_checked = K_host_or_dev; h->K_checked_n = n; }
+    if (!o->host_ptrs) k_add(h, K_host_or_dev, n);
     return TCSFM_OK;
 }
 
@@ -649,6 +669,8 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
     if (h->aux_join) (void)hipEventDestroy(h->aux_join);
     if (h->seq_pack) { (void)hipStreamSynchronize(h->seq_pack); (void)hipStreamDestroy(h->seq_pack); }
+    for (auto &g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
     for (auto &e : h->seq_copied) (void)hipEventDestroy(e);
     for (auto &e : h->seq_raw) (void)hipEventDestroy(e);
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
@@ -670,7 +692,7 @@ void tcsfm_destroy(tcsfm_handle h) {
 int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
     if (!h) return TCSFM_E_ARG;
     h->stream = (hipStream_t)hip_stream;  // NULL = legacy default stream
-    h->K_checked = nullptr;               // a new stream is a new producer of the caller's buffers: validate intrinsics again
+    k_forget(h);                          // a new stream is a new producer of the caller's buffers: validate intrinsics again
     return TCSFM_OK;
 }
 
@@ -953,9 +975,9 @@ int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, co
 // frame-level pack cache of a sequence call (kernels.h k_frame_pack / k_pack_cached): the ring's packed frames, and where this call's windows start
 struct FrameCache { const float4 *fpack; const float *fdepth; int slot0, tpos; };
 
-static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
-                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr, const FrameCache *fc = nullptr) {
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo, const FrameCache *fc) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
@@ -1037,6 +1059,83 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs == 1) HIPCHK(h, hipStreamSynchronize(h->stream));   // host_ptrs == 2: pinned + asynchronous, the caller synchronises
     return TCSFM_OK;
+}
+
+// Graph replay (tcsfm_set_graph_replay).  A B = 1 refinement is nine short launches: ~42 us of host time against ~40 us of GPU time
+// per call with three calls in flight -- on a slow host the launches, not the kernels, set the rate.  A call whose arguments (options,
+// sizes, every pointer) equal those of an earlier call on this handle / lane is captured once (the second time it is seen: the first
+// run validates the intrinsics and allocates scratch, which a capture must not) and replayed with ONE hipGraphLaunch from then on.
+// The kernels, their order and their arguments are exactly those of the plain path: results are bit-identical.
+static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr, const FrameCache *fc = nullptr) {
+    const bool eligible = h && o && h->graph_slots > 0 && !h->capturing && !o->host_ptrs && !wo && !fc && !h->profiling && !h->trace_bits &&
+                          !h->trace_decide && !h->dbg_stamps && h->stream != nullptr;
+    if (!eligible) return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    tcsfm_ctx::CallKey key;
+    memset(&key, 0, sizeof(key));
+    key.o = *o; key.N = N; key.win_B = win_B; key.win_S = win_S;
+    const void *ptrs[10] = {tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out};
+    memcpy(key.p, ptrs, sizeof(ptrs));
+    tcsfm_ctx::CallGraph *e = nullptr;
+    for (auto &g : h->graphs) if (!memcmp(&g.key, &key, sizeof(key))) { e = &g; break; }
+    if (e && e->exec) {                                    // replay
+        int rc = check_common(h, o, N);
+        if (rc) return rc;
+        DeviceGuard dev_guard(h->device);
+        if (int rc_ = pending_error(h)) return rc_;
+        e->used = ++h->graph_clock;
+        if (h->tickets_dirty) {                            // (a failed call may have left group tickets non-zero: what run_pack would do)
+            HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp_alloc * sizeof(int), h->stream));
+            h->tickets_dirty = false;
+        }
+        HIPCHK(h, hipGraphLaunch(e->exec, h->stream));
+        h->graph_replays++;
+        return TCSFM_OK;
+    }
+    if (!e) {                                              // first sighting: plain run, remember the call
+        if ((int)h->graphs.size() >= h->graph_slots) {     // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); i++) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+            if (h->graphs[lru].exec) (void)hipGraphExecDestroy(h->graphs[lru].exec);
+            h->graphs.erase(h->graphs.begin() + lru);
+        }
+        tcsfm_ctx::CallGraph g;
+        g.key = key; g.exec = nullptr; g.seen = 1; g.used = ++h->graph_clock;
+        h->graphs.push_back(g);
+        return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    }
+    e->used = ++h->graph_clock;
+    const int nimg_t = win_B ? win_B : N;
+    if (e->seen != 1 || !k_known(h, K, nimg_t))      // marked uncapturable, or the intrinsics would be re-validated (a blocking copy)
+        return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    {                                                      // second sighting: capture the plain path's launches
+        DeviceGuard dev_guard(h->device);
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            e->seen = -1;
+            return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+        }
+        h->capturing = true;
+        const std::string err_before = h->err;
+        int rc = refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+        h->capturing = false;
+        hipGraph_t graph = nullptr;
+        hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc == TCSFM_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            e->exec = exec;
+            h->graph_captures++;
+            HIPCHK(h, hipGraphLaunch(exec, h->stream));
+            return TCSFM_OK;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        e->seen = -1;                                      // not capturable in this configuration: plain launches from now on
+        h->err = err_before;
+    }
+    return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
 }
 
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
@@ -1311,8 +1410,33 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
         hipError_t e = hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming);
         if (e != hipSuccess) { tcsfm_destroy(c); return fail(h, TCSFM_E_HIP, "tcsfm_set_lanes: hipEventCreate failed"); }
+        c->graph_slots = h->graph_slots;
         h->lanes.push_back(c);
     }
+    return TCSFM_OK;
+}
+
+static void drop_graphs(tcsfm_ctx *c) {
+    for (auto &g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
+int tcsfm_set_graph_replay(tcsfm_handle h, int max_graphs) {
+    if (!h) return TCSFM_E_ARG;
+    if (max_graphs < 0 || max_graphs > 64) return fail(h, TCSFM_E_ARG, "tcsfm_set_graph_replay: 0 <= max_graphs <= 64");
+    DeviceGuard dev_guard(h->device);
+    h->graph_slots = max_graphs;
+    if ((int)h->graphs.size() > max_graphs) drop_graphs(h);
+    for (tcsfm_ctx *c : h->lanes) { c->graph_slots = max_graphs; if ((int)c->graphs.size() > max_graphs) drop_graphs(c); }
+    return TCSFM_OK;
+}
+
+int tcsfm_graph_replay_counts(tcsfm_handle h, int *captures, int *replays) {
+    if (!h) return TCSFM_E_ARG;
+    int c_ = h->graph_captures, r_ = h->graph_replays;
+    for (tcsfm_ctx *c : h->lanes) { c_ += c->graph_captures; r_ += c->graph_replays; }
+    if (captures) *captures = c_;
+    if (replays) *replays = r_;
     return TCSFM_OK;
 }
 
@@ -1497,7 +1621,7 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
         if (pn && !(net[l] = pn_for_lane(pn, lane[l]))) return fail(h, TCSFM_E_NOMEM, "tcsfm_odometry_sequence: no memory for a lane's PoseNet activations");
         ls[l] = l == 0 ? h->stream : lane[l]->own_stream;
         lane[l]->stream = ls[l];
-        lane[l]->K_checked = h->seq_K; lane[l]->K_checked_n = WB;    // validated on the host above
+        k_add(lane[l], h->seq_K, WB);        // validated on the host above
     }
     std::vector<long long> slot_reader(R, -1);             // last CALL that reads the frame in this slot (-1: none pending)
     const int np = np_of(&o);

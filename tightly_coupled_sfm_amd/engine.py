@@ -375,6 +375,17 @@ class Engine:
     # -- lanes: several refinements in flight (include/tcsfm.h "lanes") -----------------------------------------
     def set_lanes(self, n: int):
         self._call(self.lib.tcsfm_set_lanes(self._h, int(n)))
+
+    def set_graph_replay(self, max_graphs: int = 4):
+        """tcsfm_set_graph_replay: repeated device-pointer refine calls (same tensors, same options) are captured once and
+        replayed as one HIP graph per call -- one host launch instead of nine; bit-identical results.  0 switches it off."""
+        self._call(self.lib.tcsfm_set_graph_replay(self._h, int(max_graphs)))
+
+    def graph_replay_counts(self):
+        """(captures, replays) so far, handle + lanes"""
+        c, r = C.c_int(0), C.c_int(0)
+        self._call(self.lib.tcsfm_graph_replay_counts(self._h, C.byref(c), C.byref(r)))
+        return c.value, r.value
         self.lanes = int(n)
 
     def refine_window_async(self, lane: int, tgt, srcs, depth_t, depth_s, K, pose, pose_out, opts: Opts, log_scale=None, log_scale_out=None):
