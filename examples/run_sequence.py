@@ -51,11 +51,14 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--sources", type=int, default=1, choices=(1, 2))
     ap.add_argument("--gn-iters", type=int, default=8)
+    ap.add_argument("--window-rule", default="reference", choices=("reference", "pair"),
+                    help="S = 2: minimise the reference's own compute_optimization_loss (default, as the mirror does) or every directed pair's "
+                         "own cost (converges in about half the iterations: DESIGN.md section 2)")
     args = ap.parse_args()
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
     rng = np.random.default_rng(0)
     options = {"diff_img_argmin": True, "automasking": True, "mode": "scaled", "l_depth_consist": True, "l_depth_consist_weight": 0.15,
-               "l_inverse_reconstruction": True, "num_source_imgs": args.sources, "gn_iters": args.gn_iters}
+               "l_inverse_reconstruction": True, "num_source_imgs": args.sources, "gn_iters": args.gn_iters, "window_rule": args.window_rule}
     config = {"minibatch": 1, "device": "cuda", "min_depth": 0.06, "max_depth": 2.67, "iterations": 1, "camera_height": 1.65, "flow_type": "none"}
     gt, init, opt, conv, t_total = [], [], [], [], 0.0
     for i in range(args.frames):
