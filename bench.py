@@ -26,6 +26,9 @@ the data path); one RCCL all_gather of the refined poses AFTER the timed region 
 separately (`final_gather_us`).
 
 The JSON line also carries
+  launch_mode   the lanes' calls of the timed region were enqueued either as plain launches (nine per call) or as one captured HIP graph
+                per call (tcsfm_set_graph_replay; same kernels, same bits): untimed probe blocks of both modes decide (--graph-replay
+                auto), `other_mode` repeats the blocks in the mode that lost, `host_enqueue_us_per_step` is the host's share of a step.
   roofline      dominant kernel (k_linearize): algorithmic bytes (32 B/pixel/pair/iteration) per launch divided by the
                 launch's duration.  Headline `frac` / `achieved` / `avg_launch_us`: rocprofv3's AverageNs of the kernel in the
                 COMMITTED --kernel-trace --stats run of this command with one call in flight (profiles/<tag>_lanes1_kernel_stats.csv;
@@ -187,8 +190,10 @@ def main():
     ap.add_argument("--sat-windows", type=int, default=32, help="windows per call of the chip-filling roofline leg (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of wall time given to the CPU baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=3, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
-    ap.add_argument("--graph-replay", type=int, default=1, help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph "
-                    "(tcsfm_set_graph_replay: one host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches")
+    ap.add_argument("--graph-replay", default="auto", choices=("auto", "0", "1"),
+                    help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph (tcsfm_set_graph_replay: one "
+                         "host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches; auto: untimed blocks of "
+                         "both before the timed region, the faster mode is timed (a slow host favours replay, a fast one plain launches)")
     ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered refined poses [world, pairs, 6] to this .npy file (tests)")
     args = ap.parse_args()
 
@@ -231,8 +236,6 @@ def main():
     dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
     eng = Engine(H, W, npairs, lanes=lanes)
     eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
-    if args.graph_replay:
-        eng.set_graph_replay(4)
     torch.cuda.synchronize()
     opts = default_opts(n_iters=ITERS)
     # the window form of the same batch (the library forms the fwd / inv pairs itself, bit-identical to the pair form): targets
@@ -283,21 +286,50 @@ def main():
         med = blocks[len(blocks) // 2] if len(blocks) % 2 else 0.5 * (blocks[len(blocks) // 2 - 1] + blocks[len(blocks) // 2])
         return med, blocks
 
+    windows_per_block = args.steps * B * world
+
+    def set_mode(replay):    # launch mode of the lanes' calls; replay: every lane's call captured now, outside any timed block
+        eng.set_graph_replay(4 if replay else 0)
+        if replay:
+            for _ in range(3):
+                for l in range(lanes):
+                    step_on(l)
+        fence(lanes)
+
+    def probe(replay):       # untimed: median of a few K-step blocks in this mode
+        set_mode(replay)
+        for k in range(args.warmup):
+            step_on(k % lanes)
+        ts = sorted(block(lanes) for _ in range(int(min(16, max(3, np.ceil(0.01 * 1e3 / max(args.steps * 0.05, 1e-9)))))))
+        return ts[len(ts) // 2]
+
+    if args.graph_replay == "auto":
+        t_mode = torch.tensor([probe(False), probe(True)], device=coll_dev, dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(t_mode, op=dist.ReduceOp.MAX)     # every rank takes the same decision: the slowest rank's times
+        use_replay = bool(t_mode[1] < t_mode[0])
+    else:
+        use_replay = args.graph_replay == "1"
+    set_mode(use_replay)
+    del enqueue_s[:]
     elapsed, blocks = timed(lanes)
     host_enqueue_us = float(np.median(enqueue_s)) / args.steps * 1e6
     for l in range(lanes):                   # a deferred device-side error of any lane surfaces here
         eng.lane_synchronize(l)
-    plain = None
-    if args.graph_replay:                    # the same blocks with plain launches (nine per call), for comparison; bit-identical poses
-        replayed = [o_.clone() for o_ in outs]
-        counts = eng.graph_replay_counts()
-        eng.set_graph_replay(0)
-        del enqueue_s[:]
-        p_el, p_blocks = timed(lanes)
-        plain = {"value": None, "ms_per_step": round(p_el / args.steps * 1e3, 5), "host_enqueue_us_per_step": round(float(np.median(enqueue_s)) / args.steps * 1e6, 2),
-                 "same_poses": bool(all(torch.equal(a_, b_) for a_, b_ in zip(replayed, outs))), "captures": counts[0], "replays": counts[1]}
-        for l in range(lanes):
-            eng.lane_synchronize(l)
+    # the same blocks in the OTHER launch mode, for comparison; bit-identical poses
+    mine_out = [o_.clone() for o_ in outs]
+    counts = eng.graph_replay_counts()
+    set_mode(not use_replay)
+    del enqueue_s[:]
+    o_el, _ = timed(lanes)
+    counts2 = eng.graph_replay_counts()
+    other = {"mode": "plain launches (9 per call)" if use_replay else "graph replay", "value": round(windows_per_block / o_el, 2),
+             "ms_per_step": round(o_el / args.steps * 1e3, 5), "host_enqueue_us_per_step": round(float(np.median(enqueue_s)) / args.steps * 1e6, 2),
+             "same_poses": bool(all(torch.equal(a_, b_) for a_, b_ in zip(mine_out, outs))),
+             "captures": max(counts[0], counts2[0]), "replays": max(counts[1], counts2[1])}
+    for l in range(lanes):
+        eng.lane_synchronize(l)
+    eng.set_graph_replay(0)
     # one call in flight: the host is not what binds (74 us of GPU time against 42 us of launches per call) and a graph launch adds
     # ~4 us of GPU time to the call -- the latency figure uses plain launches
     single = timed(1) if lanes > 1 else (elapsed, blocks)       # the same steps strictly one after the other
@@ -455,9 +487,10 @@ def main():
                                       "the headline keeps `steps_in_flight` independent calls in flight on the handle's lanes, which fills "
                                       "the idle time between the short kernels of a B=1 call"},
             "host_enqueue_us_per_step": round(host_enqueue_us, 2),
-            "launch_mode": ("graph replay: every lane's call (same buffers every step) is captured once and launched as ONE HIP graph "
-                            "(tcsfm_set_graph_replay); same kernels, bit-identical poses" if args.graph_replay else "plain launches (9 per call)"),
-            "plain_launches": None if plain is None else dict(plain, value=round(windows_per_block / (plain["ms_per_step"] * args.steps * 1e-3), 2)),
+            "launch_mode": {"timed": ("graph replay: every lane's call (same buffers every step) is captured once and launched as ONE HIP graph "
+                                      "(tcsfm_set_graph_replay); same kernels, bit-identical poses" if use_replay else "plain launches (9 per call)"),
+                            "chosen_by": ("untimed probe blocks of both modes before the timed region" if args.graph_replay == "auto" else "--graph-replay " + args.graph_replay),
+                            "other_mode": other},
             "final_gather_us": None if gather_us is None else round(gather_us, 1),
             "roofline": roof,
             "roofline_saturated": roof_sat,

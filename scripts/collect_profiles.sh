@@ -19,6 +19,6 @@ for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BU
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY" \
          "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $P | cut -d' ' -f1)
-  rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --lanes 1 --steps 20 --warmup 5 --cpu-sample 0 --sat-windows 0 > $OUT/pmc_$tag.log 2>&1
+  rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_$tag -- python $ROOT/bench.py --lanes 1 --graph-replay 0 --steps 20 --warmup 5 --cpu-sample 0 --sat-windows 0 > $OUT/pmc_$tag.log 2>&1   # (plain launches under counter collection)
 done
 ls $OUT

@@ -45,10 +45,12 @@ def test_bench_single_process():
     assert cb["one_thread"]["value"] > 0 and cb["one_thread"]["cores"] == 1
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert "workload" in d["config"] and d["roofline_saturated"]["achieved"] > rf["achieved"]
-    # the timed steps are graph replays of the lanes' calls (one capture per lane), checked against plain launches in the same run
-    pl = d["plain_launches"]
-    assert "graph replay" in d["launch_mode"] and pl["same_poses"] is True and pl["captures"] == 3 and pl["replays"] >= 60 - 6
-    assert pl["value"] > 100 and d["host_enqueue_us_per_step"] < pl["host_enqueue_us_per_step"]
+    # both launch modes ran (the faster one in the timed region, chosen on untimed probe blocks) and gave the same bits
+    lm = d["launch_mode"]
+    ot = lm["other_mode"]
+    assert ("graph replay" in lm["timed"]) != ("graph replay" in ot["mode"]) and "probe" in lm["chosen_by"]
+    assert ot["same_poses"] is True and ot["captures"] >= 3 and ot["replays"] >= 60 - 6 and ot["value"] > 100
+    assert d["host_enqueue_us_per_step"] > 0 and ot["host_enqueue_us_per_step"] > 0
 
 
 def _free_port():
