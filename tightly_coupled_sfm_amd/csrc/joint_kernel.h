@@ -234,8 +234,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             }
             float diff = e1 + e2;
             float m = (real && ax.y > 0.5f && (!J.automask || diff < ax.z)) ? 1.f : 0.f;
-            if (P.ext_mask != nullptr)      // min over the sources: the selection mask of forward pair n
-                m = (real && P.ext_mask[(size_t)n * hw + (size_t)(real ? gy_ * W + gx_ : 0)] != 0.f) ? 1.f : 0.f;
+            if (P.ext_diff != nullptr)      // min over the sources: does forward pair n keep this pixel?
+                m = (real && ext_selected(P, n, gy_ * W + gx_, hw)) ? 1.f : 0.f;
             float w = m * ax.x;    // M_s W_s
             float4 *cr = coef + (ly * W1 + lx) * 3;
             lds_write1(cr + 0, w * cA[0], w * cA[1], w * cA[2], w * cB[0]);

@@ -13,7 +13,6 @@
 //                   curvature -> per-workgroup J'J / J'r partial sums.  Reads 36 B/pixel, writes one partial-sum record
 //                   per workgroup; measured VALU-issue bound (~1050 instructions per 64-pixel wave), see DESIGN.md.
 //                   MODE_COST / MODE_MAPS variants: scalar cost only / the reference's residual maps.
-//   k_select      window form with the min over sources (optimizer.py:47-69): per-pixel selection masks of the forward pairs
 //   k_solve       once per iteration, one workgroup per pair: deterministic fp64 reduction of the partial sums,
 //                   LM/GN logic, lane-parallel Gauss-Jordan on the 6x6 / 7x7 system, SE(3) retraction, emits the fp32
 //                   constants of the next iteration.
@@ -67,8 +66,10 @@ struct LinParams {
     int shared_image;       // all problems read packed image pair 0 (loss-surface sweeps); kept OUT of PairConst so that the
                             // first image loads do not wait for the scalar loads of the pair constants
     int direct;             // 1: no in-launch group reduction -- k_solve sums the workgroup records itself (small grids)
-    const float *ext_mask;  // dense window mode: [n_ext][H][W] min-over-sources selection replacing the own mask of pairs n < n_ext
-    int n_ext;
+    // dense window modes: residual maps [ext_S * ext_B][H][W] of the forward pairs (k_linearize<MODE_MAPS> at the current poses); the
+    // min-over-sources selection formed from them (ext_selected) replaces the own mask of pairs n < n_ext
+    const float *ext_diff, *ext_valid;
+    int n_ext, ext_B, ext_S;
     int sel_B, sel_S;       // k_linearize<SEL>: window geometry; pairs n < sel_B * sel_S are the forward pairs n = s * sel_B + b
     // Frame-level pack cache (sequence calls, tcsfm_refine_sequence): the packed source image (rgb + depth, zero border) and the
     // converted depth plane exist ONCE per frame of the ring (k_frame_pack, when the frame's copy lands) instead of once per
@@ -526,29 +527,22 @@ __global__ __launch_bounds__(256) void k_pack_cached(PackCachedParams P) {
     P.tgtpack[(size_t)n * hw + idx] = make_float4(tc.x, tc.y, tc.z, ae);
 }
 
-// Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69): from the forward pairs'
-// diff / valid maps at the current poses -> one 0/1 selection mask per forward pair (see oracle orc_window_select).
-struct SelectParams {
-    const float *diff, *valid;   // [S*B][H*W] written by k_linearize<MODE_MAPS>
-    const float4 *tgtpack;       // .w = auto_err of the pair
-    float *mask;                 // [S*B][H*W]
-    int B, S, hw, automask;
-};
-
-__global__ __launch_bounds__(256) void k_select(SelectParams P) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (idx >= P.hw) return;
+// Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69; oracle orc_window_select), dense window
+// modes: does forward pair n = s B + b keep pixel gi?  From the residual maps of all sources of its target at the current poses: the
+// source with the smallest error (first minimum, as torch.min), under the union validity and the auto-mask of the minima.  Every
+// workgroup that needs the answer computes it (a few loads per pixel) -- a separate selection launch cost more than that.
+__device__ __forceinline__ bool ext_selected(const LinParams &P, int n, int gi, int hw) {
+    const int b = n % P.ext_B, s_own = n / P.ext_B;
     int smin = 0;
     float dmin = 0.f, amin = 0.f, vany = 0.f;
-    for (int s = 0; s < P.S; s++) {
-        const size_t o = (size_t)(s * P.B + b) * P.hw + idx;
-        const float d = P.diff[o], a = P.tgtpack[o].w, v = P.valid[o];
-        if (s == 0 || d < dmin) { dmin = d; smin = s; }      // first minimum, like torch.min
+    for (int s = 0; s < P.ext_S; s++) {
+        const size_t o = (size_t)(s * P.ext_B + b) * hw + gi;
+        const float d = P.ext_diff[o], a = P.tgtpack[o].w, v = P.ext_valid[o];
+        if (s == 0 || d < dmin) { dmin = d; smin = s; }
         amin = (s == 0) ? a : fminf(amin, a);
         vany = fmaxf(vany, v);
     }
-    const bool keep = vany > 0.f && (!P.automask || dmin < amin);
-    for (int s = 0; s < P.S; s++) P.mask[(size_t)(s * P.B + b) * P.hw + idx] = (keep && s == smin) ? 1.f : 0.f;
+    return vany > 0.f && (!P.automask || dmin < amin) && s_own == smin;
 }
 
 // SSIM_Loss.forward, losses.py:27-41, on C planes of N images: x, y [N*C, H, W] -> out (same shape)
@@ -886,7 +880,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     // For a forward pair n = s B + b the other sources of target b are warped with THEIR poses (and their copy of the target
     // depth), colours only, and their photometric error at the tile's pixels is reduced to four numbers per pixel: the smallest
     // error among the sources before / after s (torch.min keeps the FIRST minimum), the union of their validity and the
-    // smallest auto-mask threshold.  Same arithmetic as the maps pass + k_select pair it replaces, without the two launches.
+    // smallest auto-mask threshold.  Same arithmetic as the maps pass + selection it replaces (the dense modes keep the maps pass: ext_selected).
     float sel_before = 3.0e38f, sel_after = 3.0e38f, sel_valid = 0.f, sel_ae = 3.0e38f;
     float sel_w0 = 1.f;      // REFERENCE rule: depth-consistency weight of SOURCE 0 at this pixel (pairs of the other sources)
     const bool sel_pair = SEL && n < P.sel_B * P.sel_S;

@@ -56,7 +56,7 @@ struct tcsfm_ctx {
     int jrec_S = 0;
     hipStream_t aux_stream = nullptr;  // joint dense mode: the inverse pairs' refinement runs beside the forward group's (fork / join by events)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-    float *sel_maps = nullptr;   // window mode scratch: diff | valid | selection mask, [3][max_pairs][H*W], allocated on first use
+    float *sel_maps = nullptr;   // dense window modes: the forward pairs' diff | valid maps, [2][max_pairs][H*W], allocated on first use
     unsigned *scale_keys = nullptr, *scale_hist = nullptr;   // scale recovery scratch (keys, 256 bins + 4 state words)
     long long *dbg_stamps = nullptr;  // TCSFM_DEBUG_STAMPS=1: 8 wall-clock stamps of the last k_solve launch (100 MHz ticks)
     std::vector<HostStage> stage;
@@ -433,7 +433,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     int rc;
     constexpr int DTW = 32, DTH = 16, DNT = 512;
     const int tiles_x = (h->W + DTW - 1) / DTW, tiles_y = (h->H + DTH - 1) / DTH, nblk = tiles_x * tiles_y;
-    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
+    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
     if (!h->dense_rec) {
         HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
@@ -467,9 +467,8 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     // ---- forward group: joint
     LinParams Pj = lin_params(h, &oo, 6);
     Pj.tiles_x = tiles_x; Pj.tiles_y = tiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
-    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
-          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
-    if (n_sel) { Pj.ext_mask = sel_mask; Pj.n_ext = n_sel; }
+    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr;
+    if (n_sel) { Pj.ext_diff = sel_diff; Pj.ext_valid = sel_valid; Pj.n_ext = n_sel; Pj.ext_B = B; Pj.ext_S = S; }
     JointParams J;
     J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = o->lambda_depth; J.w_prior = o->prior_depth;
     J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
@@ -546,11 +545,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
         if (n_sel) {       // selection masks of the forward pairs at the current poses and the current SHARED depth
             LinParams M = lin_params(h, &oo, 6);
             M.o_diff = sel_diff; M.o_valid = sel_valid;
-            launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
-            SelectParams Q;
-            Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
-            Q.B = B; Q.S = S; Q.hw = (int)hw; Q.automask = o->automask;
-            hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), B), dim3(256), 0, fs, Q);
+            launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);      // (the selection itself: ext_selected, inside the joint kernel)
         }
         take_stamp(h, Pj, (size_t)nblk * B);
         ProfScope prof(h, 0);
@@ -1244,7 +1239,7 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
-    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)3 * h->max_pairs * hw * sizeof(float)));
+    if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (lm && !h->dense_rec_acc) {
         HIPCHK(h, hipMalloc((void **)&h->dense_rec_acc, n * hw * 8 * sizeof(float)));
@@ -1318,17 +1313,12 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     float *Dbuf[2] = {h->depth_work, h->depth_alt}, *Rbuf[2] = {h->dense_rec, h->dense_rec2};
     // min over the sources (window form): selection masks of the forward pairs from their residual maps at the current poses
     // AND current depth copies, rebuilt before every linearisation (same two launches as in the pose mode)
-    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr,
-          *sel_mask = h->sel_maps ? h->sel_maps + (size_t)2 * h->max_pairs * hw : nullptr;
-    if (n_sel) { P.ext_mask = sel_mask; P.n_ext = n_sel; }
+    float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr;
+    if (n_sel) { P.ext_diff = sel_diff; P.ext_valid = sel_valid; P.n_ext = n_sel; P.ext_B = win_B; P.ext_S = win_S; }
     auto select_pass = [&]() {
         LinParams M = lin_params(h, &oo, 6);
         M.o_diff = sel_diff; M.o_valid = sel_valid;
-        launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);
-        SelectParams Q;
-        Q.diff = sel_diff; Q.valid = sel_valid; Q.tgtpack = h->tgtpack; Q.mask = sel_mask;
-        Q.B = win_B; Q.S = win_S; Q.hw = (int)hw; Q.automask = o->automask;
-        hipLaunchKernelGGL(k_select, dim3((unsigned)((hw + 255) / 256), win_B), dim3(256), 0, h->stream, Q);
+        launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);          // (the selection itself: ext_selected, inside the dense kernel)
     };
     auto linearize = [&]() {
         if (n_sel) select_pass();
