@@ -664,8 +664,12 @@ void tcsfm_destroy(tcsfm_handle h) {
     if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
     if (h->aux_join) (void)hipEventDestroy(h->aux_join);
     if (h->seq_pack) { (void)hipStreamSynchronize(h->seq_pack); (void)hipStreamDestroy(h->seq_pack); }
-    for (auto &g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
+    if (!h->graphs.empty()) {             // a replay may still be running: drain the streams it can be on before the executables go
+        if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+        if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);
+        for (auto &g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+    }
     for (auto &e : h->seq_copied) (void)hipEventDestroy(e);
     for (auto &e : h->seq_raw) (void)hipEventDestroy(e);
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
@@ -1092,7 +1096,7 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         if ((int)h->graphs.size() >= h->graph_slots) {     // evict the least recently used entry
             size_t lru = 0;
             for (size_t i = 1; i < h->graphs.size(); i++) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
-            if (h->graphs[lru].exec) (void)hipGraphExecDestroy(h->graphs[lru].exec);
+            if (h->graphs[lru].exec) { (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->graphs[lru].exec); }      // (it may still be running)
             h->graphs.erase(h->graphs.begin() + lru);
         }
         tcsfm_ctx::CallGraph g;
@@ -1407,6 +1411,8 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
 }
 
 static void drop_graphs(tcsfm_ctx *c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);      // (a replay may still be running)
+    if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto &g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
 }
