@@ -113,3 +113,46 @@ def test_segment_errors_closed_forms():
     off = gt.copy(); off[:, 0, 3] += 0.5
     mt, mr = mean_err(gt, off)
     assert abs(mt - 0.5) < 1e-12 and mr < 1e-12
+
+
+def test_segment_errors_against_an_independent_scipy_implementation():
+    """KITTI-devkit segment errors on a random curved trajectory against a brute-force implementation that shares no code with the
+    package: scipy Rotation for every rotation, explicit 4x4 inverses, a linear scan for the segment end"""
+    from scipy.spatial.transform import Rotation as R
+    from tightly_coupled_sfm_amd.trajectory import TrajectoryMetrics
+    rng = np.random.default_rng(7)
+
+    def rollout(noise):
+        T = [np.eye(4)]
+        for k in range(400):
+            step = np.eye(4)
+            step[:3, :3] = R.from_rotvec(np.array([0.002, 0.01 * np.sin(k / 30.0), 0.001]) + noise * rng.normal(size=3) * 1e-3).as_matrix()
+            step[:3, 3] = np.array([0.02, -0.01, 1.0]) * (1 + noise * 0.02 * rng.normal()) 
+            T.append(T[-1] @ step)
+        return np.array(T)
+
+    gt, est = rollout(0.0), rollout(1.0)
+    lengths = [50, 120, 300]
+    every, avg = TrajectoryMetrics(list(gt), list(est)).segment_errors(lengths, rot_unit="rad")
+    d = [0.0]
+    for k in range(1, len(gt)):
+        d.append(d[-1] + np.linalg.norm(gt[k][:3, 3] - gt[k - 1][:3, 3]))
+    want_all = []
+    for L in lengths:
+        for i in range(len(gt)):
+            j = next((m for m in range(i, len(gt)) if d[m] - d[i] >= L), None)
+            if j is None:
+                break
+            dg, de = np.linalg.inv(gt[i]) @ gt[j], np.linalg.inv(est[i]) @ est[j]
+            E = np.linalg.inv(dg) @ de
+            want_all.append((L, np.linalg.norm(E[:3, 3]) / L, np.linalg.norm(R.from_matrix(E[:3, :3]).as_rotvec()) / L))
+    want_all = np.array(want_all)
+    assert every.shape == want_all.shape and np.allclose(every, want_all, rtol=1e-9, atol=1e-12)
+    for row in avg:
+        sel = want_all[want_all[:, 0] == row[0]]
+        assert np.allclose(row[1:], sel[:, 1:].mean(0), rtol=1e-9)
+    # per-frame errors and their mean against the same independent arithmetic
+    tm = TrajectoryMetrics(list(gt), list(est))
+    per = np.array([[np.linalg.norm((np.linalg.inv(g) @ e)[:3, 3]), np.linalg.norm(R.from_matrix((np.linalg.inv(g) @ e)[:3, :3]).as_rotvec())]
+                    for g, e in zip(gt, est)])
+    assert np.allclose(tm.mean_err(), per.mean(0), rtol=1e-9) and np.allclose(tm.rms_err(), np.sqrt((per ** 2).mean(0)), rtol=1e-9)

@@ -54,10 +54,12 @@ def rms_err(gt_traj, est_traj):
     return float(np.sqrt(np.mean(e[:, 0] ** 2))), float(np.sqrt(np.mean(e[:, 1] ** 2)))
 
 
-def segment_errors(gt_traj, est_traj, seg_lengths, step=1):
+def segment_errors(gt_traj, est_traj, seg_lengths, step=1, return_all=False):
+    """-> rows [n_lengths, 3] = (length, mean translational error / length, mean rotational error / length); with return_all also the
+    individual segments [n_segments, 3] = (length, translational error / length, rotational error / length), one per start frame"""
     gt = np.asarray(gt_traj); est = np.asarray(est_traj)
     dist = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(gt[:, :3, 3], axis=0), axis=1))])
-    rows = []
+    rows, every = [], []
     for L in seg_lengths:
         errs = []
         for i in range(0, len(gt), step):
@@ -70,9 +72,11 @@ def segment_errors(gt_traj, est_traj, seg_lengths, step=1):
         if errs:
             errs = np.array(errs)
             rows.append((L, errs[:, 0].mean(), errs[:, 1].mean()))
+            every += [(L, t, r) for t, r in errs]
         else:
             rows.append((L, np.nan, np.nan))
-    return np.array(rows)
+    rows = np.array(rows)
+    return (rows, np.array(every).reshape(-1, 3)) if return_all else rows
 
 
 def compute_trajectory(pose_vec, gt_traj, method="odom", compute_seg_err=False, verbose=False):
@@ -115,8 +119,10 @@ class TrajectoryMetrics:
         return np.float64(t), np.float64(r)
 
     def segment_errors(self, segment_lengths, rot_unit="rad"):
-        """-> (per-length rows, array [n_lengths, 3] = (length, translational error / length, rotational error / length))"""
-        rows = segment_errors(self.gt, self.est, list(segment_lengths))
+        """-> (every segment [n_segments, 3], per-length averages [n_lengths, 3]); columns: length, translational error / length,
+        rotational error / length.  validate.py:82 reads the second element."""
+        rows, every = segment_errors(self.gt, self.est, list(segment_lengths), return_all=True)
         if rot_unit == "deg":
             rows = rows.copy(); rows[:, 2] *= 180.0 / np.pi
-        return rows, rows
+            every = every.copy(); every[:, 2] *= 180.0 / np.pi
+        return every, rows
