@@ -1097,7 +1097,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         // validity dropped them -- skips it (wave-uniform branch; the skipped terms would have been multiplied by zero).
         if (MODE == MODE_LIN && __builtin_amdgcn_ballot_w64(m) != 0ull) {
             // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
-            const f2 cA01 = {cA[0], cA[1]}, cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
+            // d SSIM_p / d y_q = cA + cB (y_q - y_c) + cC (x_q - x_c): the centre shift goes into the constant once per pixel
+            // instead of three packed subtractions per neighbour
+            const f2 cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
+            const f2 cA01 = f2{cA[0], cA[1]} - cB01 * yc01 - cC01 * xc01;
+            const float cA2 = cA[2] - cB[2] * yx2c.x - cC[2] * yx2c.y;
             f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, G2 = {0.f, 0.f};   // 3x3 sums of the image gradients (curvature model)
             const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
 #pragma unroll 1
@@ -1105,10 +1109,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 f32x4 n0, n1, n2, n3, n4, n5;
                 lds_read6v(nb, n0, n1, n2, n3, n4, n5);   // one LDS round trip per neighbour
                 Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
-                f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
-                f2 cf = cA01 + cB01 * ey + cC01 * ex;
-                f2 e2v = pk_sub(n2.lo, yx2c);
-                float cf2 = cA[2] + cB[2] * e2v.x + cC[2] * e2v.y;
+                f2 cf = cA01 + cB01 * n0.lo + cC01 * n0.hi;
+                float cf2 = cA2 + cB[2] * n2.x + cC[2] * n2.y;
                 f2 tx = cf * n1.lo, ty = cf * n1.hi;
                 float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
                 de2[0] += sx * n3.lo; de2[0] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
