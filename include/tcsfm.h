@@ -336,8 +336,8 @@ int tcsfm_stream_wait_event(tcsfm_handle h, void *hip_stream, void *event);
 /* ---- graph replay of repeated calls -------------------------------------------------------------------
  * A B = 1 refinement is nine short launches; with several calls in flight the HOST's launch rate (about 42 us per call), not the
  * kernels (about 40 us per call), sets the throughput, and on a slow host it alone does.  tcsfm_set_graph_replay(h, n > 0) lets the
- * handle and its lanes keep up to n captured calls each: a tcsfm_refine / tcsfm_refine_window (also through
- * tcsfm_refine_window_async) with DEVICE pointers whose arguments -- options, sizes and every pointer -- equal those of an earlier
+ * handle and its lanes keep up to n captured calls each: a tcsfm_refine / tcsfm_refine_window / tcsfm_refine_dense / tcsfm_refine_dense_window
+ * (also through the _async forms) with DEVICE pointers whose arguments -- options, sizes and every pointer -- equal those of an earlier
  * call is captured as one HIP graph the second time it is seen and replayed with a single hipGraphLaunch from the third time on
  * (least recently used entry evicted).  Same kernels, same order, same arguments: results are bit-identical to plain launches.
  * Calls with host pointers, under tcsfm_debug_trace / tcsfm_profile_begin, or on HIP's NULL stream are launched plainly.

@@ -102,3 +102,59 @@ def test_replay_eviction_pair_form_lm_and_bypasses():
                                 P(out), None, None)
         assert rc == 0
     assert np.array_equal(out, wa.cpu().numpy()) and e.graph_replay_counts() == (2, 6)
+
+
+def test_replay_of_dense_calls_per_pair_and_joint():
+    """the dense entry points go through the same capture: S = 1 windows on the lanes, and the joint S = 2 window whose inverse pairs run
+    on a second stream inside the call (fork / join by events, captured with it)"""
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    d = _batch(H, W, 5)
+    o = default_opts(n_iters=3, min_depth=0.03, max_depth=3.0)
+    tgt, srcs = d["tgt"][0:1].contiguous(), d["src"][0:1].contiguous()[None]
+    dt, ds, K, p0 = d["depth_t"][0:1].contiguous(), d["depth_s"][0:1].contiguous()[None], d["K"][0:1].contiguous(), d["pose_init"].clone()
+    torch.cuda.synchronize()
+    ref = Engine(H, W, 2)
+    wp, wd, _ = ref.refine_dense_window(tgt, srcs, dt, ds, K, p0, o)
+    e = Engine(H, W, 2, lanes=2)
+    e.use_own_stream()
+    e.set_graph_replay(2)
+    po = [torch.empty(2, 6, device="cuda") for _ in range(2)]
+    do = [torch.empty(2, 1, H, W, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for lane in range(2):
+            e.refine_dense_window_async(lane, tgt, srcs, dt, ds, K, p0, po[lane], do[lane], o)
+        for lane in range(2):
+            e.lane_synchronize(lane)
+            assert torch.equal(po[lane], wp) and torch.equal(do[lane], wd), (rep, lane)
+    assert e.graph_replay_counts() == (2, 4)
+    # joint dense window, S = 2, min over the sources
+    S = 2
+    b = synth.make_batch(2 * S, H, W, seed0=21)
+    t = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    tg2, sr2 = t["tgt"][:1].contiguous(), t["src"][:S].reshape(S, 1, 3, H, W).contiguous()
+    dt2, ds2 = t["depth_t"][:1].contiguous(), t["depth_s"][:S].reshape(S, 1, 1, H, W).contiguous()
+    pose = torch.cat([t["pose_init"][:S], -t["pose_init"][:S]]).contiguous()
+    K2 = t["K"][:1].contiguous()
+    torch.cuda.synchronize()
+    oj = default_opts(n_iters=3, min_depth=0.03, max_depth=3.0, dense_joint=1)
+    ref2 = Engine(H, W, 2 * S)
+    jp, jd, _ = ref2.refine_dense_window(tg2, sr2, dt2, ds2, K2, pose, oj, argmin=True)
+    e2 = Engine(H, W, 2 * S)
+    e2.use_own_stream()
+    e2.set_graph_replay(1)
+    import ctypes as C
+    oj.argmin = 1
+    gp, gd = torch.empty_like(jp), torch.empty_like(jd)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        gp.zero_(); gd.zero_()
+        torch.cuda.synchronize()
+        rc = e2.lib.tcsfm_refine_dense_window(e2._h, C.byref(oj), 1, S, e2._p(tg2), e2._p(sr2), e2._p(dt2), e2._p(ds2), e2._p(K2), e2._p(pose),
+                                              e2._p(gp), e2._p(gd), None)
+        assert rc == 0
+        e2.synchronize()
+        assert torch.equal(gp, jp) and torch.equal(gd, jd), rep
+    assert e2.graph_replay_counts() == (1, 2)

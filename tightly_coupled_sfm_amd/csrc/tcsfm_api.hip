@@ -1064,18 +1064,20 @@ static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
 // per call with three calls in flight -- on a slow host the launches, not the kernels, set the rate.  A call whose arguments (options,
 // sizes, every pointer) equal those of an earlier call on this handle / lane is captured once (the second time it is seen: the first
 // run validates the intrinsics and allocates scratch, which a capture must not) and replayed with ONE hipGraphLaunch from then on.
-// The kernels, their order and their arguments are exactly those of the plain path: results are bit-identical.
-static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
-                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
-                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr, const FrameCache *fc = nullptr) {
-    const bool eligible = h && o && h->graph_slots > 0 && !h->capturing && !o->host_ptrs && !wo && !fc && !h->profiling && !h->trace_bits &&
+// The kernels, their order and their arguments are exactly those of the plain path (`body`): results are bit-identical.
+// kind: 0 pose refinement, 1 dense refinement (the joint dense mode forks its inverse pairs onto a second stream and joins it again
+// through events: that fork / join is captured with it).
+extern "C++" {
+template <class Body>
+static int replay_or_run(tcsfm_ctx *h, const tcsfm_opts *o, int kind, int N, int win_B, int win_S, const void *const *ptrs, const float *K,
+                         bool bypass, Body body) {
+    const bool eligible = h && o && h->graph_slots > 0 && !h->capturing && !o->host_ptrs && !bypass && !h->profiling && !h->trace_bits &&
                           !h->trace_decide && !h->dbg_stamps && h->stream != nullptr;
-    if (!eligible) return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    if (!eligible) return body();
     tcsfm_ctx::CallKey key;
     memset(&key, 0, sizeof(key));
-    key.o = *o; key.N = N; key.win_B = win_B; key.win_S = win_S;
-    const void *ptrs[10] = {tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out};
-    memcpy(key.p, ptrs, sizeof(ptrs));
+    key.o = *o; key.N = N; key.win_B = win_B; key.win_S = win_S; key.pad = kind;
+    memcpy(key.p, ptrs, sizeof(key.p));
     tcsfm_ctx::CallGraph *e = nullptr;
     for (auto &g : h->graphs) if (!memcmp(&g.key, &key, sizeof(key))) { e = &g; break; }
     if (e && e->exec) {                                    // replay
@@ -1102,22 +1104,22 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         tcsfm_ctx::CallGraph g;
         g.key = key; g.exec = nullptr; g.seen = 1; g.used = ++h->graph_clock;
         h->graphs.push_back(g);
-        return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+        return body();
     }
     e->used = ++h->graph_clock;
     const int nimg_t = win_B ? win_B : N;
-    if (e->seen != 1 || !k_known(h, K, nimg_t))      // marked uncapturable, or the intrinsics would be re-validated (a blocking copy)
-        return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    if (e->seen != 1 || !k_known(h, K, nimg_t))           // marked uncapturable, or the intrinsics would be re-validated (a blocking copy)
+        return body();
     {                                                      // second sighting: capture the plain path's launches
         DeviceGuard dev_guard(h->device);
         if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
             e->seen = -1;
-            return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+            return body();
         }
         h->capturing = true;
         const std::string err_before = h->err;
-        int rc = refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+        int rc = body();
         h->capturing = false;
         hipGraph_t graph = nullptr;
         hipError_t ce = hipStreamEndCapture(h->stream, &graph);
@@ -1134,7 +1136,17 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         e->seen = -1;                                      // not capturable in this configuration: plain launches from now on
         h->err = err_before;
     }
-    return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    return body();
+}
+}  // extern "C++"
+
+static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo = nullptr, const FrameCache *fc = nullptr) {
+    const void *ptrs[10] = {tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out};
+    return replay_or_run(h, o, 0, N, win_B, win_S, ptrs, K, wo != nullptr || fc != nullptr, [&]() {
+        return refine_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out, wo, fc);
+    });
 }
 
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
@@ -1228,9 +1240,9 @@ int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *d
 }
 
 // shared body of tcsfm_refine_dense (win_B == 0) and tcsfm_refine_dense_window
-static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
-                      float *depth_out, float *stats_out, const WinOff *wo = nullptr) {
+                      float *depth_out, float *stats_out, const WinOff *wo) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
@@ -1376,6 +1388,15 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;
+}
+
+static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
+                      const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                      float *depth_out, float *stats_out, const WinOff *wo = nullptr) {
+    const void *ptrs[10] = {tgt, src, depth_t, depth_s, K, pose_in, nullptr, pose_out, depth_out, stats_out};
+    return replay_or_run(h, o, 1, N, win_B, win_S, ptrs, K, wo != nullptr, [&]() {
+        return dense_body(h, o, N, win_B, win_S, tgt, src, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out, wo);
+    });
 }
 
 int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
