@@ -12,7 +12,7 @@ frame-pair is counted per window (not per directed pair).  Inputs are synthetic 
 before the timed region.
 
 Calls in flight.  Steps are independent windows (as the windows of a sequence are), so the handle keeps --lanes of them (default
-3) in flight on its lanes (include/tcsfm.h: own HIP stream and scratch per lane): the kernels of one call fill the gaps between
+4) in flight on its lanes (include/tcsfm.h: own HIP stream and scratch per lane): the kernels of one call fill the gaps between
 the short kernels of the other.  Every step is still one B-window ``tcsfm_refine_window`` call; `single_stream` reports the same
 blocks with one call in flight (the round-1 protocol).
 
@@ -189,7 +189,7 @@ def main():
                     "the whole job (BASELINE config 3: 64), split evenly over the ranks (SURVEY 8e: report both)")
     ap.add_argument("--sat-windows", type=int, default=32, help="windows per call of the chip-filling roofline leg (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of wall time given to the CPU baseline (0 = skip)")
-    ap.add_argument("--lanes", type=int, default=3, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
+    ap.add_argument("--lanes", type=int, default=4, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
     ap.add_argument("--graph-replay", default="auto", choices=("auto", "0", "1"),
                     help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph (tcsfm_set_graph_replay: one "
                          "host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches; auto: untimed blocks of "
@@ -198,6 +198,7 @@ def main():
     args = ap.parse_args()
 
     import numpy as np
+    from tightly_coupled_sfm_amd import _lib as _hip_env_defaults    # noqa: F401  (HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES defaults: before HIP initialises)
     import torch
     import torch.distributed as dist
 

@@ -304,8 +304,8 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  *   pose_init / pose_out [T-S, 2*S, 6], log_scale_out [T-S, 2*S] or NULL (TCSFM_REFINE_POSE_SCALE; the scale starts at 0).
  * Every frame crosses PCIe once, on a high-priority copy stream of the handle, four frames per copy, into a device ring of `ring`
  * frames (0 = default; at least windows_per_call + S + 4, or S + 2 with one window per call and single-frame copies); the calls are
- * issued round robin on the handle's lanes (tcsfm_set_lanes; 2-3 lanes: the GPU runs four hardware queues at once and the copy
- * stream is one of them) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
+ * issued round robin on the handle's lanes (tcsfm_set_lanes; 2-3 lanes: HIP maps a process's streams onto four hardware queues
+ * unless GPU_MAX_HW_QUEUES is raised before the first HIP call, and the call's copy and pack streams take queues too) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
  * finished.  windows_per_call (0 = default 8, capped by max_pairs / (2 S)): the targets and every source of consecutive windows
  * are runs of the ring, so one call refines that many windows at once (the kernels fill the chip).  The call returns when all
  * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window, whatever the lanes,

@@ -23,6 +23,13 @@ elif os.environ["HIP_FORCE_DEV_KERNARG"] != "1":
     _w.warn("tightly_coupled_sfm_amd: HIP_FORCE_DEV_KERNARG is set to something other than 1: chains of short kernels (a B=1 refinement) "
             "run ~17 % slower with kernel arguments in host memory", RuntimeWarning)
 
+# Lanes (several refinements in flight, include/tcsfm.h) are HIP streams, and this ROCm maps a process's streams onto FOUR hardware
+# queues unless told otherwise: with four lanes -- or two lanes beside a sequence call's copy and pack streams -- two of them share a
+# queue and run one after the other (measured: 4 lanes 17 000-18 600 frame-pairs/s on 4 queues, 22 300 / 24 800 on 8; a sequence with 16
+# windows per call on two lanes 13 800 -> 20 700 windows/s).  Only a default, read by HIP when the process first touches the GPU.
+if "GPU_MAX_HW_QUEUES" not in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtcsfm_hip.so")
 
