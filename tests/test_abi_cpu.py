@@ -149,3 +149,13 @@ def test_liegroups_stand_in(lib, oracle64):
     A, B = SE3.exp([0.5, 0, 2.0, 0, 0.1, 0]), SE3.exp([0.6, 0.05, 3.0, 0.01, 0.12, 0])
     rel = A.inv().dot(B)
     assert np.allclose(SE3.exp(rel.log()).as_matrix(), rel.as_matrix(), atol=1e-12)
+
+
+def test_runtime_environment_defaults():
+    """importing the binding sets the two HIP runtime defaults the launch structure depends on -- when the caller has not set them"""
+    import subprocess, sys
+    code = ("import os\nfor k in ('HIP_FORCE_DEV_KERNARG', 'GPU_MAX_HW_QUEUES'): os.environ.pop(k, None)\n"
+            "from tightly_coupled_sfm_amd import _lib\nprint(os.environ['HIP_FORCE_DEV_KERNARG'], os.environ['GPU_MAX_HW_QUEUES'])\n"
+            "os.environ['GPU_MAX_HW_QUEUES'] = '2'\nimport importlib; importlib.reload(_lib)\nprint(os.environ['GPU_MAX_HW_QUEUES'])")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO, text=True).split()
+    assert out == ["1", "8", "2"]          # defaults when absent; a caller's own setting is kept
