@@ -159,3 +159,22 @@ def test_runtime_environment_defaults():
             "os.environ['GPU_MAX_HW_QUEUES'] = '2'\nimport importlib; importlib.reload(_lib)\nprint(os.environ['GPU_MAX_HW_QUEUES'])")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO, text=True).split()
     assert out == ["1", "8", "2"]          # defaults when absent; a caller's own setting is kept
+
+
+def test_runtime_environment_defaults_opt_out():
+    """TCSFM_NO_ENV_DEFAULTS=1 leaves the process environment alone (the variables are process-wide: torch and RCCL see them)"""
+    import subprocess, sys
+    code = ("import os\nfor k in ('HIP_FORCE_DEV_KERNARG', 'GPU_MAX_HW_QUEUES'): os.environ.pop(k, None)\n"
+            "os.environ['TCSFM_NO_ENV_DEFAULTS'] = '1'\nfrom tightly_coupled_sfm_amd import _lib\n"
+            "print('HIP_FORCE_DEV_KERNARG' in os.environ, 'GPU_MAX_HW_QUEUES' in os.environ, _lib.ENV_APPLIED)")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO, text=True).split()
+    assert out == ["False", "False", "{}"]
+
+
+def test_engine_set_lanes_updates_attribute():
+    """Engine.set_lanes keeps Engine.lanes current (the assignment had slipped behind a return)"""
+    import inspect
+    from tightly_coupled_sfm_amd import engine
+    src = inspect.getsource(engine.Engine.set_lanes)
+    assert "self.lanes = int(n)" in src and src.index("tcsfm_set_lanes") < src.index("self.lanes = int(n)")
+    assert "self.lanes" not in inspect.getsource(engine.Engine.graph_replay_counts)

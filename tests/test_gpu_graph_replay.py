@@ -22,6 +22,7 @@ def test_replay_is_bit_identical_and_counts():
     want, _, _ = plain.refine(d["tgt"], d["src"], d["depth_t"], d["depth_s"], d["K"], d["pose_init"], o)
     torch.cuda.synchronize()
     e = Engine(H, W, 2, lanes=2)
+    assert e.lanes == 2
     e.use_own_stream()
     e.set_graph_replay(2)
     win = dict(tgt=d["tgt"][0:1].contiguous(), srcs=d["src"][0:1].contiguous()[None], depth_t=d["depth_t"][0:1].contiguous(),
@@ -158,3 +159,74 @@ def test_replay_of_dense_calls_per_pair_and_joint():
         e2.synchronize()
         assert torch.equal(gp, jp) and torch.equal(gd, jd), rep
     assert e2.graph_replay_counts() == (1, 2)
+
+
+def test_replay_survives_a_larger_joint_call_and_a_stream_switch():
+    """the joint scratch a captured graph points into must not move when a call with more sources arrives, and a handle
+    that switches streams must not replay a graph that may still run on the old one: replay S = 2, call S = 3, replay S = 2 again,
+    switch the stream, call once more -- every result equals the plain launches' bits."""
+    import ctypes as C
+    from tightly_coupled_sfm_amd import synth
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    oj = default_opts(n_iters=3, min_depth=0.03, max_depth=3.0, dense_joint=1)
+    oj.argmin = 1
+
+    def window(S, seed):
+        b = synth.make_batch(2 * S, H, W, seed0=seed)
+        t = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+        return dict(tgt=t["tgt"][:1].contiguous(), srcs=t["src"][:S].reshape(S, 1, 3, H, W).contiguous(), dt=t["depth_t"][:1].contiguous(),
+                    ds=t["depth_s"][:S].reshape(S, 1, 1, H, W).contiguous(), K=t["K"][:1].contiguous(),
+                    pose=torch.cat([t["pose_init"][:S], -t["pose_init"][:S]]).contiguous(), S=S)
+
+    w2, w3 = window(2, 21), window(3, 33)
+    torch.cuda.synchronize()
+    ref = Engine(H, W, 6)
+    want = {}
+    for w in (w2, w3):
+        want[w["S"]] = ref.refine_dense_window(w["tgt"], w["srcs"], w["dt"], w["ds"], w["K"], w["pose"], oj, argmin=True)[:2]
+    torch.cuda.synchronize()
+    e = Engine(H, W, 6)
+    e.use_own_stream()
+    e.set_graph_replay(2)
+
+    def call(w):
+        gp = torch.zeros(2 * w["S"], 6, device="cuda"); gd = torch.zeros(2 * w["S"], 1, H, W, device="cuda")
+        torch.cuda.synchronize()
+        rc = e.lib.tcsfm_refine_dense_window(e._h, C.byref(oj), 1, w["S"], e._p(w["tgt"]), e._p(w["srcs"]), e._p(w["dt"]), e._p(w["ds"]), e._p(w["K"]),
+                                             e._p(w["pose"]), e._p(gp), e._p(gd), None)
+        assert rc == 0, e.last_error()
+        e.synchronize()
+        assert torch.equal(gp, want[w["S"]][0]) and torch.equal(gd, want[w["S"]][1]), w["S"]
+
+    # the same output tensors must be reused for a call to repeat: keep them per window
+    outs = {}
+    def call_fixed(w):
+        if w["S"] not in outs:
+            outs[w["S"]] = (torch.zeros(2 * w["S"], 6, device="cuda"), torch.zeros(2 * w["S"], 1, H, W, device="cuda"))
+        gp, gd = outs[w["S"]]
+        gp.zero_(); gd.zero_()
+        torch.cuda.synchronize()
+        rc = e.lib.tcsfm_refine_dense_window(e._h, C.byref(oj), 1, w["S"], e._p(w["tgt"]), e._p(w["srcs"]), e._p(w["dt"]), e._p(w["ds"]), e._p(w["K"]),
+                                             e._p(w["pose"]), e._p(gp), e._p(gd), None)
+        assert rc == 0, e.last_error()
+        e.synchronize()
+        assert torch.equal(gp, want[w["S"]][0]) and torch.equal(gd, want[w["S"]][1]), w["S"]
+
+    for _ in range(3):
+        call_fixed(w2)                                   # plain, capture, replay
+    assert e.graph_replay_counts() == (1, 1)
+    call_fixed(w3)                                       # more sources: the joint scratch must stay where the S = 2 graph expects it
+    call_fixed(w2)
+    assert e.graph_replay_counts() == (1, 2)
+    call_fixed(w3); call_fixed(w3)                       # S = 3 captured and replayed beside it
+    call_fixed(w2)
+    assert e.graph_replay_counts() == (2, 4)
+    # stream switch: the captures are dropped (drained first), the next calls run plainly on the new stream, then capture again
+    st = torch.cuda.Stream()
+    e.set_stream(st.cuda_stream)
+    assert e.graph_replay_counts() == (2, 4)
+    for _ in range(3):
+        call_fixed(w2)
+    assert e.graph_replay_counts() == (3, 5)
+    call(w3)

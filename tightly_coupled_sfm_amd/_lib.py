@@ -5,30 +5,54 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-# A refinement is a chain of short dependent kernels: kernel arguments must sit in device memory (this ROCm's default; with 0 every
-# launch fetches them over PCIe and a B=1 call takes 90 us instead of 72 us).  Only a default, and only effective when this module is
-# imported before the process's first HIP call.
-if "HIP_FORCE_DEV_KERNARG" not in os.environ:
-    os.environ["HIP_FORCE_DEV_KERNARG"] = "1"
-    import sys as _sys
-    _t = _sys.modules.get("torch")
-    if _t is not None and getattr(_t, "cuda", None) is not None and _t.cuda.is_initialized():
-        # too late for this process: HIP read the variable when the caller first touched the GPU
-        import warnings as _w
-        _w.warn("tightly_coupled_sfm_amd: the GPU was initialised before this package was imported and HIP_FORCE_DEV_KERNARG was not set; "
-                "a B=1 refinement is a chain of short kernels and runs ~17 % slower with kernel arguments in host memory "
-                "(90 vs 72 us per call measured) -- export HIP_FORCE_DEV_KERNARG=1 or import this package first", RuntimeWarning)
-elif os.environ["HIP_FORCE_DEV_KERNARG"] != "1":
-    import warnings as _w
-    _w.warn("tightly_coupled_sfm_amd: HIP_FORCE_DEV_KERNARG is set to something other than 1: chains of short kernels (a B=1 refinement) "
-            "run ~17 % slower with kernel arguments in host memory", RuntimeWarning)
+# Process-wide HIP runtime defaults.  Both variables are read by HIP at the process's FIRST HIP call and they affect every HIP user
+# of the process (torch, RCCL), not only this library: they are set here only when absent, and TCSFM_NO_ENV_DEFAULTS=1 leaves the
+# environment untouched (README "Runtime environment").
+#  * HIP_FORCE_DEV_KERNARG=1 -- a refinement is a chain of short dependent kernels: kernel arguments must sit in device memory
+#    (with 0 every launch fetches them over PCIe and a B=1 call takes 90 us instead of 72 us).
+#  * GPU_MAX_HW_QUEUES=8 -- lanes (several refinements in flight, include/tcsfm.h) are HIP streams, and this ROCm maps a process's
+#    streams onto FOUR hardware queues unless told otherwise: with four lanes -- or two lanes beside a sequence call's copy and pack
+#    streams -- two of them share a queue and run one after the other (measured: 4 lanes 17 000-18 600 frame-pairs/s on 4 queues,
+#    22 300 / 24 800 on 8; a sequence with 16 windows per call on two lanes 13 800 -> 20 700 windows/s).
+ENV_DEFAULTS = {"HIP_FORCE_DEV_KERNARG": "1", "GPU_MAX_HW_QUEUES": "8"}
+ENV_APPLIED = {}          # variable -> True (set here, in time) / False (set here, but HIP was already initialised: no effect)
 
-# Lanes (several refinements in flight, include/tcsfm.h) are HIP streams, and this ROCm maps a process's streams onto FOUR hardware
-# queues unless told otherwise: with four lanes -- or two lanes beside a sequence call's copy and pack streams -- two of them share a
-# queue and run one after the other (measured: 4 lanes 17 000-18 600 frame-pairs/s on 4 queues, 22 300 / 24 800 on 8; a sequence with 16
-# windows per call on two lanes 13 800 -> 20 700 windows/s).  Only a default, read by HIP when the process first touches the GPU.
-if "GPU_MAX_HW_QUEUES" not in os.environ:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
+def _hip_initialised() -> bool:
+    import sys
+    t = sys.modules.get("torch")
+    return t is not None and getattr(t, "cuda", None) is not None and t.cuda.is_initialized()
+
+
+def _apply_env_defaults():
+    import warnings
+    if os.environ.get("TCSFM_NO_ENV_DEFAULTS", "0") not in ("", "0"):
+        return
+    late = _hip_initialised()
+    for k, v in ENV_DEFAULTS.items():
+        if k not in os.environ:
+            os.environ[k] = v
+            ENV_APPLIED[k] = not late
+    if ENV_APPLIED.get("HIP_FORCE_DEV_KERNARG") is False:
+        # too late for this process: HIP read the variable when the caller first touched the GPU
+        warnings.warn("tightly_coupled_sfm_amd: the GPU was initialised before this package was imported and HIP_FORCE_DEV_KERNARG was not set; "
+                      "a B=1 refinement is a chain of short kernels and runs ~17 % slower with kernel arguments in host memory "
+                      "(90 vs 72 us per call measured) -- export HIP_FORCE_DEV_KERNARG=1 or import this package first", RuntimeWarning)
+    elif os.environ.get("HIP_FORCE_DEV_KERNARG", "1") != "1":
+        warnings.warn("tightly_coupled_sfm_amd: HIP_FORCE_DEV_KERNARG is set to something other than 1: chains of short kernels (a B=1 "
+                      "refinement) run ~17 % slower with kernel arguments in host memory", RuntimeWarning)
+
+
+def warn_if_queues_late(lanes: int):
+    """Engine.set_lanes: more than two lanes only run side by side on more than HIP's default four hardware queues"""
+    if lanes > 2 and ENV_APPLIED.get("GPU_MAX_HW_QUEUES") is False:
+        import warnings
+        warnings.warn(f"tightly_coupled_sfm_amd: {lanes} lanes requested, but the GPU was initialised before this package was imported and "
+                      "GPU_MAX_HW_QUEUES was not set: HIP maps the streams onto four hardware queues and lanes that share one run one "
+                      "after the other -- export GPU_MAX_HW_QUEUES=8 or import this package first", RuntimeWarning)
+
+
+_apply_env_defaults()
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libtcsfm_hip.so")

@@ -133,6 +133,19 @@ struct DeviceGuard {
         }                                                                                            \
     } while (0)
 
+// Captured call graphs bake in the handle's scratch pointers and run on the stream they were last launched on: whoever frees or
+// re-sizes such scratch, switches the stream or evicts an entry drains BOTH streams a replay can be on first.
+void sync_graph_streams(tcsfm_ctx *c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+}
+void drop_graphs(tcsfm_ctx *c) {
+    if (c->graphs.empty()) return;
+    sync_graph_streams(c);
+    for (auto &g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+}
+
 int fail(tcsfm_ctx *h, int code, const char *msg) {
     h->err = msg;
     return code;
@@ -444,17 +457,17 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
         HIPCHK(h, hipMalloc((void **)&h->depth_acc, n * hw * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
     }
-    if (!h->jrec || h->jrec_S < S) {      // targets <= max_pairs / (2 S) <= max_pairs / 4
-        for (void **q : {(void **)&h->jrec, (void **)&h->jrec_acc, (void **)&h->jblockrec, (void **)&h->jdepth_acc, (void **)&h->jstate, (void **)&h->jdelta})
-            if (*q) { HIPCHK(h, hipFree(*q)); *q = nullptr; }
+    if (!h->jrec) {      // targets <= max_pairs / (2 S) <= max_pairs / 4.  Sized ONCE for the largest S (JMAXS): a captured call graph
+                         // (tcsfm_set_graph_replay) bakes these pointers in, so they are never freed or re-sized while the handle lives
+        using JM = JointLayout<JMAXS>;
         const size_t nb = (n + 3) / 4;
-        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JL::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JL::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JL::NACC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JM::NACC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
         HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
-        h->jrec_S = S;
+        h->jrec_S = JMAXS;
     }
     if (lm && !h->lm_accept) HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
     if ((size_t)nblk > (size_t)h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
@@ -690,6 +703,10 @@ void tcsfm_destroy(tcsfm_handle h) {
 
 int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
     if (!h) return TCSFM_E_ARG;
+    if ((hipStream_t)hip_stream != h->stream && !h->graphs.empty()) {   // captured calls may still be running on the old stream, and a graph
+        DeviceGuard dev_guard(h->device);                              // captured there is not replayed on another producer's stream
+        drop_graphs(h);
+    }
     h->stream = (hipStream_t)hip_stream;  // NULL = legacy default stream
     k_forget(h);                          // a new stream is a new producer of the caller's buffers: validate intrinsics again
     return TCSFM_OK;
@@ -1098,7 +1115,7 @@ static int replay_or_run(tcsfm_ctx *h, const tcsfm_opts *o, int kind, int N, int
         if ((int)h->graphs.size() >= h->graph_slots) {     // evict the least recently used entry
             size_t lru = 0;
             for (size_t i = 1; i < h->graphs.size(); i++) if (h->graphs[i].used < h->graphs[lru].used) lru = i;
-            if (h->graphs[lru].exec) { (void)hipStreamSynchronize(h->stream); (void)hipGraphExecDestroy(h->graphs[lru].exec); }      // (it may still be running)
+            if (h->graphs[lru].exec) { sync_graph_streams(h); (void)hipGraphExecDestroy(h->graphs[lru].exec); }      // (it may still be running)
             h->graphs.erase(h->graphs.begin() + lru);
         }
         tcsfm_ctx::CallGraph g;
@@ -1429,13 +1446,6 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
         h->lanes.push_back(c);
     }
     return TCSFM_OK;
-}
-
-static void drop_graphs(tcsfm_ctx *c) {
-    if (c->stream) (void)hipStreamSynchronize(c->stream);      // (a replay may still be running)
-    if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
-    for (auto &g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    c->graphs.clear();
 }
 
 int tcsfm_set_graph_replay(tcsfm_handle h, int max_graphs) {

@@ -92,6 +92,15 @@ class Engine:
         self._follow_torch = False
         self._call(self.lib.tcsfm_use_own_stream(self._h))
 
+    def set_stream(self, hip_stream: int):
+        """Run on the given HIP stream (a raw hipStream_t, e.g. ``torch.cuda.Stream().cuda_stream``) from now on; the engine stops
+        following torch's current stream.  Captured call graphs of the old stream are dropped (tcsfm_set_stream)."""
+        self._follow_torch = False
+        self._call(self.lib.tcsfm_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
+    def last_error(self) -> str:
+        return self.lib.tcsfm_last_error(self._h).decode()
+
     def synchronize(self):
         self._call(self.lib.tcsfm_synchronize(self._h))
 
@@ -374,7 +383,9 @@ class Engine:
 
     # -- lanes: several refinements in flight (include/tcsfm.h "lanes") -----------------------------------------
     def set_lanes(self, n: int):
+        _lib.warn_if_queues_late(int(n))
         self._call(self.lib.tcsfm_set_lanes(self._h, int(n)))
+        self.lanes = int(n)
 
     def set_graph_replay(self, max_graphs: int = 4):
         """tcsfm_set_graph_replay: repeated device-pointer refine calls (same tensors, same options) are captured once and
@@ -386,7 +397,6 @@ class Engine:
         c, r = C.c_int(0), C.c_int(0)
         self._call(self.lib.tcsfm_graph_replay_counts(self._h, C.byref(c), C.byref(r)))
         return c.value, r.value
-        self.lanes = int(n)
 
     def refine_window_async(self, lane: int, tgt, srcs, depth_t, depth_s, K, pose, pose_out, opts: Opts, log_scale=None, log_scale_out=None):
         """tcsfm_refine_window on `lane`, zero-allocation and asynchronous: tensors must be validated / contiguous float32 CUDA
