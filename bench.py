@@ -4,12 +4,17 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--windows-per-gpu B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts itself: the parent process, which never touches
+the GPU, launches torch.distributed.run with N ranks of this file (one per GPU, rendezvous on 127.0.0.1) and exits with its code.
+
 Workload.  N = 1 (default): BASELINE.json configs[1] / SURVEY 8d config #2 -- one window of B=1 target frame with S=1 source
 frame -> the reference's fwd + inv directed pairs (2 S B = 2, train_mono.py:54-62), 640x192, 4 Gauss-Newton iterations of the
 6-DoF pose of each directed pair.  N > 1: configs[2] / config #3 -- 64 windows over 8 GPUs = 8 windows (16 directed pairs) per
 rank and step (--windows-per-gpu overrides either default).  One *step* = one ``tcsfm_refine_window`` call over the rank's batch; one
 frame-pair is counted per window (not per directed pair).  Inputs are synthetic (tightly_coupled_sfm_amd.synth), resident in HBM
-before the timed region.
+before the timed region.  The steps ROTATE over a ring of distinct windows whose inputs exceed the 256 MiB Infinity Cache (--ring-mb,
+default 320 MB: 84 windows at B=1), so the images a step reads were last touched ~80 steps earlier and come from HBM, as in a real
+sequence; `hot_cache` repeats the blocks on ONE window (the round-3 protocol: everything cache resident) and says how far `value` moves.
 
 Calls in flight.  Steps are independent windows (as the windows of a sequence are), so the handle keeps --lanes of them (default
 4) in flight on its lanes (include/tcsfm.h: own HIP stream and scratch per lane): the kernels of one call fill the gaps between
@@ -30,14 +35,18 @@ The JSON line also carries
                 per call (tcsfm_set_graph_replay; same kernels, same bits): untimed probe blocks of both modes decide (--graph-replay
                 auto), `other_mode` repeats the blocks in the mode that lost, `host_enqueue_us_per_step` is the host's share of a step.
   roofline      dominant kernel (k_linearize): algorithmic bytes (32 B/pixel/pair/iteration) per launch divided by the
-                launch's duration.  Headline `frac` / `achieved` / `avg_launch_us`: rocprofv3's AverageNs of the kernel in the
-                COMMITTED --kernel-trace --stats run of this command with one call in flight (profiles/<tag>_lanes1_kernel_stats.csv;
-                `frac_source` names the file) -- every figure is recomputable from profiles/.  `live` carries this run's own
-                measurements: the GPU's bracket of every launch (every workgroup stamps s_memrealtime at its start and end, duration =
-                latest end - earliest start, tcsfm_profile_kernel_time; ~1.4 us below rocprof's duration, which includes dispatch and
-                completion) and the HIP event pair around the same launches on the launch stream (2-4 us high on a ~10 us kernel).
-                `traffic` = HBM bytes per launch of THIS workload from the committed PMC passes (profiles/<tag>_pmc_traffic.json).  `valu_bound`: the bound the kernel actually runs into (see
-                profiles/r03_valu_census.json): VALU issue time of its instruction stream priced with measured per-class costs.
+                launch's duration MEASURED IN THIS RUN with one call in flight: `frac` / `achieved` / `avg_launch_us` come from the GPU's
+                own bracket of every launch (every workgroup stamps s_memrealtime at its start and end, duration = latest end - earliest
+                start, tcsfm_profile_kernel_time); `avg_launch_us_hip_events` is the HIP event pair around the same launches on the
+                launch stream (2-4 us high on a ~10 us kernel).  `rocprof_committed` is rocprofv3's AverageNs of the kernel in the
+                committed --kernel-trace --stats run of this command (profiles/<tag>_lanes1_kernel_stats.csv; it includes ~1.2 us of
+                dispatch and completion the in-kernel bracket does not see); `frac_consistent` is false when the two differ by more
+                than 15 % after that offset -- a stale profile or a regressed kernel -- and `profiles_match_source` says whether the
+                profiles were collected on the kernel sources of this tree (hash in profiles/<tag>_meta.json).  `traffic` = HBM bytes
+                per launch of THIS workload from the committed PMC passes (profiles/<tag>_pmc_traffic.json).  `bound_actual` = "valu":
+                the bound the kernel really runs into is VALU issue (`valu_bound`: its instruction stream priced with measured
+                per-class issue costs, profiles/<tag>_valu_census.json); `whole_call` relates the traffic of all nine launches of a
+                call to its algorithmic bytes.
   cpu_baseline  the float64 CPU oracle (a scalar C port of the same algorithm, oracle/tcsfm_oracle.c) timed on this box's host
                 cores on a bounded sample of the same workload: all cores of the box's share (`value`) and one core (`one_thread`),
                 plus the reference's own style of step (PyTorch autograd + Adam, oracle/torch_twin.py).
@@ -121,14 +130,45 @@ def cpu_baseline(seconds: float):
 
 
 # The committed profiles this bench line cites (scripts/collect_profiles.sh <tag> on the GPU box, scripts/summarise_profiles.py <tag>):
-# ONE tag, exact file names -- no globbing (r02's line picked up another mode's PMC file through sorted(glob)[-1]).
-PROFILE_TAG = "r03"
+# exact file names of the NEWEST tag that has the file -- no globbing (r02's line picked up another mode's PMC file through sorted(glob)[-1]).
+PROFILE_TAGS = ("r04", "r03")
 KERNEL = "k_linearize<6, false, 1"       # the S = 1, no-depth-consistency, MODE_LIN instantiation the bench workload runs
+DISPATCH_OFFSET_US = 1.2                  # rocprofv3's kernel duration minus the in-kernel bracket (dispatch + completion), measured r02 / r03
+SOURCE_FILES = ("tightly_coupled_sfm_amd/csrc", "include/tcsfm.h")
+
+
+def source_hash():
+    """sha256 over the kernel sources: profiles collected on another tree say so (profiles/<tag>_meta.json, scripts/summarise_profiles.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for rel in SOURCE_FILES:
+        p = os.path.join(ROOT, rel)
+        files += sorted(os.path.join(p, f) for f in os.listdir(p)) if os.path.isdir(p) else [p]
+    for f in files:
+        if f.endswith((".h", ".hip")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _profile(name):
-    f = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}")
-    return f if os.path.exists(f) else None
+    for tag in PROFILE_TAGS:
+        f = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        if os.path.exists(f):
+            return f
+    return None
+
+
+def profiles_meta():
+    """{tag, source_hash, matches} of the newest committed profile set, or None"""
+    f = _profile("meta.json")
+    if not f:
+        return None
+    try:
+        m = json.load(open(f))
+        return {"file": os.path.relpath(f, ROOT), "source_hash": m.get("source_hash"), "matches": m.get("source_hash") == source_hash()}
+    except Exception:
+        return None
 
 
 def load_pmc(key="hbm_bytes_per_linearize_launch"):
@@ -162,11 +202,16 @@ def rocprof_avg_us(kernel_substr=KERNEL):
     return out or None
 
 
+def consistent(live_us, rocprof_us):
+    """the live in-kernel bracket against the committed rocprof average of the same kernel: equal within 15 % after the dispatch offset"""
+    return abs(live_us + DISPATCH_OFFSET_US - rocprof_us) <= 0.15 * rocprof_us
+
+
 def valu_bound(avg_s, pairs_per_launch):
     """VALU issue time of one launch: waves per SIMD x (instructions of one wave priced with the measured per-class issue costs,
-    profiles/r03_valu_census.json) / shader clock.  The kernel cannot run faster than this whatever the memory system does."""
-    f = os.path.join(ROOT, "profiles", "r03_valu_census.json")
-    if not os.path.exists(f):
+    profiles/<tag>_valu_census.json) / shader clock.  The kernel cannot run faster than this whatever the memory system does."""
+    f = _profile("valu_census.json")
+    if not f:
         return None
     c = json.load(open(f))
     waves = (H * W // 64) * pairs_per_launch                     # one wave per 64 target pixels
@@ -174,7 +219,21 @@ def valu_bound(avg_s, pairs_per_launch):
     ghz = c.get("shader_clock_GHz", 2.4)
     t = clk / (ghz * 1e9)
     return {"valu_insts_per_wave": c["valu_insts_per_wave_census"], "busy_clk_per_wave": c["predicted_valu_busy_clk_per_wave"],
-            "bound_us": round(t * 1e6, 3), "frac_of_bound": round(t / avg_s, 4), "clock_GHz": ghz, "census": "profiles/r03_valu_census.json"}
+            "bound_us": round(t * 1e6, 3), "frac_of_bound": round(t / avg_s, 4), "clock_GHz": ghz, "census": os.path.relpath(f, ROOT)}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: this process (which has not touched the GPU and will not) starts
+    N ranks of this file, one per GPU, and returns their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -190,12 +249,17 @@ def main():
     ap.add_argument("--sat-windows", type=int, default=32, help="windows per call of the chip-filling roofline leg (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=20.0, help="seconds of wall time given to the CPU baseline (0 = skip)")
     ap.add_argument("--lanes", type=int, default=4, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
+    ap.add_argument("--ring-mb", type=float, default=320.0, help="the steps rotate over distinct calls whose inputs add up to at least this many MB "
+                    "(> the 256 MiB Infinity Cache: a step's images come from HBM); 0 = every step re-runs ONE call (the round-3 protocol)")
     ap.add_argument("--graph-replay", default="auto", choices=("auto", "0", "1"),
                     help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph (tcsfm_set_graph_replay: one "
                          "host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches; auto: untimed blocks of "
                          "both before the timed region, the faster mode is timed (a slow host favours replay, a fast one plain launches)")
     ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered refined poses [world, pairs, 6] to this .npy file (tests)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:     # started the way the driver starts it: launch the ranks, touch no GPU here
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     from tightly_coupled_sfm_amd import _lib as _hip_env_defaults    # noqa: F401  (HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES defaults: before HIP initialises)
@@ -206,8 +270,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N ranks with torch.distributed.run, or unset WORLD_SIZE and let bench.py launch them")
     distributed = world > 1 or bool(os.environ.get("TCSFM_BENCH_FORCE_DIST"))     # (forced: the RCCL path on ONE rank, tests/test_gpu_bench.py)
     # rehearsal switches (tests/test_gpu_bench.py): several ranks sharing ONE card over gloo -- RCCL refuses duplicate devices
     backend = os.environ.get("TCSFM_BENCH_BACKEND", "nccl")
@@ -215,12 +278,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
+    coll_world = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        coll_world = dist.get_world_size()
 
     from tightly_coupled_sfm_amd import synth
     from tightly_coupled_sfm_amd.engine import Engine, default_opts
@@ -232,24 +297,35 @@ def main():
     npairs = 2 * SOURCES * B
     lanes = max(1, args.lanes)
     # rank r owns windows r*B .. r*B+B-1 of the global minibatch (contiguous block split, tightly_coupled_sfm_amd/parallel.py);
-    # a window = the fwd + inv directed pair of one (target, source) frame pair
-    b = synth.make_batch(npairs, H, W, seed0=100 * rank, both_directions=True)
-    dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    # a window = the fwd + inv directed pair of one (target, source) frame pair.  Ring entry 0 is that minibatch; the further entries
+    # are other minibatches of the same shape (other seeds), so that consecutive steps read different images.
+    call_bytes = B * (2 * 3 + 2) * H * W * 4                 # target + source colours, two depth maps per window
+    R = lanes if args.ring_mb <= 0 else int(-(-max(1.0, args.ring_mb * 1e6 / call_bytes) // lanes) * lanes)    # multiple of the lanes: a call
+    R = max(R, lanes)                                                                                         # always runs on the same lane
     eng = Engine(H, W, npairs, lanes=lanes)
     eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
-    torch.cuda.synchronize()
     opts = default_opts(n_iters=ITERS)
-    # the window form of the same batch (the library forms the fwd / inv pairs itself, bit-identical to the pair form): targets
-    # [B], the S=1 source of each, initial poses in the stacked order [forward pairs | inverse pairs]
-    win = dict(tgt=dev["tgt"][0::2].contiguous(), srcs=dev["src"][0::2].contiguous()[None], depth_t=dev["depth_t"][0::2].contiguous(),
-               depth_s=dev["depth_s"][0::2].contiguous()[None], K=dev["K"][0::2].contiguous(),
-               pose=torch.cat([dev["pose_init"][0::2], dev["pose_init"][1::2]]).contiguous())
-    outs = [torch.empty_like(win["pose"]) for _ in range(lanes)]
-    gt_w = torch.cat([dev["pose_gt"][0::2], dev["pose_gt"][1::2]])
-    counter = [0]
 
-    def step_on(lane):   # every step starts from the same initial poses and writes the refined poses to the lane's output
-        eng.refine_window_async(lane, win["tgt"], win["srcs"], win["depth_t"], win["depth_s"], win["K"], win["pose"], outs[lane], opts)
+    def make_call(j):
+        # the window form of a batch (the library forms the fwd / inv pairs itself, bit-identical to the pair form): targets [B], the
+        # S=1 source of each, initial poses in the stacked order [forward pairs | inverse pairs]
+        b = synth.make_batch(npairs, H, W, seed0=100 * rank + 7919 * j, both_directions=True)
+        dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+        win = dict(tgt=dev["tgt"][0::2].contiguous(), srcs=dev["src"][0::2].contiguous()[None], depth_t=dev["depth_t"][0::2].contiguous(),
+                   depth_s=dev["depth_s"][0::2].contiguous()[None], K=dev["K"][0::2].contiguous(),
+                   pose=torch.cat([dev["pose_init"][0::2], dev["pose_init"][1::2]]).contiguous())
+        win["out"] = torch.empty_like(win["pose"])
+        return (dev if j == 0 else None), win
+
+    dev, win0 = make_call(0)
+    ring = [win0] + [make_call(j)[1] for j in range(1, R)]
+    gt_w = torch.cat([dev["pose_gt"][0::2], dev["pose_gt"][1::2]])
+    torch.cuda.synchronize()
+    rot = [True]         # False: every step re-runs ring entries 0 .. lanes-1 (hot caches, the round-3 protocol)
+
+    def step_k(k, nl):   # step k of a run with nl calls in flight: its ring entry on its lane; every step starts from its window's
+        w = ring[k % R] if rot[0] else ring[k % nl]          # initial poses and writes the refined poses to the window's output
+        eng.refine_window_async(k % nl, w["tgt"], w["srcs"], w["depth_t"], w["depth_s"], w["K"], w["pose"], w["out"], opts)
 
     def fence(nl):     # the contract's bracket: device-wide synchronise (it covers the lanes' streams) + barrier
         torch.cuda.synchronize()
@@ -257,21 +333,24 @@ def main():
             dist.barrier()
 
     enqueue_s = []       # host time spent enqueueing the K steps of a block (inside the block's wall time)
+    kpos = [0]           # the ring position carries over from block to block
 
     def block(nl):
         fence(nl)
+        k0 = kpos[0]
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            step_on(k % nl)
+        for k in range(k0, k0 + args.steps):
+            step_k(k, nl)
         t1 = time.perf_counter()
         fence(nl)
+        kpos[0] = (k0 + args.steps) % (R * nl // np.gcd(R, nl))
         enqueue_s.append(t1 - t0)
         return time.perf_counter() - t0
 
     def timed(nl):
         """W warm-up steps, then R blocks of exactly K steps with `nl` calls in flight -> (median block seconds, sorted blocks)"""
         for k in range(args.warmup):
-            step_on(k % nl)
+            step_k(k, nl)
         blocks = [block(nl)]
         reps = int(min(64, max(args.min_blocks, np.ceil(0.05 / max(blocks[0], 1e-9)))))
         if distributed:      # every rank runs the same number of blocks
@@ -288,19 +367,20 @@ def main():
         return med, blocks
 
     windows_per_block = args.steps * B * world
+    graph_slots = min(64, max(4, R // lanes + 1))            # every (lane, ring entry) call is captured once
 
-    def set_mode(replay):    # launch mode of the lanes' calls; replay: every lane's call captured now, outside any timed block
-        eng.set_graph_replay(4 if replay else 0)
+    def set_mode(replay):    # launch mode of the lanes' calls; replay: every call of the ring captured now, outside any timed block
+        eng.set_graph_replay(graph_slots if replay else 0)
         if replay:
             for _ in range(3):
-                for l in range(lanes):
-                    step_on(l)
+                for k in range(R):
+                    step_k(k, lanes)
         fence(lanes)
 
     def probe(replay):       # untimed: median of a few K-step blocks in this mode
         set_mode(replay)
         for k in range(args.warmup):
-            step_on(k % lanes)
+            step_k(k, lanes)
         ts = sorted(block(lanes) for _ in range(int(min(16, max(3, np.ceil(0.01 * 1e3 / max(args.steps * 0.05, 1e-9)))))))
         return ts[len(ts) // 2]
 
@@ -317,27 +397,37 @@ def main():
     host_enqueue_us = float(np.median(enqueue_s)) / args.steps * 1e6
     for l in range(lanes):                   # a deferred device-side error of any lane surfaces here
         eng.lane_synchronize(l)
+    # the round-3 protocol beside it: the same blocks re-running ONE window per lane (inputs, packs and records all cache resident)
+    hot = None
+    if R > lanes:
+        rot[0] = False
+        h_el, _ = timed(lanes)
+        rot[0] = True
+        for l in range(lanes):
+            eng.lane_synchronize(l)
+        hv, cv = windows_per_block / h_el, windows_per_block / elapsed
+        hot = {"value": round(hv, 2), "ms_per_step": round(h_el / args.steps * 1e3, 5), "value_over_ring_value": round(hv / cv, 4),
+               "what": f"the same K-step blocks re-running one window per lane (working set {lanes} x ~9 MB: Infinity-Cache resident) -- what rounds 1-3 "
+                       f"reported; the headline rotates over {R} distinct calls ({R * call_bytes / 1e6:.0f} MB of inputs)"}
     # the same blocks in the OTHER launch mode, for comparison; bit-identical poses
-    mine_out = [o_.clone() for o_ in outs]
+    mine_out = [w["out"].clone() for w in ring]
     counts = eng.graph_replay_counts()
     set_mode(not use_replay)
     del enqueue_s[:]
     o_el, _ = timed(lanes)
+    for l in range(lanes):
+        eng.lane_synchronize(l)
     counts2 = eng.graph_replay_counts()
     other = {"mode": "plain launches (9 per call)" if use_replay else "graph replay", "value": round(windows_per_block / o_el, 2),
              "ms_per_step": round(o_el / args.steps * 1e3, 5), "host_enqueue_us_per_step": round(float(np.median(enqueue_s)) / args.steps * 1e6, 2),
-             "same_poses": bool(all(torch.equal(a_, b_) for a_, b_ in zip(mine_out, outs))),
+             "same_poses": bool(all(torch.equal(a_, w["out"]) for a_, w in zip(mine_out, ring))),
              "captures": max(counts[0], counts2[0]), "replays": max(counts[1], counts2[1])}
-    for l in range(lanes):
-        eng.lane_synchronize(l)
     eng.set_graph_replay(0)
     # one call in flight: the host is not what binds (74 us of GPU time against 42 us of launches per call) and a graph launch adds
     # ~4 us of GPU time to the call -- the latency figure uses plain launches
     single = timed(1) if lanes > 1 else (elapsed, blocks)       # the same steps strictly one after the other
-    pose_io = outs[0]
-
-    def step():          # single-stream step of the instrumented passes below
-        step_on(0)
+    eng.lane_synchronize(0)
+    pose_io = ring[0]["out"]
 
     # final gather of the refined poses (RCCL over xGMI), outside the timed region; timed on its own (second call: no setup cost)
     final = pose_io.clone()
@@ -359,11 +449,12 @@ def main():
     if args.dump_poses and rank == 0:
         np.save(args.dump_poses, final_all.cpu().numpy())
 
-    # instrumented pass on EVERY rank: in-kernel brackets + HIP events around every kernel launch, same steps
+    # instrumented pass on EVERY rank: in-kernel brackets + HIP events around every kernel launch, same steps (ring rotation, one call
+    # in flight: the kernel has the chip -- what a roofline compares against)
     n_prof = min(max(args.steps, 300), 500)                 # enough launches for a stable average, whatever K the driver asked for
     eng.profile_begin()
-    for _ in range(n_prof):
-        step()
+    for k in range(n_prof):
+        step_k(k, 1)
     prof = eng.profile_end()
     alg_bytes = 32 * H * W * npairs                          # 32 B/pixel/pair/iteration x pixels x pairs/launch
     k_ms, k_n = prof["linearize_kernel"]
@@ -378,7 +469,7 @@ def main():
     if lanes > 1:
         eng.profile_begin()
         for k in range(n_prof):
-            step_on(k % lanes)
+            step_k(k, lanes)
         for l in range(lanes):
             eng.lane_synchronize(l)
         prof2 = eng.profile_end()
@@ -394,28 +485,39 @@ def main():
     roof = None
     if rank == 0:
         rp = rocprof_avg_us() if B == 1 else None
-        # Headline figure: algorithmic bytes / rocprofv3's AverageNs of this kernel in the COMMITTED run of this command with one
-        # call in flight (profiles/<tag>_lanes1_kernel_stats.csv) -- recomputable from the repository.  The live measurements of
-        # this very run stand beside it: the GPU's own bracket of every launch (`frac_in_kernel`: excludes ~1.4 us of dispatch and
-        # completion that rocprof's duration includes) and the HIP event pair (2-4 us high on a ~10 us kernel).
+        meta = profiles_meta()
+        # Headline: THIS run's in-kernel bracket.  The committed rocprofv3 average of the same kernel stands beside it and must agree
+        # (it includes ~1.2 us of dispatch and completion): frac_consistent.
+        committed = None
         if rp and "lanes_1" in rp:
-            head_us, src = rp["lanes_1"]["us"], f"rocprofv3 --kernel-trace --stats AverageNs, {rp['lanes_1']['file']} (committed run of `python bench.py --lanes 1`)"
-        else:
-            head_us, src = mine["avg_launch_us"], "live in-kernel bracket (no committed rocprof CSV for this tag / workload)"
-        roof = {"bound": "hbm", "achieved": round(alg_bytes / (head_us * 1e-6) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(alg_bytes / (head_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5), "frac_source": src, "avg_launch_us": head_us,
-                "traffic": load_pmc() if B == 1 else None,
+            c_us = rp["lanes_1"]["us"]
+            committed = {"avg_launch_us": c_us, "achieved": round(alg_bytes / (c_us * 1e-6) / 1e9, 2),
+                         "frac": round(alg_bytes / (c_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5), "file": rp["lanes_1"]["file"],
+                         "what": "rocprofv3 --kernel-trace --stats AverageNs of the committed run of `python bench.py --lanes 1`",
+                         "dispatch_offset_us": DISPATCH_OFFSET_US}
+        traffic = load_pmc() if B == 1 else None
+        call_traffic = load_pmc("hbm_bytes_per_call") if B == 1 else None
+        vb = valu_bound(avg_s, npairs)
+        roof = {"bound": "hbm", "bound_actual": "valu", "achieved": mine["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mine["frac"],
+                "frac_source": "this run: in-kernel s_memrealtime bracket of every k_linearize launch (earliest workgroup start -> latest workgroup "
+                               "end), one call in flight, steps rotating over the ring",
+                "avg_launch_us": mine["avg_launch_us"], "avg_launch_us_hip_events": round(ev_s * 1e6, 3),
+                "valu_frac_of_bound": None if vb is None else vb["frac_of_bound"],
+                "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 3),
                 "kernel": "k_linearize", "launches": int(k_n), "algorithmic_bytes_per_launch": alg_bytes,
-                "live": {"avg_launch_us_in_kernel": mine["avg_launch_us"], "achieved_in_kernel": mine["achieved"], "frac_in_kernel": mine["frac"],
-                         "timer": "in-kernel s_memrealtime bracket (earliest workgroup start -> latest workgroup end), this run",
-                         "avg_launch_us_hip_events": round(ev_s * 1e6, 3)},
+                "rocprof_committed": committed,
+                "frac_consistent": None if committed is None else bool(consistent(mine["avg_launch_us"], committed["avg_launch_us"])),
+                "profiles_match_source": None if meta is None else meta["matches"], "profiles_meta": meta,
                 "rocprof_avg_us": rp,
-                "rocprof_note": f"profiles/{PROFILE_TAG}_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this very command (its average covers the "
+                "rocprof_note": "profiles/<tag>_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this very command (its average covers the "
                                 "launches of the timed blocks with `steps_in_flight` calls in flight, of the single-stream blocks and of both instrumented passes); "
-                                f"profiles/{PROFILE_TAG}_lanes1_kernel_stats.csv: the same command with --lanes 1 (every launch has the chip); "
-                                f"profiles/{PROFILE_TAG}_sat_kernel_stats.csv: scripts/sat_workload.py (32 windows per call)",
+                                "profiles/<tag>_lanes1_kernel_stats.csv: the same command with --lanes 1 (every launch has the chip); "
+                                "profiles/<tag>_sat_kernel_stats.csv: scripts/sat_workload.py (32 windows per call)",
                 "other_kernels_avg_us_hip_events": {k: round(v[0] / max(v[1], 1) * 1e3, 3) for k, v in prof.items() if k in ("solve", "pack")},
-                "valu_bound": valu_bound(avg_s, npairs),
+                "valu_bound": vb,
+                "whole_call": {"algorithmic_bytes": ITERS * alg_bytes, "traffic_bytes": call_traffic,
+                               "traffic_over_algorithmic": None if call_traffic is None else round(call_traffic / (ITERS * alg_bytes), 3),
+                               "what": "all launches of one call (pack + 4 x (linearise + solve)) against 4 x the algorithmic bytes of a linearisation"},
                 "measured_with": "ONE call in flight (the kernel has the chip: what a roofline compares against); `in_flight` repeats the live bracket under the timed region's conditions",
                 "in_flight": inflight}
         if distributed:
@@ -447,25 +549,26 @@ def main():
         avg_b = kb_ms / max(kb_n, 1) * 1e-3
         alg_b = 32 * H * W * 2 * rep
         rps = (rocprof_avg_us() or {}).get("saturated") if rep == 32 else None
-        sat_us = rps["us"] if rps else avg_b * 1e6
-        roof_sat = {"workload": f"{rep} windows ({2 * rep} directed pairs) per call", "achieved": round(alg_b / (sat_us * 1e-6) / 1e9, 2),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_b / (sat_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
-                    "frac_source": (f"rocprofv3 AverageNs, {rps['file']}" if rps else "live in-kernel bracket"), "avg_launch_us": round(sat_us, 2),
-                    "live": {"avg_launch_us_in_kernel": round(avg_b * 1e6, 2), "frac_in_kernel": round(alg_b / avg_b / 1e9 / HBM_PEAK_GBPS, 5),
-                             "avg_launch_us_hip_events": round(prof_b["linearize"][0] / max(prof_b["linearize"][1], 1) * 1e3, 2)},
-                    "rocprof_avg_us": rps,
-                    "algorithmic_bytes_per_launch": alg_b, "frame_pairs_per_s": round(rep / wall, 1), "valu_bound": valu_bound(avg_b, 2 * rep)}
+        vbs = valu_bound(avg_b, 2 * rep)
+        roof_sat = {"workload": f"{rep} windows ({2 * rep} directed pairs) per call", "achieved": round(alg_b / avg_b / 1e9, 2),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg_b / avg_b / 1e9 / HBM_PEAK_GBPS, 5),
+                    "frac_source": "this run: in-kernel s_memrealtime bracket", "avg_launch_us": round(avg_b * 1e6, 2),
+                    "avg_launch_us_hip_events": round(prof_b["linearize"][0] / max(prof_b["linearize"][1], 1) * 1e3, 2),
+                    "rocprof_committed": None if not rps else {"avg_launch_us": rps["us"], "frac": round(alg_b / (rps["us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                                               "file": rps["file"]},
+                    "frac_consistent": None if not rps else bool(abs(avg_b * 1e6 - rps["us"]) <= 0.15 * rps["us"]),
+                    "bound_actual": "valu", "valu_frac_of_bound": None if vbs is None else vbs["frac_of_bound"],
+                    "algorithmic_bytes_per_launch": alg_b, "frame_pairs_per_s": round(rep / wall, 1), "valu_bound": vbs}
         del eng_b, big, out_b
 
     if rank == 0:
         windows_per_block = args.steps * B * world
         # sanity figures from one extra, untimed call: the cost the 4 linearisations saw, and how far the refined poses are from
-        # the scene's true poses (the minimiser of the reference's residual is NOT the true pose on rendered data: its warp
-        # samples at u W/(W-1) - 1/2 and blends borders with zero padding, SURVEY 8a row a5 -- a few per cent of the motion)
+        # the scene's true poses
         _, _, st = eng.refine(dev["tgt"], dev["src"], dev["depth_t"], dev["depth_s"], dev["K"], dev["pose_init"], opts, stats=True)
         cost_traj = [round(float(x), 6) for x in st[:, :ITERS, 0].mean(0).cpu()]
         err_t = float((final[:, :3] - gt_w[:, :3]).norm(dim=1).mean() / gt_w[:, :3].norm(dim=1).mean())
-        err_0 = float((win["pose"][:, :3] - gt_w[:, :3]).norm(dim=1).mean() / gt_w[:, :3].norm(dim=1).mean())
+        err_0 = float((ring[0]["pose"][:, :3] - gt_w[:, :3]).norm(dim=1).mean() / gt_w[:, :3].norm(dim=1).mean())
         cfg_name = ("KITTI-like 640x192, batch=1 frame-pair (fwd+inv directed pairs), 4 GN iters, 6-DoF pose" if B == 1 else
                     f"KITTI-like 640x192, {B * world} frame-pairs sharded over {world} GPU(s) ({B} windows = {npairs} directed pairs per GPU and step), 4 GN iters, 6-DoF pose")
         out = {
@@ -478,17 +581,19 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
                        "global_batch_frame_pairs": B * world, "gn_iters": ITERS, "solver": "gn", "param": "se3",
-                       "steps_in_flight": lanes, "collective_backend": backend if distributed else None,
+                       "steps_in_flight": lanes, "ring_calls": R, "ring_input_MB": round(R * call_bytes / 1e6, 1),
+                       "collective_backend": backend if distributed else None, "collective_world_size": coll_world,
                        "parallelism": f"{world} independent shards, no data-path collective; one all_gather of the poses after the timed region"},
             "timed_blocks": len(blocks),
             "ms_per_step_blocks": {"min": round(blocks[0] / args.steps * 1e3, 5), "median": round(elapsed / args.steps * 1e3, 5),
                                    "max": round(blocks[-1] / args.steps * 1e3, 5)},
+            "hot_cache": hot,
             "single_stream": {"value": round(windows_per_block / single[0], 2), "ms_per_step": round(single[0] / args.steps * 1e3, 5),
                               "what": "the same K-step blocks with ONE call in flight (steps_in_flight = 1), plain launches: the per-call latency figure; "
                                       "the headline keeps `steps_in_flight` independent calls in flight on the handle's lanes, which fills "
                                       "the idle time between the short kernels of a B=1 call"},
             "host_enqueue_us_per_step": round(host_enqueue_us, 2),
-            "launch_mode": {"timed": ("graph replay: every lane's call (same buffers every step) is captured once and launched as ONE HIP graph "
+            "launch_mode": {"timed": ("graph replay: every call of the ring (same buffers each time round) is captured once and launched as ONE HIP graph "
                                       "(tcsfm_set_graph_replay); same kernels, bit-identical poses" if use_replay else "plain launches (9 per call)"),
                             "chosen_by": ("untimed probe blocks of both modes before the timed region" if args.graph_replay == "auto" else "--graph-replay " + args.graph_replay),
                             "other_mode": other},
@@ -497,8 +602,7 @@ def main():
             "roofline_saturated": roof_sat,
             "cpu_baseline": cpu_baseline(args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None,
             "check": {"mean_cost_at_each_linearisation": cost_traj,
-                      "rel_translation_distance_to_scene_truth": {"initial": round(err_0, 5), "refined": round(err_t, 5),
-                                                                  "note": "the residual's minimiser is offset from the scene truth by design of the reference's warp"}},
+                      "rel_translation_distance_to_scene_truth": {"initial": round(err_0, 5), "refined": round(err_t, 5)}},
         }
         print(json.dumps(out), flush=True)
     if distributed:

@@ -8,8 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+python -c "import sys, json; sys.path.insert(0, '$ROOT'); import bench; json.dump({'source_hash': bench.source_hash(), 'tag': '$TAG'}, open('$OUT/meta.json', 'w'))"
 python $ROOT/bench.py --steps 2000 --warmup 200 > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-200
+python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err      # the driver's block length
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --steps 300 --warmup 50 --cpu-sample 0 --sat-windows 0 > $OUT/trace.log 2>&1
 # the same with one call in flight: every k_linearize launch has the chip to itself (what bench.py's `roofline` block measures)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes1 -- python $ROOT/bench.py --lanes 1 --steps 300 --warmup 50 --cpu-sample 0 --sat-windows 0 > $OUT/trace_lanes1.log 2>&1
