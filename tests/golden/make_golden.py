@@ -439,10 +439,10 @@ def main():
             g12[f"{tag}_feat1_sub"] = N(feats[0][:, :, ::9, ::13]); g12[f"{tag}_feat4_sub"] = N(feats[3][:, ::8])
             g12[f"{tag}_feat7"] = N(feats[6])
         w12 = standins.make_window(2, 2, 48, 160, seed0=90)
-        from oracle.oracle import Oracle as _O
-        o64 = _O("f64")
-        dts = [torch.tensor(o64.disp_to_depth(w12["disp_t"], 0.06, 2.67)[1].astype(np.float32))] + \
-              [torch.tensor(o64.disp_to_depth(w12["disp_s"][i], 0.06, 2.67)[1].astype(np.float32)) for i in range(2)]
+        # input depths from the REFERENCE's own disp_to_depth (utils/learning_helpers.py:77-86; float64, then rounded to float32 as the
+        # tests form them) -- a golden generator does not import the thing it pins (the oracle stood here)
+        _d2d = lambda a: ref["learning_helpers"].disp_to_depth(torch.tensor(np.asarray(a, dtype=np.float64)), 0.06, 2.67)[1].to(torch.float32)
+        dts = [_d2d(w12["disp_t"])] + [_d2d(w12["disp_s"][i]) for i in range(2)]
         reset_grid()
         poses, poses_inv, outs = ref["train_mono"].solve_pose_iteratively(4, dts, net, torch.tensor(w12["target"]), [torch.tensor(w12["sources"][i]) for i in range(2)],
                                                                         torch.tensor(w12["K"]), return_errors=True)
