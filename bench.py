@@ -302,8 +302,6 @@ def main():
     call_bytes = B * (2 * 3 + 2) * H * W * 4                 # target + source colours, two depth maps per window
     R = lanes if args.ring_mb <= 0 else int(-(-max(1.0, args.ring_mb * 1e6 / call_bytes) // lanes) * lanes)    # multiple of the lanes: a call
     R = max(R, lanes)                                                                                         # always runs on the same lane
-    eng = Engine(H, W, npairs, lanes=lanes)
-    eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
     opts = default_opts(n_iters=ITERS)
 
     def make_call(j):
@@ -319,7 +317,16 @@ def main():
 
     dev, win0 = make_call(0)
     ring = [win0] + [make_call(j)[1] for j in range(1, R)]
+    for w in ring[1:]:       # ONE camera: every call passes the same intrinsics tensor, as the windows of a sequence do (the library
+        assert torch.equal(w["K"], win0["K"])                # validates a device intrinsics pointer, with a blocking copy, the first
+        w["K"] = win0["K"]                                   # time it sees it -- 84 different pointers would thrash its 4-entry cache)
     gt_w = torch.cat([dev["pose_gt"][0::2], dev["pose_gt"][1::2]])
+    # The handle is created AFTER the inputs are on the card, as a pipeline that loads its data first would: on this ROCm the order in
+    # which a process creates its streams decides how the lanes' hardware queues are placed, and a handle created before the process's
+    # first device work can end up with lanes that slow each other down (4 lanes 10 000 instead of 24 000 frame-pairs/s, reproducibly:
+    # scripts/lane_order_probe.py, profiles/r04_lane_order_probe.txt; DESIGN section 4 "Lanes")
+    eng = Engine(H, W, npairs, lanes=lanes)
+    eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
     torch.cuda.synchronize()
     rot = [True]         # False: every step re-runs ring entries 0 .. lanes-1 (hot caches, the round-3 protocol)
 
