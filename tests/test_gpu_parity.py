@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import load_golden, REPO
 import parity_util as PU
 
 torch = pytest.importorskip("torch")
@@ -1033,3 +1033,33 @@ def test_degenerate_inputs_stay_contained():
             assert np.isnan(got[1][:3]).all()                                                             # a NaN start pose is not laundered into numbers
     again = e.refine(*_dev(b), _t(b["pose_init"]), o)[0].cpu().numpy()
     assert np.array_equal(again, clean)                                                                   # and the handle is none the worse
+
+
+def test_adjoint_form_of_the_ssim_gradient_is_the_same_gradient(tmp_path):
+    """k_linearize<ADJ> (TCSFM_ADJOINT=1, kernels.h): the adjoint form of the 3x3-coupled SSIM gradient sums the same products in another
+    order -- gradient and refined poses equal the default form's to rounding (measured slower, kept as an option: profiles/r04_adjoint_ab.txt)"""
+    import subprocess, sys
+    code = (
+        "import numpy as np, torch, sys\n"
+        "from tightly_coupled_sfm_amd import synth\n"
+        "from tightly_coupled_sfm_amd.engine import Engine, default_opts\n"
+        "b = synth.make_batch(4, 96, 320, seed0=7, both_directions=True)\n"
+        "d = {k: torch.as_tensor(v).cuda() for k, v in b.items()}\n"
+        "e = Engine(96, 320, 4)\n"
+        "out = {}\n"
+        "for tag, o in (('pose', default_opts(n_iters=4, w_dc=0.15)), ('scale', default_opts(n_iters=4, refine=1))):\n"
+        "    lin = e.linearize(d['tgt'], d['src'], d['depth_t'], d['depth_s'], d['K'], d['pose_init'], o)\n"
+        "    pose, ls, _ = e.refine(d['tgt'], d['src'], d['depth_t'], d['depth_s'], d['K'], d['pose_init'], o)\n"
+        "    out[tag + '_g'] = lin['g']; out[tag + '_H'] = lin['H']; out[tag + '_pose'] = pose.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    res = {}
+    for adj in ("0", "1"):
+        f = str(tmp_path / f"adj{adj}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, TCSFM_ADJOINT=adj), capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[adj] = np.load(f)
+    for k in res["0"].files:
+        a, b = res["0"][k], res["1"][k]
+        tol = 2e-5 if k.endswith("_g") else (1e-6 if k.endswith("_H") else 1e-5)
+        assert np.abs(a - b).max() <= tol * np.abs(a).max(), (k, np.abs(a - b).max(), np.abs(a).max())
+    assert not np.array_equal(res["0"]["pose_g"], res["1"]["pose_g"])       # (it really is another code path)

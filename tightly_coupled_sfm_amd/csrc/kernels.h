@@ -700,6 +700,21 @@ __device__ __forceinline__ void lds_read6v(const float4 *p, f32x4 &a, f32x4 &b, 
                  "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f) : "v"(lds_addr(p)) : "memory");
 }
+// Split form: issue the six reads of a record, then wait for the first three (LDS returns in order) and for the rest separately, so
+// that the arithmetic on the colour / gradient part overlaps the arrival of the Jacobian part.  The "+v" operands tie the uses of the
+// registers to the wait (hipcc does not track asm loads).
+__device__ __forceinline__ void lds_issue6v(const float4 *p, f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f) {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                 "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f) : "v"(lds_addr(p)) : "memory");
+}
+__device__ __forceinline__ void lds_wait3of6(f32x4 &a, f32x4 &b, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b), "+v"(c) : : "memory"); }
+__device__ __forceinline__ void lds_wait0(f32x4 &a, f32x4 &b, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory"); }
+__device__ __forceinline__ void lds_issue02v(const float4 *p, f32x4 &a, f32x4 &c) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32" : "=&v"(a), "=&v"(c) : "v"(lds_addr(p)) : "memory");
+}
+__device__ __forceinline__ void lds_wait2(f32x4 &a, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(c) : : "memory"); }
+__device__ __forceinline__ void lds_wait0(f32x4 &a, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(c) : : "memory"); }
 __device__ __forceinline__ float4 lds_read1(const float4 *p) {
     f32x4 x;
     asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(lds_addr(p)) : "memory");
@@ -842,7 +857,15 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
 
 // TRACE: the parity-test build of the kernel that records its discrete decisions (tcsfm_debug_trace); a template parameter so that
 // the production instantiation carries none of it (not even the branches: the kernel sits at its 128-VGPR budget)
-template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false>
+// ADJ: the ADJOINT form of the 3x3-coupled SSIM gradient (round 4; the dense kernels have used it since round 2).  Instead of every
+// residual pixel p visiting the full record (colours, image gradients, geometric Jacobian: 96 bytes) of its 9 window pixels and
+// forming 9 x (2 x 6) products (pass B below: ~20 packed instructions per neighbour), p leaves its nine SSIM coefficients
+// m W (cA, cB, cC)_c in LDS; every position q of the tile AND its ring then sums the coefficient records of the residual pixels that
+// see it (9 x 5 additions), forms d C / d(ix, iy) at q with its OWN colours and image gradients and applies its OWN Jacobian once.
+// The gradient is the same sum in another order (exact; H is untouched).  The coefficient records alias the colour part of the
+// staged records (dead after pass A once every thread holds its own colours in registers), so LDS stays at 68.5 KB; the price is
+// two more workgroup barriers and the window sums of the image gradients (curvature model) moving into pass A (+3 per neighbour).
+template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
     constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
@@ -850,6 +873,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     using L = AccLayout<NP>;
     __shared__ float4 lds[NCOMP * (LDS_REC / 4)];
     __shared__ float red[(NT / 64) * L::NACC];
+    __shared__ unsigned adj_any;                              // ADJ: bit w = wave w has a pixel that counts
+    constexpr bool ADJL = ADJ && MODE == MODE_LIN;
+    if (ADJL && threadIdx.x == 0) adj_any = 0u;              // (ordered before its first use by the phase-1 barrier)
 
     // XCD-aware tile order: consecutive workgroups land on different XCDs (round-robin dispatch), so give each
     // of the 8 XCDs a contiguous band of tiles -> halo / source-texel reuse stays inside one XCD's L2.
@@ -1046,24 +1072,27 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         const float4 *nbA = ctr - (CW + 1) * (LDS_REC / 4);
         f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, S2, SS2;
         float Sxy2;
+        f2 aGx01 = {0.f, 0.f}, aGy01 = {0.f, 0.f}, aG2s = {0.f, 0.f};   // ADJ: 3x3 sums of the image gradients (curvature model), taken here
         {
-            f32x4 n0, n2;
-            lds_read02v(nbA, n0, n2);
+            f32x4 n0, n1 = {0.f, 0.f, 0.f, 0.f}, n2;
+            if (ADJL) lds_read3v(nbA, n0, n1, n2); else lds_read02v(nbA, n0, n2);
             nbA += LDS_REC / 4;
             Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
             Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
             S2 = pk_sub(n2.lo, yx2c);            // (y2 - y2c, x2 - x2c)
             SS2 = S2 * S2; Sxy2 = S2.x * S2.y;
+            if (ADJL) { aGx01 = n1.lo; aGy01 = n1.hi; aG2s = n2.hi; }
         }
 #pragma unroll 1
         for (int kk = 1; kk < 9; kk++) {
-            f32x4 n0, n2;
-            lds_read02v(nbA, n0, n2);
+            f32x4 n0, n1 = {0.f, 0.f, 0.f, 0.f}, n2;
+            if (ADJL) lds_read3v(nbA, n0, n1, n2); else lds_read02v(nbA, n0, n2);
             nbA += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
             f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
             Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
             f2 e2v = pk_sub(n2.lo, yx2c);
             S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
+            if (ADJL) { aGx01 += n1.lo; aGy01 += n1.hi; aG2s += n2.hi; }
         }
         // per-channel SSIM value / gradient coefficients / curvature weights and the L1 term: channels (0,1) as one packed
         // evaluation, channel 2 as a scalar one (same code, ssim_l1_channel<T>)
@@ -1090,12 +1119,114 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             m = inimg && sel_keep && (diff < sel_before) && (diff <= sel_after);
         }
 
+        // depth consistency, train_mono.py:91-92
+        float cd = c_cd[k], pd = c_pd[k];
+        float sum = cd + pd, dif = c_dif[k], isum = frcp(sum);
+        float raw = fabsf(dif) * isum;
+        float dd = clamp01(raw), Wt = 1.f - dd;
+        // REFERENCE window rule (optimizer.py:69): Wp = the weight on the photometric term -- source 0's map for every forward
+        // pair; wext: it is not this pair's own (no e dW/d theta term); crossf: source 0's weight also multiplies the pixels the
+        // other sources won, their error times d W_0 / d theta enters source 0's gradient
+        float Wp = Wt, crossf = 0.f;
+        bool wext = false;
+        if (SEL && sel_pair && P.rule) {
+            if (s_own != 0) { Wp = sel_w0; wext = true; }
+            else crossf = (inimg && sel_keep && !m) ? sel_dothers : 0.f;
+        }
+
         f2 de2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // d(e2)/d theta, column pairs (01)(23)(45)
         float de6 = 0.f;
         // Pass B only serves masked-in pixels (its results are multiplied by the mask): a wave whose 64 pixels are ALL masked out --
         // the other source won them (min over the sources: the sources win in coherent regions), the auto-mask or the warp's
         // validity dropped them -- skips it (wave-uniform branch; the skipped terms would have been multiplied by zero).
-        if (MODE == MODE_LIN && __builtin_amdgcn_ballot_w64(m) != 0ull) {
+        float adj_sx = 0.f, adj_sy = 0.f;      // ADJ: d C / d(ix, iy) of this thread's own position, SSIM part (carries m W of the residual pixels)
+        f2 ring_g2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // ADJ: contribution of this thread's ring position (first NHALO threads)
+        float ring_g6 = 0.f;
+        if (ADJL) {
+            const unsigned long long anyw = __builtin_amdgcn_ballot_w64(m);
+            if (anyw != 0ull) {     // GN curvature of the SSIM term from the gradient sums of pass A (as at the end of pass B below)
+                const float n9 = 1.f / 9.f;
+                const f2 mx = aGx01 * n9, my = aGy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+                const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
+                         qyy = t01.id2 * ey * ey + t01.id1 * my * my;
+                const float mx2 = aG2s.x * n9, my2 = aG2s.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
+                lxx += qxx.x + qxx.y + t2.id2 * ex2 * ex2 + t2.id1 * mx2 * mx2;
+                lxy += qxy.x + qxy.y + t2.id2 * ex2 * ey2 + t2.id1 * mx2 * my2;
+                lyy += qyy.x + qyy.y + t2.id2 * ey2 * ey2 + t2.id1 * my2 * my2;
+                if ((tid & 63) == 0) atomicOr(&adj_any, 1u << (tid >> 6));
+            }
+            // coefficient record of this residual pixel: m W (cA, cB, cC) per channel, re-centred from its own colours to 1/2 so that it
+            // serves every position q:  d e2_p / d y_q = cA + cB (y_q - 1/2) + cC (x_q - 1/2)
+            const float wq = m ? Wp : 0.f;
+            const f2 h01 = {0.5f, 0.5f};
+            const f2 wA01 = wq * (t01.cA + t01.cB * (h01 - yc01) + t01.cC * (h01 - xc01)), wB01 = wq * t01.cB, wC01 = wq * t01.cC;
+            const float wA2 = wq * (t2.cA + t2.cB * (0.5f - yx2c.x) + t2.cC * (0.5f - yx2c.y)), wB2 = wq * t2.cB, wC2 = wq * t2.cC;
+            // ring position of this thread (first NHALO threads): its colours / image gradients leave LDS before the records are reused
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
+            int rlx = 0, rly = 0;
+            const bool ring_thread = tid < HALO_THREADS;      // wave-uniform
+            if (ring_thread) {
+                const int hi = min(tid, NHALO - 1);
+                if (hi < CW) { rly = 0; rlx = hi; }
+                else if (hi < 2 * CW) { rly = CH - 1; rlx = hi - CW; }
+                else { const int kq = hi - 2 * CW; rly = 1 + (kq >> 1); rlx = (kq & 1) ? CW - 1 : 0; }
+                lds_read3v(lds + (rly * CW + rlx) * (LDS_REC / 4), r0, r1, r2);
+            }
+            __syncthreads();                                  // every pass-A read of the colour records is done
+            {
+                float4 *cr = const_cast<float4 *>(ctr);
+                lds_write1(cr + 0, wA01.x, wA01.y, wB01.x, wB01.y);
+                lds_write1(cr + 1, wC01.x, wC01.y, wA2, wB2);
+                lds_write1(cr + 2, wC2, 0.f, 0.f, 0.f);
+                if (ring_thread && tid < NHALO) {             // ring positions carry no residual of this tile
+                    float4 *rr = lds + (rly * CW + rlx) * (LDS_REC / 4);
+                    lds_write1(rr + 0, 0.f, 0.f, 0.f, 0.f); lds_write1(rr + 1, 0.f, 0.f, 0.f, 0.f); lds_write1(rr + 2, 0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned anyb = adj_any;
+            const int wv = tid >> 6;
+            // own position: residual pixels of rows ly-1 .. ly+1 live in waves wv-1 .. wv+1 (a wave = two tile rows)
+            if ((anyb & (7u << wv) >> 1) != 0u) {
+                f2 sA01 = {0.f, 0.f}, sB01 = {0.f, 0.f}, sC01 = {0.f, 0.f}, sAB2 = {0.f, 0.f};
+                float sC2 = 0.f;
+                const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
+#pragma unroll 1
+                for (int kk = 0; kk < 9; kk++) {
+                    f32x4 c0, c1, c2;
+                    lds_read3v(nb, c0, c1, c2);
+                    nb += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
+                    sA01 += c0.lo; sB01 += c0.hi; sC01 += c1.lo; sAB2 += c1.hi; sC2 += c2.x;
+                }
+                const f2 lam01 = sA01 + sB01 * (yc01 - h01) + sC01 * (xc01 - h01);
+                const float lam2 = sAB2.x + sAB2.y * (yx2c.x - 0.5f) + sC2 * (yx2c.y - 0.5f);
+                const f2 tx = lam01 * gxc01, ty = lam01 * gyc01;
+                adj_sx = tx.x + tx.y + lam2 * g2c.x; adj_sy = ty.x + ty.y + lam2 * g2c.y;
+            }
+            if (ring_thread && anyb != 0u) {                  // the ring position: only residual pixels inside the tile see it
+                f2 sA01 = {0.f, 0.f}, sB01 = {0.f, 0.f}, sC01 = {0.f, 0.f}, sAB2 = {0.f, 0.f};
+                float sC2 = 0.f;
+#pragma unroll 1
+                for (int kk = 0; kk < 9; kk++) {
+                    const int ny = rly + kk / 3 - 1, nx = rlx + (kk - (kk / 3) * 3) - 1;
+                    const bool ok = nx >= 1 && nx <= TW && ny >= 1 && ny <= TH;
+                    f32x4 c0, c1, c2;
+                    lds_read3v(lds + ((ok ? ny : rly) * CW + (ok ? nx : rlx)) * (LDS_REC / 4), c0, c1, c2);   // (own record: zeros)
+                    sA01 += c0.lo; sB01 += c0.hi; sC01 += c1.lo; sAB2 += c1.hi; sC2 += c2.x;
+                }
+                const f2 lam01 = sA01 + sB01 * (r0.lo - h01) + sC01 * (r0.hi - h01);
+                const float lam2 = sAB2.x + sAB2.y * (r2.x - 0.5f) + sC2 * (r2.y - 0.5f);
+                const f2 tx = lam01 * r1.lo, ty = lam01 * r1.hi;
+                const float live = tid < NHALO ? 1.f : 0.f;   // (threads NHALO .. HALO_THREADS-1 repeat the last ring position)
+                const float rsx = live * (tx.x + tx.y + lam2 * r2.z), rsy = live * (ty.x + ty.y + lam2 * r2.w);
+                f32x4 q3, q4, q5;
+                lds_read3bv(lds + (rly * CW + rlx) * (LDS_REC / 4), q3, q4, q5);
+                ring_g2[0] = rsx * q3.lo + rsy * q4.hi; ring_g2[1] = rsx * q3.hi + rsy * q5.lo; ring_g2[2] = rsx * q4.lo + rsy * q5.hi;
+                if (NP == 7) { float4 q6 = lds_read1(lds + (rly * CW + rlx) * (LDS_REC / 4) + 6); ring_g6 = rsx * q6.x + rsy * q6.y; }
+            }
+        }
+        if (!ADJL && MODE == MODE_LIN && __builtin_amdgcn_ballot_w64(m) != 0ull) {
             // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
             // d SSIM_p / d y_q = cA + cB (y_q - y_c) + cC (x_q - x_c): the centre shift goes into the constant once per pixel
             // instead of three packed subtractions per neighbour
@@ -1107,12 +1238,14 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
                 f32x4 n0, n1, n2, n3, n4, n5;
-                lds_read6v(nb, n0, n1, n2, n3, n4, n5);   // one LDS round trip per neighbour
+                lds_issue6v(nb, n0, n1, n2, n3, n4, n5);  // one LDS round trip per neighbour; the colour part is used while the Jacobians arrive
+                lds_wait3of6(n0, n1, n2);
                 Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
                 f2 cf = cA01 + cB01 * n0.lo + cC01 * n0.hi;
                 float cf2 = cA2 + cB[2] * n2.x + cC[2] * n2.y;
                 f2 tx = cf * n1.lo, ty = cf * n1.hi;
                 float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
+                lds_wait0(n3, n4, n5);
                 de2[0] += sx * n3.lo; de2[0] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
                 de2[1] += sx * n3.hi; de2[1] += sy * n5.lo;
                 de2[2] += sx * n4.lo; de2[2] += sy * n5.hi;
@@ -1129,21 +1262,6 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 lxy += qxy.x + qxy.y + t2.id2 * ex2 * ey2 + t2.id1 * mx2 * my2;
                 lyy += qyy.x + qyy.y + t2.id2 * ey2 * ey2 + t2.id1 * my2 * my2;
             }
-        }
-
-        // depth consistency, train_mono.py:91-92
-        float cd = c_cd[k], pd = c_pd[k];
-        float sum = cd + pd, dif = c_dif[k], isum = frcp(sum);
-        float raw = fabsf(dif) * isum;
-        float dd = clamp01(raw), Wt = 1.f - dd;
-        // REFERENCE window rule (optimizer.py:69): Wp = the weight on the photometric term -- source 0's map for every forward
-        // pair; wext: it is not this pair's own (no e dW/d theta term); crossf: source 0's weight also multiplies the pixels the
-        // other sources won, their error times d W_0 / d theta enters source 0's gradient
-        float Wp = Wt, crossf = 0.f;
-        bool wext = false;
-        if (SEL && sel_pair && P.rule) {
-            if (s_own != 0) { Wp = sel_w0; wext = true; }
-            else crossf = (inimg && sel_keep && !m) ? sel_dothers : 0.f;
         }
 
         if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && inimg) {   // parity tests replay these decisions in the float64 oracle
@@ -1188,8 +1306,13 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 const f2 zc2 = {c_zc[k][2 * p], c_zc[k][2 * p + 1]};
                 f2 dpd = c_dgx[k] * a2[p] + c_dgy[k] * b2[p];
                 ddJ2[p] = kdd * (pd * zc2 - cd * dpd);
-                f2 row = Wp * (de2[p] + l1x * a2[p] + l1y * b2[p]) - dsub * ddJ2[p];   // d(W (e1+e2))/d theta
-                aG2[p] += mf * row;
+                if (ADJL) {      // adjoint form: the SSIM part arrives as d C / d(ix, iy) of this position (m W inside), L1 joins it
+                    const float sxt = adj_sx + mf * Wp * l1x, syt = adj_sy + mf * Wp * l1y;
+                    aG2[p] += sxt * a2[p] + syt * b2[p] - (mf * dsub) * ddJ2[p] + ring_g2[p];
+                } else {
+                    f2 row = Wp * (de2[p] + l1x * a2[p] + l1y * b2[p]) - dsub * ddJ2[p];   // d(W (e1+e2))/d theta
+                    aG2[p] += mf * row;
+                }
                 if (SEL) aG2[p] -= crossf * ddJ2[p];
                 la2[p] = wxx * a2[p] + wxy * b2[p];
                 lb2[p] = wxy * a2[p] + wyy * b2[p];
@@ -1198,7 +1321,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (NP == 7) {
                 float dpd = c_dgx[k] * a6 + c_dgy[k] * b6 + pd;
                 ddJ6 = kdd * (pd * c_zc[k][NP - 1] - cd * dpd);
-                aG6 += mf * (Wp * (de6 + l1x * a6 + l1y * b6) - dsub * ddJ6);
+                if (ADJL) aG6 += (adj_sx + mf * Wp * l1x) * a6 + (adj_sy + mf * Wp * l1y) * b6 - (mf * dsub) * ddJ6 + ring_g6;
+                else aG6 += mf * (Wp * (de6 + l1x * a6 + l1y * b6) - dsub * ddJ6);
                 if (SEL) aG6 -= crossf * ddJ6;
                 la6 = wxx * a6 + wxy * b6; lb6 = wxy * a6 + wyy * b6;
             }

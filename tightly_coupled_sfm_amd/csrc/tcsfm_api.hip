@@ -295,17 +295,30 @@ void take_stamp(tcsfm_ctx *h, LinParams &P, size_t workgroups) {
     }
 }
 
-template <int NP, bool DC, int MODE>
-void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
+// k_linearize's SSIM gradient in its adjoint form (kernels.h, ADJ) or as the round-3 neighbour-visiting pass B: TCSFM_ADJOINT=0/1,
+// read once per process (default: see adjoint_default below; both forms are exact, they differ in rounding only)
+constexpr int kAdjointDefault = 0;
+bool use_adjoint() {
+    static const int v = [] { const char *e = getenv("TCSFM_ADJOINT"); return e ? (atoi(e) != 0) : (kAdjointDefault != 0); }();
+    return v != 0;
+}
+
+template <int NP, bool DC, int MODE, bool ADJ>
+void launch_lin_a(tcsfm_ctx *h, const LinParams &P, int N) {
     dim3 grid(h->nblk, N), block(TILE_NT);
     const bool sel = MODE != MODE_MAPS && P.sel_S > 1;   // window form with the min over sources: selection inside the kernel
     if (MODE != MODE_MAPS && P.trace != nullptr) {       // parity tests: the decision-recording build
-        if (sel) hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, true>), grid, block, 0, h->stream, P);
-        else hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, false, true>), grid, block, 0, h->stream, P);
+        if (sel) hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, true, ADJ>), grid, block, 0, h->stream, P);
+        else hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, false, true, ADJ>), grid, block, 0, h->stream, P);
     } else if (sel)
-        hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true>), grid, block, 0, h->stream, P);
+        hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, false, ADJ>), grid, block, 0, h->stream, P);
     else
-        hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT>), grid, block, 0, h->stream, P);
+        hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, false, false, ADJ>), grid, block, 0, h->stream, P);
+}
+template <int NP, bool DC, int MODE>
+void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
+    if (MODE == MODE_LIN && use_adjoint()) launch_lin_a<NP, DC, MODE, MODE == MODE_LIN>(h, P, N);
+    else launch_lin_a<NP, DC, MODE, false>(h, P, N);
 }
 
 void launch_lin(tcsfm_ctx *h, const LinParams &P_in, int N, int np, bool dc, int mode, int prof_class = 0) {
