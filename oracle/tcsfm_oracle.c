@@ -1915,6 +1915,422 @@ void orc_refine_dense_joint(int H, int W, int B, int S, const real *tgt, const r
 }
 
 /* ------------------------------------------------------------------------- */
+/* DENSE mode on the REFERENCE's own loss (round 4): poses of all 2 S B directed pairs + ONE inverse-depth map per target,        */
+/* compute_optimization_loss as optimize_depth_pred minimises it (optimizer.py:47-90, 194-198, 235-247)                           */
+/*
+ *   L = c_f / K_f  sum_{b,p} sum_s M_s W_x diff_s                                 forward term (:47-73)
+ *     + 0.25 / K_i sum_{s,b,p} M_i W_i diff_i                                     inverse term (:75-81)
+ *     + w_dc / (S B HW) sum_{s,b,p} (dd_fwd + dd_inv)                             depth consistency (:83-86)
+ *     + w_init / (B HW) sum_{b,p} SSIM(sigma_b, sigma0_b)(p)                      l_depth_init (:89-90), sigma = sigmoid disparity
+ *   argmin: M_s = min-over-sources selection, W_x = W_0 (weight map of SOURCE 0 on every selected pixel), c_f = 1, K_f summed over
+ *   the batch;  no argmin: M_s = valid_s, W_x = W_s, c_f = 0.25.   K_i: sum of valid x auto-mask over all S B inverse pairs.
+ * Unknowns: left perturbations xi_n of all 2 S B warps and rho_b(q) = 1 / depth_t(b, q); the SOURCE depth maps are held at their
+ * input (the reference lets them drift too, with no prior on them; the engine refines the map the prior and `disp_opt` are about).
+ * The target depth enters the forward pairs as the back-projected depth (local in q) and the inverse pairs as the SAMPLED depth
+ * (stn.py:271: through the depth-consistency weight and term only): the gradient below contains both -- the second by the adjoint
+ * of the bilinear sample, a scatter over the four taps -- and equals reference autograd (goldens `full`, `fullinit`).
+ * Gauss-Newton model: forward group of a target = the joint dense system of linearize_joint (curvature per (pixel, source), depth
+ * block diagonal, Schur complement on 6 S poses) + the IRLS curvature of its depth-consistency terms + a DIAGONAL model of the
+ * 3x3-coupled prior, D_q += w / r^2 (1 / d2_q + 1 / (9 d1_q)) (d1, d2 = the SSIM denominators at q, r = 1/min_depth - 1/max_depth;
+ * the diagonal of the Gauss-Newton matrix of SSIM's mean / covariance decomposition with the pixel's own denominators); the
+ * sampled-depth terms and e dW/d. terms are gradient-only, as in every other mode.  Inverse pairs: 6 x 6 pose systems under the
+ * window REFERENCE rule (linearize_masked with the batch normaliser), their depth is not an unknown.
+ */
+typedef struct {
+    double loss, L_fwd, L_inv, L_dc, L_init, Kf, Ki;
+} dref_scal;
+
+static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                                const real *depth0, const real *K, const orc_opts *op, int argmin, double w_init, double min_depth, double max_depth,
+                                double lambda_depth, const double *T /* [2SB][12] */, const real *const *ae /* [2SB] */, const unsigned short *bits /* [2SB][n] or NULL */,
+                                dref_scal *sc, double *g_xi /* [2SB][6] */, double *g_rho /* [B][n] */, double *Hj /* [B][6S x 6S] */, double *gj /* [B][6S] */,
+                                double *Dq /* [B][n] */, double *Bq /* [B][n][6S] */, double *Hi /* [SB][36] */, double *gi /* [SB][6] */) {
+    const int n = H * W, SB = S * B, NP = 6 * S;
+    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3), reps = (real)op->irls_eps;
+    const double bdc = op->w_dc / ((double)SB * n), eps = op->irls_eps;
+    const double mind = 1.0 / max_depth, rd = 1.0 / min_depth - 1.0 / max_depth;
+    memset(sc, 0, sizeof(*sc));
+    memset(g_xi, 0, sizeof(double) * 12 * SB);
+    memset(g_rho, 0, sizeof(double) * (size_t)B * n);
+    /* ---------- inverse pairs: masks, the batch normaliser K_i ---------- */
+    real *imask = (real *)malloc(sizeof(real) * (size_t)SB * n);
+    double Ki = 0;
+    for (int m = 0; m < SB; m++) {
+        const int b = m % B;
+        real *d = (real *)malloc(sizeof(real) * n), *va = (real *)malloc(sizeof(real) * n), *am = (real *)malloc(sizeof(real) * n);
+        g_force_bits = NULL;
+        orc_photometric(H, W, srcs + (size_t)m * 3 * n, tgt + (size_t)b * 3 * n, depth_s + (size_t)m * n, depth_t + (size_t)b * n, T + 12 * (SB + m), K + 9 * b, 0.0,
+                        op->w_l1, op->w_ssim, d, va, NULL, NULL, am, NULL);
+        for (int i = 0; i < n; i++) {
+            real mk = va[i] * (op->automask ? am[i] : 1);
+            if (bits) mk = (real)(bits[(size_t)(SB + m) * n + i] & 1);
+            imask[(size_t)m * n + i] = mk; Ki += mk;
+        }
+        free(d); free(va); free(am);
+    }
+    sc->Ki = Ki;
+    const double a_i = Ki > 0 ? 0.25 / Ki : 0.0;
+    /* ---------- inverse pairs: pose systems under the window rule, and the scatter of d L / d (sampled target depth) ---------- */
+    double *ext = (double *)calloc((size_t)B * n, sizeof(double));       /* d L / d depth_t(b, q) through the inverse pairs' samples */
+    for (int m = 0; m < SB; m++) {
+        const int b = m % B, pn = SB + m;
+        lin_ext x;
+        memset(&x, 0, sizeof(x));
+        x.norm = Ki; x.scale = 0.25; x.b_dc = bdc;
+        orc_opts o6 = *op;
+        o6.nparam = 6;
+        lin_t L;
+        real *Eo = (real *)malloc(sizeof(real) * 3 * n), *Mo = (real *)malloc(sizeof(real) * n);
+        g_force_bits = bits ? bits + (size_t)pn * n : NULL;
+        linearize_masked(H, W, srcs + (size_t)m * 3 * n, tgt + (size_t)b * 3 * n, depth_s + (size_t)m * n, depth_t + (size_t)b * n, T + 12 * pn, K + 9 * b, 0.0,
+                         &o6, ae[pn], bits ? NULL : imask + (size_t)m * n, &x, &L, NULL, NULL, NULL, Eo, Mo);
+        for (int j = 0; j < 6; j++) { g_xi[6 * pn + j] = L.g[j]; if (gi) gi[6 * m + j] = L.g[j]; }
+        if (Hi) for (int j = 0; j < 36; j++) Hi[36 * m + j] = L.H[(j / 6) * 6 + (j % 6)];
+        sc->L_inv += L.cost_photo; sc->L_dc += L.cost_dc;
+        /* scatter: term(p) = a_i M W diff + b dd, W = 1 - dd, dd = clamp(|cd - pd| / (cd + pd)); pd = sample of the target depth */
+        cam_t c;
+        cam_setup(&c, H, W, K + 9 * b, T + 12 * pn, 0.0);
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                const int i = v * W + u;
+                geo_t g;
+                warp_geo(&c, u, v, depth_s[(size_t)m * n + i], &g);
+                if (g.oobx || g.ooby) continue;
+                real pdv, dgx, dgy;
+                bilinear_cell(depth_t + (size_t)b * n, H, W, g.ix, g.iy, g.adjx, g.adjy, &pdv, &dgx, &dgy);
+                const real cd = g.Z, pd = pdv, sum = cd + pd, dif = cd - pd, raw = fabs(dif) / sum;
+                if (!(raw >= 0 && raw <= 1)) continue;
+                const real sg = forced_sign(dif, (real)1e-6 * sum, i, 4);
+                const double ddd = -(double)sg * 2.0 * cd / ((double)sum * sum);          /* d dd / d pd */
+                const double Wd = (double)Eo[3 * i] + Eo[3 * i + 1];                      /* W (e1 + e2) */
+                const double dd = Eo[3 * i + 2], Wt = 1.0 - dd, diff = Wt > 0 ? Wd / Wt : 0.0;
+                const double coef = (bdc * fmin(1.0, dd / eps) - a_i * Mo[i] * diff) * ddd;
+                const real fx = floor(g.ix) + (real)g.adjx, fy = floor(g.iy) + (real)g.adjy, wx = g.ix - fx, wy = g.iy - fy;
+                const int x0 = (int)fx, y0 = (int)fy;
+                const double w4[4] = {(1 - wx) * (1 - wy), wx * (1 - wy), (1 - wx) * wy, wx * wy};
+                for (int t = 0; t < 4; t++) {
+                    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+                    if (xx >= 0 && xx < W && yy >= 0 && yy < H) ext[(size_t)b * n + yy * W + xx] += coef * w4[t];
+                }
+            }
+        free(Eo); free(Mo);
+    }
+    g_force_bits = NULL;
+    /* ---------- forward pairs: per-pixel quantities, masks, the batch normaliser K_f ---------- */
+    px_t **px = (px_t **)malloc(sizeof(px_t *) * SB);
+    real **rec = (real **)malloc(sizeof(real *) * SB);
+    real *diff = (real *)malloc(sizeof(real) * (size_t)SB * n), *valid = (real *)malloc(sizeof(real) * (size_t)SB * n), *Wm = (real *)malloc(sizeof(real) * (size_t)SB * n);
+    real *mask = (real *)calloc((size_t)SB * n, sizeof(real)), *margin = (real *)malloc(sizeof(real) * n);
+    for (int m = 0; m < SB; m++) {
+        const int b = m % B;
+        cam_t c;
+        cam_setup(&c, H, W, K + 9 * b, T + 12 * m, 0.0);
+        px[m] = (px_t *)malloc(sizeof(px_t) * n);
+        rec[m] = (real *)malloc(sizeof(real) * 3 * n);
+        g_force_bits = bits ? bits + (size_t)m * n : NULL;
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                px_t *P = &px[m][v * W + u];
+                px_eval(&c, srcs + (size_t)m * 3 * n, depth_t + (size_t)b * n, depth_s + (size_t)m * n, u, v, 7, P);
+                const real D = depth_t[(size_t)b * n + v * W + u];        /* scale column -> inverse-depth column; the source depth is fixed */
+                P->a[6] *= -D; P->b[6] *= -D; P->zc[6] *= -D;
+                P->dpd[6] = P->dgx * P->a[6] + P->dgy * P->b[6];
+            }
+        for (int i = 0; i < n; i++)
+            for (int ch = 0; ch < 3; ch++) rec[m][ch * n + i] = px[m][i].rec[ch];
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                const int i = v * W + u;
+                const px_t *P = &px[m][i];
+                real e = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    ssim_t q;
+                    ssim_at(tgt + (size_t)b * 3 * n + ch * n, rec[m] + ch * n, H, W, u, v, &q);
+                    e += wl * clamp01(fabs(rec[m][ch * n + i] - tgt[(size_t)b * 3 * n + ch * n + i])) + ws * q.s;
+                }
+                diff[(size_t)m * n + i] = e; Wm[(size_t)m * n + i] = 1 - clamp01(fabs(P->cd - P->pd) / (P->cd + P->pd));
+                valid[(size_t)m * n + i] = (real)P->nat_valid;
+            }
+    }
+    g_force_bits = NULL;
+    for (int b = 0; b < B; b++) {
+        if (argmin && S > 1) {
+            real *df = (real *)malloc(sizeof(real) * (size_t)S * n), *vf = (real *)malloc(sizeof(real) * (size_t)S * n), *af = (real *)malloc(sizeof(real) * (size_t)S * n);
+            for (int s = 0; s < S; s++) {
+                memcpy(df + (size_t)s * n, diff + (size_t)(s * B + b) * n, sizeof(real) * n);
+                memcpy(vf + (size_t)s * n, valid + (size_t)(s * B + b) * n, sizeof(real) * n);
+                memcpy(af + (size_t)s * n, ae[s * B + b], sizeof(real) * n);
+            }
+            window_select_maps(H, W, S, df, vf, af, op->automask, mask + (size_t)b * n, (size_t)B * n, margin);
+            free(df); free(vf); free(af);
+        } else {
+            for (int s = 0; s < S; s++) {
+                const int m = s * B + b, am = op->automask && (argmin || S == 1) && argmin;   /* no argmin: no auto-mask (:71-73) */
+                for (int i = 0; i < n; i++)
+                    mask[(size_t)m * n + i] = (valid[(size_t)m * n + i] > 0 && (!am || diff[(size_t)m * n + i] < ae[m][i])) ? 1 : 0;
+            }
+            for (int i = 0; i < n; i++) margin[i] = (real)1e30;
+        }
+        if (bits)
+            for (int s = 0; s < S; s++) {
+                const int m = s * B + b;
+                for (int i = 0; i < n; i++) {
+                    const int fm = bits[(size_t)m * n + i] & 1;
+                    flip_note(mask[(size_t)m * n + i], fm, (argmin && S > 1) ? margin[i] < ORC_TIE
+                              : (px[m][i].nat_valid != px[m][i].valid) || fabs(diff[(size_t)m * n + i] - ae[m][i]) < ORC_TIE);
+                    mask[(size_t)m * n + i] = (real)fm;
+                }
+            }
+    }
+    double Kf = 0;
+    for (size_t i = 0; i < (size_t)SB * n; i++) Kf += mask[i];
+    sc->Kf = Kf;
+    const double a_f = Kf > 0 ? (argmin ? 1.0 : 0.25) / Kf : 0.0;
+    /* ---------- forward group of every target ---------- */
+    double *gx_adj = (double *)malloc(sizeof(double) * (size_t)n * 2 * S), *Lam = (double *)malloc(sizeof(double) * (size_t)n * 3 * S);
+    double *own = (double *)malloc(sizeof(double) * n), *gxi = (double *)malloc(sizeof(double) * NP), *Hxx = (double *)malloc(sizeof(double) * (size_t)NP * NP);
+    double *Sm = (double *)malloc(sizeof(double) * (size_t)NP * NP), *gs = (double *)malloc(sizeof(double) * NP);
+    double *pri_g = (double *)malloc(sizeof(double) * n), *pri_D = (double *)malloc(sizeof(double) * n);
+    real *sig = (real *)malloc(sizeof(real) * n), *sig0 = (real *)malloc(sizeof(real) * n);
+    for (int b = 0; b < B; b++) {
+        const real *tg = tgt + (size_t)b * 3 * n;
+        memset(gx_adj, 0, sizeof(double) * (size_t)n * 2 * S); memset(Lam, 0, sizeof(double) * (size_t)n * 3 * S);
+        memset(own, 0, sizeof(double) * n); memset(gxi, 0, sizeof(double) * NP); memset(Hxx, 0, sizeof(double) * (size_t)NP * NP);
+        memset(Sm, 0, sizeof(double) * (size_t)NP * NP); memset(gs, 0, sizeof(double) * NP);
+        memset(pri_g, 0, sizeof(double) * n); memset(pri_D, 0, sizeof(double) * n);
+        for (int s = 0; s < S; s++) {
+            const int m = s * B + b, x = (argmin ? 0 : s) * B + b;      /* whose weight map multiplies this source's pixels (:69) */
+            g_force_bits = bits ? bits + (size_t)m * n : NULL;
+            for (int v = 0; v < H; v++)
+                for (int u = 0; u < W; u++) {
+                    const int i = v * W + u;
+                    const double am = mask[(size_t)m * n + i];
+                    if (am == 0) continue;
+                    const px_t *P = &px[m][i];
+                    const real Wt = Wm[(size_t)x * n + i];
+                    sc->L_fwd += a_f * am * Wt * diff[(size_t)m * n + i];
+                    double lxx = 0, lxy = 0, lyy = 0;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const real *xx = tg + ch * n, *y = rec[m] + ch * n;
+                        real r = y[i] - xx[i], ar = fabs(r);
+                        real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 6 + 2 * ch) : (real)0;
+                        gx_adj[((size_t)s * n + i) * 2] += am * Wt * wl * sgn * P->gx[ch];
+                        gx_adj[((size_t)s * n + i) * 2 + 1] += am * Wt * wl * sgn * P->gy[ch];
+                        if (ar <= 1) {
+                            real w1 = wl * Wt / (ar > reps ? ar : reps);
+                            lxx += w1 * P->gx[ch] * P->gx[ch]; lxy += w1 * P->gx[ch] * P->gy[ch]; lyy += w1 * P->gy[ch] * P->gy[ch];
+                        }
+                        ssim_t q;
+                        ssim_at(xx, y, H, W, u, v, &q);
+                        if (!q.clamped) {
+                            real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
+                            real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
+                            real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);
+                            real Sx = 0, Sy = 0;
+                            for (int dv = -1; dv <= 1; dv++)
+                                for (int du = -1; du <= 1; du++) {
+                                    int qi = refl(v + dv, H) * W + refl(u + du, W);
+                                    real cf = ws * (cA + cB * y[qi] + cC * xx[qi]);
+                                    gx_adj[((size_t)s * n + qi) * 2] += am * Wt * cf * px[m][qi].gx[ch];
+                                    gx_adj[((size_t)s * n + qi) * 2 + 1] += am * Wt * cf * px[m][qi].gy[ch];
+                                    Sx += px[m][qi].gx[ch]; Sy += px[m][qi].gy[ch];
+                                }
+                            const real ninth = (real)1 / 9;
+                            real mx = Sx * ninth, my = Sy * ninth, ex = P->gx[ch] - mx, ey = P->gy[ch] - my;
+                            real w2 = ws * Wt / q.d2 * (real)1.125, w3 = ws * Wt / q.d1;
+                            lxx += w2 * ex * ex + w3 * mx * mx; lxy += w2 * ex * ey + w3 * mx * my; lyy += w2 * ey * ey + w3 * my * my;
+                        }
+                    }
+                    Lam[((size_t)s * n + i) * 3] = lxx; Lam[((size_t)s * n + i) * 3 + 1] = lxy; Lam[((size_t)s * n + i) * 3 + 2] = lyy;
+                }
+            /* weight terms: -M_s diff_s d dd_x / d theta at the pixel itself (sign of cd_x - pd_x: pair x's code) */
+            g_force_bits = bits ? bits + (size_t)x * n : NULL;
+            const int sx_ = argmin ? 0 : s;
+            for (int i = 0; i < n; i++) {
+                const double am = mask[(size_t)m * n + i];
+                if (am == 0) continue;
+                const px_t *X = &px[x][i];
+                real sum = X->cd + X->pd, dif = X->cd - X->pd, raw = fabs(dif) / sum;
+                real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
+                double kdd = sg * 2.0 / ((double)sum * sum), e = diff[(size_t)m * n + i];
+                for (int j = 0; j < 6; j++) gxi[6 * sx_ + j] -= am * e * kdd * (X->pd * X->zc[j] - X->cd * X->dpd[j]);
+                own[i] -= am * e * kdd * (X->pd * X->zc[6] - X->cd * X->dpd[6]);
+            }
+        }
+        g_force_bits = NULL;
+        /* the prior: SSIM between the current and the initial sigmoid disparity of the target (optimizer.py:89-90) */
+        if (w_init > 0 && depth0) {
+            const double wp = w_init / ((double)B * n);
+            for (int i = 0; i < n; i++) {
+                sig[i] = (real)((1.0 / (double)depth_t[(size_t)b * n + i] - mind) / rd);
+                sig0[i] = (real)((1.0 / (double)depth0[(size_t)b * n + i] - mind) / rd);
+            }
+            for (int v = 0; v < H; v++)
+                for (int u = 0; u < W; u++) {
+                    ssim_t q;
+                    ssim_at(sig0, sig, H, W, u, v, &q);          /* (symmetric in its arguments; differentiated w.r.t. the second, as everywhere) */
+                    sc->L_init += wp * q.s;
+                    if (q.clamped) continue;
+                    real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
+                    real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
+                    real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);
+                    for (int dv = -1; dv <= 1; dv++)
+                        for (int du = -1; du <= 1; du++) {
+                            int qi = refl(v + dv, H) * W + refl(u + du, W);
+                            pri_g[qi] += wp * (cA + cB * sig[qi] + cC * sig0[qi]) / rd;          /* d sigma / d rho = 1 / r */
+                        }
+                    pri_D[v * W + u] = wp / (rd * rd) * (1.0 / q.d2 + 1.0 / (9.0 * q.d1));
+                }
+        }
+        /* assemble */
+        for (int i = 0; i < n; i++) {
+            const double dep = depth_t[(size_t)b * n + i];
+            double gr = a_f * own[i] + pri_g[i] - dep * dep * ext[(size_t)b * n + i], D = pri_D[i], Bv[6 * JMAXS];
+            for (int s = 0; s < S; s++) {
+                const int m = s * B + b;
+                const px_t *P = &px[m][i];
+                const double ax = a_f * gx_adj[((size_t)s * n + i) * 2], ay = a_f * gx_adj[((size_t)s * n + i) * 2 + 1];
+                for (int j = 0; j < 6; j++) gxi[6 * s + j] += gx_adj[((size_t)s * n + i) * 2] * P->a[j] + gx_adj[((size_t)s * n + i) * 2 + 1] * P->b[j];
+                gr += ax * P->a[6] + ay * P->b[6];
+                const double am = a_f * mask[(size_t)m * n + i];
+                const double lxx = am * Lam[((size_t)s * n + i) * 3], lxy = am * Lam[((size_t)s * n + i) * 3 + 1], lyy = am * Lam[((size_t)s * n + i) * 3 + 2];
+                /* depth consistency of THIS forward pair (every pixel of the image) */
+                real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum, dd = clamp01(raw);
+                g_force_bits = bits ? bits + (size_t)m * n : NULL;
+                real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
+                g_force_bits = NULL;
+                double ddJ[7];
+                for (int j = 0; j < 7; j++) ddJ[j] = sg * 2.0 * (P->pd * P->zc[j] - P->cd * P->dpd[j]) / ((double)sum * sum);
+                sc->L_dc += bdc * dd;
+                const double inf = bdc * fmin(1.0, dd / eps), k3 = P->dc_in ? bdc / fmax((double)dd, eps) : 0.0;
+                gr += inf * ddJ[6];
+                const double la6 = lxx * P->a[6] + lxy * P->b[6], lb6 = lxy * P->a[6] + lyy * P->b[6];
+                D += la6 * P->a[6] + lb6 * P->b[6] + k3 * ddJ[6] * ddJ[6];
+                for (int j = 0; j < 6; j++) {
+                    g_xi[6 * m + j] += inf * ddJ[j];
+                    const double la = lxx * P->a[j] + lxy * P->b[j], lb = lxy * P->a[j] + lyy * P->b[j];
+                    Bv[6 * s + j] = la * P->a[6] + lb * P->b[6] + k3 * ddJ[j] * ddJ[6];
+                    for (int k = 0; k <= j; k++) Hxx[(size_t)(6 * s + j) * NP + 6 * s + k] += la * P->a[k] + lb * P->b[k] + k3 * ddJ[j] * ddJ[k];
+                }
+            }
+            for (int s = 0; s < S; s++)
+                if (px[s * B + b][i].valid && !px[s * B + b][i].dc_in) D = 0;    /* sampled across the zero padding: the pixel keeps its depth */
+            g_rho[(size_t)b * n + i] = gr;
+            if (Dq) Dq[(size_t)b * n + i] = D;
+            if (Bq) memcpy(Bq + ((size_t)b * n + i) * NP, Bv, sizeof(double) * NP);
+            const double Dd = (1.0 + lambda_depth) * D;
+            if (Dd > 1e-30)
+                for (int j = 0; j < NP; j++) {
+                    gs[j] -= Bv[j] * gr / Dd;
+                    for (int k = 0; k <= j; k++) Sm[(size_t)j * NP + k] -= Bv[j] * Bv[k] / Dd;
+                }
+        }
+        for (int s = 0; s < S; s++)
+            for (int j = 0; j < 6; j++) g_xi[6 * (s * B + b) + j] += a_f * gxi[6 * s + j];
+        if (Hj && gj)
+            for (int j = 0; j < NP; j++) {
+                gj[(size_t)b * NP + j] = g_xi[6 * ((j / 6) * B + b) + (j % 6)] + gs[j];
+                for (int k = 0; k <= j; k++) {
+                    const double v = Hxx[(size_t)j * NP + k] + Sm[(size_t)j * NP + k];
+                    Hj[(size_t)b * NP * NP + j * NP + k] = v; Hj[(size_t)b * NP * NP + k * NP + j] = v;
+                }
+            }
+    }
+    sc->loss = sc->L_fwd + sc->L_inv + sc->L_dc + sc->L_init;
+    for (int m = 0; m < SB; m++) { free(px[m]); free(rec[m]); }
+    free(px); free(rec); free(diff); free(valid); free(Wm); free(mask); free(margin); free(imask); free(ext);
+    free(gx_adj); free(Lam); free(own); free(gxi); free(Hxx); free(Sm); free(gs); free(pri_g); free(pri_D); free(sig); free(sig0);
+}
+
+static void dref_auto_err(int H, int W, int B, int S, const real *tgt, const real *srcs, const orc_opts *op, real *ae /* [2SB][n] */, const real **aep) {
+    const int n = H * W, SB = S * B;
+    for (int m = 0; m < SB; m++) {
+        const int b = m % B;
+        photo_err_map(H, W, tgt + (size_t)b * 3 * n, srcs + (size_t)m * 3 * n, op->w_l1, op->w_ssim, ae + (size_t)m * n);
+        photo_err_map(H, W, srcs + (size_t)m * 3 * n, tgt + (size_t)b * 3 * n, op->w_l1, op->w_ssim, ae + (size_t)(SB + m) * n);
+        aep[m] = ae + (size_t)m * n; aep[SB + m] = ae + (size_t)(SB + m) * n;
+    }
+}
+
+/* one linearisation at given poses: the loss, its gradients, the Gauss-Newton blocks (tests: reference autograd pin, golden G13) */
+void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s, const real *depth0,
+                             const real *K, const orc_opts *op, int argmin, double w_init, double min_depth, double max_depth, double lambda_depth,
+                             const double *pose /* [2SB][6] */, double *scal /* [7]: loss, L_fwd, L_inv, L_dc, L_init, K_f, K_i */, double *g_xi, double *g_rho,
+                             double *Hj, double *gj, double *Dq, double *Bq, double *Hi, double *gi) {
+    const int n = H * W, SB = S * B;
+    real *ae = (real *)malloc(sizeof(real) * (size_t)2 * SB * n);
+    const real **aep = (const real **)malloc(sizeof(real *) * 2 * SB);
+    double *T = (double *)malloc(sizeof(double) * 24 * SB);
+    dref_auto_err(H, W, B, S, tgt, srcs, op, ae, aep);
+    for (int m = 0; m < 2 * SB; m++) orc_pose_to_T(pose + 6 * m, T + 12 * m);
+    dref_scal sc;
+    linearize_dense_ref(H, W, B, S, tgt, srcs, depth_t, depth_s, depth0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep, NULL, &sc,
+                        g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi);
+    scal[0] = sc.loss; scal[1] = sc.L_fwd; scal[2] = sc.L_inv; scal[3] = sc.L_dc; scal[4] = sc.L_init; scal[5] = sc.Kf; scal[6] = sc.Ki;
+    free(ae); free(aep); free(T);
+}
+
+/* Gauss-Newton on the reference loss: n_iters x { linearise ; joint step of every target's (poses, depth map) ; step of every
+ * inverse pair's pose }, fixed damping lambda0 on the pose blocks (Marquardt-scaled) and lambda_depth on the depth block.
+ * depth_io [B][n] in / out; pose_io [2SB][6]; stats [n_iters][7] (the scalars of every linearisation) or NULL;
+ * bits [n_iters][2SB][n]: forced replay of the engine's decisions. */
+void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
+                          const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                          double *pose_io, double *stats, const unsigned short *bits) {
+    const int n = H * W, SB = S * B, NP = 6 * S;
+    const double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
+    real *ae = (real *)malloc(sizeof(real) * (size_t)2 * SB * n), *d0 = (real *)malloc(sizeof(real) * (size_t)B * n);
+    const real **aep = (const real **)malloc(sizeof(real *) * 2 * SB);
+    double *T = (double *)malloc(sizeof(double) * 24 * SB);
+    double *g_xi = (double *)malloc(sizeof(double) * 12 * SB), *g_rho = (double *)malloc(sizeof(double) * (size_t)B * n);
+    double *Hj = (double *)malloc(sizeof(double) * (size_t)B * NP * NP), *gj = (double *)malloc(sizeof(double) * (size_t)B * NP);
+    double *Dq = (double *)malloc(sizeof(double) * (size_t)B * n), *Bq = (double *)malloc(sizeof(double) * (size_t)B * n * NP);
+    double *Hi = (double *)malloc(sizeof(double) * 36 * SB), *gi = (double *)malloc(sizeof(double) * 6 * SB);
+    dref_auto_err(H, W, B, S, tgt, srcs, op, ae, aep);
+    memcpy(d0, depth_io, sizeof(real) * (size_t)B * n);
+    for (int m = 0; m < 2 * SB; m++) orc_pose_to_T(pose_io + 6 * m, T + 12 * m);
+    for (int it = 0; it < op->n_iters; it++) {
+        dref_scal sc;
+        g_lin_idx = bits ? it : -1;
+        linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep,
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi);
+        g_lin_idx = -1;
+        if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
+        for (int b = 0; b < B; b++) {       /* forward group: (S + lambda diag S + 1e-12 I) d = -gS, back-substitution of the depth map */
+            double A[36 * JMAXS * JMAXS], dl[6 * JMAXS];
+            for (int i = 0; i < NP; i++) {
+                for (int j = 0; j < NP; j++) A[i * NP + j] = Hj[(size_t)b * NP * NP + i * NP + j];
+                A[i * NP + i] += op->lambda0 * Hj[(size_t)b * NP * NP + i * NP + i] + 1e-12;
+                dl[i] = -gj[(size_t)b * NP + i];
+            }
+            if (chol_solve(NP, A, dl)) memset(dl, 0, sizeof(dl));
+            for (int s = 0; s < S; s++) {
+                double E[12], Tn[12];
+                orc_se3_exp(dl + 6 * s, E);
+                orc_se3_mul(E, T + 12 * (s * B + b), Tn);
+                memcpy(T + 12 * (s * B + b), Tn, sizeof(Tn));
+            }
+            for (int i = 0; i < n; i++) {
+                const double Dd = (1.0 + lambda_depth) * Dq[(size_t)b * n + i];
+                if (!(Dd > 1e-30)) continue;
+                double bd = 0;
+                for (int j = 0; j < NP; j++) bd += Bq[((size_t)b * n + i) * NP + j] * dl[j];
+                depth_io[(size_t)b * n + i] = (real)(1.0 / depth_step(1.0 / (double)depth_io[(size_t)b * n + i], -(g_rho[(size_t)b * n + i] + bd) / Dd, lo, hi));
+            }
+        }
+        for (int m = 0; m < SB; m++) {      /* inverse pairs: their own 6 x 6 systems */
+            orc_opts o6 = *op;
+            o6.nparam = 6; o6.param = 0;
+            double Tn[12], sdummy;
+            apply_step(&o6, Hi + 36 * m, gi + 6 * m, op->lambda0, T + 12 * (SB + m), 0.0, Tn, &sdummy);
+            memcpy(T + 12 * (SB + m), Tn, sizeof(Tn));
+        }
+    }
+    for (int m = 0; m < 2 * SB; m++) orc_T_to_pose(T + 12 * m, pose_io + 6 * m);
+    free(ae); free(d0); free(aep); free(T); free(g_xi); free(g_rho); free(Hj); free(gj); free(Dq); free(Bq); free(Hi); free(gi);
+}
+
+/* ------------------------------------------------------------------------- */
 /* DNet ground-plane scale recovery, models/dnet_layers.py:249-327                            */
 
 static void v3_norm(real *v) { /* F.normalize: v / max(|v|, 1e-12) */

@@ -303,6 +303,32 @@ def main():
                 for d in ("fwd", "inv"):
                     for k in ("diff_img", "valid_mask", "weight_mask", "auto_mask_error"):
                         g13[f"{d}_{k}"] = N(outputs[d][k][:, 0])
+        # round 4: the COMPLETE default loss of optimize_depth_pred -- forward + inverse + depth consistency + l_depth_init, the SSIM
+        # prior between the target's current sigmoid disparity and its initial one (optimizer.py:89-90) -- with the target's sigmoid
+        # disparity as the leaf (depth = the reference's disp_to_depth of it, utils/learning_helpers.py:77-86; min / max depth as
+        # run_mono_exps_kitti.sh:5): d loss / d pose of every directed pair and d loss / d sigma_target through every term
+        MIN_D, MAX_D = 0.06, 2.67
+        r_d = 1.0 / MIN_D - 1.0 / MAX_D
+        sig_np = (1.0 / g13["depth_t"] - 1.0 / MAX_D) / r_d                                    # [B,1,H,W], inside (0, 1) for these scenes
+        assert sig_np.min() > 0.0 and sig_np.max() < 1.0
+        yy, xx = np.mgrid[0:H13, 0:W13]
+        sig0_np = sig_np * (1.0 + 0.04 * np.cos(xx / 3.0 + 0.7 * yy)[None, None] + 0.02 * np.sin(yy / 2.0)[None, None])   # the "initial" map
+        g13["sig_t"] = sig_np[:, 0]; g13["sig_t0"] = sig0_np[:, 0]; g13["min_max_depth"] = np.array([MIN_D, MAX_D])
+        for tag, upd in (("fullinit", {'l_inverse_reconstruction': True, 'l_depth_consist': True, 'l_depth_init': True}),
+                         ("fwdinit", {'l_depth_init': True})):
+            fp = T(first, dt).clone().requires_grad_()
+            sig = T(sig_np, dt).clone().requires_grad_()
+            d_t = ref["learning_helpers"].disp_to_depth(sig, MIN_D, MAX_D)[1]
+            d_s = [T(g13["depth_s"][i], dt).clone() for i in range(S13)]
+            _, _, outputs = ref["train_mono"].solve_pose_iteratively(1, [d_t] + d_s, LeafPose(fp), T(g13["target"], dt),
+                                                                    [T(g13["sources"][i], dt) for i in range(S13)], T(g13["K"], dt), return_errors=True)
+            o = object.__new__(DO)
+            o.options = dict(base_opts, **upd); o.ssim_loss = losses.SSIM_Loss()
+            o.target_disparity = T(sig0_np, dt)
+            loss = DO.compute_optimization_loss(o, 0, 0, T(g13["target"], dt), sig, outputs['fwd'], outputs['inv']).reshape(-1)[0]
+            loss.backward()
+            g13[f"{tag}_loss"] = np.array(loss.item()); g13[f"{tag}_grad_pose"] = N(fp.grad); g13[f"{tag}_grad_sig_t"] = N(sig.grad[:, 0])
+            g13[f"{tag}_init_term"] = np.array((0.1 * losses.SSIM_Loss()(T(sig_np, dt), T(sig0_np, dt)).mean()).item())
         out[f"winloss{tagsz}"] = g13
 
     # ------------------------------------------------------------------ G7: loss-surface sweeps (f32, as the reference runs it)
