@@ -90,7 +90,8 @@ typedef struct tcsfm_opts {
     int32_t dense_joint;   /* tcsfm_refine_dense_window with S > 1 (default 1): the S forward pairs of a target share ONE inverse-
                               depth map and are solved JOINTLY (6S x 6S reduced camera system); 0: every forward pair refines its own
                               copy of the target depth (the round-2 behaviour)                                                  */
-    int32_t reserved2;
+    float prior_init;      /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_depth_init_weight'] if options['l_depth_init'] else 0
+                              (optimizer.py:89-90): weight of mean SSIM(current, initial sigmoid disparity of the target); default 0.1  */
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.
@@ -227,10 +228,42 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
  *     depth_out hold the same refined map; stats rows of the forward pairs: [joint cost of the target, own share, own mask
  *     count, lambda, iterate].  The inverse pairs refine their pose and the depth of THEIR target (source frame (s,b)) as before.
  *   PER-PAIR COPIES (o->dense_joint = 0, or S = 1 where the two coincide): every directed pair refines ITS OWN copy of its
- *     target's depth; with o->argmin the forward pairs use the min over the sources at the current poses and depth copies. */
+ *     target's depth; with o->argmin the forward pairs use the min over the sources at the current poses and depth copies.
+ *   REFERENCE LOSS (o->window_rule = TCSFM_WINDOW_REFERENCE; S = 1 .. 3, Gauss-Newton; round 4): the scalar that is minimised is
+ *     the reference's compute_optimization_loss as optimize_depth_pred sees it (optimizer.py:47-90):
+ *       c_f / K_f sum M_s W_x diff_s  (forward term: K_f summed over the call's B targets; W_x = the weight map of SOURCE 0 on every
+ *                                      selected pixel under o->argmin, c_f = 1; without argmin W_x = W_s, c_f = 0.25, no auto-mask)
+ *       + 0.25 / K_i sum M_i W_i diff_i  (inverse pairs, K_i summed over all of them)
+ *       + o->w_dc / (S B HW) sum (dd_fwd + dd_inv)  (depth consistency of both directions; w_dc > 0 is allowed in this mode)
+ *       + o->prior_init / (B HW) sum SSIM(sigma, sigma_0)  (l_depth_init: SSIM between the target's current and initial sigmoid
+ *                                      disparity, sigma = (1/depth - 1/max_depth) / (1/min_depth - 1/max_depth))
+ *     Unknowns: the poses of all 2 S B directed pairs and ONE inverse-depth map per target; the source depth maps stay at their
+ *     input (the reference lets them drift too, with no prior on them).  The target depth enters the forward pairs as the
+ *     back-projected depth and the inverse pairs as the depth they SAMPLE (stn.py:271): the gradient contains both -- the second as
+ *     the adjoint of the bilinear sample, scattered with 64-bit fixed-point atomics (order-independent: results stay bit-
+ *     reproducible) -- and equals reference autograd w.r.t. every pose and the shared depth (golden G13 `full`, `fullinit`; see
+ *     tcsfm_linearize_dense_window).  Curvature: the joint dense model + the IRLS curvature of the depth-consistency terms + a
+ *     diagonal model of the 3x3-coupled prior, w / r^2 (1/d2 + 1/(9 d1)) with the pixel's own SSIM denominators; the sampled-depth
+ *     terms are gradient-only.  The inverse pairs take 6 x 6 pose steps under the window rule.  After every step the new map also
+ *     replaces the depth the inverse pairs sample.  depth_out: the S forward slots hold the refined map, the inverse slots the
+ *     (unchanged) source depths.  stats rows of the forward pairs: [forward group's loss (forward + its depth consistency + prior),
+ *     own share, own mask count, lambda, iterate]; of the inverse pairs: as tcsfm_refine_window under the rule. */
 int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                               float *depth_out, float *stats_out);
+
+/* ONE linearisation of tcsfm_refine_dense_window's REFERENCE-LOSS mode at `pose` and `depth_t` (nothing is updated): the loss and its
+ * exact gradients, for pinning against the reference's loss and autograd (golden G13) -- the dense counterpart of
+ * tcsfm_linearize_window.  Outputs (HOST pointers, float64): scal_out [8] = loss, forward group (forward term + its depth
+ * consistency + prior), inverse photometric term, inverse depth-consistency term, K_f, K_i, a_f = c_f / K_f, 0;
+ * g_pose_out [2*S*B][6] = d loss / d (left SE(3) perturbation of every directed pair's warp transform) in the stacked pair order;
+ * g_rho_out [B][H*W] float32 (device or host pointer as o->host_ptrs says) = d loss / d (inverse depth of target b).
+ * depth0 [B,1,H,W] (same kind of pointer as depth_t; DEPTH, not disparity) or NULL: the centre of the l_depth_init prior -- the
+ * reference's self.target_disparity, the map the optimisation started from (optimizer.py:156,90); NULL: depth_t itself (the state at
+ * the first epoch, where the prior and its gradient vanish). */
+int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
+                                 double *scal_out, double *g_pose_out, float *g_rho_out);
 
 /* ScaleRecovery.forward, models/dnet_layers.py:249-327 (the step right after the path in optimize_window,
  * optimizer.py:254-258): camera-height map |P.n| from 8-neighbour surface normals, ground mask, exact lower median of the

@@ -2170,7 +2170,9 @@ static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, con
                     ssim_t q;
                     ssim_at(sig0, sig, H, W, u, v, &q);          /* (symmetric in its arguments; differentiated w.r.t. the second, as everywhere) */
                     sc->L_init += wp * q.s;
-                    if (q.clamped) continue;
+                    /* SSIM <= 1, so the loss value (1 - SSIM) / 2 is never below 0 except by rounding -- which is exactly what happens at
+                     * the first linearisation, where sigma == sigma0 bit for bit: only the upper clamp switches the derivative off */
+                    if ((1 - (q.n1 * q.n2) / (q.d1 * q.d2)) / 2 > 1) continue;
                     real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
                     real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
                     real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);

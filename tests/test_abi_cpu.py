@@ -32,8 +32,8 @@ def test_opts_struct_matches_header(lib):
     o = _lib.default_opts()
     assert (o.n_iters, o.solver, o.param, o.refine, o.automask) == (4, 0, 0, 0, 1)
     assert abs(o.w_l1 - 0.15) < 1e-7 and abs(o.w_ssim - 0.85) < 1e-7 and abs(o.max_depth - 2.67) < 1e-6
-    assert C.sizeof(_lib.Opts) == 8 * 4 + 13 * 4 + 3 * 4          # 8 int32, 13 float, then window_rule / dense_joint / reserved2
-    assert (o.window_rule, o.dense_joint, o.reserved2) == (_lib.WINDOW_PAIR, 1, 0)
+    assert C.sizeof(_lib.Opts) == 8 * 4 + 13 * 4 + 3 * 4          # 8 int32, 13 float, then window_rule / dense_joint (int32) / prior_init (float)
+    assert (o.window_rule, o.dense_joint) == (_lib.WINDOW_PAIR, 1) and abs(o.prior_init - 0.1) < 1e-7
     # the header's struct, compiled by the C compiler, has the same size and the same offsets of the last fields
     import subprocess, tempfile, os
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "tcsfm.h"\nint main(void){printf("%zu %zu %zu %zu", sizeof(tcsfm_opts), offsetof(tcsfm_opts, prior_depth), offsetof(tcsfm_opts, window_rule), offsetof(tcsfm_opts, dense_joint));return 0;}'

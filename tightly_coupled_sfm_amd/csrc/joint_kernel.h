@@ -40,7 +40,15 @@ struct JointParams {
     float lambda_depth, w_prior;
     int B, S, argmin;        // every pixel is weighted by the depth-consistency map of the source it counts for (see tcsfm.h)
     int automask;            // own masks (no argmin): optimizer.py:71-73 has no auto-mask there -> 0 from the host when S > 1
+    // REF (k_dense_joint<.., REF = true>): the forward group under the reference's COMPLETE loss (optimizer.py:47-90, dense_ref_kernel.h):
+    const int *norms;        // [2] batch-summed mask counts K_f (forward selection) and K_i (inverse pairs) of THIS linearisation (k_dref_prepass)
+    const long long *ext;    // [B][H*W][2] fixed-point (2^-40) adjoint sums of the inverse pairs' samples of the target depth (k_dref_prepass)
+    float c_f;               // factor on the forward term: 1 with the min over the sources, 0.25 without (:73)
+    float b_dc;              // per-pixel weight of the depth-consistency terms: w_dc / (S B H W) (:83-86)
+    float w_init_px;         // per-pixel weight of the SSIM prior between current and initial sigmoid disparity: w_init / (B H W) (:89-90)
+    float sig_lo, sig_ir;    // sigmoid disparity = (rho - sig_lo) * sig_ir: 1 / max_depth and 1 / (1 / min_depth - 1 / max_depth)
 };
+constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums (integer atomics: order-independent)
 
 // reduce N (<= 32) per-thread values over the workgroup and ADD them to LDS accumulators acc[slot(k)], k = 0..N-1
 template <int N, int NT, class SlotFn>
@@ -57,7 +65,7 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
     __syncthreads();
 }
 
-template <int NS, int TW, int TH, int NT, bool TRACE = false>
+template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false>
 __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams J) {
     using JL = JointLayout<NS>;
     constexpr int NP = 6;
@@ -70,6 +78,17 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     __shared__ float4 coef[N1 * 3];
     __shared__ float red[(NT / 64) * 32];
     __shared__ float acc[JL::NACC];
+    __shared__ float w0[REF ? N2 : 1];             // REF: depth-consistency weight of SOURCE 0 on tile + 2-pixel halo (optimizer.py:69)
+    __shared__ float sgq[REF ? 2 * N2 : 1];        // REF: (sigma, sigma0) on tile + 2-pixel halo: the l_depth_init prior (optimizer.py:89-90)
+    // REF: everything is accumulated in units of the forward term's factor a_f = c_f / K_f (k_solve_joint multiplies by it)
+    float r_dc = 0.f, r_init = 0.f, r_inv = 0.f;
+    if (REF) {
+        const float Kf = (float)J.norms[0], Ki = (float)J.norms[1];
+        const float iaf = Kf > 0.f ? Kf / J.c_f : 0.f;                 // 1 / a_f
+        r_dc = J.b_dc * iaf; r_init = J.w_init_px * iaf; r_inv = Ki > 0.f ? 0.25f / Ki * iaf : 0.f;
+    }
+    const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
+    const bool ref_prior = REF && J.w_init_px > 0.f;
 
     const int nblk = P.tiles_x * P.tiles_y;
     int bid = blockIdx.x;
@@ -94,11 +113,15 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     // per-pixel state across the sources
     float o_depth = 1.f, g_rho = 0.f, Dsum = 0.f, mcnt = 0.f;
     bool o_pad = false;      // some source's sample at this pixel is valid but blends with the zero padding: the pixel keeps its depth
+    float ddJ0[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // REF: d dd_0 / d(xi_0, rho) at this pixel (the weight term of every source's pixels)
+    float extra_cost = 0.f;                                // REF: depth-consistency and prior cost of this pixel (units of a_f)
+    float o_sig = 0.f, o_sig0 = 0.f, o_pd1 = 1.f, o_pd2 = 1.f;   // REF prior: own sigmoid disparities and SSIM denominators
+    bool o_pcl = true;                                     // REF prior: SSIM value clamped (no gradient / curvature)
 
     constexpr int NRING = N2 - NCEN;
     static_assert(NRING <= NT, "one ring round");
     constexpr int RING_THREADS = (NRING + 63) / 64 * 64;
-    struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
+    struct Stage { int lx, ly, px, py; float4 tp; float dep, dep0; Geo g; Tap t; };
 
 #pragma unroll 1
     for (int s = 0; s < NS; s++) {
@@ -108,12 +131,14 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         const float4 *srcpack = P.srcpack + (size_t)n * (H + 2) * (W + 2);
         float a[7], bb[7], zc[7];
         float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f;
+        bool o_dcin = false;     // this source's projected-depth sample is a real depth sample (no zero padding in its footprint)
 
         // ---------------- phase 1: tile + 2-pixel halo, warped with the shared depth ----------------
         auto s_load = [&](Stage &S) {
             S.px = refl_idx(x00 + S.lx - 2, W); S.py = refl_idx(y00 + S.ly - 2, H);
             const int gi = S.py * W + S.px;
             S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+            S.dep0 = (REF && ref_prior && s == 0) ? J.depth0[(size_t)b * hw + gi] : 1.f;
         };
         auto s_warp = [&](Stage &S) {
             warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
@@ -126,11 +151,19 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             float pd = c.es * val.w, cd = S.g.Z;
             float Wt = 1.f - clamp01(fabsf(cd - pd) * frcp(cd + pd));
             if (write) {
+                float Wuse = Wt;
+                if (REF && ref_w0) {            // the same thread stages the same position for every source: no barrier needed
+                    if (s == 0) w0[S.ly * W2 + S.lx] = Wt; else Wuse = w0[S.ly * W2 + S.lx];
+                }
+                if (REF && ref_prior && s == 0) {
+                    sgq[2 * (S.ly * W2 + S.lx)] = (frcp(S.dep) - J.sig_lo) * J.sig_ir;
+                    sgq[2 * (S.ly * W2 + S.lx) + 1] = (frcp(S.dep0) - J.sig_lo) * J.sig_ir;
+                }
                 float4 *rec = rec1 + (S.ly * W2 + S.lx) * 3;
                 lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
                 lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
                 lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
-                lds_write1(aux + S.ly * W2 + S.lx, Wt, oob ? 0.f : 1.f, S.tp.w, 0.f);
+                lds_write1(aux + S.ly * W2 + S.lx, Wuse, oob ? 0.f : 1.f, S.tp.w, 0.f);
             }
             if (own) {
                 if (TRACE && P.trace != nullptr && inimg)
@@ -140,6 +173,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 a[6] *= -S.dep; bb[6] *= -S.dep; zc[6] *= -S.dep;      // scale column -> inverse-depth column
                 o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
                 o_pad = o_pad || (!oob && !S.t.inside);
+                o_dcin = !oob && S.t.inside;
             }
         };
         {
@@ -236,11 +270,43 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             float m = (real && ax.y > 0.5f && (!J.automask || diff < ax.z)) ? 1.f : 0.f;
             if (P.ext_diff != nullptr)      // min over the sources: does forward pair n keep this pixel?
                 m = (real && ext_selected(P, n, gy_ * W + gx_, hw)) ? 1.f : 0.f;
-            float w = m * ax.x;    // M_s W_s
+            float w = m * ax.x;    // M_s W_x
+            float pA = 0.f, pB = 0.f, pC = 0.f;
+            if (REF && ref_prior && s == 0) {
+                // l_depth_init: SSIM_Loss(sigma, sigma0) at this position (losses.py:27-41 on one channel, reflect-padded as the region is);
+                // d s_p / d sigma_q = pA + pB (sigma_q - 1/2) + pC (sigma0_q - 1/2) for the nine q of its window
+                const float *sc = sgq + 2 * ((ly + 1) * W2 + lx + 1);
+                const float yc_ = sc[0], xc_ = sc[1];
+                float Sy = 0.f, Sx = 0.f, Syy = 0.f, Sxx = 0.f, Sxy = 0.f;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const float ey = sc[2 * (dy * W2 + dx)] - yc_, ex = sc[2 * (dy * W2 + dx) + 1] - xc_;
+                        Sy += ey; Sx += ex; Syy += ey * ey; Sxx += ex * ex; Sxy += ex * ey;
+                    }
+                const float n9 = 1.f / 9.f;
+                const float mdx = Sx * n9, mdy = Sy * n9, mux = xc_ + mdx, muy = yc_ + mdy;
+                const float sigx = Sxx * n9 - mdx * mdx, sigy = Syy * n9 - mdy * mdy, sigxy = Sxy * n9 - mdx * mdy;
+                const float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+                const float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+                const float idn = frcp(d1 * d2), ratio = n1 * n2 * idn, raw = (1.f - ratio) * 0.5f;
+                const bool cl = raw > 1.f;      // (the lower clamp is rounding only -- SSIM <= 1 -- and sigma == sigma0 at the first linearisation: oracle)
+                if (real && !cl) {
+                    const float pre = idn * (-0.5f * n9);
+                    pB = pre * (ratio * d1) * -2.f;
+                    pC = pre * n1 * 2.f;
+                    pA = pre * 2.f * (mux * n2 - ratio * muy * d2) - pB * mdy - pC * mdx + pB * (0.5f - yc_) + pC * (0.5f - xc_);
+                }
+                if (r == 0) {
+                    o_sig = yc_; o_sig0 = xc_; o_pd1 = d1; o_pd2 = d2; o_pcl = cl;
+                    if (real) extra_cost += r_init * clamp01(raw);
+                }
+            }
             float4 *cr = coef + (ly * W1 + lx) * 3;
             lds_write1(cr + 0, w * cA[0], w * cA[1], w * cA[2], w * cB[0]);
             lds_write1(cr + 1, w * cB[1], w * cB[2], w * cC[0], w * cC[1]);
-            lds_write1(cr + 2, w * cC[2], 0.f, 0.f, 0.f);
+            lds_write1(cr + 2, w * cC[2], pA, pB, pC);
             if (r == 0) {
                 o_valid = ax.y;
                 o_diff = diff; o_w = w; o_m = m; o_lxx = lxx; o_lxy = lxy; o_lyy = lyy; o_l1x = l1x; o_l1y = l1y;
@@ -253,6 +319,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
 
         // ---------------- phase 2b: adjoint gather; this source's gradient, curvature block and depth terms ----------------
         float v[29];      // H_ss (21, pre-Schur) | g_s (6) | share_s | n_mask_s
+        float vx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 29; i++) v[i] = 0.f;
         if (inimg) {
@@ -271,6 +338,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             const float myu = (gyo == 1) ? 2.f : 1.f, myd = (gyo == H - 2) ? 2.f : 1.f;
             const float yq[3] = {o_y[0] - 0.5f, o_y[1] - 0.5f, o_y[2] - 0.5f}, xq[3] = {o_x[0] - 0.5f, o_x[1] - 0.5f, o_x[2] - 0.5f};
             float sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0}, sC[3] = {0, 0, 0};
+            float sP[3] = {0, 0, 0};          // REF: the prior's coefficient sums (source 0's records carry them)
 #pragma unroll 1
             for (int r = 0; r < 3; r++) {
                 const float fy = r == 0 ? myu : (r == 2 ? myd : 1.f);
@@ -283,6 +351,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                     sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
                     sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
                     sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
+                    if (REF) { sP[0] += fm * c2.y; sP[1] += fm * c2.z; sP[2] += fm * c2.w; }
                 }
             }
             float sx = o_w * o_l1x, sy = o_w * o_l1y;
@@ -291,11 +360,27 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 const float lam = sA[ch] + sB[ch] * yq[ch] + sC[ch] * xq[ch];
                 sx += lam * o_gx[ch]; sy += lam * o_gy[ch];
             }
-            // weight term -M_s diff_s d dd_s / d theta (own pixel, own source)
-            const float kdd = o_m * o_diff * sg;
+            // d dd_s / d(xi_s, rho) = sg (pd zc - cd dpd) of THIS source at this pixel
+            float ddJ[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) ddJ[j] = sg * (o_pd * zc[j] - o_cd * (o_dgx * a[j] + o_dgy * bb[j]));
+            if (REF && ref_w0 && s == 0) {
+#pragma unroll
+                for (int j = 0; j < 7; j++) ddJ0[j] = ddJ[j];
+            }
+            // weight term -M_s diff_s d dd_x / d theta: own source's map (x = s), or under the reference's rule source 0's (x = 0): for the
+            // pixels of the other sources it then lands in source 0's pose gradient (cross, below) and in the shared depth
+            const float kdd = o_m * o_diff;
+            const bool wown = !(REF && ref_w0 && s > 0);
             float grow[7];
 #pragma unroll
-            for (int j = 0; j < 7; j++) grow[j] = sx * a[j] + sy * bb[j] - kdd * (o_pd * zc[j] - o_cd * (o_dgx * a[j] + o_dgy * bb[j]));
+            for (int j = 0; j < 7; j++) grow[j] = sx * a[j] + sy * bb[j] - (wown ? kdd * ddJ[j] : 0.f);
+            float cross[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!wown) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) cross[j] = -kdd * ddJ0[j];
+                grow[6] -= kdd * ddJ0[6];
+            }
             const float wxx = o_w * o_lxx, wxy = o_w * o_lxy, wyy = o_w * o_lyy;
             float la[7], lb[7];
 #pragma unroll
@@ -306,6 +391,26 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             float Bq[6];
 #pragma unroll
             for (int j = 0; j < 6; j++) Bq[j] = la[j] * a[6] + lb[j] * bb[6];
+            // REF: depth consistency of this forward pair (optimizer.py:83-86; every pixel of the image): Huberised gradient, IRLS
+            // curvature over real depth samples only -- as k_linearize has it for the poses, here with the inverse-depth column
+            float kdc = 0.f;
+            if (REF && r_dc > 0.f) {
+                const float dd = clamp01(fabsf(o_cd - o_pd) * frcp(o_cd + o_pd));
+                const float inf = r_dc * fminf(1.f, dd * frcp(P.eps));
+                kdc = o_dcin ? r_dc * frcp(fmaxf(dd, P.eps)) : 0.f;
+                extra_cost += r_dc * dd;
+#pragma unroll
+                for (int j = 0; j < 7; j++) grow[j] += inf * ddJ[j];
+                g_rho += inf * ddJ[6];
+                Dsum += kdc * ddJ[6] * ddJ[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) Bq[j] += kdc * ddJ[j] * ddJ[6];
+            }
+            if (REF && ref_prior && s == 0) {      // the prior's gradient (adjoint of the 3x3 window) and its diagonal curvature model
+                const float pl = sP[0] + sP[1] * (o_sig - 0.5f) + sP[2] * (o_sig0 - 0.5f);
+                g_rho += r_init * J.sig_ir * pl;
+                if (!o_pcl) Dsum += r_init * J.sig_ir * J.sig_ir * (frcp(o_pd2) + (1.f / 9.f) * frcp(o_pd1));
+            }
             // B_s goes straight into the pixel's record (read back for the Schur terms below and by the back-substitution)
             jr[2 + 6 * s + 0] = Bq[0]; jr[2 + 6 * s + 1] = Bq[1]; jr[2 + 6 * s + 2] = Bq[2];
             jr[2 + 6 * s + 3] = Bq[3]; jr[2 + 6 * s + 4] = Bq[4]; jr[2 + 6 * s + 5] = Bq[5];
@@ -314,10 +419,14 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             for (int j = 0; j < 6; j++) {
                 v[21 + j] = grow[j];
 #pragma unroll
-                for (int i = 0; i <= j; i++) { v[h] = la[j] * a[i] + lb[j] * bb[i]; h++; }
+                for (int i = 0; i <= j; i++) { v[h] = la[j] * a[i] + lb[j] * bb[i] + ((REF) ? kdc * ddJ[j] * ddJ[i] : 0.f); h++; }
             }
             v[27] = o_w * o_diff;
             v[28] = o_m;
+            if (REF && ref_w0 && s > 0) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) vx[j] = cross[j];
+            }
         }
         joint_reduce_add<29, NT>(v, red, acc, [&](int k) {
             if (k >= 27) return k == 27 ? JL::OFF_SHARE + s : JL::OFF_NM + s;
@@ -326,6 +435,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             while ((j + 1) * (j + 2) / 2 <= k) j++;
             return JL::tri(6 * s + j, 6 * s + (k - j * (j + 1) / 2));
         }, tid);          // (its barriers also protect rec1 / aux / coef for the next source)
+        if (REF && ref_w0 && s > 0)          // the cross term: source 0's weight map on this source's pixels -> source 0's pose gradient
+            joint_reduce_add<6, NT>(vx, red, acc, [&](int k) { return JL::OFF_G + k; }, tid);
     }
 
     // ---------------- after the sources: prior, per-pixel Schur elimination of the shared depth ----------------
@@ -336,13 +447,19 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         for (int j = 0; j < 6; j++) Bv[s][j] = 0.f;
     float prior_cost = 0.f;
     if (inimg) {
+        if (REF) {      // the inverse pairs see this depth through their bilinear samples of it: adjoint sums of k_dref_prepass (fixed point)
+            const long long *e = J.ext + ((size_t)b * hw + gyo * W + gxo) * 2;
+            const float E1 = (float)((double)e[0] * (1.0 / DREF_FIX)), E2 = (float)((double)e[1] * (1.0 / DREF_FIX));
+            g_rho -= o_depth * o_depth * (r_dc * E2 - r_inv * E1);          // d depth / d rho = -depth^2
+            prior_cost = extra_cost;
+        }
         float D = Dsum;
         if (J.w_prior > 0.f) {
             float rho = frcp(o_depth), rho0 = frcp(J.depth0[(size_t)b * hw + gyo * W + gxo]);
             float ir2 = frcp(rho0 * rho0), dr = rho - rho0;
             g_rho += mcnt * 2.f * J.w_prior * dr * ir2;
             D += mcnt * 2.f * J.w_prior * ir2;
-            prior_cost = mcnt * J.w_prior * dr * dr * ir2;
+            prior_cost += mcnt * J.w_prior * dr * dr * ir2;
         }
         const float Dd = (1.f + J.lambda_depth) * D;
         const bool elim = Dd > 1e-30f && !o_pad;         // (dense_kernel.h: pixels sampled across the zero padding keep their depth)
@@ -372,7 +489,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             return JL::tri(6 * s + j, 6 * s + (k - j * (j + 1) / 2));
         }, tid);
     }
-    if (!J.argmin) {                     // off-diagonal blocks: the shared depth couples the poses (18 values per reduction)
+    if (!J.argmin || (REF && r_dc > 0.f)) {   // off-diagonal blocks: the shared depth couples the poses (18 values per reduction); under the
+                                              // reference's loss the depth-consistency terms of ALL sources see the depth of every pixel
 #pragma unroll
         for (int s = 1; s < NS; s++)
 #pragma unroll
@@ -417,6 +535,9 @@ struct JointSolveParams {
     double *delta_out;        // [B][6 JMAXS] pose step of this iteration (back-substitution)
     int *accept_out;          // [B] LM decision (or null)
     int *trace_decide;        // [N] slot of every forward pair of the target, or null
+    const int *norms;         // REF (or null): [2] batch-summed mask counts; the records are in units of c_f / norms[0]
+    double c_f;
+    double *export_out;       // linearisation export (tcsfm_linearize_dense_window): [B][2 + 6 JMAXS] = cost, factor a_f, g (per source 6), or null
 };
 
 constexpr int JSOLVE_NT = 1024;
@@ -470,8 +591,14 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
         }
     }
     __syncthreads();
-    const double Kn = tot[JL::OFF_S + 1], an = Kn > 0 ? 1.0 / Kn : 0.0;
+    double Kn = tot[JL::OFF_S + 1], an = Kn > 0 ? 1.0 / Kn : 0.0;
+    if (P.norms) { Kn = (double)P.norms[0]; an = Kn > 0 ? P.c_f / Kn : 0.0; }      // the reference's batch normaliser (optimizer.py:69)
     const double cost = an * tot[JL::OFF_S];
+    if (P.export_out) {       // one linearisation, exported (no step): cost, a_f and the pose gradients of the group's records
+        if (tid == 0) { P.export_out[(size_t)b * (2 + 6 * JMAXS)] = cost; P.export_out[(size_t)b * (2 + 6 * JMAXS) + 1] = an; }
+        if (tid < NP) P.export_out[(size_t)b * (2 + 6 * JMAXS) + 2 + tid] = an * tot[JL::OFF_G + tid];
+        return;
+    }
     double lambda = P.it == 0 && P.mode == 0 ? P.lambda0 : S_lambda;
     const bool have_cur = !(P.it == 0 && P.mode == 0) && S_have_cur;
     const double cost_cur = S_cost_cur;
@@ -604,6 +731,8 @@ struct JointUpdateParams {
     float *depth_out;         // optional: [.][H*W] same layout (the caller's buffer), or null
     int hw, B, S, mode;       // mode 0: step; 1: final LM decision (keep the trial or fall back to the accepted map), no step
     float rho_lo, rho_hi;
+    float4 *srcpack_inv;      // REF (or null): packs of the inverse pairs (pair S B + s B + b samples target b's depth: channel w), refreshed
+    int W, H;                 //   with the new map so that the inverse pairs of the next linearisation see the depth the forward pairs see
 };
 
 template <int NS>
@@ -647,6 +776,11 @@ __global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P)
     for (int s = 0; s < P.S; s++) {
         P.depth[(size_t)(s * P.B + b) * P.hw + idx] = dep;
         if (P.depth_out) P.depth_out[(size_t)(s * P.B + b) * P.hw + idx] = dep;
+    }
+    if (P.srcpack_inv) {
+        const int v = idx / P.W, u = idx - v * P.W;
+        for (int s = 0; s < P.S; s++)
+            P.srcpack_inv[((size_t)(s * P.B + b) * (P.H + 2) + v + 1) * (P.W + 2) + u + 1].w = dep;
     }
 }
 

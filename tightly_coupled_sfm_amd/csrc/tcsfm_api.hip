@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "dense_kernel.h"
 #include "joint_kernel.h"
+#include "dense_ref_kernel.h"
 #include "scale_kernel.h"
 #include "posenet_kernel.h"
 
@@ -54,6 +55,10 @@ struct tcsfm_ctx {
     JointState *jstate = nullptr;
     double *jdelta = nullptr;
     int jrec_S = 0;
+    // dense mode on the reference's loss (dense_ref_kernel.h): mask counts, fixed-point scatter sums, linearisation export
+    int *dref_norms = nullptr;
+    long long *dref_ext = nullptr;
+    double *dref_export = nullptr;
     hipStream_t aux_stream = nullptr;  // joint dense mode: the inverse pairs' refinement runs beside the forward group's (fork / join by events)
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     float *sel_maps = nullptr;   // dense window modes: the forward pairs' diff | valid maps, [2][max_pairs][H*W], allocated on first use
@@ -496,6 +501,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr;
     if (n_sel) { Pj.ext_diff = sel_diff; Pj.ext_valid = sel_valid; Pj.n_ext = n_sel; Pj.ext_B = B; Pj.ext_S = S; }
     JointParams J;
+    memset(&J, 0, sizeof(J));
     J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = o->lambda_depth; J.w_prior = o->prior_depth;
     J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
     J.automask = 0;                             // own masks only without argmin, where the reference's forward term has no auto-mask (:71-73)
@@ -505,6 +511,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     Sj.n_iters = o->n_iters; Sj.solver = o->solver; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
     Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = lm ? h->lm_accept : nullptr;
     JointUpdateParams Uj;
+    memset(&Uj, 0, sizeof(Uj));
     Uj.jrec = h->jrec; Uj.jrec_acc = lm ? h->jrec_acc : nullptr; Uj.depth_acc = lm ? h->jdepth_acc : nullptr; Uj.delta = h->jdelta;
     Uj.accept = lm ? h->lm_accept : nullptr; Uj.depth = h->depth_work; Uj.depth_out = nullptr; Uj.hw = (int)hw; Uj.B = B; Uj.S = S; Uj.mode = 0;
     Uj.rho_lo = 1.f / o->max_depth; Uj.rho_hi = 1.f / o->min_depth;
@@ -604,6 +611,172 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     return TCSFM_OK;
 }
 
+
+// tiny export kernel of tcsfm_linearize_dense_window: d loss / d rho = a_f x the joint kernel's per-pixel record
+__global__ __launch_bounds__(256) void k_dref_export_grho(const float *jrec, int jrec_stride, const double *exp_out, int exp_stride, float *out, int hw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (idx >= hw) return;
+    out[(size_t)b * hw + idx] = (float)(exp_out[(size_t)b * exp_stride + 1] * (double)jrec[((size_t)b * hw + idx) * jrec_stride]);
+}
+
+// Dense window mode on the REFERENCE's loss (include/tcsfm.h, dense_ref_kernel.h).  Inputs on the device.  lin_export != nullptr: ONE
+// linearisation at the given poses, nothing updated: host outputs of tcsfm_linearize_dense_window.
+struct DrefExport { double *scal, *g_pose; float *d_g_rho; const float *d_depth0; };
+template <int NS>
+int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, const float *d_src, const float *d_dt, const float *d_ds,
+                  const float *d_K, const float *d_pose_in, float *d_pose_out, float *d_depth_out, float *d_stats, const WinOff *wo, const DrefExport *ex) {
+    using JL = JointLayout<NS>;
+    using JM = JointLayout<JMAXS>;
+    constexpr int S = NS;
+    const int SB = S * B, N = 2 * SB;
+    const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
+    int rc;
+    constexpr int DTW = 32, DTH = 16, DNT = 512;
+    static_assert(DTW == TILE_W && DTH == TILE_H, "the joint kernel and the pose kernel share the tile grid");
+    const int nblk = h->nblk;
+    const bool sel = o->argmin && S > 1, dc = o->w_dc > 0.f;
+    if (!h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
+    if (!h->dense_rec) {
+        HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->delta, n * 8 * sizeof(double)));
+    }
+    if (!h->jrec) {
+        const size_t nb = (n + 3) / 4;
+        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JM::NACC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
+        HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
+        h->jrec_S = JMAXS;
+    }
+    if (!h->dref_norms) {
+        HIPCHK(h, hipMalloc((void **)&h->dref_norms, 4 * sizeof(int)));
+        HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * 2 * sizeof(long long)));      // (targets <= max_pairs / 2)
+        HIPCHK(h, hipMalloc((void **)&h->dref_export, ((n + 1) / 2) * (2 + 6 * JMAXS) * sizeof(double)));
+    }
+    tcsfm_opts oo = *o;
+    oo.refine = TCSFM_REFINE_POSE;
+    oo.window_rule = TCSFM_WINDOW_PAIR;          // (the couplings are set explicitly below)
+    InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
+    I.K_mod = B;
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, B, S, h->depth0, wo))) return rc;
+    if (ex && ex->d_depth0)       // the prior's centre given explicitly (slots of the forward pairs (0, b): index b)
+        HIPCHK(h, hipMemcpyAsync(h->depth0, ex->d_depth0, (size_t)B * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if ((rc = trace_check(h, o, N))) return rc;
+    const bool tr = h->trace_bits != nullptr;
+    float *maps_diff = h->sel_maps, *maps_valid = h->sel_maps + (size_t)h->max_pairs * hw;
+    // ---- residual maps of all pairs
+    LinParams M = lin_params(h, &oo, 6);
+    M.o_diff = maps_diff; M.o_valid = maps_valid;
+    // ---- prepass: counts and the scatter of the inverse pairs' depth samples
+    LinParams Pp = lin_params(h, &oo, 6);
+    Pp.ext_diff = maps_diff; Pp.ext_valid = maps_valid; Pp.n_ext = SB; Pp.ext_B = B; Pp.ext_S = S;
+    DrefPrepassParams Dp;
+    Dp.diff = maps_diff; Dp.valid = maps_valid; Dp.norms = h->dref_norms; Dp.ext = h->dref_ext; Dp.B = B; Dp.S = S;
+    Dp.argmin = o->argmin ? 1 : 0; Dp.automask = o->automask; Dp.eps = o->irls_eps;
+    // ---- inverse pairs: pose kernels on views offset by S B pairs, window rule REFERENCE (all of them are the rule's inverse group)
+    LinParams Pi = lin_params(h, &oo, 6);
+    const int nacc6 = AccLayout<6>::NACC;
+    Pi.tgtpack += (size_t)SB * hw; Pi.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pi.depth_t += (size_t)SB * hw; Pi.pc += SB;
+    Pi.blockrec += (size_t)SB * h->nblk * nacc6; Pi.tickets += (size_t)SB * h->ngrp; Pi.partials += (size_t)SB * h->ngrp * nacc6;
+    SolveParams Si = solve_params(h, &oo, 6, 0);
+    Si.partials = direct_records(h) ? Pi.blockrec : Pi.partials;
+    Si.st = h->state + SB; Si.pc = h->pconst + SB; Si.lin_out = h->lin_out + (size_t)SB * kLinOut;
+    Si.rule = 1; Si.grp_fwd = 0; Si.n_pairs = SB; Si.scale_fwd = 1.0; Si.scale_inv = 0.25;
+    Si.b_dc = (double)o->w_dc / ((double)SB * (double)hw);
+    Si.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
+    // ---- forward group: the joint kernel under the reference's rule
+    LinParams Pj = lin_params(h, &oo, 6);
+    Pj.tiles_x = h->tiles_x; Pj.tiles_y = h->tiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
+    if (sel) { Pj.ext_diff = maps_diff; Pj.ext_valid = maps_valid; Pj.n_ext = SB; Pj.ext_B = B; Pj.ext_S = S; }
+    JointParams J;
+    memset(&J, 0, sizeof(J));
+    J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = ex ? 1e20f : o->lambda_depth;      // (export: depth block frozen, the reduced right-hand side IS the pose gradient) J.w_prior = 0.f;
+    J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
+    J.automask = o->argmin ? o->automask : 0;     // own masks: with one source the min is the source itself; without argmin no auto-mask (:71-73)
+    J.norms = h->dref_norms; J.ext = h->dref_ext; J.c_f = o->argmin ? 1.f : 0.25f;
+    J.b_dc = o->w_dc / ((float)SB * (float)hw); J.w_init_px = o->prior_init / ((float)B * (float)hw);
+    J.sig_lo = 1.f / o->max_depth; J.sig_ir = 1.f / (1.f / o->min_depth - 1.f / o->max_depth);
+    JointSolveParams Sj;
+    memset(&Sj, 0, sizeof(Sj));
+    Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
+    Sj.n_iters = o->n_iters; Sj.solver = TCSFM_SOLVER_GN; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
+    Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = nullptr;
+    Sj.norms = h->dref_norms; Sj.c_f = J.c_f;
+    JointUpdateParams Uj;
+    memset(&Uj, 0, sizeof(Uj));
+    Uj.jrec = h->jrec; Uj.delta = h->jdelta; Uj.depth = h->depth_work; Uj.hw = (int)hw; Uj.B = B; Uj.S = S; Uj.mode = 0;
+    Uj.rho_lo = 1.f / o->max_depth; Uj.rho_hi = 1.f / o->min_depth;
+    Uj.srcpack_inv = h->srcpack + (size_t)SB * (h->H + 2) * (h->W + 2); Uj.W = h->W; Uj.H = h->H;
+    const dim3 px_t((unsigned)((hw + 255) / 256), B), px_all((unsigned)((hw + 255) / 256), N);
+    hipStream_t st = h->stream;
+    auto linearise = [&](int lin) -> int {
+        HIPCHK(h, hipMemsetAsync(h->dref_norms, 0, 4 * sizeof(int), st));
+        HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)B * hw * 2 * sizeof(long long), st));
+        launch_lin(h, M, N, 6, false, MODE_MAPS, 2);
+        hipLaunchKernelGGL(k_dref_prepass, px_all, dim3(256), 0, st, Pp, Dp);
+        Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
+        Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
+        launch_lin(h, Pi, SB, 6, dc, MODE_LIN, 2);
+        Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
+        Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
+        take_stamp(h, Pj, (size_t)nblk * B);
+        ProfScope prof(h, 0);
+        if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+        else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+        return TCSFM_OK;
+    };
+    if (ex) {        // one linearisation, exported
+        if ((rc = linearise(0))) return rc;
+        Si.mode = 2; Si.it = 0;
+        launch_solve(h, Si, SB, 6);
+        Sj.it = 0; Sj.mode = 0; Sj.export_out = h->dref_export;
+        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
+        hipLaunchKernelGGL(k_dref_export_grho, px_t, dim3(256), 0, st, (const float *)h->jrec, (int)JL::JREC, (const double *)h->dref_export, 2 + 6 * JMAXS, ex->d_g_rho, (int)hw);
+        HIPCHK(h, hipGetLastError());
+        constexpr int kLin6 = 6 * 6 + 6 + 4;          // k_solve<6> mode 2: H [36], g [6], cost, cost_photo, cost_dc, n_mask
+        std::vector<double> lin((size_t)SB * kLin6), jx((size_t)B * (2 + 6 * JMAXS));
+        int norms[4];
+        HIPCHK(h, hipMemcpyAsync(lin.data(), Si.lin_out, lin.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(jx.data(), h->dref_export, jx.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(norms, h->dref_norms, sizeof(norms), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        double fwd = 0, inv_p = 0, inv_d = 0;
+        for (int b = 0; b < B; b++) {
+            fwd += jx[(size_t)b * (2 + 6 * JMAXS)];
+            for (int s_ = 0; s_ < S; s_++)
+                for (int j = 0; j < 6; j++) ex->g_pose[(size_t)(s_ * B + b) * 6 + j] = jx[(size_t)b * (2 + 6 * JMAXS) + 2 + 6 * s_ + j];
+        }
+        for (int m = 0; m < SB; m++) {
+            const double *q = &lin[(size_t)m * kLin6];
+            for (int j = 0; j < 6; j++) ex->g_pose[(size_t)(SB + m) * 6 + j] = q[36 + j];
+            inv_p += q[36 + 6 + 1]; inv_d += q[36 + 6 + 2];
+        }
+        ex->scal[0] = fwd + inv_p + inv_d; ex->scal[1] = fwd; ex->scal[2] = inv_p; ex->scal[3] = inv_d;
+        ex->scal[4] = norms[0]; ex->scal[5] = norms[1]; ex->scal[6] = jx[1]; ex->scal[7] = 0.0;
+        return TCSFM_OK;
+    }
+    for (int it = 0; it < o->n_iters; it++) {
+        if ((rc = linearise(it))) return rc;
+        const bool last = it == o->n_iters - 1;
+        Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
+        launch_solve(h, Si, SB, 6);
+        Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
+        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
+        hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (o->n_iters == 0) {
+        FinishParams F;
+        F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = nullptr; F.N = N;
+        hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, st, F);
+    }
+    HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return TCSFM_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -619,6 +792,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->prior_scale = 1.0f;
     o->lambda_depth = 1.0f; o->prior_depth = 10.0f;
     o->window_rule = TCSFM_WINDOW_PAIR; o->dense_joint = 1;
+    o->prior_init = 0.1f;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -701,7 +875,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
@@ -1276,7 +1450,10 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
-    if (o->w_dc > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth)");
+    const bool ref_mode = win_B && o->window_rule == TCSFM_WINDOW_REFERENCE;      // the reference's own loss (dense_ref_kernel.h)
+    if (o->w_dc > 0.f && !ref_mode) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth), except under window_rule = TCSFM_WINDOW_REFERENCE");
+    if (ref_mode && (win_S > JMAXS || o->solver != TCSFM_SOLVER_GN || !(o->prior_init >= 0.f)))
+        return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: window_rule REFERENCE needs S <= 3, the Gauss-Newton solver and prior_init >= 0");
     if (o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: SE(3) chart only");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
     DeviceGuard dev_guard(h->device);
@@ -1311,6 +1488,17 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (stats_out) {
         if ((rc = out_dev(h, o, 9, stats_out, nstats, &d_stats))) return rc;
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
+    }
+    if (ref_mode) {
+        rc = win_S == 1 ? dense_ref_run<1>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr)
+           : win_S == 2 ? dense_ref_run<2>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr)
+                        : dense_ref_run<3>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr);
+        if (rc) return rc;
+        if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
+        if ((rc = copy_back(h, o, depth_out, d_depth_out, N * hw))) return rc;
+        if ((rc = copy_back(h, o, stats_out, d_stats, nstats))) return rc;
+        if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+        return TCSFM_OK;
     }
     if (win_B && o->dense_joint && win_S >= 2 && win_S <= JMAXS) {   // one depth map per target, 6S x 6S reduced system (joint_kernel.h)
         rc = win_S == 2 ? dense_joint_run<2>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo)
@@ -1441,6 +1629,43 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: need 1 <= 2*B*S <= max_pairs");
     return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+}
+
+int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
+                                 double *scal_out, double *g_pose_out, float *g_rho_out) {
+    if (!h) return TCSFM_E_ARG;
+    if (B < 1 || S < 1 || S > JMAXS || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_dense_window: need 1 <= S <= 3 and 2*B*S <= max_pairs");
+    const int N = 2 * B * S;
+    int rc = check_common(h, o, N);
+    if (rc) return rc;
+    if (!tgt || !srcs || !depth_t || !depth_s || !K || !pose || !scal_out || !g_pose_out || !g_rho_out) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_dense_window: NULL argument");
+    if (!(o->min_depth > 0 && o->max_depth > o->min_depth) || !(o->prior_init >= 0.f)) return fail(h, TCSFM_E_ARG, "min_depth / max_depth / prior_init invalid");
+    DeviceGuard dev_guard(h->device);
+    if (int rc_ = pending_error(h)) return rc_;
+    if ((rc = check_intrinsics(h, o, K, B))) return rc;
+    const size_t hw = (size_t)h->H * h->W;
+    const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose;
+    if ((rc = to_dev(h, o, 0, tgt, (size_t)B * 3 * hw, &d_tgt))) return rc;
+    if ((rc = to_dev(h, o, 1, srcs, (size_t)S * B * 3 * hw, &d_src))) return rc;
+    if ((rc = to_dev(h, o, 2, depth_t, (size_t)B * hw, &d_dt))) return rc;
+    if ((rc = to_dev(h, o, 3, depth_s, (size_t)S * B * hw, &d_ds))) return rc;
+    if ((rc = to_dev(h, o, 4, K, (size_t)B * 9, &d_K))) return rc;
+    if ((rc = to_dev(h, o, 5, pose, (size_t)N * 6, &d_pose))) return rc;
+    const float *d_d0 = nullptr;
+    if (depth0 && (rc = to_dev(h, o, 6, depth0, (size_t)B * hw, &d_d0))) return rc;
+    float *d_g;
+    if ((rc = out_dev(h, o, 7, g_rho_out, (size_t)B * hw, &d_g))) return rc;
+    tcsfm_opts oo = *o;
+    oo.n_iters = 1; oo.solver = TCSFM_SOLVER_GN;
+    DrefExport ex{scal_out, g_pose_out, d_g, d_d0};
+    rc = S == 1 ? dense_ref_run<1>(h, &oo, B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose, nullptr, nullptr, nullptr, nullptr, &ex)
+       : S == 2 ? dense_ref_run<2>(h, &oo, B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose, nullptr, nullptr, nullptr, nullptr, &ex)
+                : dense_ref_run<3>(h, &oo, B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose, nullptr, nullptr, nullptr, nullptr, &ex);
+    if (rc) return rc;
+    if ((rc = copy_back(h, o, g_rho_out, d_g, (size_t)B * hw))) return rc;
+    if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return TCSFM_OK;
 }
 
 int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {

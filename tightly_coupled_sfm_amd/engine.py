@@ -367,6 +367,34 @@ class Engine:
                                                       self._p(st)))
         return pose_out, depth_out, st
 
+    def linearize_dense_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, argmin: Optional[bool] = None, depth0=None):
+        """tcsfm_linearize_dense_window: ONE linearisation of the dense window mode on the reference's own loss (window_rule REFERENCE;
+        optimizer.py:47-90) -> dict(loss, fwd, inv_photo, inv_dc, K_f, K_i, a_f, g_pose [2SB,6] float64 (w.r.t. the left SE(3)
+        perturbation of every pair's warp), g_rho [B,1,H,W] GPU tensor = d loss / d inverse depth of every target);
+        depth0 [B,1,H,W]: the centre of the l_depth_init prior (default: depth_t)"""
+        self._bind()
+        o = _copy_opts(opts or default_opts())
+        if argmin is not None:
+            o.argmin = 1 if argmin else 0
+        o.window_rule = _lib.WINDOW_REFERENCE
+        if isinstance(srcs, (list, tuple)):
+            srcs = torch.stack(list(srcs), 0)
+        if isinstance(depth_s, (list, tuple)):
+            depth_s = torch.stack(list(depth_s), 0)
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        N = 2 * S * B
+        tgt = _chk(tgt, (B, 3, self.H, self.W), "tgt"); srcs = _chk(srcs, (S, B, 3, self.H, self.W), "srcs")
+        depth_t = _chk(depth_t, (B, 1, self.H, self.W), "depth_t"); depth_s = _chk(depth_s, (S, B, 1, self.H, self.W), "depth_s")
+        K = _chk(K, (B, 3, 3), "K"); pose = _chk(pose, (N, 6), "pose")
+        d0 = None if depth0 is None else _chk(depth0, (B, 1, self.H, self.W), "depth0")
+        scal = np.zeros(8); gp = np.zeros((N, 6))
+        g_rho = torch.empty((B, 1, self.H, self.W), device=pose.device, dtype=torch.float32)
+        self._call(self.lib.tcsfm_linearize_dense_window(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                                         self._p(K), self._p(pose), self._p(d0), scal.ctypes.data_as(C.c_void_p),
+                                                         gp.ctypes.data_as(C.c_void_p), self._p(g_rho)))
+        torch.cuda.synchronize(self.device)
+        return dict(loss=scal[0], fwd=scal[1], inv_photo=scal[2], inv_dc=scal[3], K_f=scal[4], K_i=scal[5], a_f=scal[6], g_pose=gp, g_rho=g_rho)
+
     def scale_recovery(self, depth, intrinsics, real_cam_height: float, pad_to_batch: int = 0, maps: bool = False):
         """ScaleRecovery.forward (dnet_layers.py:306-327): depth [N,1,H,W], K [N,3,3] -> scale [1] (GPU tensor)
         (+ median [1], height [N,1,H,W], mask [N,1,H,W] with maps=True)"""
