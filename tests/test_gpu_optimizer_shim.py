@@ -101,12 +101,27 @@ def test_tuple_form_dense_mode_and_legacy_switches():
     pose_model, depth_model = standins.window_models(w, iters, device="cuda")
     opt = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True), _config(B, iters), pose_model, depth_model, "09_02")
     r = opt.optimize_window(0, data)                                           # the demo's 11-tuple form
-    assert len(r["depths_opt"]) == S + 1
-    for d0, d1 in zip(r["depths_init"], r["depths_opt"]):
-        assert d1.shape == d0.shape and torch.isfinite(d1).all()
-        rel = ((d1 - d0).abs() / d0)
-        assert 1e-6 < float(rel.mean()) < 0.05                                  # depth moved, and stayed near the prior
+    assert len(r["depths_opt"]) == S + 1 and opt._dense_reference()
+    # default: Gauss-Newton on the reference's OWN loss (window rule REFERENCE): the target's map is the unknown ...
+    d0, d1 = r["depths_init"][0], r["depths_opt"][0]
+    assert d1.shape == d0.shape and torch.isfinite(d1).all() and 1e-6 < float(((d1 - d0).abs() / d0).mean()) < 0.05
+    for d0, d1 in zip(r["depths_init"][1:], r["depths_opt"][1:]):               # ... the source maps stay at the network's prediction
+        assert torch.equal(d0, d1)
     assert np.all(r["gn_cost"].numpy()[:, 3] < r["gn_cost"].numpy()[:, 0])
+    # ... and the reference's loss itself, evaluated by the engine at the start and at the result, went down
+    from tightly_coupled_sfm_amd.engine import Engine
+    eo = opt._opts()
+    e2 = Engine(*w["target"].shape[2:], 2 * S * B)
+    args = lambda dt, pose: (t(w["target"]), torch.stack([t(w["sources"][i]) for i in range(S)]), dt, torch.stack(list(r["depths_init"][1:])), t(w["K"]), pose)
+    p_init = torch.cat([r["poses_init"], r["poses_inv_init"]]).cuda(); p_opt = torch.cat([r["poses_opt"], r["poses_inv_opt"]]).cuda()
+    L0 = e2.linearize_dense_window(*args(r["depths_init"][0], p_init), eo, argmin=True)["loss"]
+    L1 = e2.linearize_dense_window(*args(r["depths_opt"][0], p_opt), eo, argmin=True, depth0=r["depths_init"][0])["loss"]
+    assert L1 < 0.97 * L0, (L0, L1)
+    # options['window_rule'] = 'pair': the library's joint dense mode -- every frame's depth refined (the source frames by their inverse pair)
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    rp = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True, window_rule="pair"), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)
+    for d0, d1 in zip(rp["depths_init"], rp["depths_opt"]):
+        assert d1.shape == d0.shape and torch.isfinite(d1).all() and 1e-6 < float(((d1 - d0).abs() / d0).mean()) < 0.05
 
     # pose + one depth scale per pair
     pose_model, depth_model = standins.window_models(w, iters, device="cuda")

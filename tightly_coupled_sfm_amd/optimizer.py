@@ -14,9 +14,10 @@ LM iterations on the reference's own residual (libtcsfm_hip.so).  New option key
     (the reference's own `diff_img_argmin`, `automasking`, `l_depth_consist(+_weight)`, `mode` keys are honoured),
     prior_depth, lambda_depth (dense mode).
 The reference's `optimize_depth_pred` switch (Adam on the disparity maps themselves, optimizer.py:194-198) selects
-refine='pose+depth' unless `refine` is given: pose + per-pixel inverse depth by Gauss-Newton with a Schur complement
-(window form: every directed pair refines its own copy of its target's depth; the target frame's copies are fused by averaging
-inverse depths; `diff_img_argmin` is honoured there too).
+refine='pose+depth' unless `refine` is given: pose + per-pixel inverse depth of the target by Gauss-Newton with a Schur complement,
+by default ON THE REFERENCE'S OWN LOSS (optimizer.py:47-90: forward term with source 0's weight map, 0.25 x inverse term, depth
+consistency, l_depth_init SSIM prior; `diff_img_argmin`, `automasking`, `l_depth_consist(+_weight)`, `l_depth_init(+_weight)` honoured;
+include/tcsfm.h "REFERENCE LOSS"); options['window_rule'] = 'pair' or solver 'lm' select the library's own joint / per-pair dense modes.
 Its weight-tuning switches (optimize_depth_encoder, ...) need autograd through the networks, which is out of scope:
 they are ignored with a warning, or refused when options['strict_legacy'] is set.
 """
@@ -113,10 +114,26 @@ class DepthOptimizer:
         o = self.options
         return o.get("refine", "pose+depth" if o.get("optimize_depth_pred", False) else "pose")
 
+    def _dense_reference(self):
+        """pose + depth by default minimises the reference's own loss (window rule REFERENCE, S <= 3 sources, Gauss-Newton);
+        options['window_rule'] = 'pair' or solver 'lm' select the library's own dense modes"""
+        o = self.options
+        return o.get("window_rule", "reference") != "pair" and o.get("solver", "gn") != "lm" and int(o.get("num_source_imgs", 2)) <= 3
+
     def _opts(self):
         o = self.options
-        if self._refine_mode() == "pose+depth":     # dense mode: GN on the SE(3) chart, depth prior instead of the DC term
+        if self._refine_mode() == "pose+depth":
             kw = {k: float(o[k]) for k in ("prior_depth", "lambda_depth") if k in o}
+            if self._dense_reference():
+                # the reference's OWN loss (optimizer.py:47-90; round 4, golden G13 `full` / `fullinit`): forward term with source 0's
+                # weights, 0.25 x inverse term, depth consistency, l_depth_init -- each switched by the reference's option keys
+                return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0,
+                                    w_dc=float(o.get("l_depth_consist_weight", 0.15)) if o.get("l_depth_consist", False) else 0.0,
+                                    prior_init=float(o.get("l_depth_init_weight", 0.1)) if o.get("l_depth_init", True) else 0.0,
+                                    solver=_lib.SOLVER_GN, lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
+                                    max_depth=float(self.config["max_depth"]), window_rule=_lib.WINDOW_REFERENCE,
+                                    **{k: v for k, v in kw.items() if k == "lambda_depth"})
+            # the library's per-pair / joint dense modes: GN on the SE(3) chart, Tikhonov depth prior instead of the DC term
             return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0, w_dc=0.0,
                                 solver=_lib.SOLVER_LM if o.get("solver", "gn") == "lm" else _lib.SOLVER_GN,
                                 lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
@@ -214,6 +231,8 @@ class DepthOptimizer:
             pose, log_scale, stats = eng.refine_window(
                 target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
                 intrinsics.float(), pose0, opts, stats=True, argmin=bool(self.options.get("diff_img_argmin", True)))
+        if dense and self._dense_reference() and S > 3:
+            raise ValueError("pose + depth on the reference's loss handles up to 3 source images per target (options['window_rule'] = 'pair' lifts it)")
         if not self.options.get("l_inverse_reconstruction", True):
             # the reference then leaves the inverse direction out of its objective (optimizer.py:74-79): the inverse poses stay
             # what the pose network predicted
@@ -234,6 +253,7 @@ class DepthOptimizer:
             # joint mode (default): the S forward slots hold ONE refined map of the target frame, shared by its S forward pairs
             # (the mean below is then the identity); options['dense_joint'] = False: every forward pair refined its own copy and
             # the copies are fused by averaging inverse depths.  Source frame s was refined by its inverse pair
+            # reference-loss mode (default): the inverse slots are the source depths as given (not unknowns there)
             inv_t = (1.0 / depth_ref[:split]).reshape(S, B, 1, H, W).mean(0)
             depths = [1.0 / inv_t] + [depth_ref[split + i * B: split + (i + 1) * B] for i in range(S)]
         res["depths_opt"] = depths
