@@ -121,12 +121,27 @@ def _room_depth(rays, R, t, room):
     return best
 
 
+def _rays_sampler(H, W, K):
+    """rays through the positions at which the reference's warp reads SOURCE pixel (x, y): it samples the source image at
+    ix = u W/(W-1) - 1/2 for the projected camera coordinate u (models/stn.py:198-231,266; grid_sample with align_corners=False
+    on coordinates normalised by W-1), so source pixel x stands for the camera coordinate u = (x + 1/2)(W-1)/W"""
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    pix = np.stack([(u + 0.5) * (W - 1) / W, (v + 0.5) * (H - 1) / H, np.ones_like(u)], -1)
+    return pix @ np.linalg.inv(K).T
+
+
 def make_pair(H=192, W=640, seed=0, pose_gt=None, noise=0.003, K=None,
-              room=(0.055, 1.5, 0.28, 0.33), dtype=np.float32):
+              room=(0.055, 1.5, 0.28, 0.33), dtype=np.float32, sampler_consistent=False):
     """One photoconsistent (target, source) pair.
 
     Returns dict: tgt,src [3,H,W]; depth_t, depth_s [H,W]; K [3,3]; pose_gt [6]
     (all ``dtype``).  Deterministic in (H,W,seed,pose_gt,noise,room).
+
+    sampler_consistent: the SOURCE image and depth map are rendered through the reference's own sampling model (_rays_sampler),
+    so that warping them with the true pose and depth reproduces the target up to bilinear interpolation and the minimiser of the
+    reference's residual IS the scene's true pose (with the plain pinhole rendering it is offset by up to half a pixel of flow,
+    SURVEY 8a row a5).  Such a source is only consistent in the sampled role: use it for directed pairs, not as the target of an
+    inverse pair.
     """
     K = scaled_K(H, W) if K is None else np.asarray(K, dtype=np.float64)
     rng = np.random.default_rng(1000 + seed)
@@ -137,10 +152,11 @@ def make_pair(H=192, W=640, seed=0, pose_gt=None, noise=0.003, K=None,
     R, t = T[:, :3], T[:, 3]
     tex = _Texture(seed)
     rays = _rays(H, W, K)
+    rays_s = _rays_sampler(H, W, K) if sampler_consistent else rays
     d_t = _room_depth(rays, np.eye(3), np.zeros(3), room)
-    d_s = _room_depth(rays, R, t, room)
+    d_s = _room_depth(rays_s, R, t, room)
     X_t = rays * d_t[..., None]                      # target-frame points seen by target
-    X_s = rays * d_s[..., None]                      # source-frame points seen by source
+    X_s = rays_s * d_s[..., None]                    # source-frame points seen by source
     X_s_in_t = (X_s - t) @ R                         # R^T (X_s - t)
     tgt = tex(X_t)
     src = tex(X_s_in_t)
