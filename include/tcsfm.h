@@ -307,7 +307,12 @@ int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter
  * optimize_window); consecutive windows do not depend on each other.  A B=1 refinement leaves the GPU idle between its short
  * kernels, and a host-pointer call spends more time on PCIe than on the refinement, so the library can keep several calls in
  * flight: lane k >= 1 owns a HIP stream and a full set of scratch buffers (lane 0 is the handle itself).
- *   tcsfm_set_lanes          1..8 lanes (allocates / frees the lanes' scratch; default 1)
+ *   tcsfm_set_lanes          1..8 lanes (allocates / frees the lanes' scratch; default 1).  MEASURED HAZARD (round 4, ROCm 7.2 / MI355X,
+ *                            scripts/lane_order_probe.py): how well lanes overlap depends on the order in which the PROCESS created
+ *                            its HIP streams.  A handle (and its lanes) created before the process's first device work -- an upload, a
+ *                            kernel -- gives four lanes that are slower than one (10 000 against 13 500 frame-pairs/s; created after
+ *                            the inputs are on the card: 22 000-26 000), and so do five or more lanes in any order: create the handle
+ *                            after the first upload, and use at most four lanes.
  *   tcsfm_refine_window_async   tcsfm_refine_window on `lane`, asynchronously.  Device pointers (host_ptrs = 0): the lane first
  *                            waits for the work queued on the handle's stream at call time (the producers of the inputs).
  *                            Pinned host pointers (host_ptrs = 2): the copies run on the lane's stream -- they overlap the other
@@ -338,11 +343,16 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  * Every frame crosses PCIe once, on a high-priority copy stream of the handle, four frames per copy, into a device ring of `ring`
  * frames (0 = default; at least windows_per_call + S + 4, or S + 2 with one window per call and single-frame copies); the calls are
  * issued round robin on the handle's lanes (tcsfm_set_lanes; 2-3 lanes: HIP maps a process's streams onto four hardware queues
- * unless GPU_MAX_HW_QUEUES is raised before the first HIP call, and the call's copy and pack streams take queues too) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
+ * unless GPU_MAX_HW_QUEUES is raised before the first HIP call, and the call's copy and pack streams take queues too; create the
+ * handle AFTER the process's first device work -- see tcsfm_set_lanes) from the ring by pointer; a slot is recycled -- on the device, by events -- once every call reading it has
  * finished.  windows_per_call (0 = default 8, capped by max_pairs / (2 S)): the targets and every source of consecutive windows
  * are runs of the ring, so one call refines that many windows at once (the kernels fill the chip).  The call returns when all
- * windows are done (it synchronises).  Results are bit-identical to one tcsfm_refine_window call per window, whatever the lanes,
- * the ring and windows_per_call. */
+ * windows are done (it synchronises).  Under o->window_rule = TCSFM_WINDOW_PAIR (the default) results are bit-identical to one
+ * tcsfm_refine_window call per window, whatever the lanes, the ring and windows_per_call.  Under TCSFM_WINDOW_REFERENCE the
+ * reference's batch-summed normalisers (optimizer.py:69,79) are taken over the windows of ONE CALL: windows_per_call plays the
+ * role of the reference's config['minibatch'] (run_sequential_optimization.py:186 hands optimize_window a DataLoader batch of that
+ * many windows), results depend on it exactly as the reference's loss depends on the minibatch, and are bit-identical to
+ * tcsfm_refine_window calls over the same groups of windows; windows_per_call = 1 gives the per-window loss. */
 int tcsfm_refine_sequence(tcsfm_handle h, const tcsfm_opts *o, int T, int S, const float *frames, const float *depths, const float *K,
                           const float *pose_init, float *pose_out, float *log_scale_out, int ring, int windows_per_call, int target_pos);
 /* The same loop with the reference's pose initialisation inside it: for every window the coupled PoseNet loop of

@@ -50,3 +50,28 @@ def test_documented_sequence_stub_runs_and_matches_engine():
     out = ns["refine_sequence"](frames, depths, seq["K"], seq["init"], sources=1, gn_iters=3, lanes=2)
     ref = Engine(H, W, 2, lanes=2).refine_sequence(frames, depths, seq["K"], seq["init"], default_opts(n_iters=3))
     assert out.shape == (T - 1, 2, 6) and np.array_equal(out, ref.numpy())
+
+
+def test_documented_dense_reference_stub_runs_and_matches_engine():
+    """the documented stub for the dense mode on the reference's own loss (round 4), executed on top of the binding block"""
+    from tightly_coupled_sfm_amd import _lib
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    import test_gpu_dense_reference as T
+    _lib.load()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    base = re.search(r"```python\n(# tcsfm_binding\.py.*?)```", text, re.S).group(1).replace('C.CDLL("libtcsfm_hip.so")', f'C.CDLL({_lib.LIB_PATH!r})')
+    dense = re.search(r"```python\n(# the dense mode on the reference's own loss.*?)```", text, re.S).group(1)
+    ns = {}
+    exec(compile(base, "INTEGRATION.md:tcsfm_binding", "exec"), ns)
+    exec(compile(dense, "INTEGRATION.md:dense_reference", "exec"), ns)
+    H, W, S = 48, 160, 2
+    w = T._window(1, S, H, W, seed=12)
+    t = {k: T._dev(v) for k, v in w.items()}
+    options = {'diff_img_argmin': True, 'automasking': True, 'l_depth_consist': True, 'l_depth_consist_weight': 0.15, 'l_depth_init': True, 'l_depth_init_weight': 0.1}
+    config = {'min_depth': 0.06, 'max_depth': 2.67}
+    depths = [t["depth_t"][:, None].contiguous()] + [t["depth_s"][s][:, None].contiguous() for s in range(S)]
+    pose, depth = ns["refine_window_dense"](t["tgt"], [t["srcs"][s] for s in range(S)], depths, t["K"], t["pose"], options, config, gn_iters=3)
+    o = default_opts(n_iters=3, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE)
+    rp, rd, _ = Engine(H, W, 2 * S).refine_dense_window(t["tgt"], t["srcs"], depths[0], torch.stack(depths[1:]), t["K"], t["pose"], o, argmin=True)
+    torch.cuda.synchronize()
+    assert torch.equal(pose, rp) and torch.equal(depth, rd[:1]) and not torch.equal(depth, depths[0])
