@@ -21,6 +21,11 @@ Calls in flight.  Steps are independent windows (as the windows of a sequence ar
 the short kernels of the other.  Every step is still one B-window ``tcsfm_refine_window`` call; `single_stream` reports the same
 blocks with one call in flight (the round-1 protocol).
 
+Merged sequences.  The same steps are also run as QUEUED calls (tcsfm_refine_window_queued): the library merges every --coalesce of them
+(default 10) into ONE launch sequence over all their directed pairs -- one stream, so nothing depends on how the runtime places the lanes'
+hardware queues (DESIGN section 4 "Lanes") -- and what is still waiting at the end of a block is launched by the block's closing flush.  Per
+window the poses are the same bits.  The faster of the two ways is the headline; `launch_mode.merged` / `launch_mode.lanes` report both.
+
 Timing.  W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides and
 reduced with MAX over the ranks.  One block is the contract's measurement; because the driver's K=20 block lasts ~1.5 ms, the
 block is repeated (R blocks, >= 50 ms in total, R <= 64) and the MEDIAN block is reported (`timed_blocks`, `ms_per_step_blocks`
@@ -251,6 +256,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="refine calls kept in flight (lanes of the handle, include/tcsfm.h); 1 = strictly one after the other")
     ap.add_argument("--ring-mb", type=float, default=320.0, help="the steps rotate over distinct calls whose inputs add up to at least this many MB "
                     "(> the 256 MiB Infinity Cache: a step's images come from HBM); 0 = every step re-runs ONE call (the round-3 protocol)")
+    ap.add_argument("--coalesce", type=int, default=10, help="also time the steps as QUEUED calls that the library merges into one launch sequence per "
+                    "this many calls (tcsfm_refine_window_queued, include/tcsfm.h; bit-identical per window); the faster of lanes / merged is the "
+                    "headline, the other is reported beside it; 0 = lanes only")
     ap.add_argument("--graph-replay", default="auto", choices=("auto", "0", "1"),
                     help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph (tcsfm_set_graph_replay: one "
                          "host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches; auto: untimed blocks of "
@@ -325,16 +333,24 @@ def main():
     # which a process creates its streams decides how the lanes' hardware queues are placed, and a handle created before the process's
     # first device work can end up with lanes that slow each other down (4 lanes 10 000 instead of 24 000 frame-pairs/s, reproducibly:
     # scripts/lane_order_probe.py, profiles/r04_lane_order_probe.txt; DESIGN section 4 "Lanes")
-    eng = Engine(H, W, npairs, lanes=lanes)
+    coal = 0 if args.coalesce <= 1 else max(1, min(args.coalesce, 16, 20 // B))      # merged sequences of at most ~20 windows
+    eng = Engine(H, W, npairs * max(1, coal), lanes=lanes)
     eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
     torch.cuda.synchronize()
     rot = [True]         # False: every step re-runs ring entries 0 .. lanes-1 (hot caches, the round-3 protocol)
 
     def step_k(k, nl):   # step k of a run with nl calls in flight: its ring entry on its lane; every step starts from its window's
         w = ring[k % R] if rot[0] else ring[k % nl]          # initial poses and writes the refined poses to the window's output
-        eng.refine_window_async(k % nl, w["tgt"], w["srcs"], w["depth_t"], w["depth_s"], w["K"], w["pose"], w["out"], opts)
+        if queued[0]:
+            eng.refine_window_queued(w["tgt"], w["srcs"], w["depth_t"], w["depth_s"], w["K"], w["pose"], w["out"], opts)
+        else:
+            eng.refine_window_async(k % nl, w["tgt"], w["srcs"], w["depth_t"], w["depth_s"], w["K"], w["pose"], w["out"], opts)
+
+    queued = [False]     # True: the steps are queued calls that the library merges (tcsfm_refine_window_queued) instead of lane calls
 
     def fence(nl):     # the contract's bracket: device-wide synchronise (it covers the lanes' streams) + barrier
+        if queued[0]:
+            eng.flush()                      # what is still waiting is launched inside the timed block
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -430,6 +446,29 @@ def main():
              "same_poses": bool(all(torch.equal(a_, w["out"]) for a_, w in zip(mine_out, ring))),
              "captures": max(counts[0], counts2[0]), "replays": max(counts[1], counts2[1])}
     eng.set_graph_replay(0)
+    # the same steps as QUEUED calls merged by the library into one launch sequence per `coal` calls (one stream: no reliance on how the
+    # runtime places the lanes' hardware queues); per window the same bits
+    merged = None
+    if coal > 1:
+        lanes_out = [w["out"].clone() for w in ring]
+        eng.set_coalesce(coal)
+        queued[0] = True
+        del enqueue_s[:]
+        c_el, c_blocks = timed(lanes)
+        queued[0] = False
+        eng.set_coalesce(0)
+        merged = {"calls_per_sequence": coal, "value": round(windows_per_block / c_el, 2), "ms_per_step": round(c_el / args.steps * 1e3, 5),
+                  "host_enqueue_us_per_step": round(float(np.median(enqueue_s)) / args.steps * 1e6, 2),
+                  "same_poses": bool(all(torch.equal(a_, w["out"]) for a_, w in zip(lanes_out, ring))),
+                  "what": "tcsfm_refine_window_queued: the library runs every `calls_per_sequence` queued calls as ONE pack / (linearise, solve) x 4 "
+                          "sequence over all their directed pairs (pointer table), the rest of a block at its closing flush"}
+        lanes_res = {"calls_in_flight": lanes, "value": round(windows_per_block / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 5)}
+        if c_el < elapsed:          # the merged sequences are the faster way of running these steps: they are the headline
+            elapsed, blocks = c_el, c_blocks
+            host_enqueue_us = merged["host_enqueue_us_per_step"]
+            merged["timed"] = True
+        else:
+            merged["timed"] = False
     # one call in flight: the host is not what binds (74 us of GPU time against 42 us of launches per call) and a graph launch adds
     # ~4 us of GPU time to the call -- the latency figure uses plain launches
     single = timed(1) if lanes > 1 else (elapsed, blocks)       # the same steps strictly one after the other
@@ -588,7 +627,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg_name, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
                        "global_batch_frame_pairs": B * world, "gn_iters": ITERS, "solver": "gn", "param": "se3",
-                       "steps_in_flight": lanes, "ring_calls": R, "ring_input_MB": round(R * call_bytes / 1e6, 1),
+                       "steps_in_flight": (coal if (merged and merged["timed"]) else lanes), "lanes": lanes, "ring_calls": R, "ring_input_MB": round(R * call_bytes / 1e6, 1),
                        "collective_backend": backend if distributed else None, "collective_world_size": coll_world,
                        "parallelism": f"{world} independent shards, no data-path collective; one all_gather of the poses after the timed region"},
             "timed_blocks": len(blocks),
@@ -600,8 +639,11 @@ def main():
                                       "the headline keeps `steps_in_flight` independent calls in flight on the handle's lanes, which fills "
                                       "the idle time between the short kernels of a B=1 call"},
             "host_enqueue_us_per_step": round(host_enqueue_us, 2),
-            "launch_mode": {"timed": ("graph replay: every call of the ring (same buffers each time round) is captured once and launched as ONE HIP graph "
+            "launch_mode": {"timed": ("merged sequences: the steps are queued calls, the library runs them %d at a time as one launch sequence "
+                                      "(tcsfm_refine_window_queued); bit-identical poses" % coal) if (merged and merged["timed"]) else
+                                     ("graph replay: every call of the ring (same buffers each time round) is captured once and launched as ONE HIP graph "
                                       "(tcsfm_set_graph_replay); same kernels, bit-identical poses" if use_replay else "plain launches (9 per call)"),
+                            "merged": merged, "lanes": None if not merged else lanes_res,
                             "chosen_by": ("untimed probe blocks of both modes before the timed region" if args.graph_replay == "auto" else "--graph-replay " + args.graph_replay),
                             "other_mode": other},
             "final_gather_us": None if gather_us is None else round(gather_us, 1),

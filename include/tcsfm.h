@@ -331,6 +331,26 @@ int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int
 int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                     const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                                     float *depth_out, float *stats_out);
+/* ---- coalesced calls (round 4): queued B-window calls of one shape run as ONE launch sequence ------------------------
+ * The robust way of keeping the chip busy with small calls: lanes depend on how the runtime places their hardware queues (see
+ * tcsfm_set_lanes), a merged launch sequence does not.  tcsfm_refine_window_queued takes the arguments of tcsfm_refine_window
+ * (device pointers, TCSFM_REFINE_POSE, no log-scale / statistics outputs) and only NOTES the call; when `max_calls` calls of the same
+ * shape (B, S) and options are waiting -- or at tcsfm_flush / tcsfm_synchronize, or when a call of another shape arrives -- they run as
+ * one pack / (linearise, solve) x n_iters sequence over all their directed pairs on the handle's stream: the kernels reach every
+ * call's own buffers through a pointer table (k_pack_coal) and every call's refined poses go to its own pose_out.  Per window the
+ * results are the bits of tcsfm_refine_window run on its own (the kernels are batch-independent under TCSFM_WINDOW_PAIR; a call under
+ * TCSFM_WINDOW_REFERENCE, whose loss couples the windows of a call, is never merged with others and runs at once).  The caller's
+ * buffers must stay valid and unchanged until the flush that runs them has been issued AND has completed on the handle's stream.
+ *   tcsfm_set_coalesce(h, max_calls)   0 / 1: off (every queued call runs at once); up to 16; the handle's max_pairs bounds the merged
+ *                                      sequence as well (2 S B x calls <= max_pairs)
+ *   tcsfm_flush(h)                     launch what is waiting (asynchronous on the handle's stream)
+ *   tcsfm_coalesce_counts              launch sequences issued / calls they carried, since the handle was created */
+int tcsfm_set_coalesce(tcsfm_handle h, int max_calls);
+int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out);
+int tcsfm_flush(tcsfm_handle h);
+int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls);
+
 /* The reference's sequential driver loop as ONE call (run_sequential_optimization.py:186-247: for every window DataLoader batch ->
  * H2D in process_sample_batch, data/kitti_loader.py:60-98 -> optimize_window, strictly one window after the other).
  * Window w = the S + 1 consecutive frames w .. w+S, w = 0 .. T-S-1: its target is frame w + target_pos (target_pos = -1: the middle

@@ -1,0 +1,98 @@
+"""Coalesced calls (tcsfm_refine_window_queued / tcsfm_set_coalesce / tcsfm_flush, round 4): queued B-window calls of one shape run
+as ONE launch sequence through a pointer table -- per window the bits of the call run on its own, whatever the grouping."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _calls(n, H, W, S=1, B=1, seed=50):
+    from tightly_coupled_sfm_amd import synth
+    out = []
+    for i in range(n):
+        b = synth.make_batch(2 * S * B, H, W, seed0=seed + 13 * i, both_directions=True)
+        d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+        # window layout from the pair form: targets = every second pair's target, its source(s) the partner's
+        tgt = d["tgt"][0::2][:B].contiguous()
+        srcs = torch.stack([d["src"][0::2][s * B:(s + 1) * B] if S > 1 else d["src"][0::2][:B] for s in range(S)]).contiguous()
+        dt = d["depth_t"][0::2][:B].contiguous()
+        ds = torch.stack([d["depth_s"][0::2][s * B:(s + 1) * B] if S > 1 else d["depth_s"][0::2][:B] for s in range(S)]).contiguous()
+        pose = torch.cat([d["pose_init"][0::2][:S * B], d["pose_init"][1::2][:S * B]]).contiguous()
+        out.append(dict(tgt=tgt, srcs=srcs, dt=dt, ds=ds, K=d["K"][0::2][:B].contiguous(), pose=pose))
+    K0 = out[0]["K"]
+    for c in out:
+        c["K"] = K0           # one camera
+    return out
+
+
+def test_coalesced_calls_are_bit_identical_to_single_calls():
+    from tightly_coupled_sfm_amd import _lib
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    calls = _calls(7, H, W)
+    o = default_opts(n_iters=4)
+    ref = Engine(H, W, 2)
+    want = [ref.refine_window(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], o)[0].clone() for c in calls]
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2 * 4)
+    e.set_coalesce(4)
+    outs = [torch.zeros_like(c["pose"]) for c in calls]
+    for c, out in zip(calls, outs):
+        e.refine_window_queued(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], out, o)
+    assert e.coalesce_counts() == (1, 4)                       # four ran when the queue filled; three are waiting
+    e.synchronize()                                            # (flushes)
+    assert e.coalesce_counts() == (2, 7)
+    for got, w in zip(outs, want):
+        assert torch.equal(got, w)
+    # another shape / other options flush what is waiting; the REFERENCE rule couples a call's windows and is never merged
+    o2 = default_opts(n_iters=2, w_dc=0.15)
+    w2 = [ref.refine_window(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], o2)[0].clone() for c in calls[:2]]
+    orf = default_opts(n_iters=2, window_rule=_lib.WINDOW_REFERENCE)
+    wr = ref.refine_window(calls[2]["tgt"], calls[2]["srcs"], calls[2]["dt"], calls[2]["ds"], calls[2]["K"], calls[2]["pose"], orf)[0].clone()
+    torch.cuda.synchronize()
+    for out in outs:
+        out.zero_()
+    torch.cuda.synchronize()
+    e.refine_window_queued(calls[0]["tgt"], calls[0]["srcs"], calls[0]["dt"], calls[0]["ds"], calls[0]["K"], calls[0]["pose"], outs[0], o)
+    e.refine_window_queued(calls[0]["tgt"], calls[0]["srcs"], calls[0]["dt"], calls[0]["ds"], calls[0]["K"], calls[0]["pose"], outs[3], o2)   # flushes the first
+    e.refine_window_queued(calls[1]["tgt"], calls[1]["srcs"], calls[1]["dt"], calls[1]["ds"], calls[1]["K"], calls[1]["pose"], outs[4], o2)
+    e.refine_window_queued(calls[2]["tgt"], calls[2]["srcs"], calls[2]["dt"], calls[2]["ds"], calls[2]["K"], calls[2]["pose"], outs[5], orf)  # flushes those, runs at once
+    e.flush(); e.synchronize()
+    assert torch.equal(outs[0], want[0]) and torch.equal(outs[3], w2[0]) and torch.equal(outs[4], w2[1]) and torch.equal(outs[5], wr)
+    assert e.coalesce_counts() == (5, 11)
+    # coalescing off: every queued call runs at once
+    e.set_coalesce(0)
+    outs[6].zero_()
+    e.refine_window_queued(calls[6]["tgt"], calls[6]["srcs"], calls[6]["dt"], calls[6]["ds"], calls[6]["K"], calls[6]["pose"], outs[6], o)
+    assert e.coalesce_counts() == (6, 12)
+    e.synchronize()
+    assert torch.equal(outs[6], want[6])
+
+
+def test_coalesced_kitti_windows_two_targets_two_sources():
+    """calls with B = 2 targets and S = 2 sources each, min over the sources: the pointer table addresses (call, local target, source)"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    import test_gpu_dense_reference as T
+    H, W, B, S = 48, 160, 2, 2
+    calls = []
+    for i in range(3):
+        w = T._window(B, S, H, W, seed=70 + i, bias=1.0)
+        t = {k: T._dev(v) for k, v in w.items()}
+        calls.append(dict(tgt=t["tgt"], srcs=t["srcs"], dt=t["depth_t"][:, None].contiguous(), ds=t["depth_s"][:, :, None].contiguous(), K=t["K"], pose=t["pose"]))
+    for c in calls:
+        c["K"] = calls[0]["K"]
+    o = default_opts(n_iters=3, w_dc=0.15)
+    o.argmin = 1
+    ref = Engine(H, W, 2 * S * B)
+    want = [ref.refine_window(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], o)[0].clone() for c in calls]
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2 * S * B * 3)
+    e.set_coalesce(3)
+    outs = [torch.zeros_like(c["pose"]) for c in calls]
+    for c, out in zip(calls, outs):
+        e.refine_window_queued(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], out, o)
+    e.synchronize()
+    assert e.coalesce_counts() == (1, 3)
+    for got, w_ in zip(outs, want):
+        assert torch.equal(got, w_)

@@ -107,6 +107,10 @@ _SIGNATURES = {
     "tcsfm_set_lanes": (C.c_int, [_P, C.c_int]),
     "tcsfm_set_graph_replay": (C.c_int, [_P, C.c_int]),
     "tcsfm_graph_replay_counts": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tcsfm_set_coalesce": (C.c_int, [_P, C.c_int]),
+    "tcsfm_refine_window_queued": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 7),
+    "tcsfm_flush": (C.c_int, [_P]),
+    "tcsfm_coalesce_counts": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tcsfm_refine_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
     "tcsfm_refine_dense_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_refine_sequence": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 6 + [C.c_int, C.c_int, C.c_int]),

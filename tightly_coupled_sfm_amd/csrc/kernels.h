@@ -293,6 +293,28 @@ __device__ __forceinline__ void write_const_lanes(int lane, const double *K, con
     if (NP == 7 && lane == 0) c.es = (s == 0.0) ? 1.f : (float)exp(s);
 }
 
+// Coalesced calls (tcsfm_refine_window_queued, round 4): up to TC_MAX_COAL queued B-window calls of one shape run as ONE launch sequence
+// over their 2 S B ncall directed pairs; every call keeps its own buffers, the kernels reach them through this pointer table.
+// Batch pair n in the stacked order over Bt = ncall cB targets (forward n = s Bt + b, inverse S Bt + s Bt + b); target b belongs to
+// call b / cB as its local target b % cB.  Results per window are the bits of the call run on its own (the kernels are batch-independent).
+constexpr int TC_MAX_COAL = 16;
+struct CoalTab {
+    int ncall, cB, cS, pad;
+    const float *tgt[TC_MAX_COAL], *src[TC_MAX_COAL], *dt[TC_MAX_COAL], *ds[TC_MAX_COAL], *K[TC_MAX_COAL], *pose[TC_MAX_COAL];
+};
+struct CoalIdx { int call, bl, s, inv, li; };      // li: the pair's index in ITS call's stacked order
+__device__ __forceinline__ CoalIdx coal_index(int ncall, int cB, int cS, int n) {
+    const int Bt = ncall * cB, SB = cS * Bt;
+    CoalIdx r;
+    r.inv = n >= SB;
+    const int q = r.inv ? n - SB : n;
+    r.s = q / Bt;
+    const int b = q - r.s * Bt;
+    r.call = b / cB; r.bl = b - r.call * cB;
+    r.li = (r.inv ? cS * cB : 0) + r.s * cB + r.bl;
+    return r;
+}
+
 struct InitParams {
     const float *pose, *log_scale, *K;  // [N,6], [N] or null, [Nimg,3,3]
     PairState *st;
@@ -303,13 +325,18 @@ struct InitParams {
     int *err;                           // host-mapped status word: set to 1 when a pair's intrinsics are not pinhole (or null)
 };
 
-__device__ inline void init_pair(const InitParams &P, int n) {
+__device__ inline void init_pair(const InitParams &P, int n, const CoalTab *ct = nullptr) {
     PairState &S = P.st[n];
     int img = P.shared_image ? 0 : n;
     const int kidx = P.K_mod > 0 ? n % P.K_mod : img;
-    for (int i = 0; i < 9; i++) S.K[i] = (double)P.K[kidx * 9 + i];
+    const float *Kp = P.K + kidx * 9, *pp = P.pose + n * 6;
+    if (ct != nullptr) {      // coalesced calls: intrinsics and initial pose from the pair's own call
+        const CoalIdx ci = coal_index(ct->ncall, ct->cB, ct->cS, n);
+        Kp = ct->K[ci.call] + ci.bl * 9; pp = ct->pose[ci.call] + ci.li * 6;
+    }
+    for (int i = 0; i < 9; i++) S.K[i] = (double)Kp[i];
     double pose[6];
-    for (int i = 0; i < 6; i++) pose[i] = (double)P.pose[n * 6 + i];
+    for (int i = 0; i < 6; i++) pose[i] = (double)pp[i];
     {   // device-side guard of the pinhole contract (the host validates a given intrinsics buffer only once)
         const double *K = S.K;
         if (K[1] != 0.0 || K[3] != 0.0 || K[6] != 0.0 || K[7] != 0.0 || K[8] != 1.0 || K[0] == 0.0 || K[4] == 0.0) {
@@ -393,16 +420,21 @@ __device__ inline float photo_err_planar(const float *__restrict__ x, const floa
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_pack(PackParams P) {
+__device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     int n = blockIdx.y;
     const int hw = P.H * P.W;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n < P.init.N) init_pair(P.init, n);  // independent of the packing below
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n < P.init.N) init_pair(P.init, n, ct);  // independent of the packing below
     if (idx >= hw) return;
     int v = idx / P.W, u = idx - v * P.W;
     const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
     const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
-    if (P.win_B > 0) {
+    if (ct != nullptr) {      // coalesced calls: the pair's images live in its own call's buffers (window layout of that call)
+        const CoalIdx ci = coal_index(ct->ncall, ct->cB, ct->cS, n);
+        const float *ti = ct->tgt[ci.call] + (size_t)ci.bl * 3 * hw, *si = ct->src[ci.call] + (size_t)(ci.s * ct->cB + ci.bl) * 3 * hw;
+        const float *td = ct->dt[ci.call] + (size_t)ci.bl * hw, *sd = ct->ds[ci.call] + (size_t)(ci.s * ct->cB + ci.bl) * hw;
+        t = ci.inv ? si : ti; s = ci.inv ? ti : si; dtp = ci.inv ? sd : td; dsp = ci.inv ? td : sd;
+    } else if (P.win_B > 0) {
         const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, qi = win_src_image(P.win_off, q, P.win_B);
         const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)qi * 3 * hw;
         const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)qi * hw;
@@ -432,6 +464,8 @@ __global__ __launch_bounds__(256) void k_pack(PackParams P) {
     P.depth_out[(size_t)n * hw + idx] = dt;
     if (P.depth_out2) P.depth_out2[(size_t)n * hw + idx] = dt;
 }
+__global__ __launch_bounds__(256) void k_pack(PackParams P) { pack_body(P, nullptr); }
+__global__ __launch_bounds__(256) void k_pack_coal(PackParams P, CoalTab T) { pack_body(P, &T); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Frame-level pack cache of the sequence calls (run_sequential_optimization.py:186-247 streams a sequence; every frame belongs to
@@ -1441,6 +1475,9 @@ struct SolveParams {
     // mask count summed over ALL forward (n < grp_fwd) or ALL inverse (grp_fwd <= n < n_pairs) pairs of the call, times `scale`
     int rule, grp_fwd, n_pairs;
     double scale_fwd, scale_inv;      // 1 (argmin) or 0.25 (no argmin, :73) / 0.25 (:79)
+    // coalesced calls (CoalTab): the refined pose of batch pair n goes to ITS call's output, at the pair's index in that call
+    int c_ncall, c_B, c_S, c_pad;
+    float *c_pose_out[TC_MAX_COAL];
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -1649,8 +1686,10 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     if (final_pose && P.pose_out && tid == 0) {  // last launch of a refine call: emit the reference 6-vector
         float pose[6];
         T_to_pose_f32(Tfin, pose);
+        float *po = P.pose_out + n * 6;
+        if (P.c_ncall > 0) { const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n); po = P.c_pose_out[ci.call] + ci.li * 6; }
 #pragma unroll
-        for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
+        for (int i = 0; i < 6; i++) po[i] = pose[i];
         if (P.log_scale_out) P.log_scale_out[n] = (float)sfin;
         if (P.stats && P.mode == 0) {                  // GN: last row = final iterate (its cost is not evaluated)
             float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;

@@ -100,6 +100,13 @@ struct tcsfm_ctx {
     unsigned long long graph_clock = 0;
     int graph_captures = 0, graph_replays = 0;
     bool capturing = false;
+    // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
+    struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; };
+    int coal_max = 0;
+    std::vector<PendingCall> pending;
+    tcsfm_opts pend_opts;
+    int pend_B = 0, pend_S = 0;
+    int coal_batches = 0, coal_calls = 0;
     unsigned short *trace_bits = nullptr;   // tcsfm_debug_trace: caller-owned device buffers (null = off)
     int *trace_decide = nullptr;
     long long trace_bits_cap = 0, trace_decide_cap = 0;
@@ -376,7 +383,8 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
 
 // init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
 int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
-             const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr, const WinOff *wo = nullptr) {
+             const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr, const WinOff *wo = nullptr,
+             const CoalTab *ct = nullptr) {
     PackParams P;
     P.depth_out2 = depth_copy;
     if (wo) P.win_off = *wo; else P.win_off.on = 0;
@@ -401,7 +409,8 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
     int hw = h->H * h->W;
     {
         ProfScope prof(h, 2);
-        hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P);
+        if (ct) hipLaunchKernelGGL(k_pack_coal, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P, *ct);
+        else hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P);
     }
     HIPCHK(h, hipGetLastError());
     return TCSFM_OK;
@@ -782,6 +791,8 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
 // =================================================================================================
 extern "C" {
 
+static int flush_pending(tcsfm_ctx *h);
+
 void tcsfm_default_opts(tcsfm_opts *o) {
     memset(o, 0, sizeof(*o));
     o->n_iters = 4; o->solver = TCSFM_SOLVER_GN; o->param = TCSFM_PARAM_SE3; o->refine = TCSFM_REFINE_POSE;
@@ -908,6 +919,7 @@ int tcsfm_use_own_stream(tcsfm_handle h) {
 int tcsfm_synchronize(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
     DeviceGuard dev_guard(h->device);
+    if (int rc_ = flush_pending(h)) return rc_;          // queued calls (tcsfm_refine_window_queued) are launched first
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return pending_error(h);
 }
@@ -1180,14 +1192,18 @@ struct FrameCache { const float4 *fpack; const float *fdepth; int slot0, tpos; }
 
 static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
-                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo, const FrameCache *fc) {
+                       float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo, const FrameCache *fc,
+                       const CoalTab *ct = nullptr, float *const *ct_out = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
+    if (ct) {        // coalesced calls (flush_pending): every array argument comes from the table; device pointers, validated at enqueue
+        tgt = ct->tgt[0]; src = ct->src[0]; depth_t = ct->dt[0]; depth_s = ct->ds[0]; K = ct->K[0]; pose_in = ct->pose[0]; pose_out = ct_out[0];
+    }
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine: NULL input");
     DeviceGuard dev_guard(h->device);
     if (int rc_ = pending_error(h)) return rc_;
-    const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
-    if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
+    const int nimg_t = ct ? ct->cB : (win_B ? win_B : N), nimg_s = ct ? ct->cB * ct->cS : (win_B ? win_B * win_S : N);   // image sets behind tgt / src
+    if (!ct && (rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W;
     const int np = np_of(o);
     const float *d_tgt, *d_src, *d_dt, *d_ds, *d_K, *d_pose_in, *d_ls_in;
@@ -1227,9 +1243,13 @@ static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         }
         HIPCHK(h, hipGetLastError());
         P.srcpack = fc->fpack; P.depth_t = fc->fdepth; P.pair_src = C.pair_src; P.pair_dep = C.pair_dep;
-    } else if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo))) return rc;
+    } else if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo, ct))) return rc;
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
+    if (ct) {
+        S.c_ncall = ct->ncall; S.c_B = ct->cB; S.c_S = ct->cS;
+        for (int i = 0; i < ct->ncall; i++) S.c_pose_out[i] = ct_out[i];
+    }
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (n_sel) { P.sel_B = win_B; P.sel_S = win_S; }   // min over the sources: evaluated inside k_linearize<SEL>
@@ -1629,6 +1649,72 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: need 1 <= 2*B*S <= max_pairs");
     return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+}
+
+// ---- coalesced calls: queued B-window calls of one shape as ONE launch sequence (include/tcsfm.h)
+static int flush_pending(tcsfm_ctx *h) {
+    if (h->pending.empty()) return TCSFM_OK;
+    std::vector<tcsfm_ctx::PendingCall> calls;
+    calls.swap(h->pending);
+    const tcsfm_opts o = h->pend_opts;
+    const int B = h->pend_B, S = h->pend_S, n = (int)calls.size();
+    h->coal_batches++; h->coal_calls += n;
+    if (n == 1) {
+        const auto &c = calls[0];
+        return refine_impl(h, &o, 2 * B * S, B, S, c.tgt, c.srcs, c.dt, c.ds, c.K, c.pose_in, nullptr, c.pose_out, nullptr, nullptr);
+    }
+    CoalTab ct;
+    memset(&ct, 0, sizeof(ct));
+    ct.ncall = n; ct.cB = B; ct.cS = S;
+    float *outs[TC_MAX_COAL];
+    for (int i = 0; i < n; i++) {
+        ct.tgt[i] = calls[i].tgt; ct.src[i] = calls[i].srcs; ct.dt[i] = calls[i].dt; ct.ds[i] = calls[i].ds; ct.K[i] = calls[i].K; ct.pose[i] = calls[i].pose_in;
+        outs[i] = calls[i].pose_out;
+    }
+    return refine_body(h, &o, 2 * B * S * n, B * n, S, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ct, outs);
+}
+
+int tcsfm_set_coalesce(tcsfm_handle h, int max_calls) {
+    if (!h) return TCSFM_E_ARG;
+    if (max_calls < 0 || max_calls > TC_MAX_COAL) return fail(h, TCSFM_E_ARG, "tcsfm_set_coalesce: 0 <= max_calls <= 16");
+    int rc = flush_pending(h);
+    h->coal_max = max_calls;
+    return rc;
+}
+
+int tcsfm_flush(tcsfm_handle h) {
+    if (!h) return TCSFM_E_ARG;
+    return flush_pending(h);
+}
+
+int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls) {
+    if (!h) return TCSFM_E_ARG;
+    if (batches) *batches = h->coal_batches;
+    if (calls) *calls = h->coal_calls;
+    return TCSFM_OK;
+}
+
+int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
+                               const float *depth_s, const float *K, const float *pose_in, float *pose_out) {
+    if (!h) return TCSFM_E_ARG;
+    if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: need 1 <= 2*B*S <= max_pairs");
+    int rc = check_common(h, o, 2 * B * S);
+    if (rc) return rc;
+    if (!tgt || !srcs || !depth_t || !depth_s || !K || !pose_in || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: NULL argument");
+    if (o->host_ptrs || o->refine != TCSFM_REFINE_POSE)
+        return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: device pointers and TCSFM_REFINE_POSE only");
+    // the REFERENCE rule couples the windows of a call through its batch normalisers: such calls are never merged with others
+    const bool mergeable = h->coal_max > 1 && o->window_rule == TCSFM_WINDOW_PAIR && !h->trace_bits && !h->trace_decide && !h->profiling;
+    DeviceGuard dev_guard(h->device);
+    if ((rc = check_intrinsics(h, o, K, B))) return rc;            // (blocking only the first time a pointer is seen)
+    if (!h->pending.empty() && (memcmp(&h->pend_opts, o, sizeof(*o)) != 0 || h->pend_B != B || h->pend_S != S ||
+                                (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs))
+        if ((rc = flush_pending(h))) return rc;
+    h->pend_opts = *o; h->pend_B = B; h->pend_S = S;
+    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out});
+    if (!mergeable || (int)h->pending.size() >= h->coal_max || (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs)
+        return flush_pending(h);
+    return TCSFM_OK;
 }
 
 int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,

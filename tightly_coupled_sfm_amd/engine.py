@@ -426,6 +426,28 @@ class Engine:
         self._call(self.lib.tcsfm_graph_replay_counts(self._h, C.byref(c), C.byref(r)))
         return c.value, r.value
 
+    # -- coalesced calls: queued calls of one shape as ONE launch sequence (include/tcsfm.h "coalesced calls") -------------------
+    def set_coalesce(self, max_calls: int):
+        """tcsfm_set_coalesce: up to `max_calls` queued refine_window_queued calls of one shape run as one launch sequence"""
+        self._call(self.lib.tcsfm_set_coalesce(self._h, int(max_calls)))
+
+    def refine_window_queued(self, tgt, srcs, depth_t, depth_s, K, pose, pose_out, opts: Opts):
+        """tcsfm_refine_window_queued: note a window call (validated contiguous float32 CUDA tensors in the window layout, see
+        refine_window); it runs -- merged with the other waiting calls of its shape -- when the queue is full, at flush() or at
+        synchronize().  Per window the result is bit-identical to refine_window on its own."""
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        self._call(self.lib.tcsfm_refine_window_queued(self._h, C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                                       self._p(K), self._p(pose), self._p(pose_out)))
+
+    def flush(self):
+        self._call(self.lib.tcsfm_flush(self._h))
+
+    def coalesce_counts(self):
+        """(launch sequences issued, calls they carried)"""
+        b, c = C.c_int(0), C.c_int(0)
+        self._call(self.lib.tcsfm_coalesce_counts(self._h, C.byref(b), C.byref(c)))
+        return b.value, c.value
+
     def refine_window_async(self, lane: int, tgt, srcs, depth_t, depth_s, K, pose, pose_out, opts: Opts, log_scale=None, log_scale_out=None):
         """tcsfm_refine_window on `lane`, zero-allocation and asynchronous: tensors must be validated / contiguous float32 CUDA
         tensors in the window layout (see refine_window); the lane waits for the work queued on this engine's stream so far.
