@@ -5,10 +5,10 @@
 //
 // Unknowns: the poses of all 2 S B directed pairs and ONE inverse-depth map per target.  Per linearisation, on one stream:
 //   k_linearize<MODE_MAPS>   residual maps (diff, valid) of all 2 S B pairs at the current poses / depth            (kernels.h)
-//   k_dref_prepass           forward pairs: the batch-summed count K_f of the min-over-sources selection; inverse pairs: their count K_i
-//                            and the ADJOINT of their bilinear samples of the target depth -- d L / d pd of every inverse pixel scattered
-//                            onto its four taps (64-bit fixed-point atomics: integer addition is order-independent, the result is
-//                            bit-reproducible)
+//   k_dref_count             the batch-summed mask counts: K_f of the forward pairs' min-over-sources selection, K_i of the inverse pairs
+//   k_dref_scatter           the ADJOINT of the inverse pairs' bilinear samples of the target depth -- d L / d pd of every inverse pixel onto
+//                            its four taps, summed per tile in LDS and written with 64-bit fixed-point atomics (integer addition is
+//                            order-independent: the result is bit-reproducible)
 //   k_linearize<6, DC> + k_solve<6> (window rule REFERENCE)   the inverse pairs' 6 x 6 pose systems                  (kernels.h)
 //   k_dense_joint<S, .., REF>  the forward group: source 0's weight map on every selected pixel with its cross term, depth consistency
 //                            with its inverse-depth column, the SSIM prior, the scattered sums; per-pixel Schur elimination  (joint_kernel.h)
@@ -20,64 +20,124 @@ namespace tc {
 
 struct DrefPrepassParams {
     const float *diff, *valid;    // [2SB][H*W] residual maps of all pairs (k_linearize<MODE_MAPS>)
-    int *norms;                   // [2] K_f, K_i (zeroed before the launch)
-    long long *ext;               // [B][H*W][2] fixed-point scatter sums (zeroed before the launch): sum M diff ddd w_tap, sum h ddd w_tap
+    int *norms;                   // [2] K_f, K_i (zeroed before k_dref_count)
+    long long *ext;               // [B][H*W] fixed-point scatter sums (zeroed before k_dref_scatter), in units of u (see dref_unit)
     int B, S, argmin, automask;
     float eps;
+    float b_dc;                   // w_dc / (S B H W)
 };
 
-// one thread per pixel of one directed pair; the LinParams carry the packs, the pair constants and (ext_*) the maps for the selection
-__global__ __launch_bounds__(256) void k_dref_prepass(LinParams P, DrefPrepassParams D) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+// The scattered sum of a target pixel is  sum_p (b_dc h - a_i M diff) ddd w_tap  with a_i = 0.25 / K_i.  It is accumulated in units of
+// u = a_i (u = b_dc when no inverse pixel counts): O(1) numbers for the 2^-40 fixed point whatever the image size.
+__device__ __forceinline__ void dref_unit(const int *norms, float b_dc, float &ratio_dc, float &w_photo) {
+    const float Ki = (float)norms[1];
+    if (Ki > 0.f) { ratio_dc = b_dc * Ki * 4.f; w_photo = 1.f; }     // b_dc / a_i, and the photometric part at weight 1
+    else { ratio_dc = 1.f; w_photo = 0.f; }
+}
+
+// pass 1: the batch-summed mask counts.  DREF_CNT_WG workgroups per directed pair stride over its pixels, count in registers (ballot +
+// popcount per wave), combine in LDS and issue ONE integer atomic per workgroup: a few hundred same-address atomics per linearisation
+// (one per wave of pixels -- 7 680 of them at 640x192 -- serialised on the two counters and took 80 us)
+constexpr int DREF_CNT_WG = 64;
+__global__ __launch_bounds__(256) void k_dref_count(LinParams P, DrefPrepassParams D) {
+    __shared__ int wsum;
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int hw = P.H * P.W, SB = D.S * D.B;
+    if (tid == 0) wsum = 0;
+    __syncthreads();
+    int cnt = 0;                  // wave-uniform
+    for (int base = blockIdx.x * 256; base < hw; base += DREF_CNT_WG * 256) {
+        const int idx = base + tid;
+        const bool live = idx < hw;
+        const int gi = live ? idx : 0;
+        bool count = false;
+        if (live) {
+            const bool valid = P.ext_valid[(size_t)n * hw + gi] > 0.5f;
+            const float diff = P.ext_diff[(size_t)n * hw + gi], ae = P.tgtpack[(size_t)n * hw + gi].w;
+            if (n < SB) count = (D.argmin && D.S > 1) ? ext_selected(P, n, gi, hw) : (valid && (!(D.automask && D.argmin) || diff < ae));
+            else count = valid && (!D.automask || diff < ae);
+        }
+        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(count));
+    }
+    if ((tid & 63) == 0 && cnt != 0) atomicAdd(&wsum, cnt);
+    __syncthreads();
+    if (tid == 0 && wsum != 0) atomicAdd(D.norms + (n < SB ? 0 : 1), wsum);
+}
+
+// pass 2: the adjoint of the inverse pairs' bilinear samples of the target depth.  One workgroup = one 32 x 8 tile of one inverse pair;
+// its taps land in a window of the TARGET image displaced by the tile's flow: the contributions are first summed in LDS (64-bit
+// fixed-point adds on a (32 + 2M) x (8 + 2M) window placed by the flow of the tile's centre pixel), then every non-zero window entry
+// goes out with ONE global atomic -- a third of the atomics of scattering tap by tap, and neighbouring lanes write neighbouring
+// addresses.  A tap outside the window (depth edges) goes to global memory directly.  Integer adds: order-independent, bit-reproducible.
+constexpr int DREF_TW = 32, DREF_TH = 8, DREF_M = 6;
+__global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P, DrefPrepassParams D) {
+    constexpr int WW = DREF_TW + 2 * DREF_M, WH = DREF_TH + 2 * DREF_M;
+    __shared__ unsigned long long win[WW * WH];
     const int H = P.H, W = P.W, hw = H * W, SB = D.S * D.B;
-    const bool live = idx < hw;
-    const int gi = live ? idx : 0;
-    bool count = false;
-    if (n < SB) {               // forward pair: does it keep the pixel (min over the sources / own validity)?
-        if (live) count = (D.argmin && D.S > 1) ? ext_selected(P, n, gi, hw)
-                                                : (P.ext_valid[(size_t)n * hw + gi] > 0.5f &&
-                                                   (!(D.automask && D.argmin) || P.ext_diff[(size_t)n * hw + gi] < P.tgtpack[(size_t)n * hw + gi].w));
-    } else if (live) {          // inverse pair: own mask (validity x auto-mask) and the adjoint of its depth sample
-        const int m = n - SB, b = m % D.B;
-        const float diff = P.ext_diff[(size_t)n * hw + gi];
+    const int m = blockIdx.y, n = SB + m, b = m % D.B;
+    const int tiles_x = (W + DREF_TW - 1) / DREF_TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tid = threadIdx.x, lx = tid % DREF_TW, ly = tid / DREF_TW;
+    const int u = tx * DREF_TW + lx, v = ty * DREF_TH + ly;
+    const PairConst &c = P.pc[n];
+    const float *depth_t = P.depth_t + (size_t)n * hw;
+    for (int i = tid; i < WW * WH; i += DREF_TW * DREF_TH) win[i] = 0ull;
+    // window origin: the tile's own origin displaced by the flow of its centre pixel (every thread evaluates it: no broadcast, no barrier)
+    int ox, oy;
+    {
+        const int cu = min(tx * DREF_TW + DREF_TW / 2, W - 1), cv = min(ty * DREF_TH + DREF_TH / 2, H - 1);
+        Geo gc;
+        warp_geo(c, W, H, cu, cv, depth_t[cv * W + cu], gc);
+        const float fx = fminf(fmaxf(gc.rx, -4096.f), 4096.f), fy = fminf(fmaxf(gc.ry, -4096.f), 4096.f);
+        ox = tx * DREF_TW + (int)floorf(fx) - DREF_M; oy = ty * DREF_TH + (int)floorf(fy) - DREF_M;
+    }
+    float ratio_dc, w_photo;
+    dref_unit(D.norms, D.b_dc, ratio_dc, w_photo);
+    __syncthreads();
+    long long *ext = D.ext + (size_t)b * hw;
+    if (u < W && v < H) {
+        const int gi = v * W + u;
         const bool valid = P.ext_valid[(size_t)n * hw + gi] > 0.5f;
-        count = valid && (!D.automask || diff < P.tgtpack[(size_t)n * hw + gi].w);
         if (valid) {
-            const int v = gi / W, u = gi - v * W;
-            const PairConst &c = P.pc[n];
+            const float diff = P.ext_diff[(size_t)n * hw + gi];
+            const bool count = !D.automask || diff < P.tgtpack[(size_t)n * hw + gi].w;
             Geo g;
-            warp_geo(c, W, H, u, v, P.depth_t[(size_t)n * hw + gi], g);
+            warp_geo(c, W, H, u, v, depth_t[gi], g);
             Tap t;
             tap4_fetch(P.srcpack + (size_t)n * (H + 2) * (W + 2), W, H, u, v, g.rx, g.ry, false, t);
             float4 val, gx, gy;
             tap4_lerp(t, val, gx, gy);
             const float pd = c.es * val.w, cd = g.Z, sum = cd + pd, isum = frcp(sum);
-            const float dif = dc_diff(c, g, t, P.depth_t[(size_t)n * hw + gi], pd), raw = fabsf(dif) * isum;
+            const float dif = dc_diff(c, g, t, depth_t[gi], pd), raw = fabsf(dif) * isum;
             if (raw >= 0.f && raw <= 1.f) {
                 const float sg = dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f);
                 const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)
                 const float dd = fminf(raw, 1.f);
-                const float e1 = count ? diff * ddd : 0.f, e2 = fminf(1.f, dd * frcp(D.eps)) * ddd;
-                // the four taps in bordered coordinates (tap4_fetch); a tap in the zero border is no pixel of the target
-                const float fx = floorf(g.rx), fy = floorf(g.ry);
-                const int xi = u + (int)fx, yi = v + (int)fy;
+                const float coef = (ratio_dc * fminf(1.f, dd * frcp(D.eps)) - (count ? w_photo * diff : 0.f)) * ddd;
+                const int xi = u + (int)floorf(g.rx), yi = v + (int)floorf(g.ry);
                 const float wx = t.wx, wy = t.wy;
                 const float w4[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int xx = xi + (k & 1), yy = yi + (k >> 1);
-                    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-                        long long *e = D.ext + ((size_t)b * hw + (size_t)yy * W + xx) * 2;
-                        const long long a1 = (long long)llrint((double)(e1 * w4[k]) * DREF_FIX), a2 = (long long)llrint((double)(e2 * w4[k]) * DREF_FIX);
-                        if (a1 != 0) atomicAdd(reinterpret_cast<unsigned long long *>(e), (unsigned long long)a1);
-                        if (a2 != 0) atomicAdd(reinterpret_cast<unsigned long long *>(e + 1), (unsigned long long)a2);
+                    if (xx >= 0 && xx < W && yy >= 0 && yy < H) {         // (a tap in the zero border is no pixel of the target)
+                        const long long a = (long long)llrint((double)(coef * w4[k]) * DREF_FIX);
+                        const int wxl = xx - ox, wyl = yy - oy;
+                        if (a != 0) {
+                            if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a);
+                            else atomicAdd(reinterpret_cast<unsigned long long *>(ext + (size_t)yy * W + xx), (unsigned long long)a);
+                        }
                     }
                 }
             }
         }
     }
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(count);
-    if ((threadIdx.x & 63) == 0 && bal != 0ull) atomicAdd(D.norms + (n < SB ? 0 : 1), __builtin_popcountll(bal));
+    __syncthreads();
+    for (int i = tid; i < WW * WH; i += DREF_TW * DREF_TH) {
+        const unsigned long long a = win[i];
+        const int yy = oy + i / WW, xx = ox + i % WW;
+        if (a != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) atomicAdd(reinterpret_cast<unsigned long long *>(ext + (size_t)yy * W + xx), a);
+    }
 }
 
 }  // namespace tc

@@ -41,8 +41,8 @@ struct JointParams {
     int B, S, argmin;        // every pixel is weighted by the depth-consistency map of the source it counts for (see tcsfm.h)
     int automask;            // own masks (no argmin): optimizer.py:71-73 has no auto-mask there -> 0 from the host when S > 1
     // REF (k_dense_joint<.., REF = true>): the forward group under the reference's COMPLETE loss (optimizer.py:47-90, dense_ref_kernel.h):
-    const int *norms;        // [2] batch-summed mask counts K_f (forward selection) and K_i (inverse pairs) of THIS linearisation (k_dref_prepass)
-    const long long *ext;    // [B][H*W][2] fixed-point (2^-40) adjoint sums of the inverse pairs' samples of the target depth (k_dref_prepass)
+    const int *norms;        // [2] batch-summed mask counts K_f (forward selection) and K_i (inverse pairs) of THIS linearisation (k_dref_count)
+    const long long *ext;    // [B][H*W] fixed-point (2^-40) adjoint sums of the inverse pairs' samples of the target depth (k_dref_scatter)
     float c_f;               // factor on the forward term: 1 with the min over the sources, 0.25 without (:73)
     float b_dc;              // per-pixel weight of the depth-consistency terms: w_dc / (S B H W) (:83-86)
     float w_init_px;         // per-pixel weight of the SSIM prior between current and initial sigmoid disparity: w_init / (B H W) (:89-90)
@@ -81,11 +81,12 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     __shared__ float w0[REF ? N2 : 1];             // REF: depth-consistency weight of SOURCE 0 on tile + 2-pixel halo (optimizer.py:69)
     __shared__ float sgq[REF ? 2 * N2 : 1];        // REF: (sigma, sigma0) on tile + 2-pixel halo: the l_depth_init prior (optimizer.py:89-90)
     // REF: everything is accumulated in units of the forward term's factor a_f = c_f / K_f (k_solve_joint multiplies by it)
-    float r_dc = 0.f, r_init = 0.f, r_inv = 0.f;
+    float r_dc = 0.f, r_init = 0.f, r_ext = 0.f;
     if (REF) {
         const float Kf = (float)J.norms[0], Ki = (float)J.norms[1];
         const float iaf = Kf > 0.f ? Kf / J.c_f : 0.f;                 // 1 / a_f
-        r_dc = J.b_dc * iaf; r_init = J.w_init_px * iaf; r_inv = Ki > 0.f ? 0.25f / Ki * iaf : 0.f;
+        r_dc = J.b_dc * iaf; r_init = J.w_init_px * iaf;
+        r_ext = (Ki > 0.f ? 0.25f / Ki : J.b_dc) * iaf;                // the scattered sums' unit u (dense_ref_kernel.h dref_unit) over a_f
     }
     const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
     const bool ref_prior = REF && J.w_init_px > 0.f;
@@ -447,10 +448,11 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         for (int j = 0; j < 6; j++) Bv[s][j] = 0.f;
     float prior_cost = 0.f;
     if (inimg) {
-        if (REF) {      // the inverse pairs see this depth through their bilinear samples of it: adjoint sums of k_dref_prepass (fixed point)
-            const long long *e = J.ext + ((size_t)b * hw + gyo * W + gxo) * 2;
-            const float E1 = (float)((double)e[0] * (1.0 / DREF_FIX)), E2 = (float)((double)e[1] * (1.0 / DREF_FIX));
-            g_rho -= o_depth * o_depth * (r_dc * E2 - r_inv * E1);          // d depth / d rho = -depth^2
+        if (REF) {      // the inverse pairs see this depth through their bilinear samples of it: adjoint sums of k_dref_scatter (fixed point)
+            long long *ep = const_cast<long long *>(J.ext) + (size_t)b * hw + gyo * W + gxo;
+            const float E = (float)((double)*ep * (1.0 / DREF_FIX));     // in units of u (dref_unit)
+            *ep = 0;                                                     // consumed: the next linearisation's scatter starts from zero (no memset launch)
+            g_rho -= o_depth * o_depth * r_ext * E;                        // d depth / d rho = -depth^2
             prior_cost = extra_cost;
         }
         float D = Dsum;
@@ -731,6 +733,7 @@ struct JointUpdateParams {
     float *depth_out;         // optional: [.][H*W] same layout (the caller's buffer), or null
     int hw, B, S, mode;       // mode 0: step; 1: final LM decision (keep the trial or fall back to the accepted map), no step
     float rho_lo, rho_hi;
+    int *norms_zero;          // REF (or null): the two batch counters, consumed by k_solve_joint before this launch: zeroed for the next linearisation
     float4 *srcpack_inv;      // REF (or null): packs of the inverse pairs (pair S B + s B + b samples target b's depth: channel w), refreshed
     int W, H;                 //   with the new map so that the inverse pairs of the next linearisation see the depth the forward pairs see
 };
@@ -739,6 +742,7 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P) {
     using JL = JointLayout<NS>;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (P.norms_zero && idx == 0 && b == 0) { P.norms_zero[0] = 0; P.norms_zero[1] = 0; }
     if (idx >= P.hw) return;
     const size_t o = (size_t)b * P.hw + idx;
     float dep;

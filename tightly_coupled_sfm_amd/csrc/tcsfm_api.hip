@@ -662,7 +662,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     }
     if (!h->dref_norms) {
         HIPCHK(h, hipMalloc((void **)&h->dref_norms, 4 * sizeof(int)));
-        HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * 2 * sizeof(long long)));      // (targets <= max_pairs / 2)
+        HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * sizeof(long long)));      // (targets <= max_pairs / 2)
         HIPCHK(h, hipMalloc((void **)&h->dref_export, ((n + 1) / 2) * (2 + 6 * JMAXS) * sizeof(double)));
     }
     tcsfm_opts oo = *o;
@@ -685,6 +685,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     DrefPrepassParams Dp;
     Dp.diff = maps_diff; Dp.valid = maps_valid; Dp.norms = h->dref_norms; Dp.ext = h->dref_ext; Dp.B = B; Dp.S = S;
     Dp.argmin = o->argmin ? 1 : 0; Dp.automask = o->automask; Dp.eps = o->irls_eps;
+    Dp.b_dc = o->w_dc / ((float)SB * (float)hw);
     // ---- inverse pairs: pose kernels on views offset by S B pairs, window rule REFERENCE (all of them are the rule's inverse group)
     LinParams Pi = lin_params(h, &oo, 6);
     const int nacc6 = AccLayout<6>::NACC;
@@ -721,11 +722,18 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     Uj.srcpack_inv = h->srcpack + (size_t)SB * (h->H + 2) * (h->W + 2); Uj.W = h->W; Uj.H = h->H;
     const dim3 px_t((unsigned)((hw + 255) / 256), B), px_all((unsigned)((hw + 255) / 256), N);
     hipStream_t st = h->stream;
+    // (one stream: running the inverse pairs' linearise + solve on a second stream beside the forward group's, forked behind the scatter and
+    // joined after the depth update, was measured SLOWER -- 261 vs 232 us per 240x320 window, 383 vs 361 at 192x640 S=2: the event hops cost
+    // more than the ~18 us of overlap they buy)
+    // the counters and the scatter sums are zero when a linearisation starts: zeroed here once per call, and by their consumers afterwards
+    // (k_dense_joint clears every sum it reads, k_dense_joint_update the counters) -- two memset launches per iteration cost 10 us
+    HIPCHK(h, hipMemsetAsync(h->dref_norms, 0, 4 * sizeof(int), st));
+    HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)B * hw * sizeof(long long), st));
+    Uj.norms_zero = h->dref_norms;
     auto linearise = [&](int lin) -> int {
-        HIPCHK(h, hipMemsetAsync(h->dref_norms, 0, 4 * sizeof(int), st));
-        HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)B * hw * 2 * sizeof(long long), st));
         launch_lin(h, M, N, 6, false, MODE_MAPS, 2);
-        hipLaunchKernelGGL(k_dref_prepass, px_all, dim3(256), 0, st, Pp, Dp);
+        hipLaunchKernelGGL(k_dref_count, dim3(DREF_CNT_WG, N), dim3(256), 0, st, Pp, Dp);
+        hipLaunchKernelGGL(k_dref_scatter, dim3((unsigned)(((h->W + DREF_TW - 1) / DREF_TW) * ((h->H + DREF_TH - 1) / DREF_TH)), SB), dim3(DREF_TW * DREF_TH), 0, st, Pp, Dp);
         Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
         Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
         launch_lin(h, Pi, SB, 6, dc, MODE_LIN, 2);
