@@ -462,7 +462,8 @@ def main():
                   "same_poses": bool(all(torch.equal(a_, w["out"]) for a_, w in zip(lanes_out, ring))),
                   "what": "tcsfm_refine_window_queued: the library runs every `calls_per_sequence` queued calls as ONE pack / (linearise, solve) x 4 "
                           "sequence over all their directed pairs (pointer table), the rest of a block at its closing flush"}
-        lanes_res = {"calls_in_flight": lanes, "value": round(windows_per_block / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 5)}
+        lanes_res = {"calls_in_flight": lanes, "value": round(windows_per_block / elapsed, 2), "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                     "mode": "graph replay" if use_replay else "plain launches (9 per call)"}
         if c_el < elapsed:          # the merged sequences are the faster way of running these steps: they are the headline
             elapsed, blocks = c_el, c_blocks
             host_enqueue_us = merged["host_enqueue_us_per_step"]

@@ -1,8 +1,8 @@
 """diagnostic: per-pixel depth disagreements of the dense mode against the replayed float64 oracle -- where do they start and what
 discontinuity of the residual's derivative does the pixel (or one of its 3x3 neighbours) sit on?"""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np, torch
 from oracle.oracle import Oracle, default_opts as oopts
 from tightly_coupled_sfm_amd import synth

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """diagnostic: dense REFERENCE mode, engine vs float64 oracle after k Gauss-Newton iterations (poses, depth map), term by term"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np, torch
 from oracle.oracle import Oracle, default_opts as oo_
 from tightly_coupled_sfm_amd.engine import Engine, default_opts

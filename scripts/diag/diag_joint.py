@@ -1,7 +1,7 @@
 """diagnostic: the pixel(s) where the joint dense mode and its replayed oracle disagree"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import parity_util as PU
 from oracle.oracle import Oracle, default_opts as oopts

@@ -2,7 +2,7 @@
 300-iteration limit, translation (relative) and rotation (deg), and the gradient norm at the iterate."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle.oracle import Oracle, default_opts
 from tightly_coupled_sfm_amd import synth
 H, W, S, B = 96, 320, 2, 1

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np, torch
 os.environ["TCSFM_DEBUG_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 H, W = 192, 640

@@ -1,6 +1,6 @@
 #!/bin/bash
 # value / single-stream value / block spread of bench.py over several fresh processes, under environment variants (one per argument,
-# "-" = unchanged):   bash scripts/bench_repeat.sh <runs> <steps> "-" "GPU_MAX_HW_QUEUES=8" ...
+# "-" = unchanged):   bash scripts/experiments/bench_repeat.sh <runs> <steps> "-" "GPU_MAX_HW_QUEUES=8" ...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 R=$1; K=$2; shift; shift
 for r in $(seq 1 $R); do

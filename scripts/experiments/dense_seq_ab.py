@@ -1,6 +1,6 @@
 """(the other tree: `mkdir ab_r02 && git archive <commit> tightly_coupled_sfm_amd include | tar -x -C ab_r02`, build it there with the flags of
 build.py; ab_*/ is git-ignored but travels to the GPU box)
-A/B of tcsfm_refine_dense_sequence between library trees on ONE box: python scripts/dense_seq_ab.py <tree-root>
+A/B of tcsfm_refine_dense_sequence between library trees on ONE box: python scripts/experiments/dense_seq_ab.py <tree-root>
 (the tree's own package is imported; prints windows/s for lanes x windows_per_call)"""
 import json, os, sys, time
 root = os.path.abspath(sys.argv[1])

@@ -1,7 +1,7 @@
 """Does replaying the 9-launch refine sequence as one HIP graph beat 9 individual launches?  (B=1 bench workload)"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 H, W = 192, 640

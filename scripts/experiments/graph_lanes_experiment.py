@@ -2,7 +2,7 @@
 robin.  Compares with the library's lanes (plain launches, host-bound at 9 launches per call)."""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 H, W, N = 192, 640, 3000

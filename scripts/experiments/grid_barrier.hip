@@ -13,7 +13,7 @@
 // Output: one JSON line per variant: microseconds per iteration above the stand-in work (GPU's own clock: earliest workgroup start
 // -> latest workgroup end, as tcsfm_profile_kernel_time does), median of `reps` launches.
 //
-// build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 scripts/grid_barrier.hip -o /tmp/grid_barrier && /tmp/grid_barrier
+// build + run on the GPU box:  hipcc -O3 --offload-arch=gfx950 scripts/experiments/grid_barrier.hip -o /tmp/grid_barrier && /tmp/grid_barrier
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

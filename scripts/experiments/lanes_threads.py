@@ -1,7 +1,7 @@
 """B=1 windows from device-resident frames: lanes driven by ONE host thread vs one host thread PER lane (the refine call spends
 ~50 us enqueueing 9 kernel launches; ctypes releases the GIL for that time, so threads overlap the enqueue cost)"""
 import json, os, sys, time, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts

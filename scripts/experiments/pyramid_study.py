@@ -4,9 +4,9 @@
 Pyramid level l: images and INVERSE depths area-averaged over 2^l x 2^l blocks, intrinsics scaled (fx, fy, cx + 1/2, cy + 1/2
 divided by 2^l, minus 1/2: pixel centres).  LM at every level, coarse to fine.  'Converged' = the final pose is within
 `tol` (relative translation / rotation error) of the full-resolution optimum (a long LM run from the ground truth).
-    python scripts/pyramid_study.py [n_seeds] [H] [W]"""
+    python scripts/experiments/pyramid_study.py [n_seeds] [H] [W]"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle.oracle import Oracle, default_opts
 from tightly_coupled_sfm_amd import synth
@@ -76,4 +76,4 @@ if __name__ == "__main__":
             summary[f"{name} | {tag}"] = {"converged": float(np.mean(conv)), "median_trans_err_rel": float(np.median(e[:, 0])), "median_rot_err_rad": float(np.median(e[:, 1])),
                                           "initial_trans_err_rel": float(np.median(e0[:, 0])), "initial_rot_err_rad": float(np.median(e0[:, 1])), "n": int(len(e))}
     print(json.dumps(summary, indent=1))
-    json.dump(summary, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r02_pyramid_study_{H}x{W}.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", f"r02_pyramid_study_{H}x{W}.json"), "w"), indent=1)

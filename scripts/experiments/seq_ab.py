@@ -1,6 +1,6 @@
 """(the other tree: `mkdir ab_r02 && git archive <commit> tightly_coupled_sfm_amd include | tar -x -C ab_r02`, build it there with the flags of
 build.py; ab_*/ is git-ignored but travels to the GPU box)
-A/B of tcsfm_refine_sequence between library trees on ONE box: python scripts/seq_ab.py <tree-root>   (every run's windows/s)"""
+A/B of tcsfm_refine_sequence between library trees on ONE box: python scripts/experiments/seq_ab.py <tree-root>   (every run's windows/s)"""
 import json, os, sys, time
 root = os.path.abspath(sys.argv[1])
 sys.path.insert(0, root)

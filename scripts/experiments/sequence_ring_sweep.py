@@ -1,6 +1,6 @@
 """tcsfm_refine_sequence: PCIe-inclusive windows/s of a 200-frame 640x192 sequence against the number of lanes and ring slots"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts

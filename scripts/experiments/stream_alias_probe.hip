@@ -2,7 +2,7 @@
 // ROCclr maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, default 4, per priority level); two streams that land
 // in the same queue serialise.  For every pair (i, j) of K streams: a 300 us spin kernel on i, then a tiny kernel on j; if j's kernel
 // finishes before i's, the two streams are concurrent.  Prints the K x K matrix ('.' = concurrent, 'X' = serialised).
-//   hipcc -O3 --offload-arch=gfx950 scripts/stream_alias_probe.hip -o /tmp/probe && /tmp/probe [K]
+//   hipcc -O3 --offload-arch=gfx950 scripts/experiments/stream_alias_probe.hip -o /tmp/probe && /tmp/probe [K]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,7 +1,7 @@
 """Host-side enqueue cost and end-to-end step time of the B=1 bench workload on different streams."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 H, W = 192, 640

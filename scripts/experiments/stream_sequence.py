@@ -3,7 +3,7 @@ window = (frame t, frame t+1) -> fwd + inv directed pairs, 4 GN iterations.  Com
   (a) the round-1 host-pointer path: one synchronous tcsfm_refine per window, both pairs' arrays handed over (7.9 MB / window)
   (b) SequenceRefiner: every frame uploaded once, window form, 1 / 2 / 3 lanes"""
 import json, os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
@@ -72,7 +72,7 @@ for lanes, wpc in ((1, 1), (2, 1), (3, 1), (1, 8), (2, 8), (3, 8), (2, 16)):
     e.close()
 # (d) with the reference's pose initialisation inside the loop: per window the coupled PoseNet loop (4 evaluations + 3 warps), then the
 #     refinement -- tcsfm_odometry_sequence against the same work issued window by window from Python (frames already on the device)
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import standins
 from tightly_coupled_sfm_amd.posenet import PoseNetHIP
 params = standins.posenet_params(0)

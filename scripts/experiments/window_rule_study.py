@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Which scalar goes down faster: the reference's compute_optimization_loss (optimizer.py:47-86) evaluated at the poses
 that k Gauss-Newton iterations reach under the PAIR rule and under the REFERENCE rule (float64 oracle, CPU).
-    python scripts/window_rule_study.py  ->  profiles/r03_window_rule_study.json"""
+    python scripts/experiments/window_rule_study.py  ->  profiles/r03_window_rule_study.json"""
 import json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import standins
 from oracle.oracle import Oracle, default_opts as oopts

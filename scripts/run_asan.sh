@@ -6,7 +6,7 @@
 #   bash scripts/run_asan.sh [report-file]
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=${1:-$ROOT/profiles/r03_asan.txt}
+OUT=${1:-$ROOT/profiles/r04_asan.txt}
 cd "$ROOT"
 LIBASAN=$(gcc -print-file-name=libasan.so)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
@@ -17,7 +17,7 @@ export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 UBSAN_OPTION
   echo "## 1. oracle/tcsfm_oracle.c (float64 + float32) under its pinning and replay tests"
   make -C oracle -s asan || fail=1
   LD_PRELOAD=$LIBASAN TCSFM_ORACLE_BUILD_DIR=$ROOT/oracle/_build_asan python -m pytest -q -p no:cacheprovider \
-      tests/test_oracle_vs_golden.py tests/test_oracle_replay_cpu.py tests/test_posenet_cpu.py 2>&1 | tail -4
+      tests/test_oracle_vs_golden.py tests/test_oracle_replay_cpu.py tests/test_posenet_cpu.py tests/test_solver_independent_cpu.py 2>&1 | tail -4
   [ ${PIPESTATUS[0]} -eq 0 ] || fail=1
   echo "## 2. host SE(3) routines of the C ABI (se3_math.h, host path) -- scipy pin + edge cases"
   g++ $SAN -std=c++17 -fPIC -shared tests/asan/se3_host.cpp -o oracle/_build_asan/libtcsfm_se3_host.so -lm || fail=1

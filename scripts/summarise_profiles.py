@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/<tag>/ (from scripts/collect_profiles.sh) into profiles/<tag>_*: kernel stats CSV, a PMC summary
 and the HBM-traffic JSON bench.py reads (FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950)."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob as _glob, json, os, shutil, sys
+
+
+class glob:          # newest first: a directory that still holds an earlier collection's files is summarised from the latest ones
+    @staticmethod
+    def glob(pat):
+        return sorted(_glob.glob(pat), key=os.path.getmtime, reverse=True)
+
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +27,10 @@ for name in ("bench.json", "bench_k20.json", "meta.json"):      # meta.json: has
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 pmc = collections.defaultdict(dict)
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    newest.setdefault(os.path.dirname(f), f)
+for f in newest.values():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(f)):
         acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -37,7 +47,7 @@ if lin:
                "valu_insts_per_linearize_launch": lin.get("SQ_INSTS_VALU"), "waves_per_linearize_launch": lin.get("SQ_WAVES"),
                "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
                "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE; "
-                       "separate rocprofv3 --pmc passes of `python bench.py --lanes 1 --graph-replay 0 --steps 20 --warmup 5`; per-launch average"}
+                       "separate rocprofv3 --pmc passes of `python bench.py --lanes 1 --coalesce 0 --graph-replay 0 --steps 20 --warmup 5`; per-launch average"}
     # the whole call: pack + 4 x (linearise + solve), every kernel's own per-launch average (same correction)
     hb = lambda v: (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024
     pack = next((v for k, v in pmc.items() if "k_pack" in k and "FETCH_SIZE" in v), None)

@@ -59,7 +59,8 @@ def test_bench_single_process():
     # both launch modes ran (the faster one in the timed region, chosen on untimed probe blocks) and gave the same bits
     lm = d["launch_mode"]
     ot = lm["other_mode"]
-    assert ("graph replay" in lm["timed"]) != ("graph replay" in ot["mode"]) and "probe" in lm["chosen_by"]
+    assert ("graph replay" in ln["mode"]) != ("graph replay" in ot["mode"]) and "probe" in lm["chosen_by"]
+    assert ("merged sequences" in lm["timed"]) == mg["timed"]
     assert ot["same_poses"] is True and ot["captures"] >= d["config"]["ring_calls"] and ot["replays"] >= 60 - 6 and ot["value"] > 100
     assert d["host_enqueue_us_per_step"] > 0 and ot["host_enqueue_us_per_step"] > 0
 

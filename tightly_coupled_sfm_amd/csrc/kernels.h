@@ -414,55 +414,77 @@ __device__ inline float photo_err_planar(const float *__restrict__ x, const floa
         float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
         float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
         float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
-        float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+        // (the two squares are rounded on their own: mux mux + muy muy must not contract into ONE fma, whose result depends on which of
+        // the two images is called x -- the error of (x, y) and of (y, x) is the same number, bit for bit, and the window forms compute
+        // it once for a forward pair and its inverse)
+        float d = ((__fmul_rn(mux, mux) + __fmul_rn(muy, muy)) + SSIM_C1) * (sigx + sigy + SSIM_C2);
         acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n * frcp(d)) * 0.5f);
     }
     return acc;
 }
 
+// source image of pair n with its 1-texel zero border (see tap4); edge pixels also write the border texels next to them
+__device__ __forceinline__ void pack_write_src(const PackParams &P, int n, int u, int v, const float4 &val) {
+    const int WB = P.W + 2;
+    float4 *sp = P.srcpack + (size_t)n * (P.H + 2) * WB;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    sp[(v + 1) * WB + u + 1] = val;
+    if (u == 0) sp[(v + 1) * WB] = zero;
+    if (u == P.W - 1) sp[(v + 1) * WB + P.W + 1] = zero;
+    if (v == 0) { sp[u + 1] = zero; if (u == 0) sp[0] = zero; if (u == P.W - 1) sp[P.W + 1] = zero; }
+    if (v == P.H - 1) {
+        sp[(P.H + 1) * WB + u + 1] = zero;
+        if (u == 0) sp[(P.H + 1) * WB] = zero;
+        if (u == P.W - 1) sp[(P.H + 1) * WB + P.W + 1] = zero;
+    }
+}
+
+// Pair form (win_B == 0, no table): blockIdx.y = directed pair n.  Window forms (win_B > 0, or the coalesced calls' table): blockIdx.y =
+// the forward pair q < S B; the thread packs pair q AND its inverse S B + q -- the same two images with their roles swapped, and
+// photo_err_planar(x, y) == photo_err_planar(y, x) bit for bit -- so every input value is loaded once and the 3x3 error evaluated once
+// (round 4: k_pack 8.6 -> see DESIGN section 4; the bits equal those of the pair form on the same images).
 __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     int n = blockIdx.y;
     const int hw = P.H * P.W;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && n < P.init.N) init_pair(P.init, n, ct);  // independent of the packing below
-    if (idx >= hw) return;
-    int v = idx / P.W, u = idx - v * P.W;
+    const bool both = ct != nullptr || P.win_B > 0;
+    int n_inv = 0;
     const float *t = P.tgt + (size_t)n * 3 * hw, *s = P.src + (size_t)n * 3 * hw;
     const float *dtp = P.depth_t + (size_t)n * hw, *dsp = P.depth_s + (size_t)n * hw;
     if (ct != nullptr) {      // coalesced calls: the pair's images live in its own call's buffers (window layout of that call)
         const CoalIdx ci = coal_index(ct->ncall, ct->cB, ct->cS, n);
-        const float *ti = ct->tgt[ci.call] + (size_t)ci.bl * 3 * hw, *si = ct->src[ci.call] + (size_t)(ci.s * ct->cB + ci.bl) * 3 * hw;
-        const float *td = ct->dt[ci.call] + (size_t)ci.bl * hw, *sd = ct->ds[ci.call] + (size_t)(ci.s * ct->cB + ci.bl) * hw;
-        t = ci.inv ? si : ti; s = ci.inv ? ti : si; dtp = ci.inv ? sd : td; dsp = ci.inv ? td : sd;
+        n_inv = ct->cS * ct->ncall * ct->cB + n;
+        t = ct->tgt[ci.call] + (size_t)ci.bl * 3 * hw; s = ct->src[ci.call] + (size_t)(ci.s * ct->cB + ci.bl) * 3 * hw;
+        dtp = ct->dt[ci.call] + (size_t)ci.bl * hw; dsp = ct->ds[ci.call] + (size_t)(ci.s * ct->cB + ci.bl) * hw;
     } else if (P.win_B > 0) {
-        const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, qi = win_src_image(P.win_off, q, P.win_B);
-        const float *ti = P.tgt + (size_t)b * 3 * hw, *si = P.src + (size_t)qi * 3 * hw;
-        const float *td = P.depth_t + (size_t)b * hw, *sd = P.depth_s + (size_t)qi * hw;
-        t = inv ? si : ti; s = inv ? ti : si; dtp = inv ? sd : td; dsp = inv ? td : sd;
+        const int b = n % P.win_B, qi = win_src_image(P.win_off, n, P.win_B);
+        n_inv = P.win_S * P.win_B + n;
+        t = P.tgt + (size_t)b * 3 * hw; s = P.src + (size_t)qi * 3 * hw;
+        dtp = P.depth_t + (size_t)b * hw; dsp = P.depth_s + (size_t)qi * hw;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 2) {            // independent of the packing below
+        const int ni = threadIdx.x == 0 ? n : n_inv;
+        if ((threadIdx.x == 0 || both) && ni < P.init.N) init_pair(P.init, ni, ct);
+    }
+    if (idx >= hw) return;
+    int v = idx / P.W, u = idx - v * P.W;
     float ae = photo_err_planar(t, s, P.H, P.W, u, v, P.wl, P.ws);
     float dt = dtp[idx], ds = dsp[idx];
     if (P.depth_is_disp) {  // disp_to_depth, learning_helpers.py:77-86
         dt = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * dt);
         ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
     }
-    P.tgtpack[(size_t)n * hw + idx] = make_float4(t[idx], t[hw + idx], t[2 * hw + idx], ae);
-    {   // source image with its 1-texel zero border (see tap4); edge pixels also write the border texels next to them
-        const int WB = P.W + 2;
-        float4 *sp = P.srcpack + (size_t)n * (P.H + 2) * WB;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        sp[(v + 1) * WB + u + 1] = make_float4(s[idx], s[hw + idx], s[2 * hw + idx], ds);
-        if (u == 0) sp[(v + 1) * WB] = zero;
-        if (u == P.W - 1) sp[(v + 1) * WB + P.W + 1] = zero;
-        if (v == 0) { sp[u + 1] = zero; if (u == 0) sp[0] = zero; if (u == P.W - 1) sp[P.W + 1] = zero; }
-        if (v == P.H - 1) {
-            sp[(P.H + 1) * WB + u + 1] = zero;
-            if (u == 0) sp[(P.H + 1) * WB] = zero;
-            if (u == P.W - 1) sp[(P.H + 1) * WB + P.W + 1] = zero;
-        }
-    }
+    const float t0 = t[idx], t1 = t[hw + idx], t2 = t[2 * hw + idx], s0 = s[idx], s1 = s[hw + idx], s2 = s[2 * hw + idx];
+    P.tgtpack[(size_t)n * hw + idx] = make_float4(t0, t1, t2, ae);
+    pack_write_src(P, n, u, v, make_float4(s0, s1, s2, ds));
     P.depth_out[(size_t)n * hw + idx] = dt;
     if (P.depth_out2) P.depth_out2[(size_t)n * hw + idx] = dt;
+    if (both) {             // the inverse pair: target and source swapped, the same error
+        P.tgtpack[(size_t)n_inv * hw + idx] = make_float4(s0, s1, s2, ae);
+        pack_write_src(P, n_inv, u, v, make_float4(t0, t1, t2, dt));
+        P.depth_out[(size_t)n_inv * hw + idx] = ds;
+        if (P.depth_out2) P.depth_out2[(size_t)n_inv * hw + idx] = ds;
+    }
 }
 __global__ __launch_bounds__(256) void k_pack(PackParams P) { pack_body(P, nullptr); }
 __global__ __launch_bounds__(256) void k_pack_coal(PackParams P, CoalTab T) { pack_body(P, &T); }
@@ -537,28 +559,34 @@ __device__ inline float photo_err_packs(const float4 *__restrict__ x, const floa
         float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
         float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
         float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
-        float d = (mux * mux + muy * muy + SSIM_C1) * (sigx + sigy + SSIM_C2);
+        // (the two squares are rounded on their own: mux mux + muy muy must not contract into ONE fma, whose result depends on which of
+        // the two images is called x -- the error of (x, y) and of (y, x) is the same number, bit for bit, and the window forms compute
+        // it once for a forward pair and its inverse)
+        float d = ((__fmul_rn(mux, mux) + __fmul_rn(muy, muy)) + SSIM_C1) * (sigx + sigy + SSIM_C2);
         acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n * frcp(d)) * 0.5f);
     }
     return acc;
 }
+// blockIdx.y = forward pair q < S B; the thread also serves the inverse pair S B + q (the same error, see pack_body)
 __global__ __launch_bounds__(256) void k_pack_cached(PackCachedParams P) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
     const int hw = P.H * P.W;
-    const int SB = P.win_S * P.win_B, inv = n >= SB, q = inv ? n - SB : n, b = q % P.win_B, s = q / P.win_B;
+    const int SB = P.win_S * P.win_B, b = n % P.win_B, s = n / P.win_B, n_inv = SB + n;
     const int ts = P.slot0 + P.tpos + b, ss = P.slot0 + P.win_off.off[s] + b;     // window b: its target / its source s
-    const int tslot = inv ? ss : ts, sslot = inv ? ts : ss;                       // THIS pair's target / source frame
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        P.pair_src[n] = sslot; P.pair_dep[n] = tslot;
-        if (n < P.init.N) init_pair(P.init, n);
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        const bool inv = threadIdx.x == 1;
+        const int ni = inv ? n_inv : n;
+        P.pair_src[ni] = inv ? ts : ss; P.pair_dep[ni] = inv ? ss : ts;           // THIS pair's source / target frame
+        if (ni < P.init.N) init_pair(P.init, ni);
     }
     if (idx >= hw) return;
     const int v = idx / P.W, u = idx - v * P.W;
     const size_t fs = (size_t)(P.H + 2) * (P.W + 2);
-    const float4 *t = P.fpack + (size_t)tslot * fs, *sp = P.fpack + (size_t)sslot * fs;
+    const float4 *t = P.fpack + (size_t)ts * fs, *sp = P.fpack + (size_t)ss * fs;
     const float ae = photo_err_packs(t, sp, P.H, P.W, u, v, P.wl, P.ws);
-    const float4 tc = t[(v + 1) * (P.W + 2) + u + 1];
+    const float4 tc = t[(v + 1) * (P.W + 2) + u + 1], sc = sp[(v + 1) * (P.W + 2) + u + 1];
     P.tgtpack[(size_t)n * hw + idx] = make_float4(tc.x, tc.y, tc.z, ae);
+    P.tgtpack[(size_t)n_inv * hw + idx] = make_float4(sc.x, sc.y, sc.z, ae);
 }
 
 // Per-pixel min over the S sources of one target (compute_optimization_loss, optimizer.py:47-69; oracle orc_window_select), dense window
@@ -899,6 +927,12 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
 // The gradient is the same sum in another order (exact; H is untouched).  The coefficient records alias the colour part of the
 // staged records (dead after pass A once every thread holds its own colours in registers), so LDS stays at 68.5 KB; the price is
 // two more workgroup barriers and the window sums of the image gradients (curvature model) moving into pass A (+3 per neighbour).
+// Measurement hook (scripts/passa_probe.sh; appendix R4): a build with -DTC_PROBE_PASSA_VISITS=5 visits 5 of the 9 window positions in
+// pass A -- WRONG statistics, timing only -- which removes more pass-A work (48 VALU + 8 LDS reads per wave, no extra barrier, no
+// extra LDS) than an exactly separable form could: a measured upper bound on what that form can buy.  Production builds: 9.
+#ifndef TC_PROBE_PASSA_VISITS
+#define TC_PROBE_PASSA_VISITS 9
+#endif
 template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
@@ -1118,7 +1152,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (ADJL) { aGx01 = n1.lo; aGy01 = n1.hi; aG2s = n2.hi; }
         }
 #pragma unroll 1
-        for (int kk = 1; kk < 9; kk++) {
+        for (int kk = 1; kk < TC_PROBE_PASSA_VISITS; kk++) {
             f32x4 n0, n1 = {0.f, 0.f, 0.f, 0.f}, n2;
             if (ADJL) lds_read3v(nbA, n0, n1, n2); else lds_read02v(nbA, n0, n2);
             nbA += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);

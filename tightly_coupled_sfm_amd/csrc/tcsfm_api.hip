@@ -407,10 +407,14 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
     P.min_disp = o->depth_is_disp ? 1.f / o->max_depth : 0.f;
     P.max_disp = o->depth_is_disp ? 1.f / o->min_depth : 0.f;
     int hw = h->H * h->W;
+    if (ct ? Nimg != 2 * ct->cS * ct->ncall * ct->cB : (win_B > 0 && Nimg != 2 * win_S * win_B))
+        return fail(h, TCSFM_E_ARG, "internal: a window-form pack covers the 2 S B directed pairs of its windows");
     {
         ProfScope prof(h, 2);
-        if (ct) hipLaunchKernelGGL(k_pack_coal, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P, *ct);
-        else hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, Nimg), dim3(256), 0, h->stream, P);
+        // window forms: one row of workgroups per FORWARD pair, which packs its inverse too (pack_body)
+        const int rows = (ct || win_B > 0) ? Nimg / 2 : Nimg;
+        if (ct) hipLaunchKernelGGL(k_pack_coal, dim3((hw + 255) / 256, rows), dim3(256), 0, h->stream, P, *ct);
+        else hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, rows), dim3(256), 0, h->stream, P);
     }
     HIPCHK(h, hipGetLastError());
     return TCSFM_OK;
@@ -703,7 +707,8 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     if (sel) { Pj.ext_diff = maps_diff; Pj.ext_valid = maps_valid; Pj.n_ext = SB; Pj.ext_B = B; Pj.ext_S = S; }
     JointParams J;
     memset(&J, 0, sizeof(J));
-    J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.lambda_depth = ex ? 1e20f : o->lambda_depth;      // (export: depth block frozen, the reduced right-hand side IS the pose gradient) J.w_prior = 0.f;
+    J.jrec = h->jrec; J.depth0 = h->depth0; J.jblockrec = h->jblockrec; J.w_prior = 0.f;
+    J.lambda_depth = ex ? 1e20f : o->lambda_depth;      // (export: depth block frozen, the reduced right-hand side IS the pose gradient)
     J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
     J.automask = o->argmin ? o->automask : 0;     // own masks: with one source the min is the source itself; without argmin no auto-mask (:71-73)
     J.norms = h->dref_norms; J.ext = h->dref_ext; J.c_f = o->argmin ? 1.f : 0.25f;
@@ -1247,7 +1252,7 @@ static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         C.wl = o->w_l1 / 3.f; C.ws = o->w_ssim / 3.f; C.init = I;
         {
             ProfScope prof(h, 2);
-            hipLaunchKernelGGL(k_pack_cached, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, h->stream, C);
+            hipLaunchKernelGGL(k_pack_cached, dim3((unsigned)((hw + 255) / 256), N / 2), dim3(256), 0, h->stream, C);      // (a row per forward pair)
         }
         HIPCHK(h, hipGetLastError());
         P.srcpack = fc->fpack; P.depth_t = fc->fdepth; P.pair_src = C.pair_src; P.pair_dep = C.pair_dep;
