@@ -22,9 +22,9 @@ the short kernels of the other.  Every step is still one B-window ``tcsfm_refine
 blocks with one call in flight (the round-1 protocol).
 
 Merged sequences.  The same steps are also run as QUEUED calls (tcsfm_refine_window_queued): the library merges every --coalesce of them
-(default 10) into ONE launch sequence over all their directed pairs -- one stream, so nothing depends on how the runtime places the lanes'
-hardware queues (DESIGN section 4 "Lanes") -- and what is still waiting at the end of a block is launched by the block's closing flush.  Per
-window the poses are the same bits.  The faster of the two ways is the headline; `launch_mode.merged` / `launch_mode.lanes` report both.
+(default 10) into ONE launch sequence over all their directed pairs; consecutive sequences alternate over --coalesce-lanes streams of the handle
+(default 2: the 20-workgroup solve kernels of one sequence overlap the chip-filling launches of the other), and what is still waiting at the
+end of a block is launched by the block's closing flush.  Per window the poses are the same bits.  The faster of the two ways is the headline; `launch_mode.merged` / `launch_mode.lanes` report both.
 
 Timing.  W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides and
 reduced with MAX over the ranks.  One block is the contract's measurement; because the driver's K=20 block lasts ~1.5 ms, the
@@ -259,6 +259,8 @@ def main():
     ap.add_argument("--coalesce", type=int, default=10, help="also time the steps as QUEUED calls that the library merges into one launch sequence per "
                     "this many calls (tcsfm_refine_window_queued, include/tcsfm.h; bit-identical per window); the faster of lanes / merged is the "
                     "headline, the other is reported beside it; 0 = lanes only")
+    ap.add_argument("--coalesce-lanes", type=int, default=2, help="streams of the handle the merged sequences alternate over (tcsfm_set_coalesce_lanes): "
+                    "the solve kernels of one sequence overlap the chip-filling launches of the other; 1 = the handle's stream only")
     ap.add_argument("--graph-replay", default="auto", choices=("auto", "0", "1"),
                     help="1: the handle replays the (repeated) refine call of every lane as one captured HIP graph (tcsfm_set_graph_replay: one "
                          "host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches; auto: untimed blocks of "
@@ -452,12 +454,15 @@ def main():
     if coal > 1:
         lanes_out = [w["out"].clone() for w in ring]
         eng.set_coalesce(coal)
+        coal_streams = max(1, min(args.coalesce_lanes, lanes))
+        eng.set_coalesce_lanes(coal_streams)
         queued[0] = True
         del enqueue_s[:]
         c_el, c_blocks = timed(lanes)
         queued[0] = False
+        eng.set_coalesce_lanes(1)
         eng.set_coalesce(0)
-        merged = {"calls_per_sequence": coal, "value": round(windows_per_block / c_el, 2), "ms_per_step": round(c_el / args.steps * 1e3, 5),
+        merged = {"calls_per_sequence": coal, "streams": coal_streams, "value": round(windows_per_block / c_el, 2), "ms_per_step": round(c_el / args.steps * 1e3, 5),
                   "host_enqueue_us_per_step": round(float(np.median(enqueue_s)) / args.steps * 1e6, 2),
                   "same_poses": bool(all(torch.equal(a_, w["out"]) for a_, w in zip(lanes_out, ring))),
                   "what": "tcsfm_refine_window_queued: the library runs every `calls_per_sequence` queued calls as ONE pack / (linearise, solve) x 4 "

@@ -343,9 +343,16 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  * buffers must stay valid and unchanged until the flush that runs them has been issued AND has completed on the handle's stream.
  *   tcsfm_set_coalesce(h, max_calls)   0 / 1: off (every queued call runs at once); up to 16; the handle's max_pairs bounds the merged
  *                                      sequence as well (2 S B x calls <= max_pairs)
- *   tcsfm_flush(h)                     launch what is waiting (asynchronous on the handle's stream)
+ *   tcsfm_set_coalesce_lanes(h, n)     merged sequences alternate over n of the handle's streams (1: the handle's own, the default;
+ *                                      up to the lanes of tcsfm_set_lanes): sequence k runs on lane k mod n, behind everything queued
+ *                                      on the handle's stream when it is issued.  The 20-workgroup solve kernels of one sequence then
+ *                                      overlap the chip-filling launches of the other (same bits).  A sequence issued on a lane is
+ *                                      ordered before later work of the handle's stream only by tcsfm_flush / tcsfm_synchronize.
+ *   tcsfm_flush(h)                     launch what is waiting (asynchronous) and order the handle's stream behind every merged sequence
+ *                                      issued so far, whichever lane ran it
  *   tcsfm_coalesce_counts              launch sequences issued / calls they carried, since the handle was created */
 int tcsfm_set_coalesce(tcsfm_handle h, int max_calls);
+int tcsfm_set_coalesce_lanes(tcsfm_handle h, int n_streams);
 int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out);
 int tcsfm_flush(tcsfm_handle h);

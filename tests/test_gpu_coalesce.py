@@ -96,3 +96,41 @@ def test_coalesced_kitti_windows_two_targets_two_sources():
     assert e.coalesce_counts() == (1, 3)
     for got, w_ in zip(outs, want):
         assert torch.equal(got, w_)
+
+
+def test_merged_sequences_alternating_over_lanes():
+    """tcsfm_set_coalesce_lanes: consecutive merged sequences run on different streams of the handle (the solve kernels of one overlap
+    the launches of the other); every window's poses are still the bits of its own call, tcsfm_flush orders the handle's stream (and a
+    consumer queued on it) behind every sequence, and a lane count above the handle's lanes is refused"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    calls = _calls(11, H, W, seed=90)
+    o = default_opts(n_iters=4)
+    ref = Engine(H, W, 2)
+    want = [ref.refine_window(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], o)[0].clone() for c in calls]
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2 * 3, lanes=3)
+    with pytest.raises(RuntimeError):
+        e.set_coalesce_lanes(4)
+    e.set_coalesce(3)
+    e.set_coalesce_lanes(3)
+    for rep in range(3):                                          # sequences 0..3 of every round land on lanes 0, 1, 2, 0 (then rotate on)
+        outs = [torch.zeros_like(c["pose"]) for c in calls]
+        for c, out in zip(calls, outs):
+            e.refine_window_queued(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], out, o)
+        e.flush()
+        # a consumer on the handle's stream (what Engine.set_stream / the current torch stream is NOT: order it explicitly)
+        e.synchronize()
+        for got, w in zip(outs, want):
+            assert torch.equal(got, w)
+    assert e.coalesce_counts() == (12, 33)
+    # back to one stream, and fewer lanes than coal_lanes: clamped, still the same bits
+    e.set_lanes(2)
+    outs = [torch.zeros_like(c["pose"]) for c in calls]
+    for c, out in zip(calls, outs):
+        e.refine_window_queued(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], out, o)
+    e.synchronize()
+    for got, w in zip(outs, want):
+        assert torch.equal(got, w)
+    e.set_coalesce_lanes(1)
+    e.set_coalesce(0)

@@ -103,6 +103,8 @@ struct tcsfm_ctx {
     // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; };
     int coal_max = 0;
+    int coal_lanes = 1;                // merged sequences alternate over this many of the handle's streams (tcsfm_set_coalesce_lanes)
+    unsigned coal_dirty = 0;           // bit l: lane l ran a merged sequence the handle's stream has not been ordered behind yet
     std::vector<PendingCall> pending;
     tcsfm_opts pend_opts;
     int pend_B = 0, pend_S = 0;
@@ -805,6 +807,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
 extern "C" {
 
 static int flush_pending(tcsfm_ctx *h);
+static int join_coalesce_lanes(tcsfm_ctx *h);
 
 void tcsfm_default_opts(tcsfm_opts *o) {
     memset(o, 0, sizeof(*o));
@@ -933,7 +936,10 @@ int tcsfm_synchronize(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
     DeviceGuard dev_guard(h->device);
     if (int rc_ = flush_pending(h)) return rc_;          // queued calls (tcsfm_refine_window_queued) are launched first
+    if (int rc_ = join_coalesce_lanes(h)) return rc_;    // (merged sequences that ran on lanes: the handle's stream waits for them)
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (tcsfm_ctx *c : h->lanes)
+        if (int rc_ = pending_error(c)) { h->err = c->err; return rc_; }
     return pending_error(h);
 }
 
@@ -1665,26 +1671,54 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
 }
 
 // ---- coalesced calls: queued B-window calls of one shape as ONE launch sequence (include/tcsfm.h)
+// the handle's stream is ordered behind the merged sequences that ran on lanes (consumers queued on it see their poses)
+static int join_coalesce_lanes(tcsfm_ctx *h) {
+    for (int l = 1; l <= (int)h->lanes.size() && h->coal_dirty; l++)
+        if (h->coal_dirty & (1u << l)) {
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->lanes[l - 1]->done_ev, 0));
+            h->coal_dirty &= ~(1u << l);
+        }
+    return TCSFM_OK;
+}
+
 static int flush_pending(tcsfm_ctx *h) {
     if (h->pending.empty()) return TCSFM_OK;
     std::vector<tcsfm_ctx::PendingCall> calls;
     calls.swap(h->pending);
     const tcsfm_opts o = h->pend_opts;
     const int B = h->pend_B, S = h->pend_S, n = (int)calls.size();
+    // merged sequences alternate over coal_lanes streams (tcsfm_set_coalesce_lanes): sequence k runs on lane k mod coal_lanes, behind
+    // everything queued on the handle's stream so far; the short tail kernels of one sequence (k_solve: 20 workgroups, 6 us) then
+    // overlap the other's chip-filling launches.  tcsfm_flush / tcsfm_synchronize order the handle's stream behind them.
+    const int nl = std::min(h->coal_lanes, (int)h->lanes.size() + 1), l = nl > 1 ? h->coal_batches % nl : 0;
+    tcsfm_ctx *c = l == 0 ? h : h->lanes[l - 1];
     h->coal_batches++; h->coal_calls += n;
+    if (c != h) {
+        HIPCHK(h, hipEventRecord(c->in_ev, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(c->own_stream, c->in_ev, 0));
+        c->stream = c->own_stream;
+    }
+    int rc;
     if (n == 1) {
-        const auto &c = calls[0];
-        return refine_impl(h, &o, 2 * B * S, B, S, c.tgt, c.srcs, c.dt, c.ds, c.K, c.pose_in, nullptr, c.pose_out, nullptr, nullptr);
+        const auto &q = calls[0];
+        rc = refine_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, nullptr, q.pose_out, nullptr, nullptr);
+    } else {
+        CoalTab ct;
+        memset(&ct, 0, sizeof(ct));
+        ct.ncall = n; ct.cB = B; ct.cS = S;
+        float *outs[TC_MAX_COAL];
+        for (int i = 0; i < n; i++) {
+            ct.tgt[i] = calls[i].tgt; ct.src[i] = calls[i].srcs; ct.dt[i] = calls[i].dt; ct.ds[i] = calls[i].ds; ct.K[i] = calls[i].K; ct.pose[i] = calls[i].pose_in;
+            outs[i] = calls[i].pose_out;
+        }
+        rc = refine_body(c, &o, 2 * B * S * n, B * n, S, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ct, outs);
     }
-    CoalTab ct;
-    memset(&ct, 0, sizeof(ct));
-    ct.ncall = n; ct.cB = B; ct.cS = S;
-    float *outs[TC_MAX_COAL];
-    for (int i = 0; i < n; i++) {
-        ct.tgt[i] = calls[i].tgt; ct.src[i] = calls[i].srcs; ct.dt[i] = calls[i].dt; ct.ds[i] = calls[i].ds; ct.K[i] = calls[i].K; ct.pose[i] = calls[i].pose_in;
-        outs[i] = calls[i].pose_out;
+    if (c != h) {
+        if (rc) { h->err = c->err; return rc; }
+        HIPCHK(h, hipEventRecord(c->done_ev, c->own_stream));
+        h->coal_dirty |= 1u << l;
     }
-    return refine_body(h, &o, 2 * B * S * n, B * n, S, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ct, outs);
+    return rc;
 }
 
 int tcsfm_set_coalesce(tcsfm_handle h, int max_calls) {
@@ -1695,9 +1729,21 @@ int tcsfm_set_coalesce(tcsfm_handle h, int max_calls) {
     return rc;
 }
 
+int tcsfm_set_coalesce_lanes(tcsfm_handle h, int n_streams) {
+    if (!h) return TCSFM_E_ARG;
+    if (n_streams < 1 || n_streams > (int)h->lanes.size() + 1) return fail(h, TCSFM_E_ARG, "tcsfm_set_coalesce_lanes: 1 <= n_streams <= lanes of the handle (tcsfm_set_lanes)");
+    DeviceGuard dev_guard(h->device);
+    int rc = flush_pending(h);
+    if (!rc) rc = join_coalesce_lanes(h);
+    h->coal_lanes = n_streams;
+    return rc;
+}
+
 int tcsfm_flush(tcsfm_handle h) {
     if (!h) return TCSFM_E_ARG;
-    return flush_pending(h);
+    DeviceGuard dev_guard(h->device);
+    int rc = flush_pending(h);
+    return rc ? rc : join_coalesce_lanes(h);
 }
 
 int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls) {
@@ -1771,7 +1817,11 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
     if (!h) return TCSFM_E_ARG;
     if (n_lanes < 1 || n_lanes > 8) return fail(h, TCSFM_E_ARG, "tcsfm_set_lanes: 1 <= n_lanes <= 8");
     DeviceGuard dev_guard(h->device);
+    if (int rc_ = flush_pending(h)) return rc_;
+    if (int rc_ = join_coalesce_lanes(h)) return rc_;
+    if ((int)h->lanes.size() + 1 > n_lanes) HIPCHK(h, hipStreamSynchronize(h->stream));     // (a lane about to go may still run a merged sequence)
     while ((int)h->lanes.size() + 1 > n_lanes) { tcsfm_destroy(h->lanes.back()); h->lanes.pop_back(); }
+    h->coal_lanes = std::min(h->coal_lanes, n_lanes);
     while ((int)h->lanes.size() + 1 < n_lanes) {
         tcsfm_ctx *c = nullptr;
         int rc = tcsfm_create(&c, h->device, h->H, h->W, h->max_pairs);

@@ -431,6 +431,11 @@ class Engine:
         """tcsfm_set_coalesce: up to `max_calls` queued refine_window_queued calls of one shape run as one launch sequence"""
         self._call(self.lib.tcsfm_set_coalesce(self._h, int(max_calls)))
 
+    def set_coalesce_lanes(self, n_streams: int):
+        """tcsfm_set_coalesce_lanes: merged sequences alternate over `n_streams` of the handle's streams (needs that many lanes);
+        `flush()` / `synchronize()` order the handle's stream behind them"""
+        self._call(self.lib.tcsfm_set_coalesce_lanes(self._h, int(n_streams)))
+
     def refine_window_queued(self, tgt, srcs, depth_t, depth_s, K, pose, pose_out, opts: Opts):
         """tcsfm_refine_window_queued: note a window call (validated contiguous float32 CUDA tensors in the window layout, see
         refine_window); it runs -- merged with the other waiting calls of its shape -- when the queue is full, at flush() or at
