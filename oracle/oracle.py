@@ -301,6 +301,42 @@ class Oracle:
                                       C.c_double(min_depth), C.c_double(max_depth), self._p(poses), self._p(stats), self._p(b))
         return poses, depth_t, stats
 
+    def refine_dense_ref_q(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06,
+                           max_depth=2.67, bits=None):
+        """the same in the reference's parametrisation (optimizer.py:194-198, 235-239: QUARTER-resolution map, upsampled x4 bilinear every
+        linearisation; orc_refine_dense_ref_q) -> (poses, depth_t [B,H,W] = the upsampled map, stats, rho_q [B,H/4,W/4])"""
+        o = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K, poses, S, B, H, W = self._dref_args(tgt, srcs, depth_t, depth_s, K, poses)
+        assert H % 4 == 0 and W % 4 == 0
+        stats = np.zeros((o.n_iters, 7))
+        rq = np.zeros((B, H // 4, W // 4))
+        b, _ = self._forced(bits, None)
+        self.lib.orc_refine_dense_ref_q(C.c_int(H), C.c_int(W), C.c_int(B), C.c_int(S), self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                        self._p(K), C.byref(o), C.c_int(1 if argmin else 0), C.c_double(w_init), C.c_double(lambda_depth),
+                                        C.c_double(min_depth), C.c_double(max_depth), self._p(poses), self._p(stats), self._p(b), self._p(rq))
+        return poses, depth_t, stats, rq
+
+    def up4(self, q):
+        """F.interpolate(q, x4, bilinear, align_corners=False) of one map [h,w] -> [4h,4w] (orc_up4)"""
+        q = np.ascontiguousarray(q, np.float64)
+        out = np.empty((4 * q.shape[0], 4 * q.shape[1]))
+        self.lib.orc_up4(C.c_int(out.shape[0]), C.c_int(out.shape[1]), self._p(q), self._p(out))
+        return out
+
+    def down4(self, full):
+        """F.interpolate(full, (H/4, W/4), bilinear, align_corners=False) of one map (orc_down4)"""
+        full = np.ascontiguousarray(full, np.float64)
+        out = np.empty((full.shape[0] // 4, full.shape[1] // 4))
+        self.lib.orc_down4(C.c_int(full.shape[0]), C.c_int(full.shape[1]), self._p(full), self._p(out))
+        return out
+
+    def up4_adjoint(self, full):
+        """transpose of up4: [H,W] -> [H/4,W/4] (the chain rule from d / d full-resolution map to d / d quarter-resolution map)"""
+        full = np.ascontiguousarray(full, np.float64)
+        out = np.empty((full.shape[0] // 4, full.shape[1] // 4))
+        self.lib.orc_up4_adjoint(C.c_int(full.shape[0]), C.c_int(full.shape[1]), self._p(full), self._p(out))
+        return out
+
     def ground_height(self, depth, K):
         """DNet camera-height map and ground mask of one image (dnet_layers.py:259-304,319-322)"""
         depth, K = self._r(depth), self._r(K)

@@ -2333,6 +2333,161 @@ void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const rea
 }
 
 /* ------------------------------------------------------------------------- */
+/* The reference's PARAMETRISATION of optimize_depth_pred (optimizer.py:194-198, 235-239): the unknown is the QUARTER-resolution      */
+/* sigmoid disparity; every epoch upsamples it x4 (F.interpolate, bilinear, align_corners = False) and converts with disp_to_depth.  */
+/* sigma and rho = 1 / depth are affine in each other and the interpolation weights of a pixel sum to one, so the quarter-resolution  */
+/* inverse depth rho_q with rho = U rho_q is the same parametrisation.                                                                */
+/*
+ * torch's bilinear kernels (aten/native/UpSample.h area_pixel_compute_source_index, align_corners = False):
+ *   upsample x4:   destination x reads source s = max((x + 0.5) / 4 - 0.5, 0): taps i0 = floor(s), i1 = min(i0 + 1, n - 1), weights 1 - l, l = s - i0
+ *   downsample /4: destination i reads source 4 i + 1.5: taps 4 i + 1 and 4 i + 2, weights 1/2 (both axes: the mean of the block's 2 x 2 centre)
+ * pinned on the reference's own F.interpolate outputs (golden G13 `q_sig`, `q_up`).
+ */
+static void up4_taps(int x, int nq, int *i0, int *i1, double *l1) {
+    double s = (x + 0.5) * 0.25 - 0.5;
+    if (s < 0) s = 0;
+    int a = (int)floor(s);
+    *i0 = a; *i1 = a + 1 < nq ? a + 1 : nq - 1; *l1 = s - a;
+}
+void orc_down4(int H, int W, const double *full, double *q) {
+    const int h = H / 4, w = W / 4;
+    for (int cy = 0; cy < h; cy++)
+        for (int cx = 0; cx < w; cx++) {
+            const double *p = full + (size_t)(4 * cy + 1) * W + 4 * cx + 1;
+            q[cy * w + cx] = 0.5 * (0.5 * p[0] + 0.5 * p[1]) + 0.5 * (0.5 * p[W] + 0.5 * p[W + 1]);
+        }
+}
+void orc_up4(int H, int W, const double *q, double *full) {
+    const int h = H / 4, w = W / 4;
+    for (int y = 0; y < H; y++) {
+        int y0, y1; double ly;
+        up4_taps(y, h, &y0, &y1, &ly);
+        for (int x = 0; x < W; x++) {
+            int x0, x1; double lx;
+            up4_taps(x, w, &x0, &x1, &lx);
+            full[y * W + x] = (1 - ly) * ((1 - lx) * q[y0 * w + x0] + lx * q[y0 * w + x1]) + ly * ((1 - lx) * q[y1 * w + x0] + lx * q[y1 * w + x1]);
+        }
+    }
+}
+/* adjoint of orc_up4: q[c] += sum_p U_pc full[p] (q is NOT cleared); stride: `full` holds `stride` values per pixel, `q` per cell */
+static void up4_adjoint(int H, int W, int stride, const double *full, const unsigned char *skip, double *q) {
+    const int h = H / 4, w = W / 4;
+    for (int y = 0; y < H; y++) {
+        int y0, y1; double ly;
+        up4_taps(y, h, &y0, &y1, &ly);
+        for (int x = 0; x < W; x++) {
+            if (skip && skip[y * W + x]) continue;
+            int x0, x1; double lx;
+            up4_taps(x, w, &x0, &x1, &lx);
+            const double wts[4] = {(1 - ly) * (1 - lx), (1 - ly) * lx, ly * (1 - lx), ly * lx};
+            const int cs[4] = {y0 * w + x0, y0 * w + x1, y1 * w + x0, y1 * w + x1};
+            for (int t = 0; t < 4; t++)
+                for (int k = 0; k < stride; k++) q[(size_t)cs[t] * stride + k] += wts[t] * full[(size_t)(y * W + x) * stride + k];
+        }
+    }
+}
+void orc_up4_adjoint(int H, int W, const double *full, double *q) {
+    memset(q, 0, sizeof(double) * (size_t)(H / 4) * (W / 4));
+    up4_adjoint(H, W, 1, full, NULL, q);
+}
+
+/* Gauss-Newton on the reference loss in the reference's parametrisation: unknowns = the poses of all 2 S B pairs and the QUARTER-
+ * resolution inverse depth of every target.  Per linearisation the full-resolution quantities of linearize_dense_ref (gradient g, the
+ * diagonal curvature model D, the pose coupling B of every pixel) are carried to the cells by the chain rule through U:
+ *     g_c = sum_p U_pc g_p  (exact),   B_c = sum_p U_pc B_p  (exact),   D_c = sum_p U_pc D_p
+ * D_c is the row-sum lumping of U' diag(D) U: the rows of U are convex weights, so (sum_c U_pc x_c)^2 <= sum_c U_pc x_c^2 and
+ * diag(D_c) majorises U' diag(D) U -- the cell block stays diagonal and the elimination of the depth stays per cell.  Pixels the
+ * full-resolution mode freezes (sampled across the zero padding, or no curvature) contribute nothing.  The step of a cell goes through
+ * the same trust region as a pixel's (depth_step).  depth_io [B][n] in: the full-resolution input map (its quarter-resolution
+ * projection is the start, as optimizer.py:194-196); out: U rho_q as depth.  depth0: centre of the SSIM prior (the full-resolution
+ * input, optimizer.py:89-90 `self.target_disparity`).  rho_q_out [B][n/16] or NULL. */
+void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
+                            const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                            double *pose_io, double *stats, const unsigned short *bits, double *rho_q_out) {
+    const int n = H * W, SB = S * B, NP = 6 * S, h = H / 4, w = W / 4, nq = h * w;
+    const double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
+    real *ae = (real *)malloc(sizeof(real) * (size_t)2 * SB * n), *d0 = (real *)malloc(sizeof(real) * (size_t)B * n);
+    const real **aep = (const real **)malloc(sizeof(real *) * 2 * SB);
+    double *T = (double *)malloc(sizeof(double) * 24 * SB);
+    double *g_xi = (double *)malloc(sizeof(double) * 12 * SB), *g_rho = (double *)malloc(sizeof(double) * (size_t)B * n);
+    double *Hj = (double *)malloc(sizeof(double) * (size_t)B * NP * NP), *gj = (double *)malloc(sizeof(double) * (size_t)B * NP);
+    double *Dq = (double *)malloc(sizeof(double) * (size_t)B * n), *Bq = (double *)malloc(sizeof(double) * (size_t)B * n * NP);
+    double *Hi = (double *)malloc(sizeof(double) * 36 * SB), *gi = (double *)malloc(sizeof(double) * 6 * SB);
+    double *rq = (double *)malloc(sizeof(double) * (size_t)B * nq), *full = (double *)malloc(sizeof(double) * n);
+    double *pix = (double *)malloc(sizeof(double) * (size_t)n * (NP + 2)), *cell = (double *)malloc(sizeof(double) * (size_t)nq * (NP + 2));
+    unsigned char *skip = (unsigned char *)malloc(n);
+    dref_auto_err(H, W, B, S, tgt, srcs, op, ae, aep);
+    memcpy(d0, depth_io, sizeof(real) * (size_t)B * n);
+    for (int b = 0; b < B; b++) {       /* the start: quarter-resolution projection of the input, upsampled again */
+        for (int i = 0; i < n; i++) full[i] = 1.0 / (double)depth_io[(size_t)b * n + i];
+        orc_down4(H, W, full, rq + (size_t)b * nq);
+        orc_up4(H, W, rq + (size_t)b * nq, full);
+        for (int i = 0; i < n; i++) depth_io[(size_t)b * n + i] = (real)(1.0 / full[i]);
+    }
+    for (int m = 0; m < 2 * SB; m++) orc_pose_to_T(pose_io + 6 * m, T + 12 * m);
+    for (int it = 0; it < op->n_iters; it++) {
+        dref_scal sc;
+        g_lin_idx = bits ? it : -1;
+        /* lambda_depth = infinity: no per-pixel elimination inside -- Hj / gj come back as the pose blocks and pose gradients themselves */
+        linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, INFINITY, T, aep,
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi);
+        g_lin_idx = -1;
+        if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
+        for (int b = 0; b < B; b++) {
+            for (int i = 0; i < n; i++) {
+                const double D = Dq[(size_t)b * n + i];
+                skip[i] = !((1.0 + lambda_depth) * D > 1e-30);
+                pix[(size_t)i * (NP + 2)] = g_rho[(size_t)b * n + i]; pix[(size_t)i * (NP + 2) + 1] = D;
+                for (int j = 0; j < NP; j++) pix[(size_t)i * (NP + 2) + 2 + j] = Bq[((size_t)b * n + i) * NP + j];
+            }
+            memset(cell, 0, sizeof(double) * (size_t)nq * (NP + 2));
+            up4_adjoint(H, W, NP + 2, pix, skip, cell);
+            double A[36 * JMAXS * JMAXS], dl[6 * JMAXS], gs[6 * JMAXS];
+            for (int i = 0; i < NP; i++) {
+                gs[i] = gj[(size_t)b * NP + i];
+                for (int j = 0; j < NP; j++) A[i * NP + j] = Hj[(size_t)b * NP * NP + i * NP + j];
+            }
+            for (int c = 0; c < nq; c++) {
+                const double *q = cell + (size_t)c * (NP + 2), Dd = (1.0 + lambda_depth) * q[1];
+                if (!(Dd > 1e-30)) continue;
+                for (int j = 0; j < NP; j++) {
+                    gs[j] -= q[2 + j] * q[0] / Dd;
+                    for (int k = 0; k < NP; k++) A[j * NP + k] -= q[2 + j] * q[2 + k] / Dd;
+                }
+            }
+            for (int i = 0; i < NP; i++) { A[i * NP + i] += op->lambda0 * A[i * NP + i] + 1e-12; dl[i] = -gs[i]; }
+            if (chol_solve(NP, A, dl)) memset(dl, 0, sizeof(dl));
+            for (int s = 0; s < S; s++) {
+                double E[12], Tn[12];
+                orc_se3_exp(dl + 6 * s, E);
+                orc_se3_mul(E, T + 12 * (s * B + b), Tn);
+                memcpy(T + 12 * (s * B + b), Tn, sizeof(Tn));
+            }
+            for (int c = 0; c < nq; c++) {
+                const double *q = cell + (size_t)c * (NP + 2), Dd = (1.0 + lambda_depth) * q[1];
+                if (!(Dd > 1e-30)) continue;
+                double bd = 0;
+                for (int j = 0; j < NP; j++) bd += q[2 + j] * dl[j];
+                rq[(size_t)b * nq + c] = depth_step(rq[(size_t)b * nq + c], -(q[0] + bd) / Dd, lo, hi);
+            }
+            orc_up4(H, W, rq + (size_t)b * nq, full);
+            for (int i = 0; i < n; i++) depth_io[(size_t)b * n + i] = (real)(1.0 / full[i]);
+        }
+        for (int m = 0; m < SB; m++) {      /* inverse pairs: their own 6 x 6 systems */
+            orc_opts o6 = *op;
+            o6.nparam = 6; o6.param = 0;
+            double Tn[12], sdummy;
+            apply_step(&o6, Hi + 36 * m, gi + 6 * m, op->lambda0, T + 12 * (SB + m), 0.0, Tn, &sdummy);
+            memcpy(T + 12 * (SB + m), Tn, sizeof(Tn));
+        }
+    }
+    for (int m = 0; m < 2 * SB; m++) orc_T_to_pose(T + 12 * m, pose_io + 6 * m);
+    if (rho_q_out) memcpy(rho_q_out, rq, sizeof(double) * (size_t)B * nq);
+    free(ae); free(d0); free(aep); free(T); free(g_xi); free(g_rho); free(Hj); free(gj); free(Dq); free(Bq); free(Hi); free(gi);
+    free(rq); free(full); free(pix); free(cell); free(skip);
+}
+
+/* ------------------------------------------------------------------------- */
 /* DNet ground-plane scale recovery, models/dnet_layers.py:249-327                            */
 
 static void v3_norm(real *v) { /* F.normalize: v / max(|v|, 1e-12) */

@@ -329,6 +329,30 @@ def main():
             loss.backward()
             g13[f"{tag}_loss"] = np.array(loss.item()); g13[f"{tag}_grad_pose"] = N(fp.grad); g13[f"{tag}_grad_sig_t"] = N(sig.grad[:, 0])
             g13[f"{tag}_init_term"] = np.array((0.1 * losses.SSIM_Loss()(T(sig_np, dt), T(sig0_np, dt)).mean()).item())
+        # round 4 (b): the reference's own PARAMETRISATION of optimize_depth_pred (optimizer.py:194-198, 235-239): the leaf is the
+        # QUARTER-resolution sigmoid disparity of every frame (target + sources: F.interpolate of the concatenated maps to (H/4, W/4),
+        # bilinear), every epoch upsamples it x4 (bilinear) and converts with disp_to_depth.  Recorded: the quarter-resolution maps, their
+        # upsampled versions (pins the engine's / the oracle's interpolation weights on torch's), the complete default loss at them and its
+        # autograd gradients w.r.t. the poses and w.r.t. the quarter-resolution maps.
+        F = torch.nn.functional
+        sig_s_np = (1.0 / g13["depth_s"] - 1.0 / MAX_D) / r_d                                  # [S,B,1,H,W]
+        assert sig_s_np.min() > 0.0 and sig_s_np.max() < 1.0
+        full = torch.cat([T(sig_np, dt)] + [T(sig_s_np[i], dt) for i in range(S13)], 1)        # [B, S+1, H, W]
+        quarter = F.interpolate(full, (int(full.shape[2] / 4), int(full.shape[3] / 4)), mode='bilinear').clone().detach()
+        quarter = quarter.requires_grad_()
+        up = F.interpolate(quarter, (int(quarter.shape[2] * 4), int(quarter.shape[3] * 4)), mode='bilinear')
+        dl = [up[:, i:i + 1] for i in range(0, quarter.shape[1])]
+        depths_q = [ref["learning_helpers"].disp_to_depth(d, MIN_D, MAX_D)[1] for d in dl]
+        fp = T(first, dt).clone().requires_grad_()
+        _, _, outputs = ref["train_mono"].solve_pose_iteratively(1, depths_q, LeafPose(fp), T(g13["target"], dt),
+                                                                [T(g13["sources"][i], dt) for i in range(S13)], T(g13["K"], dt), return_errors=True)
+        o = object.__new__(DO)
+        o.options = dict(base_opts, **{'l_inverse_reconstruction': True, 'l_depth_consist': True, 'l_depth_init': True}); o.ssim_loss = losses.SSIM_Loss()
+        o.target_disparity = T(sig0_np, dt)
+        loss = DO.compute_optimization_loss(o, 0, 0, T(g13["target"], dt), dl[0], outputs['fwd'], outputs['inv']).reshape(-1)[0]
+        loss.backward()
+        g13["q_sig"] = N(quarter.detach()); g13["q_up"] = N(up.detach())
+        g13["qinit_loss"] = np.array(loss.item()); g13["qinit_grad_pose"] = N(fp.grad); g13["qinit_grad_q"] = N(quarter.grad)
         out[f"winloss{tagsz}"] = g13
 
     # ------------------------------------------------------------------ G7: loss-surface sweeps (f32, as the reference runs it)

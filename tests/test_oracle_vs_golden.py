@@ -592,3 +592,57 @@ def test_dense_reference_refinement_lowers_the_reference_loss(oracle64):
     # inconsistent -- source maps of this fixture: large changes at a few pixels are the loss's own minimum, the bulk moves by per cents)
     rel = np.abs(d / a[2] - 1)
     assert np.isfinite(p).all() and np.isfinite(d).all() and 0 < np.median(rel) < 0.05 and rel.max() < 1.25 ** 5
+
+
+@pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
+def test_quarter_resolution_parametrisation_vs_reference_G13(name, oracle64):
+    """round 4: the reference's own parametrisation of optimize_depth_pred (optimizer.py:194-198, 235-239) -- the leaf is the QUARTER-
+    resolution sigmoid disparity, upsampled x4 (bilinear) every epoch.  (a) the oracle's down / up-sampling weights are torch's (the
+    fixture holds F.interpolate's outputs); (b) at the upsampled maps the oracle's loss and pose gradients equal the reference's, and
+    its full-resolution depth gradient carried through the TRANSPOSE of the upsampling equals reference autograd w.r.t. the quarter-
+    resolution leaf (golden G13 `qinit`)"""
+    g = load_golden(name)
+    S, B = g["sources"].shape[:2]
+    SB = S * B
+    mind, maxd = (float(x) for x in g["min_max_depth"])
+    rd = 1.0 / mind - 1.0 / maxd
+    sig_full = np.concatenate([g["sig_t"][:, None], np.transpose((1.0 / g["depth_s"][:, :, 0] - 1.0 / maxd) / rd, (1, 0, 2, 3))], 1)    # [B, S+1, H, W]
+    for b in range(B):
+        for c in range(S + 1):
+            assert _maxabs(oracle64.down4(sig_full[b, c]), g["q_sig"][b, c]) < 1e-15
+            assert _maxabs(oracle64.up4(g["q_sig"][b, c]), g["q_up"][b, c]) < 1e-15
+    depth_of = lambda sig: 1.0 / (1.0 / maxd + rd * sig)
+    depth_t = depth_of(g["q_up"][:, 0])
+    depth_s = np.stack([depth_of(g["q_up"][:, 1 + s]) for s in range(S)])
+    op = default_opts(n_iters=1, irls_eps=1e-12, w_dc=0.15)
+    L = oracle64.linearize_dense_ref(g["target"], g["sources"], depth_t, depth_s, g["K"], g["first"], op, argmin=True, w_init=0.1,
+                                     depth0=depth_of(g["sig_t0"]), min_depth=mind, max_depth=maxd)
+    ref_loss = float(g["qinit_loss"])
+    assert abs(L["loss"] - ref_loss) < 1e-12 * ref_loss, (L["loss"], ref_loss)
+    gp = np.stack([oracle64.euler_left_jacobian(g["first"][m]).T @ L["g_xi"][m] for m in range(2 * SB)])
+    assert _maxabs(gp, g["qinit_grad_pose"]) < 1e-10 * np.abs(g["qinit_grad_pose"]).max()
+    gq = np.stack([oracle64.up4_adjoint(L["g_rho"][b] * rd) for b in range(B)])           # d / d sigma_q = U' (r d / d rho)
+    ref = g["qinit_grad_q"][:, 0]
+    assert _maxabs(gq, ref) < 1e-10 * np.abs(ref).max(), (_maxabs(gq, ref), np.abs(ref).max())
+    # (a quarter-resolution cell gathers ~16 pixels' gradients: the chain rule is not a formality at the pin's tolerance)
+    assert np.abs(gq - (L["g_rho"] * rd)[:, 1::4, 1::4]).max() > 0.5 * np.abs(gq).max()
+
+
+def test_quarter_resolution_refinement_lowers_the_reference_loss(oracle64):
+    """Gauss-Newton in the reference's parametrisation (quarter-resolution map, lumped cell curvature): the loss falls from linearisation
+    to linearisation; the returned map IS the x4 upsampling of the returned quarter-resolution unknown; the start is the projection of
+    the input (optimizer.py:194-196), not the input itself"""
+    g = load_golden("winloss48x160")
+    d_in = g["depth_t"][:, 0] * 1.03
+    a = (g["target"], g["sources"], d_in, g["depth_s"][:, :, 0], g["K"], g["first"])
+    o = default_opts(n_iters=5, w_dc=0.15)
+    p, d, st, rq = oracle64.refine_dense_ref_q(*a, o, argmin=True, w_init=0.1, lambda_depth=1.0)
+    assert np.all(np.diff(st[:, 0]) < 0), st[:, 0]
+    assert st[-1, 0] < 0.95 * st[0, 0]
+    for b in range(d.shape[0]):
+        assert _maxabs(1.0 / oracle64.up4(rq[b]), d[b]) < 1e-12
+    p0, d0, st0, rq0 = oracle64.refine_dense_ref_q(*a, default_opts(n_iters=0, w_dc=0.15), argmin=True, w_init=0.1, lambda_depth=1.0)
+    assert _maxabs(rq0[0], oracle64.down4(1.0 / d_in[0])) < 1e-15 and _maxabs(d0, d_in) > 1e-5 and np.allclose(p0, g["first"])
+    # the full-resolution mode reaches a lower loss in the same number of steps (16 x the unknowns); both start from a comparable value
+    pf, df, stf = oracle64.refine_dense_ref(*a, o, argmin=True, w_init=0.1, lambda_depth=1.0)
+    assert stf[-1, 0] < st[-1, 0] and abs(stf[0, 0] - st[0, 0]) < 0.05 * st[0, 0]
