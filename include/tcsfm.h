@@ -67,6 +67,18 @@ enum { TCSFM_REFINE_POSE = 0,        /* 6 DoF                                   
  *              reference's loss depends on config['minibatch']. */
 enum { TCSFM_WINDOW_PAIR = 0, TCSFM_WINDOW_REFERENCE = 1 };
 
+/* the unknown of a target's depth in the dense window mode under TCSFM_WINDOW_REFERENCE:
+ * FULL     one inverse depth per pixel (default).
+ * QUARTER  the reference's own parametrisation of optimize_depth_pred (optimizer.py:194-198, 235-239): the QUARTER-resolution map
+ *          (F.interpolate of the input to (H/4, W/4), bilinear), which every linearisation sees through its x4 bilinear upsampling
+ *          (align_corners = False; sigmoid disparity and inverse depth are affine in each other, so it is the same unknown).  H and W
+ *          must be multiples of 4.  The call starts from the quarter-resolution projection of the input map -- as the reference does --
+ *          and returns the upsampled map; the SSIM prior stays centred on the full-resolution input (`self.target_disparity`, :89-90).
+ *          Gradient: the full-resolution one through the transpose of the upsampling (exact; pinned on reference autograd w.r.t. the
+ *          quarter-resolution leaf, golden G13 `qinit`).  Curvature: every cell gets the row-sum lumping sum_p U_pc D_p of the pixels'
+ *          diagonal model, which majorises U' diag(D) U, so the depth is still eliminated per cell (a 6S x 6S system per target). */
+enum { TCSFM_DEPTH_FULL = 0, TCSFM_DEPTH_QUARTER = 1 };
+
 typedef struct tcsfm_opts {
     int32_t n_iters;       /* linearisations per refine call (BASELINE.json: 4)                         */
     int32_t solver;        /* TCSFM_SOLVER_*                                                             */
@@ -92,6 +104,7 @@ typedef struct tcsfm_opts {
                               copy of the target depth (the round-2 behaviour)                                                  */
     float prior_init;      /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_depth_init_weight'] if options['l_depth_init'] else 0
                               (optimizer.py:89-90): weight of mean SSIM(current, initial sigmoid disparity of the target); default 0.1  */
+    int32_t depth_param;   /* TCSFM_DEPTH_*: dense window mode under TCSFM_WINDOW_REFERENCE (default FULL)                             */
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.

@@ -108,3 +108,76 @@ def test_dense_reference_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
     # the loss the engine reports (forward group + inverse pairs) is the oracle's, and it falls
     assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
     assert np.abs(depth[0, 0] / f32(w["depth_t"])[0] - 1).max() > 1e-3          # the map really moved
+
+
+@pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
+def test_quarter_resolution_gradient_vs_reference_autograd_G13(name, orc):
+    """the reference's PARAMETRISATION (optimizer.py:194-198, 235-239): at the x4-upsampled quarter-resolution maps the engine's loss and
+    pose gradients are the reference's, and its depth gradient carried through the transposed upsampling equals reference autograd w.r.t.
+    the quarter-resolution leaf (golden G13 `qinit`: F.interpolate and loss.backward() of the reference run)"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    g = load_golden(name)
+    S, B = g["sources"].shape[:2]
+    H, W = g["target"].shape[-2:]
+    SB = S * B
+    mind, maxd = (float(x) for x in g["min_max_depth"])
+    rd = 1.0 / mind - 1.0 / maxd
+    depth_of = lambda sig: 1.0 / (1.0 / maxd + rd * sig)
+    e = Engine(H, W, 2 * SB)
+    o = default_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, prior_init=0.1, min_depth=mind, max_depth=maxd)
+    depth_s = np.stack([depth_of(g["q_up"][:, 1 + s]) for s in range(S)])
+    L = e.linearize_dense_window(_dev(g["target"]), _dev(g["sources"]), _dev(depth_of(g["q_up"][:, 0])[:, None]), _dev(depth_s[:, :, None]), _dev(g["K"]),
+                                 _dev(g["first"]), o, argmin=True, depth0=_dev(depth_of(g["sig_t0"])[:, None]))
+    ref_loss = float(g["qinit_loss"])
+    assert abs(L["loss"] - ref_loss) < 1e-5 * ref_loss, (L["loss"], ref_loss)
+    gp = np.stack([orc.euler_left_jacobian(g["first"][m]).T @ L["g_pose"][m] for m in range(2 * SB)])
+    assert np.abs(gp - g["qinit_grad_pose"]).max() < 2e-4 * np.abs(g["qinit_grad_pose"]).max()
+    g_rho = L["g_rho"][:, 0].cpu().numpy().astype(np.float64)
+    gq = np.stack([orc.up4_adjoint(g_rho[b] * rd) for b in range(B)])
+    ref = g["qinit_grad_q"][:, 0]
+    assert np.abs(gq - ref).max() < 2e-4 * np.abs(ref).max(), (np.abs(gq - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("H,W,S,mind,maxd", [(240, 320, 1, 0.03, 3.0), (192, 640, 2, 0.06, 2.67)])
+def test_quarter_resolution_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
+    """depth_param = TCSFM_DEPTH_QUARTER: Gauss-Newton on the quarter-resolution unknown (k_qres_*: projection of the input, x4 upsampling,
+    cell records through the transposed upsampling, lumped cell curvature, per-cell Schur complement) follows orc_refine_dense_ref_q -- poses and
+    every pixel of the returned (upsampled) map within 1e-4, the engine's discrete decisions replayed"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    B, n_it = 1, 3
+    w = _window(B, S, H, W, seed=31)
+    N = 2 * S * B
+    e = Engine(H, W, N)
+    o = default_opts(n_iters=n_it, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE, lambda_depth=1.0,
+                     depth_param=_lib.DEPTH_QUARTER)
+    t = {k: _dev(v) for k, v in w.items()}
+    dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
+    e.trace_begin(n_it, N)
+    pose, depth, st = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    bits, _ = e.trace_end()
+    pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    oo = oracle_opts(n_iters=n_it, w_dc=0.15)
+    orc.flip_stats_reset()
+    po, do, so, rq = orc.refine_dense_ref_q(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=True,
+                                            w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
+    nf, hard = orc.flip_stats(n_it)
+    assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
+    for m in range(N):
+        et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
+        assert et < 1e-4 and er < 1e-4, (m, et, er)
+    for s in range(S):
+        assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
+    assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
+    # the returned map is a x4 upsampling: its quarter-resolution projection upsampled again reproduces it (a full-resolution map would not)
+    back = 1.0 / orc.up4(rq[0])
+    assert np.abs(depth[0, 0] / back - 1).max() < 1e-4 and np.abs(rq[0] - orc.down4(1.0 / f32(w["depth_t"])[0])).max() > 1e-4
+    # full resolution on the same inputs is a different iterate; n_iters = 0 returns the projected-and-upsampled input
+    o0 = default_opts(n_iters=0, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER)
+    _, d0, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o0, stats=True, argmin=True)
+    want0 = 1.0 / orc.up4(orc.down4(1.0 / f32(w["depth_t"])[0]))
+    assert np.abs(d0[0, 0].cpu().numpy().astype(np.float64) / want0 - 1).max() < 1e-5
+    # H or W not a multiple of 4, or the PAIR rule: refused
+    with pytest.raises(RuntimeError):
+        e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, depth_param=_lib.DEPTH_QUARTER), argmin=True)

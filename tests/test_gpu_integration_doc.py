@@ -71,7 +71,8 @@ def test_documented_dense_reference_stub_runs_and_matches_engine():
     config = {'min_depth': 0.06, 'max_depth': 2.67}
     depths = [t["depth_t"][:, None].contiguous()] + [t["depth_s"][s][:, None].contiguous() for s in range(S)]
     pose, depth = ns["refine_window_dense"](t["tgt"], [t["srcs"][s] for s in range(S)], depths, t["K"], t["pose"], options, config, gn_iters=3)
-    o = default_opts(n_iters=3, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE)
+    o = default_opts(n_iters=3, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE,
+                     depth_param=_lib.DEPTH_QUARTER)         # (the stub asks for the reference's quarter-resolution unknown: H, W are multiples of 4)
     rp, rd, _ = Engine(H, W, 2 * S).refine_dense_window(t["tgt"], t["srcs"], depths[0], torch.stack(depths[1:]), t["K"], t["pose"], o, argmin=True)
     torch.cuda.synchronize()
     assert torch.equal(pose, rp) and torch.equal(depth, rd[:1]) and not torch.equal(depth, depths[0])

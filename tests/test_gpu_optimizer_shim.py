@@ -99,9 +99,21 @@ def test_tuple_form_dense_mode_and_legacy_switches():
 
     # optimize_depth_pred (Adam on the disparity maps in the reference) -> pose + per-pixel inverse depth by GN + Schur
     pose_model, depth_model = standins.window_models(w, iters, device="cuda")
-    opt = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True), _config(B, iters), pose_model, depth_model, "09_02")
+    # default unknown = the reference's: the QUARTER-resolution map (optimizer.py:194-198, 235-239), returned upsampled x4
+    optq = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True), _config(B, iters), pose_model, depth_model, "09_02")
+    rq = optq.optimize_window(0, data)
+    def bend(d):          # a x4 bilinear upsampling is LINEAR across pixels 4c+2 .. 4c+5 of a row: second differences of 1/depth at x = 4c+3
+        rho = 1.0 / d.cpu().numpy().astype(np.float64)[:, 0]
+        a, m, c = rho[:, :, 2::4], rho[:, :, 3::4], rho[:, :, 4::4]
+        k = min(a.shape[2], m.shape[2], c.shape[2])
+        return np.abs(a[:, :, :k] - 2 * m[:, :, :k] + c[:, :, :k]).max() / np.abs(rho).max()
+    assert bend(rq["depths_opt"][0]) < 1e-5 and bend(rq["depths_init"][0]) > 1e-4
+    assert np.all(rq["gn_cost"].numpy()[:, 3] < rq["gn_cost"].numpy()[:, 0])
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    opt = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True, depth_param="full"), _config(B, iters), pose_model, depth_model, "09_02")
     r = opt.optimize_window(0, data)                                           # the demo's 11-tuple form
     assert len(r["depths_opt"]) == S + 1 and opt._dense_reference()
+    assert bend(r["depths_opt"][0]) > 1e-4                                      # (the full-resolution unknown is not an upsampling)
     # default: Gauss-Newton on the reference's OWN loss (window rule REFERENCE): the target's map is the unknown ...
     d0, d1 = r["depths_init"][0], r["depths_opt"][0]
     assert d1.shape == d0.shape and torch.isfinite(d1).all() and 1e-6 < float(((d1 - d0).abs() / d0).mean()) < 0.05

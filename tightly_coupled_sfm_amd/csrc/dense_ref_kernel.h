@@ -140,4 +140,150 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The reference's PARAMETRISATION of optimize_depth_pred (optimizer.py:194-198, 235-239; TCSFM_DEPTH_QUARTER): the unknown of a target
+// is its QUARTER-resolution map; every linearisation sees its x4 bilinear upsampling (F.interpolate, align_corners = False).  Inverse
+// depth and sigmoid disparity are affine in each other and the interpolation weights of a pixel sum to one: rho = U rho_q.
+// Mirrors orc_refine_dense_ref_q of the oracle (which is pinned on the reference's F.interpolate outputs and autograd, golden G13 `qinit`).
+//   k_qres_init      rho_q = the /4 bilinear downsampling of the input map (the mean of every 4x4 block's 2x2 centre)
+//   k_qres_upsample  rho = U rho_q -> depth, into every forward pair's depth slot and the inverse pairs' source packs
+//   k_qres_schur     after k_dense_joint (which leaves the pixel records g, D, B and eliminates nothing): one WAVE per cell, one lane per
+//                    pixel of the cell's 8x8 footprint -- g_c = sum U g, D_c = sum U D (the row-sum lumping of U' diag(D) U, which it
+//                    majorises: the cell block stays diagonal), B_c = sum U B -- the cell record, and the cell's Schur terms
+//                    -B_c B_c' / D_c, -B_c g_c / D_c accumulated per workgroup into records k_solve_joint sums beside the tiles'
+//   k_qres_step      rho_q += -(g_c + B_c' dxi) / D_c through the pixels' trust region (depth_step)
+struct QresParams {
+    const float *jrec;        // [B][H*W][JREC] pixel records of k_dense_joint
+    float *qrec;              // [B][nq][JREC] cell records
+    float *rho_q;             // [B][nq]
+    float *jblockrec;         // [B][rec_stride][NACC]: this kernel's records start at rec_first
+    const double *delta;      // [B][6 JMAXS]
+    float *depth;             // [.][H*W] slots of the forward pairs n = s B + b
+    float4 *srcpack_inv;      // packs of the inverse pairs (channel w = the target depth they sample)
+    int *norms_zero;          // the two batch counters, zeroed for the next linearisation (or null)
+    int H, W, B, S, rec_stride, rec_first;
+    float rho_lo, rho_hi;
+};
+constexpr int QRES_CELLS_PER_WG = 64;      // 4 waves x 16 cells
+
+// weight of cell c in the x4 upsampling taps of pixel x (torch area_pixel_compute_source_index, align_corners = False)
+__device__ __forceinline__ float up4_weight(int x, int c, int nq) {
+    float s = ((float)x + 0.5f) * 0.25f - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    const int i0 = (int)s, i1 = i0 + 1 < nq ? i0 + 1 : nq - 1;
+    const float l1 = s - (float)i0;
+    return (i0 == c ? 1.f - l1 : 0.f) + (i1 == c ? l1 : 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_qres_init(QresParams P) {
+    const int h = P.H / 4, w = P.W / 4, nq = h * w;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= nq) return;
+    const int cy = c / w, cx = c - cy * w;
+    const float *d = P.depth + (size_t)b * P.H * P.W + (size_t)(4 * cy + 1) * P.W + 4 * cx + 1;      // slot of forward pair (0, b)
+    P.rho_q[(size_t)b * nq + c] = 0.5f * (0.5f / d[0] + 0.5f / d[1]) + 0.5f * (0.5f / d[P.W] + 0.5f / d[P.W + 1]);
+}
+
+__global__ __launch_bounds__(256) void k_qres_upsample(QresParams P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, hw = P.H * P.W;
+    if (P.norms_zero && idx == 0 && b == 0) { P.norms_zero[0] = 0; P.norms_zero[1] = 0; }
+    if (idx >= hw) return;
+    const int h = P.H / 4, w = P.W / 4;
+    const int v = idx / P.W, u = idx - v * P.W;
+    float sy = ((float)v + 0.5f) * 0.25f - 0.5f, sx = ((float)u + 0.5f) * 0.25f - 0.5f;
+    sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, y1 = y0 + 1 < h ? y0 + 1 : h - 1, x0 = (int)sx, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float *q = P.rho_q + (size_t)b * h * w;
+    const float rho = (1.f - ly) * ((1.f - lx) * q[y0 * w + x0] + lx * q[y0 * w + x1]) + ly * ((1.f - lx) * q[y1 * w + x0] + lx * q[y1 * w + x1]);
+    const float dep = 1.f / rho;
+    for (int s = 0; s < P.S; s++) {
+        P.depth[(size_t)(s * P.B + b) * hw + idx] = dep;
+        P.srcpack_inv[((size_t)(s * P.B + b) * (P.H + 2) + v + 1) * (P.W + 2) + u + 1].w = dep;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_qres_schur(QresParams P) {
+    using JL = JointLayout<NS>;
+    constexpr int NV = 2 + 6 * NS, NE = JL::NHJ + JL::NP, EPL = (NE + 63) / 64;
+    __shared__ float cellv[4][32];
+    __shared__ float wacc[4][EPL * 64];
+    const int h = P.H / 4, w = P.W / 4, nq = h * w;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.y;
+    const int dy = lane >> 3, dx = lane & 7;
+    // this lane's entries of the Schur sums: e < NHJ = the lower-triangle entry (r, c) of the pose block, then the right-hand side's
+    int er[EPL], ec[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; k++) {
+        const int e = lane + 64 * k;
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= e) r++;
+        er[k] = e < JL::NHJ ? r : e - JL::NHJ; ec[k] = e < JL::NHJ ? e - r * (r + 1) / 2 : -1;
+    }
+    float acc[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; k++) acc[k] = 0.f;
+    const int c_first = (blockIdx.x * 4 + wave) * (QRES_CELLS_PER_WG / 4);
+    for (int ci = 0; ci < QRES_CELLS_PER_WG / 4; ci++) {
+        const int c = c_first + ci;
+        if (c >= nq) break;                                  // (wave-uniform)
+        const int cy = c / w, cx = c - cy * w;
+        const int py = 4 * cy - 2 + dy, px = 4 * cx - 2 + dx;
+        float v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; j++) v[j] = 0.f;
+        if (py >= 0 && py < P.H && px >= 0 && px < P.W) {
+            const float wt = up4_weight(py, cy, h) * up4_weight(px, cx, w);
+            const float4 *rt = reinterpret_cast<const float4 *>(P.jrec + ((size_t)b * P.H * P.W + (size_t)py * P.W + px) * JL::JREC);
+            float r[JL::JREC];
+#pragma unroll
+            for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = rt[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
+            if (r[1] > 0.f && wt > 0.f) {                   // (pixels the full-resolution mode freezes contribute nothing)
+#pragma unroll
+                for (int j = 0; j < NV; j++) v[j] = wt * r[j];
+            }
+        }
+        wave_reduce_store<NV>(v, cellv[wave], lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float g = cellv[wave][0], Dd = cellv[wave][1];
+        const bool on = Dd > 1e-30f;
+        const float iD = on ? 1.f / Dd : 0.f;
+        if (lane < JL::JREC) P.qrec[((size_t)b * nq + c) * JL::JREC + lane] = lane == 1 ? (on ? Dd : 0.f) : (lane < NV ? cellv[wave][lane] : 0.f);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+            const int e = lane + 64 * k;
+            if (e < NE) acc[k] -= cellv[wave][2 + er[k]] * (ec[k] >= 0 ? cellv[wave][2 + ec[k]] : g) * iD;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                      // (cellv is rewritten by the next cell)
+    }
+#pragma unroll
+    for (int k = 0; k < EPL; k++) wacc[wave][lane + 64 * k] = acc[k];
+    __syncthreads();
+    float *rec = P.jblockrec + ((size_t)b * P.rec_stride + P.rec_first + blockIdx.x) * JL::NACC;
+    for (int e = tid; e < JL::NACC; e += 256)
+        rec[e] = e < NE ? (wacc[0][e] + wacc[1][e]) + (wacc[2][e] + wacc[3][e]) : 0.f;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_qres_step(QresParams P) {
+    using JL = JointLayout<NS>;
+    const int nq = (P.H / 4) * (P.W / 4);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= nq) return;
+    const float4 *rt = reinterpret_cast<const float4 *>(P.qrec + ((size_t)b * nq + c) * JL::JREC);
+    float r[JL::JREC];
+#pragma unroll
+    for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = rt[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
+    if (!(r[1] > 0.f)) return;
+    float bd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6 * NS; j++) bd += r[2 + j] * (float)P.delta[b * 6 * JMAXS + j];
+    float *q = P.rho_q + (size_t)b * nq + c;
+    *q = depth_step(*q, -(r[0] + bd) / r[1], P.rho_lo, P.rho_hi);
+}
+
 }  // namespace tc

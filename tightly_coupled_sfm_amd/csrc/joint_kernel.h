@@ -47,6 +47,10 @@ struct JointParams {
     float b_dc;              // per-pixel weight of the depth-consistency terms: w_dc / (S B H W) (:83-86)
     float w_init_px;         // per-pixel weight of the SSIM prior between current and initial sigmoid disparity: w_init / (B H W) (:89-90)
     float sig_lo, sig_ir;    // sigmoid disparity = (rho - sig_lo) * sig_ir: 1 / max_depth and 1 / (1 / min_depth - 1 / max_depth)
+    // quarter-resolution parametrisation (TCSFM_DEPTH_QUARTER, dense_ref_kernel.h): the depth is NOT eliminated per pixel here -- the
+    // pixel records go to k_qres_schur, whose workgroup records follow this kernel's in the same per-target array
+    int qres;
+    int rec_stride;          // workgroup records per target in jblockrec (0: the tile count)
 };
 constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums (integer atomics: order-independent)
 
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         }
         const float Dd = (1.f + J.lambda_depth) * D;
         const bool elim = Dd > 1e-30f && !o_pad;         // (dense_kernel.h: pixels sampled across the zero padding keep their depth)
-        iD = elim ? frcp(Dd) : 0.f;
+        iD = (elim && !J.qres) ? frcp(Dd) : 0.f;         // (quarter resolution: eliminated per CELL by k_qres_schur, nothing here)
         jr[0] = g_rho; jr[1] = elim ? Dd : 0.f;
 #pragma unroll
         for (int s = 0; s < NS; s++)
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         acc[JL::OFF_S] += num; acc[JL::OFF_S + 1] = kk;
     }
     __syncthreads();
-    float *myrec = J.jblockrec + ((size_t)b * nblk + bid) * JL::NACC;
+    float *myrec = J.jblockrec + ((size_t)b * (J.rec_stride > 0 ? J.rec_stride : nblk) + bid) * JL::NACC;
     for (int i = tid; i < JL::NACC; i += NT) myrec[i] = acc[i];
     stamp_end(P.stamp, tid);
 }

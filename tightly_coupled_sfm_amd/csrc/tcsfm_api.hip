@@ -102,6 +102,7 @@ struct tcsfm_ctx {
     bool capturing = false;
     // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; };
+    float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
     int coal_max = 0;
     int coal_lanes = 1;                // merged sequences alternate over this many of the handle's streams (tcsfm_set_coalesce_lanes)
     unsigned coal_dirty = 0;           // bit l: lane l ran a merged sequence the handle's stream has not been ordered behind yet
@@ -671,6 +672,15 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * sizeof(long long)));      // (targets <= max_pairs / 2)
         HIPCHK(h, hipMalloc((void **)&h->dref_export, ((n + 1) / 2) * (2 + 6 * JMAXS) * sizeof(double)));
     }
+    // the reference's parametrisation (optimizer.py:194-198, 235-239): quarter-resolution unknown, x4 bilinear upsampling (dense_ref_kernel.h)
+    const bool qres = !ex && o->depth_param == TCSFM_DEPTH_QUARTER;
+    const int nq = (h->H / 4) * (h->W / 4), nqblk = qres ? (nq + QRES_CELLS_PER_WG - 1) / QRES_CELLS_PER_WG : 0;
+    if (qres && !h->qres_rho) {
+        const size_t nb = (n + 1) / 2;
+        HIPCHK(h, hipMalloc((void **)&h->qres_rho, nb * nq * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->qres_rec, nb * nq * JM::JREC * sizeof(float)));
+    }
+    if (qres && nblk + nqblk > h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the couplings are set explicitly below)
@@ -729,6 +739,19 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     Uj.srcpack_inv = h->srcpack + (size_t)SB * (h->H + 2) * (h->W + 2); Uj.W = h->W; Uj.H = h->H;
     const dim3 px_t((unsigned)((hw + 255) / 256), B), px_all((unsigned)((hw + 255) / 256), N);
     hipStream_t st = h->stream;
+    QresParams Q;
+    memset(&Q, 0, sizeof(Q));
+    if (qres) {
+        J.qres = 1; J.rec_stride = nblk + nqblk; Sj.nblk = nblk + nqblk;
+        Q.jrec = h->jrec; Q.qrec = h->qres_rec; Q.rho_q = h->qres_rho; Q.jblockrec = h->jblockrec; Q.delta = h->jdelta; Q.depth = h->depth_work;
+        Q.srcpack_inv = Uj.srcpack_inv; Q.H = h->H; Q.W = h->W; Q.B = B; Q.S = S; Q.rec_stride = nblk + nqblk; Q.rec_first = nblk;
+        Q.rho_lo = Uj.rho_lo; Q.rho_hi = Uj.rho_hi;
+        // the start is the quarter-resolution projection of the input map, upsampled again (optimizer.py:194-196, 235); the prior's centre
+        // stays the full-resolution input (`self.target_disparity`, :89-90)
+        hipLaunchKernelGGL(k_qres_init, dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
+        hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
+        Q.norms_zero = h->dref_norms;
+    }
     // (one stream: running the inverse pairs' linearise + solve on a second stream beside the forward group's, forked behind the scatter and
     // joined after the depth update, was measured SLOWER -- 261 vs 232 us per 240x320 window, 383 vs 361 at 192x640 S=2: the event hops cost
     // more than the ~18 us of overlap they buy)
@@ -750,6 +773,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         ProfScope prof(h, 0);
         if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
         else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+        if (qres) hipLaunchKernelGGL((k_qres_schur<NS>), dim3(nqblk, B), dim3(256), 0, st, Q);
         return TCSFM_OK;
     };
     if (ex) {        // one linearisation, exported
@@ -789,7 +813,10 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         launch_solve(h, Si, SB, 6);
         Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
         hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
-        hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
+        if (qres) {
+            hipLaunchKernelGGL((k_qres_step<NS>), dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
+            hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
+        } else hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
     }
     HIPCHK(h, hipGetLastError());
     if (o->n_iters == 0) {
@@ -820,6 +847,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->lambda_depth = 1.0f; o->prior_depth = 10.0f;
     o->window_rule = TCSFM_WINDOW_PAIR; o->dense_joint = 1;
     o->prior_init = 0.1f;
+    o->depth_param = TCSFM_DEPTH_FULL;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -902,7 +930,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
@@ -1493,6 +1521,8 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (o->w_dc > 0.f && !ref_mode) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth), except under window_rule = TCSFM_WINDOW_REFERENCE");
     if (ref_mode && (win_S > JMAXS || o->solver != TCSFM_SOLVER_GN || !(o->prior_init >= 0.f)))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: window_rule REFERENCE needs S <= 3, the Gauss-Newton solver and prior_init >= 0");
+    if (o->depth_param != TCSFM_DEPTH_FULL && !(o->depth_param == TCSFM_DEPTH_QUARTER && ref_mode && h->H % 4 == 0 && h->W % 4 == 0))
+        return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: depth_param QUARTER needs window_rule = TCSFM_WINDOW_REFERENCE (window form) and H, W multiples of 4");
     if (o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: SE(3) chart only");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
     DeviceGuard dev_guard(h->device);

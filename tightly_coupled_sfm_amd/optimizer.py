@@ -220,6 +220,13 @@ class DepthOptimizer:
         opts = self._opts()
         tgt = stack_imgs[:, 0:3].contiguous(); src = stack_imgs[:, 3:6].contiguous()
         dense = self._refine_mode() == "pose+depth"
+        if dense and self._dense_reference() and self.options.get("depth_param", "quarter") == "quarter":
+            # the reference's own unknown (optimizer.py:194-198, 235-239): the QUARTER-resolution map, upsampled x4 for every evaluation of
+            # the loss (golden G13 `qinit`); options['depth_param'] = 'full': one inverse depth per pixel
+            if H % 4 == 0 and W % 4 == 0:
+                opts.depth_param = _lib.DEPTH_QUARTER
+            else:
+                warnings.warn("depth_param 'quarter' needs H and W to be multiples of 4: refining the full-resolution map instead")
         if dense:
             pose, depth_ref, stats = eng.refine_dense_window(
                 target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
