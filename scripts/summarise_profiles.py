@@ -23,6 +23,13 @@ if ks1:
 kss = glob.glob(os.path.join(src, "trace_sat", "*", "*kernel_stats.csv"))
 if kss:
     shutil.copy(kss[0], os.path.join(dst, f"{tag}_sat_kernel_stats.csv"))
+for sub, name in (("_dref", "dref"), ("_dref_q", "dref_quarter")):       # dense mode on the reference's loss (scripts/collect_r04.sh)
+    kd = glob.glob(os.path.join(root, "gpurun_out", tag + sub, "*", "*kernel_stats.csv"))
+    if kd:
+        shutil.copy(kd[0], os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
+for name in ("dense_ref_timing.jsonl", "bench_modes.jsonl", "seq_cache_timing.jsonl"):
+    if os.path.exists(os.path.join(root, "gpurun_out", f"{tag}_{name}")):
+        shutil.copy(os.path.join(root, "gpurun_out", f"{tag}_{name}"), os.path.join(dst, f"{tag}_{name}"))
 for name in ("bench.json", "bench_k20.json", "meta.json"):      # meta.json: hash of the kernel sources the profiles were collected on
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))

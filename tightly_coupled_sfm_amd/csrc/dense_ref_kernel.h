@@ -165,7 +165,8 @@ struct QresParams {
     int H, W, B, S, rec_stride, rec_first;
     float rho_lo, rho_hi;
 };
-constexpr int QRES_CELLS_PER_WG = 64;      // 4 waves x 16 cells
+constexpr int QRES_CELLS_PER_WG = 16;      // 4 waves x 4 cells: the cells of a wave are loaded together (a first version walked 16 cells per wave
+                                           // one dependent load after the other: 25 us per linearisation at 240x320)
 
 // weight of cell c in the x4 upsampling taps of pixel x (torch area_pixel_compute_source_index, align_corners = False)
 __device__ __forceinline__ float up4_weight(int x, int c, int nq) {
@@ -225,26 +226,30 @@ __global__ __launch_bounds__(256) void k_qres_schur(QresParams P) {
     float acc[EPL];
 #pragma unroll
     for (int k = 0; k < EPL; k++) acc[k] = 0.f;
-    const int c_first = (blockIdx.x * 4 + wave) * (QRES_CELLS_PER_WG / 4);
-    for (int ci = 0; ci < QRES_CELLS_PER_WG / 4; ci++) {
-        const int c = c_first + ci;
-        if (c >= nq) break;                                  // (wave-uniform)
+    constexpr int CPW = QRES_CELLS_PER_WG / 4;
+    const int c_first = (blockIdx.x * 4 + wave) * CPW;
+    // all CPW cells' pixel records are requested before the first is used (unconditional loads from clamped addresses; weight 0 outside)
+    float r[CPW][JL::JREC], wt[CPW];
+#pragma unroll
+    for (int ci = 0; ci < CPW; ci++) {
+        const int c = c_first + ci < nq ? c_first + ci : nq - 1;
         const int cy = c / w, cx = c - cy * w;
         const int py = 4 * cy - 2 + dy, px = 4 * cx - 2 + dx;
+        const bool in = c_first + ci < nq && py >= 0 && py < P.H && px >= 0 && px < P.W;
+        const int qy = py < 0 ? 0 : (py >= P.H ? P.H - 1 : py), qx = px < 0 ? 0 : (px >= P.W ? P.W - 1 : px);
+        wt[ci] = in ? up4_weight(py, cy, h) * up4_weight(px, cx, w) : 0.f;
+        const float4 *rt = reinterpret_cast<const float4 *>(P.jrec + ((size_t)b * P.H * P.W + (size_t)qy * P.W + qx) * JL::JREC);
+#pragma unroll
+        for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = rt[k]; r[ci][4 * k] = q.x; r[ci][4 * k + 1] = q.y; r[ci][4 * k + 2] = q.z; r[ci][4 * k + 3] = q.w; }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CPW; ci++) {
+        const int c = c_first + ci;
+        if (c >= nq) break;                                  // (wave-uniform)
         float v[NV];
+        const float wq = r[ci][1] > 0.f ? wt[ci] : 0.f;       // (pixels the full-resolution mode freezes contribute nothing)
 #pragma unroll
-        for (int j = 0; j < NV; j++) v[j] = 0.f;
-        if (py >= 0 && py < P.H && px >= 0 && px < P.W) {
-            const float wt = up4_weight(py, cy, h) * up4_weight(px, cx, w);
-            const float4 *rt = reinterpret_cast<const float4 *>(P.jrec + ((size_t)b * P.H * P.W + (size_t)py * P.W + px) * JL::JREC);
-            float r[JL::JREC];
-#pragma unroll
-            for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = rt[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
-            if (r[1] > 0.f && wt > 0.f) {                   // (pixels the full-resolution mode freezes contribute nothing)
-#pragma unroll
-                for (int j = 0; j < NV; j++) v[j] = wt * r[j];
-            }
-        }
+        for (int j = 0; j < NV; j++) v[j] = wq * r[ci][j];
         wave_reduce_store<NV>(v, cellv[wave], lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

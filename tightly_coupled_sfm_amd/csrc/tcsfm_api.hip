@@ -498,7 +498,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
         HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JM::NACC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * 2 * h->nblk_alloc * JM::NACC * sizeof(float)));      // (tile records + the quarter-resolution mode's cell-group records)
         HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
         HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
         h->jrec_S = JMAXS;
@@ -662,7 +662,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * h->nblk_alloc * JM::NACC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * 2 * h->nblk_alloc * JM::NACC * sizeof(float)));      // (tile records + the quarter-resolution mode's cell-group records)
         HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
         HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
         h->jrec_S = JMAXS;
@@ -680,7 +680,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->qres_rho, nb * nq * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->qres_rec, nb * nq * JM::JREC * sizeof(float)));
     }
-    if (qres && nblk + nqblk > h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
+    if (qres && nblk + nqblk > 2 * h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the couplings are set explicitly below)
