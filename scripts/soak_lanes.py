@@ -1,4 +1,4 @@
-"""Soak of the round-2 concurrency code: for ~SECONDS, random interleavings of lane calls (pose windows, dense windows), whole-sequence
+"""Soak of the concurrency code (rounds 2-4): for ~SECONDS, random interleavings of lane calls (pose windows, dense windows), whole-sequence
 calls with random lane counts / ring sizes / sources, PoseNet loops and plain calls on ONE handle; every result is compared bit for bit
 with the first result of the same work item, and device memory must not grow."""
 import json, os, sys, time
@@ -18,6 +18,9 @@ init = torch.as_tensor(seq["init"])
 initd = init.cuda()
 o = default_opts(n_iters=3)
 od = default_opts(n_iters=2, min_depth=0.03, max_depth=3.0)
+from tightly_coupled_sfm_amd import _lib
+odr = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE)
+odq = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER)
 e = Engine(H, W, 4, lanes=3)
 ref = {}
 def check(key, val):
@@ -32,7 +35,7 @@ torch.cuda.synchronize()
 mem0 = None
 t0 = time.time(); n = 0
 while time.time() - t0 < SECONDS:
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 6)
     if kind == 0:      # three pose windows in flight
         ws = rng.integers(0, T - 1, size=3)
         for l, w in enumerate(ws):
@@ -56,6 +59,23 @@ while time.time() - t0 < SECONDS:
         out = e.refine_sequence(frames[n0:n1], depths[n0:n1], seq["K"], init[n0:n1 - 1], o, ring=ring, windows_per_call=wpc)
         for w in range(n0, n1 - 1):
             check(("pose", w), [out[w - n0].cuda()])
+    elif kind == 4:    # round 4: queued calls merged by the library, the merged sequences alternating over 1..3 streams of the handle
+        e.set_coalesce(int(rng.choice([2, 3, 5])))          # (the handle holds 4 pairs: sequences of at most two B=1 calls; longer requests are cut)
+        e.set_coalesce_lanes(int(rng.integers(1, 4)))
+        ws = rng.integers(0, T - 1, size=int(rng.integers(1, 8)))
+        outs = [torch.empty(2, 6, device="cuda") for _ in ws]
+        for w, out in zip(ws, outs):
+            e.refine_window_queued(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], out, o)
+        if rng.integers(0, 2):
+            e.flush()
+        e.synchronize()
+        for w, out in zip(ws, outs):
+            check(("pose", int(w)), [out])
+        e.set_coalesce_lanes(1); e.set_coalesce(0)
+    elif kind == 5:    # round 4: dense window on the reference's loss, full- and quarter-resolution unknown
+        w = int(rng.integers(0, T - 1)); q = int(rng.integers(0, 2))
+        p, d, _ = e.refine_dense_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], (odq if q else odr), argmin=True)
+        check(("dref", q, w), [p, d])
     else:              # plain synchronous call on the handle itself
         w = int(rng.integers(0, T - 1))
         p = e.refine_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], o)[0]
