@@ -181,3 +181,37 @@ def test_quarter_resolution_iterates_follow_the_oracle(H, W, S, mind, maxd, orc)
     # H or W not a multiple of 4, or the PAIR rule: refused
     with pytest.raises(RuntimeError):
         e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, depth_param=_lib.DEPTH_QUARTER), argmin=True)
+
+
+@pytest.mark.parametrize("B,S,H,W", [(2, 2, 48, 160), (3, 1, 24, 40), (1, 3, 48, 160)])
+def test_quarter_resolution_batches_and_source_counts(B, S, H, W, orc):
+    """the quarter-resolution unknown with several targets per call (the batch normalisers couple them; every target has its own cells,
+    records and reduced system) and with one / three sources per target: poses and maps follow the oracle"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    n_it = 2
+    w = _window(B, S, H, W, seed=57)
+    N = 2 * S * B
+    e = Engine(H, W, N)
+    o = default_opts(n_iters=n_it, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE, lambda_depth=1.0,
+                     depth_param=_lib.DEPTH_QUARTER)
+    t = {k: _dev(v) for k, v in w.items()}
+    dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
+    e.trace_begin(n_it, N)
+    pose, depth, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    bits, _ = e.trace_end()
+    pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    orc.flip_stats_reset()
+    po, do, so, rq = orc.refine_dense_ref_q(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]),
+                                            oracle_opts(n_iters=n_it, w_dc=0.15), argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06, max_depth=2.67,
+                                            bits=bits.reshape(n_it, N, H * W))
+    nf, hard = orc.flip_stats(n_it)
+    assert hard.sum() == 0, (nf, hard)
+    for m in range(N):
+        et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
+        assert et < 1e-4 and er < 1e-4, (m, et, er)
+    for s in range(S):
+        assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
+    for b in range(B):          # every target's map is the upsampling of ITS cells
+        assert np.abs(depth[b, 0] * orc.up4(rq[b]) - 1).max() < 1e-4
