@@ -105,6 +105,11 @@ typedef struct tcsfm_opts {
     float prior_init;      /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_depth_init_weight'] if options['l_depth_init'] else 0
                               (optimizer.py:89-90): weight of mean SSIM(current, initial sigmoid disparity of the target); default 0.1  */
     int32_t depth_param;   /* TCSFM_DEPTH_*: dense window mode under TCSFM_WINDOW_REFERENCE (default FULL)                             */
+    float w_pose_consist;  /* pose window modes under TCSFM_WINDOW_REFERENCE, 6-DoF Gauss-Newton: 0.1 if options['l_pose_consist'] else 0
+                              (default 0, as the reference's drivers) -- w * mean |p_fwd + p_inv| over the S*B x 6 entries of the
+                              reference's 6-vectors (optimizer.py:95-96).  Every pair gets the exact gradient w.r.t. its own pose (IRLS on
+                              the L1 term, floor irls_eps) and the block-Jacobi majoriser of the curvature, its partner held at the
+                              linearisation point; value and gradient pinned on reference autograd (golden G13 `full_pc`)                */
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.

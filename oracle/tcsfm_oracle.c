@@ -48,6 +48,7 @@ typedef struct {
     double irls_eps;
     double lambda0, lambda_up, lambda_down, lambda_min;
     double prior_scale; /* Tikhonov weight on (log_scale - initial log_scale)^2: fixes the scale/translation gauge of nparam 7 */
+    double w_pose_consist; /* window REFERENCE rule: options['l_pose_consist'] ? 0.1 : 0 -- 0.1 (poses + poses_inv).abs().mean(), optimizer.py:95-96 */
 } orc_opts;
 
 /* ------------------------------------------------------------------------- */
@@ -1106,6 +1107,49 @@ static const lin_ext *window_ext(const win_ctx *c, int m, lin_ext *x) {
     return x;
 }
 
+/* l_pose_consist (optimizer.py:95-96): 0.1 mean |p_fwd + p_inv| over the S B x 6 entries of the reference's 6-vectors.  Pair m sees
+ * c sum_j |r_j| with r = p_m + p_partner, c = w / (6 S B) (half of it is booked as ITS cost, so that the pairs' costs add up to the loss).
+ * Gradient in pose coordinates c r_j / max(|r_j|, eps) (IRLS; = c sign(r_j) away from zero, as autograd); curvature 2 c / max(|r_j|, eps)
+ * on the diagonal -- the factor 2 is the block-Jacobi majoriser (r moves with BOTH poses: (da + db)^2 <= 2 da^2 + 2 db^2; every pair
+ * steps with the partner held at the linearisation point).  Carried to the left perturbation by dp = A^-1 dxi, A = d xi / d pose
+ * (orc_euler_left_jacobian): A = [[-I, -Tx Je], [0, -Je]]  =>  A^-1 = [[-I, Tx], [0, -Je^-1]]. */
+static void pose_consist_term(const double Tm[12], const double Tp[12], double c, double eps, double *cost, double g[6], double H[36]) {
+    double pm[6], pp[6];
+    orc_T_to_pose(Tm, pm); orc_T_to_pose(Tp, pp);
+    const double th[2] = {-pm[3], -pm[4]};
+    const double cx = cos(th[0]), sx = sin(th[0]), cy = cos(th[1]), sy = sin(th[1]);
+    const double Je[9] = {1, 0, sy, 0, cx, -sx * cy, 0, sx, cx * cy};
+    /* inverse of Je (det = cy) by cofactors */
+    const double id = 1.0 / cy;
+    const double Ji[9] = {(Je[4] * Je[8] - Je[5] * Je[7]) * id, -(Je[1] * Je[8] - Je[2] * Je[7]) * id, (Je[1] * Je[5] - Je[2] * Je[4]) * id,
+                          -(Je[3] * Je[8] - Je[5] * Je[6]) * id, (Je[0] * Je[8] - Je[2] * Je[6]) * id, -(Je[0] * Je[5] - Je[2] * Je[3]) * id,
+                          (Je[3] * Je[7] - Je[4] * Je[6]) * id, -(Je[0] * Je[7] - Je[1] * Je[6]) * id, (Je[0] * Je[4] - Je[1] * Je[3]) * id};
+    const double tp[3] = {-pm[0], -pm[1], -pm[2]};
+    const double Tx[9] = {0, -tp[2], tp[1], tp[2], 0, -tp[0], -tp[1], tp[0], 0};
+    double Ai[36];
+    memset(Ai, 0, sizeof(Ai));
+    for (int i = 0; i < 3; i++) {
+        Ai[6 * i + i] = -1;
+        for (int j = 0; j < 3; j++) { Ai[6 * i + 3 + j] = Tx[3 * i + j]; Ai[6 * (3 + i) + 3 + j] = -Ji[3 * i + j]; }
+    }
+    double gp[6], D[6];
+    *cost = 0;
+    for (int j = 0; j < 6; j++) {
+        const double r = pm[j] + pp[j], a = fabs(r), den = a > eps ? a : eps;
+        *cost += 0.5 * c * a;
+        gp[j] = c * r / den; D[j] = 2.0 * c / den;
+    }
+    for (int i = 0; i < 6; i++) {
+        g[i] = 0;
+        for (int k = 0; k < 6; k++) g[i] += Ai[6 * k + i] * gp[k];
+        for (int j = 0; j < 6; j++) {
+            double v = 0;
+            for (int k = 0; k < 6; k++) v += Ai[6 * k + i] * D[k] * Ai[6 * k + j];
+            H[6 * i + j] = v;
+        }
+    }
+}
+
 /* bits [n_lin][2SB][H*W], decide [n_lin][2SB] (layout of the engine's trace): see orc_refine_forced.  With bits bit 0 IS the
  * mask every pair is linearised with; the selection is still evaluated here, for the flip statistics only. */
 void orc_refine_window_rule(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
@@ -1184,6 +1228,15 @@ void orc_refine_window_rule(int H, int W, int B, int S, const real *tgt, const r
                              &tr, NULL, NULL, NULL, NULL, NULL);
             g_force_bits = NULL; g_lin_idx = -1; g_sel_margin = NULL;
             if (np == 7) { tr.cost += prior; tr.g[6] += 2 * pw * (p->stry - p->s0); tr.H[6 * np + 6] += 2 * pw; }
+            if (rule && op->w_pose_consist > 0) {     /* the partner at the start-of-iteration transforms (Tf): every pair steps on its own */
+                double pc, pg[6], pH[36];
+                pose_consist_term(Tf + 12 * m, Tf + 12 * (m < SB ? m + SB : m - SB), op->w_pose_consist / (6.0 * SB), op->irls_eps, &pc, pg, pH);
+                tr.cost += pc;
+                for (int i = 0; i < 6; i++) {
+                    tr.g[i] += pg[i];
+                    for (int j = 0; j < 6; j++) tr.H[i * np + j] += pH[6 * i + j];
+                }
+            }
             if (lin_out) lin_out[m] = tr;
             if (st) { st[0] = tr.cost; st[1] = tr.cost_photo; st[2] = tr.n_mask; st[3] = p->lambda; }
             if (op->solver == 0 || !p->have_cur || (dec ? *dec != 0 : tr.cost < p->cur.cost)) {

@@ -266,7 +266,9 @@ def main():
         for tag, upd in (("fwd", {}), ("fwd_inv", {'l_inverse_reconstruction': True}),
                          ("full", {'l_inverse_reconstruction': True, 'l_depth_consist': True}),
                          ("noargmin_full", {'diff_img_argmin': False, 'l_inverse_reconstruction': True, 'l_depth_consist': True}),
-                         ("noauto_fwd", {'automasking': False}), ("noargmin_fwd", {'diff_img_argmin': False})):
+                         ("noauto_fwd", {'automasking': False}), ("noargmin_fwd", {'diff_img_argmin': False}),
+                         # round 4: + l_pose_consist, 0.1 (poses + poses_inv).abs().mean() (optimizer.py:95-96; off by default in the reference)
+                         ("full_pc", {'l_inverse_reconstruction': True, 'l_depth_consist': True, 'l_pose_consist': True})):
             fp = T(first, dt).clone().requires_grad_()
             d_t = T(g13["depth_t"], dt).clone().requires_grad_()
             d_s = [T(g13["depth_s"][i], dt).clone().requires_grad_() for i in range(S13)]

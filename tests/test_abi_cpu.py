@@ -32,16 +32,16 @@ def test_opts_struct_matches_header(lib):
     o = _lib.default_opts()
     assert (o.n_iters, o.solver, o.param, o.refine, o.automask) == (4, 0, 0, 0, 1)
     assert abs(o.w_l1 - 0.15) < 1e-7 and abs(o.w_ssim - 0.85) < 1e-7 and abs(o.max_depth - 2.67) < 1e-6
-    assert C.sizeof(_lib.Opts) == 8 * 4 + 13 * 4 + 4 * 4          # 8 int32, 13 float, then window_rule / dense_joint (int32) / prior_init (float) / depth_param (int32)
+    assert C.sizeof(_lib.Opts) == 8 * 4 + 13 * 4 + 5 * 4          # 8 int32, 13 float, then window_rule / dense_joint (int32) / prior_init (float) / depth_param (int32) / w_pose_consist (float)
     assert (o.window_rule, o.dense_joint, o.depth_param) == (_lib.WINDOW_PAIR, 1, _lib.DEPTH_FULL) and abs(o.prior_init - 0.1) < 1e-7
     # the header's struct, compiled by the C compiler, has the same size and the same offsets of the last fields
     import subprocess, tempfile, os
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tcsfm.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(tcsfm_opts), offsetof(tcsfm_opts, prior_depth), offsetof(tcsfm_opts, window_rule), offsetof(tcsfm_opts, dense_joint), offsetof(tcsfm_opts, depth_param));return 0;}'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tcsfm.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu", sizeof(tcsfm_opts), offsetof(tcsfm_opts, prior_depth), offsetof(tcsfm_opts, window_rule), offsetof(tcsfm_opts, dense_joint), offsetof(tcsfm_opts, depth_param), offsetof(tcsfm_opts, w_pose_consist));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(REPO, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         got = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
-    assert got == [C.sizeof(_lib.Opts), _lib.Opts.prior_depth.offset, _lib.Opts.window_rule.offset, _lib.Opts.dense_joint.offset, _lib.Opts.depth_param.offset]
+    assert got == [C.sizeof(_lib.Opts), _lib.Opts.prior_depth.offset, _lib.Opts.window_rule.offset, _lib.Opts.dense_joint.offset, _lib.Opts.depth_param.offset, _lib.Opts.w_pose_consist.offset]
     assert lib.tcsfm_algorithmic_bytes_per_pixel(C.byref(o)) == 32
 
 
@@ -178,3 +178,27 @@ def test_engine_set_lanes_updates_attribute():
     src = inspect.getsource(engine.Engine.set_lanes)
     assert "self.lanes = int(n)" in src and src.index("tcsfm_set_lanes") < src.index("self.lanes = int(n)")
     assert "self.lanes" not in inspect.getsource(engine.Engine.graph_replay_counts)
+
+
+def test_shim_maps_the_references_loss_switches_to_opts():
+    """DepthOptimizer._opts(): the reference's option keys select the terms of the engine's cost (no GPU needed: the options struct only)"""
+    import warnings
+    import torch
+    from tightly_coupled_sfm_amd import _lib
+    from tightly_coupled_sfm_amd.optimizer import DepthOptimizer
+    net = torch.nn.Identity()
+    base = {"epochs": 20, "diff_img_argmin": True, "automasking": True, "l_depth_consist": True, "l_depth_consist_weight": 0.15, "l_inverse_reconstruction": True,
+            "num_source_imgs": 2, "mode": "scaled", "optimize_depth_pred": False, "plotting": False}
+    cfg = {"min_depth": 0.06, "max_depth": 2.67, "iterations": 2, "minibatch": 1, "camera_height": 1.65}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # l_pose_consist is a term of the cost now: no "ignored" warning
+        o = DepthOptimizer(dict(base, l_pose_consist=True), cfg, net, net, "09_02")._opts()
+    assert abs(o.w_pose_consist - 0.1) < 1e-7 and o.window_rule == _lib.WINDOW_REFERENCE and abs(o.w_dc - 0.15) < 1e-7
+    assert DepthOptimizer(base, cfg, net, net, "09_02")._opts().w_pose_consist == 0.0
+    with pytest.warns(UserWarning):             # ... except where the engine cannot honour it: the per-pair rule
+        o = DepthOptimizer(dict(base, l_pose_consist=True, window_rule="pair"), cfg, net, net, "09_02")._opts()
+    assert o.w_pose_consist == 0.0
+    with pytest.warns(UserWarning):
+        DepthOptimizer(dict(base, l_smooth=True), cfg, net, net, "09_02")
+    od = DepthOptimizer(dict(base, optimize_depth_pred=True, l_depth_init=True, l_depth_init_weight=0.1), cfg, net, net, "09_02")._opts()
+    assert od.window_rule == _lib.WINDOW_REFERENCE and abs(od.prior_init - 0.1) < 1e-7 and od.w_pose_consist == 0.0

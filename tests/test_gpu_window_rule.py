@@ -19,7 +19,9 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 VARIANTS = (("fwd", dict(w_dc=0.0), True, "fwd"), ("fwd_inv", dict(w_dc=0.0), True, "all"), ("full", dict(w_dc=0.15), True, "all"),
-            ("noargmin_full", dict(w_dc=0.15), False, "all"), ("noauto_fwd", dict(w_dc=0.0, automask=0), True, "fwd"))
+            ("noargmin_full", dict(w_dc=0.15), False, "all"), ("noauto_fwd", dict(w_dc=0.0, automask=0), True, "fwd"),
+            # round 4: + l_pose_consist = 0.1 (poses + poses_inv).abs().mean() (optimizer.py:95-96)
+            ("full_pc", dict(w_dc=0.15, w_pose_consist=0.1), True, "all"))
 
 
 def _t(a):
@@ -73,8 +75,9 @@ def test_window_linearisation_equals_reference_loss_and_autograd_G13(name, oracl
 
 
 @pytest.mark.parametrize("kw,shape", [(dict(w_dc=0.15), (2, 2, 96, 320)), (dict(w_dc=0.15, solver=1, lambda0=1e-3), (2, 2, 96, 320)),
-                                      (dict(w_dc=0.15), (1, 2, 192, 640)), (dict(), (3, 3, 48, 160)), (dict(w_dc=0.15, refine=1, n_iters=3), (1, 2, 96, 320))],
-                         ids=["gn-96x320", "lm-96x320", "kitti-window-192x640", "three-sources", "pose+scale"])
+                                      (dict(w_dc=0.15), (1, 2, 192, 640)), (dict(), (3, 3, 48, 160)), (dict(w_dc=0.15, refine=1, n_iters=3), (1, 2, 96, 320)),
+                                      (dict(w_dc=0.15, w_pose_consist=0.1, n_iters=5), (2, 2, 96, 320))],
+                         ids=["gn-96x320", "lm-96x320", "kitti-window-192x640", "three-sources", "pose+scale", "pose-consistency"])
 def test_reference_rule_iterates_vs_oracle(kw, shape, oracle64):
     """4 iterations under the REFERENCE rule against the float64 oracle with the engine's decisions replayed: poses 1e-4, costs 2e-5,
     decisions bounded at every linearisation; and the reference's loss goes down"""
@@ -92,7 +95,12 @@ def test_reference_rule_iterates_vs_oracle(kw, shape, oracle64):
     tot = r["stats"][:, :nit, 0].sum(0)
     assert tot[-1] < tot[0], tot                                  # the scalar being minimised goes down
     # the rule matters: the per-pair rule from the same start ends elsewhere
-    p0, _, _ = e.refine_window(*(_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first")), default_opts(**kw), argmin=True)
+    kw0 = {k: v for k, v in kw.items() if k != "w_pose_consist"}          # (a term of the REFERENCE rule only)
+    p0, _, _ = e.refine_window(*(_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first")), default_opts(**kw0), argmin=True)
+    if "w_pose_consist" in kw:      # refused outside the REFERENCE rule / with LM / with the scale unknown
+        for bad in (dict(), dict(window_rule=_lib.WINDOW_REFERENCE, solver=1), dict(window_rule=_lib.WINDOW_REFERENCE, refine=1)):
+            with pytest.raises(RuntimeError):
+                e.refine_window(*(_t(w[k]) for k in ("target", "sources", "depth_t", "depth_s", "K", "first")), default_opts(w_pose_consist=0.1, **bad), argmin=True)
     assert np.abs(p0.cpu().numpy()[:S * B] - r["pose"][:S * B]).max() > 1e-7
 
 

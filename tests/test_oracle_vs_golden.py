@@ -279,7 +279,9 @@ def test_window_mode_reduces_to_pair_mode(oracle64):
 
 
 G13_VARIANTS = (("fwd", dict(w_dc=0.0), True, "fwd"), ("fwd_inv", dict(w_dc=0.0), True, "all"), ("full", dict(w_dc=0.15), True, "all"),
-                ("noargmin_full", dict(w_dc=0.15), False, "all"), ("noauto_fwd", dict(w_dc=0.0, automask=0), True, "fwd"))
+                ("noargmin_full", dict(w_dc=0.15), False, "all"), ("noauto_fwd", dict(w_dc=0.0, automask=0), True, "fwd"),
+                # round 4: + l_pose_consist = 0.1 (poses + poses_inv).abs().mean() (optimizer.py:95-96)
+                ("full_pc", dict(w_dc=0.15, w_pose_consist=0.1), True, "all"))
 
 
 @pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
@@ -310,6 +312,23 @@ def test_window_reference_rule_vs_reference_loss_G13(name, oracle64):
     op = default_opts(n_iters=1, irls_eps=1e-12, w_dc=0.15)
     L0 = oracle64.linearize_window(g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"], op, argmin=True, rule=0)
     assert abs(L0["cost"].sum() - float(g["full_loss"])) > 1e-3
+
+
+def test_pose_consistency_term_is_visible_and_lowers_its_loss(oracle64):
+    """l_pose_consist under the REFERENCE rule: the term changes loss and gradients at the pin's tolerance (so the `full_pc` pin above is
+    about the term), its Gauss-Newton iteration lowers the reference's loss WITH the term, and pulls p_fwd + p_inv towards zero"""
+    g = load_golden("winloss24x40")
+    full = (g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"])
+    assert abs(float(g["full_pc_loss"]) - float(g["full_loss"])) > 1e-5 and _maxabs(g["full_pc_grad_pose"], g["full_grad_pose"]) > 1e-3 * np.abs(g["full_grad_pose"]).max()
+    SB = g["sources"].shape[0] * g["sources"].shape[1]
+    o1 = default_opts(n_iters=8, w_dc=0.15, w_pose_consist=0.1)        # (the damped block-Jacobi / IRLS model of the L1 term needs a few more steps than 4)
+    o0 = default_opts(n_iters=8, w_dc=0.15)
+    p1, _, _ = oracle64.refine_window(*full, g["first"], o1, argmin=True, rule=1)
+    p0, _, _ = oracle64.refine_window(*full, g["first"], o0, argmin=True, rule=1)
+    L = lambda p: oracle64.linearize_window(*full, p, o1, argmin=True, rule=1)["cost"].sum()
+    assert L(p1) < L(g["first"]) and L(p1) < L(p0)
+    r = lambda p: np.abs(p[:SB] + p[SB:]).mean()
+    assert r(p1) < r(p0)
 
 
 def test_window_reference_rule_refines_and_reduces(oracle64):

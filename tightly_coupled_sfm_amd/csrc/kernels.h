@@ -323,6 +323,7 @@ struct InitParams {
     float lambda0;
     int K_mod;                          // window form: pair n uses intrinsics K[n % K_mod] (0: one matrix per pair)
     int *err;                           // host-mapped status word: set to 1 when a pair's intrinsics are not pinhole (or null)
+    double *pose_lin;                   // l_pose_consist (or null): [2][N][12] transform of every pair at the linearisation, double-buffered by iteration parity
 };
 
 __device__ inline void init_pair(const InitParams &P, int n, const CoalTab *ct = nullptr) {
@@ -346,6 +347,8 @@ __device__ inline void init_pair(const InitParams &P, int n, const CoalTab *ct =
     }
     pose_to_T(pose, S.Tcur);
     for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
+    if (P.pose_lin)
+        for (int i = 0; i < 12; i++) P.pose_lin[(size_t)n * 12 + i] = S.Tcur[i];          // (iteration 0 reads buffer 0)
     S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
     S.lambda = (double)P.lambda0;
     S.cost_cur = 0.0;
@@ -1509,6 +1512,11 @@ struct SolveParams {
     // mask count summed over ALL forward (n < grp_fwd) or ALL inverse (grp_fwd <= n < n_pairs) pairs of the call, times `scale`
     int rule, grp_fwd, n_pairs;
     double scale_fwd, scale_inv;      // 1 (argmin) or 0.25 (no argmin, :73) / 0.25 (:79)
+    // l_pose_consist (optimizer.py:95-96; window REFERENCE rule, 6-DoF Gauss-Newton): c = weight / (6 S B), 0 = off; the partner of pair n
+    // is n +- grp_fwd; pose_lin [2][n_pairs][12]: every pair's transform at linearisation `it` in buffer it & 1 (written by the pair
+    // initialisation and by the previous launch: a pair never reads what its partner writes in the SAME launch)
+    double w_pc, pc_eps;                // pc_eps: floor of |r| in the IRLS weights (opts.irls_eps)
+    double *pose_lin;
     // coalesced calls (CoalTab): the refined pose of batch pair n goes to ITS call's output, at the pair's index in that call
     int c_ncall, c_B, c_S, c_pad;
     float *c_pose_out[TC_MAX_COAL];
@@ -1550,6 +1558,12 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     // the pair's optimiser state is fetched NOW, together with the partial records, so that the serial phases below never
     // wait on a global load (each first touch used to cost a miss in the middle of the dependent chain)
     if (tid < NST) sst[tid] = reinterpret_cast<const double *>(&P.st[n])[tid];
+    __shared__ double pcT[12], pcA[36], pcD[6], pcG[6];
+    const bool pc_on = NP == 6 && P.rule && P.w_pc > 0.0 && P.pose_lin != nullptr;
+    if (pc_on && tid >= 64 && tid < 76) {
+        const int partner = n < P.grp_fwd ? n + P.grp_fwd : n - P.grp_fwd;
+        pcT[tid - 64] = P.pose_lin[((size_t)(P.it & 1) * P.n_pairs + partner) * 12 + (tid - 64)];
+    }
     __shared__ double kpart[256];
     if (P.rule) {   // batch-summed mask count of this pair's group: every record of every pair of the group, fixed order
         const int g0 = n < P.grp_fwd ? 0 : P.grp_fwd, g1 = n < P.grp_fwd ? P.grp_fwd : P.n_pairs, cnt = (g1 - g0) * P.ngrp;
@@ -1617,6 +1631,51 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         cost += P.prior_scale * ds * ds;
         if (r == 6 && c == 6) M += 2.0 * P.prior_scale;
         if (r == 6 && c == 7) M -= 2.0 * P.prior_scale * ds;
+    }
+    if (pc_on) {
+        // l_pose_consist: c sum_j |p_n + p_partner|_j with both poses at this linearisation; gradient c r / max(|r|, eps) and the
+        // block-Jacobi majoriser 2 c / max(|r|, eps) in pose coordinates, carried to the left perturbation by dp = A^-1 dxi,
+        // A^-1 = [[-I, Tx], [0, -Je^-1]] (oracle pose_consist_term; se3_math.h euler_left_jacobian is A)
+        double pm[6], pp[6];
+        T_to_pose(Lc.Ttry, pm); T_to_pose(pcT, pp);
+        const double cx = cos(-pm[3]), sx = sin(-pm[3]), cy = cos(-pm[4]), sy = sin(-pm[4]);
+        const double Je[9] = {1, 0, sy, 0, cx, -sx * cy, 0, sx, cx * cy};
+        const double id = 1.0 / cy;
+        const double Ji[9] = {(Je[4] * Je[8] - Je[5] * Je[7]) * id, -(Je[1] * Je[8] - Je[2] * Je[7]) * id, (Je[1] * Je[5] - Je[2] * Je[4]) * id,
+                              -(Je[3] * Je[8] - Je[5] * Je[6]) * id, (Je[0] * Je[8] - Je[2] * Je[6]) * id, -(Je[0] * Je[5] - Je[2] * Je[3]) * id,
+                              (Je[3] * Je[7] - Je[4] * Je[6]) * id, -(Je[0] * Je[7] - Je[1] * Je[6]) * id, (Je[0] * Je[4] - Je[1] * Je[3]) * id};
+        const double tp[3] = {-pm[0], -pm[1], -pm[2]};
+        const double Tx[9] = {0, -tp[2], tp[1], tp[2], 0, -tp[0], -tp[1], tp[0], 0};
+        if (tid < 36) {
+            const int i = tid / 6, j = tid - 6 * i;
+            double v = 0.0;
+            if (i < 3 && j < 3) v = (i == j) ? -1.0 : 0.0;
+            else if (i < 3) v = Tx[3 * i + (j - 3)];
+            else if (j >= 3) v = -Ji[3 * (i - 3) + (j - 3)];
+            pcA[tid] = v;
+        }
+        const double eps_pc = P.pc_eps;
+        double pcc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double rj = pm[j] + pp[j], a = fabs(rj), den = a > eps_pc ? a : eps_pc;
+            pcc += 0.5 * P.w_pc * a;
+            if (tid == j) { pcG[j] = P.w_pc * rj / den; pcD[j] = 2.0 * P.w_pc / den; }
+        }
+        cost += pcc;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (r < 6 && c < 6) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += pcA[6 * k + r] * pcD[k] * pcA[6 * k + c];
+            M += v;
+        } else if (r < 6 && c == 7) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += pcA[6 * k + r] * pcG[k];
+            M -= v;
+        }
     }
     if (P.mode == 2) {  // export for tcsfm_linearize / tcsfm_loss_surface
         double *o = P.lin_out + (size_t)n * (NP * NP + NP + 4);
@@ -1710,7 +1769,10 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         TC_STAMP(4)
         const double stry = Ts[36];
         const bool last_gn = (P.solver == 0 && P.it == P.n_iters - 1);   // GN: the last step is always taken
-        if (tid < 12) { const double v = Ts[24 + tid]; S.Ttry[tid] = v; if (last_gn) S.Tcur[tid] = v; }
+        if (tid < 12) {
+            const double v = Ts[24 + tid]; S.Ttry[tid] = v; if (last_gn) S.Tcur[tid] = v;
+            if (P.pose_lin) P.pose_lin[((size_t)((P.it + 1) & 1) * P.n_pairs + n) * 12 + tid] = v;
+        }
         if (tid == 0) { S.stry = stry; if (last_gn) S.scur = stry; }
         write_const_lanes<NP>(tid, Lc.K, Ts + 24, stry, P.pc[n]);
         TC_STAMP(5)

@@ -102,6 +102,7 @@ struct tcsfm_ctx {
     bool capturing = false;
     // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; };
+    double *pose_lin = nullptr;        // l_pose_consist: [2][max_pairs][12] transforms at the linearisation (k_solve, kernels.h)
     float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
     int coal_max = 0;
     int coal_lanes = 1;                // merged sequences alternate over this many of the handle's streams (tcsfm_set_coalesce_lanes)
@@ -201,6 +202,9 @@ int check_common(tcsfm_ctx *h, const tcsfm_opts *o, int N) {
     if (o->n_iters < 0 || o->n_iters > 1000) return fail(h, TCSFM_E_ARG, "opts.n_iters out of range");
     if (o->depth_is_disp && !(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
     if (o->window_rule != TCSFM_WINDOW_PAIR && o->window_rule != TCSFM_WINDOW_REFERENCE) return fail(h, TCSFM_E_ARG, "opts.window_rule unsupported");
+    if (!(o->w_pose_consist >= 0.f) || (o->w_pose_consist > 0.f && (o->window_rule != TCSFM_WINDOW_REFERENCE || o->solver != TCSFM_SOLVER_GN ||
+                                                                   o->refine != TCSFM_REFINE_POSE || o->param != TCSFM_PARAM_SE3)))
+        return fail(h, TCSFM_E_ARG, "opts.w_pose_consist needs window_rule = TCSFM_WINDOW_REFERENCE, the Gauss-Newton solver, TCSFM_REFINE_POSE and the SE(3) chart");
     return TCSFM_OK;
 }
 
@@ -212,6 +216,9 @@ void apply_window_rule(const tcsfm_ctx *h, const tcsfm_opts *o, int win_B, int w
     S.rule = 1; S.grp_fwd = win_B * win_S; S.n_pairs = N;
     S.scale_fwd = o->argmin ? 1.0 : 0.25; S.scale_inv = 0.25;
     S.b_dc = (double)o->w_dc / ((double)win_B * win_S * (double)h->H * (double)h->W);   // :83-86: mean over all S*B maps
+    if (o->w_pose_consist > 0.f) {       // :95-96: 0.1 (poses + poses_inv).abs().mean() over the S B x 6 entries
+        S.w_pc = (double)o->w_pose_consist / (6.0 * win_B * win_S); S.pc_eps = (double)o->irls_eps; S.pose_lin = h->pose_lin;
+    }
 }
 
 // Stage a host array on the device (slot-indexed scratch that grows on demand) or pass a device pointer through.
@@ -381,6 +388,7 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
     I.lambda0 = o->lambda0;
     I.K_mod = 0;
     I.err = h->err_dev;
+    I.pose_lin = (o->window_rule == TCSFM_WINDOW_REFERENCE && o->w_pose_consist > 0.f) ? h->pose_lin : nullptr;
     return I;
 }
 
@@ -848,6 +856,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->window_rule = TCSFM_WINDOW_PAIR; o->dense_joint = 1;
     o->prior_init = 0.1f;
     o->depth_param = TCSFM_DEPTH_FULL;
+    o->w_pose_consist = 0.f;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -893,6 +902,7 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (e == hipSuccess) e = hipMalloc((void **)&h->ls_dev, n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->K_dev, n * 9 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->pair_idx, 2 * n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->pose_lin, 2 * n * 12 * sizeof(double));
     if (e != hipSuccess) {
         g_create_error = std::string("tcsfm_create: ") + hipGetErrorString(e);
         tcsfm_destroy(h);
@@ -930,7 +940,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
@@ -1521,6 +1531,7 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (o->w_dc > 0.f && !ref_mode) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth), except under window_rule = TCSFM_WINDOW_REFERENCE");
     if (ref_mode && (win_S > JMAXS || o->solver != TCSFM_SOLVER_GN || !(o->prior_init >= 0.f)))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: window_rule REFERENCE needs S <= 3, the Gauss-Newton solver and prior_init >= 0");
+    if (o->w_pose_consist > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_pose_consist is a term of the pose modes (tcsfm_refine_window)");
     if (o->depth_param != TCSFM_DEPTH_FULL && !(o->depth_param == TCSFM_DEPTH_QUARTER && ref_mode && h->H % 4 == 0 && h->W % 4 == 0))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: depth_param QUARTER needs window_rule = TCSFM_WINDOW_REFERENCE (window form) and H, W multiples of 4");
     if (o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: SE(3) chart only");

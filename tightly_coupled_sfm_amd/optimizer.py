@@ -97,7 +97,10 @@ class DepthOptimizer:
             if options.get("strict_legacy", False):
                 raise NotImplementedError(msg)
             warnings.warn(msg)
-        ignored = [k for k in ("l_smooth", "l_pose_consist") if options.get(k, False)]
+        # l_pose_consist IS a term of the pose modes under the window rule REFERENCE (opts.w_pose_consist, round 4); elsewhere it is ignored
+        pc_ok = (options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm" and
+                 options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose" and options.get("param", "se3") == "se3")
+        ignored = [k for k in ("l_smooth", "l_pose_consist") if options.get(k, False) and not (k == "l_pose_consist" and pc_ok)]
         if ignored:   # off by default in the reference (run_sequential_optimization.py:87,89); not part of the per-pair GN cost
             warnings.warn(f"options {ignored} are not terms of the Gauss-Newton cost and are ignored "
                           "(losses.get_smooth_loss / compute_optimization_loss still evaluate them for logging)")
@@ -148,7 +151,10 @@ class DepthOptimizer:
             lambda0=float(o.get("lambda0", 1e-4)),
             # this class stands in for the reference's optimiser: by default the scalar it minimises is the reference's
             # compute_optimization_loss itself (optimizer.py:47-86; golden G13); 'pair' = the library's batch-independent default
-            window_rule=_lib.WINDOW_PAIR if o.get("window_rule", "reference") == "pair" else _lib.WINDOW_REFERENCE)
+            window_rule=_lib.WINDOW_PAIR if o.get("window_rule", "reference") == "pair" else _lib.WINDOW_REFERENCE,
+            # optimizer.py:95-96: 0.1 (poses + poses_inv).abs().mean(), a term of the 6-DoF Gauss-Newton pose mode under that rule
+            w_pose_consist=0.1 if (o.get("l_pose_consist", False) and o.get("window_rule", "reference") != "pair" and o.get("solver", "gn") != "lm"
+                                   and self._refine_mode() == "pose" and o.get("param", "se3") == "se3") else 0.0)
 
     def _disparities(self, imgs):
         """depth net forward in the reference's two call forms (optimizer.py:146-147) or a plain callable"""
