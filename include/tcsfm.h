@@ -110,6 +110,11 @@ typedef struct tcsfm_opts {
                               reference's 6-vectors (optimizer.py:95-96).  Every pair gets the exact gradient w.r.t. its own pose (IRLS on
                               the L1 term, floor irls_eps) and the block-Jacobi majoriser of the curvature, its partner held at the
                               linearisation point; value and gradient pinned on reference autograd (golden G13 `full_pc`)                */
+    float w_smooth;        /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_smooth_weight'] if options['l_smooth'] else 0 (default
+                              0, as the reference's drivers) -- w * get_smooth_loss(target disparity, target image) (optimizer.py:92-93,
+                              losses.py:43-61: edge-aware L1 smoothness of the mean-normalised sigmoid disparity).  Exact gradient incl. the
+                              normalisation's per-image constant (one more launch per linearisation: k_dref_smooth); curvature = the diagonal
+                              majoriser of the edges' IRLS weights; pinned on reference autograd (golden G13 `fullinit_smooth`)           */
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.

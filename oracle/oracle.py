@@ -21,7 +21,7 @@ class OrcOpts(C.Structure):
     _fields_ = [("nparam", C.c_int), ("automask", C.c_int), ("param", C.c_int), ("solver", C.c_int),
                 ("n_iters", C.c_int), ("w_l1", C.c_double), ("w_ssim", C.c_double), ("w_dc", C.c_double),
                 ("irls_eps", C.c_double), ("lambda0", C.c_double), ("lambda_up", C.c_double),
-                ("lambda_down", C.c_double), ("lambda_min", C.c_double), ("prior_scale", C.c_double), ("w_pose_consist", C.c_double)]
+                ("lambda_down", C.c_double), ("lambda_min", C.c_double), ("prior_scale", C.c_double), ("w_pose_consist", C.c_double), ("w_smooth", C.c_double)]
 
 
 class LinOut(C.Structure):
@@ -31,7 +31,7 @@ class LinOut(C.Structure):
 
 def default_opts(**kw) -> OrcOpts:
     o = OrcOpts(nparam=6, automask=1, param=0, solver=0, n_iters=4, w_l1=0.15, w_ssim=0.85, w_dc=0.0,
-                irls_eps=1e-3, lambda0=1e-4, lambda_up=10.0, lambda_down=0.1, lambda_min=1e-5, prior_scale=1.0, w_pose_consist=0.0)
+                irls_eps=1e-3, lambda0=1e-4, lambda_up=10.0, lambda_down=0.1, lambda_min=1e-5, prior_scale=1.0, w_pose_consist=0.0, w_smooth=0.0)
     for k, v in kw.items():
         if not hasattr(o, k):
             raise KeyError(k)

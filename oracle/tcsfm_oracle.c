@@ -49,6 +49,7 @@ typedef struct {
     double lambda0, lambda_up, lambda_down, lambda_min;
     double prior_scale; /* Tikhonov weight on (log_scale - initial log_scale)^2: fixes the scale/translation gauge of nparam 7 */
     double w_pose_consist; /* window REFERENCE rule: options['l_pose_consist'] ? 0.1 : 0 -- 0.1 (poses + poses_inv).abs().mean(), optimizer.py:95-96 */
+    double w_smooth;       /* dense mode on the reference's loss: options['l_smooth'] ? options['l_smooth_weight'] : 0 -- get_smooth_loss(target disparity, target image), optimizer.py:92-93 */
 } orc_opts;
 
 /* ------------------------------------------------------------------------- */
@@ -2236,6 +2237,38 @@ static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, con
                         }
                     pri_D[v * W + u] = wp / (rd * rd) * (1.0 / q.d2 + 1.0 / (9.0 * q.d1));
                 }
+        }
+        /* l_smooth (optimizer.py:92-93, losses.py:43-61): w_s [mean_x |dx d^| e^{-|dx I|} + mean_y ...] of the mean-normalised disparity
+         * d^ = sigma / (mean_image(sigma) + 1e-7); the means run over B H (W-1) and B (H-1) W edges.  Per edge e = (i, j) with weight
+         * c_e:  d/d sigma_p  c_e |d^_i - d^_j|  =  c_e s_e (delta_ip - delta_jp) / m  -  c_e |d^_i - d^_j| / (m HW): a local part and a
+         * per-image constant -T_b / (m HW), T_b = the image's whole term.  Curvature: the local part's IRLS weights c_e / (m^2 max(|d^_i -
+         * d^_j|, eps)), as the diagonal majoriser 2 x (an edge moves with both ends); the normalisation's part is gradient-only. */
+        if (op->w_smooth > 0) {
+            const real *img = tgt + (size_t)b * 3 * n;
+            double mu = 0;
+            for (int i = 0; i < n; i++) {
+                sig[i] = (real)((1.0 / (double)depth_t[(size_t)b * n + i] - mind) / rd);
+                mu += sig[i];
+            }
+            const double m = mu / n + 1e-7, cx = op->w_smooth / ((double)B * H * (W - 1)), cy = op->w_smooth / ((double)B * (H - 1) * W), eps_s = op->irls_eps;
+            double Tb = 0;
+            for (int v = 0; v < H; v++)
+                for (int u = 0; u < W; u++)
+                    for (int dir = 0; dir < 2; dir++) {
+                        if (dir == 0 ? u + 1 >= W : v + 1 >= H) continue;
+                        const int i = v * W + u, j = dir == 0 ? i + 1 : i + W;
+                        double gi_ = 0;
+                        for (int ch = 0; ch < 3; ch++) gi_ += fabs((double)img[(size_t)ch * n + i] - (double)img[(size_t)ch * n + j]);
+                        const double ce = (dir == 0 ? cx : cy) * exp(-gi_ / 3.0);
+                        const double dd_ = ((double)sig[i] - (double)sig[j]) / m, ad = fabs(dd_), den = ad > eps_s ? ad : eps_s;
+                        Tb += ce * ad;
+                        const double gl = ce * dd_ / den / m;                 /* = c_e s_e / m away from zero */
+                        pri_g[i] += gl / rd; pri_g[j] -= gl / rd;
+                        const double dl = 2.0 * ce / (m * m * den) / (rd * rd);
+                        pri_D[i] += dl; pri_D[j] += dl;
+                    }
+            for (int i = 0; i < n; i++) pri_g[i] -= Tb / (m * n) / rd;
+            sc->L_init += Tb;                                       /* (booked with the prior: both are terms on the map alone) */
         }
         /* assemble */
         for (int i = 0; i < n; i++) {

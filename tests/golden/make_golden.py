@@ -317,7 +317,9 @@ def main():
         sig0_np = sig_np * (1.0 + 0.04 * np.cos(xx / 3.0 + 0.7 * yy)[None, None] + 0.02 * np.sin(yy / 2.0)[None, None])   # the "initial" map
         g13["sig_t"] = sig_np[:, 0]; g13["sig_t0"] = sig0_np[:, 0]; g13["min_max_depth"] = np.array([MIN_D, MAX_D])
         for tag, upd in (("fullinit", {'l_inverse_reconstruction': True, 'l_depth_consist': True, 'l_depth_init': True}),
-                         ("fwdinit", {'l_depth_init': True})):
+                         ("fwdinit", {'l_depth_init': True}),
+                         # round 4: + l_smooth, l_smooth_weight (2) x get_smooth_loss(target disparity, target image) (optimizer.py:92-93; off by default)
+                         ("fullinit_smooth", {'l_inverse_reconstruction': True, 'l_depth_consist': True, 'l_depth_init': True, 'l_smooth': True})):
             fp = T(first, dt).clone().requires_grad_()
             sig = T(sig_np, dt).clone().requires_grad_()
             d_t = ref["learning_helpers"].disp_to_depth(sig, MIN_D, MAX_D)[1]

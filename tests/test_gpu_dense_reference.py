@@ -34,8 +34,9 @@ def test_linearize_dense_window_vs_reference_autograd_G13(name, orc):
     rd = 1.0 / mind - 1.0 / maxd
     e = Engine(H, W, 2 * SB)
     t = dict(tgt=_dev(g["target"]), srcs=_dev(g["sources"]), depth_t=_dev(g["depth_t"]), depth_s=_dev(g["depth_s"]), K=_dev(g["K"]), pose=_dev(g["first"]))
-    for tag, argmin, w_init in (("full", True, 0.0), ("noargmin_full", False, 0.0), ("fullinit", True, 0.1)):
-        o = default_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, prior_init=w_init, min_depth=mind, max_depth=maxd)
+    for tag, argmin, w_init in (("full", True, 0.0), ("noargmin_full", False, 0.0), ("fullinit", True, 0.1), ("fullinit_smooth", True, 0.1)):
+        w_smooth = 2.0 if tag == "fullinit_smooth" else 0.0          # l_smooth_weight x get_smooth_loss (optimizer.py:92-93)
+        o = default_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, prior_init=w_init, min_depth=mind, max_depth=maxd, w_smooth=w_smooth)
         d0 = None if w_init == 0 else 1.0 / (1.0 / maxd + rd * g["sig_t0"])          # the golden's "initial" disparity as the prior's centre
         L = e.linearize_dense_window(t["tgt"], t["srcs"], t["depth_t"], t["depth_s"], t["K"], t["pose"], o, argmin=argmin,
                                      depth0=None if d0 is None else _dev(d0[:, None]))
@@ -48,11 +49,11 @@ def test_linearize_dense_window_vs_reference_autograd_G13(name, orc):
         if tag == "full":            # d / d depth = -rho^2 d / d rho
             gd, ref = -g_rho / g["depth_t"][:, 0] ** 2, g["full_grad_depth_t"]
             assert np.abs(gd - ref).max() < 2e-4 * np.abs(ref).max(), (tag, np.abs(gd - ref).max(), np.abs(ref).max())
-        if tag == "fullinit":        # d / d sigma = r d / d rho: the whole loss incl. the SSIM prior, through the shared depth
-            gs, ref = g_rho * rd, g["fullinit_grad_sig_t"]
+        if tag in ("fullinit", "fullinit_smooth"):        # d / d sigma = r d / d rho: the whole loss incl. the SSIM prior (and l_smooth), through the shared depth
+            gs, ref = g_rho * rd, g[f"{tag}_grad_sig_t"]
             assert np.abs(gs - ref).max() < 2e-4 * np.abs(ref).max(), (tag, np.abs(gs - ref).max(), np.abs(ref).max())
         # the engine against the oracle's restatement at the same point (float64, pinned to 1e-10 on the same goldens)
-        oo = oracle_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7)
+        oo = oracle_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, w_smooth=w_smooth)
         Lo = orc.linearize_dense_ref(g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"], oo, argmin=argmin,
                                      w_init=w_init, depth0=d0, min_depth=mind, max_depth=maxd)
         assert abs(L["loss"] - Lo["loss"]) < 1e-5 * Lo["loss"] and L["K_f"] == Lo["K_f"] and L["K_i"] == Lo["K_i"]
@@ -215,3 +216,40 @@ def test_quarter_resolution_batches_and_source_counts(B, S, H, W, orc):
         assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
     for b in range(B):          # every target's map is the upsampling of ITS cells
         assert np.abs(depth[b, 0] * orc.up4(rq[b]) - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize("quarter", [False, True], ids=["full-resolution", "quarter-resolution"])
+def test_dense_reference_with_smoothness_term_follows_the_oracle(quarter, orc):
+    """l_smooth as a cost term (opts.w_smooth; optimizer.py:92-93): the iterates with the term follow the oracle, with the per-pixel and with
+    the quarter-resolution unknown; the term changes the result; outside the reference-loss mode it is refused"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    B, S, H, W, n_it = 2, 2, 48, 160, 3
+    w = _window(B, S, H, W, seed=77)
+    N = 2 * S * B
+    e = Engine(H, W, N)
+    kw = dict(n_iters=n_it, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE, lambda_depth=1.0,
+              depth_param=_lib.DEPTH_QUARTER if quarter else _lib.DEPTH_FULL)
+    t = {k: _dev(v) for k, v in w.items()}
+    dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
+    e.trace_begin(n_it, N)
+    pose, depth, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(w_smooth=2.0, **kw), stats=True, argmin=True)
+    bits, _ = e.trace_end()
+    pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    orc.flip_stats_reset()
+    fn = orc.refine_dense_ref_q if quarter else orc.refine_dense_ref
+    res = fn(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oracle_opts(n_iters=n_it, w_dc=0.15, w_smooth=2.0),
+             argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06, max_depth=2.67, bits=bits.reshape(n_it, N, H * W))
+    po, do, so = res[0], res[1], res[2]
+    nf, hard = orc.flip_stats(n_it)
+    assert hard.sum() == 0, (nf, hard)
+    for m in range(N):
+        et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
+        assert et < 1e-4 and er < 1e-4, (m, et, er)
+    assert np.abs(depth[:B, 0] / do - 1).max() < 1e-4, np.abs(depth[:B, 0] / do - 1).max()
+    assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
+    _, d_plain, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(**kw), stats=True, argmin=True)
+    assert np.abs(d_plain[:B, 0].cpu().numpy() / depth[:B, 0] - 1).max() > 1e-4          # the term moves the map
+    with pytest.raises(RuntimeError):
+        e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, w_smooth=2.0), argmin=True)

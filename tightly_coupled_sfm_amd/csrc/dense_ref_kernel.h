@@ -141,6 +141,52 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
 }
 
 
+// l_smooth prepass (optimizer.py:92-93; losses.py:43-61 get_smooth_loss): per target the mean of its sigmoid disparity and the value of its
+// whole term  T_b = (1 / m) [w_x sum_x-edges e^{-|dI|} |d sigma| + w_y sum_y-edges ...],  m = mean + 1e-7 -- the joint kernel needs both
+// before it can form the term's gradient (the mean-normalisation couples every pixel of the image to every edge).  One workgroup per
+// target, fp64 accumulation, fixed-order tree: bit-reproducible.
+struct DrefSmoothParams {
+    const float *depth;       // [.][H*W]: slot b = the target's current map
+    const float4 *tgtpack;    // [.][H*W]: slot b = the target's colours (forward pair (0, b))
+    float *out;               // [B][2]: m, T_b
+    int H, W;
+    float sig_lo, sig_ir, wx, wy;
+};
+__global__ __launch_bounds__(1024) void k_dref_smooth(DrefSmoothParams P) {
+    const int b = blockIdx.x, tid = threadIdx.x, hw = P.H * P.W;
+    const float *d = P.depth + (size_t)b * hw;
+    const float4 *t = P.tgtpack + (size_t)b * hw;
+    __shared__ double r0[1024], r1[1024], r2[1024];
+    double s = 0.0, sx = 0.0, sy = 0.0;
+    for (int i = tid; i < hw; i += 1024) {
+        const int v = i / P.W, u = i - v * P.W;
+        const float sg = (frcp(d[i]) - P.sig_lo) * P.sig_ir;
+        const float4 c = t[i];
+        s += (double)sg;
+        if (u + 1 < P.W) {
+            const float4 q = t[i + 1];
+            const float gi_ = (fabsf(c.x - q.x) + fabsf(c.y - q.y) + fabsf(c.z - q.z)) * (1.f / 3.f);
+            sx += (double)(__expf(-gi_) * fabsf(sg - (frcp(d[i + 1]) - P.sig_lo) * P.sig_ir));
+        }
+        if (v + 1 < P.H) {
+            const float4 q = t[i + P.W];
+            const float gi_ = (fabsf(c.x - q.x) + fabsf(c.y - q.y) + fabsf(c.z - q.z)) * (1.f / 3.f);
+            sy += (double)(__expf(-gi_) * fabsf(sg - (frcp(d[i + P.W]) - P.sig_lo) * P.sig_ir));
+        }
+    }
+    r0[tid] = s; r1[tid] = sx; r2[tid] = sy;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { r0[tid] += r0[tid + o]; r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double m = r0[0] / (double)hw + 1e-7;
+        P.out[2 * b] = (float)m;
+        P.out[2 * b + 1] = (float)(((double)P.wx * r1[0] + (double)P.wy * r2[0]) / m);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The reference's PARAMETRISATION of optimize_depth_pred (optimizer.py:194-198, 235-239; TCSFM_DEPTH_QUARTER): the unknown of a target
 // is its QUARTER-resolution map; every linearisation sees its x4 bilinear upsampling (F.interpolate, align_corners = False).  Inverse

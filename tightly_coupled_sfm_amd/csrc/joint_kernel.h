@@ -51,6 +51,9 @@ struct JointParams {
     // pixel records go to k_qres_schur, whose workgroup records follow this kernel's in the same per-target array
     int qres;
     int rec_stride;          // workgroup records per target in jblockrec (0: the tile count)
+    // l_smooth (optimizer.py:92-93, losses.py:43-61): edge-aware smoothness of the mean-normalised sigmoid disparity of the target
+    const float *smooth;     // [B][2] per target: m = mean(sigma) + 1e-7 and T_b = the target's whole term (k_dref_smooth), or null
+    float w_smooth_x, w_smooth_y;      // weight / (B H (W-1)), weight / (B (H-1) W); 0: off
 };
 constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums (integer atomics: order-independent)
 
@@ -94,6 +97,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     }
     const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
     const bool ref_prior = REF && J.w_init_px > 0.f;
+    const bool ref_smooth = REF && J.smooth != nullptr && (J.w_smooth_x > 0.f || J.w_smooth_y > 0.f);
+    const bool ref_sig = ref_prior || ref_smooth;          // (sigma, sigma0) staged on tile + 2-pixel halo
 
     const int nblk = P.tiles_x * P.tiles_y;
     int bid = blockIdx.x;
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     float extra_cost = 0.f;                                // REF: depth-consistency and prior cost of this pixel (units of a_f)
     float o_sig = 0.f, o_sig0 = 0.f, o_pd1 = 1.f, o_pd2 = 1.f;   // REF prior: own sigmoid disparities and SSIM denominators
     bool o_pcl = true;                                     // REF prior: SSIM value clamped (no gradient / curvature)
+    float o_sm_g = 0.f, o_sm_D = 0.f;                      // REF l_smooth: local gradient / diagonal curvature of this pixel w.r.t. sigma (true units)
 
     constexpr int NRING = N2 - NCEN;
     static_assert(NRING <= NT, "one ring round");
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             S.px = refl_idx(x00 + S.lx - 2, W); S.py = refl_idx(y00 + S.ly - 2, H);
             const int gi = S.py * W + S.px;
             S.tp = tgtpack[gi]; S.dep = depth_t[gi];
-            S.dep0 = (REF && ref_prior && s == 0) ? J.depth0[(size_t)b * hw + gi] : 1.f;
+            S.dep0 = (REF && ref_sig && s == 0) ? J.depth0[(size_t)b * hw + gi] : 1.f;
         };
         auto s_warp = [&](Stage &S) {
             warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 if (REF && ref_w0) {            // the same thread stages the same position for every source: no barrier needed
                     if (s == 0) w0[S.ly * W2 + S.lx] = Wt; else Wuse = w0[S.ly * W2 + S.lx];
                 }
-                if (REF && ref_prior && s == 0) {
+                if (REF && ref_sig && s == 0) {
                     sgq[2 * (S.ly * W2 + S.lx)] = (frcp(S.dep) - J.sig_lo) * J.sig_ir;
                     sgq[2 * (S.ly * W2 + S.lx) + 1] = (frcp(S.dep0) - J.sig_lo) * J.sig_ir;
                 }
@@ -308,6 +314,28 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                     if (real) extra_cost += r_init * clamp01(raw);
                 }
             }
+            if (REF && ref_smooth && s == 0 && r == 0 && real) {
+                // l_smooth at the own pixel: for each of its (up to four) edges  c_e |d^_p - d^_q|,  d^ = sigma / m:  local gradient
+                // c_e ((sigma_p - sigma_q) / m) / max(|.|, eps) / m  and the diagonal majoriser 2 c_e / (m^2 max(|.|, eps)); the per-image
+                // constant of the normalisation is added after the sources (oracle: linearize_dense_ref)
+                const float m_ = J.smooth[2 * b], im = frcp(m_);
+                const int q0 = (ly + 1) * W2 + lx + 1;
+                const float sp = sgq[2 * q0];
+                const float4 c0 = rec1[q0 * 3], c2 = rec1[q0 * 3 + 2];
+                const int dq[4] = {1, -1, W2, -W2};
+                const bool ok4[4] = {gx_ + 1 < W, gx_ >= 1, gy_ + 1 < H, gy_ >= 1};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int q = q0 + dq[e];
+                    const float4 n0 = rec1[q * 3], n2 = rec1[q * 3 + 2];
+                    const float gi_ = (fabsf(c0.z - n0.z) + fabsf(c0.w - n0.w) + fabsf(c2.y - n2.y)) * (1.f / 3.f);
+                    const float ce = (e < 2 ? J.w_smooth_x : J.w_smooth_y) * __expf(-gi_);
+                    const float dd_ = (sp - sgq[2 * q]) * im, den = fmaxf(fabsf(dd_), P.eps);
+                    const float t_ = ok4[e] ? ce * frcp(den) * im : 0.f;
+                    o_sm_g += t_ * dd_;
+                    o_sm_D += 2.f * t_ * im;
+                }
+            }
             float4 *cr = coef + (ly * W1 + lx) * 3;
             lds_write1(cr + 0, w * cA[0], w * cA[1], w * cA[2], w * cB[0]);
             lds_write1(cr + 1, w * cB[1], w * cB[2], w * cC[0], w * cC[1]);
@@ -415,6 +443,13 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 const float pl = sP[0] + sP[1] * (o_sig - 0.5f) + sP[2] * (o_sig0 - 0.5f);
                 g_rho += r_init * J.sig_ir * pl;
                 if (!o_pcl) Dsum += r_init * J.sig_ir * J.sig_ir * (frcp(o_pd2) + (1.f / 9.f) * frcp(o_pd1));
+            }
+            if (REF && ref_smooth && s == 0) {     // l_smooth: local part minus the per-image constant T_b / (m HW), in units of a_f
+                const float iaf_s = (float)J.norms[0] > 0.f ? (float)J.norms[0] / J.c_f : 0.f;
+                const float m_ = J.smooth[2 * b], Gb = J.smooth[2 * b + 1] * frcp(m_ * (float)hw);
+                g_rho += iaf_s * J.sig_ir * (o_sm_g - Gb);
+                Dsum += iaf_s * J.sig_ir * J.sig_ir * o_sm_D;
+                if (bid == 0 && tid == 0) extra_cost += iaf_s * J.smooth[2 * b + 1];       // the term's value, booked once per target
             }
             // B_s goes straight into the pixel's record (read back for the Schur terms below and by the back-substitution)
             jr[2 + 6 * s + 0] = Bq[0]; jr[2 + 6 * s + 1] = Bq[1]; jr[2 + 6 * s + 2] = Bq[2];

@@ -102,6 +102,7 @@ struct tcsfm_ctx {
     bool capturing = false;
     // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; };
+    float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
     double *pose_lin = nullptr;        // l_pose_consist: [2][max_pairs][12] transforms at the linearisation (k_solve, kernels.h)
     float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
     int coal_max = 0;
@@ -679,6 +680,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->dref_norms, 4 * sizeof(int)));
         HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * sizeof(long long)));      // (targets <= max_pairs / 2)
         HIPCHK(h, hipMalloc((void **)&h->dref_export, ((n + 1) / 2) * (2 + 6 * JMAXS) * sizeof(double)));
+        HIPCHK(h, hipMalloc((void **)&h->dref_smooth, ((n + 1) / 2) * 2 * sizeof(float)));
     }
     // the reference's parametrisation (optimizer.py:194-198, 235-239): quarter-resolution unknown, x4 bilinear upsampling (dense_ref_kernel.h)
     const bool qres = !ex && o->depth_param == TCSFM_DEPTH_QUARTER;
@@ -734,6 +736,15 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     J.norms = h->dref_norms; J.ext = h->dref_ext; J.c_f = o->argmin ? 1.f : 0.25f;
     J.b_dc = o->w_dc / ((float)SB * (float)hw); J.w_init_px = o->prior_init / ((float)B * (float)hw);
     J.sig_lo = 1.f / o->max_depth; J.sig_ir = 1.f / (1.f / o->min_depth - 1.f / o->max_depth);
+    DrefSmoothParams Ds;
+    memset(&Ds, 0, sizeof(Ds));
+    const bool smooth = o->w_smooth > 0.f && h->H > 1 && h->W > 1;
+    if (smooth) {       // optimizer.py:92-93: l_smooth_weight x [mean over B H (W-1) x-edges + mean over B (H-1) W y-edges]
+        J.smooth = h->dref_smooth;
+        J.w_smooth_x = o->w_smooth / ((float)B * (float)h->H * (float)(h->W - 1)); J.w_smooth_y = o->w_smooth / ((float)B * (float)(h->H - 1) * (float)h->W);
+        Ds.depth = h->depth_work; Ds.tgtpack = h->tgtpack; Ds.out = h->dref_smooth; Ds.H = h->H; Ds.W = h->W;
+        Ds.sig_lo = J.sig_lo; Ds.sig_ir = J.sig_ir; Ds.wx = J.w_smooth_x; Ds.wy = J.w_smooth_y;
+    }
     JointSolveParams Sj;
     memset(&Sj, 0, sizeof(Sj));
     Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
@@ -777,6 +788,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         launch_lin(h, Pi, SB, 6, dc, MODE_LIN, 2);
         Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
+        if (smooth) hipLaunchKernelGGL(k_dref_smooth, dim3(B), dim3(1024), 0, st, Ds);
         take_stamp(h, Pj, (size_t)nblk * B);
         ProfScope prof(h, 0);
         if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
@@ -857,6 +869,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->prior_init = 0.1f;
     o->depth_param = TCSFM_DEPTH_FULL;
     o->w_pose_consist = 0.f;
+    o->w_smooth = 0.f;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -940,7 +953,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
@@ -1532,6 +1545,8 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (ref_mode && (win_S > JMAXS || o->solver != TCSFM_SOLVER_GN || !(o->prior_init >= 0.f)))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: window_rule REFERENCE needs S <= 3, the Gauss-Newton solver and prior_init >= 0");
     if (o->w_pose_consist > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_pose_consist is a term of the pose modes (tcsfm_refine_window)");
+    if (!(o->w_smooth >= 0.f) || (o->w_smooth > 0.f && !ref_mode))
+        return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_smooth needs the window form under window_rule = TCSFM_WINDOW_REFERENCE");
     if (o->depth_param != TCSFM_DEPTH_FULL && !(o->depth_param == TCSFM_DEPTH_QUARTER && ref_mode && h->H % 4 == 0 && h->W % 4 == 0))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: depth_param QUARTER needs window_rule = TCSFM_WINDOW_REFERENCE (window form) and H, W multiples of 4");
     if (o->param != TCSFM_PARAM_SE3) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: SE(3) chart only");

@@ -100,7 +100,10 @@ class DepthOptimizer:
         # l_pose_consist IS a term of the pose modes under the window rule REFERENCE (opts.w_pose_consist, round 4); elsewhere it is ignored
         pc_ok = (options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm" and
                  options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose" and options.get("param", "se3") == "se3")
-        ignored = [k for k in ("l_smooth", "l_pose_consist") if options.get(k, False) and not (k == "l_pose_consist" and pc_ok)]
+        # l_smooth IS a term of the pose + depth mode on the reference's loss (opts.w_smooth, round 4)
+        sm_ok = (options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose+depth" and
+                 options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm" and int(options.get("num_source_imgs", 2)) <= 3)
+        ignored = [k for k in ("l_smooth", "l_pose_consist") if options.get(k, False) and not ((k == "l_pose_consist" and pc_ok) or (k == "l_smooth" and sm_ok))]
         if ignored:   # off by default in the reference (run_sequential_optimization.py:87,89); not part of the per-pair GN cost
             warnings.warn(f"options {ignored} are not terms of the Gauss-Newton cost and are ignored "
                           "(losses.get_smooth_loss / compute_optimization_loss still evaluate them for logging)")
@@ -133,6 +136,7 @@ class DepthOptimizer:
                 return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0,
                                     w_dc=float(o.get("l_depth_consist_weight", 0.15)) if o.get("l_depth_consist", False) else 0.0,
                                     prior_init=float(o.get("l_depth_init_weight", 0.1)) if o.get("l_depth_init", True) else 0.0,
+                                    w_smooth=float(o.get("l_smooth_weight", 2.0)) if o.get("l_smooth", False) else 0.0,      # optimizer.py:92-93
                                     solver=_lib.SOLVER_GN, lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
                                     max_depth=float(self.config["max_depth"]), window_rule=_lib.WINDOW_REFERENCE,
                                     **{k: v for k, v in kw.items() if k == "lambda_depth"})
