@@ -99,22 +99,28 @@ struct PnConvParams {
     int N;
 };
 
-// One wave = 16 output pixels x (16 NB) output channels; a workgroup = 4 waves = 64 consecutive output pixels of ONE sample.
-// grid = (ceil(OH OW / 64), COUT / (16 NB), N * ksplit).
-template <int NB, bool FIRST>
+// One wave = PB blocks of 16 output pixels x (16 NB) output channels; a workgroup = 4 waves = 64 PB consecutive output pixels of ONE sample.
+// grid = (ceil(OH OW / (64 PB)), COUT / (16 NB), N * ksplit).  PB = 2 (round 4, the many-images regime, layers with >= 64 pixels): every
+// weight / scale-shift float4 a lane loads feeds two pixel blocks -- 0.375 instead of 0.625 loads per MFMA in layer 2, 0.25 instead of 0.44
+// in the 64-channel-block layers -- and the per-group address work is shared.
+template <int NB, bool FIRST, int PB = 1>
 __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
+    static_assert(!FIRST || PB == 1, "the first layer's generic form has one pixel block per wave");
     const PnLayer &L = P.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, kq = lane >> 4;
     const int ksp = blockIdx.z % L.ksplit, n = blockIdx.z / L.ksplit;
     const int npix = L.oh * L.ow;
-    const int pix = (blockIdx.x * 4 + wave) * 16 + m;           // this lane's output pixel (A operand row)
+    const int pix0 = ((blockIdx.x * 4 + wave) * PB) * 16;         // first output pixel of this wave's first block
+    const int pix = pix0 + m;                                     // this lane's output pixel in block 0 (A operand row)
     const bool pvalid = pix < npix;
     const int oy = pvalid ? pix / L.ow : 0, ox = pvalid ? pix - (pix / L.ow) * L.ow : 0;
     const int cbase = blockIdx.y * 16 * NB;
-    pn_f4 acc[NB];
+    pn_f4 acc[PB][NB];
 #pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] = (pn_f4){0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < PB; p++)
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[p][b] = (pn_f4){0.f, 0.f, 0.f, 0.f};
     // K groups of this split: contiguous ranges
     const int g0 = (L.kgroups * ksp) / L.ksplit, g1 = (L.kgroups * (ksp + 1)) / L.ksplit;
     // The K loop is latency-bound, not matrix-bound (a layer has only a few hundred waves, far fewer than would hide a global load
@@ -157,48 +163,77 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
-                    for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b4[u][b][t], acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; b++) acc[0][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b4[u][b][t], acc[0][b], 0, 0, 0);
         }
     } else {
-        constexpr int GC = 4;
+        // Addressing without divisions (round 4): the K group index is walked as (ky, kx, c16) counters, every address is a per-lane base
+        // (fixed for the whole loop) plus a wave-uniform offset, and the zero-padding test of a tap is a bit of two per-lane masks.  The first
+        // version divided the group index by c16n and ks for EVERY group -- two ~30-instruction scalar divisions in front of every batch of
+        // loads, on the wave's critical path, as long as the group's MFMAs -- and rebuilt every 64-bit address on the vector ALU
+        // (1 586 VALU and 1 430 SALU per wave beside 200 MFMAs in layer 2: profiles/r02b_posenet16_pmc_summary.json).
+        constexpr int GC = NB * PB >= 8 ? 2 : (NB * PB == 4 ? 3 : 4);      // (batch sizes that keep the kernel at four waves per SIMD)
         const int c16n = L.cin / 16;
         const float *in = P.in + (size_t)n * L.ih * L.iw * L.cin;
-        const pn_f4 *scsh = reinterpret_cast<const pn_f4 *>(P.scsh + (size_t)n * L.cin * 2);   // [(scale, shift) pairs]: 2 channels per float4
+        const pn_f4 *scsh = reinterpret_cast<const pn_f4 *>(P.scsh + (size_t)n * L.cin * 2) + 2 * kq;   // [(scale, shift) pairs]: 2 channels per float4
+        unsigned rowm[PB], colm[PB];                      // bit k: input row iy0 + k / column ix0 + k lies inside the image (ks <= 7)
+        int lane_in[PB];                                  // this lane's input offset of tap (0, 0), channel block 0 (may be negative)
+#pragma unroll
+        for (int p = 0; p < PB; p++) {
+            const int px = pix + 16 * p;
+            const bool pv = px < npix;
+            const int oy_ = pv ? px / L.ow : 0, ox_ = pv ? px - (px / L.ow) * L.ow : 0;
+            const int iy0 = oy_ * 2 - L.pad, ix0 = ox_ * 2 - L.pad;
+            rowm[p] = 0u; colm[p] = 0u;
+            for (int k = 0; k < L.ks; k++) {
+                rowm[p] |= (pv && iy0 + k >= 0 && iy0 + k < L.ih) ? (1u << k) : 0u;
+                colm[p] |= (ix0 + k >= 0 && ix0 + k < L.iw) ? (1u << k) : 0u;
+            }
+            lane_in[p] = (iy0 * L.iw + ix0) * L.cin + 4 * kq;
+        }
+        const pn_f4 *wl = P.w4 + (size_t)kq * L.cout + cbase + m;       // this lane's weight base: group g, block b at wl[g * 4 * cout + b * 16]
+        // start of this K split, once per wave
+        int tap = g0 / c16n, c16 = g0 - tap * c16n, ky = tap / L.ks, kx = tap - ky * L.ks;
         for (int gb = g0; gb < g1; gb += GC) {
-            pn_f4 a[GC], s01[GC], s23[GC], b4[GC][NB];
-            bool ok[GC];
+            pn_f4 a[GC][PB], s01[GC], s23[GC], b4[GC][NB];
+            bool ok[GC][PB];
 #pragma unroll
             for (int u = 0; u < GC; u++) {
-                const int g = gb + u < g1 ? gb + u : g0;
-                const int tap = g / c16n, c16 = g - tap * c16n;
-                const int ky = tap / L.ks, kx = tap - ky * L.ks;
-                const int iy = oy * 2 + ky - L.pad, ix = ox * 2 + kx - L.pad;
-                ok[u] = gb + u < g1 && pvalid && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
-                const int c0 = c16 * 16 + 4 * kq;
-                a[u] = *reinterpret_cast<const pn_f4 *>(in + ((size_t)(ok[u] ? iy : 0) * L.iw + (ok[u] ? ix : 0)) * L.cin + c0);
-                s01[u] = scsh[c0 / 2]; s23[u] = scsh[c0 / 2 + 1];            // (sc0, sh0, sc1, sh1), (sc2, sh2, sc3, sh3)
+                const bool live = gb + u < g1;                                   // (wave-uniform)
+                const int g = live ? gb + u : g0;
+                const int uoff = live ? (ky * L.iw + kx) * L.cin + c16 * 16 : 0;    // wave-uniform part of the input offset
 #pragma unroll
-                for (int b = 0; b < NB; b++) b4[u][b] = P.w4[(size_t)(g * 4 + kq) * L.cout + cbase + b * 16 + m];
+                for (int p = 0; p < PB; p++) {
+                    ok[u][p] = live && ((rowm[p] >> (live ? ky : 0)) & (colm[p] >> (live ? kx : 0)) & 1u);
+                    a[u][p] = *reinterpret_cast<const pn_f4 *>(in + (ok[u][p] ? lane_in[p] + uoff : 0));
+                }
+                const int cq = live ? c16 * 8 : 0;                                // (c16 * 16 + 4 kq) / 2 float4 of (scale, shift) pairs
+                s01[u] = scsh[cq]; s23[u] = scsh[cq + 1];                         // (sc0, sh0, sc1, sh1), (sc2, sh2, sc3, sh3)
+#pragma unroll
+                for (int b = 0; b < NB; b++) b4[u][b] = wl[(size_t)g * 4 * L.cout + b * 16];
+                if (live) { c16++; if (c16 == c16n) { c16 = 0; kx++; if (kx == L.ks) { kx = 0; ky++; } } }
             }
             __builtin_amdgcn_sched_barrier(0);       // all loads of the batch are issued before the first use
 #pragma unroll
-            for (int u = 0; u < GC; u++) {     // GroupNorm + ReLU of the producer, zero padding AFTER it; a group past the end contributes 0
-                a[u][0] = ok[u] ? fmaxf(a[u][0] * s01[u][0] + s01[u][1], 0.f) : 0.f;
-                a[u][1] = ok[u] ? fmaxf(a[u][1] * s01[u][2] + s01[u][3], 0.f) : 0.f;
-                a[u][2] = ok[u] ? fmaxf(a[u][2] * s23[u][0] + s23[u][1], 0.f) : 0.f;
-                a[u][3] = ok[u] ? fmaxf(a[u][3] * s23[u][2] + s23[u][3], 0.f) : 0.f;
-            }
+            for (int u = 0; u < GC; u++)       // GroupNorm + ReLU of the producer, zero padding AFTER it; a group past the end contributes 0
+#pragma unroll
+                for (int p = 0; p < PB; p++) {
+                    a[u][p][0] = ok[u][p] ? fmaxf(a[u][p][0] * s01[u][0] + s01[u][1], 0.f) : 0.f;
+                    a[u][p][1] = ok[u][p] ? fmaxf(a[u][p][1] * s01[u][2] + s01[u][3], 0.f) : 0.f;
+                    a[u][p][2] = ok[u][p] ? fmaxf(a[u][p][2] * s23[u][0] + s23[u][1], 0.f) : 0.f;
+                    a[u][p][3] = ok[u][p] ? fmaxf(a[u][p][3] * s23[u][2] + s23[u][3], 0.f) : 0.f;
+                }
 #pragma unroll
             for (int u = 0; u < GC; u++)
 #pragma unroll
                 for (int t = 0; t < 4; t++)
 #pragma unroll
-                    for (int b = 0; b < NB; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b4[u][b][t], acc[b], 0, 0, 0);
+                    for (int p = 0; p < PB; p++)
+#pragma unroll
+                        for (int b = 0; b < NB; b++) acc[p][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][p][t], b4[u][b][t], acc[p][b], 0, 0, 0);
         }
     }
     // C/D layout of the 16x16 tile: column (output channel) = lane & 15, row (pixel) = 4 (lane >> 4) + reg
     float *out = P.out + ((size_t)ksp * P.N + n) * npix * L.cout;
-    const int prow0 = (blockIdx.x * 4 + wave) * 16 + 4 * kq;
     __shared__ float wsum[4][16 * NB][2];
 #pragma unroll
     for (int b = 0; b < NB; b++) {
@@ -206,13 +241,17 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
         const float bs = (P.bias != nullptr && L.ksplit == 1) ? P.bias[co] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (prow0 + r < npix) {
-                const float v = acc[b][r] + bs;
-                out[(size_t)(prow0 + r) * L.cout + co] = v;
-                s1 += v; s2 += v * v;
-            }
-        // GroupNorm partial sums of this workgroup's 64 pixels, per channel: the 4 row groups of the wave (lanes m, m+16, m+32,
+        for (int p = 0; p < PB; p++) {
+            const int prow0 = pix0 + 16 * p + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (prow0 + r < npix) {
+                    const float v = acc[p][b][r] + bs;
+                    out[(size_t)(prow0 + r) * L.cout + co] = v;
+                    s1 += v; s2 += v * v;
+                }
+        }
+        // GroupNorm partial sums of this workgroup's 64 PB pixels, per channel: the 4 row groups of the wave (lanes m, m+16, m+32,
         // m+48), then the 4 waves through LDS, both in fixed order
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -263,41 +302,61 @@ __global__ __launch_bounds__(256) void k_pn_conv1(PnConvParams P) {
         pa = inv ? s_ : t; pb = inv ? t : s_;
     } else { pa = P.imgA + (size_t)n * P.strideA; pb = P.imgB + (size_t)n * P.strideB; }
     const int hw = L.ih * L.iw;
-    // weights of this lane: group g, quarter kq, output channel m (21 float4, L2-resident: every wave reads the same 21 KB)
-    pn_f4 b4[21];
-#pragma unroll
-    for (int g = 0; g < 21; g++) b4[g] = P.w4[(size_t)(g * 4 + kq) * L.cout + m];
     // stage the patch: rows iy = 2 oy0 - 3 + row, columns ix = 2 ox0 - 3 + col
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
-    {   // all of a thread's loads are issued before the first is used (a rolled loop would pay one memory latency per element)
-        constexpr int NE = 6 * PN1_ROWS * PN1_COLS, NL = (NE + 255) / 256;
-        float v[NL];
-        bool ok[NL];
+    {   // all of a thread's loads are issued before the first is used (a rolled loop would pay one memory latency per element).
+        // Round 4: a thread keeps ONE column and walks rows, so that plane, row and the row's bounds test are compile-time / wave-uniform and
+        // only the column's test and offset are per lane (the first version decoded (plane, row, column) from a linear element index with two
+        // divisions per element: ~750 of the kernel's 1 000 non-matrix VALU instructions per wave).  Columns 0..127: thread = (column, half),
+        // half 0 walks the 27 rows of image A's three planes, half 1 those of image B (27 = 3 planes x 9 rows); the last 8 columns x 54 rows
+        // go round once more, two elements per thread.
+        static_assert(PN1_ROWS == 9 && PN1_COLS == 136, "staging pattern below");
+        const int colA = tid & 127, half = tid >> 7;
+        const float *srcA = half ? pb : pa;
+        const int ixA = ix0 + colA;
+        const bool okxA = ixA >= 0 && ixA < L.iw;
+        float vA[27], vB[2];
+        bool okA[27], okB[2];
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
+        for (int j = 0; j < 27; j++) {
+            const int pl = j / 9, ry = j - 9 * pl, iy = iy0 + ry;           // (compile-time plane / row; iy wave-uniform)
+            okA[j] = okxA && iy >= 0 && iy < L.ih;
+            vA[j] = srcA[(size_t)pl * hw + (okA[j] ? iy * L.iw + ixA : 0)];
+        }
+        int rrB[2], colB[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
             const int e = tid + 256 * j;
-            const int rowi = e / PN1_COLS, col = e - rowi * PN1_COLS;
-            const int ci = rowi / PN1_ROWS, ry = rowi - ci * PN1_ROWS;
-            const int iy = iy0 + ry, ix = ix0 + col;
-            ok[j] = e < NE && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
+            rrB[j] = e >> 3; colB[j] = 128 + (e & 7);
+            const bool live = rrB[j] < 6 * PN1_ROWS;
+            const int rr = live ? rrB[j] : 0, ci = rr / 9, ry = rr - 9 * ci, iy = iy0 + ry, ix = ix0 + colB[j];
+            okB[j] = live && iy >= 0 && iy < L.ih && ix >= 0 && ix < L.iw;
             const float *src = (ci < 3 ? pa + (size_t)ci * hw : pb + (size_t)(ci - 3) * hw);
-            v[j] = (e < NE) ? src[ok[j] ? (size_t)iy * L.iw + ix : 0] : 0.f;
+            vB[j] = src[okB[j] ? iy * L.iw + ix : 0];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NL; j++) {
-            const int e = tid + 256 * j;
-            if (e < NE) patch[e] = ok[j] ? (v[j] - 0.45f) * (1.f / 0.22f) : 0.f;
-        }
+        for (int j = 0; j < 27; j++)
+            patch[((3 * half + j / 9) * PN1_ROWS + (j % 9)) * PN1_COLS + colA] = okA[j] ? (vA[j] - 0.45f) * (1.f / 0.22f) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (rrB[j] < 6 * PN1_ROWS) patch[rrB[j] * PN1_COLS + colB[j]] = okB[j] ? (vB[j] - 0.45f) * (1.f / 0.22f) : 0.f;
     }
+    // weights of this lane: group g, quarter kq, output channel m (21 float4, L2-resident: every wave reads the same 21 KB).  Loaded AFTER
+    // the staging values have gone to LDS (round 4): the two register sets no longer coexist (132 -> fewer VGPRs: one more wave per SIMD),
+    // and the other waves of the CU cover the L2 latency
+    pn_f4 b4[21];
+#pragma unroll
+    for (int g = 0; g < 21; g++) b4[g] = P.w4[(size_t)(g * 4 + kq) * L.cout + m];
     __syncthreads();
     const int oxl = wave * 16 + m;                       // this lane's output pixel within the chunk (A operand row)
     pn_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // output rows oy0 / oy0 + 1: two independent MFMA chains, one set of weights
 #pragma unroll
     for (int g = 0; g < 21; g++) {
-        const int combo = 2 * g + (kq >> 1);             // (ci, ky)
-        const int ci = combo / 7, ky = combo - ci * 7;
-        const float *row = patch + (ci * PN1_ROWS + ky) * PN1_COLS + 2 * oxl + 4 * (kq & 1);
+        // (ci, ky) of combo = 2 g + (kq >> 1): two compile-time row offsets, one select (no division by 7 per group)
+        const int c0 = 2 * g, c1 = 2 * g + 1;          // (constants once the loop is unrolled)
+        const int roff = (kq >> 1) ? ((c1 / 7) * PN1_ROWS + (c1 % 7)) * PN1_COLS : ((c0 / 7) * PN1_ROWS + (c0 % 7)) * PN1_COLS;
+        const float *row = patch + roff + 2 * oxl + 4 * (kq & 1);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const float2 lo = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS), hi = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS + 2);

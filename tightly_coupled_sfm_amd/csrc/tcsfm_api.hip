@@ -2499,12 +2499,17 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         if (wo) P.win_off = *wo;
         P.in = l > 0 ? pn->act[l - 1] : nullptr; P.scsh = l > 0 ? pn->scsh[l - 1] : nullptr;
         P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = L.ksplit == 1 ? pn->part[l] : nullptr; P.L = L; P.N = N;
-        dim3 grid((L.oh * L.ow + 63) / 64, L.cout / (16 * nb), N * L.ksplit);
+        // two pixel blocks per wave in the many-images regime where a layer has pixels to spare (posenet_kernel.h k_pn_conv PB): a fixed
+        // function of the regime and the layer, so results stay bit-identical for every batch within a regime
+        const int pb = (cfg == 1 && l > 0 && L.oh * L.ow >= 64 && nb >= 2) ? 2 : 1;
+        dim3 grid((L.oh * L.ow + 64 * pb - 1) / (64 * pb), L.cout / (16 * nb), N * L.ksplit);
         if (l == 0) {            // LDS-staged first layer: one workgroup per 64-pixel segment of two output rows
             grid = dim3(((L.oh + 1) / 2) * ((L.ow + 63) / 64), 1, N);
             hipLaunchKernelGGL(k_pn_conv1, grid, dim3(256), 0, h->stream, P);
         } else if (nb == 1) hipLaunchKernelGGL((k_pn_conv<1, false>), grid, dim3(256), 0, h->stream, P);
+        else if (nb == 2 && pb == 2) hipLaunchKernelGGL((k_pn_conv<2, false, 2>), grid, dim3(256), 0, h->stream, P);
         else if (nb == 2) hipLaunchKernelGGL((k_pn_conv<2, false>), grid, dim3(256), 0, h->stream, P);
+        else if (pb == 2) hipLaunchKernelGGL((k_pn_conv<4, false, 2>), grid, dim3(256), 0, h->stream, P);
         else hipLaunchKernelGGL((k_pn_conv<4, false>), grid, dim3(256), 0, h->stream, P);
         // GroupNorm statistics (+ K-split combination) as their own launch.  Round 3 measured the alternative -- statistics, K-split
         // combination and the head in the convolutions' tails by the last-arriver ticket protocol, 7 launches instead of 15: every
