@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void k_pn_conv(PnConvParams P) {
     for (int p = 0; p < PB; p++)
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[p][b] = (pn_f4){0.f, 0.f, 0.f, 0.f};
-    // K groups of this split: contiguous ranges
-    const int g0 = (L.kgroups * ksp) / L.ksplit, g1 = (L.kgroups * (ksp + 1)) / L.ksplit;
+    // K groups of this split: contiguous ranges.  A wave whose pixel blocks all lie past the image (the last layers have 30 and 10 pixels
+    // per sample: three of a workgroup's four waves) has nothing to multiply: it skips the loop (round 4; it used to run every K group on
+    // zeros) and only takes part in the epilogue's statistics barrier
+    const int g0 = (L.kgroups * ksp) / L.ksplit, g1 = pix0 < npix ? (L.kgroups * (ksp + 1)) / L.ksplit : g0;
     // The K loop is latency-bound, not matrix-bound (a layer has only a few hundred waves, far fewer than would hide a global load
     // behind other waves' MFMAs): the loads of GC consecutive K groups are issued together, then their 16 GC MFMAs run -- the
     // compiler keeps the whole batch of loads in flight (one wait per batch instead of one per group).
