@@ -2501,7 +2501,10 @@ int pn_run(tcsfm_posenet *pn, int N, const float *imgA, long long strideA, const
         P.w4 = pn->w4[l]; P.bias = pn->bias[l]; P.out = pn->act[l]; P.part = L.ksplit == 1 ? pn->part[l] : nullptr; P.L = L; P.N = N;
         // two pixel blocks per wave in the many-images regime where a layer has pixels to spare (posenet_kernel.h k_pn_conv PB): a fixed
         // function of the regime and the layer, so results stay bit-identical for every batch within a regime
-        const int pb = (cfg == 1 && l > 0 && L.oh * L.ow >= 64 && nb >= 2) ? 2 : 1;
+        // (A/B on one box, KITTI odometry sequence at 8 / 12 windows per call: layers 2-5 with two blocks 3 632-3 640 / 3 702-3 710 windows/s,
+        // layer 2 only 3 609-3 637 / 3 621-3 626, none 3 504-3 510)
+        static const int pb_min_px = getenv("TCSFM_PN_PB_MIN_PIXELS") ? atoi(getenv("TCSFM_PN_PB_MIN_PIXELS")) : 64;        // (measurement hook)
+        const int pb = (cfg == 1 && l > 0 && nb >= 2 && L.oh * L.ow >= pb_min_px) ? 2 : 1;
         dim3 grid((L.oh * L.ow + 64 * pb - 1) / (64 * pb), L.cout / (16 * nb), N * L.ksplit);
         if (l == 0) {            // LDS-staged first layer: one workgroup per 64-pixel segment of two output rows
             grid = dim3(((L.oh + 1) / 2) * ((L.ow + 63) / 64), 1, N);
