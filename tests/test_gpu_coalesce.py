@@ -134,3 +134,13 @@ def test_merged_sequences_alternating_over_lanes():
         assert torch.equal(got, w)
     e.set_coalesce_lanes(1)
     e.set_coalesce(0)
+
+
+def test_example_queued_windows_runs():
+    """examples/queued_windows.py: the three ways of running many B = 1 windows give the same bits (the example asserts it)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "queued_windows.py"), "--windows", "60", "--distinct", "12"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "same poses: True" in r.stdout
