@@ -344,29 +344,44 @@ __global__ __launch_bounds__(256) void k_pn_conv1(PnConvParams P) {
         for (int j = 0; j < 2; j++)
             if (rrB[j] < 6 * PN1_ROWS) patch[rrB[j] * PN1_COLS + colB[j]] = okB[j] ? (vB[j] - 0.45f) * (1.f / 0.22f) : 0.f;
     }
-    // weights of this lane: group g, quarter kq, output channel m (21 float4, L2-resident: every wave reads the same 21 KB).  Loaded AFTER
-    // the staging values have gone to LDS (round 4): the two register sets no longer coexist (132 -> fewer VGPRs: one more wave per SIMD),
-    // and the other waves of the CU cover the L2 latency
-    pn_f4 b4[21];
+    // weights of this lane: group g, quarter kq, output channel m (21 float4, L2-resident: every wave reads the same 21 KB).  Round 4: they are
+    // loaded in three chunks of seven groups, the next chunk in flight under the current chunk's MFMAs, and only after the staging values have
+    // gone to LDS -- 56 instead of 84 registers of weights that no longer coexist with the staging set (132 -> about 90 VGPRs: the kernel runs
+    // five waves per SIMD, what its 30 KB of LDS allow, instead of three)
+    pn_f4 bA[7], bB[7];
+    auto wload = [&](pn_f4 *b, int g0_) {
 #pragma unroll
-    for (int g = 0; g < 21; g++) b4[g] = P.w4[(size_t)(g * 4 + kq) * L.cout + m];
+        for (int g = 0; g < 7; g++) b[g] = P.w4[(size_t)((g0_ + g) * 4 + kq) * L.cout + m];
+    };
+    wload(bA, 0);
     __syncthreads();
     const int oxl = wave * 16 + m;                       // this lane's output pixel within the chunk (A operand row)
     pn_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // output rows oy0 / oy0 + 1: two independent MFMA chains, one set of weights
+    auto wmul = [&](const pn_f4 *b, int g0_) {
 #pragma unroll
-    for (int g = 0; g < 21; g++) {
-        // (ci, ky) of combo = 2 g + (kq >> 1): two compile-time row offsets, one select (no division by 7 per group)
-        const int c0 = 2 * g, c1 = 2 * g + 1;          // (constants once the loop is unrolled)
-        const int roff = (kq >> 1) ? ((c1 / 7) * PN1_ROWS + (c1 % 7)) * PN1_COLS : ((c0 / 7) * PN1_ROWS + (c0 % 7)) * PN1_COLS;
-        const float *row = patch + roff + 2 * oxl + 4 * (kq & 1);
+        for (int gg = 0; gg < 7; gg++) {
+            // (ci, ky) of combo = 2 g + (kq >> 1): two compile-time row offsets, one select (no division by 7 per group)
+            const int g = g0_ + gg, c0 = 2 * g, c1 = 2 * g + 1;          // (constants once the loops are unrolled)
+            const int roff = (kq >> 1) ? ((c1 / 7) * PN1_ROWS + (c1 % 7)) * PN1_COLS : ((c0 / 7) * PN1_ROWS + (c0 % 7)) * PN1_COLS;
+            const float *row = patch + roff + 2 * oxl + 4 * (kq & 1);
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const float2 lo = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS), hi = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS + 2);
-            const pn_f4 a = {lo.x, lo.y, hi.x, hi.y};
+            for (int r = 0; r < 2; r++) {
+                const float2 lo = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS), hi = *reinterpret_cast<const float2 *>(row + 2 * r * PN1_COLS + 2);
+                const pn_f4 a = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b4[g][t], acc[r], 0, 0, 0);
+                for (int t = 0; t < 4; t++) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[gg][t], acc[r], 0, 0, 0);
+            }
         }
-    }
+    };
+    wload(bB, 7);
+    __builtin_amdgcn_sched_barrier(0);
+    wmul(bA, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    wload(bA, 14);
+    __builtin_amdgcn_sched_barrier(0);
+    wmul(bB, 7);
+    __builtin_amdgcn_sched_barrier(0);
+    wmul(bA, 14);
     // C/D layout: column (output channel) = lane & 15, row (pixel) = 4 (lane >> 4) + reg
     float *out = P.out + (size_t)n * L.oh * L.ow * L.cout;
     const float bs = P.bias != nullptr ? P.bias[m] : 0.f;
