@@ -63,6 +63,11 @@ def test_bench_single_process():
     assert ("merged sequences" in lm["timed"]) == mg["timed"]
     assert ot["same_poses"] is True and ot["captures"] >= d["config"]["ring_calls"] and ot["replays"] >= 60 - 6 and ot["value"] > 100
     assert d["host_enqueue_us_per_step"] > 0 and ot["host_enqueue_us_per_step"] > 0
+    # the accuracy check on pairs rendered through the reference's own sampling model (the residual's minimiser is the scene truth there):
+    # 4 GN iterations move the poses towards it, 16 LM iterations reach about 1 % / 0.02 degrees (tests/test_gpu_truth.py asserts the bar)
+    tr = d["check"]["truth_sampler_consistent"]
+    assert tr["gn_4_iterations"]["translation_rel"] < 0.8 * tr["initial"]["translation_rel"]
+    assert tr["lm_16_iterations"]["translation_rel"] < 0.02 and tr["lm_16_iterations"]["rotation_deg"] < 0.05
 
 
 def _free_port():

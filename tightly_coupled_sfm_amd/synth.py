@@ -186,14 +186,14 @@ def depth_to_sigmoid_disp(depth, min_depth=KITTI_MIN_DEPTH, max_depth=KITTI_MAX_
     return (1.0 / depth - min_disp) / (max_disp - min_disp)
 
 
-def make_batch(N, H=192, W=640, seed0=0, noise=0.003, dtype=np.float32, both_directions=False):
+def make_batch(N, H=192, W=640, seed0=0, noise=0.003, dtype=np.float32, both_directions=False, sampler_consistent=False):
     """N directed pairs stacked: tgt,src [N,3,H,W]; depth_t,depth_s [N,1,H,W]; K [N,3,3];
     pose_gt, pose_init [N,6].  With ``both_directions`` pair 2i+1 is pair 2i reversed
     (the reference's fwd/inv stacking, train_mono.py:54-62) with pose_gt negated."""
     out = {k: [] for k in ("tgt", "src", "depth_t", "depth_s", "K", "pose_gt", "pose_init")}
     i = 0
     while len(out["tgt"]) < N:
-        p = make_pair(H, W, seed=seed0 + i, noise=noise, dtype=dtype)
+        p = make_pair(H, W, seed=seed0 + i, noise=noise, dtype=dtype, sampler_consistent=sampler_consistent)
         init = perturb_pose(p["pose_gt"], seed=seed0 + i)
         for flip in ((False, True) if both_directions else (False,)):
             if len(out["tgt"]) >= N:
