@@ -426,6 +426,47 @@ __device__ inline float photo_err_planar(const float *__restrict__ x, const floa
     return acc;
 }
 
+// The same value from an LDS tile (round 4): a workgroup owns a PT_W x PT_H tile of pixels, stages the tile + 1-pixel reflect halo of the six
+// colour planes once (about 9 coalesced loads per thread instead of 54 cache hits) and every thread reads its 3 x 3 window from LDS.  Same
+// neighbours (the halo is filled through refl_idx, as photo_err_planar indexes), same operation order -> the same bits.
+constexpr int PT_W = 64, PT_H = 4, PT_CW = PT_W + 2, PT_CH = PT_H + 2, PT_N = PT_CW * PT_CH;
+__device__ __forceinline__ void pack_stage_tile(float (*tile)[PT_N], const float *__restrict__ x, const float *__restrict__ y, int H, int W, int x0, int y0) {
+    const int hw = H * W;
+    for (int e = threadIdx.x; e < PT_N; e += 256) {
+        const int ly = e / PT_CW, lx = e - ly * PT_CW;
+        const int gi = refl_idx(y0 + ly - 1, H) * W + refl_idx(x0 + lx - 1, W);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { tile[c][e] = x[c * hw + gi]; tile[3 + c][e] = y[c * hw + gi]; }
+    }
+}
+__device__ __forceinline__ float photo_err_tile(const float (*tile)[PT_N], int tx, int ty, float wl, float ws, float *xc3, float *yc3) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float xv[9], yv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int q = (ty + k / 3) * PT_CW + tx + (k % 3);
+            xv[k] = tile[c][q]; yv[k] = tile[3 + c][q];
+        }
+        const float x0 = xv[4], y0 = yv[4];
+        xc3[c] = x0; yc3[c] = y0;
+        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float a = xv[k] - x0, b = yv[k] - y0;  // shifted by the centre value: fp32-safe variances
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+        const float n9 = 1.f / 9.f;
+        float mdx = sx * n9, mdy = sy * n9, mux = x0 + mdx, muy = y0 + mdy;
+        float sigx = sxx * n9 - mdx * mdx, sigy = syy * n9 - mdy * mdy, sigxy = sxy * n9 - mdx * mdy;
+        float n = (2.f * mux * muy + SSIM_C1) * (2.f * sigxy + SSIM_C2);
+        float d = ((__fmul_rn(mux, mux) + __fmul_rn(muy, muy)) + SSIM_C1) * (sigx + sigy + SSIM_C2);      // (symmetric in x, y: see photo_err_planar)
+        acc += wl * clamp01(fabsf(y0 - x0)) + ws * clamp01((1.f - n * frcp(d)) * 0.5f);
+    }
+    return acc;
+}
+
 // source image of pair n with its 1-texel zero border (see tap4); edge pixels also write the border texels next to them
 __device__ __forceinline__ void pack_write_src(const PackParams &P, int n, int u, int v, const float4 &val) {
     const int WB = P.W + 2;
@@ -447,7 +488,10 @@ __device__ __forceinline__ void pack_write_src(const PackParams &P, int n, int u
 // photo_err_planar(x, y) == photo_err_planar(y, x) bit for bit -- so every input value is loaded once and the 3x3 error evaluated once
 // (round 4: k_pack 8.6 -> see DESIGN section 4; the bits equal those of the pair form on the same images).
 __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float tile[6][PT_N];
+    const int tiles_x = (P.W + PT_W - 1) / PT_W;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    const int x0 = txi * PT_W, y0 = tyi * PT_H, tx = threadIdx.x & (PT_W - 1), ty = threadIdx.x / PT_W;
     int n = blockIdx.y;
     const int hw = P.H * P.W;
     const bool both = ct != nullptr || P.win_B > 0;
@@ -469,15 +513,18 @@ __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct
         const int ni = threadIdx.x == 0 ? n : n_inv;
         if ((threadIdx.x == 0 || both) && ni < P.init.N) init_pair(P.init, ni, ct);
     }
-    if (idx >= hw) return;
-    int v = idx / P.W, u = idx - v * P.W;
-    float ae = photo_err_planar(t, s, P.H, P.W, u, v, P.wl, P.ws);
+    pack_stage_tile(tile, t, s, P.H, P.W, x0, y0);
+    __syncthreads();
+    const int u = x0 + tx, v = y0 + ty, idx = v * P.W + u;
+    if (u >= P.W || v >= P.H) return;
+    float tc[3], sc[3];
+    float ae = photo_err_tile(tile, tx, ty, P.wl, P.ws, tc, sc);
     float dt = dtp[idx], ds = dsp[idx];
     if (P.depth_is_disp) {  // disp_to_depth, learning_helpers.py:77-86
         dt = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * dt);
         ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
     }
-    const float t0 = t[idx], t1 = t[hw + idx], t2 = t[2 * hw + idx], s0 = s[idx], s1 = s[hw + idx], s2 = s[2 * hw + idx];
+    const float t0 = tc[0], t1 = tc[1], t2 = tc[2], s0 = sc[0], s1 = sc[1], s2 = sc[2];
     P.tgtpack[(size_t)n * hw + idx] = make_float4(t0, t1, t2, ae);
     pack_write_src(P, n, u, v, make_float4(s0, s1, s2, ds));
     P.depth_out[(size_t)n * hw + idx] = dt;

@@ -425,8 +425,9 @@ int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, cons
         ProfScope prof(h, 2);
         // window forms: one row of workgroups per FORWARD pair, which packs its inverse too (pack_body)
         const int rows = (ct || win_B > 0) ? Nimg / 2 : Nimg;
-        if (ct) hipLaunchKernelGGL(k_pack_coal, dim3((hw + 255) / 256, rows), dim3(256), 0, h->stream, P, *ct);
-        else hipLaunchKernelGGL(k_pack, dim3((hw + 255) / 256, rows), dim3(256), 0, h->stream, P);
+        const unsigned ptiles = (unsigned)(((h->W + PT_W - 1) / PT_W) * ((h->H + PT_H - 1) / PT_H));       // 64 x 4 pixel tiles (pack_body)
+        if (ct) hipLaunchKernelGGL(k_pack_coal, dim3(ptiles, rows), dim3(256), 0, h->stream, P, *ct);
+        else hipLaunchKernelGGL(k_pack, dim3(ptiles, rows), dim3(256), 0, h->stream, P);
     }
     HIPCHK(h, hipGetLastError());
     return TCSFM_OK;
