@@ -58,7 +58,38 @@ def run_window(name, opts, dense=False, steps=300, warm=30):
     print(json.dumps({"config": name, "HxW": f"{H}x{W}", "directed_pairs": 4, "iters": opts.n_iters, "us_per_call": round(dt_ * 1e6, 1), "windows_per_s": round(1 / dt_, 1)}))
 
 
+def run_window_merged(name, opts, calls=5, streams=2, steps=400, distinct=12):
+    """the same KITTI windows as QUEUED calls merged by the library (tcsfm_refine_window_queued, `calls` per launch sequence, the sequences
+    alternating over `streams` streams of the handle); distinct windows, per window the bits of the single call (checked)"""
+    H, W, B, S = 192, 640, 1, 2
+    ws = []
+    for i in range(distinct):
+        b = synth.make_batch(2 * S, H, W, seed0=40 * i)
+        d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+        ws.append(dict(tgt=d["tgt"][:1].contiguous(), srcs=d["src"][:S].reshape(S, B, 3, H, W).contiguous(), dt=d["depth_t"][:1].contiguous(),
+                       ds=d["depth_s"][:S].reshape(S, B, 1, H, W).contiguous(), pose=torch.cat([d["pose_init"][:S], -d["pose_init"][:S]]).contiguous(),
+                       out=torch.empty(2 * S, 6, device="cuda")))
+    K = torch.as_tensor(synth.make_batch(1, H, W, seed0=0)["K"][:1]).cuda().contiguous()
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2 * S * B * calls, lanes=max(2, streams))
+    want = [e.refine_window(w["tgt"], w["srcs"], w["dt"], w["ds"], K, w["pose"], opts, argmin=True)[0].clone() for w in ws]
+    e.set_coalesce(calls); e.set_coalesce_lanes(streams)
+    def block(n):
+        for k in range(n):
+            w = ws[k % distinct]
+            e.refine_window_queued(w["tgt"], w["srcs"], w["dt"], w["ds"], K, w["pose"], w["out"], opts)
+        e.flush(); torch.cuda.synchronize()
+    block(60)
+    same = all(torch.equal(w["out"], x) for w, x in zip(ws, want))
+    t0 = time.perf_counter(); block(steps); dt_ = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": name, "HxW": f"{H}x{W}", "directed_pairs": 4, "iters": opts.n_iters, "calls_per_sequence": calls, "streams": streams,
+                      "us_per_window": round(dt_ * 1e6, 1), "windows_per_s": round(1 / dt_, 1), "same_poses_as_single_calls": same}))
+    e.set_coalesce_lanes(1); e.set_coalesce(0); e.close()
+
+
 run_window("KITTI window B=1 S=2, depth consistency, min over sources (window rule PAIR)", default_opts(n_iters=4, w_dc=0.15))
+run_window_merged("KITTI windows QUEUED and merged by the library, 5 per launch sequence on 2 streams (window rule PAIR)", default_opts(n_iters=4, w_dc=0.15, argmin=1))
+run_window_merged("KITTI windows QUEUED and merged by the library, 8 per launch sequence on 2 streams (window rule PAIR)", default_opts(n_iters=4, w_dc=0.15, argmin=1), calls=8)
 run_window("KITTI window B=1 S=2, depth consistency, min over sources (window rule REFERENCE)", default_opts(n_iters=4, w_dc=0.15, window_rule=1))
 run_window("KITTI window B=1 S=2 without the depth-consistency term", default_opts(n_iters=4))
 run_window("KITTI window dense JOINT (shared depth, 12x12)", default_opts(n_iters=4, dense_joint=1), dense=True)
