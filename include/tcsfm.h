@@ -380,6 +380,13 @@ int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S
                                const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out);
 int tcsfm_flush(tcsfm_handle h);
 int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls);
+/* The dense counterpart (arguments of tcsfm_refine_dense_window, device pointers, no statistics): queued per-pair Gauss-Newton dense calls
+ * with ONE source per target (S = 1, TCSFM_WINDOW_PAIR) of the same shape and options are merged like the pose calls -- every call's
+ * refined poses and depth maps go to its own outputs, bit-identical to the call on its own; any other dense call (S > 1, LM, the
+ * reference-loss mode) flushes what is waiting and runs at once.  Pose calls and dense calls are never merged with each other. */
+int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                     const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
+                                     float *depth_out);
 
 /* The reference's sequential driver loop as ONE call (run_sequential_optimization.py:186-247: for every window DataLoader batch ->
  * H2D in process_sample_batch, data/kitti_loader.py:60-98 -> optimize_window, strictly one window after the other).

@@ -144,3 +144,40 @@ def test_example_queued_windows_runs():
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "same poses: True" in r.stdout
+
+
+def test_merged_dense_calls_are_bit_identical_to_single_calls():
+    """tcsfm_refine_dense_window_queued: per-pair Gauss-Newton dense calls (one source per target) merged through the pointer table -- every
+    call's poses AND depth maps are the bits of the call on its own; dense and pose calls are never merged with each other; a KITTI window
+    (S = 2, joint mode) runs at once"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    calls = _calls(7, H, W, seed=120)
+    o = default_opts(n_iters=3, min_depth=0.03, max_depth=3.0)
+    ref = Engine(H, W, 2)
+    want = []
+    for c in calls:
+        p, d, _ = ref.refine_dense_window(c["tgt"], c["srcs"], c["dt"][:, None].contiguous() if c["dt"].dim() == 3 else c["dt"], c["ds"][:, :, None].contiguous() if c["ds"].dim() == 4 else c["ds"],
+                                          c["K"], c["pose"], o)
+        want.append((p.clone(), d.clone()))
+    torch.cuda.synchronize()
+    dt4 = [c["dt"][:, None].contiguous() if c["dt"].dim() == 3 else c["dt"] for c in calls]
+    ds5 = [c["ds"][:, :, None].contiguous() if c["ds"].dim() == 4 else c["ds"] for c in calls]
+    e = Engine(H, W, 2 * 4, lanes=2)
+    e.set_coalesce(4); e.set_coalesce_lanes(2)
+    po = [torch.zeros(2, 6, device="cuda") for _ in calls]
+    do = [torch.zeros(2, 1, H, W, device="cuda") for _ in calls]
+    for c, a, b, p, d in zip(calls, dt4, ds5, po, do):
+        e.refine_dense_window_queued(c["tgt"], c["srcs"], a, b, c["K"], c["pose"], p, d, o)
+    assert e.coalesce_counts() == (1, 4)
+    # a pose call of the same shape flushes the waiting dense calls (three) before it is queued itself
+    op = default_opts(n_iters=3)
+    pose_only = torch.zeros(2, 6, device="cuda")
+    e.refine_window_queued(calls[0]["tgt"], calls[0]["srcs"], calls[0]["dt"], calls[0]["ds"], calls[0]["K"], calls[0]["pose"], pose_only, op)
+    assert e.coalesce_counts() == (2, 7)
+    e.synchronize()
+    assert e.coalesce_counts() == (3, 8)
+    for (wp, wd), p, d in zip(want, po, do):
+        assert torch.equal(p, wp) and torch.equal(d, wd)
+    assert torch.equal(pose_only, ref.refine_window(calls[0]["tgt"], calls[0]["srcs"], calls[0]["dt"], calls[0]["ds"], calls[0]["K"], calls[0]["pose"], op)[0])
+    e.set_coalesce_lanes(1); e.set_coalesce(0)

@@ -350,6 +350,9 @@ struct DenseUpdateParams {
     float *depth_out;         // [N][H*W] out (may be the same buffer)
     int hw;
     float rho_lo, rho_hi;
+    // coalesced calls (CoalTab, kernels.h): the refined map of batch pair n goes to ITS call's output, at the pair's index in that call
+    int c_ncall, c_B, c_S, c_pad;
+    float *c_depth_out[TC_MAX_COAL];
 };
 
 __global__ __launch_bounds__(256) void k_dense_update(DenseUpdateParams P) {
@@ -361,7 +364,9 @@ __global__ __launch_bounds__(256) void k_dense_update(DenseUpdateParams P) {
     float d[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) d[j] = (float)P.delta[n * 8 + j];
-    P.depth_out[(size_t)n * P.hw + idx] = dense_advance(P.depth[(size_t)n * P.hw + idx], r0, r1, d, P.rho_lo, P.rho_hi);
+    float *dst = P.depth_out + (size_t)n * P.hw;
+    if (P.c_ncall > 0) { const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n); dst = P.c_depth_out[ci.call] + (size_t)ci.li * P.hw; }
+    dst[idx] = dense_advance(P.depth[(size_t)n * P.hw + idx], r0, r1, d, P.rho_lo, P.rho_hi);
 }
 
 // LM variant of the back-substitution: an accepted trial first becomes the accepted state (depth map and per-pixel records),

@@ -101,11 +101,12 @@ struct tcsfm_ctx {
     int graph_captures = 0, graph_replays = 0;
     bool capturing = false;
     // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
-    struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; };
+    struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; float *depth_out; };      // depth_out: dense calls
     float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
     double *pose_lin = nullptr;        // l_pose_consist: [2][max_pairs][12] transforms at the linearisation (k_solve, kernels.h)
     float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
     int coal_max = 0;
+    int pend_dense = 0;                // the waiting calls are dense-mode calls (tcsfm_refine_dense_window_queued)
     int coal_lanes = 1;                // merged sequences alternate over this many of the handle's streams (tcsfm_set_coalesce_lanes)
     unsigned coal_dirty = 0;           // bit l: lane l ran a merged sequence the handle's stream has not been ordered behind yet
     std::vector<PendingCall> pending;
@@ -1537,9 +1538,14 @@ int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *d
 // shared body of tcsfm_refine_dense (win_B == 0) and tcsfm_refine_dense_window
 static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                       const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
-                      float *depth_out, float *stats_out, const WinOff *wo) {
+                      float *depth_out, float *stats_out, const WinOff *wo, const CoalTab *ct = nullptr, float *const *ct_pose = nullptr,
+                      float *const *ct_depth = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
+    if (ct) {        // coalesced dense calls (flush_pending): per-pair Gauss-Newton form only, every array argument comes from the table
+        tgt = ct->tgt[0]; src = ct->src[0]; depth_t = ct->dt[0]; depth_s = ct->ds[0]; K = ct->K[0]; pose_in = ct->pose[0];
+        pose_out = ct_pose[0]; depth_out = ct_depth[0];
+    }
     if (!tgt || !src || !depth_t || !depth_s || !pose_in || !pose_out || !depth_out || !K) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: NULL argument");
     const bool ref_mode = win_B && o->window_rule == TCSFM_WINDOW_REFERENCE;      // the reference's own loss (dense_ref_kernel.h)
     if (o->w_dc > 0.f && !ref_mode) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth), except under window_rule = TCSFM_WINDOW_REFERENCE");
@@ -1554,10 +1560,12 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
     DeviceGuard dev_guard(h->device);
     if (int rc_ = pending_error(h)) return rc_;
-    const int nimg_t = win_B ? win_B : N, nimg_s = win_B ? win_B * win_S : N;   // image sets behind tgt / src
-    if ((rc = check_intrinsics(h, o, K, nimg_t))) return rc;
+    const int nimg_t = ct ? ct->cB : (win_B ? win_B : N), nimg_s = ct ? ct->cB * ct->cS : (win_B ? win_B * win_S : N);   // image sets behind tgt / src
+    if (!ct && (rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
+    if (ct && (ref_mode || n_sel || o->solver != TCSFM_SOLVER_GN || o->host_ptrs || o->n_iters < 1 || (o->dense_joint && win_S >= 2)))
+        return fail(h, TCSFM_E_ARG, "internal: only per-pair Gauss-Newton dense calls on device pointers are merged");
     if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (lm && !h->dense_rec_acc) {
@@ -1620,7 +1628,7 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         HIPCHK(h, hipMalloc((void **)&h->depth_alt, n * hw * sizeof(float)));
     }
     // every pair gets its OWN copy of its target's depth; the pack also leaves the prior centre depth0
-    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, h->depth0, wo))) return rc;
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, h->depth0, wo, ct))) return rc;
     // the dense kernel's own tile grid (32x16 tiles of 512 threads, as k_linearize; 16x16 / 256 threads measured slower except
     // for 320x240 at B=1: 10.9 vs 11.8 us per launch there, 234 vs 200 us with the chip full) and reduction-group count
     constexpr int DTW = 32, DTH = 16, DNT = 512;
@@ -1633,11 +1641,16 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     P.direct = nblk <= 512;
     S.partials = P.direct ? h->blockrec : h->partials; S.ngrp = P.direct ? nblk : P.ngrp;
     S.stats = d_stats; S.delta_out = h->delta;
+    if (ct) {
+        S.c_ncall = ct->ncall; S.c_B = ct->cB; S.c_S = ct->cS;
+        for (int i = 0; i < ct->ncall; i++) S.c_pose_out[i] = ct_pose[i];
+    }
     DenseParams Dn;
     Dn.dense_rec = h->dense_rec; Dn.depth0 = h->depth0; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
     Dn.prev_rec = nullptr; Dn.prev_delta = h->delta; Dn.depth_next = nullptr;
     Dn.rho_lo = 1.f / o->max_depth; Dn.rho_hi = 1.f / o->min_depth;
     DenseUpdateParams U;
+    memset(&U, 0, sizeof(U));
     U.dense_rec = h->dense_rec; U.delta = h->delta; U.depth = h->depth_work; U.depth_out = h->depth_work; U.hw = (int)hw;
     U.rho_lo = Dn.rho_lo; U.rho_hi = Dn.rho_hi;
     float *Dbuf[2] = {h->depth_work, h->depth_alt}, *Rbuf[2] = {h->dense_rec, h->dense_rec2};
@@ -1680,6 +1693,10 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (fuse) {   // the last back-substitution writes the caller's depth map directly
         const int nit = o->n_iters;
         U.dense_rec = Rbuf[(nit - 1) & 1]; U.depth = Dbuf[nit & 1]; U.depth_out = d_depth_out;
+        if (ct) {
+            U.c_ncall = ct->ncall; U.c_B = ct->cB; U.c_S = ct->cS;
+            for (int i = 0; i < ct->ncall; i++) U.c_depth_out[i] = ct_depth[i];
+        }
         hipLaunchKernelGGL(k_dense_update, px_grid, dim3(256), 0, h->stream, U);
     }
     if (lm && o->n_iters > 0) {   // evaluate the last trial once more; keep it only if it lowered the cost (pose and depth map)
@@ -1756,9 +1773,21 @@ static int flush_pending(tcsfm_ctx *h) {
         c->stream = c->own_stream;
     }
     int rc;
+    const bool dense = h->pend_dense != 0;
     if (n == 1) {
         const auto &q = calls[0];
-        rc = refine_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, nullptr, q.pose_out, nullptr, nullptr);
+        rc = dense ? dense_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, q.pose_out, q.depth_out, nullptr)
+                   : refine_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, nullptr, q.pose_out, nullptr, nullptr);
+    } else if (dense) {
+        CoalTab ct;
+        memset(&ct, 0, sizeof(ct));
+        ct.ncall = n; ct.cB = B; ct.cS = S;
+        float *outs[TC_MAX_COAL], *douts[TC_MAX_COAL];
+        for (int i = 0; i < n; i++) {
+            ct.tgt[i] = calls[i].tgt; ct.src[i] = calls[i].srcs; ct.dt[i] = calls[i].dt; ct.ds[i] = calls[i].ds; ct.K[i] = calls[i].K; ct.pose[i] = calls[i].pose_in;
+            outs[i] = calls[i].pose_out; douts[i] = calls[i].depth_out;
+        }
+        rc = dense_body(c, &o, 2 * B * S * n, B * n, S, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ct, outs, douts);
     } else {
         CoalTab ct;
         memset(&ct, 0, sizeof(ct));
@@ -1823,12 +1852,40 @@ int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S
     const bool mergeable = h->coal_max > 1 && o->window_rule == TCSFM_WINDOW_PAIR && !h->trace_bits && !h->trace_decide && !h->profiling;
     DeviceGuard dev_guard(h->device);
     if ((rc = check_intrinsics(h, o, K, B))) return rc;            // (blocking only the first time a pointer is seen)
-    if (!h->pending.empty() && (memcmp(&h->pend_opts, o, sizeof(*o)) != 0 || h->pend_B != B || h->pend_S != S ||
+    if (!h->pending.empty() && (h->pend_dense || memcmp(&h->pend_opts, o, sizeof(*o)) != 0 || h->pend_B != B || h->pend_S != S ||
                                 (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs))
         if ((rc = flush_pending(h))) return rc;
-    h->pend_opts = *o; h->pend_B = B; h->pend_S = S;
-    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out});
+    h->pend_opts = *o; h->pend_B = B; h->pend_S = S; h->pend_dense = 0;
+    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, nullptr});
     if (!mergeable || (int)h->pending.size() >= h->coal_max || (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs)
+        return flush_pending(h);
+    return TCSFM_OK;
+}
+
+// the dense counterpart of tcsfm_refine_window_queued: per-pair Gauss-Newton dense calls with ONE source per target are merged (k_pack_coal,
+// per-call pose and depth outputs through the pointer table); every other dense call flushes what is waiting and runs at once
+int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
+                                     const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out) {
+    if (!h) return TCSFM_E_ARG;
+    if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: need 1 <= 2*B*S <= max_pairs");
+    int rc = check_common(h, o, 2 * B * S);
+    if (rc) return rc;
+    if (!tgt || !srcs || !depth_t || !depth_s || !K || !pose_in || !pose_out || !depth_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: NULL argument");
+    if (o->host_ptrs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: device pointers only");
+    const bool mergeable = h->coal_max > 1 && S == 1 && o->window_rule == TCSFM_WINDOW_PAIR && o->solver == TCSFM_SOLVER_GN && o->n_iters >= 1 &&
+                           o->w_dc == 0.f && o->param == TCSFM_PARAM_SE3 && !h->trace_bits && !h->trace_decide && !h->profiling;
+    DeviceGuard dev_guard(h->device);
+    if (!mergeable) {
+        if ((rc = flush_pending(h))) return rc;
+        return tcsfm_refine_dense_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, nullptr);
+    }
+    if ((rc = check_intrinsics(h, o, K, B))) return rc;            // (blocking only the first time a pointer is seen)
+    if (!h->pending.empty() && (!h->pend_dense || memcmp(&h->pend_opts, o, sizeof(*o)) != 0 || h->pend_B != B || h->pend_S != S ||
+                                (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs))
+        if ((rc = flush_pending(h))) return rc;
+    h->pend_opts = *o; h->pend_B = B; h->pend_S = S; h->pend_dense = 1;
+    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out});
+    if ((int)h->pending.size() >= h->coal_max || (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs)
         return flush_pending(h);
     return TCSFM_OK;
 }

@@ -444,6 +444,13 @@ class Engine:
         self._call(self.lib.tcsfm_refine_window_queued(self._h, C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
                                                        self._p(K), self._p(pose), self._p(pose_out)))
 
+    def refine_dense_window_queued(self, tgt, srcs, depth_t, depth_s, K, pose, pose_out, depth_out, opts: Opts):
+        """tcsfm_refine_dense_window_queued: the dense counterpart of refine_window_queued (window layout of refine_dense_window; depth_out
+        [2*S*B,1,H,W]); per-pair Gauss-Newton calls with one source per target are merged, anything else runs at once"""
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        self._call(self.lib.tcsfm_refine_dense_window_queued(self._h, C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                                             self._p(K), self._p(pose), self._p(pose_out), self._p(depth_out)))
+
     def flush(self):
         self._call(self.lib.tcsfm_flush(self._h))
 
