@@ -357,7 +357,7 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
 /* ---- coalesced calls (round 4): queued B-window calls of one shape run as ONE launch sequence ------------------------
  * The robust way of keeping the chip busy with small calls: lanes depend on how the runtime places their hardware queues (see
  * tcsfm_set_lanes), a merged launch sequence does not.  tcsfm_refine_window_queued takes the arguments of tcsfm_refine_window
- * (device pointers, TCSFM_REFINE_POSE, no log-scale / statistics outputs) and only NOTES the call; when `max_calls` calls of the same
+ * (device pointers, no statistics outputs; tcsfm_refine_window_scale_queued carries the log depth-scales of TCSFM_REFINE_POSE_SCALE) and only NOTES the call; when `max_calls` calls of the same
  * shape (B, S) and options are waiting -- or at tcsfm_flush / tcsfm_synchronize, or when a call of another shape arrives -- they run as
  * one pack / (linearise, solve) x n_iters sequence over all their directed pairs on the handle's stream: the kernels reach every
  * call's own buffers through a pointer table (k_pack_coal) and every call's refined poses go to its own pose_out.  Per window the
@@ -378,6 +378,10 @@ int tcsfm_set_coalesce(tcsfm_handle h, int max_calls);
 int tcsfm_set_coalesce_lanes(tcsfm_handle h, int n_streams);
 int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out);
+/* the same with the depth-scale unknown (TCSFM_REFINE_POSE_SCALE): log_scale_in [2*S*B] or NULL (0), log_scale_out [2*S*B] or NULL */
+int tcsfm_refine_window_scale_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                     const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
+                                     const float *log_scale_in, float *pose_out, float *log_scale_out);
 int tcsfm_flush(tcsfm_handle h);
 int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls);
 /* The dense counterpart (arguments of tcsfm_refine_dense_window, device pointers, no statistics): queued per-pair Gauss-Newton dense calls

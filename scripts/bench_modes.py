@@ -40,6 +40,37 @@ run("#5 dense 448x256", 256, 448, 2, default_opts(n_iters=4, min_depth=0.03, max
 run("dense 640x192", 192, 640, 2, default_opts(n_iters=4), dense=True)
 
 
+def run_scale_merged(name, opts, calls=10, streams=2, steps=400, distinct=12):
+    """BASELINE config 4 (pose + log depth-scale, 7 x 7) as QUEUED calls merged by the library (tcsfm_refine_window_scale_queued)"""
+    H, W = 192, 640
+    ws = []
+    for i in range(distinct):
+        b = synth.make_batch(2, H, W, seed0=31 * i, both_directions=True)
+        d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+        ws.append(dict(tgt=d["tgt"][:1].contiguous(), srcs=d["src"][:1][None].contiguous(), dt=d["depth_t"][:1].contiguous(), ds=d["depth_s"][:1][None].contiguous(),
+                       pose=d["pose_init"].contiguous(), po=torch.empty(2, 6, device="cuda"), lo=torch.empty(2, device="cuda")))
+    K = torch.as_tensor(synth.make_batch(1, H, W)["K"][:1]).cuda().contiguous()
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2 * calls, lanes=max(2, streams))
+    want = [e.refine_window(w["tgt"], w["srcs"], w["dt"], w["ds"], K, w["pose"], opts)[:2] for w in ws]
+    want = [(p.clone(), l.clone()) for p, l in want]
+    e.set_coalesce(calls); e.set_coalesce_lanes(streams)
+    def block(n):
+        for k in range(n):
+            w = ws[k % distinct]
+            e.refine_window_scale_queued(w["tgt"], w["srcs"], w["dt"], w["ds"], K, w["pose"], None, w["po"], w["lo"], opts)
+        e.flush(); torch.cuda.synchronize()
+    block(60)
+    same = all(torch.equal(w["po"], x[0]) and torch.equal(w["lo"], x[1]) for w, x in zip(ws, want))
+    t0 = time.perf_counter(); block(steps); dt_ = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": name, "HxW": f"{H}x{W}", "directed_pairs": 2, "iters": opts.n_iters, "calls_per_sequence": calls, "streams": streams,
+                      "us_per_window": round(dt_ * 1e6, 1), "windows_per_s": round(1 / dt_, 1), "same_results_as_single_calls": same}))
+    e.set_coalesce_lanes(1); e.set_coalesce(0); e.close()
+
+
+run_scale_merged("#4 pose+scale 8 iters as QUEUED calls merged by the library, 10 per launch sequence on 2 streams", default_opts(n_iters=8, refine=1))
+
+
 def run_window(name, opts, dense=False, steps=300, warm=30):
     """the reference's KITTI window as ONE call: B=1 target, S=2 sources (4 directed pairs), min over the sources"""
     H, W, B, S = 192, 640, 1, 2

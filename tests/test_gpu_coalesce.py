@@ -181,3 +181,30 @@ def test_merged_dense_calls_are_bit_identical_to_single_calls():
         assert torch.equal(p, wp) and torch.equal(d, wd)
     assert torch.equal(pose_only, ref.refine_window(calls[0]["tgt"], calls[0]["srcs"], calls[0]["dt"], calls[0]["ds"], calls[0]["K"], calls[0]["pose"], op)[0])
     e.set_coalesce_lanes(1); e.set_coalesce(0)
+
+
+def test_merged_pose_scale_calls_are_bit_identical_to_single_calls():
+    """tcsfm_refine_window_scale_queued: BASELINE config 4 (pose + one log depth-scale per pair, 7 x 7) through the merged sequences -- poses
+    and log scales of every call are the bits of the call on its own, with given and with default (0) initial scales"""
+    from tightly_coupled_sfm_amd import _lib
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    H, W = 96, 320
+    calls = _calls(5, H, W, seed=150)
+    o = default_opts(n_iters=6, refine=_lib.REFINE_POSE_SCALE)
+    ref = Engine(H, W, 2)
+    ls0 = [torch.tensor([0.01 * (i - 2), -0.005 * i], device="cuda") for i in range(len(calls))]
+    want = [ref.refine_window(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], o, log_scale=(l if i % 2 else None))[:2] for i, (c, l) in enumerate(zip(calls, ls0))]
+    want = [(p.clone(), l.clone()) for p, l in want]
+    torch.cuda.synchronize()
+    e = Engine(H, W, 2 * 3, lanes=2)
+    e.set_coalesce(3); e.set_coalesce_lanes(2)
+    po = [torch.zeros(2, 6, device="cuda") for _ in calls]
+    lo = [torch.zeros(2, device="cuda") for _ in calls]
+    for i, (c, l, p, q) in enumerate(zip(calls, ls0, po, lo)):
+        e.refine_window_scale_queued(c["tgt"], c["srcs"], c["dt"], c["ds"], c["K"], c["pose"], l if i % 2 else None, p, q, o)
+    e.synchronize()
+    assert e.coalesce_counts() == (2, 5)
+    for (wp, wl), p, q in zip(want, po, lo):
+        assert torch.equal(p, wp) and torch.equal(q, wl)
+    assert float(torch.stack(lo).abs().max()) > 1e-4
+    e.set_coalesce_lanes(1); e.set_coalesce(0)

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "tcsfm_set_coalesce_lanes": (C.c_int, [_P, C.c_int]),
     "tcsfm_refine_window_queued": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 7),
     "tcsfm_refine_dense_window_queued": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 8),
+    "tcsfm_refine_window_scale_queued": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_flush": (C.c_int, [_P]),
     "tcsfm_coalesce_counts": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tcsfm_refine_window_async": (C.c_int, [_P, C.c_int, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),

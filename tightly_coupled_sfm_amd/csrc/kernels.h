@@ -301,6 +301,7 @@ constexpr int TC_MAX_COAL = 16;
 struct CoalTab {
     int ncall, cB, cS, pad;
     const float *tgt[TC_MAX_COAL], *src[TC_MAX_COAL], *dt[TC_MAX_COAL], *ds[TC_MAX_COAL], *K[TC_MAX_COAL], *pose[TC_MAX_COAL];
+    const float *ls[TC_MAX_COAL];       // per call: initial log depth-scales of its pairs (TCSFM_REFINE_POSE_SCALE), or null (0)
 };
 struct CoalIdx { int call, bl, s, inv, li; };      // li: the pair's index in ITS call's stacked order
 __device__ __forceinline__ CoalIdx coal_index(int ncall, int cB, int cS, int n) {
@@ -349,7 +350,9 @@ __device__ inline void init_pair(const InitParams &P, int n, const CoalTab *ct =
     for (int i = 0; i < 12; i++) S.Ttry[i] = S.Tcur[i];
     if (P.pose_lin)
         for (int i = 0; i < 12; i++) P.pose_lin[(size_t)n * 12 + i] = S.Tcur[i];          // (iteration 0 reads buffer 0)
-    S.scur = S.stry = S.s0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
+    double ls0 = P.log_scale ? (double)P.log_scale[n] : 0.0;
+    if (ct != nullptr) { const CoalIdx ci = coal_index(ct->ncall, ct->cB, ct->cS, n); ls0 = ct->ls[ci.call] ? (double)ct->ls[ci.call][ci.li] : 0.0; }
+    S.scur = S.stry = S.s0 = ls0;
     S.lambda = (double)P.lambda0;
     S.cost_cur = 0.0;
     S.have_cur = 0;
@@ -1567,6 +1570,7 @@ struct SolveParams {
     // coalesced calls (CoalTab): the refined pose of batch pair n goes to ITS call's output, at the pair's index in that call
     int c_ncall, c_B, c_S, c_pad;
     float *c_pose_out[TC_MAX_COAL];
+    float *c_ls_out[TC_MAX_COAL];       // (np == 7) per call, or null
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -1833,7 +1837,10 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         if (P.c_ncall > 0) { const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n); po = P.c_pose_out[ci.call] + ci.li * 6; }
 #pragma unroll
         for (int i = 0; i < 6; i++) po[i] = pose[i];
-        if (P.log_scale_out) P.log_scale_out[n] = (float)sfin;
+        if (P.c_ncall > 0) {
+            const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n);
+            if (NP == 7 && P.c_ls_out[ci.call]) P.c_ls_out[ci.call][ci.li] = (float)sfin;
+        } else if (P.log_scale_out) P.log_scale_out[n] = (float)sfin;
         if (P.stats && P.mode == 0) {                  // GN: last row = final iterate (its cost is not evaluated)
             float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;
 #pragma unroll

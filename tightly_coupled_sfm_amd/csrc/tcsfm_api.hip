@@ -101,7 +101,8 @@ struct tcsfm_ctx {
     int graph_captures = 0, graph_replays = 0;
     bool capturing = false;
     // tcsfm_refine_window_queued: calls of one shape waiting to run as ONE launch sequence (tcsfm_set_coalesce / tcsfm_flush)
-    struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; float *depth_out; };      // depth_out: dense calls
+    struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; float *depth_out; const float *ls_in; float *ls_out; };
+                                       // depth_out: dense calls; ls_in / ls_out: pose + scale calls (or null)
     float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
     double *pose_lin = nullptr;        // l_pose_consist: [2][max_pairs][12] transforms at the linearisation (k_solve, kernels.h)
     float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
@@ -1265,7 +1266,7 @@ struct FrameCache { const float4 *fpack; const float *fdepth; int slot0, tpos; }
 static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int win_S, const float *tgt, const float *src,
                        const float *depth_t, const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in,
                        float *pose_out, float *log_scale_out, float *stats_out, const WinOff *wo, const FrameCache *fc,
-                       const CoalTab *ct = nullptr, float *const *ct_out = nullptr) {
+                       const CoalTab *ct = nullptr, float *const *ct_out = nullptr, float *const *ct_ls_out = nullptr) {
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (ct) {        // coalesced calls (flush_pending): every array argument comes from the table; device pointers, validated at enqueue
@@ -1320,7 +1321,7 @@ static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
     S.stats = d_stats;
     if (ct) {
         S.c_ncall = ct->ncall; S.c_B = ct->cB; S.c_S = ct->cS;
-        for (int i = 0; i < ct->ncall; i++) S.c_pose_out[i] = ct_out[i];
+        for (int i = 0; i < ct->ncall; i++) { S.c_pose_out[i] = ct_out[i]; S.c_ls_out[i] = ct_ls_out ? ct_ls_out[i] : nullptr; }
     }
     const bool dc = o->w_dc > 0.f;
     const bool lm = o->solver == TCSFM_SOLVER_LM;
@@ -1777,7 +1778,7 @@ static int flush_pending(tcsfm_ctx *h) {
     if (n == 1) {
         const auto &q = calls[0];
         rc = dense ? dense_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, q.pose_out, q.depth_out, nullptr)
-                   : refine_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, nullptr, q.pose_out, nullptr, nullptr);
+                   : refine_impl(c, &o, 2 * B * S, B, S, q.tgt, q.srcs, q.dt, q.ds, q.K, q.pose_in, q.ls_in, q.pose_out, q.ls_out, nullptr);
     } else if (dense) {
         CoalTab ct;
         memset(&ct, 0, sizeof(ct));
@@ -1797,7 +1798,9 @@ static int flush_pending(tcsfm_ctx *h) {
             ct.tgt[i] = calls[i].tgt; ct.src[i] = calls[i].srcs; ct.dt[i] = calls[i].dt; ct.ds[i] = calls[i].ds; ct.K[i] = calls[i].K; ct.pose[i] = calls[i].pose_in;
             outs[i] = calls[i].pose_out;
         }
-        rc = refine_body(c, &o, 2 * B * S * n, B * n, S, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ct, outs);
+        float *louts[TC_MAX_COAL];
+        for (int i = 0; i < n; i++) { ct.ls[i] = calls[i].ls_in; louts[i] = calls[i].ls_out; }
+        rc = refine_body(c, &o, 2 * B * S * n, B * n, S, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ct, outs, louts);
     }
     if (c != h) {
         if (rc) { h->err = c->err; return rc; }
@@ -1841,13 +1844,19 @@ int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls) {
 
 int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
                                const float *depth_s, const float *K, const float *pose_in, float *pose_out) {
+    return tcsfm_refine_window_scale_queued(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, nullptr, pose_out, nullptr);
+}
+
+int tcsfm_refine_window_scale_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs, const float *depth_t,
+                                     const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
+                                     float *log_scale_out) {
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: need 1 <= 2*B*S <= max_pairs");
     int rc = check_common(h, o, 2 * B * S);
     if (rc) return rc;
     if (!tgt || !srcs || !depth_t || !depth_s || !K || !pose_in || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: NULL argument");
-    if (o->host_ptrs || o->refine != TCSFM_REFINE_POSE)
-        return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: device pointers and TCSFM_REFINE_POSE only");
+    if (o->host_ptrs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: device pointers only");
+    if (o->refine != TCSFM_REFINE_POSE_SCALE) { log_scale_in = nullptr; log_scale_out = nullptr; }
     // the REFERENCE rule couples the windows of a call through its batch normalisers: such calls are never merged with others
     const bool mergeable = h->coal_max > 1 && o->window_rule == TCSFM_WINDOW_PAIR && !h->trace_bits && !h->trace_decide && !h->profiling;
     DeviceGuard dev_guard(h->device);
@@ -1856,7 +1865,7 @@ int tcsfm_refine_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S
                                 (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs))
         if ((rc = flush_pending(h))) return rc;
     h->pend_opts = *o; h->pend_B = B; h->pend_S = S; h->pend_dense = 0;
-    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, nullptr});
+    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, nullptr, log_scale_in, log_scale_out});
     if (!mergeable || (int)h->pending.size() >= h->coal_max || (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs)
         return flush_pending(h);
     return TCSFM_OK;
@@ -1884,7 +1893,7 @@ int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B,
                                 (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs))
         if ((rc = flush_pending(h))) return rc;
     h->pend_opts = *o; h->pend_B = B; h->pend_S = S; h->pend_dense = 1;
-    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out});
+    h->pending.push_back({tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, nullptr, nullptr});
     if ((int)h->pending.size() >= h->coal_max || (long long)2 * B * S * ((long long)h->pending.size() + 1) > h->max_pairs)
         return flush_pending(h);
     return TCSFM_OK;

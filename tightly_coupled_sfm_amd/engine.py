@@ -444,6 +444,12 @@ class Engine:
         self._call(self.lib.tcsfm_refine_window_queued(self._h, C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
                                                        self._p(K), self._p(pose), self._p(pose_out)))
 
+    def refine_window_scale_queued(self, tgt, srcs, depth_t, depth_s, K, pose, log_scale, pose_out, log_scale_out, opts: Opts):
+        """tcsfm_refine_window_scale_queued: refine_window_queued with the depth-scale unknown (opts.refine = REFINE_POSE_SCALE)"""
+        S, B = int(srcs.shape[0]), int(srcs.shape[1])
+        self._call(self.lib.tcsfm_refine_window_scale_queued(self._h, C.byref(opts), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                                             self._p(K), self._p(pose), self._p(log_scale), self._p(pose_out), self._p(log_scale_out)))
+
     def refine_dense_window_queued(self, tgt, srcs, depth_t, depth_s, K, pose, pose_out, depth_out, opts: Opts):
         """tcsfm_refine_dense_window_queued: the dense counterpart of refine_window_queued (window layout of refine_dense_window; depth_out
         [2*S*B,1,H,W]); per-pair Gauss-Newton calls with one source per target are merged, anything else runs at once"""
