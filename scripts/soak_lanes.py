@@ -35,7 +35,7 @@ torch.cuda.synchronize()
 mem0 = None
 t0 = time.time(); n = 0
 while time.time() - t0 < SECONDS:
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 7)
     if kind == 0:      # three pose windows in flight
         ws = rng.integers(0, T - 1, size=3)
         for l, w in enumerate(ws):
@@ -71,6 +71,16 @@ while time.time() - t0 < SECONDS:
         e.synchronize()
         for w, out in zip(ws, outs):
             check(("pose", int(w)), [out])
+        e.set_coalesce_lanes(1); e.set_coalesce(0)
+    elif kind == 6:    # round 4: queued DENSE calls merged by the library (per-pair Gauss-Newton, one source per target)
+        e.set_coalesce(2); e.set_coalesce_lanes(int(rng.integers(1, 4)))
+        ws = rng.integers(0, T - 1, size=int(rng.integers(1, 6)))
+        pq = [torch.empty(2, 6, device="cuda") for _ in ws]; dq = [torch.empty(2, 1, H, W, device="cuda") for _ in ws]
+        for w, p_, d_ in zip(ws, pq, dq):
+            e.refine_dense_window_queued(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], p_, d_, od)
+        e.synchronize()
+        for w, p_, d_ in zip(ws, pq, dq):
+            check(("dense", int(w)), [p_, d_])
         e.set_coalesce_lanes(1); e.set_coalesce(0)
     elif kind == 5:    # round 4: dense window on the reference's loss, full- and quarter-resolution unknown
         w = int(rng.integers(0, T - 1)); q = int(rng.integers(0, 2))

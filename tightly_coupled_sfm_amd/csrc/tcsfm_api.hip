@@ -556,6 +556,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     Dn.dense_rec = h->dense_rec + (size_t)SB * hw * 8; Dn.depth0 = h->depth0 + (size_t)SB * hw; Dn.lambda_depth = o->lambda_depth; Dn.w_prior = o->prior_depth;
     Dn.prev_rec = nullptr; Dn.prev_delta = h->delta; Dn.depth_next = nullptr; Dn.rho_lo = Uj.rho_lo; Dn.rho_hi = Uj.rho_hi;
     DenseUpdateParams Ui;
+    memset(&Ui, 0, sizeof(Ui));          // (no coalesce table: c_ncall = 0)
     Ui.dense_rec = Dn.dense_rec; Ui.delta = Si.delta_out; Ui.depth = h->depth_work + (size_t)SB * hw; Ui.depth_out = h->depth_work + (size_t)SB * hw; Ui.hw = (int)hw;
     Ui.rho_lo = Uj.rho_lo; Ui.rho_hi = Uj.rho_hi;
     DenseLmParams Ul;
