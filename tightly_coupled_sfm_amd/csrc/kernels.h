@@ -226,12 +226,15 @@ __device__ __forceinline__ void geo_jac(const PairConst &c, const Geo &g, int W,
         dp0[6] = c.fx * q0 + c.cx * q2; dp1[6] = c.fy * q1 + c.cy * q2; dp2[6] = q2;
     }
     float sa = g.oobx ? 0.f : cw * g.iz, sb = g.ooby ? 0.f : ch * g.iz, zf = g.zcl ? 0.f : 1.f;
+    // Columns 0, 1, 5 (translation along x / y, rotation about the optical axis) do not change the depth: their dz is a literal zero,
+    // not a product the compiler has to keep (x * 0 does not fold under IEEE rules).  Same values as the general expression.
 #pragma unroll
     for (int j = 0; j < NP; j++) {
-        float dz = zf * dp2[j];
+        const bool nz = (j == 2 || j == 3 || j == 4 || j == 6);
+        float dz = nz ? zf * dp2[j] : 0.f;
         zc[j] = dz;
-        a[j] = sa * (dp0[j] - g.uz * dz);
-        b[j] = sb * (dp1[j] - g.vz * dz);
+        a[j] = nz ? sa * (dp0[j] - g.uz * dz) : sa * dp0[j];
+        b[j] = nz ? sb * (dp1[j] - g.vz * dz) : sb * dp1[j];
     }
 }
 
@@ -828,6 +831,28 @@ __device__ __forceinline__ void lds_wait0(f32x4 &a, f32x4 &b, f32x4 &c) { asm vo
 __device__ __forceinline__ void lds_issue02v(const float4 *p, f32x4 &a, f32x4 &c) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32" : "=&v"(a), "=&v"(c) : "v"(lds_addr(p)) : "memory");
 }
+// Reads at a compile-time byte offset from a base address (the offset rides in the instruction: no address arithmetic; DS offsets are
+// unsigned 16-bit) and counted waits for the software-pipelined neighbour passes: colour part (floats 0..11) / Jacobian part (12..23).
+template <int OFF>
+__device__ __forceinline__ void lds_issue3c_at(unsigned addr, f32x4 &a, f32x4 &b, f32x4 &c) {
+    asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(addr), "i"(OFF), "i"(OFF + 16), "i"(OFF + 32) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_issue3j_at(unsigned addr, f32x4 &a, f32x4 &b, f32x4 &c) {
+    asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(addr), "i"(OFF + 48), "i"(OFF + 64), "i"(OFF + 80) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_waitn(f32x4 &a, f32x4 &b, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "i"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void lds_waitn(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f) {
+    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "i"(N) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_issue02v_at(unsigned addr, f32x4 &a, f32x4 &c) {       // record floats 0..3 and 8..11
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(a), "=&v"(c) : "v"(addr), "i"(OFF), "i"(OFF + 32) : "memory");
+}
 __device__ __forceinline__ void lds_wait2(f32x4 &a, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(c) : : "memory"); }
 __device__ __forceinline__ void lds_wait0(f32x4 &a, f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(c) : : "memory"); }
 __device__ __forceinline__ float4 lds_read1(const float4 *p) {
@@ -919,7 +944,14 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
     using L = AccLayout<NP>;
     constexpr int NPH = L::NH + NP;
     const int wave = tid >> 6, lane = tid & 63;
+#ifdef TC_PROBE_NOREDUCE      // timing-only build (WRONG sums): what the wave butterfly costs (profiles/r04_reduce_probe.txt)
+    { float s_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < NLIVE; i++) s_ += v[i];
+      if (lane < NLIVE) red[wave * L::NACC + lane] = s_; }
+#else
     wave_reduce_store<NLIVE>(v, red + wave * L::NACC, lane);
+#endif
     __syncthreads();
     // A single workgroup can only pull ~6 GB/s of freshly written records (measured: 110 KB = 480 records in 19 us), so the
     // solve kernel must not read one record per workgroup.  Groups of RG consecutive workgroups reduce themselves: every
@@ -985,6 +1017,17 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
 // extra LDS) than an exactly separable form could: a measured upper bound on what that form can buy.  Production builds: 9.
 #ifndef TC_PROBE_PASSA_VISITS
 #define TC_PROBE_PASSA_VISITS 9
+#endif
+// Software-pipelined neighbour passes (round 4, second session): 1 = production; 0 = the rolled loops they replace (A/B builds).
+// TC_PASSB_J2 = 1 double-buffers the Jacobian parts of pass B as well: measured no faster (profiles/r04_lds_pipeline_ab.txt), default off.
+#ifndef TC_PASSA_PIPELINED
+#define TC_PASSA_PIPELINED 1
+#endif
+#ifndef TC_PASSB_PIPELINED
+#define TC_PASSB_PIPELINED 1
+#endif
+#ifndef TC_PASSB_J2
+#define TC_PASSB_J2 0
 #endif
 template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
@@ -1067,6 +1110,29 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
                 f2 Sy01 = {0.f, 0.f}, Sx01 = {0.f, 0.f}, Syy01 = {0.f, 0.f}, Sxx01 = {0.f, 0.f}, Sxy01 = {0.f, 0.f}, S2 = {0.f, 0.f}, SS2 = {0.f, 0.f};
                 float Sxy2 = 0.f;
+#if TC_PASSA_PIPELINED
+                {   // software-pipelined like pass A of phase 2 (same operations in the same order)
+                    constexpr int RB = LDS_REC * 4, ROWB = CW * LDS_REC * 4;
+                    const unsigned base = lds_addr(nb);
+                    f32x4 u0, u2, w0, w2;
+                    auto more = [&](const f32x4 &n0, const f32x4 &n2) {
+                        f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01), e2v = pk_sub(n2.lo, yx2c);
+                        Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+                        S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
+                    };
+                    lds_issue02v_at<0>(base, u0, u2);
+                    lds_issue02v_at<RB>(base, w0, w2);
+                    lds_wait2(u0, u2); more(u0, u2); lds_issue02v_at<2 * RB>(base, u0, u2);
+                    lds_wait2(w0, w2); more(w0, w2); lds_issue02v_at<ROWB>(base, w0, w2);
+                    lds_wait2(u0, u2); more(u0, u2); lds_issue02v_at<ROWB + RB>(base, u0, u2);
+                    lds_wait2(w0, w2); more(w0, w2); lds_issue02v_at<ROWB + 2 * RB>(base, w0, w2);
+                    lds_wait2(u0, u2); more(u0, u2); lds_issue02v_at<2 * ROWB>(base, u0, u2);
+                    lds_wait2(w0, w2); more(w0, w2); lds_issue02v_at<2 * ROWB + RB>(base, w0, w2);
+                    lds_wait2(u0, u2); more(u0, u2); lds_issue02v_at<2 * ROWB + 2 * RB>(base, u0, u2);
+                    lds_wait2(w0, w2); more(w0, w2);
+                    lds_wait0(u0, u2); more(u0, u2);
+                }
+#else
 #pragma unroll 1
                 for (int kk = 0; kk < 9; kk++) {
                     f32x4 n0, n2;
@@ -1076,6 +1142,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                     Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
                     S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
                 }
+#endif
                 const f2 e01 = ssim_l1_value<f2>(xc01, yc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl);
                 const float d_o = e01.x + e01.y + ssim_l1_value<float>(yx2c.y, yx2c.x, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl);
                 if (so < s_own) sel_before = fminf(sel_before, d_o); else sel_after = fminf(sel_after, d_o);
@@ -1111,17 +1178,19 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float a[NP], b[NP], zc[NP];
         if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
         float4 *rec = lds + (S.ly * CW + S.lx) * (LDS_REC / 4);
-        // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0..a3][a4 a5 b0 b1][b2..b5]([a6 b6 - -]) : channel pairs and
-        // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles
+        // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0 b1 a2 a3][a4 a5 b2 b3][b4 b5 (a6 b6)] : channel pairs and
+        // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles.
+        // a1 = d ix / d rho_y and b0 = d iy / d rho_x are STRUCTURALLY zero (pinhole K: a translation along y moves the sample along
+        // iy only, see geo_jac), so they are not staged: (a0, b1) travel as one pair -- pass B spends one packed FMA on columns (0,1)
+        // instead of two -- and the seventh column of the pose + depth-scale mode takes their place (six 16-byte rows for NP = 7 too)
         if (write) {
             lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
             if (MODE == MODE_LIN) {
                 lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
                 lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
-                lds_write1(rec + 3, a[0], a[1], a[2], a[3]);
-                lds_write1(rec + 4, a[4], a[5], b[0], b[1]);
-                lds_write1(rec + 5, b[2], b[3], b[4], b[5]);
-                if (NP == 7) lds_write1(rec + 6, a[NP - 1], b[NP - 1], 0.f, 0.f);
+                lds_write1(rec + 3, a[0], b[1], a[2], a[3]);
+                lds_write1(rec + 4, a[4], a[5], b[2], b[3]);
+                lds_write1(rec + 5, b[4], b[5], NP == 7 ? a[NP - 1] : 0.f, NP == 7 ? b[NP - 1] : 0.f);
             } else {
                 lds_write1(rec + 2, val.z, S.tp.z, 0.f, 0.f);
             }
@@ -1194,6 +1263,47 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, S2, SS2;
         float Sxy2;
         f2 aGx01 = {0.f, 0.f}, aGy01 = {0.f, 0.f}, aG2s = {0.f, 0.f};   // ADJ: 3x3 sums of the image gradients (curvature model), taken here
+#if TC_PASSA_PIPELINED
+        if (!ADJL && TC_PROBE_PASSA_VISITS == 9) {
+            // Software-pipelined form: the reads of window position k + 1 are in flight while position k is accumulated (two register
+            // sets, counted waits: LDS returns in order), and every position is a compile-time offset from the window's first record,
+            // so the walk costs no address arithmetic.  Same operations on the same values in the same order as the rolled loop below.
+            constexpr int RB = LDS_REC * 4, ROWB = CW * LDS_REC * 4;      // bytes per record / per row of records
+            const unsigned base = lds_addr(nbA);
+            f32x4 u0, u2, w0, w2;
+            auto first = [&](const f32x4 &n0, const f32x4 &n2) {
+                Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
+                Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
+                S2 = pk_sub(n2.lo, yx2c);            // (y2 - y2c, x2 - x2c)
+                SS2 = S2 * S2; Sxy2 = S2.x * S2.y;
+            };
+            auto more = [&](const f32x4 &n0, const f32x4 &n2) {
+                f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+                Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+                f2 e2v = pk_sub(n2.lo, yx2c);
+                S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
+            };
+            lds_issue02v_at<0>(base, u0, u2);
+            lds_issue02v_at<RB>(base, w0, w2);
+            lds_wait2(u0, u2); first(u0, u2);
+            lds_issue02v_at<2 * RB>(base, u0, u2);
+            lds_wait2(w0, w2); more(w0, w2);
+            lds_issue02v_at<ROWB>(base, w0, w2);
+            lds_wait2(u0, u2); more(u0, u2);
+            lds_issue02v_at<ROWB + RB>(base, u0, u2);
+            lds_wait2(w0, w2); more(w0, w2);
+            lds_issue02v_at<ROWB + 2 * RB>(base, w0, w2);
+            lds_wait2(u0, u2); more(u0, u2);
+            lds_issue02v_at<2 * ROWB>(base, u0, u2);
+            lds_wait2(w0, w2); more(w0, w2);
+            lds_issue02v_at<2 * ROWB + RB>(base, w0, w2);
+            lds_wait2(u0, u2); more(u0, u2);
+            lds_issue02v_at<2 * ROWB + 2 * RB>(base, u0, u2);
+            lds_wait2(w0, w2); more(w0, w2);
+            lds_wait0(u0, u2); more(u0, u2);
+        } else
+#endif
+        {
         {
             f32x4 n0, n1 = {0.f, 0.f, 0.f, 0.f}, n2;
             if (ADJL) lds_read3v(nbA, n0, n1, n2); else lds_read02v(nbA, n0, n2);
@@ -1214,6 +1324,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             f2 e2v = pk_sub(n2.lo, yx2c);
             S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
             if (ADJL) { aGx01 += n1.lo; aGy01 += n1.hi; aG2s += n2.hi; }
+        }
         }
         // per-channel SSIM value / gradient coefficients / curvature weights and the L1 term: channels (0,1) as one packed
         // evaluation, channel 2 as a scalar one (same code, ssim_l1_channel<T>)
@@ -1343,8 +1454,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 const float rsx = live * (tx.x + tx.y + lam2 * r2.z), rsy = live * (ty.x + ty.y + lam2 * r2.w);
                 f32x4 q3, q4, q5;
                 lds_read3bv(lds + (rly * CW + rlx) * (LDS_REC / 4), q3, q4, q5);
-                ring_g2[0] = rsx * q3.lo + rsy * q4.hi; ring_g2[1] = rsx * q3.hi + rsy * q5.lo; ring_g2[2] = rsx * q4.lo + rsy * q5.hi;
-                if (NP == 7) { float4 q6 = lds_read1(lds + (rly * CW + rlx) * (LDS_REC / 4) + 6); ring_g6 = rsx * q6.x + rsy * q6.y; }
+                ring_g2[0] = rsx * f2{q3.x, 0.f} + rsy * f2{0.f, q3.y}; ring_g2[1] = rsx * q3.hi + rsy * q4.hi; ring_g2[2] = rsx * q4.lo + rsy * q5.lo;
+                if (NP == 7) ring_g6 = rsx * q5.z + rsy * q5.w;
             }
         }
         if (!ADJL && MODE == MODE_LIN && __builtin_amdgcn_ballot_w64(m) != 0ull) {
@@ -1356,6 +1467,72 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             const float cA2 = cA[2] - cB[2] * yx2c.x - cC[2] * yx2c.y;
             f2 Gx01 = {0.f, 0.f}, Gy01 = {0.f, 0.f}, G2 = {0.f, 0.f};   // 3x3 sums of the image gradients (curvature model)
             const float4 *nb = ctr - (CW + 1) * (LDS_REC / 4);
+#if TC_PASSB_PIPELINED
+            {
+                // Software-pipelined over the nine window positions (unrolled; every position is a compile-time offset from the window's
+                // first record): two register sets for the colour / gradient parts -- position k + 2's is requested as soon as position
+                // k's has been consumed -- and one for the Jacobian parts, requested a position ahead.  Issue order C0 C1 J0 | C2 J1 | C3 J2 ...;
+                // LDS returns in order, so ONE counted wait per position (lgkmcnt(3): everything but the newest colour request) covers
+                // the Jacobians of this position and the colours of the next.  Same operations on the same values in the same order
+                // as the rolled loop below: bit-identical results.
+                constexpr int RB = LDS_REC * 4, ROWB = CW * LDS_REC * 4;
+                const unsigned base = lds_addr(nb);
+                f32x4 A0, A1, A2, B0, B1, B2, J3, J4, J5;
+                float sx, sy;
+                auto colour = [&](const f32x4 &n0, const f32x4 &n1, const f32x4 &n2) {
+                    Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
+                    f2 cf = cA01 + cB01 * n0.lo + cC01 * n0.hi;
+                    float cf2 = cA2 + cB[2] * n2.x + cC[2] * n2.y;
+                    f2 tx = cf * n1.lo, ty = cf * n1.hi;
+                    sx = tx.x + tx.y + cf2 * n2.z; sy = ty.x + ty.y + cf2 * n2.w;
+                };
+                auto rows = [&](const f32x4 &n3, const f32x4 &n4, const f32x4 &n5) {
+                    const f2 sxy = {sx, sy};
+                    de2[0] += sxy * n3.lo;                          // (sx a0, sy b1): a1 = b0 = 0
+                    de2[1] += sx * n3.hi; de2[1] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
+                    de2[2] += sx * n4.lo; de2[2] += sy * n5.lo;
+                    if (NP == 7) de6 += sx * n5.z + sy * n5.w;
+                };
+#define TC_POS(k) (((k) / 3) * ROWB + ((k) % 3) * RB)
+#if TC_PASSB_J2
+                // Jacobian parts double-buffered as well (two positions ahead): issue order C0 C1 J0 J1 | C2 J2 | C3 J3 | ...; at most 12 reads in flight
+                f32x4 K3, K4, K5;
+                lds_issue3c_at<TC_POS(0)>(base, A0, A1, A2);
+                lds_issue3c_at<TC_POS(1)>(base, B0, B1, B2);
+                lds_issue3j_at<TC_POS(0)>(base, J3, J4, J5);
+                lds_issue3j_at<TC_POS(1)>(base, K3, K4, K5);
+                lds_waitn<9>(A0, A1, A2);
+                colour(A0, A1, A2); lds_issue3c_at<TC_POS(2)>(base, A0, A1, A2); lds_waitn<6>(J3, J4, J5, B0, B1, B2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(2)>(base, J3, J4, J5);
+                colour(B0, B1, B2); lds_issue3c_at<TC_POS(3)>(base, B0, B1, B2); lds_waitn<9>(K3, K4, K5);             rows(K3, K4, K5); lds_issue3j_at<TC_POS(3)>(base, K3, K4, K5);
+#define TC_STEP(CA, CB, CC, JA, JB, JC, k) lds_waitn<9>(CA, CB, CC); colour(CA, CB, CC); lds_issue3c_at<TC_POS((k) + 2)>(base, CA, CB, CC); \
+                lds_waitn<9>(JA, JB, JC); rows(JA, JB, JC); lds_issue3j_at<TC_POS((k) + 2)>(base, JA, JB, JC);
+                TC_STEP(A0, A1, A2, J3, J4, J5, 2)
+                TC_STEP(B0, B1, B2, K3, K4, K5, 3)
+                TC_STEP(A0, A1, A2, J3, J4, J5, 4)
+                TC_STEP(B0, B1, B2, K3, K4, K5, 5)
+                TC_STEP(A0, A1, A2, J3, J4, J5, 6)
+#undef TC_STEP
+                // outstanding: C7 J7 C8 J8
+                lds_waitn<9>(B0, B1, B2); colour(B0, B1, B2); lds_waitn<6>(K3, K4, K5); rows(K3, K4, K5);
+                lds_waitn<3>(A0, A1, A2); colour(A0, A1, A2); lds_waitn<0>(J3, J4, J5); rows(J3, J4, J5);
+#else
+                lds_issue3c_at<TC_POS(0)>(base, A0, A1, A2);
+                lds_issue3c_at<TC_POS(1)>(base, B0, B1, B2);
+                lds_issue3j_at<TC_POS(0)>(base, J3, J4, J5);
+                lds_waitn<6>(A0, A1, A2);
+                colour(A0, A1, A2); lds_issue3c_at<TC_POS(2)>(base, A0, A1, A2); lds_waitn<3>(J3, J4, J5, B0, B1, B2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(1)>(base, J3, J4, J5);
+                colour(B0, B1, B2); lds_issue3c_at<TC_POS(3)>(base, B0, B1, B2); lds_waitn<3>(J3, J4, J5, A0, A1, A2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(2)>(base, J3, J4, J5);
+                colour(A0, A1, A2); lds_issue3c_at<TC_POS(4)>(base, A0, A1, A2); lds_waitn<3>(J3, J4, J5, B0, B1, B2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(3)>(base, J3, J4, J5);
+                colour(B0, B1, B2); lds_issue3c_at<TC_POS(5)>(base, B0, B1, B2); lds_waitn<3>(J3, J4, J5, A0, A1, A2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(4)>(base, J3, J4, J5);
+                colour(A0, A1, A2); lds_issue3c_at<TC_POS(6)>(base, A0, A1, A2); lds_waitn<3>(J3, J4, J5, B0, B1, B2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(5)>(base, J3, J4, J5);
+                colour(B0, B1, B2); lds_issue3c_at<TC_POS(7)>(base, B0, B1, B2); lds_waitn<3>(J3, J4, J5, A0, A1, A2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(6)>(base, J3, J4, J5);
+                colour(A0, A1, A2); lds_issue3c_at<TC_POS(8)>(base, A0, A1, A2); lds_waitn<3>(J3, J4, J5, B0, B1, B2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(7)>(base, J3, J4, J5);
+                colour(B0, B1, B2);                                               lds_waitn<0>(J3, J4, J5, A0, A1, A2); rows(J3, J4, J5); lds_issue3j_at<TC_POS(8)>(base, J3, J4, J5);
+                colour(A0, A1, A2);                                               lds_waitn<0>(J3, J4, J5);             rows(J3, J4, J5);
+#endif
+#undef TC_POS
+            }
+#else
 #pragma unroll 1
             for (int kk = 0; kk < 9; kk++) {
                 f32x4 n0, n1, n2, n3, n4, n5;
@@ -1367,12 +1544,14 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 f2 tx = cf * n1.lo, ty = cf * n1.hi;
                 float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
                 lds_wait0(n3, n4, n5);
-                de2[0] += sx * n3.lo; de2[0] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
-                de2[1] += sx * n3.hi; de2[1] += sy * n5.lo;
-                de2[2] += sx * n4.lo; de2[2] += sy * n5.hi;
-                if (NP == 7) { float4 n6 = lds_read1(nb + 6); de6 += sx * n6.x + sy * n6.y; }
+                const f2 sxy = {sx, sy};
+                de2[0] += sxy * n3.lo;                          // (sx a0, sy b1): a1 = b0 = 0
+                de2[1] += sx * n3.hi; de2[1] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
+                de2[2] += sx * n4.lo; de2[2] += sy * n5.lo;
+                if (NP == 7) de6 += sx * n5.z + sy * n5.w;
                 nb += (kk == 2 || kk == 5) ? (CW - 2) * (LDS_REC / 4) : (LDS_REC / 4);
             }
+#endif
             {   // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1, Cov ~ 9/8 (g - mean)(g - mean)' (centre sample)
                 const float n9 = 1.f / 9.f;
                 const f2 mx = Gx01 * n9, my = Gy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
@@ -1413,9 +1592,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             // own geometric Jacobian (centre record), as column pairs
             f32x4 q3, q4, q5;
             lds_read3bv(ctr, q3, q4, q5);
-            const f2 a2[3] = {q3.lo, q3.hi, q4.lo}, b2[3] = {q4.hi, q5.lo, q5.hi};
+            const f2 a2[3] = {f2{q3.x, 0.f}, q3.hi, q4.lo}, b2[3] = {f2{0.f, q3.y}, q4.hi, q5.lo};
             float a6 = 0.f, b6 = 0.f;
-            if (NP == 7) { float4 q6 = lds_read1(ctr + 6); a6 = q6.x; b6 = q6.y; }
+            if (NP == 7) { a6 = q5.z; b6 = q5.w; }
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
             float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;

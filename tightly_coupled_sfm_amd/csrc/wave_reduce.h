@@ -83,6 +83,17 @@ __device__ __forceinline__ void wave_reduce64(float *v, int lane) {
     halve<4, 4>(v, lane);
     halve<2, 8>(v, lane);
 }
+// 8 values: index slot8(lane) = bits (5,4,0); the xor 2, 4, 8 steps are plain reductions.  Every width combines the lanes in the same
+// order (32, 16, 1, 2, 4, 8), so a value's sum does not depend on which chunk carries it.
+__device__ __forceinline__ int slot8(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + (lane & 1); }
+__device__ __forceinline__ void wave_reduce8(float *v, int lane) {
+    halve<8, 32>(v, lane);
+    halve<4, 16>(v, lane);
+    halve<2, 1>(v, lane);
+    v[0] += dpp_xor<2>(v[0]);
+    v[0] += dpp_xor<4>(v[0]);
+    v[0] += dpp_xor<8>(v[0]);
+}
 // 4 values (cost-only mode): index slot4(lane) = bits (5,4); the in-row part is a plain reduction
 __device__ __forceinline__ int slot4(int lane) { return ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1); }
 __device__ __forceinline__ void wave_reduce4(float *v, int lane) {
@@ -98,7 +109,15 @@ __device__ __forceinline__ void wave_reduce4(float *v, int lane) {
 template <int NLIVE, int BASE = 0>
 __device__ __forceinline__ void wave_reduce_store(const float *vals, float *dst, int lane) {
     constexpr int REM = NLIVE - BASE;
-    if constexpr (REM > 32) {
+    if constexpr (REM > 32 && REM <= 40) {          // 33..40 values (pose + depth scale: 38): a 32-chunk and an 8-chunk, not a 64-chunk
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) v[i] = vals[BASE + i];
+        wave_reduce32(v, lane);
+        const int s = slot32(lane);
+        if (!(lane & 8)) dst[BASE + s] = v[0];
+        wave_reduce_store<NLIVE, BASE + 32>(vals, dst, lane);
+    } else if constexpr (REM > 32) {
         float v[64];
 #pragma unroll
         for (int i = 0; i < 64; i++) v[i] = (i < REM) ? vals[BASE + i] : 0.f;
@@ -106,6 +125,13 @@ __device__ __forceinline__ void wave_reduce_store(const float *vals, float *dst,
         const int s = slot64(lane);
         if (s < REM) dst[BASE + s] = v[0];
         wave_reduce_store<NLIVE, BASE + 64>(vals, dst, lane);
+    } else if constexpr (REM > 4 && REM <= 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (i < REM) ? vals[BASE + i] : 0.f;
+        wave_reduce8(v, lane);
+        const int s = slot8(lane);
+        if (s < REM && !(lane & 14)) dst[BASE + s] = v[0];
     } else if constexpr (REM > 4) {
         float v[32];
 #pragma unroll
