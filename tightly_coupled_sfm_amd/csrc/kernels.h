@@ -176,8 +176,13 @@ __device__ __forceinline__ void tap4_fetch(const float4 *__restrict__ img, int W
     xi = oob ? -2 : xi;                                         // both columns clamp to the left border: all four taps are zero
     const int x0 = min(max(xi, -1), W) + 1, x1 = min(max(xi + 1, -1), W) + 1;   // bordered coordinates 0 .. W+1
     const int y0 = min(max(yi, -1), H) + 1, y1 = min(max(yi + 1, -1), H) + 1;
-    const int WB = W + 2;
-    t.v00 = img[y0 * WB + x0]; t.v01 = img[y0 * WB + x1]; t.v10 = img[y1 * WB + x0]; t.v11 = img[y1 * WB + x1];
+    // 32-bit byte offsets from the (wave-uniform) image base: the loads take the base in an SGPR pair and the offset in one VGPR instead
+    // of a sign-extended 64-bit address per tap (a bordered image is (H + 2)(W + 2) 16 B < 4 GB)
+    const unsigned WB = (unsigned)(W + 2);
+    const char *base = reinterpret_cast<const char *>(img);
+    const unsigned r0 = (unsigned)y0 * WB, r1 = (unsigned)y1 * WB;
+    t.v00 = *reinterpret_cast<const float4 *>(base + ((r0 + (unsigned)x0) << 4)); t.v01 = *reinterpret_cast<const float4 *>(base + ((r0 + (unsigned)x1) << 4));
+    t.v10 = *reinterpret_cast<const float4 *>(base + ((r1 + (unsigned)x0) << 4)); t.v11 = *reinterpret_cast<const float4 *>(base + ((r1 + (unsigned)x1) << 4));
 }
 // bilinear value and d/dix, d/diy of the four channels
 __device__ __forceinline__ void tap4_lerp(const Tap &t, float4 &val, float4 &gx, float4 &gy) {
@@ -803,6 +808,20 @@ __device__ __forceinline__ void lds_read3bv(const float4 *p, f32x4 &a, f32x4 &b,
     asm volatile("ds_read_b128 %0, %3 offset:48\n\tds_read_b128 %1, %3 offset:64\n\tds_read_b128 %2, %3 offset:80\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(lds_addr(p)) : "memory");
 }
+// Packed multiply / FMA with ONE half of `s` broadcast over both halves of `v` (HI = 0: s.x, 1: s.y).  hipcc broadcasts a low half through
+// op_sel_hi but copies a HIGH half into a low one first (one v_mov per use); the modifiers select it in place.
+template <int HI>
+__device__ __forceinline__ f2 pk_mul_b(f2 s, f2 v) {
+    f2 r;
+    if (HI) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(s), "v"(v));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(s), "v"(v));
+    return r;
+}
+template <int HI>
+__device__ __forceinline__ void pk_fma_b(f2 &d, f2 s, f2 v) {      // d += s.{x|y} * v
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(s), "v"(v));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(d) : "v"(s), "v"(v));
+}
 // a - b on both halves in ONE instruction (hipcc lowers a float2 subtraction to two v_sub_f32)
 __device__ __forceinline__ f2 pk_sub(f2 a, f2 b) {
     f2 r;
@@ -883,6 +902,17 @@ template <class T> __device__ __forceinline__ T vsplat(float a);
 template <> __device__ __forceinline__ float vsplat<float>(float a) { return a; }
 template <> __device__ __forceinline__ f2 vsplat<f2>(float a) { return (f2){a, a}; }
 
+// clamp(a, 0, 1) in one instruction (v_med3_f32), and wl * sign(r) for 0 < |r| <= 1, else 0, with integer compares / bit operations
+// (full-rate) in place of three float compares and three selects: |r| lies in (0, 1] exactly when its bit pattern lies in
+// [1, 0x3f800000] (non-negative floats order like their bit patterns; NaN patterns are larger: no sign, as before).
+__device__ __forceinline__ float vclamp01(float a) { return __builtin_amdgcn_fmed3f(a, 0.f, 1.f); }
+__device__ __forceinline__ f2 vclamp01(f2 a) { return (f2){__builtin_amdgcn_fmed3f(a.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(a.y, 0.f, 1.f)}; }
+__device__ __forceinline__ float l1_sign(float r, float ar, float wl) {
+    const bool in = (__float_as_uint(ar) - 1u) < 0x3f800000u;
+    return in ? __uint_as_float(__float_as_uint(wl) ^ (__float_as_uint(r) & 0x80000000u)) : 0.f;
+}
+__device__ __forceinline__ f2 l1_sign(f2 r, f2 ar, float wl) { return (f2){l1_sign(r.x, ar.x, wl), l1_sign(r.y, ar.y, wl)}; }
+
 template <class T>
 struct ChanTerms {
     T e1, e2;          // w_l1/3 |y-x|.clamp(0,1),  w_ssim/3 SSIM            (train_mono.py:87, losses.py:27-41)
@@ -904,8 +934,9 @@ __device__ __forceinline__ void ssim_l1_channel(T xc, T yc, T gxc, T gyc, T Sx, 
     T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
     T idn = vrcp(d1 * d2), ratio = n1 * n2 * idn;
     T raw = (one - ratio) * 0.5f;
-    auto cl = (raw < zero) || (raw > one);
-    o.e2 = ws * vmin(vmax(raw, zero), one);
+    const T rawc = vclamp01(raw);
+    auto cl = rawc != raw;                         // clamped: the value is a constant there (no gradient)
+    o.e2 = ws * rawc;
     T pre = vsel(cl, zero, idn * (-0.5f * n9 * ws));
     o.cB = pre * (ratio * d1) * -2.f;
     o.cC = pre * n1 * 2.f;
@@ -916,7 +947,7 @@ __device__ __forceinline__ void ssim_l1_channel(T xc, T yc, T gxc, T gyc, T Sx, 
     T rr = yc - xc, ar = vabs(rr);
     auto inr = ar <= one;
     o.e1 = wl * vmin(ar, one);
-    T sgn = vsel(inr, vsel(rr > zero, one, vsel(rr < zero, -one, zero)), zero) * wl;
+    T sgn = l1_sign(rr, ar, wl);                   // wl sign(rr) inside 0 < |rr| <= 1, else 0
     o.l1x = sgn * gxc; o.l1y = sgn * gyc;
     T w1 = vsel(inr, wl * vrcp(vmax(ar, vsplat<T>(eps))), zero);
     o.lxx = w1 * gxc * gxc; o.lxy = w1 * gxc * gyc; o.lyy = w1 * gyc * gyc;
@@ -933,7 +964,7 @@ __device__ __forceinline__ T ssim_l1_value(T xc, T yc, T Sx, T Sy, T Sxx, T Syy,
     T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
     T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
     T raw = (one - n1 * n2 * vrcp(d1 * d2)) * 0.5f;
-    return ws * vmin(vmax(raw, zero), one) + wl * vmin(vabs(yc - xc), one);
+    return ws * vclamp01(raw) + wl * vmin(vabs(yc - xc), one);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1165,8 +1196,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     struct Stage { int lx, ly, px, py; float4 tp; float dep; Geo g; Tap t; };
     auto s_load = [&](Stage &S) {
         S.px = refl_idx(x00 + S.lx - 1, W); S.py = refl_idx(y00 + S.ly - 1, H);
-        const int gi = S.py * W + S.px;
-        S.tp = tgtpack[gi]; S.dep = depth_t[gi];
+        const unsigned gi = (unsigned)(S.py * W + S.px);          // 32-bit offsets from the wave-uniform bases (see tap4_fetch)
+        S.tp = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tgtpack) + (gi << 4));
+        S.dep = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(depth_t) + (gi << 2));
     };
     auto s_warp = [&](Stage &S) {
         warp_geo(c, W, H, S.px, S.py, S.dep, S.g);
@@ -1489,8 +1521,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 auto rows = [&](const f32x4 &n3, const f32x4 &n4, const f32x4 &n5) {
                     const f2 sxy = {sx, sy};
                     de2[0] += sxy * n3.lo;                          // (sx a0, sy b1): a1 = b0 = 0
-                    de2[1] += sx * n3.hi; de2[1] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
-                    de2[2] += sx * n4.lo; de2[2] += sy * n5.lo;
+                    pk_fma_b<0>(de2[1], sxy, n3.hi); pk_fma_b<1>(de2[1], sxy, n4.hi);   // sx / sy broadcast from their halves of the pair
+                    pk_fma_b<0>(de2[2], sxy, n4.lo); pk_fma_b<1>(de2[2], sxy, n5.lo);
                     if (NP == 7) de6 += sx * n5.z + sy * n5.w;
                 };
 #define TC_POS(k) (((k) / 3) * ROWB + ((k) % 3) * RB)
@@ -1592,17 +1624,35 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             // own geometric Jacobian (centre record), as column pairs
             f32x4 q3, q4, q5;
             lds_read3bv(ctr, q3, q4, q5);
-            const f2 a2[3] = {f2{q3.x, 0.f}, q3.hi, q4.lo}, b2[3] = {f2{0.f, q3.y}, q4.hi, q5.lo};
-            float a6 = 0.f, b6 = 0.f;
-            if (NP == 7) { a6 = q5.z; b6 = q5.w; }
+            const f2 a2[3] = {f2{q3.x, 0.f}, q3.hi, q4.lo}, b2[3] = {f2{0.f, q3.y}, q4.hi, q5.lo};   // ([0]: not used below, see ab0)
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
             float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;
             const float wxx = mf * Wp * lxx, wxy = mf * Wp * lxy, wyy = mf * Wp * lyy;
             const float dsub = (SEL && wext) ? 0.f : diff;
-            f2 ddJ2[3], la2[3], lb2[3];
+            // Columns (0,1) of the Jacobian are (a0, 0) and (0, b1) (structural zeros, see the record layout): their products are formed from the
+            // pair ab0 = (a0, b1) with ONE packed instruction where the general column pairs need two; the curvature rows travel as pairs
+            // lalb_j = (la_j, lb_j) so that row j x columns (0,1) is the elementwise product lalb_j * ab0.  Same values as the general
+            // expressions (the dropped terms are exact zeros; every remaining product / FMA keeps its operands and order).
+            const f2 ab0 = q3.lo;
+            f2 ddJ2[3], lalb[6];
+            const f2 wA = {wxx, wxy}, wB = {wxy, wyy};
+            {   // p = 0
+                const f2 dpd = f2{c_dgx[k], c_dgy[k]} * ab0;
+                ddJ2[0] = kdd * (-(cd * dpd));
+                if (ADJL) {
+                    const float sxt = adj_sx + mf * Wp * l1x, syt = adj_sy + mf * Wp * l1y;
+                    aG2[0] += f2{sxt, syt} * ab0 - (mf * dsub) * ddJ2[0] + ring_g2[0];
+                } else {
+                    f2 row = Wp * (de2[0] + f2{l1x, l1y} * ab0) - dsub * ddJ2[0];   // d(W (e1+e2))/d theta
+                    aG2[0] += mf * row;
+                }
+                if (SEL) aG2[0] -= crossf * ddJ2[0];
+                lalb[0] = pk_mul_b<0>(ab0, wA);       // b0 = 0
+                lalb[1] = pk_mul_b<1>(ab0, wB);       // a1 = 0
+            }
 #pragma unroll
-            for (int p = 0; p < 3; p++) {
+            for (int p = 1; p < 3; p++) {
                 const f2 zc2 = {c_zc[k][2 * p], c_zc[k][2 * p + 1]};
                 f2 dpd = c_dgx[k] * a2[p] + c_dgy[k] * b2[p];
                 ddJ2[p] = kdd * (pd * zc2 - cd * dpd);
@@ -1614,31 +1664,36 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                     aG2[p] += mf * row;
                 }
                 if (SEL) aG2[p] -= crossf * ddJ2[p];
-                la2[p] = wxx * a2[p] + wxy * b2[p];
-                lb2[p] = wxy * a2[p] + wyy * b2[p];
+                // (la_j, lb_j) = (wxx a_j + wxy b_j, wxy a_j + wyy b_j) for j = 2p, 2p + 1: the scalar a_j / b_j is broadcast from its half
+                lalb[2 * p] = pk_mul_b<0>(b2[p], wB);     pk_fma_b<0>(lalb[2 * p], a2[p], wA);
+                lalb[2 * p + 1] = pk_mul_b<1>(b2[p], wB); pk_fma_b<1>(lalb[2 * p + 1], a2[p], wA);
             }
-            float ddJ6 = 0.f, la6 = 0.f, lb6 = 0.f;
+            float ddJ6 = 0.f;
+            f2 lalb6 = {0.f, 0.f};
+            float a6 = 0.f, b6 = 0.f;
             if (NP == 7) {
+                a6 = q5.z; b6 = q5.w;
                 float dpd = c_dgx[k] * a6 + c_dgy[k] * b6 + pd;
                 ddJ6 = kdd * (pd * c_zc[k][NP - 1] - cd * dpd);
                 if (ADJL) aG6 += (adj_sx + mf * Wp * l1x) * a6 + (adj_sy + mf * Wp * l1y) * b6 - (mf * dsub) * ddJ6 + ring_g6;
                 else aG6 += mf * (Wp * (de6 + l1x * a6 + l1y * b6) - dsub * ddJ6);
                 if (SEL) aG6 -= crossf * ddJ6;
-                la6 = wxx * a6 + wxy * b6; lb6 = wxy * a6 + wyy * b6;
+                lalb6 = wA * a6 + wB * b6;
             }
-            // H row j (scalar la_j, lb_j) x column pairs p <= j/2
+            // H row j (la_j, lb_j) x column pairs p <= j/2
             {
                 int h = 0;
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
-                    const float la = (j & 1) ? la2[j >> 1].y : la2[j >> 1].x, lb = (j & 1) ? lb2[j >> 1].y : lb2[j >> 1].x;
+                    aH2[h] += lalb[j] * ab0; h++;                          // columns (0,1): (la_j a0, lb_j b1)
 #pragma unroll
-                    for (int p = 0; p <= (j >> 1); p++) { aH2[h] += la * a2[p]; aH2[h] += lb * b2[p]; h++; }
+                    for (int p = 1; p <= (j >> 1); p++) { aH2[h] += lalb[j].x * a2[p]; pk_fma_b<1>(aH2[h], lalb[j], b2[p]); h++; }
                 }
                 if (NP == 7) {
+                    aH2[h] += lalb6 * ab0; h++;
 #pragma unroll
-                    for (int p = 0; p < 3; p++) { aH2[h] += la6 * a2[p]; aH2[h] += lb6 * b2[p]; h++; }
-                    aH66 += la6 * a6 + lb6 * b6;
+                    for (int p = 1; p < 3; p++) { aH2[h] += lalb6.x * a2[p]; pk_fma_b<1>(aH2[h], lalb6, b2[p]); h++; }
+                    aH66 += lalb6.x * a6 + lalb6.y * b6;
                 }
             }
             if (DC) {
