@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float a[NP], b[NP], zc[NP];
         if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
         float4 *rec = lds + (S.ly * CW + S.lx) * (LDS_REC / 4);
-        // record: [y0 y1 x0 x1][gx0 gx1 gy0 gy1][y2 x2 gx2 gy2][a0 b1 a2 a3][a4 a5 b2 b3][b4 b5 (a6 b6)] : channel pairs and
+        // record: [y0 y1 x0 x1][gx0 gy0 gx1 gy1][y2 x2 gx2 gy2][a0 b1 a2 a3][a4 a5 b2 b3][b4 b5 (a6 b6)] : channel pairs and
         // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles.
         // a1 = d ix / d rho_y and b0 = d iy / d rho_x are STRUCTURALLY zero (pinhole K: a translation along y moves the sample along
         // iy only, see geo_jac), so they are not staged: (a0, b1) travel as one pair -- pass B spends one packed FMA on columns (0,1)
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         if (write) {
             lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
             if (MODE == MODE_LIN) {
-                lds_write1(rec + 1, gx.x, gx.y, gy.x, gy.y);
+                lds_write1(rec + 1, gx.x, gy.x, gx.y, gy.y);     // (gx, gy) pairs per channel: pass B forms (sx, sy) with packed FMAs
                 lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
                 lds_write1(rec + 3, a[0], b[1], a[2], a[3]);
                 lds_write1(rec + 4, a[4], a[5], b[2], b[3]);
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         f32x4 q0, q1 = {0.f, 0.f, 0.f, 0.f}, q2;
         if (MODE == MODE_LIN) lds_read3v(ctr, q0, q1, q2);
         else lds_read02v(ctr, q0, q2);               // the gradient part of the records is only staged for linearisations
-        const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = q1.lo, gyc01 = q1.hi, yx2c = q2.lo, g2c = q2.hi;
+        const f2 yc01 = q0.lo, xc01 = q0.hi, gxc01 = {q1.x, q1.z}, gyc01 = {q1.y, q1.w}, yx2c = q2.lo, g2c = q2.hi;   // (channel pairs for the per-channel terms)
         const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
         const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
 
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             const unsigned long long anyw = __builtin_amdgcn_ballot_w64(m);
             if (anyw != 0ull) {     // GN curvature of the SSIM term from the gradient sums of pass A (as at the end of pass B below)
                 const float n9 = 1.f / 9.f;
-                const f2 mx = aGx01 * n9, my = aGy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+                const f2 mx = f2{aGx01.x, aGy01.x} * n9, my = f2{aGx01.y, aGy01.y} * n9, ex = gxc01 - mx, ey = gyc01 - my;   // (the sums travel as (gx, gy) pairs of channels 0 / 1)
                 const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
                          qyy = t01.id2 * ey * ey + t01.id1 * my * my;
                 const float mx2 = aG2s.x * n9, my2 = aG2s.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
@@ -1481,9 +1481,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 }
                 const f2 lam01 = sA01 + sB01 * (r0.lo - h01) + sC01 * (r0.hi - h01);
                 const float lam2 = sAB2.x + sAB2.y * (r2.x - 0.5f) + sC2 * (r2.y - 0.5f);
-                const f2 tx = lam01 * r1.lo, ty = lam01 * r1.hi;
+                const f2 rs2 = lam01.x * r1.lo + lam01.y * r1.hi + lam2 * r2.hi;
                 const float live = tid < NHALO ? 1.f : 0.f;   // (threads NHALO .. HALO_THREADS-1 repeat the last ring position)
-                const float rsx = live * (tx.x + tx.y + lam2 * r2.z), rsy = live * (ty.x + ty.y + lam2 * r2.w);
+                const float rsx = live * rs2.x, rsy = live * rs2.y;
                 f32x4 q3, q4, q5;
                 lds_read3bv(lds + (rly * CW + rlx) * (LDS_REC / 4), q3, q4, q5);
                 ring_g2[0] = rsx * f2{q3.x, 0.f} + rsy * f2{0.f, q3.y}; ring_g2[1] = rsx * q3.hi + rsy * q4.hi; ring_g2[2] = rsx * q4.lo + rsy * q5.lo;
@@ -1510,20 +1510,20 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 constexpr int RB = LDS_REC * 4, ROWB = CW * LDS_REC * 4;
                 const unsigned base = lds_addr(nb);
                 f32x4 A0, A1, A2, B0, B1, B2, J3, J4, J5;
-                float sx, sy;
+                f2 sxy;
                 auto colour = [&](const f32x4 &n0, const f32x4 &n1, const f32x4 &n2) {
                     Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
                     f2 cf = cA01 + cB01 * n0.lo + cC01 * n0.hi;
                     float cf2 = cA2 + cB[2] * n2.x + cC[2] * n2.y;
-                    f2 tx = cf * n1.lo, ty = cf * n1.hi;
-                    sx = tx.x + tx.y + cf2 * n2.z; sy = ty.x + ty.y + cf2 * n2.w;
+                    sxy = pk_mul_b<0>(cf, n1.lo);            // (sx, sy) = cf_0 (gx0, gy0) + cf_1 (gx1, gy1) + cf_2 (gx2, gy2): three packed instructions
+                    pk_fma_b<1>(sxy, cf, n1.hi);
+                    sxy += cf2 * n2.hi;
                 };
                 auto rows = [&](const f32x4 &n3, const f32x4 &n4, const f32x4 &n5) {
-                    const f2 sxy = {sx, sy};
                     de2[0] += sxy * n3.lo;                          // (sx a0, sy b1): a1 = b0 = 0
                     pk_fma_b<0>(de2[1], sxy, n3.hi); pk_fma_b<1>(de2[1], sxy, n4.hi);   // sx / sy broadcast from their halves of the pair
                     pk_fma_b<0>(de2[2], sxy, n4.lo); pk_fma_b<1>(de2[2], sxy, n5.lo);
-                    if (NP == 7) de6 += sx * n5.z + sy * n5.w;
+                    if (NP == 7) de6 += sxy.x * n5.z + sxy.y * n5.w;
                 };
 #define TC_POS(k) (((k) / 3) * ROWB + ((k) % 3) * RB)
 #if TC_PASSB_J2
@@ -1573,10 +1573,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 Gx01 += n1.lo; Gy01 += n1.hi; G2 += n2.hi;
                 f2 cf = cA01 + cB01 * n0.lo + cC01 * n0.hi;
                 float cf2 = cA2 + cB[2] * n2.x + cC[2] * n2.y;
-                f2 tx = cf * n1.lo, ty = cf * n1.hi;
-                float sx = tx.x + tx.y + cf2 * n2.z, sy = ty.x + ty.y + cf2 * n2.w;
+                f2 sxy = pk_mul_b<0>(cf, n1.lo);
+                pk_fma_b<1>(sxy, cf, n1.hi);
+                sxy += cf2 * n2.hi;
+                const float sx = sxy.x, sy = sxy.y;
                 lds_wait0(n3, n4, n5);
-                const f2 sxy = {sx, sy};
                 de2[0] += sxy * n3.lo;                          // (sx a0, sy b1): a1 = b0 = 0
                 de2[1] += sx * n3.hi; de2[1] += sy * n4.hi;     // separate statements: each contracts to one v_pk_fma_f32
                 de2[2] += sx * n4.lo; de2[2] += sy * n5.lo;
@@ -1586,7 +1587,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
 #endif
             {   // GN curvature of the SSIM term: Cov/d2 + mean mean'/d1, Cov ~ 9/8 (g - mean)(g - mean)' (centre sample)
                 const float n9 = 1.f / 9.f;
-                const f2 mx = Gx01 * n9, my = Gy01 * n9, ex = gxc01 - mx, ey = gyc01 - my;
+                const f2 mx = f2{Gx01.x, Gy01.x} * n9, my = f2{Gx01.y, Gy01.y} * n9, ex = gxc01 - mx, ey = gyc01 - my;   // (Gx01 / Gy01 hold the (gx, gy) sums of channel 0 / 1)
                 const f2 qxx = t01.id2 * ex * ex + t01.id1 * mx * mx, qxy = t01.id2 * ex * ey + t01.id1 * mx * my,
                          qyy = t01.id2 * ey * ey + t01.id1 * my * my;
                 const float mx2 = G2.x * n9, my2 = G2.y * n9, ex2 = g2c.x - mx2, ey2 = g2c.y - my2;
