@@ -90,9 +90,9 @@ def classify(op, operands, table, costs, prev_vcc_write):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="k_linearizeILi6ELb0ELi1ELi32ELi16ELi512ELb0ELb0E")
+    ap.add_argument("--kernel", default="k_linearizeILi6ELb0ELi1ELi32ELi16ELi512ELb0ELb0ELb0E")
     ap.add_argument("--rates", default=os.path.join(ROOT, "profiles", "r02_valu_rate.jsonl"))
-    ap.add_argument("--trips", default="8,9", help="trip counts of the loops in program order")
+    ap.add_argument("--trips", default="1", help="trip counts of the loops in program order (rounds 2-3: 8,9 -- the rolled neighbour loops; the round-4 kernel has them unrolled)")
     ap.add_argument("--frac", default="", help="executing fraction of each skipped region in program order (see --list)")
     ap.add_argument("--list", action="store_true", help="print loops / regions with their line ranges and exit")
     ap.add_argument("--pmc", default=os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json"))

@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_warp(WarpParams P) {
 // partial-sum record per workgroup to HBM (deterministic: no atomics).
 
 constexpr int RG = 16;       // workgroups per in-launch reduction group
-constexpr int LDS_REC = 28;  // floats per staged pixel (12 + 2*NP <= 26, padded to 28 for bank spread)
+constexpr int LDS_REC = 28;  // floats per staged pixel: 24 used (six 16-byte rows, NP = 7 included), stride 28 for the banks (28 l mod 64 visits every bank group once)
 
 template <int NP>
 struct AccLayout {
@@ -1285,12 +1285,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         const float yc[3] = {yc01.x, yc01.y, yx2c.x}, xc[3] = {xc01.x, xc01.y, yx2c.y};
         const float gxc[3] = {gxc01.x, gxc01.y, g2c.x}, gyc[3] = {gyc01.x, gyc01.y, g2c.y};
 
-        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances) + gradient window
-        // sums.  Rolled (one neighbour live at a time); 14 packed instructions per neighbour.
-        // neighbour pointer walks the 3x3 window with ONE vector add per step (the step is wave-uniform).  The first neighbour
-        // is peeled: it INITIALISES the accumulators (no zero-fill instructions), the loop adds the other eight.  Only the
-        // colour part of the records is read here (32 of their 112 bytes): the neighbour passes are LDS-bandwidth limited, and
-        // the gradient window sums the curvature needs are gathered in pass B, which reads the gradients anyway.
+        // pass A: SSIM statistics over the 3x3 window, shifted by the centre value (fp32-safe variances); 11 VALU per neighbour.
+        // The first neighbour INITIALISES the accumulators (no zero-fill instructions), the other eight are added.  Only the colour
+        // part of the records is read here (32 of their 96 bytes); the gradient window sums the curvature needs are gathered in
+        // pass B, which reads the gradients anyway.  Production form: software-pipelined (below); the rolled loop (one neighbour
+        // live at a time, the pointer walking the window with one vector add per step) remains for the adjoint form and the A/B builds.
         const float4 *nbA = ctr - (CW + 1) * (LDS_REC / 4);
         f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, S2, SS2;
         float Sxy2;
@@ -1491,7 +1490,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             }
         }
         if (!ADJL && MODE == MODE_LIN && __builtin_amdgcn_ballot_w64(m) != 0ull) {
-            // pass B: exact SSIM gradient rows (neighbour geometry included); ~20 packed instructions per neighbour
+            // pass B: exact SSIM gradient rows (neighbour geometry included); 15 VALU per neighbour (13 packed)
             // d SSIM_p / d y_q = cA + cB (y_q - y_c) + cC (x_q - x_c): the centre shift goes into the constant once per pixel
             // instead of three packed subtractions per neighbour
             const f2 cB01 = {cB[0], cB[1]}, cC01 = {cC[0], cC[1]};
