@@ -66,6 +66,9 @@ struct LinParams {
     int shared_image;       // all problems read packed image pair 0 (loss-surface sweeps); kept OUT of PairConst so that the
                             // first image loads do not wait for the scalar loads of the pair constants
     int direct;             // 1: no in-launch group reduction -- k_solve sums the workgroup records itself (small grids)
+    int one_generation;     // 1: the whole grid is resident at once (<= 2 workgroups per CU): its workgroups run their phases in lockstep and the
+                            // two-position waves of phase 1 are the critical path to the barrier -- they raise their priority (a full chip
+                            // prefers them unprioritised: measured both ways, profiles/r04_lds_pipeline_ab.txt).  Scheduling only: same bits.
     // dense window modes: residual maps [ext_S * ext_B][H][W] of the forward pairs (k_linearize<MODE_MAPS> at the current poses); the
     // min-over-sources selection formed from them (ext_selected) replaces the own mask of pairs n < n_ext
     const float *ext_diff, *ext_valid;
@@ -1246,6 +1249,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         Stage A;
         A.ly = tid / TW + 1; A.lx = tid - (tid / TW) * TW + 1;
         if (tid < HALO_THREADS) {
+            if (P.one_generation) __builtin_amdgcn_s_setprio(3);     // (wave-uniform; see LinParams)
             Stage B;
             const int hi = min(tid, NHALO - 1);   // ring enumeration: top row, bottom row, then left/right columns
             if (hi < CW) { B.ly = 0; B.lx = hi; }
@@ -1254,6 +1258,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             s_load(A); s_load(B);
             s_warp(A); s_warp(B);
             s_store(A, true, true); s_store(B, tid < NHALO, false);
+            if (P.one_generation) __builtin_amdgcn_s_setprio(0);
         } else {
             s_load(A); s_warp(A); s_store(A, true, true);
         }

@@ -349,6 +349,7 @@ void launch_lin_t(tcsfm_ctx *h, const LinParams &P, int N) {
 void launch_lin(tcsfm_ctx *h, const LinParams &P_in, int N, int np, bool dc, int mode, int prof_class = 0) {
     LinParams P = P_in;
     if (prof_class == 0) take_stamp(h, P, (size_t)h->nblk * N); else P.stamp = nullptr;
+    P.one_generation = (size_t)h->nblk * N <= 512;          // 256 CUs x 2 resident workgroups
     ProfScope prof(h, prof_class);
     if (np == 6) {
         if (mode == MODE_MAPS) launch_lin_t<6, false, MODE_MAPS>(h, P, N);
