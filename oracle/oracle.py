@@ -274,19 +274,21 @@ class Oracle:
         """ONE linearisation of the dense mode on the reference's loss (orc_linearize_dense_ref): tgt [B,3,H,W], srcs [S,B,3,H,W],
         depth_t [B,H,W], depth_s [S,B,H,W], K [B,3,3], poses [2SB,6] (forward pairs source-major, then the inverse pairs) ->
         dict(loss, L_fwd, L_inv, L_dc, L_init, K_f, K_i, g_xi [2SB,6] (w.r.t. the left perturbation), g_rho [B,H,W], H_joint [B,6S,6S],
-        g_joint [B,6S], D [B,H,W], B [B,H,W,6S], H_inv [SB,6,6], g_inv [SB,6])"""
+        g_joint [B,6S], D [B,H,W], B [B,H,W,6S], H_inv [SB,6,6], g_inv [SB,6], g_rho_s [S,B,H,W]: the gradient w.r.t. the SOURCE inverse-depth maps,
+        which the engine holds fixed and the reference optimises too)"""
         o = opts or default_opts()
         tgt, srcs, depth_t, depth_s, K, poses, S, B, H, W = self._dref_args(tgt, srcs, depth_t, depth_s, K, poses)
         d0 = None if depth0 is None else self._r(depth0)
         SB, NP, n = S * B, 6 * S, H * W
         scal = np.zeros(7); g_xi = np.zeros((2 * SB, 6)); g_rho = np.zeros((B, H, W)); Hj = np.zeros((B, NP, NP)); gj = np.zeros((B, NP))
         Dq = np.zeros((B, H, W)); Bq = np.zeros((B, H, W, NP)); Hi = np.zeros((SB, 6, 6)); gi = np.zeros((SB, 6))
+        g_rho_s = np.zeros((S, B, H, W))
         self.lib.orc_linearize_dense_ref(C.c_int(H), C.c_int(W), C.c_int(B), C.c_int(S), self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
                                          self._p(d0), self._p(K), C.byref(o), C.c_int(1 if argmin else 0), C.c_double(w_init), C.c_double(min_depth),
                                          C.c_double(max_depth), C.c_double(lambda_depth), self._p(poses), self._p(scal), self._p(g_xi), self._p(g_rho),
-                                         self._p(Hj), self._p(gj), self._p(Dq), self._p(Bq), self._p(Hi), self._p(gi))
+                                         self._p(Hj), self._p(gj), self._p(Dq), self._p(Bq), self._p(Hi), self._p(gi), self._p(g_rho_s))
         return dict(loss=scal[0], L_fwd=scal[1], L_inv=scal[2], L_dc=scal[3], L_init=scal[4], K_f=scal[5], K_i=scal[6], g_xi=g_xi, g_rho=g_rho,
-                    H_joint=Hj, g_joint=gj, D=Dq, B=Bq, H_inv=Hi, g_inv=gi)
+                    H_joint=Hj, g_joint=gj, D=Dq, B=Bq, H_inv=Hi, g_inv=gi, g_rho_s=g_rho_s)
 
     def refine_dense_ref(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06,
                          max_depth=2.67, bits=None):

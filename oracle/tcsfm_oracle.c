@@ -1990,6 +1990,118 @@ void orc_refine_dense_joint(int H, int W, int B, int S, const real *tgt, const r
  * sampled-depth terms and e dW/d. terms are gradient-only, as in every other mode.  Inverse pairs: 6 x 6 pose systems under the
  * window REFERENCE rule (linearize_masked with the batch normaliser), their depth is not an unknown.
  */
+/* Gradient of the same loss w.r.t. the SOURCE inverse-depth maps rho_s(m, q) = 1 / depth_s(m, q), m = (s, b) -- the leaves of the
+ * reference's optimize_depth_pred that the engine holds fixed (optimizer.py:194-198: the quarter-resolution disparities of the target AND
+ * of every source are optimised).  Their role mirrors the target map's:
+ *   (i)  LOCAL in the inverse pair SB + m, whose back-projected depth they are: the photometric term a_i M W diff through the sample
+ *        position of every window pixel (SSIM adjoint) and through the pair's own weight W = 1 - dd, and the pair's depth-consistency term;
+ *   (ii) SAMPLED by the forward pair m (stn.py:271): through the weight map it provides (source 0's map multiplies every selected pixel
+ *        under argmin, optimizer.py:69; its own pixels otherwise) and through its depth-consistency term -- the adjoint of the bilinear
+ *        sample, a scatter over the four taps.
+ * Natural decisions only (no forced replay); masks / errors / normalisers are the caller's (linearize_dense_ref).  Pinned on reference
+ * autograd: golden G13 `full_grad_depth_s` and the source channels of `qinit_grad_q` (tests/test_oracle_vs_golden.py). */
+static void dref_source_depth_gradient(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
+                                       const real *K, const orc_opts *op, int argmin, const double *T, const real *const *ae, const real *imask /* [SB][n] */,
+                                       const real *fmask /* [SB][n] */, const real *fdiff /* [SB][n] */, double a_f, double a_i, double bdc, double *g_rho_s) {
+    const int n = H * W, SB = S * B;
+    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3);
+    const double eps = op->irls_eps;
+    (void)ae;
+    memset(g_rho_s, 0, sizeof(double) * (size_t)SB * n);
+    px_t *px = (px_t *)malloc(sizeof(px_t) * n);
+    real *rec = (real *)malloc(sizeof(real) * 3 * n);
+    double *adj = (double *)malloc(sizeof(double) * 2 * n);
+    for (int m = 0; m < SB; m++) {
+        const int b = m % B, pn = SB + m;
+        const real *ti = srcs + (size_t)m * 3 * n;      /* the inverse pair's target image = source image m */
+        const real *ds = depth_s + (size_t)m * n;
+        double *gr = g_rho_s + (size_t)m * n;
+        /* ---- (i) the inverse pair: per-pixel quantities with the inverse-depth column ---- */
+        cam_t c;
+        cam_setup(&c, H, W, K + 9 * b, T + 12 * pn, 0.0);
+        g_force_bits = NULL;
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                px_t *P = &px[v * W + u];
+                px_eval(&c, tgt + (size_t)b * 3 * n, ds, depth_t + (size_t)b * n, u, v, 7, P);
+                const real D = ds[v * W + u];
+                P->a[6] *= -D; P->b[6] *= -D; P->zc[6] *= -D;
+                P->dpd[6] = P->dgx * P->a[6] + P->dgy * P->b[6];
+            }
+        for (int i = 0; i < n; i++)
+            for (int ch = 0; ch < 3; ch++) rec[ch * n + i] = px[i].rec[ch];
+        memset(adj, 0, sizeof(double) * 2 * n);
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                const int i = v * W + u;
+                const px_t *P = &px[i];
+                const real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum, dd = clamp01(raw);
+                const real sg = (raw >= 0 && raw <= 1) ? (dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0)) : (real)0;
+                const double ddJ6 = sg * 2.0 * (P->pd * P->zc[6] - P->cd * P->dpd[6]) / ((double)sum * sum);
+                gr[i] += bdc * fmin(1.0, dd / eps) * ddJ6;                                   /* depth consistency of the inverse pair */
+                const double am = imask[(size_t)m * n + i];
+                if (am == 0) continue;
+                const real Wt = 1 - dd;
+                real e = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    const real *xx = ti + ch * n, *y = rec + ch * n;
+                    const real r = y[i] - xx[i], ar = fabs(r);
+                    const real sgn = (ar <= 1) ? (r > 0 ? (real)1 : (r < 0 ? (real)-1 : (real)0)) : (real)0;
+                    adj[2 * i] += am * Wt * wl * sgn * P->gx[ch];
+                    adj[2 * i + 1] += am * Wt * wl * sgn * P->gy[ch];
+                    ssim_t q;
+                    ssim_at(xx, y, H, W, u, v, &q);
+                    e += wl * clamp01(ar) + ws * q.s;
+                    if (!q.clamped) {
+                        const real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
+                        const real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
+                        const real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);
+                        for (int dv = -1; dv <= 1; dv++)
+                            for (int du = -1; du <= 1; du++) {
+                                const int qi = refl(v + dv, H) * W + refl(u + du, W);
+                                const real cf = ws * (cA + cB * y[qi] + cC * xx[qi]);
+                                adj[2 * qi] += am * Wt * cf * px[qi].gx[ch];
+                                adj[2 * qi + 1] += am * Wt * cf * px[qi].gy[ch];
+                            }
+                    }
+                }
+                gr[i] -= a_i * am * e * ddJ6;                                                /* the pair's own weight: -M diff d dd / d rho */
+            }
+        for (int i = 0; i < n; i++) gr[i] += a_i * (adj[2 * i] * px[i].a[6] + adj[2 * i + 1] * px[i].b[6]);
+        /* ---- (ii) the forward pair m samples this map: adjoint of the bilinear sample ---- */
+        cam_setup(&c, H, W, K + 9 * b, T + 12 * m, 0.0);
+        const int provider = argmin ? (m / B == 0) : 1;        /* does this pair's weight map multiply photometric terms (optimizer.py:69) */
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                const int i = v * W + u;
+                geo_t g;
+                warp_geo(&c, u, v, depth_t[(size_t)b * n + i], &g);
+                if (g.oobx || g.ooby) continue;
+                real pdv, dgx, dgy;
+                bilinear_cell(ds, H, W, g.ix, g.iy, g.adjx, g.adjy, &pdv, &dgx, &dgy);
+                const real cd = g.Z, pd = pdv, sum = cd + pd, dif = cd - pd, raw = fabs(dif) / sum;
+                if (!(raw >= 0 && raw <= 1)) continue;
+                const real sg = dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0);
+                const double ddd = -(double)sg * 2.0 * cd / ((double)sum * sum);              /* d dd / d pd */
+                const double dd = clamp01(raw);
+                double E = 0;                                                                 /* sum of M diff of the pixels this weight multiplies */
+                if (provider) {
+                    if (argmin) for (int s2 = 0; s2 < S; s2++) E += fmask[(size_t)(s2 * B + b) * n + i] * fdiff[(size_t)(s2 * B + b) * n + i];
+                    else E = fmask[(size_t)m * n + i] * fdiff[(size_t)m * n + i];
+                }
+                const double coef = (bdc * fmin(1.0, dd / eps) - a_f * E) * ddd;             /* d L / d pd(p) */
+                const real fx = floor(g.ix) + (real)g.adjx, fy = floor(g.iy) + (real)g.adjy, wx = g.ix - fx, wy = g.iy - fy;
+                const int x0 = (int)fx, y0 = (int)fy;
+                const double w4[4] = {(1 - wx) * (1 - wy), wx * (1 - wy), (1 - wx) * wy, wx * wy};
+                for (int t = 0; t < 4; t++) {
+                    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+                    if (xx >= 0 && xx < W && yy >= 0 && yy < H) gr[yy * W + xx] -= (double)ds[yy * W + xx] * ds[yy * W + xx] * coef * w4[t];   /* d / d rho = -depth^2 d / d depth */
+                }
+            }
+    }
+    free(px); free(rec); free(adj);
+}
+
 typedef struct {
     double loss, L_fwd, L_inv, L_dc, L_init, Kf, Ki;
 } dref_scal;
@@ -1998,7 +2110,8 @@ static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, con
                                 const real *depth0, const real *K, const orc_opts *op, int argmin, double w_init, double min_depth, double max_depth,
                                 double lambda_depth, const double *T /* [2SB][12] */, const real *const *ae /* [2SB] */, const unsigned short *bits /* [2SB][n] or NULL */,
                                 dref_scal *sc, double *g_xi /* [2SB][6] */, double *g_rho /* [B][n] */, double *Hj /* [B][6S x 6S] */, double *gj /* [B][6S] */,
-                                double *Dq /* [B][n] */, double *Bq /* [B][n][6S] */, double *Hi /* [SB][36] */, double *gi /* [SB][6] */) {
+                                double *Dq /* [B][n] */, double *Bq /* [B][n][6S] */, double *Hi /* [SB][36] */, double *gi /* [SB][6] */,
+                                double *g_rho_s /* [SB][n] or NULL: d L / d (1 / depth_s) -- see dref_source_depth_gradient */) {
     const int n = H * W, SB = S * B, NP = 6 * S;
     const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3), reps = (real)op->irls_eps;
     const double bdc = op->w_dc / ((double)SB * n), eps = op->irls_eps;
@@ -2325,6 +2438,8 @@ static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, con
             }
     }
     sc->loss = sc->L_fwd + sc->L_inv + sc->L_dc + sc->L_init;
+    if (g_rho_s)
+        dref_source_depth_gradient(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, T, ae, imask, mask, diff, a_f, a_i, bdc, g_rho_s);
     for (int m = 0; m < SB; m++) { free(px[m]); free(rec[m]); }
     free(px); free(rec); free(diff); free(valid); free(Wm); free(mask); free(margin); free(imask); free(ext);
     free(gx_adj); free(Lam); free(own); free(gxi); free(Hxx); free(Sm); free(gs); free(pri_g); free(pri_D); free(sig); free(sig0);
@@ -2344,7 +2459,7 @@ static void dref_auto_err(int H, int W, int B, int S, const real *tgt, const rea
 void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s, const real *depth0,
                              const real *K, const orc_opts *op, int argmin, double w_init, double min_depth, double max_depth, double lambda_depth,
                              const double *pose /* [2SB][6] */, double *scal /* [7]: loss, L_fwd, L_inv, L_dc, L_init, K_f, K_i */, double *g_xi, double *g_rho,
-                             double *Hj, double *gj, double *Dq, double *Bq, double *Hi, double *gi) {
+                             double *Hj, double *gj, double *Dq, double *Bq, double *Hi, double *gi, double *g_rho_s /* [SB][n] or NULL */) {
     const int n = H * W, SB = S * B;
     real *ae = (real *)malloc(sizeof(real) * (size_t)2 * SB * n);
     const real **aep = (const real **)malloc(sizeof(real *) * 2 * SB);
@@ -2353,7 +2468,7 @@ void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const 
     for (int m = 0; m < 2 * SB; m++) orc_pose_to_T(pose + 6 * m, T + 12 * m);
     dref_scal sc;
     linearize_dense_ref(H, W, B, S, tgt, srcs, depth_t, depth_s, depth0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep, NULL, &sc,
-                        g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi);
+                        g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s);
     scal[0] = sc.loss; scal[1] = sc.L_fwd; scal[2] = sc.L_inv; scal[3] = sc.L_dc; scal[4] = sc.L_init; scal[5] = sc.Kf; scal[6] = sc.Ki;
     free(ae); free(aep); free(T);
 }
@@ -2381,7 +2496,7 @@ void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const rea
         dref_scal sc;
         g_lin_idx = bits ? it : -1;
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep,
-                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi);
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, NULL);
         g_lin_idx = -1;
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {       /* forward group: (S + lambda diag S + 1e-12 I) d = -gS, back-substitution of the depth map */
@@ -2516,7 +2631,7 @@ void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const r
         g_lin_idx = bits ? it : -1;
         /* lambda_depth = infinity: no per-pixel elimination inside -- Hj / gj come back as the pose blocks and pose gradients themselves */
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, INFINITY, T, aep,
-                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi);
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, NULL);
         g_lin_idx = -1;
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {

@@ -585,6 +585,11 @@ def test_dense_reference_loss_and_gradients_vs_reference_autograd_G13(name, orac
         if tag == "full":            # d / d depth = -rho^2 d / d rho
             gd, ref = -L["g_rho"] / g["depth_t"][:, 0] ** 2, g["full_grad_depth_t"]
             assert _maxabs(gd, ref) < 1e-10 * np.abs(ref).max(), (tag, _maxabs(gd, ref), np.abs(ref).max())
+            # the SOURCE depth maps -- leaves of the reference's optimize_depth_pred that the engine holds fixed: local in their inverse pair,
+            # sampled by their forward pair (whose weight map multiplies every selected pixel under argmin); equal to reference autograd too
+            gds, refs = -L["g_rho_s"] / g["depth_s"][:, :, 0] ** 2, g["full_grad_depth_s"]
+            assert _maxabs(gds, refs) < 1e-10 * np.abs(refs).max(), (tag, _maxabs(gds, refs), np.abs(refs).max())
+            assert np.abs(refs).max() > 0.1 * np.abs(ref).max()        # (not a negligible part of the loss's gradient)
         if tag == "fullinit_smooth":     # the smoothness term through the shared map, incl. the mean-normalisation's per-image constant
             gs, ref = L["g_rho"] * rd, g["fullinit_smooth_grad_sig_t"]
             assert _maxabs(gs, ref) < 1e-10 * np.abs(ref).max(), (tag, _maxabs(gs, ref), np.abs(ref).max())
@@ -649,6 +654,11 @@ def test_quarter_resolution_parametrisation_vs_reference_G13(name, oracle64):
     gq = np.stack([oracle64.up4_adjoint(L["g_rho"][b] * rd) for b in range(B)])           # d / d sigma_q = U' (r d / d rho)
     ref = g["qinit_grad_q"][:, 0]
     assert _maxabs(gq, ref) < 1e-10 * np.abs(ref).max(), (_maxabs(gq, ref), np.abs(ref).max())
+    # the source channels of the reference's quarter-resolution leaf (held fixed by the engine): the same chain on the source maps' gradient
+    for s_ in range(S):
+        gqs = np.stack([oracle64.up4_adjoint(L["g_rho_s"][s_, b] * rd) for b in range(B)])
+        refs = g["qinit_grad_q"][:, 1 + s_]
+        assert _maxabs(gqs, refs) < 1e-10 * np.abs(refs).max(), (s_, _maxabs(gqs, refs), np.abs(refs).max())
     # (a quarter-resolution cell gathers ~16 pixels' gradients: the chain rule is not a formality at the pin's tolerance)
     assert np.abs(gq - (L["g_rho"] * rd)[:, 1::4, 1::4]).max() > 0.5 * np.abs(gq).max()
 
