@@ -288,6 +288,18 @@ int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int
                                  const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
                                  double *scal_out, double *g_pose_out, float *g_rho_out);
 
+/* The same linearisation with one more output: g_rho_src_out [S][B][H*W] float32 (kind of pointer as o->host_ptrs says) = d loss /
+ * d (inverse depth of SOURCE map (s, b)) -- the depth maps tcsfm_refine_dense_window holds fixed, which the reference's optimize_depth_pred
+ * optimises as well (optimizer.py:194-198: the quarter-resolution disparities of the target AND of every source are leaves).  A source
+ * map is the back-projected depth of its inverse pair (local: photometric term through the SSIM window, the pair's own weight, its depth-
+ * consistency term) and the depth its forward pair SAMPLES (stn.py:271: through that pair's depth-consistency term and the weight map it
+ * provides -- source 0's multiplies every selected pixel under o->argmin, optimizer.py:69): both parts, the second as the adjoint of the
+ * bilinear sample.  Equals reference autograd (golden G13 `full_grad_depth_s`; oracle: dref_source_depth_gradient).  With this every leaf
+ * of the reference's loss has its exact gradient on the device; making the source maps unknowns of the Gauss-Newton step is not done. */
+int tcsfm_linearize_dense_window_sources(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                         const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
+                                         double *scal_out, double *g_pose_out, float *g_rho_out, float *g_rho_src_out);
+
 /* ScaleRecovery.forward, models/dnet_layers.py:249-327 (the step right after the path in optimize_window,
  * optimizer.py:254-258): camera-height map |P.n| from 8-neighbour surface normals, ground mask, exact lower median of the
  * masked heights over the batch, scale = real_cam_height / median.  pad_to_batch mirrors the reference's padding of a short

@@ -61,6 +61,33 @@ def test_linearize_dense_window_vs_reference_autograd_G13(name, orc):
         assert np.abs(L["g_rho"][:, 0].cpu().numpy() - Lo["g_rho"]).max() < 2e-4 * np.abs(Lo["g_rho"]).max()
 
 
+@pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
+def test_gradient_wrt_the_source_depth_maps_vs_reference_autograd_G13(name, orc):
+    """tcsfm_linearize_dense_window_sources: the gradient of the reference's loss w.r.t. the SOURCE depth maps -- leaves of the reference's
+    optimize_depth_pred (optimizer.py:194-198) that the refinement holds fixed -- equals reference autograd (golden G13 `full_grad_depth_s`),
+    with and without the min over the sources against the float64 oracle; the other outputs are the bits of tcsfm_linearize_dense_window"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    g = load_golden(name)
+    S, B = g["sources"].shape[:2]
+    H, W = g["target"].shape[-2:]
+    mind, maxd = (float(x) for x in g["min_max_depth"])
+    e = Engine(H, W, 2 * S * B)
+    t = dict(tgt=_dev(g["target"]), srcs=_dev(g["sources"]), depth_t=_dev(g["depth_t"]), depth_s=_dev(g["depth_s"]), K=_dev(g["K"]), pose=_dev(g["first"]))
+    for argmin in (True, False):
+        o = default_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, prior_init=0.0, min_depth=mind, max_depth=maxd)
+        L = e.linearize_dense_window(t["tgt"], t["srcs"], t["depth_t"], t["depth_s"], t["K"], t["pose"], o, argmin=argmin, sources=True)
+        L0 = e.linearize_dense_window(t["tgt"], t["srcs"], t["depth_t"], t["depth_s"], t["K"], t["pose"], o, argmin=argmin)
+        assert L["loss"] == L0["loss"] and np.array_equal(L["g_pose"], L0["g_pose"]) and torch.equal(L["g_rho"], L0["g_rho"])
+        gs = L["g_rho_src"][:, :, 0].cpu().numpy().astype(np.float64)
+        Lo = orc.linearize_dense_ref(g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"],
+                                     oracle_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7), argmin=argmin, min_depth=mind, max_depth=maxd)
+        assert np.abs(gs - Lo["g_rho_s"]).max() < 2e-4 * np.abs(Lo["g_rho_s"]).max(), (argmin, np.abs(gs - Lo["g_rho_s"]).max(), np.abs(Lo["g_rho_s"]).max())
+        if argmin:           # d / d depth = -rho^2 d / d rho against reference autograd itself
+            gd, ref = -gs / g["depth_s"][:, :, 0] ** 2, g["full_grad_depth_s"]
+            assert np.abs(gd - ref).max() < 2e-4 * np.abs(ref).max(), (np.abs(gd - ref).max(), np.abs(ref).max())
+    e.close()
+
+
 def _window(B, S, H, W, seed, bias=1.02):
     from tightly_coupled_sfm_amd import synth
     # B targets x S sources: target b with sources from independent pairs that share its target image / depth

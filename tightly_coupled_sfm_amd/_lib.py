@@ -98,6 +98,7 @@ _SIGNATURES = {
     "tcsfm_refine": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 10),
     "tcsfm_refine_dense_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 9),
     "tcsfm_linearize_dense_window": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 10),
+    "tcsfm_linearize_dense_window_sources": (C.c_int, [_P, C.POINTER(Opts), C.c_int, C.c_int] + [_P] * 11),
     "tcsfm_refine_dense": (C.c_int, [_P, C.POINTER(Opts), C.c_int] + [_P] * 9),
     "tcsfm_scale_recovery": (C.c_int, [_P, C.POINTER(Opts), C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P]),
     "tcsfm_posenet_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),

@@ -141,6 +141,67 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
 }
 
 
+// The mirror image of k_dref_scatter for the SOURCE maps (tcsfm_linearize_dense_window_sources: the gradient of the reference's loss w.r.t.
+// the depth maps the engine holds fixed; oracle: dref_source_depth_gradient).  Forward pair m = (s, b) samples source map m (stn.py:271):
+// through its depth-consistency term and through the weight map it provides -- source 0's map multiplies EVERY selected pixel under argmin
+// (optimizer.py:69), a pair's own pixels otherwise.  d L / d pd(p) = (b_dc h(dd) - a_f E(p)) d dd / d pd, E = the sum of M diff over the
+// pixels this weight multiplies, scattered over the four taps in units of a_f = c_f / K_f (b_dc when no pixel counts).  A verification
+// path, not a timed one: one thread per pixel, one 64-bit fixed-point atomic per tap (order-independent: bit-reproducible).
+__global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepassParams D, long long *ext_src /* [SB][H*W] */, float c_f) {
+    const int H = P.H, W = P.W, hw = H * W;
+    const int m = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int b = m % D.B, s = m / D.B, v = idx / W, u = idx - v * W;
+    const PairConst &c = P.pc[m];
+    const float dep = P.depth_t[(size_t)m * hw + idx];
+    Geo g;
+    warp_geo(c, W, H, u, v, dep, g);
+    if (g.oobx || g.ooby) return;
+    Tap t;
+    tap4_fetch(P.srcpack + (size_t)m * (H + 2) * (W + 2), W, H, u, v, g.rx, g.ry, false, t);
+    float4 val, gx, gy;
+    tap4_lerp(t, val, gx, gy);
+    const float pd = c.es * val.w, cd = g.Z, isum = frcp(cd + pd);
+    const float dif = dc_diff(c, g, t, dep, pd), raw = fabsf(dif) * isum;
+    if (!(raw >= 0.f && raw <= 1.f)) return;
+    const float sg = dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f);
+    const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)
+    const float dd = fminf(raw, 1.f);
+    float E = 0.f;
+    if (!D.argmin || s == 0) {
+        const int s_lo = D.argmin ? 0 : s, s_hi = D.argmin ? D.S : s + 1;
+        for (int s2 = s_lo; s2 < s_hi; s2++) {
+            const int n2 = s2 * D.B + b;
+            const bool valid = P.ext_valid[(size_t)n2 * hw + idx] > 0.5f;
+            const float diff = P.ext_diff[(size_t)n2 * hw + idx], ae = P.tgtpack[(size_t)n2 * hw + idx].w;
+            const bool count = (D.argmin && D.S > 1) ? ext_selected(P, n2, idx, hw) : (valid && (!(D.automask && D.argmin) || diff < ae));   // (k_dref_count's rule)
+            if (count) E += diff;
+        }
+    }
+    const float Kf = (float)D.norms[0];
+    const float ratio_dc = Kf > 0.f ? D.b_dc * Kf / c_f : 1.f, w_photo = Kf > 0.f ? 1.f : 0.f;
+    const float coef = (ratio_dc * fminf(1.f, dd * frcp(D.eps)) - w_photo * E) * ddd;
+    const int xi = u + (int)floorf(g.rx), yi = v + (int)floorf(g.ry);
+    const float wx = t.wx, wy = t.wy;
+    const float w4[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
+    long long *ext = ext_src + (size_t)m * hw;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int xx = xi + (k & 1), yy = yi + (k >> 1);
+        if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+            const long long a = (long long)llrint((double)(coef * w4[k]) * DREF_FIX);
+            if (a != 0) atomicAdd(reinterpret_cast<unsigned long long *>(ext + (size_t)yy * W + xx), (unsigned long long)a);
+        }
+    }
+}
+// d loss / d rho_s = a_i x the per-pixel record of the joint kernel run on the inverse pairs (a_i = 0.25 / K_i)
+__global__ __launch_bounds__(256) void k_dref_export_grho_src(const float *jrec, int jrec_stride, const int *norms, float *out, int hw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (idx >= hw) return;
+    const float Ki = (float)norms[1];
+    out[(size_t)m * hw + idx] = Ki > 0.f ? (0.25f / Ki) * jrec[((size_t)m * hw + idx) * jrec_stride] : 0.f;
+}
+
 // l_smooth prepass (optimizer.py:92-93; losses.py:43-61 get_smooth_loss): per target the mean of its sigmoid disparity and the value of its
 // whole term  T_b = (1 / m) [w_x sum_x-edges e^{-|dI|} |d sigma| + w_y sum_y-edges ...],  m = mean + 1e-7 -- the joint kernel needs both
 // before it can form the term's gradient (the mean-normalisation couples every pixel of the image to every edge).  One workgroup per

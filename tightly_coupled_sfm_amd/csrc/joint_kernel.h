@@ -54,6 +54,10 @@ struct JointParams {
     // l_smooth (optimizer.py:92-93, losses.py:43-61): edge-aware smoothness of the mean-normalised sigmoid disparity of the target
     const float *smooth;     // [B][2] per target: m = mean(sigma) + 1e-7 and T_b = the target's whole term (k_dref_smooth), or null
     float w_smooth_x, w_smooth_y;      // weight / (B H (W-1)), weight / (B (H-1) W); 0: off
+    // the kernel run on the INVERSE pairs as S = 1 groups (their back-projected depth = the source map: tcsfm_linearize_dense_window_sources):
+    // the scattered sums then come from the FORWARD pairs' samples of that map, in units of ext_c / ext_norm[0] = the forward factor a_f
+    const int *ext_norm;     // null: the unit of dref_unit (0.25 / norms[1])
+    float ext_c;
 };
 constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums (integer atomics: order-independent)
 
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         const float iaf = Kf > 0.f ? Kf / J.c_f : 0.f;                 // 1 / a_f
         r_dc = J.b_dc * iaf; r_init = J.w_init_px * iaf;
         r_ext = (Ki > 0.f ? 0.25f / Ki : J.b_dc) * iaf;                // the scattered sums' unit u (dense_ref_kernel.h dref_unit) over a_f
+        if (J.ext_norm) { const float Ke = (float)J.ext_norm[0]; r_ext = (Ke > 0.f ? J.ext_c / Ke : J.b_dc) * iaf; }
     }
     const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
     const bool ref_prior = REF && J.w_init_px > 0.f;

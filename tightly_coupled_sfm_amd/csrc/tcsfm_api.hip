@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void k_dref_export_grho(const float *jrec, int
 
 // Dense window mode on the REFERENCE's loss (include/tcsfm.h, dense_ref_kernel.h).  Inputs on the device.  lin_export != nullptr: ONE
 // linearisation at the given poses, nothing updated: host outputs of tcsfm_linearize_dense_window.
-struct DrefExport { double *scal, *g_pose; float *d_g_rho; const float *d_depth0; };
+struct DrefExport { double *scal, *g_pose; float *d_g_rho; const float *d_depth0; float *d_g_rho_src; /* [S B][H W] or null: tcsfm_linearize_dense_window_sources */ };
 template <int NS>
 int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, const float *d_src, const float *d_dt, const float *d_ds,
                   const float *d_K, const float *d_pose_in, float *d_pose_out, float *d_depth_out, float *d_stats, const WinOff *wo, const DrefExport *ex) {
@@ -808,6 +808,25 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         Sj.it = 0; Sj.mode = 0; Sj.export_out = h->dref_export;
         hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
         hipLaunchKernelGGL(k_dref_export_grho, px_t, dim3(256), 0, st, (const float *)h->jrec, (int)JL::JREC, (const double *)h->dref_export, 2 + 6 * JMAXS, ex->d_g_rho, (int)hw);
+        if (ex->d_g_rho_src) {
+            // The gradient w.r.t. the SOURCE inverse-depth maps (held fixed by the refinement; leaves of the reference's optimize_depth_pred).
+            // Their role mirrors the target map's: local in the inverse pair -- the joint kernel run on the inverse pairs as S = 1 groups
+            // without argmin IS the reference's inverse term (0.25 / K_i, own weights, valid x auto-mask, its depth-consistency term) --
+            // and sampled by the forward pair: k_dref_scatter_src, in units of the forward factor a_f.  Oracle: dref_source_depth_gradient.
+            HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)SB * hw * sizeof(long long), st));
+            const dim3 px_f((unsigned)((hw + 255) / 256), SB);
+            hipLaunchKernelGGL(k_dref_scatter_src, px_f, dim3(256), 0, st, Pp, Dp, h->dref_ext, J.c_f);
+            LinParams Pj2 = lin_params(h, &oo, 6);
+            Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
+            Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
+            JointParams J2 = J;
+            J2.jrec = h->jrec_acc; J2.depth0 = nullptr; J2.B = SB; J2.S = 1; J2.argmin = 0; J2.automask = o->automask;
+            J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
+            J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
+            J2.ext = h->dref_ext; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
+            hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            hipLaunchKernelGGL(k_dref_export_grho_src, px_f, dim3(256), 0, st, (const float *)h->jrec_acc, (int)JointLayout<1>::JREC, (const int *)h->dref_norms, ex->d_g_rho_src, (int)hw);
+        }
         HIPCHK(h, hipGetLastError());
         constexpr int kLin6 = 6 * 6 + 6 + 4;          // k_solve<6> mode 2: H [36], g [6], cost, cost_photo, cost_dc, n_mask
         std::vector<double> lin((size_t)SB * kLin6), jx((size_t)B * (2 + 6 * JMAXS));
@@ -1901,9 +1920,9 @@ int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B,
     return TCSFM_OK;
 }
 
-int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
-                                 const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
-                                 double *scal_out, double *g_pose_out, float *g_rho_out) {
+static int linearize_dense_window_impl(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                       const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
+                                       double *scal_out, double *g_pose_out, float *g_rho_out, float *g_rho_src_out) {
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || S > JMAXS || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_dense_window: need 1 <= S <= 3 and 2*B*S <= max_pairs");
     const int N = 2 * B * S;
@@ -1924,18 +1943,32 @@ int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int
     if ((rc = to_dev(h, o, 5, pose, (size_t)N * 6, &d_pose))) return rc;
     const float *d_d0 = nullptr;
     if (depth0 && (rc = to_dev(h, o, 6, depth0, (size_t)B * hw, &d_d0))) return rc;
-    float *d_g;
+    float *d_g, *d_gs = nullptr;
     if ((rc = out_dev(h, o, 7, g_rho_out, (size_t)B * hw, &d_g))) return rc;
+    if (g_rho_src_out && (rc = out_dev(h, o, 8, g_rho_src_out, (size_t)S * B * hw, &d_gs))) return rc;
     tcsfm_opts oo = *o;
     oo.n_iters = 1; oo.solver = TCSFM_SOLVER_GN;
-    DrefExport ex{scal_out, g_pose_out, d_g, d_d0};
+    DrefExport ex{scal_out, g_pose_out, d_g, d_d0, d_gs};
     rc = S == 1 ? dense_ref_run<1>(h, &oo, B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose, nullptr, nullptr, nullptr, nullptr, &ex)
        : S == 2 ? dense_ref_run<2>(h, &oo, B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose, nullptr, nullptr, nullptr, nullptr, &ex)
                 : dense_ref_run<3>(h, &oo, B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose, nullptr, nullptr, nullptr, nullptr, &ex);
     if (rc) return rc;
     if ((rc = copy_back(h, o, g_rho_out, d_g, (size_t)B * hw))) return rc;
+    if (g_rho_src_out && (rc = copy_back(h, o, g_rho_src_out, d_gs, (size_t)S * B * hw))) return rc;
     if (o->host_ptrs) HIPCHK(h, hipStreamSynchronize(h->stream));
     return TCSFM_OK;
+}
+
+int tcsfm_linearize_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                 const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
+                                 double *scal_out, double *g_pose_out, float *g_rho_out) {
+    return linearize_dense_window_impl(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose, depth0, scal_out, g_pose_out, g_rho_out, nullptr);
+}
+int tcsfm_linearize_dense_window_sources(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
+                                         const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
+                                         double *scal_out, double *g_pose_out, float *g_rho_out, float *g_rho_src_out) {
+    if (!g_rho_src_out) return h ? fail(h, TCSFM_E_ARG, "tcsfm_linearize_dense_window_sources: NULL argument") : TCSFM_E_ARG;
+    return linearize_dense_window_impl(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose, depth0, scal_out, g_pose_out, g_rho_out, g_rho_src_out);
 }
 
 int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {

@@ -367,11 +367,13 @@ class Engine:
                                                       self._p(st)))
         return pose_out, depth_out, st
 
-    def linearize_dense_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, argmin: Optional[bool] = None, depth0=None):
+    def linearize_dense_window(self, tgt, srcs, depth_t, depth_s, K, pose, opts: Optional[Opts] = None, argmin: Optional[bool] = None, depth0=None,
+                               sources: bool = False):
         """tcsfm_linearize_dense_window: ONE linearisation of the dense window mode on the reference's own loss (window_rule REFERENCE;
         optimizer.py:47-90) -> dict(loss, fwd, inv_photo, inv_dc, K_f, K_i, a_f, g_pose [2SB,6] float64 (w.r.t. the left SE(3)
         perturbation of every pair's warp), g_rho [B,1,H,W] GPU tensor = d loss / d inverse depth of every target);
-        depth0 [B,1,H,W]: the centre of the l_depth_init prior (default: depth_t)"""
+        depth0 [B,1,H,W]: the centre of the l_depth_init prior (default: depth_t).  sources=True (tcsfm_linearize_dense_window_sources):
+        also g_rho_src [S,B,1,H,W] = d loss / d inverse depth of every SOURCE map (held fixed by the refinement)"""
         self._bind()
         o = _copy_opts(opts or default_opts())
         if argmin is not None:
@@ -389,11 +391,20 @@ class Engine:
         d0 = None if depth0 is None else _chk(depth0, (B, 1, self.H, self.W), "depth0")
         scal = np.zeros(8); gp = np.zeros((N, 6))
         g_rho = torch.empty((B, 1, self.H, self.W), device=pose.device, dtype=torch.float32)
-        self._call(self.lib.tcsfm_linearize_dense_window(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
-                                                         self._p(K), self._p(pose), self._p(d0), scal.ctypes.data_as(C.c_void_p),
-                                                         gp.ctypes.data_as(C.c_void_p), self._p(g_rho)))
+        g_src = torch.empty((S, B, 1, self.H, self.W), device=pose.device, dtype=torch.float32) if sources else None
+        if sources:
+            self._call(self.lib.tcsfm_linearize_dense_window_sources(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                                                     self._p(K), self._p(pose), self._p(d0), scal.ctypes.data_as(C.c_void_p),
+                                                                     gp.ctypes.data_as(C.c_void_p), self._p(g_rho), self._p(g_src)))
+        else:
+            self._call(self.lib.tcsfm_linearize_dense_window(self._h, C.byref(o), B, S, self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                                             self._p(K), self._p(pose), self._p(d0), scal.ctypes.data_as(C.c_void_p),
+                                                             gp.ctypes.data_as(C.c_void_p), self._p(g_rho)))
         torch.cuda.synchronize(self.device)
-        return dict(loss=scal[0], fwd=scal[1], inv_photo=scal[2], inv_dc=scal[3], K_f=scal[4], K_i=scal[5], a_f=scal[6], g_pose=gp, g_rho=g_rho)
+        out = dict(loss=scal[0], fwd=scal[1], inv_photo=scal[2], inv_dc=scal[3], K_f=scal[4], K_i=scal[5], a_f=scal[6], g_pose=gp, g_rho=g_rho)
+        if sources:
+            out["g_rho_src"] = g_src
+        return out
 
     def scale_recovery(self, depth, intrinsics, real_cam_height: float, pad_to_batch: int = 0, maps: bool = False):
         """ScaleRecovery.forward (dnet_layers.py:306-327): depth [N,1,H,W], K [N,3,3] -> scale [1] (GPU tensor)
