@@ -303,6 +303,21 @@ class Oracle:
                                       C.c_double(min_depth), C.c_double(max_depth), self._p(poses), self._p(stats), self._p(b))
         return poses, depth_t, stats
 
+    def refine_dense_ref_free(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06,
+                              max_depth=2.67, bits=None):
+        """orc_refine_dense_ref_free: as refine_dense_ref with the SOURCE depth maps as unknowns too (the reference's optimize_depth_pred
+        optimises them, with no prior): every inverse pair is a group of its pose and the source map it back-projects
+        -> (poses [2SB,6], depth_t [B,H,W], depth_s [S,B,H,W], stats [n_iters,7])"""
+        o = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K, poses, S, B, H, W = self._dref_args(tgt, srcs, depth_t, depth_s, K, poses)
+        depth_s = np.ascontiguousarray(depth_s).copy()
+        stats = np.zeros((o.n_iters, 7))
+        b, _ = self._forced(bits, None)
+        self.lib.orc_refine_dense_ref_free(C.c_int(H), C.c_int(W), C.c_int(B), C.c_int(S), self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                           self._p(K), C.byref(o), C.c_int(1 if argmin else 0), C.c_double(w_init), C.c_double(lambda_depth),
+                                           C.c_double(min_depth), C.c_double(max_depth), self._p(poses), self._p(stats), self._p(b))
+        return poses, depth_t, depth_s, stats
+
     def refine_dense_ref_q(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06,
                            max_depth=2.67, bits=None):
         """the same in the reference's parametrisation (optimizer.py:194-198, 235-239: QUARTER-resolution map, upsampled x4 bilinear every

@@ -1990,6 +1990,7 @@ void orc_refine_dense_joint(int H, int W, int B, int S, const real *tgt, const r
  * sampled-depth terms and e dW/d. terms are gradient-only, as in every other mode.  Inverse pairs: 6 x 6 pose systems under the
  * window REFERENCE rule (linearize_masked with the batch normaliser), their depth is not an unknown.
  */
+typedef struct { double *Dq, *Bq, *Hs, *gs; } dref_src_sys;   /* [SB][n], [SB][n][6], [SB][36] (reduced), [SB][6] (reduced) */
 /* Gradient of the same loss w.r.t. the SOURCE inverse-depth maps rho_s(m, q) = 1 / depth_s(m, q), m = (s, b) -- the leaves of the
  * reference's optimize_depth_pred that the engine holds fixed (optimizer.py:194-198: the quarter-resolution disparities of the target AND
  * of every source are optimised).  Their role mirrors the target map's:
@@ -2002,75 +2003,28 @@ void orc_refine_dense_joint(int H, int W, int B, int S, const real *tgt, const r
  * autograd: golden G13 `full_grad_depth_s` and the source channels of `qinit_grad_q` (tests/test_oracle_vs_golden.py). */
 static void dref_source_depth_gradient(int H, int W, int B, int S, const real *tgt, const real *srcs, const real *depth_t, const real *depth_s,
                                        const real *K, const orc_opts *op, int argmin, const double *T, const real *const *ae, const real *imask /* [SB][n] */,
-                                       const real *fmask /* [SB][n] */, const real *fdiff /* [SB][n] */, double a_f, double a_i, double bdc, double *g_rho_s) {
+                                       const real *fmask /* [SB][n] */, const real *fdiff /* [SB][n] */, double a_f, double a_i, double bdc,
+                                       const unsigned short *bits /* [2SB][n] or NULL: forced replay */, double lambda_depth, double *g_rho_s,
+                                       double *Dq_s /* [SB][n] or NULL */, double *Bq_s /* [SB][n][6] or NULL */, double *Hs /* [SB][36]: reduced pose systems, or NULL */,
+                                       double *gs /* [SB][6] */) {
     const int n = H * W, SB = S * B;
-    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3);
+    const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3), reps = (real)op->irls_eps;
     const double eps = op->irls_eps;
     (void)ae;
     memset(g_rho_s, 0, sizeof(double) * (size_t)SB * n);
     px_t *px = (px_t *)malloc(sizeof(px_t) * n);
     real *rec = (real *)malloc(sizeof(real) * 3 * n);
-    double *adj = (double *)malloc(sizeof(double) * 2 * n);
+    double *adj = (double *)malloc(sizeof(double) * 2 * n), *Lam = (double *)calloc((size_t)3 * n, sizeof(double));
     for (int m = 0; m < SB; m++) {
         const int b = m % B, pn = SB + m;
         const real *ti = srcs + (size_t)m * 3 * n;      /* the inverse pair's target image = source image m */
         const real *ds = depth_s + (size_t)m * n;
         double *gr = g_rho_s + (size_t)m * n;
-        /* ---- (i) the inverse pair: per-pixel quantities with the inverse-depth column ---- */
+        /* ---- (ii) first: the forward pair m samples this map: adjoint of the bilinear sample (its sums join the local gradient below) ---- */
         cam_t c;
-        cam_setup(&c, H, W, K + 9 * b, T + 12 * pn, 0.0);
-        g_force_bits = NULL;
-        for (int v = 0; v < H; v++)
-            for (int u = 0; u < W; u++) {
-                px_t *P = &px[v * W + u];
-                px_eval(&c, tgt + (size_t)b * 3 * n, ds, depth_t + (size_t)b * n, u, v, 7, P);
-                const real D = ds[v * W + u];
-                P->a[6] *= -D; P->b[6] *= -D; P->zc[6] *= -D;
-                P->dpd[6] = P->dgx * P->a[6] + P->dgy * P->b[6];
-            }
-        for (int i = 0; i < n; i++)
-            for (int ch = 0; ch < 3; ch++) rec[ch * n + i] = px[i].rec[ch];
-        memset(adj, 0, sizeof(double) * 2 * n);
-        for (int v = 0; v < H; v++)
-            for (int u = 0; u < W; u++) {
-                const int i = v * W + u;
-                const px_t *P = &px[i];
-                const real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum, dd = clamp01(raw);
-                const real sg = (raw >= 0 && raw <= 1) ? (dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0)) : (real)0;
-                const double ddJ6 = sg * 2.0 * (P->pd * P->zc[6] - P->cd * P->dpd[6]) / ((double)sum * sum);
-                gr[i] += bdc * fmin(1.0, dd / eps) * ddJ6;                                   /* depth consistency of the inverse pair */
-                const double am = imask[(size_t)m * n + i];
-                if (am == 0) continue;
-                const real Wt = 1 - dd;
-                real e = 0;
-                for (int ch = 0; ch < 3; ch++) {
-                    const real *xx = ti + ch * n, *y = rec + ch * n;
-                    const real r = y[i] - xx[i], ar = fabs(r);
-                    const real sgn = (ar <= 1) ? (r > 0 ? (real)1 : (r < 0 ? (real)-1 : (real)0)) : (real)0;
-                    adj[2 * i] += am * Wt * wl * sgn * P->gx[ch];
-                    adj[2 * i + 1] += am * Wt * wl * sgn * P->gy[ch];
-                    ssim_t q;
-                    ssim_at(xx, y, H, W, u, v, &q);
-                    e += wl * clamp01(ar) + ws * q.s;
-                    if (!q.clamped) {
-                        const real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
-                        const real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
-                        const real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);
-                        for (int dv = -1; dv <= 1; dv++)
-                            for (int du = -1; du <= 1; du++) {
-                                const int qi = refl(v + dv, H) * W + refl(u + du, W);
-                                const real cf = ws * (cA + cB * y[qi] + cC * xx[qi]);
-                                adj[2 * qi] += am * Wt * cf * px[qi].gx[ch];
-                                adj[2 * qi + 1] += am * Wt * cf * px[qi].gy[ch];
-                            }
-                    }
-                }
-                gr[i] -= a_i * am * e * ddJ6;                                                /* the pair's own weight: -M diff d dd / d rho */
-            }
-        for (int i = 0; i < n; i++) gr[i] += a_i * (adj[2 * i] * px[i].a[6] + adj[2 * i + 1] * px[i].b[6]);
-        /* ---- (ii) the forward pair m samples this map: adjoint of the bilinear sample ---- */
         cam_setup(&c, H, W, K + 9 * b, T + 12 * m, 0.0);
         const int provider = argmin ? (m / B == 0) : 1;        /* does this pair's weight map multiply photometric terms (optimizer.py:69) */
+        g_force_bits = bits ? bits + (size_t)m * n : NULL;
         for (int v = 0; v < H; v++)
             for (int u = 0; u < W; u++) {
                 const int i = v * W + u;
@@ -2081,7 +2035,7 @@ static void dref_source_depth_gradient(int H, int W, int B, int S, const real *t
                 bilinear_cell(ds, H, W, g.ix, g.iy, g.adjx, g.adjy, &pdv, &dgx, &dgy);
                 const real cd = g.Z, pd = pdv, sum = cd + pd, dif = cd - pd, raw = fabs(dif) / sum;
                 if (!(raw >= 0 && raw <= 1)) continue;
-                const real sg = dif > 0 ? (real)1 : (dif < 0 ? (real)-1 : (real)0);
+                const real sg = forced_sign(dif, (real)1e-6 * sum, i, 4);
                 const double ddd = -(double)sg * 2.0 * cd / ((double)sum * sum);              /* d dd / d pd */
                 const double dd = clamp01(raw);
                 double E = 0;                                                                 /* sum of M diff of the pixels this weight multiplies */
@@ -2098,8 +2052,112 @@ static void dref_source_depth_gradient(int H, int W, int B, int S, const real *t
                     if (xx >= 0 && xx < W && yy >= 0 && yy < H) gr[yy * W + xx] -= (double)ds[yy * W + xx] * ds[yy * W + xx] * coef * w4[t];   /* d / d rho = -depth^2 d / d depth */
                 }
             }
+        /* ---- (i) the inverse pair: per-pixel quantities with the inverse-depth column ---- */
+        cam_setup(&c, H, W, K + 9 * b, T + 12 * pn, 0.0);
+        g_force_bits = bits ? bits + (size_t)pn * n : NULL;
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                px_t *P = &px[v * W + u];
+                px_eval(&c, tgt + (size_t)b * 3 * n, ds, depth_t + (size_t)b * n, u, v, 7, P);
+                const real D = ds[v * W + u];
+                P->a[6] *= -D; P->b[6] *= -D; P->zc[6] *= -D;
+                P->dpd[6] = P->dgx * P->a[6] + P->dgy * P->b[6];
+            }
+        for (int i = 0; i < n; i++)
+            for (int ch = 0; ch < 3; ch++) rec[ch * n + i] = px[i].rec[ch];
+        memset(adj, 0, sizeof(double) * 2 * n);
+        memset(Lam, 0, sizeof(double) * 3 * n);
+        double gxi[6] = {0, 0, 0, 0, 0, 0}, Hxx[36], Sm[36], gsv[6] = {0, 0, 0, 0, 0, 0};
+        memset(Hxx, 0, sizeof(Hxx)); memset(Sm, 0, sizeof(Sm));
+        for (int v = 0; v < H; v++)
+            for (int u = 0; u < W; u++) {
+                const int i = v * W + u;
+                const px_t *P = &px[i];
+                const double am = imask[(size_t)m * n + i];
+                if (am == 0) continue;
+                const real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum, dd = clamp01(raw);
+                const real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
+                const double kdd = sg * 2.0 / ((double)sum * sum);
+                const real Wt = 1 - dd;
+                real e = 0;
+                double lxx = 0, lxy = 0, lyy = 0;
+                for (int ch = 0; ch < 3; ch++) {
+                    const real *xx = ti + ch * n, *y = rec + ch * n;
+                    const real r = y[i] - xx[i], ar = fabs(r);
+                    const real sgn = (ar <= 1) ? forced_sign(r, (real)1e-6, i, 6 + 2 * ch) : (real)0;
+                    adj[2 * i] += am * Wt * wl * sgn * P->gx[ch];
+                    adj[2 * i + 1] += am * Wt * wl * sgn * P->gy[ch];
+                    if (ar <= 1) {
+                        real w1 = wl * Wt / (ar > reps ? ar : reps);
+                        lxx += w1 * P->gx[ch] * P->gx[ch]; lxy += w1 * P->gx[ch] * P->gy[ch]; lyy += w1 * P->gy[ch] * P->gy[ch];
+                    }
+                    ssim_t q;
+                    ssim_at(xx, y, H, W, u, v, &q);
+                    e += wl * clamp01(ar) + ws * q.s;
+                    if (!q.clamped) {
+                        const real nn = q.n1 * q.n2, dn = q.d1 * q.d2, ratio = nn / dn, pre = -(real)0.5 / dn / 9;
+                        const real cA = pre * (2 * q.mux * q.n2 - 2 * q.n1 * q.mux - ratio * (2 * q.muy * q.d2 - 2 * q.d1 * q.muy));
+                        const real cB = pre * (-ratio * 2 * q.d1), cC = pre * (2 * q.n1);
+                        real Sx = 0, Sy = 0;
+                        for (int dv = -1; dv <= 1; dv++)
+                            for (int du = -1; du <= 1; du++) {
+                                const int qi = refl(v + dv, H) * W + refl(u + du, W);
+                                const real cf = ws * (cA + cB * y[qi] + cC * xx[qi]);
+                                adj[2 * qi] += am * Wt * cf * px[qi].gx[ch];
+                                adj[2 * qi + 1] += am * Wt * cf * px[qi].gy[ch];
+                                Sx += px[qi].gx[ch]; Sy += px[qi].gy[ch];
+                            }
+                        const real ninth = (real)1 / 9;
+                        real mx = Sx * ninth, my = Sy * ninth, ex = P->gx[ch] - mx, ey = P->gy[ch] - my;
+                        real w2 = ws * Wt / q.d2 * (real)1.125, w3 = ws * Wt / q.d1;
+                        lxx += w2 * ex * ex + w3 * mx * mx; lxy += w2 * ex * ey + w3 * mx * my; lyy += w2 * ey * ey + w3 * my * my;
+                    }
+                }
+                Lam[3 * i] = lxx; Lam[3 * i + 1] = lxy; Lam[3 * i + 2] = lyy;
+                /* the pair's own weight: -M diff d dd / d theta */
+                for (int j = 0; j < 6; j++) gxi[j] -= a_i * am * e * kdd * (P->pd * P->zc[j] - P->cd * P->dpd[j]);
+                gr[i] -= a_i * am * e * kdd * (P->pd * P->zc[6] - P->cd * P->dpd[6]);
+            }
+        for (int i = 0; i < n; i++) {
+            const px_t *P = &px[i];
+            const double ax = a_i * adj[2 * i], ay = a_i * adj[2 * i + 1];
+            for (int j = 0; j < 6; j++) gxi[j] += ax * P->a[j] + ay * P->b[j];
+            gr[i] += ax * P->a[6] + ay * P->b[6];
+            const double am = a_i * imask[(size_t)m * n + i];
+            const double lxx = am * Lam[3 * i], lxy = am * Lam[3 * i + 1], lyy = am * Lam[3 * i + 2];
+            /* depth consistency of the inverse pair (every pixel of the image) */
+            const real sum = P->cd + P->pd, dif = P->cd - P->pd, raw = fabs(dif) / sum, dd = clamp01(raw);
+            const real sg = (raw >= 0 && raw <= 1) ? forced_sign(dif, (real)1e-6 * sum, i, 4) : (real)0;
+            double ddJ[7];
+            for (int j = 0; j < 7; j++) ddJ[j] = sg * 2.0 * (P->pd * P->zc[j] - P->cd * P->dpd[j]) / ((double)sum * sum);
+            const double inf = bdc * fmin(1.0, dd / eps), k3 = P->dc_in ? bdc / fmax((double)dd, eps) : 0.0;
+            gr[i] += inf * ddJ[6];
+            const double la6 = lxx * P->a[6] + lxy * P->b[6], lb6 = lxy * P->a[6] + lyy * P->b[6];
+            double D = la6 * P->a[6] + lb6 * P->b[6] + k3 * ddJ[6] * ddJ[6], Bv[6];
+            for (int j = 0; j < 6; j++) {
+                gxi[j] += inf * ddJ[j];
+                const double la = lxx * P->a[j] + lxy * P->b[j], lb = lxy * P->a[j] + lyy * P->b[j];
+                Bv[j] = la * P->a[6] + lb * P->b[6] + k3 * ddJ[j] * ddJ[6];
+                for (int k = 0; k <= j; k++) Hxx[j * 6 + k] += la * P->a[k] + lb * P->b[k] + k3 * ddJ[j] * ddJ[k];
+            }
+            if (P->valid && !P->dc_in) D = 0;                   /* sampled across the zero padding: the pixel keeps its depth */
+            if (Dq_s) Dq_s[(size_t)m * n + i] = D;
+            if (Bq_s) memcpy(Bq_s + ((size_t)m * n + i) * 6, Bv, sizeof(Bv));
+            const double Dd = (1.0 + lambda_depth) * D;
+            if (Dd > 1e-30)
+                for (int j = 0; j < 6; j++) {
+                    gsv[j] -= Bv[j] * gr[i] / Dd;
+                    for (int k = 0; k <= j; k++) Sm[j * 6 + k] -= Bv[j] * Bv[k] / Dd;
+                }
+        }
+        if (Hs && gs)
+            for (int j = 0; j < 6; j++) {
+                gs[6 * m + j] = gxi[j] + gsv[j];
+                for (int k = 0; k <= j; k++) { const double vv = Hxx[j * 6 + k] + Sm[j * 6 + k]; Hs[36 * m + j * 6 + k] = vv; Hs[36 * m + k * 6 + j] = vv; }
+            }
     }
-    free(px); free(rec); free(adj);
+    g_force_bits = NULL;
+    free(px); free(rec); free(adj); free(Lam);
 }
 
 typedef struct {
@@ -2111,7 +2169,8 @@ static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, con
                                 double lambda_depth, const double *T /* [2SB][12] */, const real *const *ae /* [2SB] */, const unsigned short *bits /* [2SB][n] or NULL */,
                                 dref_scal *sc, double *g_xi /* [2SB][6] */, double *g_rho /* [B][n] */, double *Hj /* [B][6S x 6S] */, double *gj /* [B][6S] */,
                                 double *Dq /* [B][n] */, double *Bq /* [B][n][6S] */, double *Hi /* [SB][36] */, double *gi /* [SB][6] */,
-                                double *g_rho_s /* [SB][n] or NULL: d L / d (1 / depth_s) -- see dref_source_depth_gradient */) {
+                                double *g_rho_s /* [SB][n] or NULL: d L / d (1 / depth_s) -- see dref_source_depth_gradient */,
+                                const dref_src_sys *src_sys /* or NULL: the inverse pairs' systems with the source map as a second unknown */) {
     const int n = H * W, SB = S * B, NP = 6 * S;
     const real wl = (real)(op->w_l1 / 3), ws = (real)(op->w_ssim / 3), reps = (real)op->irls_eps;
     const double bdc = op->w_dc / ((double)SB * n), eps = op->irls_eps;
@@ -2439,7 +2498,8 @@ static void linearize_dense_ref(int H, int W, int B, int S, const real *tgt, con
     }
     sc->loss = sc->L_fwd + sc->L_inv + sc->L_dc + sc->L_init;
     if (g_rho_s)
-        dref_source_depth_gradient(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, T, ae, imask, mask, diff, a_f, a_i, bdc, g_rho_s);
+        dref_source_depth_gradient(H, W, B, S, tgt, srcs, depth_t, depth_s, K, op, argmin, T, ae, imask, mask, diff, a_f, a_i, bdc, bits, lambda_depth, g_rho_s,
+                                   src_sys ? src_sys->Dq : NULL, src_sys ? src_sys->Bq : NULL, src_sys ? src_sys->Hs : NULL, src_sys ? src_sys->gs : NULL);
     for (int m = 0; m < SB; m++) { free(px[m]); free(rec[m]); }
     free(px); free(rec); free(diff); free(valid); free(Wm); free(mask); free(margin); free(imask); free(ext);
     free(gx_adj); free(Lam); free(own); free(gxi); free(Hxx); free(Sm); free(gs); free(pri_g); free(pri_D); free(sig); free(sig0);
@@ -2468,7 +2528,7 @@ void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const 
     for (int m = 0; m < 2 * SB; m++) orc_pose_to_T(pose + 6 * m, T + 12 * m);
     dref_scal sc;
     linearize_dense_ref(H, W, B, S, tgt, srcs, depth_t, depth_s, depth0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep, NULL, &sc,
-                        g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s);
+                        g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s, NULL);
     scal[0] = sc.loss; scal[1] = sc.L_fwd; scal[2] = sc.L_inv; scal[3] = sc.L_dc; scal[4] = sc.L_init; scal[5] = sc.Kf; scal[6] = sc.Ki;
     free(ae); free(aep); free(T);
 }
@@ -2477,9 +2537,9 @@ void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const 
  * inverse pair's pose }, fixed damping lambda0 on the pose blocks (Marquardt-scaled) and lambda_depth on the depth block.
  * depth_io [B][n] in / out; pose_io [2SB][6]; stats [n_iters][7] (the scalars of every linearisation) or NULL;
  * bits [n_iters][2SB][n]: forced replay of the engine's decisions. */
-void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
-                          const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
-                          double *pose_io, double *stats, const unsigned short *bits) {
+static void refine_dense_ref_impl(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, real *depth_s /* in / out when free_sources */,
+                                  const real *K, const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                                  double *pose_io, double *stats, const unsigned short *bits, int free_sources) {
     const int n = H * W, SB = S * B, NP = 6 * S;
     const double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
     real *ae = (real *)malloc(sizeof(real) * (size_t)2 * SB * n), *d0 = (real *)malloc(sizeof(real) * (size_t)B * n);
@@ -2489,6 +2549,15 @@ void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const rea
     double *Hj = (double *)malloc(sizeof(double) * (size_t)B * NP * NP), *gj = (double *)malloc(sizeof(double) * (size_t)B * NP);
     double *Dq = (double *)malloc(sizeof(double) * (size_t)B * n), *Bq = (double *)malloc(sizeof(double) * (size_t)B * n * NP);
     double *Hi = (double *)malloc(sizeof(double) * 36 * SB), *gi = (double *)malloc(sizeof(double) * 6 * SB);
+    /* free_sources: the source maps are unknowns too -- every inverse pair is a group of its own (its pose + the source map it back-projects),
+     * linearised by dref_source_depth_gradient: reduced 6 x 6 system Hs / gs, per-pixel g, D, B for the back-substitution */
+    dref_src_sys ss = {NULL, NULL, NULL, NULL};
+    double *g_rho_s = NULL;
+    if (free_sources) {
+        g_rho_s = (double *)malloc(sizeof(double) * (size_t)SB * n);
+        ss.Dq = (double *)malloc(sizeof(double) * (size_t)SB * n); ss.Bq = (double *)malloc(sizeof(double) * (size_t)SB * n * 6);
+        ss.Hs = (double *)malloc(sizeof(double) * 36 * SB); ss.gs = (double *)malloc(sizeof(double) * 6 * SB);
+    }
     dref_auto_err(H, W, B, S, tgt, srcs, op, ae, aep);
     memcpy(d0, depth_io, sizeof(real) * (size_t)B * n);
     for (int m = 0; m < 2 * SB; m++) orc_pose_to_T(pose_io + 6 * m, T + 12 * m);
@@ -2496,7 +2565,7 @@ void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const rea
         dref_scal sc;
         g_lin_idx = bits ? it : -1;
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep,
-                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, NULL);
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s, free_sources ? &ss : NULL);
         g_lin_idx = -1;
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {       /* forward group: (S + lambda diag S + 1e-12 I) d = -gS, back-substitution of the depth map */
@@ -2522,6 +2591,27 @@ void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const rea
             }
         }
         for (int m = 0; m < SB; m++) {      /* inverse pairs: their own 6 x 6 systems */
+            if (free_sources) {             /* ... reduced by the source map: the same step as a forward group of one source */
+                double A[36], dl[6];
+                for (int i = 0; i < 6; i++) {
+                    for (int j = 0; j < 6; j++) A[i * 6 + j] = ss.Hs[36 * m + i * 6 + j];
+                    A[i * 6 + i] += op->lambda0 * ss.Hs[36 * m + i * 6 + i] + 1e-12;
+                    dl[i] = -ss.gs[6 * m + i];
+                }
+                if (chol_solve(6, A, dl)) memset(dl, 0, sizeof(dl));
+                double E[12], Tn[12];
+                orc_se3_exp(dl, E);
+                orc_se3_mul(E, T + 12 * (SB + m), Tn);
+                memcpy(T + 12 * (SB + m), Tn, sizeof(Tn));
+                for (int i = 0; i < n; i++) {
+                    const double Dd = (1.0 + lambda_depth) * ss.Dq[(size_t)m * n + i];
+                    if (!(Dd > 1e-30)) continue;
+                    double bd = 0;
+                    for (int j = 0; j < 6; j++) bd += ss.Bq[((size_t)m * n + i) * 6 + j] * dl[j];
+                    depth_s[(size_t)m * n + i] = (real)(1.0 / depth_step(1.0 / (double)depth_s[(size_t)m * n + i], -(g_rho_s[(size_t)m * n + i] + bd) / Dd, lo, hi));
+                }
+                continue;
+            }
             orc_opts o6 = *op;
             o6.nparam = 6; o6.param = 0;
             double Tn[12], sdummy;
@@ -2531,6 +2621,18 @@ void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const rea
     }
     for (int m = 0; m < 2 * SB; m++) orc_T_to_pose(T + 12 * m, pose_io + 6 * m);
     free(ae); free(d0); free(aep); free(T); free(g_xi); free(g_rho); free(Hj); free(gj); free(Dq); free(Bq); free(Hi); free(gi);
+    free(g_rho_s); free(ss.Dq); free(ss.Bq); free(ss.Hs); free(ss.gs);
+}
+void orc_refine_dense_ref(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
+                          const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                          double *pose_io, double *stats, const unsigned short *bits) {
+    refine_dense_ref_impl(H, W, B, S, tgt, srcs, depth_io, (real *)depth_s, K, op, argmin, w_init, lambda_depth, min_depth, max_depth, pose_io, stats, bits, 0);
+}
+/* the same with the SOURCE maps as unknowns (depth_s_io [SB][n] in / out): the reference's optimize_depth_pred optimises them too, with no prior */
+void orc_refine_dense_ref_free(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, real *depth_s_io, const real *K,
+                               const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                               double *pose_io, double *stats, const unsigned short *bits) {
+    refine_dense_ref_impl(H, W, B, S, tgt, srcs, depth_io, depth_s_io, K, op, argmin, w_init, lambda_depth, min_depth, max_depth, pose_io, stats, bits, 1);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2631,7 +2733,7 @@ void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const r
         g_lin_idx = bits ? it : -1;
         /* lambda_depth = infinity: no per-pixel elimination inside -- Hj / gj come back as the pose blocks and pose gradients themselves */
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, INFINITY, T, aep,
-                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, NULL);
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, NULL, NULL);
         g_lin_idx = -1;
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {

@@ -32,16 +32,16 @@ def test_opts_struct_matches_header(lib):
     o = _lib.default_opts()
     assert (o.n_iters, o.solver, o.param, o.refine, o.automask) == (4, 0, 0, 0, 1)
     assert abs(o.w_l1 - 0.15) < 1e-7 and abs(o.w_ssim - 0.85) < 1e-7 and abs(o.max_depth - 2.67) < 1e-6
-    assert C.sizeof(_lib.Opts) == 8 * 4 + 13 * 4 + 6 * 4          # 8 int32, 13 float, then window_rule / dense_joint (int32) / prior_init (float) / depth_param (int32) / w_pose_consist, w_smooth (float)
+    assert C.sizeof(_lib.Opts) == 8 * 4 + 13 * 4 + 7 * 4          # 8 int32, 13 float, then window_rule / dense_joint (int32) / prior_init (float) / depth_param (int32) / w_pose_consist, w_smooth (float) / free_source_depths (int32)
     assert (o.window_rule, o.dense_joint, o.depth_param) == (_lib.WINDOW_PAIR, 1, _lib.DEPTH_FULL) and abs(o.prior_init - 0.1) < 1e-7
     # the header's struct, compiled by the C compiler, has the same size and the same offsets of the last fields
     import subprocess, tempfile, os
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tcsfm.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(tcsfm_opts), offsetof(tcsfm_opts, prior_depth), offsetof(tcsfm_opts, window_rule), offsetof(tcsfm_opts, dense_joint), offsetof(tcsfm_opts, depth_param), offsetof(tcsfm_opts, w_pose_consist), offsetof(tcsfm_opts, w_smooth));return 0;}'
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tcsfm.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu", sizeof(tcsfm_opts), offsetof(tcsfm_opts, prior_depth), offsetof(tcsfm_opts, window_rule), offsetof(tcsfm_opts, dense_joint), offsetof(tcsfm_opts, depth_param), offsetof(tcsfm_opts, w_pose_consist), offsetof(tcsfm_opts, w_smooth), offsetof(tcsfm_opts, free_source_depths));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(REPO, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         got = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
-    assert got == [C.sizeof(_lib.Opts), _lib.Opts.prior_depth.offset, _lib.Opts.window_rule.offset, _lib.Opts.dense_joint.offset, _lib.Opts.depth_param.offset, _lib.Opts.w_pose_consist.offset, _lib.Opts.w_smooth.offset]
+    assert got == [C.sizeof(_lib.Opts), _lib.Opts.prior_depth.offset, _lib.Opts.window_rule.offset, _lib.Opts.dense_joint.offset, _lib.Opts.depth_param.offset, _lib.Opts.w_pose_consist.offset, _lib.Opts.w_smooth.offset, _lib.Opts.free_source_depths.offset]
     assert lib.tcsfm_algorithmic_bytes_per_pixel(C.byref(o)) == 32
 
 

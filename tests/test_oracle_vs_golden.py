@@ -624,6 +624,23 @@ def test_dense_reference_refinement_lowers_the_reference_loss(oracle64):
     assert np.isfinite(p).all() and np.isfinite(d).all() and 0 < np.median(rel) < 0.05 and rel.max() < 1.25 ** 5
 
 
+def test_dense_reference_refinement_with_free_source_maps(oracle64):
+    """orc_refine_dense_ref_free: the source depth maps as unknowns too (every inverse pair a group of its pose and the map it back-projects,
+    the adjoint of the forward pair's samples in its gradient -- the gradient pinned on reference autograd above): the loss falls from
+    linearisation to linearisation and further than with the sources held fixed; with zero iterations nothing moves"""
+    g = load_golden("winloss48x160")
+    a = (g["target"], g["sources"], g["depth_t"][:, 0] * 1.03, g["depth_s"][:, :, 0], g["K"], g["first"])
+    o = default_opts(n_iters=5, w_dc=0.15)
+    p1, d1, ds1, st1 = oracle64.refine_dense_ref_free(*a, o, argmin=True, w_init=0.1, lambda_depth=1.0)
+    p0, d0, st0 = oracle64.refine_dense_ref(*a, o, argmin=True, w_init=0.1, lambda_depth=1.0)
+    assert np.all(np.diff(st1[:, 0]) < 0), st1[:, 0]
+    assert st1[0, 0] == st0[0, 0] and np.all(st1[1:, 0] < st0[1:, 0]), (st1[:, 0], st0[:, 0])
+    rel = np.abs(ds1 / a[3] - 1)
+    assert np.isfinite(p1).all() and np.isfinite(ds1).all() and 0 < np.median(rel) < 0.1 and rel.max() < 1.25 ** 5
+    # the first linearisation does not depend on which maps are free: same loss terms
+    assert np.array_equal(st1[0], st0[0])
+
+
 @pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
 def test_quarter_resolution_parametrisation_vs_reference_G13(name, oracle64):
     """round 4: the reference's own parametrisation of optimize_depth_pred (optimizer.py:194-198, 235-239) -- the leaf is the QUARTER-

@@ -64,7 +64,7 @@ class Opts(C.Structure):
                 ("automask", C.c_int32), ("depth_is_disp", C.c_int32), ("host_ptrs", C.c_int32), ("argmin", C.c_int32),
                 ("w_l1", C.c_float), ("w_ssim", C.c_float), ("w_dc", C.c_float), ("irls_eps", C.c_float),
                 ("lambda0", C.c_float), ("lambda_up", C.c_float), ("lambda_down", C.c_float), ("lambda_min", C.c_float),
-                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prior_scale", C.c_float), ("lambda_depth", C.c_float), ("prior_depth", C.c_float), ("window_rule", C.c_int32), ("dense_joint", C.c_int32), ("prior_init", C.c_float), ("depth_param", C.c_int32), ("w_pose_consist", C.c_float), ("w_smooth", C.c_float)]
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("prior_scale", C.c_float), ("lambda_depth", C.c_float), ("prior_depth", C.c_float), ("window_rule", C.c_int32), ("dense_joint", C.c_int32), ("prior_init", C.c_float), ("depth_param", C.c_int32), ("w_pose_consist", C.c_float), ("w_smooth", C.c_float), ("free_source_depths", C.c_int32)]
 
 
 SOLVER_GN, SOLVER_LM = 0, 1

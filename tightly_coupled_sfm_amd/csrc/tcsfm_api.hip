@@ -104,6 +104,8 @@ struct tcsfm_ctx {
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; float *depth_out; const float *ls_in; float *ls_out; };
                                        // depth_out: dense calls; ls_in / ls_out: pose + scale calls (or null)
     float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
+    // free source depth maps (opts.free_source_depths): the inverse pairs as groups of one source
+    float *jrec_src = nullptr; JointState *jstate_src = nullptr; double *jdelta_src = nullptr; long long *dref_ext_src = nullptr;
     double *pose_lin = nullptr;        // l_pose_consist: [2][max_pairs][12] transforms at the linearisation (k_solve, kernels.h)
     float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
     int coal_max = 0;
@@ -696,6 +698,18 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->qres_rec, nb * nq * JM::JREC * sizeof(float)));
     }
     if (qres && nblk + nqblk > 2 * h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
+    // opts.free_source_depths: the inverse pairs as S B groups of one source (the joint kernel / solve / update on views offset by S B pairs)
+    const bool free_src = !ex && o->free_source_depths != 0;
+    if (free_src && qres) return fail(h, TCSFM_E_ARG, "free_source_depths needs the full-resolution unknown (depth_param = TCSFM_DEPTH_FULL)");
+    if (free_src && !h->jrec_src) {
+        const size_t ng = n / 2;          // groups <= max_pairs / 2
+        HIPCHK(h, hipMalloc((void **)&h->jrec_src, ng * hw * JointLayout<1>::JREC * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->jstate_src, ng * sizeof(JointState)));
+        HIPCHK(h, hipMalloc((void **)&h->jdelta_src, ng * 6 * JMAXS * sizeof(double)));
+        HIPCHK(h, hipMalloc((void **)&h->dref_ext_src, ng * hw * sizeof(long long)));
+    }
+    if (free_src && (size_t)SB * nblk * JointLayout<1>::NACC > ((n + 3) / 4) * 2 * (size_t)h->nblk_alloc * JM::NACC)
+        return fail(h, TCSFM_E_ARG, "internal: the inverse groups' records exceed the scratch");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the couplings are set explicitly below)
@@ -784,13 +798,34 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     HIPCHK(h, hipMemsetAsync(h->dref_norms, 0, 4 * sizeof(int), st));
     HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)B * hw * sizeof(long long), st));
     Uj.norms_zero = h->dref_norms;
+    LinParams Pj2 = lin_params(h, &oo, 6);
+    JointParams J2 = J;
+    JointSolveParams Sj2 = Sj;
+    JointUpdateParams Uj2 = Uj;
+    if (free_src) {
+        HIPCHK(h, hipMemsetAsync(h->dref_ext_src, 0, (size_t)SB * hw * sizeof(long long), st));
+        Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
+        Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
+        J2.jrec = h->jrec_src; J2.depth0 = nullptr; J2.B = SB; J2.S = 1; J2.argmin = 0; J2.automask = o->automask;
+        J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
+        J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
+        J2.ext = h->dref_ext_src; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
+        Sj2.js = h->jstate_src; Sj2.st = h->state + SB; Sj2.pc = h->pconst + SB; Sj2.B = SB; Sj2.nblk = nblk;
+        Sj2.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
+        Sj2.delta_out = h->jdelta_src; Sj2.norms = h->dref_norms + 1; Sj2.c_f = 0.25;
+        Uj2.jrec = h->jrec_src; Uj2.delta = h->jdelta_src; Uj2.depth = h->depth_work + (size_t)SB * hw; Uj2.B = SB; Uj2.S = 1;
+        Uj2.norms_zero = nullptr;                     // (the forward update zeroes the counters: it runs after both solves)
+        Uj2.srcpack_inv = h->srcpack;                 // forward pair m samples source map m: the depth channel of ITS pack
+    }
     auto linearise = [&](int lin) -> int {
         launch_lin(h, M, N, 6, false, MODE_MAPS, 2);
         hipLaunchKernelGGL(k_dref_count, dim3(DREF_CNT_WG, N), dim3(256), 0, st, Pp, Dp);
         hipLaunchKernelGGL(k_dref_scatter, dim3((unsigned)(((h->W + DREF_TW - 1) / DREF_TW) * ((h->H + DREF_TH - 1) / DREF_TH)), SB), dim3(DREF_TW * DREF_TH), 0, st, Pp, Dp);
         Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
         Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
-        launch_lin(h, Pi, SB, 6, dc, MODE_LIN, 2);
+        if (free_src)        // the adjoint of the forward pairs' samples of the source maps (before anything moves a forward pose)
+            hipLaunchKernelGGL(k_dref_scatter_src, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Pp, Dp, h->dref_ext_src, J.c_f);
+        else launch_lin(h, Pi, SB, 6, dc, MODE_LIN, 2);
         Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
         if (smooth) hipLaunchKernelGGL(k_dref_smooth, dim3(B), dim3(1024), 0, st, Ds);
@@ -854,13 +889,26 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         if ((rc = linearise(it))) return rc;
         const bool last = it == o->n_iters - 1;
         Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
-        launch_solve(h, Si, SB, 6);
+        if (!free_src) launch_solve(h, Si, SB, 6);
         Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
         hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
+        if (free_src) {
+            // every inverse pair as a group of one source WITHOUT argmin: that is the reference's inverse term (0.25 / K_i, own weights,
+            // valid x auto-mask, its depth-consistency term), its local unknowns the pair's pose and the source map it back-projects.  The
+            // workgroup records share jblockrec with the forward groups: the forward solve above has consumed them.
+            Pj2.trace = tr ? h->trace_bits + ((size_t)it * N + SB) * hw : nullptr;
+            if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            Sj2.it = it; Sj2.mode = 0; Sj2.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr;
+            Sj2.trace_decide = h->trace_decide ? h->trace_decide + (size_t)it * N + SB : nullptr;
+            hipLaunchKernelGGL((k_solve_joint<1>), dim3(SB), dim3(JSOLVE_NT), 0, st, Sj2);
+        }
         if (qres) {
             hipLaunchKernelGGL((k_qres_step<NS>), dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
             hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
         } else hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
+        if (free_src)        // the new source maps: the inverse pairs' own depth slots AND the depth channel of the packs the forward pairs sample
+            hipLaunchKernelGGL((k_dense_joint_update<1>), dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Uj2);
     }
     HIPCHK(h, hipGetLastError());
     if (o->n_iters == 0) {
@@ -894,6 +942,7 @@ void tcsfm_default_opts(tcsfm_opts *o) {
     o->depth_param = TCSFM_DEPTH_FULL;
     o->w_pose_consist = 0.f;
     o->w_smooth = 0.f;
+    o->free_source_depths = 0;
 }
 
 int tcsfm_algorithmic_bytes_per_pixel(const tcsfm_opts *) { return 32; }
@@ -977,7 +1026,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth, h->jrec_src, h->jstate_src, h->jdelta_src, h->dref_ext_src,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
@@ -1574,6 +1623,8 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (ref_mode && (win_S > JMAXS || o->solver != TCSFM_SOLVER_GN || !(o->prior_init >= 0.f)))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: window_rule REFERENCE needs S <= 3, the Gauss-Newton solver and prior_init >= 0");
     if (o->w_pose_consist > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_pose_consist is a term of the pose modes (tcsfm_refine_window)");
+    if (o->free_source_depths != 0 && !ref_mode)
+        return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: free_source_depths needs the window form under window_rule = TCSFM_WINDOW_REFERENCE");
     if (!(o->w_smooth >= 0.f) || (o->w_smooth > 0.f && !ref_mode))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_smooth needs the window form under window_rule = TCSFM_WINDOW_REFERENCE");
     if (o->depth_param != TCSFM_DEPTH_FULL && !(o->depth_param == TCSFM_DEPTH_QUARTER && ref_mode && h->H % 4 == 0 && h->W % 4 == 0))
