@@ -267,7 +267,7 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
  *       + o->prior_init / (B HW) sum SSIM(sigma, sigma_0)  (l_depth_init: SSIM between the target's current and initial sigmoid
  *                                      disparity, sigma = (1/depth - 1/max_depth) / (1/min_depth - 1/max_depth))
  *     Unknowns: the poses of all 2 S B directed pairs and ONE inverse-depth map per target; the source depth maps stay at their
- *     input (the reference lets them drift too, with no prior on them).  The target depth enters the forward pairs as the
+ *     input unless o->free_source_depths is set (the reference lets them drift too, with no prior on them: see that field).  The target depth enters the forward pairs as the
  *     back-projected depth and the inverse pairs as the depth they SAMPLE (stn.py:271): the gradient contains both -- the second as
  *     the adjoint of the bilinear sample, scattered with 64-bit fixed-point atomics (order-independent: results stay bit-
  *     reproducible) -- and equals reference autograd w.r.t. every pose and the shared depth (golden G13 `full`, `fullinit`; see
@@ -275,7 +275,7 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
  *     diagonal model of the 3x3-coupled prior, w / r^2 (1/d2 + 1/(9 d1)) with the pixel's own SSIM denominators; the sampled-depth
  *     terms are gradient-only.  The inverse pairs take 6 x 6 pose steps under the window rule.  After every step the new map also
  *     replaces the depth the inverse pairs sample.  depth_out: the S forward slots hold the refined map, the inverse slots the
- *     (unchanged) source depths.  stats rows of the forward pairs: [forward group's loss (forward + its depth consistency + prior),
+ *     source depths (unchanged; refined under o->free_source_depths).  stats rows of the forward pairs: [forward group's loss (forward + its depth consistency + prior),
  *     own share, own mask count, lambda, iterate]; of the inverse pairs: as tcsfm_refine_window under the rule. */
 int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
