@@ -333,6 +333,21 @@ class Oracle:
                                         C.c_double(min_depth), C.c_double(max_depth), self._p(poses), self._p(stats), self._p(b), self._p(rq))
         return poses, depth_t, stats, rq
 
+    def refine_dense_ref_q_free(self, tgt, srcs, depth_t, depth_s, K, poses, opts=None, argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06,
+                                max_depth=2.67, bits=None):
+        """orc_refine_dense_ref_q_free: the reference's complete leaf set -- the QUARTER-resolution maps of the target and of every source are
+        unknowns (optimizer.py:194-198) -> (poses, depth_t [B,H,W], depth_s [S,B,H,W] (both upsampled), stats)"""
+        o = opts or default_opts()
+        tgt, srcs, depth_t, depth_s, K, poses, S, B, H, W = self._dref_args(tgt, srcs, depth_t, depth_s, K, poses)
+        assert H % 4 == 0 and W % 4 == 0
+        depth_s = np.ascontiguousarray(depth_s).copy()
+        stats = np.zeros((o.n_iters, 7))
+        b, _ = self._forced(bits, None)
+        self.lib.orc_refine_dense_ref_q_free(C.c_int(H), C.c_int(W), C.c_int(B), C.c_int(S), self._p(tgt), self._p(srcs), self._p(depth_t), self._p(depth_s),
+                                             self._p(K), C.byref(o), C.c_int(1 if argmin else 0), C.c_double(w_init), C.c_double(lambda_depth),
+                                             C.c_double(min_depth), C.c_double(max_depth), self._p(poses), self._p(stats), self._p(b), self._p(None))
+        return poses, depth_t, depth_s, stats
+
     def up4(self, q):
         """F.interpolate(q, x4, bilinear, align_corners=False) of one map [h,w] -> [4h,4w] (orc_up4)"""
         q = np.ascontiguousarray(q, np.float64)

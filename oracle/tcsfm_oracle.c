@@ -2704,9 +2704,9 @@ void orc_up4_adjoint(int H, int W, const double *full, double *q) {
  * the same trust region as a pixel's (depth_step).  depth_io [B][n] in: the full-resolution input map (its quarter-resolution
  * projection is the start, as optimizer.py:194-196); out: U rho_q as depth.  depth0: centre of the SSIM prior (the full-resolution
  * input, optimizer.py:89-90 `self.target_disparity`).  rho_q_out [B][n/16] or NULL. */
-void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
-                            const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
-                            double *pose_io, double *stats, const unsigned short *bits, double *rho_q_out) {
+static void refine_dense_ref_q_impl(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, real *depth_s /* in / out when free_sources */,
+                                    const real *K, const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                                    double *pose_io, double *stats, const unsigned short *bits, double *rho_q_out, int free_sources) {
     const int n = H * W, SB = S * B, NP = 6 * S, h = H / 4, w = W / 4, nq = h * w;
     const double lo = 1.0 / max_depth, hi = 1.0 / min_depth;
     real *ae = (real *)malloc(sizeof(real) * (size_t)2 * SB * n), *d0 = (real *)malloc(sizeof(real) * (size_t)B * n);
@@ -2719,6 +2719,21 @@ void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const r
     double *rq = (double *)malloc(sizeof(double) * (size_t)B * nq), *full = (double *)malloc(sizeof(double) * n);
     double *pix = (double *)malloc(sizeof(double) * (size_t)n * (NP + 2)), *cell = (double *)malloc(sizeof(double) * (size_t)nq * (NP + 2));
     unsigned char *skip = (unsigned char *)malloc(n);
+    /* free_sources: the quarter-resolution maps of the SOURCES are unknowns too (optimizer.py:194-198: one tensor of S + 1 channels) -- every
+     * inverse pair a group of its pose and the cells of the source map it back-projects; same projection at the start, same cell records */
+    dref_src_sys ss = {NULL, NULL, NULL, NULL};
+    double *g_rho_s = NULL, *rqs = NULL;
+    if (free_sources) {
+        g_rho_s = (double *)malloc(sizeof(double) * (size_t)SB * n); rqs = (double *)malloc(sizeof(double) * (size_t)SB * nq);
+        ss.Dq = (double *)malloc(sizeof(double) * (size_t)SB * n); ss.Bq = (double *)malloc(sizeof(double) * (size_t)SB * n * 6);
+        ss.Hs = (double *)malloc(sizeof(double) * 36 * SB); ss.gs = (double *)malloc(sizeof(double) * 6 * SB);
+        for (int m = 0; m < SB; m++) {
+            for (int i = 0; i < n; i++) full[i] = 1.0 / (double)depth_s[(size_t)m * n + i];
+            orc_down4(H, W, full, rqs + (size_t)m * nq);
+            orc_up4(H, W, rqs + (size_t)m * nq, full);
+            for (int i = 0; i < n; i++) depth_s[(size_t)m * n + i] = (real)(1.0 / full[i]);
+        }
+    }
     dref_auto_err(H, W, B, S, tgt, srcs, op, ae, aep);
     memcpy(d0, depth_io, sizeof(real) * (size_t)B * n);
     for (int b = 0; b < B; b++) {       /* the start: quarter-resolution projection of the input, upsampled again */
@@ -2733,7 +2748,7 @@ void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const r
         g_lin_idx = bits ? it : -1;
         /* lambda_depth = infinity: no per-pixel elimination inside -- Hj / gj come back as the pose blocks and pose gradients themselves */
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, INFINITY, T, aep,
-                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, NULL, NULL);
+                            bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s, free_sources ? &ss : NULL);
         g_lin_idx = -1;
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {
@@ -2777,6 +2792,45 @@ void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const r
             for (int i = 0; i < n; i++) depth_io[(size_t)b * n + i] = (real)(1.0 / full[i]);
         }
         for (int m = 0; m < SB; m++) {      /* inverse pairs: their own 6 x 6 systems */
+            if (free_sources) {             /* ... reduced by the CELLS of the source map (ss.Hs / ss.gs come back unreduced: lambda_depth = infinity above) */
+                for (int i = 0; i < n; i++) {
+                    const double D = ss.Dq[(size_t)m * n + i];
+                    skip[i] = !((1.0 + lambda_depth) * D > 1e-30);
+                    pix[(size_t)i * 8] = g_rho_s[(size_t)m * n + i]; pix[(size_t)i * 8 + 1] = D;
+                    for (int j = 0; j < 6; j++) pix[(size_t)i * 8 + 2 + j] = ss.Bq[((size_t)m * n + i) * 6 + j];
+                }
+                memset(cell, 0, sizeof(double) * (size_t)nq * 8);
+                up4_adjoint(H, W, 8, pix, skip, cell);
+                double A[36], dl[6], gsv[6];
+                for (int i = 0; i < 6; i++) {
+                    gsv[i] = ss.gs[6 * m + i];
+                    for (int j = 0; j < 6; j++) A[i * 6 + j] = ss.Hs[36 * m + i * 6 + j];
+                }
+                for (int c = 0; c < nq; c++) {
+                    const double *q = cell + (size_t)c * 8, Dd = (1.0 + lambda_depth) * q[1];
+                    if (!(Dd > 1e-30)) continue;
+                    for (int j = 0; j < 6; j++) {
+                        gsv[j] -= q[2 + j] * q[0] / Dd;
+                        for (int k = 0; k < 6; k++) A[j * 6 + k] -= q[2 + j] * q[2 + k] / Dd;
+                    }
+                }
+                for (int i = 0; i < 6; i++) { A[i * 6 + i] += op->lambda0 * A[i * 6 + i] + 1e-12; dl[i] = -gsv[i]; }
+                if (chol_solve(6, A, dl)) memset(dl, 0, sizeof(dl));
+                double E[12], Tn[12];
+                orc_se3_exp(dl, E);
+                orc_se3_mul(E, T + 12 * (SB + m), Tn);
+                memcpy(T + 12 * (SB + m), Tn, sizeof(Tn));
+                for (int c = 0; c < nq; c++) {
+                    const double *q = cell + (size_t)c * 8, Dd = (1.0 + lambda_depth) * q[1];
+                    if (!(Dd > 1e-30)) continue;
+                    double bd = 0;
+                    for (int j = 0; j < 6; j++) bd += q[2 + j] * dl[j];
+                    rqs[(size_t)m * nq + c] = depth_step(rqs[(size_t)m * nq + c], -(q[0] + bd) / Dd, lo, hi);
+                }
+                orc_up4(H, W, rqs + (size_t)m * nq, full);
+                for (int i = 0; i < n; i++) depth_s[(size_t)m * n + i] = (real)(1.0 / full[i]);
+                continue;
+            }
             orc_opts o6 = *op;
             o6.nparam = 6; o6.param = 0;
             double Tn[12], sdummy;
@@ -2788,6 +2842,18 @@ void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const r
     if (rho_q_out) memcpy(rho_q_out, rq, sizeof(double) * (size_t)B * nq);
     free(ae); free(d0); free(aep); free(T); free(g_xi); free(g_rho); free(Hj); free(gj); free(Dq); free(Bq); free(Hi); free(gi);
     free(rq); free(full); free(pix); free(cell); free(skip);
+    free(g_rho_s); free(rqs); free(ss.Dq); free(ss.Bq); free(ss.Hs); free(ss.gs);
+}
+void orc_refine_dense_ref_q(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, const real *depth_s, const real *K,
+                            const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                            double *pose_io, double *stats, const unsigned short *bits, double *rho_q_out) {
+    refine_dense_ref_q_impl(H, W, B, S, tgt, srcs, depth_io, (real *)depth_s, K, op, argmin, w_init, lambda_depth, min_depth, max_depth, pose_io, stats, bits, rho_q_out, 0);
+}
+/* the reference's complete leaf set: the quarter-resolution maps of the target AND of the sources (depth_s_io [SB][n] in / out) */
+void orc_refine_dense_ref_q_free(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, real *depth_s_io, const real *K,
+                                 const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
+                                 double *pose_io, double *stats, const unsigned short *bits, double *rho_q_out) {
+    refine_dense_ref_q_impl(H, W, B, S, tgt, srcs, depth_io, depth_s_io, K, op, argmin, w_init, lambda_depth, min_depth, max_depth, pose_io, stats, bits, rho_q_out, 1);
 }
 
 /* ------------------------------------------------------------------------- */

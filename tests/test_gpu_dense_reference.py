@@ -256,6 +256,47 @@ def test_quarter_resolution_iterates_follow_the_oracle(H, W, S, mind, maxd, orc)
         e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, depth_param=_lib.DEPTH_QUARTER), argmin=True)
 
 
+@pytest.mark.parametrize("B,S,H,W,mind,maxd", [(1, 1, 240, 320, 0.03, 3.0), (1, 2, 192, 640, 0.06, 2.67), (2, 2, 48, 160, 0.06, 2.67)])
+def test_the_reference_leaf_set_quarter_resolution_target_and_sources(B, S, H, W, mind, maxd, orc):
+    """depth_param = TCSFM_DEPTH_QUARTER with free_source_depths: the unknowns are the reference's own leaves -- the quarter-resolution maps of
+    the target AND of every source (optimizer.py:194-198: one tensor of S + 1 channels, upsampled x4 every epoch).  Poses, the target map and
+    every pixel of every (upsampled) source map follow orc_refine_dense_ref_q_free, decisions replayed"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    n_it = 3
+    w = _window(B, S, H, W, seed=31)
+    N = 2 * S * B
+    e = Engine(H, W, N)
+    o = default_opts(n_iters=n_it, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE, lambda_depth=1.0,
+                     depth_param=_lib.DEPTH_QUARTER, free_source_depths=1)
+    t = {k: _dev(v) for k, v in w.items()}
+    dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
+    e.trace_begin(n_it, N)
+    pose, depth, st = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    bits, _ = e.trace_end()
+    pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    oo = oracle_opts(n_iters=n_it, w_dc=0.15)
+    orc.flip_stats_reset()
+    po, do, dso, so = orc.refine_dense_ref_q_free(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=True,
+                                                  w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
+    nf, hard = orc.flip_stats(n_it)
+    assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
+    for m in range(N):
+        et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
+        assert et < 1e-4 and er < 1e-4, (m, et, er)
+    for s in range(S):
+        assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
+    src_gpu = depth[S * B:, 0].reshape(S, B, H, W)
+    dev = np.sort(np.abs(src_gpu / dso - 1).ravel())
+    assert dev[-1] < 1e-4, dev[-6:]          # (a cell averages 64 pixels: an isolated switch does not show as it does at full resolution)
+    assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
+    # the source maps moved away from their start (the x4 upsampling of the input's quarter-resolution projection)
+    start = 1.0 / orc.up4(orc.down4(1.0 / f32(w["depth_s"])[0, 0]))
+    assert np.abs(src_gpu[0, 0] / start - 1).max() > 1e-3
+    e.close()
+
+
 @pytest.mark.parametrize("B,S,H,W", [(2, 2, 48, 160), (3, 1, 24, 40), (1, 3, 48, 160)])
 def test_quarter_resolution_batches_and_source_counts(B, S, H, W, orc):
     """the quarter-resolution unknown with several targets per call (the batch normalisers couple them; every target has its own cells,

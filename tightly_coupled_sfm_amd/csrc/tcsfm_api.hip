@@ -106,6 +106,7 @@ struct tcsfm_ctx {
     float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
     // free source depth maps (opts.free_source_depths): the inverse pairs as groups of one source
     float *jrec_src = nullptr; JointState *jstate_src = nullptr; double *jdelta_src = nullptr; long long *dref_ext_src = nullptr;
+    float *qres_rho_src = nullptr, *qres_rec_src = nullptr;      // ... in the quarter-resolution parametrisation
     double *pose_lin = nullptr;        // l_pose_consist: [2][max_pairs][12] transforms at the linearisation (k_solve, kernels.h)
     float *qres_rho = nullptr, *qres_rec = nullptr;      // TCSFM_DEPTH_QUARTER: [targets][H/4 * W/4] cell unknowns, [targets][cells][JREC] cell records
     int coal_max = 0;
@@ -700,7 +701,6 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     if (qres && nblk + nqblk > 2 * h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
     // opts.free_source_depths: the inverse pairs as S B groups of one source (the joint kernel / solve / update on views offset by S B pairs)
     const bool free_src = !ex && o->free_source_depths != 0;
-    if (free_src && qres) return fail(h, TCSFM_E_ARG, "free_source_depths needs the full-resolution unknown (depth_param = TCSFM_DEPTH_FULL)");
     if (free_src && !h->jrec_src) {
         const size_t ng = n / 2;          // groups <= max_pairs / 2
         HIPCHK(h, hipMalloc((void **)&h->jrec_src, ng * hw * JointLayout<1>::JREC * sizeof(float)));
@@ -708,7 +708,12 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->jdelta_src, ng * 6 * JMAXS * sizeof(double)));
         HIPCHK(h, hipMalloc((void **)&h->dref_ext_src, ng * hw * sizeof(long long)));
     }
-    if (free_src && (size_t)SB * nblk * JointLayout<1>::NACC > ((n + 3) / 4) * 2 * (size_t)h->nblk_alloc * JM::NACC)
+    if (free_src && qres && !h->qres_rho_src) {
+        const size_t ng = n / 2;
+        HIPCHK(h, hipMalloc((void **)&h->qres_rho_src, ng * nq * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->qres_rec_src, ng * nq * JointLayout<1>::JREC * sizeof(float)));
+    }
+    if (free_src && (size_t)SB * (nblk + nqblk) * JointLayout<1>::NACC > ((n + 3) / 4) * 2 * (size_t)h->nblk_alloc * JM::NACC)
         return fail(h, TCSFM_E_ARG, "internal: the inverse groups' records exceed the scratch");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
@@ -790,6 +795,13 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
         Q.norms_zero = h->dref_norms;
     }
+    QresParams Q2 = Q;
+    if (qres && free_src) {      // the source maps in the same parametrisation: their quarter-resolution projection is the start (optimizer.py:194-196)
+        Q2.jrec = h->jrec_src; Q2.qrec = h->qres_rec_src; Q2.rho_q = h->qres_rho_src; Q2.delta = h->jdelta_src;
+        Q2.depth = h->depth_work + (size_t)SB * hw; Q2.srcpack_inv = h->srcpack; Q2.B = SB; Q2.S = 1; Q2.norms_zero = nullptr;
+        hipLaunchKernelGGL(k_qres_init, dim3((unsigned)((nq + 255) / 256), SB), dim3(256), 0, st, Q2);
+        hipLaunchKernelGGL(k_qres_upsample, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Q2);
+    }
     // (one stream: running the inverse pairs' linearise + solve on a second stream beside the forward group's, forked behind the scatter and
     // joined after the depth update, was measured SLOWER -- 261 vs 232 us per 240x320 window, 383 vs 361 at 192x640 S=2: the event hops cost
     // more than the ~18 us of overlap they buy)
@@ -810,7 +822,8 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
         J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
         J2.ext = h->dref_ext_src; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
-        Sj2.js = h->jstate_src; Sj2.st = h->state + SB; Sj2.pc = h->pconst + SB; Sj2.B = SB; Sj2.nblk = nblk;
+        if (qres) { J2.qres = 1; J2.rec_stride = nblk + nqblk; }
+        Sj2.js = h->jstate_src; Sj2.st = h->state + SB; Sj2.pc = h->pconst + SB; Sj2.B = SB; Sj2.nblk = qres ? nblk + nqblk : nblk;
         Sj2.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
         Sj2.delta_out = h->jdelta_src; Sj2.norms = h->dref_norms + 1; Sj2.c_f = 0.25;
         Uj2.jrec = h->jrec_src; Uj2.delta = h->jdelta_src; Uj2.depth = h->depth_work + (size_t)SB * hw; Uj2.B = SB; Uj2.S = 1;
@@ -899,6 +912,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             Pj2.trace = tr ? h->trace_bits + ((size_t)it * N + SB) * hw : nullptr;
             if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
             else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            if (qres) hipLaunchKernelGGL((k_qres_schur<1>), dim3(nqblk, SB), dim3(256), 0, st, Q2);
             Sj2.it = it; Sj2.mode = 0; Sj2.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr;
             Sj2.trace_decide = h->trace_decide ? h->trace_decide + (size_t)it * N + SB : nullptr;
             hipLaunchKernelGGL((k_solve_joint<1>), dim3(SB), dim3(JSOLVE_NT), 0, st, Sj2);
@@ -907,7 +921,10 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             hipLaunchKernelGGL((k_qres_step<NS>), dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
             hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
         } else hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
-        if (free_src)        // the new source maps: the inverse pairs' own depth slots AND the depth channel of the packs the forward pairs sample
+        if (free_src && qres) {
+            hipLaunchKernelGGL((k_qres_step<1>), dim3((unsigned)((nq + 255) / 256), SB), dim3(256), 0, st, Q2);
+            hipLaunchKernelGGL(k_qres_upsample, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Q2);
+        } else if (free_src)        // the new source maps: the inverse pairs' own depth slots AND the depth channel of the packs the forward pairs sample
             hipLaunchKernelGGL((k_dense_joint_update<1>), dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Uj2);
     }
     HIPCHK(h, hipGetLastError());
@@ -1026,7 +1043,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth, h->jrec_src, h->jstate_src, h->jdelta_src, h->dref_ext_src,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth, h->jrec_src, h->jstate_src, h->jdelta_src, h->dref_ext_src, h->qres_rho_src, h->qres_rec_src,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
