@@ -115,12 +115,13 @@ typedef struct tcsfm_opts {
                               losses.py:43-61: edge-aware L1 smoothness of the mean-normalised sigmoid disparity).  Exact gradient incl. the
                               normalisation's per-image constant (one more launch per linearisation: k_dref_smooth); curvature = the diagonal
                               majoriser of the edges' IRLS weights; pinned on reference autograd (golden G13 `fullinit_smooth`)           */
-    int32_t free_source_depths; /* dense window mode under TCSFM_WINDOW_REFERENCE, full-resolution unknown (default 0): 1 = the SOURCE depth maps
+    int32_t free_source_depths; /* dense window mode under TCSFM_WINDOW_REFERENCE, either depth_param (default 0): 1 = the SOURCE depth maps
                               are unknowns as well, as in the reference's optimize_depth_pred (optimizer.py:194-198 optimises the disparities of
                               target AND sources; no prior on the sources).  Every inverse pair then is a group of its own -- its pose and the
                               source map it back-projects, per-pixel Schur elimination as in a forward group of one source -- with the adjoint
                               of the forward pair's samples of that map in its gradient (tcsfm_linearize_dense_window_sources); after every
-                              step the forward pairs sample the new source maps.  depth_out's inverse slots return the refined source maps */
+                              step the forward pairs sample the new source maps.  depth_out's inverse slots return the refined source maps.  With
+                              depth_param = TCSFM_DEPTH_QUARTER the unknowns are the reference's own leaves: quarter-resolution maps of target and sources */
 } tcsfm_opts;
 
 /* per-pair, per-linearisation statistics written by tcsfm_refine: [N][n_iters+1][TCSFM_NSTAT] fp32.

@@ -129,6 +129,13 @@ def test_tuple_form_dense_mode_and_legacy_switches():
     L0 = e2.linearize_dense_window(*args(r["depths_init"][0], p_init), eo, argmin=True)["loss"]
     L1 = e2.linearize_dense_window(*args(r["depths_opt"][0], p_opt), eo, argmin=True, depth0=r["depths_init"][0])["loss"]
     assert L1 < 0.97 * L0, (L0, L1)
+    # options['optimize_source_depths']: the reference's complete leaf set (optimizer.py:194-198: target AND source disparities, quarter resolution
+    # by default) -- the source maps move too, as x4 upsamplings, and the loss at the result (evaluated with the refined source maps) went down
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    rs = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True, optimize_source_depths=True), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)
+    for d0, d1 in zip(rs["depths_init"][1:], rs["depths_opt"][1:]):
+        assert d1.shape == d0.shape and torch.isfinite(d1).all() and 1e-6 < float(((d1 - d0).abs() / d0).mean()) < 0.1 and bend(d1) < 1e-5
+    assert np.all(rs["gn_cost"].numpy()[:, 3] < rs["gn_cost"].numpy()[:, 0])
     # options['window_rule'] = 'pair': the library's joint dense mode -- every frame's depth refined (the source frames by their inverse pair)
     pose_model, depth_model = standins.window_models(w, iters, device="cuda")
     rp = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True, window_rule="pair"), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)

@@ -139,6 +139,10 @@ class DepthOptimizer:
                                     w_smooth=float(o.get("l_smooth_weight", 2.0)) if o.get("l_smooth", False) else 0.0,      # optimizer.py:92-93
                                     solver=_lib.SOLVER_GN, lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
                                     max_depth=float(self.config["max_depth"]), window_rule=_lib.WINDOW_REFERENCE,
+                                    # optimizer.py:194-198: the reference's leaf is ONE tensor with the disparities of the target AND of every
+                                    # source; options['optimize_source_depths'] = True makes the source maps unknowns here as well (default:
+                                    # only the target's map moves -- the one `l_depth_init` and `disp_opt` are about)
+                                    free_source_depths=1 if o.get("optimize_source_depths", False) else 0,
                                     **{k: v for k, v in kw.items() if k == "lambda_depth"})
             # the library's per-pair / joint dense modes: GN on the SE(3) chart, Tikhonov depth prior instead of the DC term
             return default_opts(n_iters=int(o.get("gn_iters", 4)), automask=1 if o.get("automasking", True) else 0, w_dc=0.0,
@@ -270,7 +274,8 @@ class DepthOptimizer:
             # joint mode (default): the S forward slots hold ONE refined map of the target frame, shared by its S forward pairs
             # (the mean below is then the identity); options['dense_joint'] = False: every forward pair refined its own copy and
             # the copies are fused by averaging inverse depths.  Source frame s was refined by its inverse pair
-            # reference-loss mode (default): the inverse slots are the source depths as given (not unknowns there)
+            # reference-loss mode (default): the inverse slots are the source depths as given (not unknowns there) -- or their refined maps
+            # under options['optimize_source_depths']
             inv_t = (1.0 / depth_ref[:split]).reshape(S, B, 1, H, W).mean(0)
             depths = [1.0 / inv_t] + [depth_ref[split + i * B: split + (i + 1) * B] for i in range(S)]
         res["depths_opt"] = depths
