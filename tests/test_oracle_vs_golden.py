@@ -639,6 +639,13 @@ def test_dense_reference_refinement_with_free_source_maps(oracle64):
     assert np.isfinite(p1).all() and np.isfinite(ds1).all() and 0 < np.median(rel) < 0.1 and rel.max() < 1.25 ** 5
     # the first linearisation does not depend on which maps are free: same loss terms
     assert np.array_equal(st1[0], st0[0])
+    # the reference's own parametrisation of all of them (quarter-resolution maps of target and sources): the loss falls as well, the returned
+    # source maps are x4 upsamplings (linear across the pixels 4c+2 .. 4c+5 of a row)
+    p2, d2, ds2, st2 = oracle64.refine_dense_ref_q_free(*a, o, argmin=True, w_init=0.1, lambda_depth=1.0)
+    assert np.all(np.diff(st2[:, 0]) < 0), st2[:, 0]
+    rho = 1.0 / ds2[0, 0]
+    assert np.abs(rho[:, 2:-4:4] - 2 * rho[:, 3:-3:4] + rho[:, 4:-2:4]).max() < 1e-12 * np.abs(rho).max()
+    assert np.isfinite(p2).all() and np.abs(ds2 / a[3] - 1).max() > 1e-3
 
 
 @pytest.mark.parametrize("name", ["winloss24x40", "winloss48x160"])
