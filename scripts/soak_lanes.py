@@ -21,6 +21,7 @@ od = default_opts(n_iters=2, min_depth=0.03, max_depth=3.0)
 from tightly_coupled_sfm_amd import _lib
 odr = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE)
 odq = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER)
+odf = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER, free_source_depths=1)
 e = Engine(H, W, 4, lanes=3)
 ref = {}
 def check(key, val):
@@ -83,8 +84,8 @@ while time.time() - t0 < SECONDS:
             check(("dense", int(w)), [p_, d_])
         e.set_coalesce_lanes(1); e.set_coalesce(0)
     elif kind == 5:    # round 4: dense window on the reference's loss, full- and quarter-resolution unknown
-        w = int(rng.integers(0, T - 1)); q = int(rng.integers(0, 2))
-        p, d, _ = e.refine_dense_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], (odq if q else odr), argmin=True)
+        w = int(rng.integers(0, T - 1)); q = int(rng.integers(0, 3))           # (2: the reference's complete leaf set -- target and source maps, quarter resolution)
+        p, d, _ = e.refine_dense_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], (odr, odq, odf)[q], argmin=True)
         check(("dref", q, w), [p, d])
     else:              # plain synchronous call on the handle itself
         w = int(rng.integers(0, T - 1))

@@ -138,8 +138,8 @@ def test_dense_reference_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
     assert np.abs(depth[0, 0] / f32(w["depth_t"])[0] - 1).max() > 1e-3          # the map really moved
 
 
-@pytest.mark.parametrize("H,W,S,mind,maxd", [(240, 320, 1, 0.03, 3.0), (192, 640, 2, 0.06, 2.67)])
-def test_free_source_depth_maps_follow_the_oracle(H, W, S, mind, maxd, orc):
+@pytest.mark.parametrize("B,H,W,S,mind,maxd", [(1, 240, 320, 1, 0.03, 3.0), (1, 192, 640, 2, 0.06, 2.67), (2, 48, 160, 2, 0.06, 2.67), (1, 48, 160, 3, 0.06, 2.67)])
+def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, orc):
     """opts.free_source_depths: the SOURCE depth maps are unknowns as well (the reference's optimize_depth_pred optimises the disparities of
     target and sources, optimizer.py:194-198) -- every inverse pair a group of its pose and the source map it back-projects (the joint kernel /
     solve / update on the inverse views, the adjoint of the forward pairs' samples in its gradient).  Poses, the target map and every pixel of
@@ -147,7 +147,7 @@ def test_free_source_depth_maps_follow_the_oracle(H, W, S, mind, maxd, orc):
     to linearisation"""
     from tightly_coupled_sfm_amd.engine import Engine, default_opts
     from tightly_coupled_sfm_amd import _lib
-    B, n_it = 1, 3
+    n_it = 3
     w = _window(B, S, H, W, seed=31)
     N = 2 * S * B
     e = Engine(H, W, N)
