@@ -180,6 +180,12 @@ def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, orc):
     assert np.quantile(dev, 0.9999) < 2e-5
     assert np.abs(src_gpu / f32(w["depth_s"]) - 1).max() > 1e-3                    # the source maps really moved
     assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
+    # without the flag the inverse slots return the inputs; under the PAIR rule (the library's own dense modes) the flag is refused
+    o.free_source_depths = 0
+    _, d_fix, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    assert torch.equal(d_fix[S * B:, 0].reshape(S, B, H, W), t["depth_s"])
+    with pytest.raises(RuntimeError):
+        e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, min_depth=mind, max_depth=maxd, free_source_depths=1), argmin=True)
     e.close()
 
 
