@@ -138,8 +138,9 @@ def test_dense_reference_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
     assert np.abs(depth[0, 0] / f32(w["depth_t"])[0] - 1).max() > 1e-3          # the map really moved
 
 
-@pytest.mark.parametrize("B,H,W,S,mind,maxd", [(1, 240, 320, 1, 0.03, 3.0), (1, 192, 640, 2, 0.06, 2.67), (2, 48, 160, 2, 0.06, 2.67), (1, 48, 160, 3, 0.06, 2.67)])
-def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, orc):
+@pytest.mark.parametrize("B,H,W,S,mind,maxd,argmin", [(1, 240, 320, 1, 0.03, 3.0, True), (1, 192, 640, 2, 0.06, 2.67, True), (2, 48, 160, 2, 0.06, 2.67, True),
+                                                       (1, 48, 160, 3, 0.06, 2.67, True), (2, 48, 160, 2, 0.06, 2.67, False)])
+def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, argmin, orc):
     """opts.free_source_depths: the SOURCE depth maps are unknowns as well (the reference's optimize_depth_pred optimises the disparities of
     target and sources, optimizer.py:194-198) -- every inverse pair a group of its pose and the source map it back-projects (the joint kernel /
     solve / update on the inverse views, the adjoint of the forward pairs' samples in its gradient).  Poses, the target map and every pixel of
@@ -156,13 +157,13 @@ def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, orc):
     t = {k: _dev(v) for k, v in w.items()}
     dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
     e.trace_begin(n_it, N)
-    pose, depth, st = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    pose, depth, st = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=argmin)
     bits, _ = e.trace_end()
     pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     oo = oracle_opts(n_iters=n_it, w_dc=0.15)
     orc.flip_stats_reset()
-    po, do, dso, so = orc.refine_dense_ref_free(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=True,
+    po, do, dso, so = orc.refine_dense_ref_free(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=argmin,
                                                 w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
     nf, hard = orc.flip_stats(n_it)
     assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
@@ -182,10 +183,10 @@ def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, orc):
     assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
     # without the flag the inverse slots return the inputs; under the PAIR rule (the library's own dense modes) the flag is refused
     o.free_source_depths = 0
-    _, d_fix, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    _, d_fix, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=argmin)
     assert torch.equal(d_fix[S * B:, 0].reshape(S, B, H, W), t["depth_s"])
     with pytest.raises(RuntimeError):
-        e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, min_depth=mind, max_depth=maxd, free_source_depths=1), argmin=True)
+        e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, min_depth=mind, max_depth=maxd, free_source_depths=1), argmin=argmin)
     e.close()
 
 
