@@ -159,6 +159,24 @@ def test_replay_of_dense_calls_per_pair_and_joint():
         e2.synchronize()
         assert torch.equal(gp, jp) and torch.equal(gd, jd), rep
     assert e2.graph_replay_counts() == (1, 2)
+    # the reference's loss with the reference's complete leaf set (quarter-resolution maps of target AND sources: free_source_depths) through
+    # the same capture -- its memsets, the scatter with integer atomics and the inverse groups' launches replay to the same bits
+    from tightly_coupled_sfm_amd import _lib
+    of = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER,
+                      free_source_depths=1, argmin=1)
+    fp, fd, _ = ref2.refine_dense_window(tg2, sr2, dt2, ds2, K2, pose, of, argmin=True)
+    torch.cuda.synchronize()
+    c0 = e2.graph_replay_counts()
+    for rep in range(4):
+        gp.zero_(); gd.zero_()
+        torch.cuda.synchronize()
+        rc = e2.lib.tcsfm_refine_dense_window(e2._h, C.byref(of), 1, S, e2._p(tg2), e2._p(sr2), e2._p(dt2), e2._p(ds2), e2._p(K2), e2._p(pose),
+                                              e2._p(gp), e2._p(gd), None)
+        assert rc == 0
+        e2.synchronize()
+        assert torch.equal(gp, fp) and torch.equal(gd, fd), rep
+    c1 = e2.graph_replay_counts()
+    assert c1[1] - c0[1] == 2 and not torch.equal(fd[S:], ds2.reshape(S, 1, H, W))          # replayed twice; the source maps moved
 
 
 def test_replay_survives_a_larger_joint_call_and_a_stream_switch():
