@@ -17,6 +17,7 @@ for H, W, S, mind, maxd in ((240, 320, 1, 0.03, 3.0), (256, 448, 1, 0.03, 3.0), 
     for name, o in (("reference loss (forward + inverse + depth consistency + SSIM prior)", default_opts(n_iters=4, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE)),
                     ("reference loss, QUARTER-resolution unknown (the reference's parametrisation, optimizer.py:194-198)", default_opts(n_iters=4, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER)),
                     ("reference loss, the SOURCE depth maps unknowns too (free_source_depths; every leaf of optimize_depth_pred moves)", default_opts(n_iters=4, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE, free_source_depths=1)),
+                    ("reference loss, the reference's complete leaf set: QUARTER-resolution maps of target AND sources (depth_param QUARTER + free_source_depths)", default_opts(n_iters=4, w_dc=0.15, prior_init=0.1, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE, depth_param=_lib.DEPTH_QUARTER, free_source_depths=1)),
                     ("reference loss, forward + inverse only", default_opts(n_iters=4, w_dc=0.0, prior_init=0.0, min_depth=mind, max_depth=maxd, window_rule=_lib.WINDOW_REFERENCE)),
                     ("library joint / pair dense mode (own weights, Tikhonov prior)", default_opts(n_iters=4, min_depth=mind, max_depth=maxd))):
         step = lambda: e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, argmin=True)
