@@ -173,8 +173,8 @@ def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, argmin
     for s in range(S):
         assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
     src_gpu = depth[S * B:, 0].reshape(S, B, H, W)
-    # every pixel of every source map within 1e-4 -- but for isolated pixels next to a switch that is not among the replayed decisions (the
-    # SSIM clamp of a window pixel: value continuous, gradient not): at most 4 of them per call, and those within 5e-4 (measured at 192 x 640,
+    # every pixel of every source map within 1e-4 -- but for isolated pixels next to a switch that is not among the replayed decisions (a
+    # candidate: the SSIM clamp of a window pixel, value continuous, gradient not): at most 4 of them per call, and those within 5e-4 (measured at 192 x 640,
     # S = 2: 1.7e-6 / 6.6e-6 after one / two iterations, after three ONE pixel of 245 760 at 1.3e-4, the 99.99 % quantile 5e-6)
     dev = np.sort(np.abs(src_gpu / dso - 1).ravel())
     assert dev[-5] < 1e-4 and dev[-1] < 5e-4, dev[-6:]
