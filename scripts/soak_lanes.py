@@ -34,8 +34,10 @@ po = [torch.empty(2, 6, device="cuda") for _ in range(3)]
 do = [torch.empty(2, 1, H, W, device="cuda") for _ in range(3)]
 torch.cuda.synchronize()
 mem0 = None
-t0 = time.time(); n = 0
+t0 = time.time(); n = 0; t_said = t0
 while time.time() - t0 < SECONDS:
+    if time.time() - t_said > 60:       # (a long run must not look hung to the GPU box's watchdog)
+        t_said = time.time(); print(f"... {n} rounds, {len(ref)} work items", file=sys.stderr, flush=True)
     kind = rng.integers(0, 7)
     if kind == 0:      # three pose windows in flight
         ws = rng.integers(0, T - 1, size=3)
