@@ -173,11 +173,12 @@ def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, argmin
     for s in range(S):
         assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
     src_gpu = depth[S * B:, 0].reshape(S, B, H, W)
-    # every pixel of every source map within 1e-4 -- but for isolated pixels next to a switch that is not among the replayed decisions (a
-    # candidate: the SSIM clamp of a window pixel, value continuous, gradient not): at most 4 of them per call, and those within 5e-4 (measured at 192 x 640,
-    # S = 2: 1.7e-6 / 6.6e-6 after one / two iterations, after three ONE pixel of 245 760 at 1.3e-4, the 99.99 % quantile 5e-6)
-    dev = np.sort(np.abs(src_gpu / dso - 1).ravel())
-    assert dev[-5] < 1e-4 and dev[-1] < 5e-4, dev[-6:]
+    # every pixel of every source map within 1e-4 (measured at 192 x 640, S = 2: worst 1.7e-6 / 6.6e-6 / 2.1e-5 after one / two / three
+    # iterations, the 99.99 % quantile 5e-6).  Until k_dref_scatter_src took the sign of cd - pd from the same fp32 expression as the forward
+    # group's kernel, ONE bilinear cell stood out at 1.3e-4: a forward sample with |cd - pd| / (cd + pd) = 2e-8, zero to the group's kernel and
+    # negative to the scatter (scripts/diag/free_source_pixel.py, appendix R4)
+    dev = np.abs(src_gpu / dso - 1)
+    assert dev.max() < 1e-4, np.sort(dev.ravel())[-6:]
     assert np.quantile(dev, 0.9999) < 2e-5
     assert np.abs(src_gpu / f32(w["depth_s"]) - 1).max() > 1e-3                    # the source maps really moved
     assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
@@ -296,7 +297,7 @@ def test_the_reference_leaf_set_quarter_resolution_target_and_sources(B, S, H, W
         assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
     src_gpu = depth[S * B:, 0].reshape(S, B, H, W)
     dev = np.sort(np.abs(src_gpu / dso - 1).ravel())
-    assert dev[-1] < 1e-4, dev[-6:]          # (a cell averages 64 pixels: an isolated switch does not show as it does at full resolution)
+    assert dev[-1] < 1e-4, dev[-6:]
     assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
     # the source maps moved away from their start (the x4 upsampling of the input's quarter-resolution projection)
     start = 1.0 / orc.up4(orc.down4(1.0 / f32(w["depth_s"])[0, 0]))

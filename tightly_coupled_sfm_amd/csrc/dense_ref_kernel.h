@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepa
     float4 val, gx, gy;
     tap4_lerp(t, val, gx, gy);
     const float pd = c.es * val.w, cd = g.Z, isum = frcp(cd + pd);
-    const float dif = dc_diff(c, g, t, dep, pd), raw = fabsf(dif) * isum;
+    // the sign of cd - pd is a decision the FORWARD group's kernel (k_dense_joint) takes on the plain fp32 difference (exactly zero is not rare
+    // there: sg = 0); the adjoint of the same term must take the same one -- dc_diff's cancellation-free value would call a pixel with
+    // |cd - pd| / (cd + pd) ~ 1e-8 negative where the group's own pose / map gradient used zero (scripts/diag/free_source_pixel.py)
+    const float dif = cd - pd, raw = fabsf(dif) * isum;
     if (!(raw >= 0.f && raw <= 1.f)) return;
     const float sg = dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f);
     const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)
