@@ -25,6 +25,8 @@ struct DrefPrepassParams {
     int B, S, argmin, automask;
     float eps;
     float b_dc;                   // w_dc / (S B H W)
+    int plain_dif;                // k_dref_scatter: the inverse pairs are linearised by k_dense_joint (free source maps), whose sign of cd - pd is the
+                                  // plain fp32 difference's -- not k_linearize's cancellation-free dc_diff: the adjoint takes the linearising kernel's
 };
 
 // The scattered sum of a target pixel is  sum_p (b_dc h - a_i M diff) ddd w_tap  with a_i = 0.25 / K_i.  It is accumulated in units of
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
             float4 val, gx, gy;
             tap4_lerp(t, val, gx, gy);
             const float pd = c.es * val.w, cd = g.Z, sum = cd + pd, isum = frcp(sum);
-            const float dif = dc_diff(c, g, t, depth_t[gi], pd), raw = fabsf(dif) * isum;
+            const float dif = D.plain_dif ? cd - pd : dc_diff(c, g, t, depth_t[gi], pd), raw = fabsf(dif) * isum;
             if (raw >= 0.f && raw <= 1.f) {
                 const float sg = dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f);
                 const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)

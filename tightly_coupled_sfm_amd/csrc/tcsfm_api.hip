@@ -736,6 +736,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     Dp.diff = maps_diff; Dp.valid = maps_valid; Dp.norms = h->dref_norms; Dp.ext = h->dref_ext; Dp.B = B; Dp.S = S;
     Dp.argmin = o->argmin ? 1 : 0; Dp.automask = o->automask; Dp.eps = o->irls_eps;
     Dp.b_dc = o->w_dc / ((float)SB * (float)hw);
+    Dp.plain_dif = (!ex && o->free_source_depths != 0) ? 1 : 0;
     // ---- inverse pairs: pose kernels on views offset by S B pairs, window rule REFERENCE (all of them are the rule's inverse group)
     LinParams Pi = lin_params(h, &oo, 6);
     const int nacc6 = AccLayout<6>::NACC;
