@@ -138,7 +138,8 @@ def test_dense_reference_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
     assert np.abs(depth[0, 0] / f32(w["depth_t"])[0] - 1).max() > 1e-3          # the map really moved
 
 
-@pytest.mark.parametrize("B,H,W,S,mind,maxd,argmin", [(1, 240, 320, 1, 0.03, 3.0, True), (1, 192, 640, 2, 0.06, 2.67, True), (2, 48, 160, 2, 0.06, 2.67, True),
+@pytest.mark.parametrize("B,H,W,S,mind,maxd,argmin", [(1, 240, 320, 1, 0.03, 3.0, True), (1, 192, 640, 2, 0.06, 2.67, True), (1, 256, 448, 1, 0.03, 3.0, True), (1, 128, 416, 3, 0.06, 2.67, True),
+                                                       (2, 48, 160, 2, 0.06, 2.67, True),
                                                        (1, 48, 160, 3, 0.06, 2.67, True), (2, 48, 160, 2, 0.06, 2.67, False)])
 def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, argmin, orc):
     """opts.free_source_depths: the SOURCE depth maps are unknowns as well (the reference's optimize_depth_pred optimises the disparities of
@@ -264,7 +265,8 @@ def test_quarter_resolution_iterates_follow_the_oracle(H, W, S, mind, maxd, orc)
         e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, depth_param=_lib.DEPTH_QUARTER), argmin=True)
 
 
-@pytest.mark.parametrize("B,S,H,W,mind,maxd", [(1, 1, 240, 320, 0.03, 3.0), (1, 2, 192, 640, 0.06, 2.67), (2, 2, 48, 160, 0.06, 2.67)])
+@pytest.mark.parametrize("B,S,H,W,mind,maxd", [(1, 1, 240, 320, 0.03, 3.0), (1, 2, 192, 640, 0.06, 2.67), (1, 1, 256, 448, 0.03, 3.0), (1, 3, 128, 416, 0.06, 2.67),
+                                                  (2, 2, 48, 160, 0.06, 2.67)])
 def test_the_reference_leaf_set_quarter_resolution_target_and_sources(B, S, H, W, mind, maxd, orc):
     """depth_param = TCSFM_DEPTH_QUARTER with free_source_depths: the unknowns are the reference's own leaves -- the quarter-resolution maps of
     the target AND of every source (optimizer.py:194-198: one tensor of S + 1 channels, upsampled x4 every epoch).  Poses, the target map and
