@@ -504,10 +504,22 @@ def main():
     # instrumented pass on EVERY rank: in-kernel brackets + HIP events around every kernel launch, same steps (ring rotation, one call
     # in flight: the kernel has the chip -- what a roofline compares against)
     n_prof = min(max(args.steps, 300), 500)                 # enough launches for a stable average, whatever K the driver asked for
-    eng.profile_begin()
-    for k in range(n_prof):
-        step_k(k, 1)
-    prof = eng.profile_end()
+    # (in five chunks, each with its own totals: the average is over ALL launches as before; the per-chunk averages show the spread -- with ONE
+    # call in flight the chip is lightly loaded and its shader clock moves between the 2.4 GHz and 1.4 GHz power states, which a VALU-bound
+    # kernel's duration follows: 8.4-8.5 us per launch in the high state, 9.4-9.6 us when the governor has stepped down; an untimed 0.3 s
+    # warm-up of the same load was tried and does not pin the state -- the light load itself is what lets the clock fall:
+    # profiles/r04_bench_repeats.jsonl, scripts/diag/clock_sampler.sh)
+    n_chunks = 5
+    chunk_us, prof = [], {}
+    for ci in range(n_chunks):
+        eng.profile_begin()
+        for k in range(ci * n_prof // n_chunks, (ci + 1) * n_prof // n_chunks):
+            step_k(k, 1)
+        pc = eng.profile_end()
+        chunk_us.append(round(pc["linearize_kernel"][0] / max(pc["linearize_kernel"][1], 1) * 1e3, 3))
+        for key, (ms_, n_) in pc.items():
+            a_, b_ = prof.get(key, (0.0, 0))
+            prof[key] = (a_ + ms_, b_ + n_)
     alg_bytes = 32 * H * W * npairs                          # 32 B/pixel/pair/iteration x pixels x pairs/launch
     k_ms, k_n = prof["linearize_kernel"]
     e_ms, e_n = prof["linearize"]
@@ -554,6 +566,7 @@ def main():
                 "frac_source": "this run: in-kernel s_memrealtime bracket of every k_linearize launch (earliest workgroup start -> latest workgroup "
                                "end), one call in flight, steps rotating over the ring",
                 "avg_launch_us": mine["avg_launch_us"], "avg_launch_us_hip_events": round(ev_s * 1e6, 3),
+                "avg_launch_us_chunks": chunk_us,
                 "valu_frac_of_bound": None if vb is None else vb["frac_of_bound"],
                 "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 3),
                 "kernel": "k_linearize", "launches": int(k_n), "algorithmic_bytes_per_launch": alg_bytes,
