@@ -383,6 +383,11 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
  * results are the bits of tcsfm_refine_window run on its own (the kernels are batch-independent under TCSFM_WINDOW_PAIR; a call under
  * TCSFM_WINDOW_REFERENCE, whose loss couples the windows of a call, is never merged with others and runs at once).  The caller's
  * buffers must stay valid and unchanged until the flush that runs them has been issued AND has completed on the handle's stream.
+ * ORDER (round 5): a queued call is never overtaken.  Every other entry point that puts work on the handle's stream (tcsfm_refine*,
+ * tcsfm_refine_dense*, the *_async and sequence calls, tcsfm_linearize*, the drop-ins, the PoseNet calls) first launches what is
+ * waiting and orders the handle's stream behind the merged sequences that ran on lanes; tcsfm_set_stream does so on the OLD stream
+ * before it switches (the queued calls were noted behind that stream's producers), tcsfm_use_own_stream likewise, and tcsfm_destroy
+ * runs what is waiting before it tears the handle down (queued calls are never dropped).
  *   tcsfm_set_coalesce(h, max_calls)   0 / 1: off (every queued call runs at once); up to 16; the handle's max_pairs bounds the merged
  *                                      sequence as well (2 S B x calls <= max_pairs)
  *   tcsfm_set_coalesce_lanes(h, n)     merged sequences alternate over n of the handle's streams (1: the handle's own, the default;

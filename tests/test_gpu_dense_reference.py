@@ -138,6 +138,45 @@ def test_dense_reference_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
     assert np.abs(depth[0, 0] / f32(w["depth_t"])[0] - 1).max() > 1e-3          # the map really moved
 
 
+@pytest.mark.parametrize("B,S,H,W,quarter", [(6, 1, 24, 40, False), (6, 1, 24, 40, True), (4, 1, 48, 160, False), (6, 2, 48, 160, False)])
+def test_dense_reference_minibatches_on_an_exactly_sized_handle(B, S, H, W, quarter, orc):
+    """with ONE source per target a call has max_pairs / 2 targets -- the per-target scratch of the joint kernels (state,
+    step, accepted depth) was sized for max_pairs / 4 and k_solve_joint<1> indexed past it.  The reference's own minibatch (6 windows,
+    run_sequential_optimization.py:186) on a handle created with exactly 2 S B pairs: poses and every pixel of every map follow the oracle"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    n_it = 2
+    w = _window(B, S, H, W, seed=91)
+    N = 2 * S * B
+    e = Engine(H, W, N)
+    assert e.max_pairs == N
+    o = default_opts(n_iters=n_it, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE, lambda_depth=1.0,
+                     depth_param=_lib.DEPTH_QUARTER if quarter else _lib.DEPTH_FULL)
+    t = {k: _dev(v) for k, v in w.items()}
+    dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
+    e.trace_begin(n_it, N)
+    pose, depth, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    bits, _ = e.trace_end()
+    pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    orc.flip_stats_reset()
+    fn = orc.refine_dense_ref_q if quarter else orc.refine_dense_ref
+    res = fn(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oracle_opts(n_iters=n_it, w_dc=0.15),
+             argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06, max_depth=2.67, bits=bits.reshape(n_it, N, H * W))
+    po, do = res[0], res[1]
+    nf, hard = orc.flip_stats(n_it)
+    assert hard.sum() == 0, (nf, hard)
+    for m in range(N):
+        et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
+        assert et < 1e-4 and er < 1e-4, (m, et, er)
+    for s in range(S):
+        assert np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max() < 1e-4, (s, np.abs(depth[s * B:(s + 1) * B, 0] / do - 1).max())
+    # a second call on the same handle (scratch reused) returns the same bits
+    pose2, depth2, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], o, stats=True, argmin=True)
+    assert np.array_equal(pose2.cpu().numpy().astype(np.float64), pose) and np.array_equal(depth2.cpu().numpy().astype(np.float64), depth)
+    e.close()
+
+
 @pytest.mark.parametrize("B,H,W,S,mind,maxd,argmin", [(1, 240, 320, 1, 0.03, 3.0, True), (1, 192, 640, 2, 0.06, 2.67, True), (1, 256, 448, 1, 0.03, 3.0, True), (1, 128, 416, 3, 0.06, 2.67, True),
                                                        (2, 48, 160, 2, 0.06, 2.67, True),
                                                        (1, 48, 160, 3, 0.06, 2.67, True), (2, 48, 160, 2, 0.06, 2.67, False)])

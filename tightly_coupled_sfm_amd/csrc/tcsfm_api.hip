@@ -481,6 +481,38 @@ SolveParams solve_params(tcsfm_ctx *h, const tcsfm_opts *o, int np, int shared) 
 }  // namespace
 
 namespace {
+// Scratch of the joint dense kernels, allocated ONCE on first use (a captured call graph -- tcsfm_set_graph_replay -- bakes these pointers
+// in, so they are never freed or re-sized while the handle lives).  The per-PIXEL records (jrec, jrec_acc) and the workgroup records are
+// sized in floats for the largest layout any call can need: S sources -> max_pairs / (2 S) targets x JREC(S) floats, largest at S = JMAXS
+// (20 floats x max_pairs / 4 targets; S = 1 under the reference's loss needs 8 x max_pairs / 2).  The per-TARGET arrays (state, step,
+// accepted depth) are sized for the most targets any call can have: (max_pairs + 1) / 2, reached at S = 1 (they were sized
+// for S >= 2 and the S = 1 reference-loss mode indexed past them).
+int joint_scratch(tcsfm_ctx *h) {
+    if (h->jrec) return TCSFM_OK;
+    using JM = JointLayout<JMAXS>;
+    const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
+    const size_t nb = (n + 3) / 4, nt = (n + 1) / 2;
+    static_assert(JointLayout<1>::JREC * 2 <= JM::JREC && JointLayout<2>::JREC <= JM::JREC, "pixel records: max_pairs / 4 targets of the S = JMAXS layout hold every case");
+    static_assert(JointLayout<1>::NACC * 2 <= JM::NACC && JointLayout<2>::NACC <= JM::NACC, "workgroup records: likewise");
+    HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
+    HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
+    HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nt * hw * sizeof(float)));
+    HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * 2 * h->nblk_alloc * JM::NACC * sizeof(float)));      // (tile records + the quarter-resolution mode's cell-group records)
+    HIPCHK(h, hipMalloc((void **)&h->jstate, nt * sizeof(JointState)));
+    HIPCHK(h, hipMalloc((void **)&h->jdelta, nt * 6 * JMAXS * sizeof(double)));
+    h->jrec_S = JMAXS;
+    return TCSFM_OK;
+}
+// capacity of that scratch for a call with B targets of NS sources each (explicit: the sizes above are derived, not per call)
+template <int NS>
+bool joint_scratch_fits(const tcsfm_ctx *h, int B, int recs_per_target) {
+    using JL = JointLayout<NS>;
+    using JM = JointLayout<JMAXS>;
+    const size_t n = h->max_pairs, nb = (n + 3) / 4, nt = (n + 1) / 2;
+    return (size_t)B <= nt && (size_t)B * JL::JREC <= nb * JM::JREC &&
+           (size_t)B * recs_per_target * JL::NACC <= nb * 2 * (size_t)h->nblk_alloc * JM::NACC;
+}
+
 // JOINT dense mode of a window (include/tcsfm.h, tcsfm_refine_dense_window): the S forward pairs of every target share one depth map
 // and are solved together (k_dense_joint / k_solve_joint / k_dense_joint_update); the inverse pairs run the pair-form dense kernels on
 // offset views of the same scratch.  Inputs already on the device.
@@ -507,20 +539,10 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
         HIPCHK(h, hipMalloc((void **)&h->depth_acc, n * hw * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
     }
-    if (!h->jrec) {      // targets <= max_pairs / (2 S) <= max_pairs / 4.  Sized ONCE for the largest S (JMAXS): a captured call graph
-                         // (tcsfm_set_graph_replay) bakes these pointers in, so they are never freed or re-sized while the handle lives
-        using JM = JointLayout<JMAXS>;
-        const size_t nb = (n + 3) / 4;
-        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * 2 * h->nblk_alloc * JM::NACC * sizeof(float)));      // (tile records + the quarter-resolution mode's cell-group records)
-        HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
-        HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
-        h->jrec_S = JMAXS;
-    }
+    if ((rc = joint_scratch(h))) return rc;
     if (lm && !h->lm_accept) HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
     if ((size_t)nblk > (size_t)h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
+    if (!joint_scratch_fits<NS>(h, B, nblk)) return fail(h, TCSFM_E_ARG, "internal: the joint dense scratch does not hold this many targets");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the pose-mode coupling; the joint kernel takes the rule through JointParams)
@@ -674,16 +696,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->depth0, n * hw * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->delta, n * 8 * sizeof(double)));
     }
-    if (!h->jrec) {
-        const size_t nb = (n + 3) / 4;
-        HIPCHK(h, hipMalloc((void **)&h->jrec, nb * hw * JM::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jrec_acc, nb * hw * JM::JREC * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jdepth_acc, nb * hw * sizeof(float)));
-        HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * 2 * h->nblk_alloc * JM::NACC * sizeof(float)));      // (tile records + the quarter-resolution mode's cell-group records)
-        HIPCHK(h, hipMalloc((void **)&h->jstate, nb * sizeof(JointState)));
-        HIPCHK(h, hipMalloc((void **)&h->jdelta, nb * 6 * JMAXS * sizeof(double)));
-        h->jrec_S = JMAXS;
-    }
+    if ((rc = joint_scratch(h))) return rc;
     if (!h->dref_norms) {
         HIPCHK(h, hipMalloc((void **)&h->dref_norms, 4 * sizeof(int)));
         HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * sizeof(long long)));      // (targets <= max_pairs / 2)
@@ -699,6 +712,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->qres_rec, nb * nq * JM::JREC * sizeof(float)));
     }
     if (qres && nblk + nqblk > 2 * h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
+    if (!joint_scratch_fits<NS>(h, B, nblk + nqblk)) return fail(h, TCSFM_E_ARG, "internal: the joint dense scratch does not hold this many targets");
     // opts.free_source_depths: the inverse pairs as S B groups of one source (the joint kernel / solve / update on views offset by S B pairs)
     const bool free_src = !ex && o->free_source_depths != 0;
     if (free_src && !h->jrec_src) {
@@ -945,6 +959,15 @@ extern "C" {
 
 static int flush_pending(tcsfm_ctx *h);
 static int join_coalesce_lanes(tcsfm_ctx *h);
+// Calls noted by the *_queued entry points are launched -- and the handle's stream ordered behind the merged sequences that ran on lanes --
+// before ANY other entry point puts work on the handle's stream, switches that stream or destroys the handle: a plain call never overtakes
+// a call queued before it (producers and consumers of the caller's pose / depth buffers keep their program order; include/tcsfm.h).
+static int drain_queued(tcsfm_ctx *h) {
+    if (!h || (h->pending.empty() && !h->coal_dirty)) return TCSFM_OK;
+    DeviceGuard dev_guard(h->device);
+    if (int rc = flush_pending(h)) return rc;
+    return join_coalesce_lanes(h);
+}
 
 void tcsfm_default_opts(tcsfm_opts *o) {
     memset(o, 0, sizeof(*o));
@@ -970,7 +993,9 @@ const char *tcsfm_last_error(tcsfm_handle h) { return h ? h->err.c_str() : g_cre
 int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
     if (!out) return TCSFM_E_ARG;
     *out = nullptr;
-    if (H < 4 || W < 4 || H > 16384 || W > 16384 || max_pairs < 1 || (size_t)H * W * max_pairs > ((size_t)1 << 33)) {
+    // (the warp gathers address a bordered image with 32-bit byte offsets -- tap4_fetch: (H + 2)(W + 2) 16 B must stay below 4 GiB)
+    if (H < 4 || W < 4 || H > 16384 || W > 16384 || max_pairs < 1 || (size_t)H * W * max_pairs > ((size_t)1 << 33) ||
+        (size_t)(H + 2) * (W + 2) >= ((size_t)1 << 28)) {
         g_create_error = "tcsfm_create: bad sizes";
         return TCSFM_E_ARG;
     }
@@ -1022,6 +1047,7 @@ int tcsfm_create(tcsfm_handle *out, int device, int H, int W, int max_pairs) {
 
 void tcsfm_destroy(tcsfm_handle h) {
     if (!h) return;
+    (void)drain_queued(h);                // queued calls are not dropped: they run, and the synchronisations below wait for them
     for (tcsfm_ctx *c : h->lanes) tcsfm_destroy(c);
     h->lanes.clear();
     DeviceGuard dev_guard(h->device);
@@ -1059,6 +1085,8 @@ void tcsfm_destroy(tcsfm_handle h) {
 
 int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
     if (!h) return TCSFM_E_ARG;
+    if ((hipStream_t)hip_stream != h->stream)           // queued calls were noted while bound to the old stream: they run there, behind its producers
+        if (int rc_q = drain_queued(h)) return rc_q;
     if ((hipStream_t)hip_stream != h->stream && !h->graphs.empty()) {   // captured calls may still be running on the old stream, and a graph
         DeviceGuard dev_guard(h->device);                              // captured there is not replayed on another producer's stream
         drop_graphs(h);
@@ -1069,6 +1097,7 @@ int tcsfm_set_stream(tcsfm_handle h, void *hip_stream) {
 }
 
 int tcsfm_use_own_stream(tcsfm_handle h) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     h->stream = h->own_stream;
     return TCSFM_OK;
@@ -1086,6 +1115,7 @@ int tcsfm_synchronize(tcsfm_handle h) {
 }
 
 int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const float *disp, float *scaled, float *depth) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (!o || !disp || n < 1) return fail(h, TCSFM_E_ARG, "tcsfm_disp_to_depth: bad argument");
     if (!(o->min_depth > 0 && o->max_depth > o->min_depth)) return fail(h, TCSFM_E_ARG, "min_depth/max_depth invalid");
@@ -1106,6 +1136,7 @@ int tcsfm_disp_to_depth(tcsfm_handle h, const tcsfm_opts *o, int64_t n, const fl
 }
 
 int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, const float *y, float *out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (!o || !x || !y || !out || planes < 1) return fail(h, TCSFM_E_ARG, "tcsfm_ssim: bad argument");
     DeviceGuard dev_guard(h->device);
@@ -1125,6 +1156,7 @@ int tcsfm_ssim(tcsfm_handle h, const tcsfm_opts *o, int planes, const float *x, 
 
 int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, const float *depth_t, const float *depth_s,
                const float *pose, const float *K, float *img_rec, float *valid, float *proj_depth, float *comp_depth) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_warp: NULL input");
@@ -1161,6 +1193,7 @@ int tcsfm_warp(tcsfm_handle h, const tcsfm_opts *o, int N, const float *src, con
 
 int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                              const float *depth_s, const float *pose, const float *K, float *posenet_in, float *valid) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose || !K || !posenet_in) return fail(h, TCSFM_E_ARG, "tcsfm_warp_posenet_input: NULL argument");
@@ -1195,6 +1228,7 @@ int tcsfm_warp_posenet_input(tcsfm_handle h, const tcsfm_opts *o, int N, const f
 int tcsfm_photometric(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                       const float *depth_s, const float *pose, const float *K, float *diff, float *valid, float *weight,
                       float *auto_err, float *auto_mask, float *img_rec) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_photometric: NULL input");
@@ -1249,6 +1283,7 @@ static int eval_once(tcsfm_ctx *h, const tcsfm_opts *o, int N, int Nimg, const f
 int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                     const float *depth_s, const float *pose, const float *log_scale, const float *K, double *Hmat, double *g,
                     double *stats) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !pose || !K) return fail(h, TCSFM_E_ARG, "tcsfm_linearize: NULL input");
@@ -1279,6 +1314,7 @@ int tcsfm_linearize(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt
 int tcsfm_linearize_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                            const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *log_scale,
                            double *Hmat, double *g, double *stats) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_window: need 1 <= 2*B*S <= max_pairs");
     const int N = 2 * B * S;
@@ -1324,6 +1360,7 @@ int tcsfm_linearize_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, co
 
 int tcsfm_loss_surface(tcsfm_handle h, const tcsfm_opts *o, const float *tgt, const float *src, const float *depth_t,
                        const float *depth_s, const float *K, int P, const float *poses, double *cost_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, P);
     if (rc) return rc;
     if (!tgt || !src || !depth_t || !depth_s || !poses || !K || !cost_out) return fail(h, TCSFM_E_ARG, "tcsfm_loss_surface: NULL argument");
@@ -1537,12 +1574,14 @@ static int refine_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
 int tcsfm_refine(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                  const float *depth_s, const float *K, const float *pose_in, const float *log_scale_in, float *pose_out,
                  float *log_scale_out, float *stats_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     return refine_impl(h, o, N, 0, 0, tgt, src, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
 }
 
 int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                         const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
                         const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window: need 1 <= 2*B*S <= max_pairs");
     return refine_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
@@ -1550,6 +1589,7 @@ int tcsfm_refine_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const
 
 int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float *depth, const float *K, float real_cam_height,
                          int pad_to_batch, float *scale_out, float *median_out, float *height_out, float *mask_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!depth || !K || !scale_out) return fail(h, TCSFM_E_ARG, "tcsfm_scale_recovery: NULL argument");
@@ -1593,6 +1633,7 @@ int tcsfm_scale_recovery(tcsfm_handle h, const tcsfm_opts *o, int N, const float
 }
 
 int tcsfm_smooth_loss(tcsfm_handle h, const tcsfm_opts *o, int N, const float *disp, const float *img, double *loss_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     int rc = check_common(h, o, N);
     if (rc) return rc;
     if (!disp || !img || !loss_out) return fail(h, TCSFM_E_ARG, "tcsfm_smooth_loss: NULL argument");
@@ -1824,12 +1865,14 @@ static int dense_impl(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
 int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *tgt, const float *src, const float *depth_t,
                        const float *depth_s, const float *K, const float *pose_in, float *pose_out, float *depth_out,
                        float *stats_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     return dense_impl(h, o, N, 0, 0, tgt, src, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
 }
 
 int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                               float *depth_out, float *stats_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: need 1 <= 2*B*S <= max_pairs");
     return dense_impl(h, o, 2 * B * S, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
@@ -1992,6 +2035,7 @@ int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B,
 static int linearize_dense_window_impl(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                        const float *depth_t, const float *depth_s, const float *K, const float *pose, const float *depth0,
                                        double *scal_out, double *g_pose_out, float *g_rho_out, float *g_rho_src_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (B < 1 || S < 1 || S > JMAXS || (long long)2 * B * S > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_linearize_dense_window: need 1 <= S <= 3 and 2*B*S <= max_pairs");
     const int N = 2 * B * S;
@@ -2089,6 +2133,7 @@ static tcsfm_ctx *lane_of(tcsfm_ctx *h, int lane) {
 int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
                               const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     tcsfm_ctx *c = lane_of(h, lane);
     if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_refine_window_async: no such lane (tcsfm_set_lanes)") : TCSFM_E_ARG;
     if (o && o->host_ptrs == 1) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_async: host_ptrs must be 0 (device) or 2 (pinned host, asynchronous)");
@@ -2108,6 +2153,7 @@ int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int
 int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                     const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                                     float *depth_out, float *stats_out) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     tcsfm_ctx *c = lane_of(h, lane);
     if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_async: no such lane (tcsfm_set_lanes)") : TCSFM_E_ARG;
     if (o && o->host_ptrs == 1) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_async: host_ptrs must be 0 (device) or 2 (pinned host, asynchronous)");
@@ -2135,6 +2181,7 @@ static int pn_max_images(const tcsfm_posenet *pn);
 static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, const float *frames, const float *depths, const float *K,
                          const float *pose_init, tcsfm_posenet *pn, int num_iter, float *pose_init_out, float *pose_out,
                          float *log_scale_out, int ring, int windows_per_call, int target_pos, float *dense_depth_out = nullptr) {
+    if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
     const int N = 2 * S, L = (int)h->lanes.size() + 1;
@@ -2709,6 +2756,7 @@ int tcsfm_posenet_forward(tcsfm_posenet *pn, int N, const float *imgs, float *po
     tcsfm_ctx *h = pn->h;
     if (!pn->loaded) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_forward: no weights loaded");
     if (N < 1 || N > pn->max_images || !imgs || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_posenet_forward: bad argument");
+    if (int rc_q = drain_queued(h)) return rc_q;
     DeviceGuard dev_guard(h->device);
     const long long hw = (long long)h->H * h->W;
     return pn_run(pn, N, imgs, 6 * hw, imgs + 3 * hw, 6 * hw, 0, 0, pose_out, 0, nullptr, 0, 1);
@@ -2749,6 +2797,7 @@ int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter
     const int N = 2 * B * S;
     if (num_iter < 1 || B < 1 || S < 1 || N > pn->max_images || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: sizes out of range");
     if (!tgt || !srcs || !depth_t || !depth_s || !K || !poses_out) return fail(h, TCSFM_E_ARG, "tcsfm_solve_pose_iteratively: NULL argument");
+    if (int rc_q = drain_queued(h)) return rc_q;
     DeviceGuard dev_guard(h->device);
     if (int rc_ = pending_error(h)) return rc_;
     return pose_loop(h, pn, num_iter, B, S, tgt, srcs, depth_t, depth_s, K, poses_out, stacked_out, nullptr);

@@ -102,7 +102,7 @@ class DepthOptimizer:
                  options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose" and options.get("param", "se3") == "se3")
         # l_smooth IS a term of the pose + depth mode on the reference's loss (opts.w_smooth, round 4)
         sm_ok = (options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose+depth" and
-                 options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm" and int(options.get("num_source_imgs", 2)) <= 3)
+                 options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm")
         ignored = [k for k in ("l_smooth", "l_pose_consist") if options.get(k, False) and not ((k == "l_pose_consist" and pc_ok) or (k == "l_smooth" and sm_ok))]
         if ignored:   # off by default in the reference (run_sequential_optimization.py:87,89); not part of the per-pair GN cost
             warnings.warn(f"options {ignored} are not terms of the Gauss-Newton cost and are ignored "
@@ -121,10 +121,11 @@ class DepthOptimizer:
         return o.get("refine", "pose+depth" if o.get("optimize_depth_pred", False) else "pose")
 
     def _dense_reference(self):
-        """pose + depth by default minimises the reference's own loss (window rule REFERENCE, S <= 3 sources, Gauss-Newton);
+        """pose + depth by default minimises the reference's own loss (window rule REFERENCE, Gauss-Newton; the kernels are instantiated for
+        S <= 3 sources per target: optimize_window checks the ACTUAL number of source images before it calls the engine);
         options['window_rule'] = 'pair' or solver 'lm' select the library's own dense modes"""
         o = self.options
-        return o.get("window_rule", "reference") != "pair" and o.get("solver", "gn") != "lm" and int(o.get("num_source_imgs", 2)) <= 3
+        return o.get("window_rule", "reference") != "pair" and o.get("solver", "gn") != "lm"
 
     def _opts(self):
         o = self.options
@@ -209,6 +210,9 @@ class DepthOptimizer:
         B, _, H, W = target_img.shape
         S = len(source_img_list)
         split = S * B
+        dense = self._refine_mode() == "pose+depth"
+        if dense and self._dense_reference() and S > 3:      # (the real S, before anything is launched: options['num_source_imgs'] may not match the batch)
+            raise ValueError("pose + depth on the reference's loss handles up to 3 source images per target (options['window_rule'] = 'pair' lifts it)")
         eng = self._eng(H, W, 2 * split)
         cfg = self.config
 
@@ -233,7 +237,6 @@ class DepthOptimizer:
 
         opts = self._opts()
         tgt = stack_imgs[:, 0:3].contiguous(); src = stack_imgs[:, 3:6].contiguous()
-        dense = self._refine_mode() == "pose+depth"
         if dense and self._dense_reference() and self.options.get("depth_param", "quarter") == "quarter":
             # the reference's own unknown (optimizer.py:194-198, 235-239): the QUARTER-resolution map, upsampled x4 for every evaluation of
             # the loss (golden G13 `qinit`); options['depth_param'] = 'full': one inverse depth per pixel
@@ -252,8 +255,6 @@ class DepthOptimizer:
             pose, log_scale, stats = eng.refine_window(
                 target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
                 intrinsics.float(), pose0, opts, stats=True, argmin=bool(self.options.get("diff_img_argmin", True)))
-        if dense and self._dense_reference() and S > 3:
-            raise ValueError("pose + depth on the reference's loss handles up to 3 source images per target (options['window_rule'] = 'pair' lifts it)")
         if not self.options.get("l_inverse_reconstruction", True):
             # the reference then leaves the inverse direction out of its objective (optimizer.py:74-79): the inverse poses stay
             # what the pose network predicted
