@@ -183,6 +183,52 @@ def test_merged_dense_calls_are_bit_identical_to_single_calls():
     e.set_coalesce_lanes(1); e.set_coalesce(0)
 
 
+@pytest.mark.parametrize("S,B,quarter,H,W", [(1, 1, False, 96, 320), (2, 1, False, 96, 320), (2, 2, True, 48, 160), (1, 1, True, 96, 320), (3, 1, False, 48, 160)])
+def test_merged_reference_loss_dense_calls_are_bit_identical_to_single_calls(S, B, quarter, H, W):
+    """round 5: queued dense calls under window_rule REFERENCE (the reference's own loss, optimizer.py:47-90) merge as well -- the loss couples
+    the windows of ONE call through its batch normalisers, so inside the merged sequence every call is a normaliser group of its own
+    (k_linearize<FRONT> counts per group, the joint / solve kernels read their group's counts): poses and depth maps of every call are the
+    bits of the call run on its own, with the per-pixel and with the quarter-resolution unknown, for one to three sources"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    calls = _calls(6, H, W, S=S, B=B, seed=300)
+    o = default_opts(n_iters=3, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE,
+                     depth_param=_lib.DEPTH_QUARTER if quarter else _lib.DEPTH_FULL)
+    o.argmin = 1
+    N = 2 * S * B
+    ref = Engine(H, W, N)
+    dt4 = [c["dt"][:, None].contiguous() if c["dt"].dim() == 3 else c["dt"] for c in calls]
+    ds5 = [c["ds"][:, :, None].contiguous() if c["ds"].dim() == 4 else c["ds"] for c in calls]
+    want = []
+    for c, a, b in zip(calls, dt4, ds5):
+        p, d, _ = ref.refine_dense_window(c["tgt"], c["srcs"], a, b, c["K"], c["pose"], o, argmin=True)
+        want.append((p.clone(), d.clone()))
+    torch.cuda.synchronize()
+    e = Engine(H, W, N * 4, lanes=2)
+    e.set_coalesce(4); e.set_coalesce_lanes(2)
+    po = [torch.zeros(N, 6, device="cuda") for _ in calls]
+    do = [torch.zeros(N, 1, H, W, device="cuda") for _ in calls]
+    for c, a, b, p, d in zip(calls, dt4, ds5, po, do):
+        e.refine_dense_window_queued(c["tgt"], c["srcs"], a, b, c["K"], c["pose"], p, d, o)
+    assert e.coalesce_counts() == (1, 4)                 # four calls ran as one sequence, two are waiting
+    e.synchronize()
+    assert e.coalesce_counts() == (2, 6)
+    for i, ((wp, wd), p, d) in enumerate(zip(want, po, do)):
+        assert torch.equal(p, wp), (i, (p - wp).abs().max())
+        assert torch.equal(d, wd), (i, (d - wd).abs().max())
+    # the free-source-map mode is not merged: it runs at once (and still gives the bits of the plain call)
+    o2 = default_opts(n_iters=2, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE, free_source_depths=1)
+    o2.argmin = 1
+    p2, d2 = torch.zeros(N, 6, device="cuda"), torch.zeros(N, 1, H, W, device="cuda")
+    e.refine_dense_window_queued(calls[0]["tgt"], calls[0]["srcs"], dt4[0], ds5[0], calls[0]["K"], calls[0]["pose"], p2, d2, o2)
+    assert e.coalesce_counts() == (2, 6)
+    wp2, wd2, _ = ref.refine_dense_window(calls[0]["tgt"], calls[0]["srcs"], dt4[0], ds5[0], calls[0]["K"], calls[0]["pose"], o2, argmin=True)
+    e.synchronize()
+    assert torch.equal(p2, wp2) and torch.equal(d2, wd2)
+    e.set_coalesce_lanes(1); e.set_coalesce(0)
+    e.close(); ref.close()
+
+
 def test_merged_pose_scale_calls_are_bit_identical_to_single_calls():
     """tcsfm_refine_window_scale_queued: BASELINE config 4 (pose + one log depth-scale per pair, 7 x 7) through the merged sequences -- poses
     and log scales of every call are the bits of the call on its own, with given and with default (0) initial scales"""

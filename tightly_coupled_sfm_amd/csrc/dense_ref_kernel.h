@@ -3,7 +3,17 @@
 //
 //   L = c_f / K_f  sum M_s W_x diff_s  +  0.25 / K_i sum M_i W_i diff_i  +  w_dc / (S B HW) sum (dd_fwd + dd_inv)  +  w_init / (B HW) sum SSIM(sigma, sigma0)
 //
-// Unknowns: the poses of all 2 S B directed pairs and ONE inverse-depth map per target.  Per linearisation, on one stream:
+// Unknowns: the poses of all 2 S B directed pairs and ONE inverse-depth map per target.
+// Round 5: FOUR dependent launches per Gauss-Newton iteration (five with the quarter-resolution unknown) instead of eight to eleven:
+//   k_linearize<6, DC, LIN, .., FRONT>  all 2 S B pairs: the forward pairs' mask / selection and its count K_f; the inverse pairs' 6 x 6
+//                            linearisation, their count K_i and the adjoint scatter of their samples of the target depth (two fixed-point
+//                            sums per target pixel: no normaliser needed when they are scattered)                        (kernels.h)
+//   k_dense_joint<S, .., REF>  the forward group (reads K_f, K_i, the selection map and the scattered sums)              (joint_kernel.h)
+//   [k_qres_schur<S>           quarter-resolution unknown: cell records and their Schur terms]
+//   k_solve_front<S>         the target groups' 6S x 6S systems AND the inverse pairs' 6 x 6 systems in one launch
+//   k_dense_joint_update<S>  back-substitution (k_qres_step_up<S>: cell step + x4 upsampling in one launch)
+// The chain below (residual maps, counts, scatter as launches of their own) remains for the free-source-map mode and the exports:
+// per linearisation, on one stream:
 //   k_linearize<MODE_MAPS>   residual maps (diff, valid) of all 2 S B pairs at the current poses / depth            (kernels.h)
 //   k_dref_count             the batch-summed mask counts: K_f of the forward pairs' min-over-sources selection, K_i of the inverse pairs
 //   k_dref_scatter           the ADJOINT of the inverse pairs' bilinear samples of the target depth -- d L / d pd of every inverse pixel onto
@@ -21,7 +31,7 @@ namespace tc {
 struct DrefPrepassParams {
     const float *diff, *valid;    // [2SB][H*W] residual maps of all pairs (k_linearize<MODE_MAPS>)
     int *norms;                   // [2] K_f, K_i (zeroed before k_dref_count)
-    long long *ext;               // [B][H*W] fixed-point scatter sums (zeroed before k_dref_scatter), in units of u (see dref_unit)
+    long long *ext;               // [B][H*W][2] fixed-point scatter sums (zero before k_dref_scatter): depth-consistency part, photometric part
     int B, S, argmin, automask;
     float eps;
     float b_dc;                   // w_dc / (S B H W)
@@ -29,13 +39,10 @@ struct DrefPrepassParams {
                                   // plain fp32 difference's -- not k_linearize's cancellation-free dc_diff: the adjoint takes the linearising kernel's
 };
 
-// The scattered sum of a target pixel is  sum_p (b_dc h - a_i M diff) ddd w_tap  with a_i = 0.25 / K_i.  It is accumulated in units of
-// u = a_i (u = b_dc when no inverse pixel counts): O(1) numbers for the 2^-40 fixed point whatever the image size.
-__device__ __forceinline__ void dref_unit(const int *norms, float b_dc, float &ratio_dc, float &w_photo) {
-    const float Ki = (float)norms[1];
-    if (Ki > 0.f) { ratio_dc = b_dc * Ki * 4.f; w_photo = 1.f; }     // b_dc / a_i, and the photometric part at weight 1
-    else { ratio_dc = 1.f; w_photo = 0.f; }
-}
+// The scattered sum of a target pixel is  sum_p (b_dc h - a_i M diff) ddd w_tap  with a_i = 0.25 / K_i.  Its two parts are accumulated
+// SEPARATELY and without their factors -- sum h ddd w and sum M diff ddd w: O(1) numbers for the 2^-40 fixed point whatever the image size,
+// and no batch normaliser is needed while scattering (round 5: the scatter rides in the launch that counts K_i); the consumer
+// (k_dense_joint) applies b_dc and a_i.
 
 // pass 1: the batch-summed mask counts.  DREF_CNT_WG workgroups per directed pair stride over its pixels, count in registers (ballot +
 // popcount per wave), combine in LDS and issue ONE integer atomic per workgroup: a few hundred same-address atomics per linearisation
@@ -73,8 +80,8 @@ __global__ __launch_bounds__(256) void k_dref_count(LinParams P, DrefPrepassPara
 // addresses.  A tap outside the window (depth edges) goes to global memory directly.  Integer adds: order-independent, bit-reproducible.
 constexpr int DREF_TW = 32, DREF_TH = 8, DREF_M = 6;
 __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P, DrefPrepassParams D) {
-    constexpr int WW = DREF_TW + 2 * DREF_M, WH = DREF_TH + 2 * DREF_M;
-    __shared__ unsigned long long win[WW * WH];
+    constexpr int WW = DREF_TW + 2 * DREF_M, WH = DREF_TH + 2 * DREF_M, NWIN = WW * WH;
+    __shared__ unsigned long long win[2 * NWIN];
     const int H = P.H, W = P.W, hw = H * W, SB = D.S * D.B;
     const int m = blockIdx.y, n = SB + m, b = m % D.B;
     const int tiles_x = (W + DREF_TW - 1) / DREF_TW;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
     const int u = tx * DREF_TW + lx, v = ty * DREF_TH + ly;
     const PairConst &c = P.pc[n];
     const float *depth_t = P.depth_t + (size_t)n * hw;
-    for (int i = tid; i < WW * WH; i += DREF_TW * DREF_TH) win[i] = 0ull;
+    for (int i = tid; i < 2 * NWIN; i += DREF_TW * DREF_TH) win[i] = 0ull;
     // window origin: the tile's own origin displaced by the flow of its centre pixel (every thread evaluates it: no broadcast, no barrier)
     int ox, oy;
     {
@@ -93,10 +100,8 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
         const float fx = fminf(fmaxf(gc.rx, -4096.f), 4096.f), fy = fminf(fmaxf(gc.ry, -4096.f), 4096.f);
         ox = tx * DREF_TW + (int)floorf(fx) - DREF_M; oy = ty * DREF_TH + (int)floorf(fy) - DREF_M;
     }
-    float ratio_dc, w_photo;
-    dref_unit(D.norms, D.b_dc, ratio_dc, w_photo);
     __syncthreads();
-    long long *ext = D.ext + (size_t)b * hw;
+    long long *ext = D.ext + (size_t)b * hw * 2;
     if (u < W && v < H) {
         const int gi = v * W + u;
         const bool valid = P.ext_valid[(size_t)n * hw + gi] > 0.5f;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
                 const float sg = dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f);
                 const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)
                 const float dd = fminf(raw, 1.f);
-                const float coef = (ratio_dc * fminf(1.f, dd * frcp(D.eps)) - (count ? w_photo * diff : 0.f)) * ddd;
+                const float f_dc = fminf(1.f, dd * frcp(D.eps)) * ddd, f_ph = count ? diff * ddd : 0.f;
                 const int xi = u + (int)floorf(g.rx), yi = v + (int)floorf(g.ry);
                 const float wx = t.wx, wy = t.wy;
                 const float w4[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
@@ -123,11 +128,15 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
                 for (int k = 0; k < 4; k++) {
                     const int xx = xi + (k & 1), yy = yi + (k >> 1);
                     if (xx >= 0 && xx < W && yy >= 0 && yy < H) {         // (a tap in the zero border is no pixel of the target)
-                        const long long a = (long long)llrint((double)(coef * w4[k]) * DREF_FIX);
+                        const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
                         const int wxl = xx - ox, wyl = yy - oy;
-                        if (a != 0) {
-                            if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a);
-                            else atomicAdd(reinterpret_cast<unsigned long long *>(ext + (size_t)yy * W + xx), (unsigned long long)a);
+                        if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) {
+                            if (a0 != 0) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a0);
+                            if (a1 != 0) atomicAdd(&win[NWIN + wyl * WW + wxl], (unsigned long long)a1);
+                        } else {
+                            unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+                            if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
+                            if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
                         }
                     }
                 }
@@ -135,10 +144,14 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
         }
     }
     __syncthreads();
-    for (int i = tid; i < WW * WH; i += DREF_TW * DREF_TH) {
-        const unsigned long long a = win[i];
+    for (int i = tid; i < NWIN; i += DREF_TW * DREF_TH) {
+        const unsigned long long a0 = win[i], a1 = win[NWIN + i];
         const int yy = oy + i / WW, xx = ox + i % WW;
-        if (a != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) atomicAdd(reinterpret_cast<unsigned long long *>(ext + (size_t)yy * W + xx), a);
+        if ((a0 | a1) != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+            unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+            if (a0 != 0ull) atomicAdd(e, a0);
+            if (a1 != 0ull) atomicAdd(e + 1, a1);
+        }
     }
 }
 
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
 // (optimizer.py:69), a pair's own pixels otherwise.  d L / d pd(p) = (b_dc h(dd) - a_f E(p)) d dd / d pd, E = the sum of M diff over the
 // pixels this weight multiplies, scattered over the four taps in units of a_f = c_f / K_f (b_dc when no pixel counts).  A verification
 // path, not a timed one: one thread per pixel, one 64-bit fixed-point atomic per tap (order-independent: bit-reproducible).
-__global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepassParams D, long long *ext_src /* [SB][H*W] */, float c_f) {
+__global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepassParams D, long long *ext_src /* [SB][H*W][2] */) {
     const int H = P.H, W = P.W, hw = H * W;
     const int m = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= hw) return;
@@ -183,19 +196,19 @@ __global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepa
             if (count) E += diff;
         }
     }
-    const float Kf = (float)D.norms[0];
-    const float ratio_dc = Kf > 0.f ? D.b_dc * Kf / c_f : 1.f, w_photo = Kf > 0.f ? 1.f : 0.f;
-    const float coef = (ratio_dc * fminf(1.f, dd * frcp(D.eps)) - w_photo * E) * ddd;
+    const float f_dc = fminf(1.f, dd * frcp(D.eps)) * ddd, f_ph = E * ddd;      // (factors b_dc and a_f = c_f / K_f: applied by the consumer)
     const int xi = u + (int)floorf(g.rx), yi = v + (int)floorf(g.ry);
     const float wx = t.wx, wy = t.wy;
     const float w4[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
-    long long *ext = ext_src + (size_t)m * hw;
+    long long *ext = ext_src + (size_t)m * hw * 2;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int xx = xi + (k & 1), yy = yi + (k >> 1);
         if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-            const long long a = (long long)llrint((double)(coef * w4[k]) * DREF_FIX);
-            if (a != 0) atomicAdd(reinterpret_cast<unsigned long long *>(ext + (size_t)yy * W + xx), (unsigned long long)a);
+            const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
+            unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+            if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
+            if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
         }
     }
 }
@@ -273,7 +286,12 @@ struct QresParams {
     const double *delta;      // [B][6 JMAXS]
     float *depth;             // [.][H*W] slots of the forward pairs n = s B + b
     float4 *srcpack_inv;      // packs of the inverse pairs (channel w = the target depth they sample)
-    int *norms_zero;          // the two batch counters, zeroed for the next linearisation (or null)
+    int *norms_zero;          // the batch counters (norms_n of them), zeroed for the next linearisation (or null)
+    int norms_n;
+    float *rho_q_next;        // k_qres_step_up: the new cell values (ping-pong: the launch reads rho_q of neighbouring cells while it writes)
+    float *depth_out;         // k_qres_step_up: optional second destination of the forward slots (the caller's buffer: last iteration), or null
+    int c_ncall, c_B;         //   ... coalesced calls: per call (as JointUpdateParams), used when c_ncall > 0
+    float *c_depth_out[TC_MAX_COAL];
     int H, W, B, S, rec_stride, rec_first;
     float rho_lo, rho_hi;
 };
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(256) void k_qres_init(QresParams P) {
 
 __global__ __launch_bounds__(256) void k_qres_upsample(QresParams P) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y, hw = P.H * P.W;
-    if (P.norms_zero && idx == 0 && b == 0) { P.norms_zero[0] = 0; P.norms_zero[1] = 0; }
+    if (P.norms_zero && idx < P.norms_n && b == 0) P.norms_zero[idx] = 0;
     if (idx >= hw) return;
     const int h = P.H / 4, w = P.W / 4;
     const int v = idx / P.W, u = idx - v * P.W;
@@ -401,6 +419,60 @@ __global__ __launch_bounds__(256) void k_qres_step(QresParams P) {
     for (int j = 0; j < 6 * NS; j++) bd += r[2 + j] * (float)P.delta[b * 6 * JMAXS + j];
     float *q = P.rho_q + (size_t)b * nq + c;
     *q = depth_step(*q, -(r[0] + bd) / r[1], P.rho_lo, P.rho_hi);
+}
+
+// k_qres_step + k_qres_upsample as ONE launch (round 5).  A workgroup owns a 32 x 8 tile of pixels = 8 x 2 cells; the x4 bilinear
+// upsampling of its pixels reads the 10 x 4 cells around them: the first 40 threads take the step of one of those cells each (the same
+// arithmetic as k_qres_step: a cell is stepped by up to four workgroups, every time to the same bits), the new values go to LDS and -- the
+// workgroup's OWN 8 x 2 cells only -- to rho_q_next (ping-pong: neighbouring workgroups still read rho_q); then every pixel interpolates
+// from LDS and writes its depth into the forward pairs' slots and the inverse pairs' packs, as k_qres_upsample.
+constexpr int QSU_TW = 32, QSU_TH = 8, QSU_CW = QSU_TW / 4 + 2, QSU_CH = QSU_TH / 4 + 2;
+template <int NS>
+__global__ __launch_bounds__(QSU_TW * QSU_TH) void k_qres_step_up(QresParams P) {
+    using JL = JointLayout<NS>;
+    __shared__ float rq[QSU_CH * QSU_CW];
+    const int h = P.H / 4, w = P.W / 4, nq = h * w, hw = P.H * P.W;
+    const int tiles_x = (P.W + QSU_TW - 1) / QSU_TW;
+    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int cx0 = txi * (QSU_TW / 4), cy0 = tyi * (QSU_TH / 4);
+    if (P.norms_zero && blockIdx.x == 0 && b == 0 && tid < P.norms_n) P.norms_zero[tid] = 0;
+    if (tid < QSU_CH * QSU_CW) {
+        const int ly = tid / QSU_CW, lx = tid - ly * QSU_CW;
+        const int cyr = cy0 - 1 + ly, cxr = cx0 - 1 + lx;
+        const int cy = min(max(cyr, 0), h - 1), cx = min(max(cxr, 0), w - 1), c = cy * w + cx;
+        const float4 *rt = reinterpret_cast<const float4 *>(P.qrec + ((size_t)b * nq + c) * JL::JREC);
+        float r[JL::JREC];
+#pragma unroll
+        for (int k = 0; k < JL::JREC / 4; k++) { const float4 q = rt[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
+        float v = P.rho_q[(size_t)b * nq + c];
+        if (r[1] > 0.f) {
+            float bd = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6 * NS; j++) bd += r[2 + j] * (float)P.delta[b * 6 * JMAXS + j];
+            v = depth_step(v, -(r[0] + bd) / r[1], P.rho_lo, P.rho_hi);
+        }
+        rq[tid] = v;
+        if (cyr == cy && cxr == cx && ly >= 1 && ly <= QSU_TH / 4 && lx >= 1 && lx <= QSU_TW / 4) P.rho_q_next[(size_t)b * nq + c] = v;      // an own cell, inside the map
+    }
+    __syncthreads();
+    const int oy = tid / QSU_TW, ox = tid - oy * QSU_TW;
+    const int u = txi * QSU_TW + ox, v = tyi * QSU_TH + oy;
+    if (u >= P.W || v >= P.H) return;
+    float sy = ((float)v + 0.5f) * 0.25f - 0.5f, sx = ((float)u + 0.5f) * 0.25f - 0.5f;
+    sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, y1 = y0 + 1 < h ? y0 + 1 : h - 1, x0 = (int)sx, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+    const float ly_ = sy - (float)y0, lx_ = sx - (float)x0;
+    const int ry0 = (y0 - cy0 + 1) * QSU_CW, ry1 = (y1 - cy0 + 1) * QSU_CW, rx0 = x0 - cx0 + 1, rx1 = x1 - cx0 + 1;
+    const float rho = (1.f - ly_) * ((1.f - lx_) * rq[ry0 + rx0] + lx_ * rq[ry0 + rx1]) + ly_ * ((1.f - lx_) * rq[ry1 + rx0] + lx_ * rq[ry1 + rx1]);
+    const float dep = 1.f / rho;
+    const int idx = v * P.W + u;
+    for (int s = 0; s < P.S; s++) {
+        P.depth[(size_t)(s * P.B + b) * hw + idx] = dep;
+        if (P.c_ncall > 0) P.c_depth_out[b / P.c_B][(size_t)(s * P.c_B + b % P.c_B) * hw + idx] = dep;
+        else if (P.depth_out) P.depth_out[(size_t)(s * P.B + b) * hw + idx] = dep;
+        P.srcpack_inv[((size_t)(s * P.B + b) * (P.H + 2) + v + 1) * (P.W + 2) + u + 1].w = dep;
+    }
 }
 
 }  // namespace tc

@@ -41,8 +41,11 @@ struct JointParams {
     int B, S, argmin;        // every pixel is weighted by the depth-consistency map of the source it counts for (see tcsfm.h)
     int automask;            // own masks (no argmin): optimizer.py:71-73 has no auto-mask there -> 0 from the host when S > 1
     // REF (k_dense_joint<.., REF = true>): the forward group under the reference's COMPLETE loss (optimizer.py:47-90, dense_ref_kernel.h):
-    const int *norms;        // [2] batch-summed mask counts K_f (forward selection) and K_i (inverse pairs) of THIS linearisation (k_dref_count)
-    const long long *ext;    // [B][H*W] fixed-point (2^-40) adjoint sums of the inverse pairs' samples of the target depth (k_dref_scatter)
+    const int *norms;        // [groups][2] batch-summed mask counts K_f (forward selection) and K_i (inverse pairs) of THIS linearisation
+                             // (k_linearize<FRONT> / k_dref_count); group of target b = b / norm_B (coalesced calls: one group per call; 0: one group)
+    int norm_B;
+    long long *ext2;         // [B][H*W][2] fixed-point (2^-40) adjoint sums of the inverse pairs' samples of the target depth: the depth-consistency
+                             // part sum h(dd) ddd w and the photometric part sum M diff ddd w (k_linearize<FRONT> / k_dref_scatter); consumed AND zeroed here
     float c_f;               // factor on the forward term: 1 with the min over the sources, 0.25 without (:73)
     float b_dc;              // per-pixel weight of the depth-consistency terms: w_dc / (S B H W) (:83-86)
     float w_init_px;         // per-pixel weight of the SSIM prior between current and initial sigmoid disparity: w_init / (B H W) (:89-90)
@@ -56,10 +59,9 @@ struct JointParams {
     float w_smooth_x, w_smooth_y;      // weight / (B H (W-1)), weight / (B (H-1) W); 0: off
     // the kernel run on the INVERSE pairs as S = 1 groups (their back-projected depth = the source map: tcsfm_linearize_dense_window_sources):
     // the scattered sums then come from the FORWARD pairs' samples of that map, in units of ext_c / ext_norm[0] = the forward factor a_f
-    const int *ext_norm;     // null: the unit of dref_unit (0.25 / norms[1])
+    const int *ext_norm;     // null: the photometric part of ext2 carries the inverse term's factor 0.25 / K_i; else ext_c / ext_norm[0]
     float ext_c;
 };
-constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums (integer atomics: order-independent)
 
 // reduce N (<= 32) per-thread values over the workgroup and ADD them to LDS accumulators acc[slot(k)], k = 0..N-1
 template <int N, int NT, class SlotFn>
@@ -92,13 +94,15 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     __shared__ float w0[REF ? N2 : 1];             // REF: depth-consistency weight of SOURCE 0 on tile + 2-pixel halo (optimizer.py:69)
     __shared__ float sgq[REF ? 2 * N2 : 1];        // REF: (sigma, sigma0) on tile + 2-pixel halo: the l_depth_init prior (optimizer.py:89-90)
     // REF: everything is accumulated in units of the forward term's factor a_f = c_f / K_f (k_solve_joint multiplies by it)
-    float r_dc = 0.f, r_init = 0.f, r_ext = 0.f;
+    float r_dc = 0.f, r_init = 0.f, r_eph = 0.f, iaf_ = 0.f;
     if (REF) {
-        const float Kf = (float)J.norms[0], Ki = (float)J.norms[1];
+        const int *nr = J.norms + 2 * (J.norm_B > 0 ? (int)blockIdx.y / J.norm_B : 0);      // the normaliser group of this target
+        const float Kf = (float)nr[0], Ki = (float)nr[1];
         const float iaf = Kf > 0.f ? Kf / J.c_f : 0.f;                 // 1 / a_f
+        iaf_ = iaf;
         r_dc = J.b_dc * iaf; r_init = J.w_init_px * iaf;
-        r_ext = (Ki > 0.f ? 0.25f / Ki : J.b_dc) * iaf;                // the scattered sums' unit u (dense_ref_kernel.h dref_unit) over a_f
-        if (J.ext_norm) { const float Ke = (float)J.ext_norm[0]; r_ext = (Ke > 0.f ? J.ext_c / Ke : J.b_dc) * iaf; }
+        r_eph = (Ki > 0.f ? 0.25f / Ki : 0.f) * iaf;                   // factor of the scattered photometric sums (the inverse term's a_i) over a_f
+        if (J.ext_norm) { const float Ke = (float)J.ext_norm[2 * (J.norm_B > 0 ? (int)blockIdx.y / J.norm_B : 0)]; r_eph = (Ke > 0.f ? J.ext_c / Ke : 0.f) * iaf; }
     }
     const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
     const bool ref_prior = REF && J.w_init_px > 0.f;
@@ -284,7 +288,9 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
             }
             float diff = e1 + e2;
             float m = (real && ax.y > 0.5f && (!J.automask || diff < ax.z)) ? 1.f : 0.f;
-            if (P.ext_diff != nullptr)      // min over the sources: does forward pair n keep this pixel?
+            if (P.sel_in != nullptr)        // min over the sources, decided by k_linearize<FRONT> at this linearisation: does forward pair n keep this pixel?
+                m = (real && P.sel_in[(size_t)n * hw + gy_ * W + gx_] > 0.5f) ? 1.f : 0.f;
+            else if (P.ext_diff != nullptr) // ... or from the residual maps of a MODE_MAPS pass
                 m = (real && ext_selected(P, n, gy_ * W + gx_, hw)) ? 1.f : 0.f;
             float w = m * ax.x;    // M_s W_x
             float pA = 0.f, pB = 0.f, pC = 0.f;
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
                 if (!o_pcl) Dsum += r_init * J.sig_ir * J.sig_ir * (frcp(o_pd2) + (1.f / 9.f) * frcp(o_pd1));
             }
             if (REF && ref_smooth && s == 0) {     // l_smooth: local part minus the per-image constant T_b / (m HW), in units of a_f
-                const float iaf_s = (float)J.norms[0] > 0.f ? (float)J.norms[0] / J.c_f : 0.f;
+                const float iaf_s = iaf_;
                 const float m_ = J.smooth[2 * b], Gb = J.smooth[2 * b + 1] * frcp(m_ * (float)hw);
                 g_rho += iaf_s * J.sig_ir * (o_sm_g - Gb);
                 Dsum += iaf_s * J.sig_ir * J.sig_ir * o_sm_D;
@@ -492,11 +498,12 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         for (int j = 0; j < 6; j++) Bv[s][j] = 0.f;
     float prior_cost = 0.f;
     if (inimg) {
-        if (REF) {      // the inverse pairs see this depth through their bilinear samples of it: adjoint sums of k_dref_scatter (fixed point)
-            long long *ep = const_cast<long long *>(J.ext) + (size_t)b * hw + gyo * W + gxo;
-            const float E = (float)((double)*ep * (1.0 / DREF_FIX));     // in units of u (dref_unit)
-            *ep = 0;                                                     // consumed: the next linearisation's scatter starts from zero (no memset launch)
-            g_rho -= o_depth * o_depth * r_ext * E;                        // d depth / d rho = -depth^2
+        if (REF) {      // the inverse pairs see this depth through their bilinear samples of it: the adjoint sums (fixed point), d L / d pd = b_dc S_dc - a_i S_ph
+            longlong2 *ep = reinterpret_cast<longlong2 *>(J.ext2 + ((size_t)b * hw + gyo * W + gxo) * 2);
+            const longlong2 e2 = *ep;
+            *ep = make_longlong2(0, 0);                                  // consumed: the next linearisation's scatter starts from zero (no memset launch)
+            const float Edc = (float)((double)e2.x * (1.0 / DREF_FIX)), Eph = (float)((double)e2.y * (1.0 / DREF_FIX));
+            g_rho -= o_depth * o_depth * (r_dc * Edc - r_eph * Eph);     // d depth / d rho = -depth^2; in units of a_f
             prior_cost = extra_cost;
         }
         float D = Dsum;
@@ -581,14 +588,18 @@ struct JointSolveParams {
     double *delta_out;        // [B][6 JMAXS] pose step of this iteration (back-substitution)
     int *accept_out;          // [B] LM decision (or null)
     int *trace_decide;        // [N] slot of every forward pair of the target, or null
-    const int *norms;         // REF (or null): [2] batch-summed mask counts; the records are in units of c_f / norms[0]
+    const int *norms;         // REF (or null): [groups][2] batch-summed mask counts; the records are in units of c_f / K_f of the target's group
+    int norm_B;               //   targets per group (coalesced calls; 0: one group)
     double c_f;
     double *export_out;       // linearisation export (tcsfm_linearize_dense_window): [B][2 + 6 JMAXS] = cost, factor a_f, g (per source 6), or null
+    // coalesced calls (CoalTab): the refined pose of forward pair n = s B + b goes to ITS call's output, at the pair's index in that call
+    int c_ncall, c_B, c_S, c_pad;
+    float *c_pose_out[TC_MAX_COAL];
 };
 
 constexpr int JSOLVE_NT = 1024;
 template <int NS>
-__global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
+__device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, const int b, const int tid) {
     using JL = JointLayout<NS>;
     constexpr int NP = JL::NP, NC = NP + 1;
     constexpr int APAD = JL::NACC <= 128 ? 128 : 256, PARTS = JSOLVE_NT / APAD;
@@ -599,7 +610,6 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
     __shared__ double dl[NP];
     __shared__ double Ts[NS][40];
     __shared__ int s_flag[2];
-    const int b = blockIdx.x, tid = threadIdx.x;
     const int NTS = JSOLVE_NT;
     // the optimiser state is fetched NOW, beside the records: the serial phases below never wait on a global load (as in k_solve)
     __shared__ double Ks[NS][12];
@@ -638,7 +648,7 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
     }
     __syncthreads();
     double Kn = tot[JL::OFF_S + 1], an = Kn > 0 ? 1.0 / Kn : 0.0;
-    if (P.norms) { Kn = (double)P.norms[0]; an = Kn > 0 ? P.c_f / Kn : 0.0; }      // the reference's batch normaliser (optimizer.py:69)
+    if (P.norms) { Kn = (double)P.norms[2 * (P.norm_B > 0 ? b / P.norm_B : 0)]; an = Kn > 0 ? P.c_f / Kn : 0.0; }      // the reference's batch normaliser (optimizer.py:69)
     const double cost = an * tot[JL::OFF_S];
     if (P.export_out) {       // one linearisation, exported (no step): cost, a_f and the pose gradients of the group's records
         if (tid == 0) { P.export_out[(size_t)b * (2 + 6 * JMAXS)] = cost; P.export_out[(size_t)b * (2 + 6 * JMAXS) + 1] = an; }
@@ -757,13 +767,28 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
         if (on && sub == 0 && last_gn && P.pose_out) {
             float pose[6];
             T_to_pose_f32(T + 24, pose);
-            for (int i = 0; i < 6; i++) P.pose_out[n * 6 + i] = pose[i];
+            float *po = P.pose_out + n * 6;
+            if (P.c_ncall > 0) { const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n); po = P.c_pose_out[ci.call] + ci.li * 6; }
+            for (int i = 0; i < 6; i++) po[i] = pose[i];
             if (P.stats) {
                 float *st = P.stats + ((size_t)n * (P.n_iters + 1) + P.n_iters) * TCSFM_NSTAT + TCSFM_STAT_POSE;
                 for (int i = 0; i < 6; i++) st[i] = pose[i];
             }
         }
     }
+}
+
+template <int NS>
+__global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) { solve_joint_body<NS>(P, blockIdx.x, threadIdx.x); }
+
+// Dense mode on the reference's loss (round 5): the target groups' reduced systems AND the inverse pairs' 6 x 6 systems of one iteration
+// in ONE launch -- they are independent (different workgroups, different state), so a second dependent launch bought nothing but its
+// ~6 us.  Workgroups [0, B): solve_joint_body; [B, B + n_inv): solve_body of inverse pair blockIdx.x - B (its record sums spread over
+// the 1024 threads).
+template <int NS>
+__global__ __launch_bounds__(JSOLVE_NT) void k_solve_front(JointSolveParams Pj, SolveParams Pi) {
+    if ((int)blockIdx.x < Pj.B) solve_joint_body<NS>(Pj, blockIdx.x, threadIdx.x);
+    else solve_body<6, JSOLVE_NT, true>(Pi, (int)blockIdx.x - Pj.B, threadIdx.x);
 }
 
 // back-substitution of the shared map; LM: promote / roll back first (as k_dense_update_lm)
@@ -777,16 +802,20 @@ struct JointUpdateParams {
     float *depth_out;         // optional: [.][H*W] same layout (the caller's buffer), or null
     int hw, B, S, mode;       // mode 0: step; 1: final LM decision (keep the trial or fall back to the accepted map), no step
     float rho_lo, rho_hi;
-    int *norms_zero;          // REF (or null): the two batch counters, consumed by k_solve_joint before this launch: zeroed for the next linearisation
+    int *norms_zero;          // REF (or null): the batch counters, consumed by the solve kernels before this launch: zeroed for the next linearisation
+    int norms_n;              //   how many of them (2 per normaliser group)
     float4 *srcpack_inv;      // REF (or null): packs of the inverse pairs (pair S B + s B + b samples target b's depth: channel w), refreshed
     int W, H;                 //   with the new map so that the inverse pairs of the next linearisation see the depth the forward pairs see
+    // coalesced calls: depth_out per call (forward slot (s, b) of the batch = slot s c_B + b % c_B of call b / c_B); used when c_ncall > 0
+    int c_ncall, c_B;
+    float *c_depth_out[TC_MAX_COAL];
 };
 
 template <int NS>
 __global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P) {
     using JL = JointLayout<NS>;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (P.norms_zero && idx == 0 && b == 0) { P.norms_zero[0] = 0; P.norms_zero[1] = 0; }
+    if (P.norms_zero && idx < P.norms_n && b == 0) P.norms_zero[idx] = 0;
     if (idx >= P.hw) return;
     const size_t o = (size_t)b * P.hw + idx;
     float dep;
@@ -823,7 +852,8 @@ __global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P)
     }
     for (int s = 0; s < P.S; s++) {
         P.depth[(size_t)(s * P.B + b) * P.hw + idx] = dep;
-        if (P.depth_out) P.depth_out[(size_t)(s * P.B + b) * P.hw + idx] = dep;
+        if (P.c_ncall > 0) P.c_depth_out[b / P.c_B][(size_t)(s * P.c_B + b % P.c_B) * P.hw + idx] = dep;
+        else if (P.depth_out) P.depth_out[(size_t)(s * P.B + b) * P.hw + idx] = dep;
     }
     if (P.srcpack_inv) {
         const int v = idx / P.W, u = idx - v * P.W;

@@ -87,7 +87,22 @@ struct LinParams {
     unsigned long long *stamp;  // tcsfm_profile_*: [workgroups of this launch][2] = start / end of every workgroup in
                                 // s_memrealtime ticks (100 MHz), or null.  Duration of the launch as the GPU sees it = latest end -
                                 // earliest start (taken on the host), free of the ~2-4 us a HIP event pair adds around a 10 us kernel.
+    // FRONT (k_linearize<.., FRONT = true>; dense mode on the reference's loss, dense_ref_kernel.h, round 5): ONE launch over all 2 S B
+    // directed pairs of a call opens every linearisation.  Pairs n < front_fwd are the FORWARD pairs: their mask only -- own mask, or the
+    // min-over-sources selection under SEL -> sel_out (what k_dense_joint reads instead of recomputing the selection from residual maps)
+    // and its count -> norms[2 g]; pairs n >= front_fwd are the INVERSE pairs: the complete 6 x 6 linearisation, their mask count ->
+    // norms[2 g + 1], and the adjoint of their bilinear samples of the target depth -> ext2 (two fixed-point sums per target pixel, so
+    // that the scatter needs no batch normaliser and rides in this launch).  g = normaliser group of the pair's target (coalesced calls:
+    // one group per call, norm_B targets each; 0: one group).
+    int front_fwd, front_Bt;    // S B; targets of the launch: the target of pair n is (n % front_fwd) % front_Bt
+    int norm_B;
+    float *sel_out;             // [front_fwd][H*W] 1 / 0 (or null: nobody reads the selection)
+    const float *sel_in;        // k_dense_joint: that map (or null: own masks / ext_selected)
+    int *norms;                 // [groups][2] K_f, K_i: zero when the launch starts
+    long long *ext2;            // [front_Bt][H*W][2]: sum of h(dd) ddd w_tap and of M diff ddd w_tap over the inverse pixels that sample the
+                                // target pixel, 2^-40 fixed point (integer atomics: order-independent, bit-reproducible); zero when the launch starts
 };
+constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums
 
 __device__ __forceinline__ unsigned sign_code(float x) { return x > 0.f ? 1u : (x < 0.f ? 2u : 0u); }
 
@@ -392,6 +407,11 @@ struct PackParams {
     float4 *tgtpack, *srcpack;
     float *depth_out;                            // [N,H,W] depth_t (converted if depth_is_disp)
     float *depth_out2;                           // optional second copy of the same (dense mode: the prior centre depth0), or null
+    float *depth_out3;                           // optional third copy (dense mode on the reference's loss: the CALLER's depth output, whose inverse
+                                                 // slots -- the source maps, not unknowns there -- are final at once), or null
+    int *zero_ints; int zero_n;                  // optional: words zeroed by this launch (the batch counters of that mode), or null
+    float *c_depth_out3[TC_MAX_COAL];            // coalesced calls: depth_out3 per call (pair li of call c at c_depth_out3[c] + li H W); used when c_out3 != 0
+    int c_out3;
     int H, W, N;
     float wl, ws;                                // w_l1/3, w_ssim/3
     int depth_is_disp;
@@ -527,6 +547,7 @@ __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct
         const int ni = threadIdx.x == 0 ? n : n_inv;
         if ((threadIdx.x == 0 || both) && ni < P.init.N) init_pair(P.init, ni, ct);
     }
+    if (P.zero_ints != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x >= 64 && (int)threadIdx.x - 64 < P.zero_n) P.zero_ints[threadIdx.x - 64] = 0;
     pack_stage_tile(tile, t, s, P.H, P.W, x0, y0);
     __syncthreads();
     const int u = x0 + tx, v = y0 + ty, idx = v * P.W + u;
@@ -543,11 +564,18 @@ __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct
     pack_write_src(P, n, u, v, make_float4(s0, s1, s2, ds));
     P.depth_out[(size_t)n * hw + idx] = dt;
     if (P.depth_out2) P.depth_out2[(size_t)n * hw + idx] = dt;
+    float *o3 = P.depth_out3 ? P.depth_out3 + (size_t)n * hw : nullptr, *o3i = P.depth_out3 ? P.depth_out3 + (size_t)n_inv * hw : nullptr;
+    if (ct != nullptr && P.c_out3) {
+        const CoalIdx ci = coal_index(ct->ncall, ct->cB, ct->cS, n);
+        o3 = P.c_depth_out3[ci.call] + (size_t)ci.li * hw; o3i = P.c_depth_out3[ci.call] + (size_t)(ct->cS * ct->cB + ci.li) * hw;
+    }
+    if (o3) o3[idx] = dt;
     if (both) {             // the inverse pair: target and source swapped, the same error
         P.tgtpack[(size_t)n_inv * hw + idx] = make_float4(s0, s1, s2, ae);
         pack_write_src(P, n_inv, u, v, make_float4(t0, t1, t2, dt));
         P.depth_out[(size_t)n_inv * hw + idx] = ds;
         if (P.depth_out2) P.depth_out2[(size_t)n_inv * hw + idx] = ds;
+        if (o3i) o3i[idx] = ds;
     }
 }
 __global__ __launch_bounds__(256) void k_pack(PackParams P) { pack_body(P, nullptr); }
@@ -1063,17 +1091,20 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
 #ifndef TC_PASSB_J2
 #define TC_PASSB_J2 0
 #endif
-template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false>
+template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false, bool FRONT = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
     constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
     static_assert(NCEN % NT == 0, "tile must be a multiple of the workgroup");
+    static_assert(!FRONT || (MODE == MODE_LIN && !ADJ && NP == 6), "FRONT: the 6-DoF linearisation in its production form");
     using L = AccLayout<NP>;
     __shared__ float4 lds[NCOMP * (LDS_REC / 4)];
     __shared__ float red[(NT / 64) * L::NACC];
     __shared__ unsigned adj_any;                              // ADJ: bit w = wave w has a pixel that counts
+    __shared__ int front_cnt, front_org[2];                   // FRONT: the tile's mask count; origin of the scatter window
     constexpr bool ADJL = ADJ && MODE == MODE_LIN;
     if (ADJL && threadIdx.x == 0) adj_any = 0u;              // (ordered before its first use by the phase-1 barrier)
+    if (FRONT && threadIdx.x == 0) front_cnt = 0;
 
     // XCD-aware tile order: consecutive workgroups land on different XCDs (round-robin dispatch), so give each
     // of the 8 XCDs a contiguous band of tiles -> halo / source-texel reuse stays inside one XCD's L2.
@@ -1083,12 +1114,18 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int n = blockIdx.y;
+    // FRONT: rows [0, S B) are the INVERSE pairs (the heavier role is dispatched first), the rows behind them the forward pairs -- all S B of
+    // them, or under SEL one row per TARGET (pair (0, b)), which decides the selection for all S sources of its target
+    const int n = FRONT ? ((int)blockIdx.y < P.front_fwd ? P.front_fwd + (int)blockIdx.y : (int)blockIdx.y - P.front_fwd) : (int)blockIdx.y;
     const PairConst &c = P.pc[n];
     const int H = P.H, W = P.W, hw = H * W;
     const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
     const int x00 = txi * TW, y00 = tyi * TH;
     const int img = P.shared_image ? 0 : n;
+    const bool ffwd = FRONT && n < P.front_fwd;                              // FRONT: a forward pair -- mask and count only (workgroup-uniform)
+    bool front_m = false;                                                    // FRONT: this thread's pixel counts
+    int f_tap = 0;                                                           // FRONT, inverse pairs: top-left tap (x + 1) | (y + 1) << 16 of the own pixel's
+    float f_wx = 0.f, f_wy = 0.f, f_dc = 0.f, f_ph = 0.f;                    // sample, its bilinear weights; scatter coefficients h(dd) ddd and M diff ddd
     const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
     const bool cached = P.pair_src != nullptr;                               // wave-uniform
     const float4 *srcpack = P.srcpack + (size_t)(cached ? P.pair_src[n] : img) * (H + 2) * (W + 2);   // zero-bordered (tap4)
@@ -1106,6 +1143,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     // error among the sources before / after s (torch.min keeps the FIRST minimum), the union of their validity and the
     // smallest auto-mask threshold.  Same arithmetic as the maps pass + selection it replaces (the dense modes keep the maps pass: ext_selected).
     float sel_before = 3.0e38f, sel_after = 3.0e38f, sel_valid = 0.f, sel_ae = 3.0e38f;
+    float sel_d1 = 3.0e38f, sel_d2 = 3.0e38f;      // FRONT: the errors of sources 1 and 2 on their own (the row of pair (0, b) decides for every source)
     float sel_w0 = 1.f;      // REFERENCE rule: depth-consistency weight of SOURCE 0 at this pixel (pairs of the other sources)
     const bool sel_pair = SEL && n < P.sel_B * P.sel_S;
     const int s_own = (SEL && sel_pair) ? n / P.sel_B : 0;
@@ -1180,6 +1218,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 const f2 e01 = ssim_l1_value<f2>(xc01, yc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl);
                 const float d_o = e01.x + e01.y + ssim_l1_value<float>(yx2c.y, yx2c.x, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl);
                 if (so < s_own) sel_before = fminf(sel_before, d_o); else sel_after = fminf(sel_after, d_o);
+                if (FRONT) { if (so == 1) sel_d1 = d_o; else sel_d2 = d_o; }
                 sel_valid = fmaxf(sel_valid, q2.z);
                 sel_ae = fminf(sel_ae, q2.w);
                 if (P.rule && so == 0) sel_w0 = lds_read1(ctr + 1).x;
@@ -1211,7 +1250,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float4 val, gx, gy;
         tap4_lerp(S.t, val, gx, gy);
         float a[NP], b[NP], zc[NP];
-        if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
+        if (FRONT && ffwd) {
+#pragma unroll
+            for (int j = 0; j < NP; j++) { a[j] = 0.f; b[j] = 0.f; zc[j] = 0.f; }
+        } else if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
         float4 *rec = lds + (S.ly * CW + S.lx) * (LDS_REC / 4);
         // record: [y0 y1 x0 x1][gx0 gy0 gx1 gy1][y2 x2 gx2 gy2][a0 b1 a2 a3][a4 a5 b2 b3][b4 b5 (a6 b6)] : channel pairs and
         // Jacobian pairs sit on aligned register pairs after ds_read_b128, so phase 2 runs on v_pk_*_f32 without shuffles.
@@ -1223,16 +1265,22 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (MODE == MODE_LIN) {
                 lds_write1(rec + 1, gx.x, gy.x, gx.y, gy.y);     // (gx, gy) pairs per channel: pass B forms (sx, sy) with packed FMAs
                 lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
-                lds_write1(rec + 3, a[0], b[1], a[2], a[3]);
-                lds_write1(rec + 4, a[4], a[5], b[2], b[3]);
-                lds_write1(rec + 5, b[4], b[5], NP == 7 ? a[NP - 1] : 0.f, NP == 7 ? b[NP - 1] : 0.f);
+                if (!(FRONT && ffwd)) {
+                    lds_write1(rec + 3, a[0], b[1], a[2], a[3]);
+                    lds_write1(rec + 4, a[4], a[5], b[2], b[3]);
+                    lds_write1(rec + 5, b[4], b[5], NP == 7 ? a[NP - 1] : 0.f, NP == 7 ? b[NP - 1] : 0.f);
+                }
             } else {
                 lds_write1(rec + 2, val.z, S.tp.z, 0.f, 0.f);
             }
         }
         if (centre) {
             c_in[0] = (x00 + S.lx - 1 < W) && (y00 + S.ly - 1 < H);
-            if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && c_in[0])    // bilinear cell parity now, mask / validity bits in phase 2
+            if (FRONT) {
+                f_tap = ((S.px + (int)floorf(S.g.rx) + 1) & 0xffff) | ((S.py + (int)floorf(S.g.ry) + 1) << 16);
+                f_wx = S.t.wx; f_wy = S.t.wy;
+            }
+            if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && c_in[0] && !ffwd)    // bilinear cell parity now, mask / validity bits in phase 2
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
@@ -1385,6 +1433,21 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             const float dmin = fminf(diff, sel_dothers);
             sel_keep = (c_valid[k] || sel_valid > 0.f) && (!P.automask || dmin < fminf(c_ae[k], sel_ae));
             m = inimg && sel_keep && (diff < sel_before) && (diff <= sel_after);
+        }
+
+        if (FRONT) front_m = m;
+        if (FRONT && ffwd) {       // a forward pair: k_dense_joint linearises it; here only its mask (the selection) and the count below
+            if (SEL) {             // the row of pair (0, b): the decision for EVERY source of target b (first minimum, as torch.min / ext_selected)
+                front_m = inimg && sel_keep;                  // exactly one source keeps the pixel
+                if (inimg) {
+                    const size_t o = (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
+                    const bool m1 = sel_keep && sel_d1 < diff && sel_d1 <= sel_d2, m2 = sel_keep && sel_d2 < diff && sel_d2 < sel_d1;
+                    P.sel_out[(size_t)n * hw + o] = m ? 1.f : 0.f;
+                    P.sel_out[(size_t)(P.sel_B + n) * hw + o] = m1 ? 1.f : 0.f;
+                    if (P.sel_S > 2) P.sel_out[(size_t)(2 * P.sel_B + n) * hw + o] = m2 ? 1.f : 0.f;
+                }
+            }
+            continue;
         }
 
         // depth consistency, train_mono.py:91-92
@@ -1633,6 +1696,11 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             float sg = (raw >= 0.f && raw <= 1.f) ? (dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f)) : 0.f;
             float kdd = sg * 2.f * isum * isum;
             float mf = m ? 1.f : 0.f;
+            if (FRONT) {      // d L / d pd of this inverse pixel, split by what multiplies it: b_dc h(dd) ddd  and  -a_i M diff ddd  (dense_ref_kernel.h)
+                const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)
+                f_dc = (inimg && c_valid[k]) ? fminf(1.f, dd * frcp(P.eps)) * ddd : 0.f;
+                f_ph = m ? diff * ddd : 0.f;
+            }
             const float wxx = mf * Wp * lxx, wxy = mf * Wp * lxy, wyy = mf * Wp * lyy;
             const float dsub = (SEL && wext) ? 0.f : diff;
             // Columns (0,1) of the Jacobian are (a0, 0) and (0, b1) (structural zeros, see the record layout): their products are formed from the
@@ -1726,6 +1794,19 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
     }
     if (MODE == MODE_MAPS) { stamp_end(P.stamp, tid); return; }
+    if (FRONT) {      // the tile's mask count -> the batch normaliser of the pair's group (one integer atomic per workgroup)
+        const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(front_m));
+        if ((tid & 63) == 0 && cnt != 0) atomicAdd(&front_cnt, cnt);
+        if (ffwd) {
+            __syncthreads();
+            if (tid == 0 && front_cnt != 0) {
+                const int b_ = (n % P.front_fwd) % P.front_Bt;
+                atomicAdd(P.norms + 2 * (P.norm_B > 0 ? b_ / P.norm_B : 0), front_cnt);
+            }
+            stamp_end(P.stamp, tid);
+            return;
+        }
+    }
 
     // unpack the row-pair accumulators into the triangular layout the reduction / solve kernel use
     float aHP[L::NH], aGP[NP], aHD[DC ? L::NH : 1], aGD[DC ? NP : 1];
@@ -1774,6 +1855,53 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         v[NLIVE - 3] = sMWd; v[NLIVE - 2] = sM; v[NLIVE - 1] = sdd;
         block_reduce_publish<NP, NLIVE, (MODE == MODE_LIN), DC, NT>(P, v, red, n, bid, nblk, tid);
     }
+    if (FRONT) {
+        // ---------------- FRONT, inverse pair: count, and the ADJOINT of this tile's bilinear samples of the target depth ----------------
+        // (every wave is past the barrier inside the reduction: phase 2 is over, the staged records are dead and front_cnt is complete.)
+        // The taps of the tile land in a window of the TARGET image displaced by the tile's flow: they are summed in LDS first -- 64-bit
+        // fixed-point adds on a (TW + 2 M) x (TH + 2 M) window placed by the tap of the tile's centre pixel, two sums per entry -- then every
+        // non-zero entry goes out with one global atomic per sum; a tap outside the window goes to global memory directly.
+        constexpr int FM = 6, WW = TW + 2 * FM, WH = TH + 2 * FM, NWIN = WW * WH;
+        static_assert(2 * NWIN * sizeof(unsigned long long) <= sizeof(lds), "the scatter window aliases the staged records");
+        unsigned long long *win = reinterpret_cast<unsigned long long *>(lds);
+        const int b_ = (n % P.front_fwd) % P.front_Bt;
+        if (tid == 0 && front_cnt != 0) atomicAdd(P.norms + 2 * (P.norm_B > 0 ? b_ / P.norm_B : 0) + 1, front_cnt);
+        for (int i = tid; i < 2 * NWIN; i += NT) win[i] = 0ull;
+        const int tx0 = (f_tap & 0xffff) - 1, ty0 = (f_tap >> 16) - 1;
+        if (tid == (TH / 2) * TW + TW / 2) { front_org[0] = tx0 - TW / 2 - FM; front_org[1] = ty0 - TH / 2 - FM; }
+        __syncthreads();
+        const int ox = front_org[0], oy = front_org[1];
+        long long *ext = P.ext2 + (size_t)b_ * hw * 2;
+        if (f_dc != 0.f || f_ph != 0.f) {
+            const float w4[4] = {(1.f - f_wx) * (1.f - f_wy), f_wx * (1.f - f_wy), (1.f - f_wx) * f_wy, f_wx * f_wy};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xx = tx0 + (k & 1), yy = ty0 + (k >> 1);
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {         // (a tap in the zero border is no pixel of the target)
+                    const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
+                    const int wxl = xx - ox, wyl = yy - oy;
+                    if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) {
+                        if (a0 != 0) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a0);
+                        if (a1 != 0) atomicAdd(&win[NWIN + wyl * WW + wxl], (unsigned long long)a1);
+                    } else {
+                        unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+                        if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
+                        if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < NWIN; i += NT) {
+            const unsigned long long a0 = win[i], a1 = win[NWIN + i];
+            const int yy = oy + i / WW, xx = ox + i % WW;
+            if ((a0 | a1) != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+                if (a0 != 0ull) atomicAdd(e, a0);
+                if (a1 != 0ull) atomicAdd(e + 1, a1);
+            }
+        }
+    }
     stamp_end(P.stamp, tid);
 }
 
@@ -1810,6 +1938,11 @@ struct SolveParams {
     int c_ncall, c_B, c_S, c_pad;
     float *c_pose_out[TC_MAX_COAL];
     float *c_ls_out[TC_MAX_COAL];       // (np == 7) per call, or null
+    // rule with the batch counts already summed (k_linearize<FRONT>, dense mode on the reference's loss): norms [groups][2] = K_f, K_i; the
+    // group of pair n is ((n % norm_Bt) / norm_B) (norm_B = 0: one group) -- replaces the sum over the group's records
+    const int *norms;
+    int norm_Bt, norm_B;
+    int c_n0;                           // coalesced calls: batch index of this launch's pair 0 (k_solve_front solves the inverse pairs as 0 .. S Bt - 1)
 };
 
 // fp32 extraction of the reference 6-vector from the fp64 transform (inverse of pose_to_T); angles are small, fp32
@@ -1829,12 +1962,15 @@ __device__ inline void T_to_pose_f32(const double *T, float *pose) {
 //      Marquardt damping and an unpivoted Gauss-Jordan elimination (SPD system) with 3 cross-lane reads per pivot
 //   3. lane 0: SE(3) retraction (series exp, no trig), next iteration's fp32 constants, pose output
 // The per-pair logic mirrors orc_refine() of the CPU oracle (which factorises with Cholesky instead).
-template <int NP>
-__global__ __launch_bounds__(256) void k_solve(SolveParams P) {
+// NT: threads that enter (256: k_solve; 1024: the pair role of k_solve_front, whose record sums are spread over four times the threads).
+// LEAN: the SE(3) chart without the pose-consistency term (what the dense mode on the reference's loss asks of it): the rare branches that
+// set the register budget of the general kernel are compiled out (k_solve_front runs 1024-thread workgroups: 128 VGPRs).
+template <int NP, int NT, bool LEAN = false>
+__device__ __forceinline__ void solve_body(const SolveParams &P, const int n, const int tid) {
     using L = AccLayout<NP>;
     constexpr int NPH = L::NH + NP;
     __shared__ double tot[L::NACC];
-    __shared__ double part[256];
+    __shared__ double part[NT];
     __shared__ double ws[3 * NP * NP];
     __shared__ double dl[8];
     __shared__ double eul[NP * NP + NP];
@@ -1842,24 +1978,23 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     constexpr int NST = (int)(sizeof(PairState) / sizeof(double));
     static_assert(sizeof(PairState) % sizeof(double) == 0 && NST <= 256, "PairState must be a whole number of doubles");
     __shared__ double sst[NST];
-    const int n = blockIdx.x, tid = threadIdx.x;
 #define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
     TC_STAMP(0)
     // the pair's optimiser state is fetched NOW, together with the partial records, so that the serial phases below never
     // wait on a global load (each first touch used to cost a miss in the middle of the dependent chain)
     if (tid < NST) sst[tid] = reinterpret_cast<const double *>(&P.st[n])[tid];
     __shared__ double pcT[12], pcA[36], pcD[6], pcG[6];
-    const bool pc_on = NP == 6 && P.rule && P.w_pc > 0.0 && P.pose_lin != nullptr;
+    const bool pc_on = !LEAN && NP == 6 && P.rule && P.w_pc > 0.0 && P.pose_lin != nullptr;
     if (pc_on && tid >= 64 && tid < 76) {
         const int partner = n < P.grp_fwd ? n + P.grp_fwd : n - P.grp_fwd;
         pcT[tid - 64] = P.pose_lin[((size_t)(P.it & 1) * P.n_pairs + partner) * 12 + (tid - 64)];
     }
-    __shared__ double kpart[256];
-    if (P.rule) {   // batch-summed mask count of this pair's group: every record of every pair of the group, fixed order
+    __shared__ double kpart[NT];
+    if (P.rule && !P.norms) {   // batch-summed mask count of this pair's group: every record of every pair of the group, fixed order
         const int g0 = n < P.grp_fwd ? 0 : P.grp_fwd, g1 = n < P.grp_fwd ? P.grp_fwd : P.n_pairs, cnt = (g1 - g0) * P.ngrp;
         const float *p = P.partials + (size_t)g0 * P.ngrp * L::NACC + L::OFF_S + 1;
         double s = 0.0;
-        for (int i = tid; i < cnt; i += 256) s += (double)p[(size_t)i * L::NACC];
+        for (int i = tid; i < cnt; i += NT) s += (double)p[(size_t)i * L::NACC];
         kpart[tid] = s;
     }
     {
@@ -1868,19 +2003,20 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         // subset) so that ALL loads of a thread are in flight before its first add -- the records were written by other CUs,
         // every load is a miss (~0.4 us each if serialised; a predicated load compiles to branch + vmcnt(0) per element).
         const int nlive = P.has_dc ? L::NACC : NPH + 3;
-        const int apad = nlive <= 32 ? 32 : (nlive <= 64 ? 64 : 128), parts = 256 / apad;
+        const int apad = nlive <= 32 ? 32 : (nlive <= 64 ? 64 : 128), parts = NT / apad;
         const int c = tid & (apad - 1), q = tid / apad;
         const int acc = (P.has_dc || c < NPH) ? c : L::OFF_S + (c - NPH);   // compact live index -> accumulator
         if (tid < L::NACC) tot[tid] = 0.0;
         double s = 0.0;
         if (c < nlive) {
             const float *p = P.partials + (size_t)n * P.ngrp * L::NACC + acc;
-            for (int r0 = q; r0 < P.ngrp; r0 += 32 * parts) {
-                float v[32];
+            constexpr int NB = NT >= 1024 ? 16 : 32;       // loads in flight per thread and batch (1024 threads: 16 x 16 subsets cover 256 records)
+            for (int r0 = q; r0 < P.ngrp; r0 += NB * parts) {
+                float v[NB];
 #pragma unroll
-                for (int j = 0; j < 32; j++) { const int r = r0 + j * parts; v[j] = p[(size_t)(r < P.ngrp ? r : 0) * L::NACC]; }
+                for (int j = 0; j < NB; j++) { const int r = r0 + j * parts; v[j] = p[(size_t)(r < P.ngrp ? r : 0) * L::NACC]; }
 #pragma unroll
-                for (int j = 0; j < 32; j++) s += (r0 + j * parts < P.ngrp) ? (double)v[j] : 0.0;
+                for (int j = 0; j < NB; j++) s += (r0 + j * parts < P.ngrp) ? (double)v[j] : 0.0;
             }
         }
         part[tid] = s;
@@ -1902,7 +2038,8 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     double an = nmask > 0 ? rcp64(nmask) : 0.0;
     if (P.rule) {
         double kn = 0.0;
-        for (int i = 0; i < 256; i++) kn += kpart[i];   // (every lane the same fixed-order sum: LDS broadcast reads)
+        if (P.norms) kn = (double)P.norms[2 * (P.norm_B > 0 ? (n % P.norm_Bt) / P.norm_B : 0) + (n < P.grp_fwd ? 0 : 1)];
+        else for (int i = 0; i < NT; i++) kn += kpart[i];   // (every lane the same fixed-order sum: LDS broadcast reads)
         an = kn > 0 ? (n < P.grp_fwd ? P.scale_fwd : P.scale_inv) * rcp64(kn) : 0.0;
     }
     const double cost_photo = an * tot[L::OFF_S], cost_dc = P.b_dc * tot[L::OFF_S + 2];
@@ -2001,7 +2138,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
             lambda *= P.lambda_up;
             M = Lc.M8[tid];
         }
-        if (P.param != 0) {   // undamped system in dense NP x NP form for the additive-Euler branch below
+        if (!LEAN && P.param != 0) {   // undamped system in dense NP x NP form for the additive-Euler branch below
             if (r < NP && c < NP) eul[r * NP + c] = M;
             if (r < NP && c == 7) eul[NP * NP + r] = -M;
         }
@@ -2032,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
             S.lambda = lambda;
             if (P.delta_out)
                 for (int i = 0; i < NP; i++) P.delta_out[n * 8 + i] = dl[i];
-            if (P.param == 0) {
+            if (LEAN || P.param == 0) {
                 double d6[6];
 #pragma unroll
                 for (int i = 0; i < 6; i++) d6[i] = dl[i];
@@ -2048,7 +2185,7 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
-        if (P.param == 0 && tid < 12) {   // T_try = exp(delta) T_accepted, one entry per lane (se3_mul's operation order)
+        if ((LEAN || P.param == 0) && tid < 12) {   // T_try = exp(delta) T_accepted, one entry per lane (se3_mul's operation order)
             const int i = tid >> 2, j = tid & 3;
             double v = Ts[4 * i] * Ts[12 + j] + Ts[4 * i + 1] * Ts[16 + j] + Ts[4 * i + 2] * Ts[20 + j];
             if (j == 3) v += Ts[4 * i + 3];
@@ -2073,11 +2210,11 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
         float pose[6];
         T_to_pose_f32(Tfin, pose);
         float *po = P.pose_out + n * 6;
-        if (P.c_ncall > 0) { const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n); po = P.c_pose_out[ci.call] + ci.li * 6; }
+        if (P.c_ncall > 0) { const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n + P.c_n0); po = P.c_pose_out[ci.call] + ci.li * 6; }
 #pragma unroll
         for (int i = 0; i < 6; i++) po[i] = pose[i];
         if (P.c_ncall > 0) {
-            const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n);
+            const CoalIdx ci = coal_index(P.c_ncall, P.c_B, P.c_S, n + P.c_n0);
             if (NP == 7 && P.c_ls_out[ci.call]) P.c_ls_out[ci.call][ci.li] = (float)sfin;
         } else if (P.log_scale_out) P.log_scale_out[n] = (float)sfin;
         if (P.stats && P.mode == 0) {                  // GN: last row = final iterate (its cost is not evaluated)
@@ -2089,6 +2226,8 @@ __global__ __launch_bounds__(256) void k_solve(SolveParams P) {
     TC_STAMP(6)
 #undef TC_STAMP
 }
+template <int NP>
+__global__ __launch_bounds__(256) void k_solve(SolveParams P) { solve_body<NP, 256>(P, blockIdx.x, threadIdx.x); }
 
 // dense sequence calls: the refined depth maps of one call, stacked [pair index j][window b] by the window form, into the caller's
 // per-window order [window b][pair index j]

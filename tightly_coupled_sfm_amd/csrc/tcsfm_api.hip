@@ -104,6 +104,8 @@ struct tcsfm_ctx {
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; float *depth_out; const float *ls_in; float *ls_out; };
                                        // depth_out: dense calls; ls_in / ls_out: pose + scale calls (or null)
     float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
+    bool dref_dirty = true;            // the scatter sums (dref_ext, dref_ext_src) may be non-zero: a call that ran to its end leaves them zero
+                                       // (k_dense_joint clears what it consumes); a fresh allocation, an export or a failed call does not
     // free source depth maps (opts.free_source_depths): the inverse pairs as groups of one source
     float *jrec_src = nullptr; JointState *jstate_src = nullptr; double *jdelta_src = nullptr; long long *dref_ext_src = nullptr;
     float *qres_rho_src = nullptr, *qres_rec_src = nullptr;      // ... in the quarter-resolution parametrisation
@@ -402,9 +404,11 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
 // init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
 int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
              const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr, const WinOff *wo = nullptr,
-             const CoalTab *ct = nullptr) {
+             const CoalTab *ct = nullptr, float *depth_copy3 = nullptr, int *zero_ints = nullptr, int zero_n = 0, float *const *ct_depth3 = nullptr) {
     PackParams P;
-    P.depth_out2 = depth_copy;
+    P.depth_out2 = depth_copy; P.depth_out3 = depth_copy3; P.zero_ints = zero_ints; P.zero_n = zero_n;
+    P.c_out3 = (ct && ct_depth3) ? 1 : 0;
+    for (int i = 0; i < TC_MAX_COAL; i++) P.c_depth_out3[i] = (ct && ct_depth3 && i < ct->ncall) ? ct_depth3[i] : nullptr;
     if (wo) P.win_off = *wo; else P.win_off.on = 0;
     memset(&P.init, 0, sizeof(P.init));
     P.win_B = win_B; P.win_S = win_S;
@@ -667,6 +671,17 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
 }
 
 
+// the fixed-point scatter sums of the reference-loss dense mode are zero between calls (their consumer clears them); after a fresh
+// allocation, an export or a call that failed midway they are cleared here
+int dref_clean(tcsfm_ctx *h) {
+    if (!h->dref_dirty) return TCSFM_OK;
+    const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
+    if (h->dref_ext) HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, ((n + 1) / 2) * hw * 2 * sizeof(long long), h->stream));
+    if (h->dref_ext_src) HIPCHK(h, hipMemsetAsync(h->dref_ext_src, 0, (n / 2) * hw * 2 * sizeof(long long), h->stream));
+    h->dref_dirty = false;
+    return TCSFM_OK;
+}
+
 // tiny export kernel of tcsfm_linearize_dense_window: d loss / d rho = a_f x the joint kernel's per-pixel record
 __global__ __launch_bounds__(256) void k_dref_export_grho(const float *jrec, int jrec_stride, const double *exp_out, int exp_stride, float *out, int hw) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
@@ -679,13 +694,19 @@ __global__ __launch_bounds__(256) void k_dref_export_grho(const float *jrec, int
 struct DrefExport { double *scal, *g_pose; float *d_g_rho; const float *d_depth0; float *d_g_rho_src; /* [S B][H W] or null: tcsfm_linearize_dense_window_sources */ };
 template <int NS>
 int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, const float *d_src, const float *d_dt, const float *d_ds,
-                  const float *d_K, const float *d_pose_in, float *d_pose_out, float *d_depth_out, float *d_stats, const WinOff *wo, const DrefExport *ex) {
+                  const float *d_K, const float *d_pose_in, float *d_pose_out, float *d_depth_out, float *d_stats, const WinOff *wo, const DrefExport *ex,
+                  const CoalTab *ct = nullptr, float *const *ct_pose = nullptr, float *const *ct_depth = nullptr) {
     using JL = JointLayout<NS>;
     using JM = JointLayout<JMAXS>;
     constexpr int S = NS;
+    // B: targets of the launch sequence.  Coalesced calls (ct): ncall queued calls of cB targets each run as ONE sequence over B = ncall cB
+    // targets; the loss couples the windows of ONE call (batch normalisers, means over the call's maps): every call is a normaliser group of
+    // its own (norm_B = cB targets), the per-map weights take the CALL's batch size Bc, inputs and outputs go through the pointer table.
+    const int Bc = ct ? ct->cB : B, ngroups = ct ? ct->ncall : 1, norm_B = ct ? ct->cB : 0;
     const int SB = S * B, N = 2 * SB;
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     int rc;
+    if (ct && (ex || o->free_source_depths != 0 || o->n_iters < 1 || d_stats || h->trace_bits)) return fail(h, TCSFM_E_ARG, "internal: merged reference-loss calls are plain refinements with fixed source maps");
     constexpr int DTW = 32, DTH = 16, DNT = 512;
     static_assert(DTW == TILE_W && DTH == TILE_H, "the joint kernel and the pose kernel share the tile grid");
     const int nblk = h->nblk;
@@ -698,8 +719,8 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     }
     if ((rc = joint_scratch(h))) return rc;
     if (!h->dref_norms) {
-        HIPCHK(h, hipMalloc((void **)&h->dref_norms, 4 * sizeof(int)));
-        HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * sizeof(long long)));      // (targets <= max_pairs / 2)
+        HIPCHK(h, hipMalloc((void **)&h->dref_norms, 2 * TC_MAX_COAL * sizeof(int)));             // (one (K_f, K_i) pair per normaliser group)
+        HIPCHK(h, hipMalloc((void **)&h->dref_ext, ((n + 1) / 2) * hw * 2 * sizeof(long long)));  // (targets <= max_pairs / 2; two sums per pixel)
         HIPCHK(h, hipMalloc((void **)&h->dref_export, ((n + 1) / 2) * (2 + 6 * JMAXS) * sizeof(double)));
         HIPCHK(h, hipMalloc((void **)&h->dref_smooth, ((n + 1) / 2) * 2 * sizeof(float)));
     }
@@ -708,7 +729,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     const int nq = (h->H / 4) * (h->W / 4), nqblk = qres ? (nq + QRES_CELLS_PER_WG - 1) / QRES_CELLS_PER_WG : 0;
     if (qres && !h->qres_rho) {
         const size_t nb = (n + 1) / 2;
-        HIPCHK(h, hipMalloc((void **)&h->qres_rho, nb * nq * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->qres_rho, 2 * nb * nq * sizeof(float)));       // (two buffers: k_qres_step_up ping-pongs)
         HIPCHK(h, hipMalloc((void **)&h->qres_rec, nb * nq * JM::JREC * sizeof(float)));
     }
     if (qres && nblk + nqblk > 2 * h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: quarter-resolution records exceed the scratch");
@@ -720,7 +741,8 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         HIPCHK(h, hipMalloc((void **)&h->jrec_src, ng * hw * JointLayout<1>::JREC * sizeof(float)));
         HIPCHK(h, hipMalloc((void **)&h->jstate_src, ng * sizeof(JointState)));
         HIPCHK(h, hipMalloc((void **)&h->jdelta_src, ng * 6 * JMAXS * sizeof(double)));
-        HIPCHK(h, hipMalloc((void **)&h->dref_ext_src, ng * hw * sizeof(long long)));
+        HIPCHK(h, hipMalloc((void **)&h->dref_ext_src, ng * hw * 2 * sizeof(long long)));
+        h->dref_dirty = true;
     }
     if (free_src && qres && !h->qres_rho_src) {
         const size_t ng = n / 2;
@@ -734,7 +756,11 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the couplings are set explicitly below)
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
     I.K_mod = B;
-    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, B, S, h->depth0, wo))) return rc;
+    // the pack also zeroes the batch counters and -- plain refinement with fixed source maps -- leaves the inputs in the caller's depth
+    // output: its inverse slots (the source maps) are final, the forward slots are overwritten by the last back-substitution
+    const bool direct_out = !ex && !(o->free_source_depths != 0) && o->n_iters > 0 && (d_depth_out != nullptr || ct != nullptr);
+    if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, ct ? 0 : B, S, h->depth0, wo, ct, direct_out && !ct ? d_depth_out : nullptr, h->dref_norms, 2 * TC_MAX_COAL,
+                       ct ? ct_depth : nullptr))) return rc;
     if (ex && ex->d_depth0)       // the prior's centre given explicitly (slots of the forward pairs (0, b): index b)
         HIPCHK(h, hipMemcpyAsync(h->depth0, ex->d_depth0, (size_t)B * hw * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if ((rc = trace_check(h, o, N))) return rc;
@@ -749,7 +775,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     DrefPrepassParams Dp;
     Dp.diff = maps_diff; Dp.valid = maps_valid; Dp.norms = h->dref_norms; Dp.ext = h->dref_ext; Dp.B = B; Dp.S = S;
     Dp.argmin = o->argmin ? 1 : 0; Dp.automask = o->automask; Dp.eps = o->irls_eps;
-    Dp.b_dc = o->w_dc / ((float)SB * (float)hw);
+    Dp.b_dc = o->w_dc / ((float)(S * Bc) * (float)hw);
     Dp.plain_dif = (!ex && o->free_source_depths != 0) ? 1 : 0;
     // ---- inverse pairs: pose kernels on views offset by S B pairs, window rule REFERENCE (all of them are the rule's inverse group)
     LinParams Pi = lin_params(h, &oo, 6);
@@ -760,7 +786,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     Si.partials = direct_records(h) ? Pi.blockrec : Pi.partials;
     Si.st = h->state + SB; Si.pc = h->pconst + SB; Si.lin_out = h->lin_out + (size_t)SB * kLinOut;
     Si.rule = 1; Si.grp_fwd = 0; Si.n_pairs = SB; Si.scale_fwd = 1.0; Si.scale_inv = 0.25;
-    Si.b_dc = (double)o->w_dc / ((double)SB * (double)hw);
+    Si.b_dc = (double)o->w_dc / ((double)(S * Bc) * (double)hw);
     Si.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
     // ---- forward group: the joint kernel under the reference's rule
     LinParams Pj = lin_params(h, &oo, 6);
@@ -772,15 +798,15 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     J.lambda_depth = ex ? 1e20f : o->lambda_depth;      // (export: depth block frozen, the reduced right-hand side IS the pose gradient)
     J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
     J.automask = o->argmin ? o->automask : 0;     // own masks: with one source the min is the source itself; without argmin no auto-mask (:71-73)
-    J.norms = h->dref_norms; J.ext = h->dref_ext; J.c_f = o->argmin ? 1.f : 0.25f;
-    J.b_dc = o->w_dc / ((float)SB * (float)hw); J.w_init_px = o->prior_init / ((float)B * (float)hw);
+    J.norms = h->dref_norms; J.norm_B = norm_B; J.ext2 = h->dref_ext; J.c_f = o->argmin ? 1.f : 0.25f;
+    J.b_dc = o->w_dc / ((float)(S * Bc) * (float)hw); J.w_init_px = o->prior_init / ((float)Bc * (float)hw);
     J.sig_lo = 1.f / o->max_depth; J.sig_ir = 1.f / (1.f / o->min_depth - 1.f / o->max_depth);
     DrefSmoothParams Ds;
     memset(&Ds, 0, sizeof(Ds));
     const bool smooth = o->w_smooth > 0.f && h->H > 1 && h->W > 1;
     if (smooth) {       // optimizer.py:92-93: l_smooth_weight x [mean over B H (W-1) x-edges + mean over B (H-1) W y-edges]
         J.smooth = h->dref_smooth;
-        J.w_smooth_x = o->w_smooth / ((float)B * (float)h->H * (float)(h->W - 1)); J.w_smooth_y = o->w_smooth / ((float)B * (float)(h->H - 1) * (float)h->W);
+        J.w_smooth_x = o->w_smooth / ((float)Bc * (float)h->H * (float)(h->W - 1)); J.w_smooth_y = o->w_smooth / ((float)Bc * (float)(h->H - 1) * (float)h->W);
         Ds.depth = h->depth_work; Ds.tgtpack = h->tgtpack; Ds.out = h->dref_smooth; Ds.H = h->H; Ds.W = h->W;
         Ds.sig_lo = J.sig_lo; Ds.sig_ir = J.sig_ir; Ds.wx = J.w_smooth_x; Ds.wy = J.w_smooth_y;
     }
@@ -789,7 +815,12 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
     Sj.n_iters = o->n_iters; Sj.solver = TCSFM_SOLVER_GN; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
     Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = nullptr;
-    Sj.norms = h->dref_norms; Sj.c_f = J.c_f;
+    Sj.norms = h->dref_norms; Sj.norm_B = norm_B; Sj.c_f = J.c_f;
+    if (ct) {
+        Sj.c_ncall = ct->ncall; Sj.c_B = ct->cB; Sj.c_S = ct->cS;
+        Si.c_ncall = ct->ncall; Si.c_B = ct->cB; Si.c_S = ct->cS; Si.c_n0 = SB;
+        for (int i = 0; i < ct->ncall; i++) { Sj.c_pose_out[i] = ct_pose[i]; Si.c_pose_out[i] = ct_pose[i]; Si.c_ls_out[i] = nullptr; }
+    }
     JointUpdateParams Uj;
     memset(&Uj, 0, sizeof(Uj));
     Uj.jrec = h->jrec; Uj.delta = h->jdelta; Uj.depth = h->depth_work; Uj.hw = (int)hw; Uj.B = B; Uj.S = S; Uj.mode = 0;
@@ -808,7 +839,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         // stays the full-resolution input (`self.target_disparity`, :89-90)
         hipLaunchKernelGGL(k_qres_init, dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
         hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
-        Q.norms_zero = h->dref_norms;
+        Q.norms_zero = h->dref_norms; Q.norms_n = 2 * ngroups;
     }
     QresParams Q2 = Q;
     if (qres && free_src) {      // the source maps in the same parametrisation: their quarter-resolution projection is the start (optimizer.py:194-196)
@@ -822,21 +853,20 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     // more than the ~18 us of overlap they buy)
     // the counters and the scatter sums are zero when a linearisation starts: zeroed here once per call, and by their consumers afterwards
     // (k_dense_joint clears every sum it reads, k_dense_joint_update the counters) -- two memset launches per iteration cost 10 us
-    HIPCHK(h, hipMemsetAsync(h->dref_norms, 0, 4 * sizeof(int), st));
-    HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)B * hw * sizeof(long long), st));
-    Uj.norms_zero = h->dref_norms;
+    if ((rc = dref_clean(h))) return rc;
+    h->dref_dirty = true;          // (until this call has issued its last consumer)
+    Uj.norms_zero = h->dref_norms; Uj.norms_n = 2 * ngroups;
     LinParams Pj2 = lin_params(h, &oo, 6);
     JointParams J2 = J;
     JointSolveParams Sj2 = Sj;
     JointUpdateParams Uj2 = Uj;
     if (free_src) {
-        HIPCHK(h, hipMemsetAsync(h->dref_ext_src, 0, (size_t)SB * hw * sizeof(long long), st));
         Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
         Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
         J2.jrec = h->jrec_src; J2.depth0 = nullptr; J2.B = SB; J2.S = 1; J2.argmin = 0; J2.automask = o->automask;
         J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
         J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
-        J2.ext = h->dref_ext_src; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
+        J2.ext2 = h->dref_ext_src; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
         if (qres) { J2.qres = 1; J2.rec_stride = nblk + nqblk; }
         Sj2.js = h->jstate_src; Sj2.st = h->state + SB; Sj2.pc = h->pconst + SB; Sj2.B = SB; Sj2.nblk = qres ? nblk + nqblk : nblk;
         Sj2.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
@@ -845,15 +875,40 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         Uj2.norms_zero = nullptr;                     // (the forward update zeroes the counters: it runs after both solves)
         Uj2.srcpack_inv = h->srcpack;                 // forward pair m samples source map m: the depth channel of ITS pack
     }
+    // Round 5: with the source maps fixed a linearisation OPENS with one launch over all 2 S B pairs (k_linearize<FRONT>: the forward pairs'
+    // selection and K_f, the inverse pairs' systems, K_i and their adjoint scatter) in place of the residual-map, count, scatter and
+    // inverse-linearisation launches; the free-source-map mode keeps those (its inverse pairs are linearised by the joint kernel).
+    const bool front = !free_src;
+    LinParams F = lin_params(h, &oo, 6);
+    if (front) {
+        F.front_fwd = SB; F.front_Bt = B; F.norm_B = norm_B; F.norms = h->dref_norms; F.ext2 = h->dref_ext;
+        F.fwd_noauto = o->argmin ? 0 : SB;                       // optimizer.py:71-73: without argmin the forward term has no auto-mask
+        F.one_generation = (size_t)nblk * (SB + (sel ? B : SB)) <= 512;
+        if (sel) { F.sel_B = B; F.sel_S = S; F.sel_out = maps_valid; Pj.ext_diff = nullptr; Pj.ext_valid = nullptr; Pj.n_ext = 0; Pj.sel_in = maps_valid; }
+        Si.norms = h->dref_norms; Si.norm_Bt = B; Si.norm_B = norm_B;
+    }
+    auto launch_front = [&](int lin) {
+        F.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
+        F.stamp = nullptr;
+        ProfScope prof(h, 2);
+        const dim3 grid(nblk, SB + (sel ? B : SB)), block(TILE_NT);     // inverse pairs, then the forward rows (under the selection: one per target)
+        if (tr) {
+            if (sel) hipLaunchKernelGGL((k_linearize<6, true, MODE_LIN, TILE_W, TILE_H, TILE_NT, true, true, false, true>), grid, block, 0, st, F);
+            else hipLaunchKernelGGL((k_linearize<6, true, MODE_LIN, TILE_W, TILE_H, TILE_NT, false, true, false, true>), grid, block, 0, st, F);
+        } else if (sel) hipLaunchKernelGGL((k_linearize<6, true, MODE_LIN, TILE_W, TILE_H, TILE_NT, true, false, false, true>), grid, block, 0, st, F);
+        else hipLaunchKernelGGL((k_linearize<6, true, MODE_LIN, TILE_W, TILE_H, TILE_NT, false, false, false, true>), grid, block, 0, st, F);
+    };
     auto linearise = [&](int lin) -> int {
-        launch_lin(h, M, N, 6, false, MODE_MAPS, 2);
-        hipLaunchKernelGGL(k_dref_count, dim3(DREF_CNT_WG, N), dim3(256), 0, st, Pp, Dp);
-        hipLaunchKernelGGL(k_dref_scatter, dim3((unsigned)(((h->W + DREF_TW - 1) / DREF_TW) * ((h->H + DREF_TH - 1) / DREF_TH)), SB), dim3(DREF_TW * DREF_TH), 0, st, Pp, Dp);
         Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
         Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
-        if (free_src)        // the adjoint of the forward pairs' samples of the source maps (before anything moves a forward pose)
-            hipLaunchKernelGGL(k_dref_scatter_src, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Pp, Dp, h->dref_ext_src, J.c_f);
-        else launch_lin(h, Pi, SB, 6, dc, MODE_LIN, 2);
+        if (front) launch_front(lin);
+        else {
+            launch_lin(h, M, N, 6, false, MODE_MAPS, 2);
+            hipLaunchKernelGGL(k_dref_count, dim3(DREF_CNT_WG, N), dim3(256), 0, st, Pp, Dp);
+            hipLaunchKernelGGL(k_dref_scatter, dim3((unsigned)(((h->W + DREF_TW - 1) / DREF_TW) * ((h->H + DREF_TH - 1) / DREF_TH)), SB), dim3(DREF_TW * DREF_TH), 0, st, Pp, Dp);
+            // the adjoint of the forward pairs' samples of the source maps (before anything moves a forward pose)
+            hipLaunchKernelGGL(k_dref_scatter_src, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Pp, Dp, h->dref_ext_src);
+        }
         Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
         if (smooth) hipLaunchKernelGGL(k_dref_smooth, dim3(B), dim3(1024), 0, st, Ds);
@@ -876,9 +931,10 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             // Their role mirrors the target map's: local in the inverse pair -- the joint kernel run on the inverse pairs as S = 1 groups
             // without argmin IS the reference's inverse term (0.25 / K_i, own weights, valid x auto-mask, its depth-consistency term) --
             // and sampled by the forward pair: k_dref_scatter_src, in units of the forward factor a_f.  Oracle: dref_source_depth_gradient.
-            HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)SB * hw * sizeof(long long), st));
+            HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)SB * hw * 2 * sizeof(long long), st));
             const dim3 px_f((unsigned)((hw + 255) / 256), SB);
-            hipLaunchKernelGGL(k_dref_scatter_src, px_f, dim3(256), 0, st, Pp, Dp, h->dref_ext, J.c_f);
+            launch_lin(h, M, N, 6, false, MODE_MAPS, 2);          // (the forward pairs' residual maps: what k_dref_scatter_src weighs the samples with)
+            hipLaunchKernelGGL(k_dref_scatter_src, px_f, dim3(256), 0, st, Pp, Dp, h->dref_ext);
             LinParams Pj2 = lin_params(h, &oo, 6);
             Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
             Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
@@ -886,7 +942,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             J2.jrec = h->jrec_acc; J2.depth0 = nullptr; J2.B = SB; J2.S = 1; J2.argmin = 0; J2.automask = o->automask;
             J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
             J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
-            J2.ext = h->dref_ext; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
+            J2.ext2 = h->dref_ext; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
             hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
             hipLaunchKernelGGL(k_dref_export_grho_src, px_f, dim3(256), 0, st, (const float *)h->jrec_acc, (int)JointLayout<1>::JREC, (const int *)h->dref_norms, ex->d_g_rho_src, (int)hw);
         }
@@ -917,9 +973,11 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         if ((rc = linearise(it))) return rc;
         const bool last = it == o->n_iters - 1;
         Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
-        if (!free_src) launch_solve(h, Si, SB, 6);
         Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
-        hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
+        if (front) {      // the target groups' and the inverse pairs' systems: independent, one launch
+            ProfScope prof(h, 1);
+            hipLaunchKernelGGL((k_solve_front<NS>), dim3(B + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
+        } else hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
         if (free_src) {
             // every inverse pair as a group of one source WITHOUT argmin: that is the reference's inverse term (0.25 / K_i, own weights,
             // valid x auto-mask, its depth-consistency term), its local unknowns the pair's pose and the source map it back-projects.  The
@@ -932,7 +990,18 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             Sj2.trace_decide = h->trace_decide ? h->trace_decide + (size_t)it * N + SB : nullptr;
             hipLaunchKernelGGL((k_solve_joint<1>), dim3(SB), dim3(JSOLVE_NT), 0, st, Sj2);
         }
-        if (qres) {
+        if (direct_out && last) {      // the last back-substitution also writes the caller's map (coalesced calls: every call's own)
+            Uj.depth_out = d_depth_out; Q.depth_out = d_depth_out;
+            if (ct) {
+                Uj.c_ncall = Q.c_ncall = ct->ncall; Uj.c_B = Q.c_B = ct->cB;
+                for (int i = 0; i < ct->ncall; i++) { Uj.c_depth_out[i] = ct_depth[i]; Q.c_depth_out[i] = ct_depth[i]; }
+            }
+        }
+        if (qres && front) {      // cell step + x4 upsampling in one launch; the cell values ping-pong between the two halves of qres_rho
+            const size_t half = ((n + 1) / 2) * (size_t)nq;
+            Q.rho_q = h->qres_rho + (it & 1) * half; Q.rho_q_next = h->qres_rho + ((it + 1) & 1) * half;
+            hipLaunchKernelGGL((k_qres_step_up<NS>), dim3((unsigned)(((h->W + QSU_TW - 1) / QSU_TW) * ((h->H + QSU_TH - 1) / QSU_TH)), B), dim3(QSU_TW * QSU_TH), 0, st, Q);
+        } else if (qres) {
             hipLaunchKernelGGL((k_qres_step<NS>), dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
             hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
         } else hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
@@ -948,7 +1017,8 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         F.st = h->state; F.pose_out = d_pose_out; F.log_scale_out = nullptr; F.N = N;
         hipLaunchKernelGGL(k_finish, dim3((N + 63) / 64), dim3(64), 0, st, F);
     }
-    HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (!direct_out) HIPCHK(h, hipMemcpyAsync(d_depth_out, h->depth_work, N * hw * sizeof(float), hipMemcpyDeviceToDevice, st));
+    h->dref_dirty = o->n_iters == 0;      // (every linearisation's sums were consumed and cleared; with no iteration the pack's zeroed counters are all there is)
     return TCSFM_OK;
 }
 
@@ -1512,6 +1582,7 @@ static int replay_or_run(tcsfm_ctx *h, const tcsfm_opts *o, int kind, int N, int
             HIPCHK(h, hipMemsetAsync(h->tickets, 0, (size_t)h->max_pairs * h->ngrp_alloc * sizeof(int), h->stream));
             h->tickets_dirty = false;
         }
+        if (kind == 1) { if (int rc_ = dref_clean(h)) return rc_; }      // (what dense_ref_run does before its first launch)
         HIPCHK(h, hipGraphLaunch(e->exec, h->stream));
         h->graph_replays++;
         return TCSFM_OK;
@@ -1696,8 +1767,9 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (!ct && (rc = check_intrinsics(h, o, K, nimg_t))) return rc;
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     const int n_sel = (win_B && win_S > 1 && o->argmin) ? win_B * win_S : 0;
-    if (ct && (ref_mode || n_sel || o->solver != TCSFM_SOLVER_GN || o->host_ptrs || o->n_iters < 1 || (o->dense_joint && win_S >= 2)))
+    if (ct && !ref_mode && (n_sel || o->solver != TCSFM_SOLVER_GN || o->host_ptrs || o->n_iters < 1 || (o->dense_joint && win_S >= 2)))
         return fail(h, TCSFM_E_ARG, "internal: only per-pair Gauss-Newton dense calls on device pointers are merged");
+    if (ct && ref_mode && (o->host_ptrs || o->n_iters < 1 || stats_out)) return fail(h, TCSFM_E_ARG, "internal: merged reference-loss calls take device pointers and no statistics");
     if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
     const bool lm = o->solver == TCSFM_SOLVER_LM;
     if (lm && !h->dense_rec_acc) {
@@ -1726,9 +1798,9 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
         HIPCHK(h, hipMemsetAsync(d_stats, 0, nstats * sizeof(float), h->stream));
     }
     if (ref_mode) {
-        rc = win_S == 1 ? dense_ref_run<1>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr)
-           : win_S == 2 ? dense_ref_run<2>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr)
-                        : dense_ref_run<3>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr);
+        rc = win_S == 1 ? dense_ref_run<1>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr, ct, ct_pose, ct_depth)
+           : win_S == 2 ? dense_ref_run<2>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr, ct, ct_pose, ct_depth)
+                        : dense_ref_run<3>(h, o, win_B, d_tgt, d_src, d_dt, d_ds, d_K, d_pose_in, d_pose_out, d_depth_out, d_stats, wo, nullptr, ct, ct_pose, ct_depth);
         if (rc) return rc;
         if ((rc = copy_back(h, o, pose_out, d_pose_out, (size_t)N * 6))) return rc;
         if ((rc = copy_back(h, o, depth_out, d_depth_out, N * hw))) return rc;
@@ -2014,8 +2086,12 @@ int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B,
     if (rc) return rc;
     if (!tgt || !srcs || !depth_t || !depth_s || !K || !pose_in || !pose_out || !depth_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: NULL argument");
     if (o->host_ptrs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: device pointers only");
-    const bool mergeable = h->coal_max > 1 && S == 1 && o->window_rule == TCSFM_WINDOW_PAIR && o->solver == TCSFM_SOLVER_GN && o->n_iters >= 1 &&
-                           o->w_dc == 0.f && o->param == TCSFM_PARAM_SE3 && !h->trace_bits && !h->trace_decide && !h->profiling;
+    const bool plain = h->coal_max > 1 && o->solver == TCSFM_SOLVER_GN && o->n_iters >= 1 && o->param == TCSFM_PARAM_SE3 && !h->trace_bits && !h->trace_decide && !h->profiling;
+    // (round 5) the reference-loss mode with fixed source maps merges too: every call is a normaliser group of its own inside the merged sequence
+    const bool merge_ref = plain && o->window_rule == TCSFM_WINDOW_REFERENCE && S <= JMAXS && o->free_source_depths == 0 && o->prior_init >= 0.f && o->w_smooth >= 0.f &&
+                           o->w_pose_consist == 0.f && (o->depth_param == TCSFM_DEPTH_FULL || (o->depth_param == TCSFM_DEPTH_QUARTER && h->H % 4 == 0 && h->W % 4 == 0)) &&
+                           o->min_depth > 0 && o->max_depth > o->min_depth;
+    const bool mergeable = merge_ref || (plain && S == 1 && o->window_rule == TCSFM_WINDOW_PAIR && o->w_dc == 0.f);
     DeviceGuard dev_guard(h->device);
     if (!mergeable) {
         if ((rc = flush_pending(h))) return rc;
