@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_dref_count(LinParams P, DrefPrepassPara
 constexpr int DREF_TW = 32, DREF_TH = 8, DREF_M = 6;
 __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P, DrefPrepassParams D) {
     constexpr int WW = DREF_TW + 2 * DREF_M, WH = DREF_TH + 2 * DREF_M, NWIN = WW * WH;
-    __shared__ unsigned long long win[2 * NWIN];
+    __shared__ unsigned long long win[NWIN];
     const int H = P.H, W = P.W, hw = H * W, SB = D.S * D.B;
     const int m = blockIdx.y, n = SB + m, b = m % D.B;
     const int tiles_x = (W + DREF_TW - 1) / DREF_TW;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
     const int u = tx * DREF_TW + lx, v = ty * DREF_TH + ly;
     const PairConst &c = P.pc[n];
     const float *depth_t = P.depth_t + (size_t)n * hw;
-    for (int i = tid; i < 2 * NWIN; i += DREF_TW * DREF_TH) win[i] = 0ull;
+    for (int i = tid; i < NWIN; i += DREF_TW * DREF_TH) win[i] = 0ull;
     // window origin: the tile's own origin displaced by the flow of its centre pixel (every thread evaluates it: no broadcast, no barrier)
     int ox, oy;
     {
@@ -100,6 +100,12 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
         const float fx = fminf(fmaxf(gc.rx, -4096.f), 4096.f), fy = fminf(fmaxf(gc.ry, -4096.f), 4096.f);
         ox = tx * DREF_TW + (int)floorf(fx) - DREF_M; oy = ty * DREF_TH + (int)floorf(fy) - DREF_M;
     }
+    // This launch runs BEHIND k_dref_count: K_i is known, so the two parts are combined into ONE sum per tap -- in the slot whose factor the
+    // consumer applies: slot 1 (factor -a_i) holds  sum (M diff - (b_dc / a_i) h) ddd w  when inverse pixels count, slot 0 (factor b_dc) holds
+    // sum h ddd w  otherwise.  (k_linearize<FRONT> scatters before the counts exist and fills both slots.)
+    const float Ki = (float)D.norms[1];
+    const int slot = Ki > 0.f ? 1 : 0;
+    const float ratio_dc = Ki > 0.f ? -D.b_dc * Ki * 4.f : 1.f, w_photo = Ki > 0.f ? -1.f : 0.f;       // (signs: slot 1 is SUBTRACTED by the consumer)
     __syncthreads();
     long long *ext = D.ext + (size_t)b * hw * 2;
     if (u < W && v < H) {
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
                 const float sg = dif > 0.f ? 1.f : (dif < 0.f ? -1.f : 0.f);
                 const float ddd = -sg * 2.f * cd * isum * isum * c.es;                  // d dd / d (sampled depth)
                 const float dd = fminf(raw, 1.f);
-                const float f_dc = fminf(1.f, dd * frcp(D.eps)) * ddd, f_ph = count ? diff * ddd : 0.f;
+                const float coef = (ratio_dc * fminf(1.f, dd * frcp(D.eps)) - (count ? w_photo * diff : 0.f)) * ddd;
                 const int xi = u + (int)floorf(g.rx), yi = v + (int)floorf(g.ry);
                 const float wx = t.wx, wy = t.wy;
                 const float w4[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
@@ -128,15 +134,11 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
                 for (int k = 0; k < 4; k++) {
                     const int xx = xi + (k & 1), yy = yi + (k >> 1);
                     if (xx >= 0 && xx < W && yy >= 0 && yy < H) {         // (a tap in the zero border is no pixel of the target)
-                        const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
+                        const long long a = (long long)llrint((double)(coef * w4[k]) * DREF_FIX);
                         const int wxl = xx - ox, wyl = yy - oy;
-                        if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) {
-                            if (a0 != 0) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a0);
-                            if (a1 != 0) atomicAdd(&win[NWIN + wyl * WW + wxl], (unsigned long long)a1);
-                        } else {
-                            unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
-                            if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
-                            if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
+                        if (a != 0) {
+                            if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a);
+                            else atomicAdd(reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2 + slot), (unsigned long long)a);
                         }
                     }
                 }
@@ -145,13 +147,9 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
     }
     __syncthreads();
     for (int i = tid; i < NWIN; i += DREF_TW * DREF_TH) {
-        const unsigned long long a0 = win[i], a1 = win[NWIN + i];
+        const unsigned long long a = win[i];
         const int yy = oy + i / WW, xx = ox + i % WW;
-        if ((a0 | a1) != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) {
-            unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
-            if (a0 != 0ull) atomicAdd(e, a0);
-            if (a1 != 0ull) atomicAdd(e + 1, a1);
-        }
+        if (a != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) atomicAdd(reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2 + slot), a);
     }
 }
 
@@ -162,7 +160,7 @@ __global__ __launch_bounds__(DREF_TW * DREF_TH) void k_dref_scatter(LinParams P,
 // (optimizer.py:69), a pair's own pixels otherwise.  d L / d pd(p) = (b_dc h(dd) - a_f E(p)) d dd / d pd, E = the sum of M diff over the
 // pixels this weight multiplies, scattered over the four taps in units of a_f = c_f / K_f (b_dc when no pixel counts).  A verification
 // path, not a timed one: one thread per pixel, one 64-bit fixed-point atomic per tap (order-independent: bit-reproducible).
-__global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepassParams D, long long *ext_src /* [SB][H*W][2] */) {
+__global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepassParams D, long long *ext_src /* [SB][H*W][2] */, float c_f) {
     const int H = P.H, W = P.W, hw = H * W;
     const int m = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= hw) return;
@@ -196,7 +194,10 @@ __global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepa
             if (count) E += diff;
         }
     }
-    const float f_dc = fminf(1.f, dd * frcp(D.eps)) * ddd, f_ph = E * ddd;      // (factors b_dc and a_f = c_f / K_f: applied by the consumer)
+    // (K_f is known here: one combined sum per tap, in the slot whose factor the consumer applies -- see k_dref_scatter)
+    const float Kf = (float)D.norms[0];
+    const int slot = Kf > 0.f ? 1 : 0;
+    const float coef = Kf > 0.f ? (E - (D.b_dc * Kf / c_f) * fminf(1.f, dd * frcp(D.eps))) * ddd : fminf(1.f, dd * frcp(D.eps)) * ddd;
     const int xi = u + (int)floorf(g.rx), yi = v + (int)floorf(g.ry);
     const float wx = t.wx, wy = t.wy;
     const float w4[4] = {(1.f - wx) * (1.f - wy), wx * (1.f - wy), (1.f - wx) * wy, wx * wy};
@@ -205,10 +206,8 @@ __global__ __launch_bounds__(256) void k_dref_scatter_src(LinParams P, DrefPrepa
     for (int k = 0; k < 4; k++) {
         const int xx = xi + (k & 1), yy = yi + (k >> 1);
         if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
-            const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
-            unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
-            if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
-            if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
+            const long long a = (long long)llrint((double)(coef * w4[k]) * DREF_FIX);
+            if (a != 0) atomicAdd(reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2 + slot), (unsigned long long)a);
         }
     }
 }

@@ -907,7 +907,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             hipLaunchKernelGGL(k_dref_count, dim3(DREF_CNT_WG, N), dim3(256), 0, st, Pp, Dp);
             hipLaunchKernelGGL(k_dref_scatter, dim3((unsigned)(((h->W + DREF_TW - 1) / DREF_TW) * ((h->H + DREF_TH - 1) / DREF_TH)), SB), dim3(DREF_TW * DREF_TH), 0, st, Pp, Dp);
             // the adjoint of the forward pairs' samples of the source maps (before anything moves a forward pose)
-            hipLaunchKernelGGL(k_dref_scatter_src, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Pp, Dp, h->dref_ext_src);
+            hipLaunchKernelGGL(k_dref_scatter_src, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Pp, Dp, h->dref_ext_src, J.c_f);
         }
         Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
@@ -934,7 +934,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, (size_t)SB * hw * 2 * sizeof(long long), st));
             const dim3 px_f((unsigned)((hw + 255) / 256), SB);
             launch_lin(h, M, N, 6, false, MODE_MAPS, 2);          // (the forward pairs' residual maps: what k_dref_scatter_src weighs the samples with)
-            hipLaunchKernelGGL(k_dref_scatter_src, px_f, dim3(256), 0, st, Pp, Dp, h->dref_ext);
+            hipLaunchKernelGGL(k_dref_scatter_src, px_f, dim3(256), 0, st, Pp, Dp, h->dref_ext, J.c_f);
             LinParams Pj2 = lin_params(h, &oo, 6);
             Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
             Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
