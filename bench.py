@@ -227,6 +227,141 @@ def valu_bound(avg_s, pairs_per_launch):
             "bound_us": round(t * 1e6, 3), "frac_of_bound": round(t / avg_s, 4), "clock_GHz": ghz, "census": os.path.relpath(f, ROOT)}
 
 
+def modes_block(budget_s=12.0):
+    """The other BASELINE.json configs and the reference-loss dense mode on ONE GPU, bounded (~`budget_s` seconds in all): per mode
+    windows/s, us per call and the roofline fraction of its dominant kernel from THIS run's in-kernel bracket (every workgroup stamps
+    s_memrealtime; tcsfm_profile_kernel_time) -- so that the driver's own bench line, not only builder-run scripts, carries a number for
+    every config.  Algorithmic bytes per pixel, directed pair and iteration: 32 (pose, pose + scale), 36 (pose + depth)."""
+    import numpy as np
+    import torch
+    from tightly_coupled_sfm_amd import synth, _lib
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    t_all = time.perf_counter()
+    out = {}
+
+    def measure(e, step, pairs, iters, px, bpp, kernel, kernel_pairs, slice_s):
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(10):
+                step()
+            n += 10
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 > slice_s or n >= 4000:
+                break
+        dt = (time.perf_counter() - t0) / n
+        e.profile_begin()
+        for _ in range(20):
+            step()
+        pr = e.profile_end()
+        k_us = pr["linearize_kernel"][0] / max(pr["linearize_kernel"][1], 1) * 1e3
+        alg_k = bpp * px * kernel_pairs
+        r = {"us_per_call": round(dt * 1e6, 1), "calls_per_s": round(1 / dt, 1), "frame_pairs_per_s": round(pairs / 2 / dt, 1), "calls_timed": n,
+             "directed_pairs_per_call": pairs, "iters": iters,
+             "whole_call": {"algorithmic_bytes": bpp * px * pairs * iters, "achieved_GBps": round(bpp * px * pairs * iters / dt / 1e9, 1),
+                            "frac": round(bpp * px * pairs * iters / dt / 1e9 / HBM_PEAK_GBPS, 5)},
+             "dominant_kernel": {"kernel": kernel, "avg_launch_us": round(k_us, 2), "algorithmic_bytes_per_launch": alg_k,
+                                 "achieved_GBps": round(alg_k / max(k_us, 1e-9) / 1e3, 1), "frac": round(alg_k / max(k_us, 1e-9) / 1e3 / HBM_PEAK_GBPS, 5),
+                                 "frac_source": "this run: in-kernel s_memrealtime bracket, one call in flight"}}
+        return r
+
+    per = budget_s / 9.0
+    # ---- BASELINE config 4: depth scale + 6-DoF pose, 8 iterations, 640x192, one window per call
+    b = synth.make_batch(2, H, W, seed0=0, both_directions=True)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    e = Engine(H, W, 2)
+    o = default_opts(n_iters=8, refine=_lib.REFINE_POSE_SCALE)
+    outp = torch.empty_like(d["pose_init"])
+    out["config4_pose_scale_8it_640x192"] = measure(e, lambda: e.refine_into(d["tgt"], d["src"], d["depth_t"], d["depth_s"], d["K"], d["pose_init"], outp, o),
+                                                     2, 8, H * W, 32, "k_linearize<7>", 2, per)
+    # ---- the reference's KITTI window as ONE call: B = 1 target, S = 2 sources, min over the sources, depth consistency, rule REFERENCE (pose mode)
+    S2 = 2
+    bw = synth.make_batch(2 * S2, H, W, seed0=0)
+    dw = {k: torch.as_tensor(v).cuda().contiguous() for k, v in bw.items()}
+    tgt, srcs = dw["tgt"][:1].contiguous(), dw["src"][:S2].reshape(S2, 1, 3, H, W).contiguous()
+    dt_, ds_ = dw["depth_t"][:1].contiguous(), dw["depth_s"][:S2].reshape(S2, 1, 1, H, W).contiguous()
+    pose_w = torch.cat([dw["pose_init"][:S2], -dw["pose_init"][:S2]]).contiguous()
+    Kw = dw["K"][:1].contiguous()
+    e2 = Engine(H, W, 2 * S2)
+    ow = default_opts(n_iters=4, w_dc=0.15, window_rule=_lib.WINDOW_REFERENCE)
+    out["kitti_window_S2_pose_reference_rule_640x192"] = measure(e2, lambda: e2.refine_window(tgt, srcs, dt_, ds_, Kw, pose_w, ow, argmin=True),
+                                                                   2 * S2, 4, H * W, 32, "k_linearize<6, DC, SEL>", 2 * S2, per)
+    # ---- the same window, pose + depth on the reference's own loss (optimize_depth_pred: optimizer.py:47-90), full-resolution unknown
+    od = default_opts(n_iters=4, w_dc=0.15, prior_init=0.1, window_rule=_lib.WINDOW_REFERENCE)
+    dt4, ds5 = dt_[:, None].contiguous() if dt_.dim() == 3 else dt_, ds_
+    out["kitti_window_S2_reference_loss_dense_640x192"] = measure(e2, lambda: e2.refine_dense_window(tgt, srcs, dt4, ds5, Kw, pose_w, od, argmin=True),
+                                                                    2 * S2, 4, H * W, 36, "k_dense_joint<2, REF> (forward pairs)", S2, per)
+    e2.close(); e.close()
+    # ---- BASELINE config 5: per-pixel inverse depth + pose, Schur complement: 320x240 and the reference's own ScanNet size 448x256
+    for (hh, ww) in ((240, 320), (256, 448)):
+        bb = synth.make_batch(2, hh, ww, seed0=0, both_directions=True)
+        dd = {k: torch.as_tensor(v).cuda().contiguous() for k, v in bb.items()}
+        ed = Engine(hh, ww, 2)
+        ol = default_opts(n_iters=4, min_depth=0.03, max_depth=3.0)
+        out[f"config5_dense_schur_{ww}x{hh}"] = measure(ed, lambda: ed.refine_dense(dd["tgt"], dd["src"], dd["depth_t"], dd["depth_s"], dd["K"], dd["pose_init"], ol),
+                                                         2, 4, hh * ww, 36, "k_dense_linearize", 2, per)
+        # ... and on the reference's loss (window form, S = 1): full-resolution and the reference's quarter-resolution parametrisation
+        t1, s1 = dd["tgt"][:1].contiguous(), dd["src"][:1][None].contiguous()
+        a1, b1 = dd["depth_t"][:1].contiguous(), dd["depth_s"][:1][None].contiguous()
+        a1 = a1[:, None].contiguous() if a1.dim() == 3 else a1
+        b1 = b1[:, :, None].contiguous() if b1.dim() == 4 else b1
+        p1 = torch.cat([dd["pose_init"][:1], dd["pose_init"][1:2]]).contiguous()
+        K1 = dd["K"][:1].contiguous()
+        for tag, dp in (("full", _lib.DEPTH_FULL), ("quarter", _lib.DEPTH_QUARTER)):
+            orf = default_opts(n_iters=4, w_dc=0.15, prior_init=0.1, min_depth=0.03, max_depth=3.0, window_rule=_lib.WINDOW_REFERENCE, depth_param=dp)
+            out[f"config5_reference_loss_{tag}_{ww}x{hh}"] = measure(ed, lambda: ed.refine_dense_window(t1, s1, a1, b1, K1, p1, orf, argmin=True),
+                                                                      2, 4, hh * ww, 36, "k_dense_joint<1, REF> (forward pair)", 1, per)
+        ed.close()
+    out["seconds"] = round(time.perf_counter() - t_all, 1)
+    out["what"] = ("one call in flight, device-resident inputs, untimed for the headline; `whole_call` = algorithmic bytes of all directed pairs and "
+                   "iterations of a call over its wall time, `dominant_kernel` = this run's in-kernel bracket of the mode's linearisation kernel")
+    return out
+
+
+def shim_block(seconds=4.0):
+    """DepthOptimizer.optimize_window (the drop-in for the reference's optimiser, optimizer.py:136-297) end to end with the stand-in
+    networks of tests/standins.py, beside the engine call inside it: what a caller of the shim sees per window."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import standins
+    from tightly_coupled_sfm_amd.optimizer import DepthOptimizer
+    res = {}
+    B, S, ITER = 1, 2, 3
+    w = standins.make_window(B, S, H, W)
+    cfg = {"minibatch": B, "device": "cuda", "min_depth": 0.06, "max_depth": 2.67, "iterations": ITER, "camera_height": 1.65, "flow_type": "none"}
+    for tag, extra in (("pose", {"optimize_depth_pred": False}), ("pose_depth_reference_loss", {"optimize_depth_pred": True})):
+        opts = {"epochs": 5, "diff_img_argmin": True, "automasking": True, "mode": "scaled", "l_depth_consist": True, "l_depth_consist_weight": 0.15,
+                "l_depth_init": True, "l_depth_init_weight": 0.1, "num_source_imgs": S, "avg_final_epochs": 5}
+        opts.update(extra)
+        pm, dm = standins.window_models(w, ITER, device="cuda")
+        opt = DepthOptimizer(opts, cfg, pm, dm, "09_02")
+        data = standins.loader_batch(w, device="cuda")
+        for _ in range(4):
+            opt.optimize_window(0, data)
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / 2 and n < 200:
+            opt.optimize_window(0, data)
+            n += 1
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        opt.time_engine = True          # the engine call inside it, on its own (device-synchronised around the call: a few extra runs, untimed above)
+        calls = []
+        for _ in range(8):
+            opt.optimize_window(0, data)
+            calls.append(opt.last_engine_call_us)
+        opt.time_engine = False
+        eng_us = round(sorted(calls)[len(calls) // 2], 1)
+        res[tag] = {"us_per_window": round(dt * 1e6, 1), "windows": n, "engine_call_us": eng_us,
+                    "over_engine_call": None if not eng_us else round(dt * 1e6 / eng_us, 2)}
+    res["what"] = (f"optimize_window(B={B}, S={S}, {W}x{H}, {ITER} PoseNet iterations, 4 GN iterations) with stand-in pose / depth networks (tests/standins.py: a lookup "
+                   "depth net and a linear pose net, so the figure is the shim's own cost: tensor plumbing, the coupled pose initialisation, the engine call, "
+                   "flip post-processing, D2H of the result dict); engine_call_us = the refine call inside it, device-synchronised, measured on its own")
+    return res
+
+
 def self_launch(n):
     """`python bench.py --gpus N` outside torch.distributed.run: this process (which has not touched the GPU and will not) starts
     N ranks of this file, one per GPU, and returns their exit code."""
@@ -266,6 +401,9 @@ def main():
                          "host launch per call instead of nine, same kernels, bit-identical results); 0: plain launches; auto: untimed blocks of "
                          "both before the timed region, the faster mode is timed (a slow host favours replay, a fast one plain launches)")
     ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered refined poses [world, pairs, 6] to this .npy file (tests)")
+    ap.add_argument("--modes-budget", type=float, default=12.0, help="seconds given to the `modes` block (BASELINE configs 4 / 5, the KITTI window, the "
+                    "reference-loss dense mode: windows/s and roofline fraction each); 0 = skip")
+    ap.add_argument("--shim-sample", type=float, default=4.0, help="seconds given to the `shim` block (DepthOptimizer.optimize_window end to end); 0 = skip")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:     # started the way the driver starts it: launch the ranks, touch no GPU here
@@ -335,7 +473,8 @@ def main():
     # which a process creates its streams decides how the lanes' hardware queues are placed, and a handle created before the process's
     # first device work can end up with lanes that slow each other down (4 lanes 10 000 instead of 24 000 frame-pairs/s, reproducibly:
     # scripts/lane_order_probe.py, profiles/r04_lane_order_probe.txt; DESIGN section 4 "Lanes")
-    coal = 0 if args.coalesce <= 1 else max(1, min(args.coalesce, 16, 20 // B))      # merged sequences of at most ~20 windows
+    coal = 0 if args.coalesce <= 1 else max(1, min(args.coalesce, 16))               # queued calls per merged sequence (the library's table holds 16;
+                                                                                     # the handle below is created for exactly that many calls' pairs)
     eng = Engine(H, W, npairs * max(1, coal), lanes=lanes)
     eng.use_own_stream()                     # lane 0 on the handle's own non-blocking stream, like the other lanes
     torch.cuda.synchronize()
@@ -542,6 +681,31 @@ def main():
         inflight = {"steps_in_flight": lanes, "avg_launch_us": round(a2 * 1e6, 3), "achieved": round(alg_bytes / a2 / 1e9, 2),
                     "frac": round(alg_bytes / a2 / 1e9 / HBM_PEAK_GBPS, 5), "launches": int(k2_n),
                     "avg_launch_us_hip_events": round(prof2["linearize"][0] / max(prof2["linearize"][1], 1) * 1e3, 3)}
+    # ... and the launches of the TIMED mode when that is the merged sequences: one k_linearize launch then covers the directed pairs of
+    # `coal` queued calls (tcsfm_refine_window_queued); bracketed in-kernel like the others (profiling does not stop the merging)
+    timed_mode = None
+    if merged and merged["timed"]:
+        eng.set_coalesce(coal)
+        eng.set_coalesce_lanes(max(1, min(args.coalesce_lanes, lanes)))
+        queued[0] = True
+        eng.profile_begin()
+        for k in range(coal * 30):
+            step_k(k, lanes)
+        eng.flush()
+        for l in range(lanes):
+            eng.lane_synchronize(l)
+        prm = eng.profile_end()
+        queued[0] = False
+        eng.set_coalesce_lanes(1)
+        eng.set_coalesce(0)
+        km_ms, km_n = prm["linearize_kernel"]
+        am = km_ms / max(km_n, 1) * 1e-3
+        alg_m = alg_bytes * coal
+        timed_mode = {"mode": f"{coal} queued B={B} calls per launch sequence, sequences alternating over {max(1, min(args.coalesce_lanes, lanes))} streams",
+                      "pairs_per_launch": npairs * coal, "avg_launch_us": round(am * 1e6, 3), "launches": int(km_n), "algorithmic_bytes_per_launch": alg_m,
+                      "achieved": round(alg_m / am / 1e9, 2), "frac": round(alg_m / am / 1e9 / HBM_PEAK_GBPS, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac_source": "this run: in-kernel s_memrealtime bracket of the merged k_linearize launches, as they run in the timed region "
+                                     "(two sequences in flight on two streams: a launch shares the chip with the other sequence's kernels)"}
     per_rank = [mine]
     if distributed:
         per_rank = [None] * world
@@ -583,8 +747,9 @@ def main():
                 "whole_call": {"algorithmic_bytes": ITERS * alg_bytes, "traffic_bytes": call_traffic,
                                "traffic_over_algorithmic": None if call_traffic is None else round(call_traffic / (ITERS * alg_bytes), 3),
                                "what": "all launches of one call (pack + 4 x (linearise + solve)) against 4 x the algorithmic bytes of a linearisation"},
-                "measured_with": "ONE call in flight (the kernel has the chip: what a roofline compares against); `in_flight` repeats the live bracket under the timed region's conditions",
-                "in_flight": inflight}
+                "measured_with": "ONE call in flight (the kernel has the chip: what a roofline compares against); `in_flight` repeats the live bracket with the "
+                                 "lanes' calls in flight, `timed_mode` brackets the launches of the mode `value` was timed in",
+                "in_flight": inflight, "timed_mode": timed_mode}
         if distributed:
             roof["per_rank"] = per_rank
 
@@ -658,6 +823,13 @@ def main():
                  "lm_16_iterations": _truth(default_opts(n_iters=16, solver=_L.SOLVER_LM))}
         cfg_name = ("KITTI-like 640x192, batch=1 frame-pair (fwd+inv directed pairs), 4 GN iters, 6-DoF pose" if B == 1 else
                     f"KITTI-like 640x192, {B * world} frame-pairs sharded over {world} GPU(s) ({B} windows = {npairs} directed pairs per GPU and step), 4 GN iters, 6-DoF pose")
+        # how the timed steps were EXECUTED is part of the workload's name (every step is one B-window call; the calls are independent windows)
+        if merged and merged["timed"]:
+            timed_as = (f"{coal} queued B={B} calls per launch sequence (tcsfm_refine_window_queued: the library merges them into one pack / (linearise, solve) x 4 sequence "
+                        f"over {npairs * coal} directed pairs; bit-identical per window); the B={B} call on its own: `single_stream`")
+        else:
+            timed_as = f"{lanes} independent B={B} calls in flight on the handle's lanes; the B={B} call on its own: `single_stream`"
+        cfg_name += "; timed as " + timed_as
         out = {
             "metric": "optimized frame-pairs/sec at 640x192, 4 GN iters",
             "value": round(windows_per_block / elapsed, 2),
@@ -666,7 +838,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong" if args.total_windows else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
+            "config": {"workload": cfg_name, "timed_as": timed_as, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
                        "global_batch_frame_pairs": B * world, "gn_iters": ITERS, "solver": "gn", "param": "se3",
                        "steps_in_flight": (coal if (merged and merged["timed"]) else lanes), "lanes": lanes, "ring_calls": R, "ring_input_MB": round(R * call_bytes / 1e6, 1),
                        "collective_backend": backend if distributed else None, "collective_world_size": coll_world,
@@ -691,6 +863,8 @@ def main():
             "roofline": roof,
             "roofline_saturated": roof_sat,
             "cpu_baseline": cpu_baseline(args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None,
+            "modes": modes_block(args.modes_budget) if (args.modes_budget > 0 and world == 1) else None,
+            "shim": shim_block(args.shim_sample) if (args.shim_sample > 0 and world == 1) else None,
             "check": {"mean_cost_at_each_linearisation": cost_traj,
                       "rel_translation_distance_to_scene_truth": {"initial": round(err_0, 5), "refined": round(err_t, 5),
                                                                    "note": "pinhole-rendered windows: the reference's sampler is offset from the renderer, see truth_sampler_consistent"},

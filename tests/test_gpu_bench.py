@@ -21,7 +21,7 @@ def _line(out):
 
 def test_bench_single_process():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10", "--cpu-sample", "1",
-                        "--sat-windows", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--sat-windows", "4", "--modes-budget", "3", "--shim-sample", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["value"] > 100
@@ -65,6 +65,27 @@ def test_bench_single_process():
     assert d["host_enqueue_us_per_step"] > 0 and ot["host_enqueue_us_per_step"] > 0
     # the accuracy check on pairs rendered through the reference's own sampling model (the residual's minimiser is the scene truth there):
     # 4 GN iterations move the poses towards it, 16 LM iterations reach about 1 % / 0.02 degrees (tests/test_gpu_truth.py asserts the bar)
+    # the driver's own line names the timed mode, brackets ITS launches, and carries a number for every BASELINE config,
+    # for the reference-loss dense mode and for the Python shim
+    assert "timed as" in d["config"]["workload"] and d["config"]["timed_as"] in d["config"]["workload"]
+    tm = rf["timed_mode"]
+    if mg["timed"]:
+        assert "queued" in d["config"]["timed_as"] and tm["pairs_per_launch"] == 20 and 0 < tm["frac"] <= 1 and tm["launches"] >= 4
+        assert abs(tm["frac"] - tm["algorithmic_bytes_per_launch"] / tm["avg_launch_us"] * 1e-3 / 8000.0) < 1e-4
+    else:
+        assert tm is None and "lanes" in d["config"]["timed_as"]
+    md = d["modes"]
+    want = {"config4_pose_scale_8it_640x192", "kitti_window_S2_pose_reference_rule_640x192", "kitti_window_S2_reference_loss_dense_640x192",
+            "config5_dense_schur_320x240", "config5_dense_schur_448x256", "config5_reference_loss_full_320x240", "config5_reference_loss_quarter_320x240",
+            "config5_reference_loss_full_448x256", "config5_reference_loss_quarter_448x256"}
+    assert want <= set(md)
+    for k in want:
+        m = md[k]
+        assert m["us_per_call"] > 0 and m["frame_pairs_per_s"] > 100 and 0 < m["whole_call"]["frac"] <= 1 and 0 < m["dominant_kernel"]["frac"] <= 1, (k, m)
+        assert m["whole_call"]["frac"] < m["dominant_kernel"]["frac"] * 1.5 + 0.05
+    sh = d["shim"]
+    for k in ("pose", "pose_depth_reference_loss"):
+        assert sh[k]["us_per_window"] > sh[k]["engine_call_us"] > 0 and sh[k]["windows"] >= 5
     tr = d["check"]["truth_sampler_consistent"]
     assert tr["gn_4_iterations"]["translation_rel"] < 0.8 * tr["initial"]["translation_rel"]
     assert tr["lm_16_iterations"]["translation_rel"] < 0.02 and tr["lm_16_iterations"]["rotation_deg"] < 0.05

@@ -2063,7 +2063,8 @@ int tcsfm_refine_window_scale_queued(tcsfm_handle h, const tcsfm_opts *o, int B,
     if (o->host_ptrs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_queued: device pointers only");
     if (o->refine != TCSFM_REFINE_POSE_SCALE) { log_scale_in = nullptr; log_scale_out = nullptr; }
     // the REFERENCE rule couples the windows of a call through its batch normalisers: such calls are never merged with others
-    const bool mergeable = h->coal_max > 1 && o->window_rule == TCSFM_WINDOW_PAIR && !h->trace_bits && !h->trace_decide && !h->profiling;
+    // (a profile session does not stop the merging: the merged launches are bracketed like any other -- bench.py's roofline.timed_mode)
+    const bool mergeable = h->coal_max > 1 && o->window_rule == TCSFM_WINDOW_PAIR && !h->trace_bits && !h->trace_decide;
     DeviceGuard dev_guard(h->device);
     if ((rc = check_intrinsics(h, o, K, B))) return rc;            // (blocking only the first time a pointer is seen)
     if (!h->pending.empty() && (h->pend_dense || memcmp(&h->pend_opts, o, sizeof(*o)) != 0 || h->pend_B != B || h->pend_S != S ||
@@ -2086,7 +2087,7 @@ int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B,
     if (rc) return rc;
     if (!tgt || !srcs || !depth_t || !depth_s || !K || !pose_in || !pose_out || !depth_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: NULL argument");
     if (o->host_ptrs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_queued: device pointers only");
-    const bool plain = h->coal_max > 1 && o->solver == TCSFM_SOLVER_GN && o->n_iters >= 1 && o->param == TCSFM_PARAM_SE3 && !h->trace_bits && !h->trace_decide && !h->profiling;
+    const bool plain = h->coal_max > 1 && o->solver == TCSFM_SOLVER_GN && o->n_iters >= 1 && o->param == TCSFM_PARAM_SE3 && !h->trace_bits && !h->trace_decide;
     // (round 5) the reference-loss mode with fixed source maps merges too: every call is a normaliser group of its own inside the merged sequence
     const bool merge_ref = plain && o->window_rule == TCSFM_WINDOW_REFERENCE && S <= JMAXS && o->free_source_depths == 0 && o->prior_init >= 0.f && o->w_smooth >= 0.f &&
                            o->w_pose_consist == 0.f && (o->depth_param == TCSFM_DEPTH_FULL || (o->depth_param == TCSFM_DEPTH_QUARTER && h->H % 4 == 0 && h->W % 4 == 0)) &&

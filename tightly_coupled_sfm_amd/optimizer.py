@@ -109,6 +109,10 @@ class DepthOptimizer:
                           "(losses.get_smooth_loss / compute_optimization_loss still evaluate them for logging)")
         self._engine = None
         self.full_results = []
+        # measurement hook (bench.py `shim`): with time_engine the refine call inside optimize_window is bracketed by device synchronisations
+        # and its wall time left in last_engine_call_us (off by default: the synchronisations are not free)
+        self.time_engine = False
+        self.last_engine_call_us = None
 
     # -- engine / options ------------------------------------------------------------------------------------
     def _eng(self, H, W, npairs):
@@ -244,6 +248,9 @@ class DepthOptimizer:
                 opts.depth_param = _lib.DEPTH_QUARTER
             else:
                 warnings.warn("depth_param 'quarter' needs H and W to be multiples of 4: refining the full-resolution map instead")
+        if self.time_engine:
+            import time as _time
+            torch.cuda.synchronize(); _t0 = _time.perf_counter()
         if dense:
             pose, depth_ref, stats = eng.refine_dense_window(
                 target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
@@ -255,6 +262,8 @@ class DepthOptimizer:
             pose, log_scale, stats = eng.refine_window(
                 target_img.float(), [s.float() for s in source_img_list], depths[0].contiguous(), [d.contiguous() for d in depths[1:]],
                 intrinsics.float(), pose0, opts, stats=True, argmin=bool(self.options.get("diff_img_argmin", True)))
+        if self.time_engine:
+            torch.cuda.synchronize(); self.last_engine_call_us = (_time.perf_counter() - _t0) * 1e6
         if not self.options.get("l_inverse_reconstruction", True):
             # the reference then leaves the inverse direction out of its objective (optimizer.py:74-79): the inverse poses stay
             # what the pose network predicted
