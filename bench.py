@@ -354,8 +354,20 @@ def shim_block(seconds=4.0):
             calls.append(opt.last_engine_call_us)
         opt.time_engine = False
         eng_us = round(sorted(calls)[len(calls) // 2], 1)
-        res[tag] = {"us_per_window": round(dt * 1e6, 1), "windows": n, "engine_call_us": eng_us,
-                    "over_engine_call": None if not eng_us else round(dt * 1e6 / eng_us, 2)}
+        # the stand-in networks' own share (tests/standins.LookupDepth FINDS the stored map of every image by comparing images and reads the
+        # winner back to the host: it costs more than the refinement; a real network's time would stand here instead)
+        t_img, srcs_ = data[0]["color_left"], data[1]["color_left"]
+        imgs = torch.cat([t_img] + list(srcs_) + [torch.flip(t_img, [3])], 0)
+        nets = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            opt._disparities(imgs)
+            torch.cuda.synchronize(); nets.append((time.perf_counter() - t1) * 1e6)
+        net_us = round(sorted(nets)[2], 1)
+        res[tag] = {"us_per_window": round(dt * 1e6, 1), "windows": n, "engine_call_us": eng_us, "standin_depth_net_us": net_us,
+                    "shim_own_us": round(dt * 1e6 - eng_us - net_us, 1),
+                    "over_engine_call": None if not eng_us else round(dt * 1e6 / eng_us, 2),
+                    "over_engine_call_without_the_standin_depth_net": None if not eng_us else round((dt * 1e6 - net_us) / eng_us, 2)}
     res["what"] = (f"optimize_window(B={B}, S={S}, {W}x{H}, {ITER} PoseNet iterations, 4 GN iterations) with stand-in pose / depth networks (tests/standins.py: a lookup "
                    "depth net and a linear pose net, so the figure is the shim's own cost: tensor plumbing, the coupled pose initialisation, the engine call, "
                    "flip post-processing, D2H of the result dict); engine_call_us = the refine call inside it, device-synchronised, measured on its own")

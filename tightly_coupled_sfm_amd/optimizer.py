@@ -206,6 +206,27 @@ class DepthOptimizer:
         return full[:, :6].contiguous(), torch.stack(stacked, 1), imgs, d_t, d_s, K
 
     # -- the call the drivers make ------------------------------------------------------------------------------
+    def _to_host(self, named):
+        """ONE device-to-host copy for all the small outputs of a window (round 5: the per-tensor `.cpu()` calls were 17 synchronisations per
+        window): the float32 tensors are flattened into one device buffer, copied once into a pinned staging buffer, and handed back as CPU
+        tensors that own their storage (the staging buffer is reused by the next window)."""
+        keys = [k for k, v in named if v is not None]
+        flat = torch.cat([v.reshape(-1).float() for k, v in named if v is not None])
+        n = flat.numel()
+        if getattr(self, "_stage", None) is None or self._stage.numel() < n:
+            self._stage = torch.empty(max(n, 4096), dtype=torch.float32).pin_memory()
+        self._stage[:n].copy_(flat, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = self._stage[:n].clone()
+        out, o = {k: None for k, _ in named}, 0
+        for k, v in named:
+            if v is None:
+                continue
+            m = v.numel()
+            out[k] = host[o:o + m].reshape(v.shape)
+            o += m
+        return out
+
     @torch.no_grad()
     def optimize_window(self, img_idx, data):
         res = {}
@@ -220,27 +241,25 @@ class DepthOptimizer:
         eng = self._eng(H, W, 2 * split)
         cfg = self.config
 
-        imgs = torch.cat([target_img] + list(source_img_list), 0)
-        disp = self._disparities(imgs).float().contiguous()
-        disparities = [disp[i * B:(i + 1) * B] for i in range(S + 1)]
-        depths = [eng.disp_to_depth(d.contiguous(), cfg["min_depth"], cfg["max_depth"])[1] for d in disparities]
+        # ONE depth-network pass for the window's S + 1 frames AND the mirrored targets of the flip-averaged disparity (helpers.py:35-49; the
+        # reference runs that second pass after its optimisation because its network weights have moved -- here they are frozen, so the
+        # prediction is the same and the pass rides in the first batch); options['batch_flip_pass'] = False keeps two passes
+        batch_flip = bool(self.options.get("batch_flip_pass", True))
+        frames = [target_img] + list(source_img_list)
+        imgs = torch.cat(frames + ([torch.flip(target_img, [3])] if batch_flip else []), 0)
+        disp_all = self._disparities(imgs).float().contiguous()
+        sd_all, depth_all = eng.disp_to_depth(disp_all, cfg["min_depth"], cfg["max_depth"])     # scaled disparity and depth of every frame: one launch
+        depths = [depth_all[i * B:(i + 1) * B] for i in range(S + 1)]
 
         pose0, stacked0, stack_imgs, d_t, d_s, K = self._solve_pose_iteratively(
             eng, int(cfg.get("iterations", 1)), depths, target_img.float(), [s.float() for s in source_img_list], intrinsics.float())
-        res["poses_init"] = pose0[:split].cpu()
-        res["poses_inv_init"] = pose0[split:].cpu()
-        res["gt_poses"] = torch.cat(gt_lie_alg_list, 0).cpu() if gt_lie_alg_list[0] is not None else None
-        res["gt_poses_inv"] = -res["gt_poses"] if res["gt_poses"] is not None else None
         res["depths_init"] = [d.clone() for d in depths]
         unscaled = self.options.get("mode", "scaled") == "unscaled"
         # DNet ground-plane rescaling of the INITIAL depths (the reference evaluates it at epoch 0, optimizer.py:254-261)
         sf_init = (eng.scale_recovery(depths[0].contiguous(), intrinsics.float().contiguous(), cfg["camera_height"] / 30.0,
-                                      pad_to_batch=int(cfg.get("minibatch", B))).cpu() if unscaled else torch.FloatTensor([1]))
-        res["stacked_poses_init"] = stacked0[:split].cpu()
-        res["stacked_poses_inv_init"] = stacked0[split:].cpu()
+                                      pad_to_batch=int(cfg.get("minibatch", B))) if unscaled else None)
 
         opts = self._opts()
-        tgt = stack_imgs[:, 0:3].contiguous(); src = stack_imgs[:, 3:6].contiguous()
         if dense and self._dense_reference() and self.options.get("depth_param", "quarter") == "quarter":
             # the reference's own unknown (optimizer.py:194-198, 235-239): the QUARTER-resolution map, upsampled x4 for every evaluation of
             # the loss (golden G13 `qinit`); options['depth_param'] = 'full': one inverse depth per pixel
@@ -269,15 +288,11 @@ class DepthOptimizer:
             # what the pose network predicted
             pose = torch.cat([pose[:split], pose0[split:]], 0)
             stats = stats.clone(); stats[split:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6] = pose0[split:, None, :]
-        res["poses_opt"] = pose[:split].cpu()
-        res["poses_inv_opt"] = pose[split:].cpu()
         traj = stats[:, :, _lib.STAT_POSE:_lib.STAT_POSE + 6].clone()   # [2SB, gn_iters+1, 6]: the iterates (cf. train_mono.py:71-79)
         traj[:, -1] = pose            # LM: the last row is the TRIAL pose even when that step was rejected; report what was returned
         res["stacked_poses_opt"] = traj[:split]
         res["stacked_poses_inv_opt"] = traj[split:]
-        res["gn_cost"] = stats[:, :, 0].cpu()          # per pair, per linearisation (extra key)
         if log_scale is not None:
-            res["log_depth_scale"] = log_scale.cpu()
             s = torch.exp(log_scale[:split].reshape(S, B).mean(0)).reshape(B, 1, 1, 1)
             depths = [d * s for d in depths]
         if dense:
@@ -290,23 +305,46 @@ class DepthOptimizer:
             depths = [1.0 / inv_t] + [depth_ref[split + i * B: split + (i + 1) * B] for i in range(S)]
         res["depths_opt"] = depths
 
-        if unscaled:
-            # DNet ground-plane rescaling of the refined depths, optimizer.py:254-256 (self.dgc = ScaleRecovery(minibatch, 192, 640))
-            sf = eng.scale_recovery(depths[0].contiguous(), intrinsics.float().contiguous(), cfg["camera_height"] / 30.0,
-                                    pad_to_batch=int(cfg.get("minibatch", B))).cpu()
-        else:
-            sf = torch.FloatTensor([1])
-        res["scale_factor"] = sf
-        res["scale_factor_init"] = sf_init
+        # DNet ground-plane rescaling of the refined depths, optimizer.py:254-256 (self.dgc = ScaleRecovery(minibatch, 192, 640))
+        sf = (eng.scale_recovery(depths[0].contiguous(), intrinsics.float().contiguous(), cfg["camera_height"] / 30.0,
+                                 pad_to_batch=int(cfg.get("minibatch", B))) if unscaled else None)
 
-        # disparity for depth evaluation: flip-averaged prediction (helpers.py:35-49)
-        flipped = self._disparities(torch.cat((target_img, torch.flip(target_img, [3])), 0)).float().contiguous()
-        sd, _ = eng.disp_to_depth(flipped, cfg["min_depth"], cfg["max_depth"])
-        pd = sd.cpu().numpy()[:, 0]
+        # disparity for depth evaluation: flip-averaged prediction (helpers.py:35-49), blended ON THE DEVICE in float64 with the operations of
+        # batch_post_process_disparity in their order (same bits as the NumPy form): one [B,H,W] float64 copy instead of two float32 maps
+        if batch_flip:
+            sd_t, sd_f = sd_all[:B, 0], sd_all[(S + 1) * B:, 0]
+        else:
+            flipped = self._disparities(torch.cat((target_img, torch.flip(target_img, [3])), 0)).float().contiguous()
+            sd2, _ = eng.disp_to_depth(flipped, cfg["min_depth"], cfg["max_depth"])
+            sd_t, sd_f = sd2[:B, 0], sd2[B:, 0]
+        key = (W, str(sd_t.device))
+        if key not in _RAMPS:
+            _RAMPS[key] = torch.as_tensor(_flip_ramp(W), dtype=torch.float64, device=sd_t.device)
+        left = _RAMPS[key]
+        right = torch.flip(left, [0])
+        r32 = torch.flip(sd_f, [2])
+        disp_dev = 0.5 * (1.0 - left - right) * (sd_t + r32).double()      # (the float32 sum first, as the NumPy form adds two float32 arrays)
+        disp_dev += right * sd_t.double()
+        disp_dev += left * r32.double()
+
+        # everything small the drivers read on the CPU: ONE staged copy
+        gt = torch.cat(gt_lie_alg_list, 0) if gt_lie_alg_list[0] is not None else None
+        hst = self._to_host([("pose0", pose0), ("stacked0", stacked0), ("pose", pose), ("traj", traj), ("cost", stats[:, :, 0]), ("gt", gt),
+                             ("log_scale", log_scale), ("sf", sf), ("sf_init", sf_init)])
+        res["poses_init"], res["poses_inv_init"] = hst["pose0"][:split], hst["pose0"][split:]
+        res["gt_poses"] = hst["gt"]
+        res["gt_poses_inv"] = -res["gt_poses"] if res["gt_poses"] is not None else None
+        res["stacked_poses_init"], res["stacked_poses_inv_init"] = hst["stacked0"][:split], hst["stacked0"][split:]
+        res["poses_opt"], res["poses_inv_opt"] = hst["pose"][:split], hst["pose"][split:]
+        res["gn_cost"] = hst["cost"]                   # per pair, per linearisation (extra key)
+        if log_scale is not None:
+            res["log_depth_scale"] = hst["log_scale"]
+        res["scale_factor"] = hst["sf"] if unscaled else torch.FloatTensor([1])
+        res["scale_factor_init"] = hst["sf_init"] if unscaled else torch.FloatTensor([1])
         # the reference hands back a float64 CPU tensor here (avg_final_predictions adds numpy arrays into a tensor, G9)
-        res["disp_opt"] = torch.from_numpy(np.ascontiguousarray(batch_post_process_disparity(pd[:B], pd[B:, :, ::-1])))
+        res["disp_opt"] = disp_dev.cpu()
         # the demo variant of the reference optimiser (optimizer_for_cont_plot.py:27,116,270) keeps one result dict per
         # optimisation step in `full_results`; here: one per Gauss-Newton iterate
-        self.full_results = [dict(res, poses_opt=traj[:split, k].cpu(), poses_inv_opt=traj[split:, k].cpu())
-                             for k in range(1, traj.shape[1])]
+        th = hst["traj"]
+        self.full_results = [dict(res, poses_opt=th[:split, k], poses_inv_opt=th[split:, k]) for k in range(1, th.shape[1])]
         return res
