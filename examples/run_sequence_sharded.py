@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--gn-iters", type=int, default=4)
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--dump", default="")
+    ap.add_argument("--dense", action="store_true", help="pose + per-pixel inverse depth (tcsfm_refine_dense_sequence per rank): poses gathered, depth "
+                    "maps left on the rank that refined them (--gather-depths: gathered onto every rank as well)")
+    ap.add_argument("--gather-depths", action="store_true")
+    ap.add_argument("--dump-depths", default="", help="--dense: rank r writes its block of depth maps to <this>.<lo>-<hi>.npy (gathered: rank 0 writes all)")
     ap.add_argument("--odometry", type=int, default=0, metavar="ITERS",
                     help="initial poses from the coupled PoseNet loop (ITERS network evaluations per window, seeded stand-in weights) instead of --init")
     args = ap.parse_args()
@@ -70,6 +74,14 @@ def main():
         net = PoseNetHIP(eng, 2 * S * args.windows_per_call, standins.posenet_params(0))
         run = lambda: parallel.odometry_sequence_sharded(net, frames, depths, K, o, sources=S, iterations=args.odometry,
                                                          windows_per_call=args.windows_per_call)[1]
+    elif args.dense:
+        o = default_opts(n_iters=args.gn_iters, min_depth=0.03, max_depth=3.0)
+        last = {}
+        def run():
+            poses, maps, blk = parallel.refine_dense_sequence_sharded(eng, frames, depths, K, init, o, sources=S, windows_per_call=args.windows_per_call,
+                                                                      gather_depths=args.gather_depths)
+            last["maps"], last["blk"] = maps, blk
+            return poses
     else:
         run = lambda: parallel.refine_sequence_sharded(eng, frames, depths, K, init, o, sources=S, windows_per_call=args.windows_per_call)
     run()      # warm-up
@@ -80,6 +92,9 @@ def main():
     poses = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if args.dense and args.dump_depths and (rank == 0 or not args.gather_depths):
+        lo, hi = last["blk"]
+        np.save(f"{args.dump_depths}.{lo}-{hi}.npy", last["maps"].numpy())
     if rank == 0:
         assert torch.isfinite(poses).all() and tuple(poses.shape) == (args.frames - S, 2 * S, 6)
         if args.dump:

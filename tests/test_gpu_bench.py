@@ -187,6 +187,22 @@ def test_sequence_sharded_two_ranks_one_card(tmp_path):
     net = PoseNetHIP(e, 16, standins.posenet_params(0))
     _, one_odo = net.odometry_sequence(frames, depths, K, default_opts(n_iters=4), sources=2, iterations=2, windows_per_call=4)
     assert np.array_equal(np.load(dump2), one_odo.numpy())
+    # the DENSE mode of the sequence over two ranks -- poses gathered, every rank keeps (and writes) the depth maps of its
+    # block; and gathered onto rank 0: poses and every pixel of every map equal to the single-process tcsfm_refine_dense_sequence
+    import glob
+    od = default_opts(n_iters=4, min_depth=0.03, max_depth=3.0)
+    one_p, one_d = e.refine_dense_sequence(frames, depths, K, init, od, sources=2, windows_per_call=4)
+    for extra in ([], ["--gather-depths"]):
+        dump3, dd = str(tmp_path / f"dense{len(extra)}.npy"), str(tmp_path / f"maps{len(extra)}")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port())] + common[:-1] + [dump3, "--dense", "--dump-depths", dd] + extra, capture_output=True, text=True,
+                           timeout=600, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert np.array_equal(np.load(dump3), one_p.numpy())
+        files = sorted(glob.glob(dd + ".*.npy"), key=lambda f: int(os.path.basename(f).split(".")[1].split("-")[0]))
+        assert len(files) == (1 if extra else 2)
+        maps = np.concatenate([np.load(f) for f in files])
+        assert maps.shape == tuple(one_d.shape) and np.array_equal(maps, one_d.numpy())
     # the pair-form helper on the real engine (single process: the gather is the identity)
     from tightly_coupled_sfm_amd import synth
     b = synth.make_batch(6, 96, 320, seed0=5, both_directions=True)

@@ -101,3 +101,45 @@ def test_sequence_sharded_gloo_world2(T, S, wpc):
         mp.spawn(_seq_worker, args=(world, port, T, S, wpc, ret), nprocs=world, join=True)
         assert all(ret[r][0] for r in range(world)), dict(ret)
         assert ret[0][1] == 0 and ret[0][2] == ret[1][1] and ret[1][2] == T - S and (ret[0][2] % wpc == 0 or ret[0][2] == T - S)
+
+
+def _dense_seq_worker(rank, world, port, T, S, wpc, gather, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tightly_coupled_sfm_amd import parallel as P
+    g = torch.Generator().manual_seed(1)
+    Hh, Ww = 4, 6
+    frames = torch.rand((T, 3, Hh, Ww), generator=g); depths = torch.rand((T, 1, Hh, Ww), generator=g) + 0.5
+    init = torch.rand((T - S, 2 * S, 6), generator=g)
+
+    def fake_dense(fr, dp, K, p0, opts, sources, windows_per_call, target_pos):
+        # poses and maps of a window depend on exactly its own S + 1 frames and initial poses -- like the real loop
+        n = p0.shape[0]
+        w = torch.stack([fr[i:i + sources + 1].sum() + dp[i:i + sources + 1].sum() for i in range(n)])
+        maps = torch.stack([torch.stack([dp[i + (j % (sources + 1))] * (1.0 + 0.01 * j) + w[i] for j in range(2 * sources)]) for i in range(n)])
+        return p0 * 2 + w[:, None, None], maps
+
+    poses, maps, (lo_r, hi_r) = P.refine_dense_sequence_sharded(None, frames, depths, None, init, None, sources=S, windows_per_call=wpc,
+                                                                gather_depths=gather, refine_fn=fake_dense)
+    full_p, full_d = fake_dense(frames, depths, None, init, None, S, wpc, 0)
+    lo, hi = P.sequence_block(T - S, rank, world, wpc)
+    ok = torch.equal(poses, full_p)
+    if gather:
+        ok = ok and (lo_r, hi_r) == (0, T - S) and torch.equal(maps, full_d)
+    else:
+        ok = ok and (lo_r, hi_r) == (lo, hi) and torch.equal(maps, full_d[lo:hi]) and tuple(maps.shape) == (hi - lo, 2 * S, 1, Hh, Ww)
+    ret[rank] = (bool(ok), lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,S,wpc,gather", [(21, 1, 8, False), (21, 1, 8, True), (12, 2, 4, True), (4, 2, 8, False), (30, 1, 1, True)])
+def test_dense_sequence_sharded_gloo_world2(T, S, wpc, gather):
+    """VERDICT r04 #6 / SURVEY 8e: the dense mode of a sequence over two ranks -- poses by all_gather, depth maps left per rank with their
+    window range or gathered (the caller's choice) -- equal to the single-process loop bit for bit"""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_dense_seq_worker, args=(world, port, T, S, wpc, gather, ret), nprocs=world, join=True)
+        assert all(ret[r][0] for r in range(world)), dict(ret)
+        assert ret[0][1] == 0 and ret[0][2] == ret[1][1] and ret[1][2] == T - S

@@ -11,6 +11,11 @@ only the frames of its block plus the S frames its last window reaches into (the
 library's own window loop (tcsfm_refine_sequence) on its block, and ONE all_gather of [windows, 2S, 6] puts the trajectory
 together.  Under the default window rule the result is bit-identical to the single-process sequence whatever the number of
 ranks (windows are independent problems and a block is a whole number of calls of `windows_per_call` windows).
+
+Round 5: `refine_dense_sequence_sharded` does the same for the dense mode (BASELINE config 5: pose + per-pixel inverse depth): the poses
+are gathered as above, the refined depth maps -- [windows, 2S, 1, H, W] fp32, 31 MB for 64 KITTI windows (SURVEY 8e "optional depth maps")
+-- either stay on the rank that refined them (returned with the block's window range: the caller that streams them to disk needs no
+collective at all) or are gathered onto every rank with a second all_gather, the caller's choice.
 """
 from __future__ import annotations
 
@@ -139,3 +144,43 @@ def odometry_sequence_sharded(net, frames: torch.Tensor, depths: torch.Tensor, K
         local = torch.zeros((0, 4 * S * 6), dtype=torch.float32)
     both = _gather_window_blocks(local, n_win, 4 * S * 6, windows_per_call, world, group, gather_device)
     return both[:, : 2 * S * 6].reshape(n_win, 2 * S, 6), both[:, 2 * S * 6:].reshape(n_win, 2 * S, 6)
+
+
+def refine_dense_sequence_sharded(engine, frames: torch.Tensor, depths: torch.Tensor, K, init_poses: torch.Tensor, opts=None, sources: int = 1,
+                                  windows_per_call: int = 8, target_pos: int = 0, gather_depths: bool = False, group=None,
+                                  gather_device: Optional[torch.device] = None, refine_fn: Optional[Callable[..., Tuple[torch.Tensor, torch.Tensor]]] = None):
+    """tcsfm_refine_dense_sequence (the reference's sequential driver with `optimize_depth_pred`: optimizer.py:289-297 returns `depths_opt`,
+    run_sequential_optimization.py:195-216 reads `disp_opt`) over all ranks of `group`: blocks of whole calls + S overlap frames per rank as
+    refine_sequence_sharded.  Arguments as there.
+
+    -> (poses [T-S, 2S, 6] on every rank, depth maps, (lo, hi)):
+       gather_depths = False (default): depth maps = THIS rank's block [hi - lo, 2S, 1, H, W] (CPU) and (lo, hi) says which windows they
+         are -- no collective beyond the bytes-scale pose gather (a driver that writes the maps out per rank, as 8 independent writers);
+       gather_depths = True: depth maps = all [T-S, 2S, 1, H, W] on every rank -- a second all_gather of world x block x 2S x H x W floats
+         (31 MB in all for BASELINE config 3's 64 windows at 640x192; over xGMI a few hundred microseconds), (lo, hi) = (0, T-S).
+    Under the default window rule every window is an independent problem and a block is a whole number of calls: poses AND maps are
+    bit-identical to the single-process tcsfm_refine_dense_sequence whatever the number of ranks.
+    refine_fn: stand-in for engine.refine_dense_sequence (CPU tests).  Unmeasured on multi-GPU hardware (the builder has one GPU)."""
+    T, S = int(frames.shape[0]), int(sources)
+    n_win = T - S
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    lo, hi = sequence_block(n_win, rank, world, windows_per_call)
+    Hh, Ww = int(frames.shape[2]), int(frames.shape[3])
+    if hi > lo:
+        run = refine_fn or engine.refine_dense_sequence
+        local_p, local_d = run(frames[lo:hi + S], depths[lo:hi + S], K, init_poses[lo:hi], opts, sources=S, windows_per_call=windows_per_call,
+                               target_pos=target_pos)
+        local_p = torch.as_tensor(local_p).reshape(hi - lo, 2 * S * 6)
+        local_d = torch.as_tensor(local_d).reshape(hi - lo, 2 * S, 1, Hh, Ww)
+    else:
+        local_p = torch.zeros((0, 2 * S * 6), dtype=torch.float32)
+        local_d = torch.zeros((0, 2 * S, 1, Hh, Ww), dtype=torch.float32)
+    poses = _gather_window_blocks(local_p, n_win, 2 * S * 6, windows_per_call, world, group, gather_device).reshape(n_win, 2 * S, 6)
+    if not gather_depths or world == 1:
+        return poses, local_d, ((lo, hi) if world > 1 else (0, n_win))
+    width = 2 * S * Hh * Ww
+    maps = _gather_window_blocks(local_d.reshape(hi - lo, width), n_win, width, windows_per_call, world, group, gather_device)
+    return poses, maps.reshape(n_win, 2 * S, 1, Hh, Ww), (0, n_win)
