@@ -422,7 +422,10 @@ def main():
         raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
-    from tightly_coupled_sfm_amd import _lib as _hip_env_defaults    # noqa: F401  (HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES defaults: before HIP initialises)
+    # this application owns its process: it sets the two HIP runtime variables the launch structure likes BEFORE HIP initialises (the package
+    # itself no longer touches the environment on import: tightly_coupled_sfm_amd/_lib.py)
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 
@@ -850,7 +853,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong" if args.total_windows else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg_name, "timed_as": timed_as, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
+            "config": {"workload": cfg_name, "timed_as": timed_as, "lane_probe": eng.lane_probe() if lanes > 1 else None, "windows_per_gpu": B, "sources": SOURCES, "directed_pairs_per_step": npairs,
                        "global_batch_frame_pairs": B * world, "gn_iters": ITERS, "solver": "gn", "param": "se3",
                        "steps_in_flight": (coal if (merged and merged["timed"]) else lanes), "lanes": lanes, "ring_calls": R, "ring_input_MB": round(R * call_bytes / 1e6, 1),
                        "collective_backend": backend if distributed else None, "collective_world_size": coll_world,

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd import synth                                    # noqa: E402
 from tightly_coupled_sfm_amd.optimizer import DepthOptimizer                  # noqa: E402
 from tightly_coupled_sfm_amd.validate import compute_trajectory               # noqa: E402

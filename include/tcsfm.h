@@ -366,6 +366,12 @@ int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter
  *                            input buffers: tcsfm_stream_wait_event(stream, mark) makes e.g. their copy stream wait, on the
  *                            device, until the lane has consumed the buffer */
 int tcsfm_set_lanes(tcsfm_handle h, int n_lanes);
+/* Round 5: tcsfm_set_lanes MEASURES whether this process's streams run side by side (16 launches of a stand-in kernel on one stream, then
+ * alternating over two; ~0.5 ms).  If they do not -- the hazard above -- the handle falls back: lane calls (tcsfm_refine_window_async, the
+ * sequence calls, the merged sequences' second stream) run on the handle's own stream, one after the other, results unchanged, one line on
+ * stderr.  tcsfm_lane_probe reports the outcome: *serial = 1 when the fallback is active, and the two probe times in ms.  The queued calls
+ * (tcsfm_set_coalesce) keep the chip busy either way.  TCSFM_LANE_PROBE=0 in the environment skips the probe. */
+int tcsfm_lane_probe(tcsfm_handle h, int *serial, float *one_stream_ms, float *two_streams_ms);
 int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
                               const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);

@@ -1,6 +1,7 @@
 import sys, time, json
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 for H, W in ((240, 320), (256, 448)):

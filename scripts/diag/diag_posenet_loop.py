@@ -4,6 +4,7 @@ import numpy as np, torch
 import standins
 from conftest import load_golden
 from oracle.oracle import Oracle
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd.engine import Engine
 from tightly_coupled_sfm_amd.posenet import PoseNetHIP
 g = load_golden("posenet")

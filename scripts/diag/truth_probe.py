@@ -1,5 +1,6 @@
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd import synth, _lib
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 H, W = 192, 640

@@ -8,6 +8,7 @@ CHILD = r'''
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, %r)
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 H, W = 192, 640

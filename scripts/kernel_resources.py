@@ -4,6 +4,7 @@ demangled name, VGPRs, AGPRs, scratch bytes, spills, LDS bytes, occupancy.    py
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd import build as B
 cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-Rpass-analysis=kernel-resource-usage"] + B.FLAGS + [B.SRC, "-o", "/tmp/_tcsfm_res.so"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr

@@ -13,6 +13,7 @@ of them overlap, rocprofv3 kernel trace), not the memory layout.  The mechanism 
 identified; the library creates plain non-blocking streams and the documentation tells callers to create the handle after their
 first device work."""
 import os, subprocess, sys, time
+os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = ("engine_first", "touch_first", "data_first", "engine_first_burn")
 

@@ -17,6 +17,7 @@ Instruction classes and their cost in clocks per wave-instruction per SIMD come 
 """
 import argparse, collections, json, os, re, subprocess, sys, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (a measurement script owns its process: HIP_FORCE_DEV_KERNARG / GPU_MAX_HW_QUEUES when absent)
 from tightly_coupled_sfm_amd.build import FLAGS
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -151,24 +151,27 @@ def test_liegroups_stand_in(lib, oracle64):
     assert np.allclose(SE3.exp(rel.log()).as_matrix(), rel.as_matrix(), atol=1e-12)
 
 
-def test_runtime_environment_defaults():
-    """importing the binding sets the two HIP runtime defaults the launch structure depends on -- when the caller has not set them"""
+def test_runtime_environment_untouched_by_default():
+    """VERDICT r04 #7: importing the binding leaves the process environment alone (the variables are process-wide: torch and RCCL see them)"""
     import subprocess, sys
-    code = ("import os\nfor k in ('HIP_FORCE_DEV_KERNARG', 'GPU_MAX_HW_QUEUES'): os.environ.pop(k, None)\n"
-            "from tightly_coupled_sfm_amd import _lib\nprint(os.environ['HIP_FORCE_DEV_KERNARG'], os.environ['GPU_MAX_HW_QUEUES'])\n"
-            "os.environ['GPU_MAX_HW_QUEUES'] = '2'\nimport importlib; importlib.reload(_lib)\nprint(os.environ['GPU_MAX_HW_QUEUES'])")
-    out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO, text=True).split()
-    assert out == ["1", "8", "2"]          # defaults when absent; a caller's own setting is kept
-
-
-def test_runtime_environment_defaults_opt_out():
-    """TCSFM_NO_ENV_DEFAULTS=1 leaves the process environment alone (the variables are process-wide: torch and RCCL see them)"""
-    import subprocess, sys
-    code = ("import os\nfor k in ('HIP_FORCE_DEV_KERNARG', 'GPU_MAX_HW_QUEUES'): os.environ.pop(k, None)\n"
-            "os.environ['TCSFM_NO_ENV_DEFAULTS'] = '1'\nfrom tightly_coupled_sfm_amd import _lib\n"
+    code = ("import os\nfor k in ('HIP_FORCE_DEV_KERNARG', 'GPU_MAX_HW_QUEUES', 'TCSFM_SET_ENV_DEFAULTS'): os.environ.pop(k, None)\n"
+            "from tightly_coupled_sfm_amd import _lib\n"
             "print('HIP_FORCE_DEV_KERNARG' in os.environ, 'GPU_MAX_HW_QUEUES' in os.environ, _lib.ENV_APPLIED)")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO, text=True).split()
     assert out == ["False", "False", "{}"]
+
+
+def test_runtime_environment_defaults_opt_in():
+    """TCSFM_SET_ENV_DEFAULTS=1 (or _lib.apply_env_defaults()) sets the two HIP runtime defaults the launch structure likes -- when the caller
+    has not set them; a caller's own setting is kept"""
+    import subprocess, sys
+    code = ("import os\nfor k in ('HIP_FORCE_DEV_KERNARG', 'GPU_MAX_HW_QUEUES'): os.environ.pop(k, None)\n"
+            "os.environ['TCSFM_SET_ENV_DEFAULTS'] = '1'\n"
+            "from tightly_coupled_sfm_amd import _lib\nprint(os.environ['HIP_FORCE_DEV_KERNARG'], os.environ['GPU_MAX_HW_QUEUES'])\n"
+            "os.environ['GPU_MAX_HW_QUEUES'] = '2'\nimport importlib; importlib.reload(_lib)\nprint(os.environ['GPU_MAX_HW_QUEUES'])\n"
+            "del os.environ['TCSFM_SET_ENV_DEFAULTS']; os.environ.pop('HIP_FORCE_DEV_KERNARG')\n_lib.apply_env_defaults(); print(os.environ['HIP_FORCE_DEV_KERNARG'])")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=REPO, text=True).split()
+    assert out == ["1", "8", "2", "1"]
 
 
 def test_engine_set_lanes_updates_attribute():

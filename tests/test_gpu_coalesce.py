@@ -254,3 +254,53 @@ def test_merged_pose_scale_calls_are_bit_identical_to_single_calls():
         assert torch.equal(p, wp) and torch.equal(q, wl)
     assert float(torch.stack(lo).abs().max()) > 1e-4
     e.set_coalesce_lanes(1); e.set_coalesce(0)
+
+
+def test_lanes_are_probed_and_safe_when_the_handle_comes_first():
+    """a handle created BEFORE the process's first device work used to give lanes that were slower than one stream.
+    tcsfm_set_lanes now measures whether the streams overlap and falls back to the handle's own stream when they do not: in a fresh process
+    that creates Engine(..., lanes=4) before anything else touches the card, four lanes are never slower than one call in flight"""
+    import os, subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, os, sys, time
+sys.path.insert(0, %r)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1"); os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+from tightly_coupled_sfm_amd.engine import Engine, default_opts
+from tightly_coupled_sfm_amd import synth
+H, W = 192, 640
+e = Engine(H, W, 2, lanes=4)                      # the handle and its lanes FIRST: no upload, no kernel so far
+probe = e.lane_probe()
+e.use_own_stream()
+ws = []
+for j in range(8):
+    b = synth.make_batch(2, H, W, seed0=11 * j, both_directions=True)
+    d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
+    ws.append(dict(tgt=d["tgt"][0::2].contiguous(), srcs=d["src"][0::2].contiguous()[None], dt=d["depth_t"][0::2].contiguous(), ds=d["depth_s"][0::2].contiguous()[None],
+                   K=d["K"][0::2].contiguous(), pose=torch.cat([d["pose_init"][0::2], d["pose_init"][1::2]]).contiguous(), out=torch.zeros(2, 6, device="cuda")))
+for w in ws: w["K"] = ws[0]["K"]
+o = default_opts(n_iters=4)
+def run(nl, n):
+    for k in range(n):
+        w = ws[k %% 8]
+        e.refine_window_async(k %% nl, w["tgt"], w["srcs"], w["dt"], w["ds"], w["K"], w["pose"], w["out"], o)
+    for l in range(4): e.lane_synchronize(l)
+def rate(nl):
+    run(nl, 40); torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        t0 = time.perf_counter(); run(nl, 200); torch.cuda.synchronize(); best = max(best, 200 / (time.perf_counter() - t0))
+    return best
+r1 = rate(1); outs1 = [w["out"].clone() for w in ws]
+r4 = rate(4); same = all(torch.equal(a, w["out"]) for a, w in zip(outs1, ws))
+print(json.dumps({"probe": probe, "one": r1, "four": r4, "same": same}))
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["same"] is True
+    assert d["probe"]["one_stream_us"] > 0 and d["probe"]["two_streams_us"] > 0
+    assert d["four"] >= 0.9 * d["one"], d                      # lanes never lose (they overlap, or the probe switched them off)
+    if d["probe"]["serial"]:
+        assert "lanes do not overlap" in r.stderr

@@ -5,9 +5,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-# Process-wide HIP runtime defaults.  Both variables are read by HIP at the process's FIRST HIP call and they affect every HIP user
-# of the process (torch, RCCL), not only this library: they are set here only when absent, and TCSFM_NO_ENV_DEFAULTS=1 leaves the
-# environment untouched (README "Runtime environment").
+# Process-wide HIP runtime settings this library's launch structure likes.  Both variables are read by HIP at the process's FIRST HIP call
+# and they affect every HIP user of the process (torch, RCCL), not only this library -- so importing the package does NOT touch the
+# environment (round 5; it used to set them when absent): export them yourself, or ask for it with TCSFM_SET_ENV_DEFAULTS=1 (then they are
+# set when absent, as before).  Without them the package says once what is being left on the table (README "Runtime environment").
 #  * HIP_FORCE_DEV_KERNARG=1 -- a refinement is a chain of short dependent kernels: kernel arguments must sit in device memory
 #    (with 0 every launch fetches them over PCIe and a B=1 call takes 90 us instead of 72 us).
 #  * GPU_MAX_HW_QUEUES=8 -- lanes (several refinements in flight, include/tcsfm.h) are HIP streams, and this ROCm maps a process's
@@ -24,9 +25,14 @@ def _hip_initialised() -> bool:
     return t is not None and getattr(t, "cuda", None) is not None and t.cuda.is_initialized()
 
 
-def _apply_env_defaults():
+def apply_env_defaults():
+    """set the two HIP defaults when absent (what TCSFM_SET_ENV_DEFAULTS=1 does at import): for applications that own their process, e.g. bench.py"""
+    _apply_env_defaults(force=True)
+
+
+def _apply_env_defaults(force=False):
     import warnings
-    if os.environ.get("TCSFM_NO_ENV_DEFAULTS", "0") not in ("", "0"):
+    if not force and os.environ.get("TCSFM_SET_ENV_DEFAULTS", "0") in ("", "0"):
         return
     late = _hip_initialised()
     for k, v in ENV_DEFAULTS.items():
@@ -43,8 +49,27 @@ def _apply_env_defaults():
                       "refinement) run ~17 % slower with kernel arguments in host memory", RuntimeWarning)
 
 
+_HINTED = set()
+
+
+def hint_env(lanes: int = 1):
+    """Engine creation / Engine.set_lanes: say ONCE per process what an unset variable leaves on the table (nothing is changed)"""
+    import warnings
+    if os.environ.get("HIP_FORCE_DEV_KERNARG") != "1" and "kernarg" not in _HINTED:
+        _HINTED.add("kernarg")
+        warnings.warn("tightly_coupled_sfm_amd: HIP_FORCE_DEV_KERNARG=1 is not set: chains of short kernels (a B=1 refinement) run ~17 % slower with "
+                      "kernel arguments in host memory (90 vs 72 us per call measured) -- export it before the process first touches the GPU, or set "
+                      "TCSFM_SET_ENV_DEFAULTS=1 and import this package first", RuntimeWarning)
+    if lanes > 2 and "GPU_MAX_HW_QUEUES" not in os.environ and "queues" not in _HINTED:
+        _HINTED.add("queues")
+        warnings.warn(f"tightly_coupled_sfm_amd: {lanes} lanes requested and GPU_MAX_HW_QUEUES is not set: HIP maps a process's streams onto four hardware "
+                      "queues and lanes that share one run one after the other -- export GPU_MAX_HW_QUEUES=8 before the process first touches the GPU",
+                      RuntimeWarning)
+
+
 def warn_if_queues_late(lanes: int):
     """Engine.set_lanes: more than two lanes only run side by side on more than HIP's default four hardware queues"""
+    hint_env(lanes)
     if lanes > 2 and ENV_APPLIED.get("GPU_MAX_HW_QUEUES") is False:
         import warnings
         warnings.warn(f"tightly_coupled_sfm_amd: {lanes} lanes requested, but the GPU was initialised before this package was imported and "
@@ -77,6 +102,7 @@ NSTAT = 10        # cost, cost_photo, n_mask, lambda, pose[6]  (include/tcsfm.h 
 
 _P = C.c_void_p
 _SIGNATURES = {
+    "tcsfm_lane_probe": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tcsfm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int]),
     "tcsfm_destroy": (None, [_P]),
     "tcsfm_last_error": (C.c_char_p, [_P]),

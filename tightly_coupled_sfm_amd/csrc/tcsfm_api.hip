@@ -104,6 +104,9 @@ struct tcsfm_ctx {
     struct PendingCall { const float *tgt, *srcs, *dt, *ds, *K, *pose_in; float *pose_out; float *depth_out; const float *ls_in; float *ls_out; };
                                        // depth_out: dense calls; ls_in / ls_out: pose + scale calls (or null)
     float *dref_smooth = nullptr;      // l_smooth: [targets][2] mean of the sigmoid disparity, the target's whole term (k_dref_smooth)
+    bool lanes_serial = false;         // tcsfm_set_lanes' self-probe found that this process's streams do NOT run side by side (they slow each other
+                                       // down: include/tcsfm.h "lanes"): the *_async calls run on the handle's own stream, one after the other
+    float lane_probe[2] = {0.f, 0.f};  // the probe's figures: ms of the stand-in launches on ONE stream / alternating over TWO streams
     bool dref_dirty = true;            // the scatter sums (dref_ext, dref_ext_src) may be non-zero: a call that ran to its end leaves them zero
                                        // (k_dense_joint clears what it consumes); a fresh allocation, an export or a failed call does not
     // free source depth maps (opts.free_source_depths): the inverse pairs as groups of one source
@@ -1970,7 +1973,7 @@ static int flush_pending(tcsfm_ctx *h) {
     // merged sequences alternate over coal_lanes streams (tcsfm_set_coalesce_lanes): sequence k runs on lane k mod coal_lanes, behind
     // everything queued on the handle's stream so far; the short tail kernels of one sequence (k_solve: 20 workgroups, 6 us) then
     // overlap the other's chip-filling launches.  tcsfm_flush / tcsfm_synchronize order the handle's stream behind them.
-    const int nl = std::min(h->coal_lanes, (int)h->lanes.size() + 1), l = nl > 1 ? h->coal_batches % nl : 0;
+    const int nl = h->lanes_serial ? 1 : std::min(h->coal_lanes, (int)h->lanes.size() + 1), l = nl > 1 ? h->coal_batches % nl : 0;
     tcsfm_ctx *c = l == 0 ? h : h->lanes[l - 1];
     h->coal_batches++; h->coal_calls += n;
     if (c != h) {
@@ -2161,6 +2164,60 @@ int tcsfm_linearize_dense_window_sources(tcsfm_handle h, const tcsfm_opts *o, in
     return linearize_dense_window_impl(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose, depth0, scal_out, g_pose_out, g_rho_out, g_rho_src_out);
 }
 
+// ---- lane self-probe.  MEASURED HAZARD (round 4): how well the streams of a process run side by side depends on the order
+// in which the process created them -- a handle created before the process's first device work gave four lanes that were SLOWER than one
+// (kernels of two overlapping lanes 40-55 us instead of 11).  The mechanism inside the runtime was not identified, so the library measures:
+// 16 launches of a stand-in kernel (480 workgroups of ~10 us of arithmetic: two of them fit the chip side by side) on the handle's stream,
+// then the same 16 alternating over the handle's stream and lane 1.  Streams that overlap finish the second run in about half the time of
+// the first; streams in the bad state take as long or longer.  ~0.5 ms, once per tcsfm_set_lanes.
+__global__ __launch_bounds__(256) void k_lane_probe(float *out, int iters) {
+    float a = (float)threadIdx.x * 1e-3f, b = 1.0001f;
+    for (int i = 0; i < iters; i++) { a = a * b + 1e-7f; b = b * 0.99999f + 1e-6f; }
+    if (a == 123.456f) out[0] = a + b;           // (never true: keeps the loop)
+}
+static int probe_lanes(tcsfm_ctx *h) {
+    h->lanes_serial = false;
+    if (h->lanes.empty()) return TCSFM_OK;
+    if (const char *e = getenv("TCSFM_LANE_PROBE")) { if (atoi(e) == 0) return TCSFM_OK; }
+    tcsfm_ctx *c = h->lanes[0];
+    hipStream_t s0 = h->own_stream, s1 = c->own_stream;
+    hipEvent_t ev[4];
+    for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
+    float *sink = h->pose_dev;
+    const int iters = 6000, rounds = 16;
+    auto run = [&](bool two, float *ms) -> int {
+        for (int w = 0; w < 2; w++) {             // (first pass: warm-up)
+            HIPCHK(h, hipStreamSynchronize(s0)); HIPCHK(h, hipStreamSynchronize(s1));
+            HIPCHK(h, hipEventRecord(ev[0], s0));
+            if (two) { HIPCHK(h, hipEventRecord(ev[2], s0)); HIPCHK(h, hipStreamWaitEvent(s1, ev[2], 0)); }
+            for (int k = 0; k < rounds; k++) hipLaunchKernelGGL(k_lane_probe, dim3(480), dim3(256), 0, (two && (k & 1)) ? s1 : s0, sink, iters);
+            if (two) { HIPCHK(h, hipEventRecord(ev[3], s1)); HIPCHK(h, hipStreamWaitEvent(s0, ev[3], 0)); }
+            HIPCHK(h, hipEventRecord(ev[1], s0));
+            HIPCHK(h, hipEventSynchronize(ev[1]));
+            HIPCHK(h, hipEventElapsedTime(ms, ev[0], ev[1]));
+        }
+        return TCSFM_OK;
+    };
+    int rc = run(false, &h->lane_probe[0]);
+    if (!rc) rc = run(true, &h->lane_probe[1]);
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (rc) return rc;
+    if (h->lane_probe[1] > 0.9f * h->lane_probe[0]) {
+        h->lanes_serial = true;
+        fprintf(stderr, "tcsfm: lanes do not overlap in this process (probe: %.0f us on one stream, %.0f us over two): lane calls run on the handle's own "
+                        "stream; use the queued calls (tcsfm_set_coalesce) to keep the chip busy\n", h->lane_probe[0] * 1e3, h->lane_probe[1] * 1e3);
+    }
+    return TCSFM_OK;
+}
+
+int tcsfm_lane_probe(tcsfm_handle h, int *serial, float *one_stream_ms, float *two_streams_ms) {
+    if (!h) return TCSFM_E_ARG;
+    if (serial) *serial = h->lanes_serial ? 1 : 0;
+    if (one_stream_ms) *one_stream_ms = h->lane_probe[0];
+    if (two_streams_ms) *two_streams_ms = h->lane_probe[1];
+    return TCSFM_OK;
+}
+
 int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
     if (!h) return TCSFM_E_ARG;
     if (n_lanes < 1 || n_lanes > 8) return fail(h, TCSFM_E_ARG, "tcsfm_set_lanes: 1 <= n_lanes <= 8");
@@ -2180,7 +2237,7 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes) {
         c->graph_slots = h->graph_slots;
         h->lanes.push_back(c);
     }
-    return TCSFM_OK;
+    return probe_lanes(h);
 }
 
 int tcsfm_set_graph_replay(tcsfm_handle h, int max_graphs) {
@@ -2214,7 +2271,7 @@ int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int
     tcsfm_ctx *c = lane_of(h, lane);
     if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_refine_window_async: no such lane (tcsfm_set_lanes)") : TCSFM_E_ARG;
     if (o && o->host_ptrs == 1) return fail(h, TCSFM_E_ARG, "tcsfm_refine_window_async: host_ptrs must be 0 (device) or 2 (pinned host, asynchronous)");
-    if (c == h) return tcsfm_refine_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
+    if (c == h || h->lanes_serial) return tcsfm_refine_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, log_scale_in, pose_out, log_scale_out, stats_out);
     DeviceGuard dev_guard(h->device);
     // the lane starts behind everything queued on the parent's stream so far (the producers of the caller's device buffers) ...
     HIPCHK(h, hipEventRecord(c->in_ev, h->stream));
@@ -2234,7 +2291,7 @@ int tcsfm_refine_dense_window_async(tcsfm_handle h, int lane, const tcsfm_opts *
     tcsfm_ctx *c = lane_of(h, lane);
     if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_async: no such lane (tcsfm_set_lanes)") : TCSFM_E_ARG;
     if (o && o->host_ptrs == 1) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window_async: host_ptrs must be 0 (device) or 2 (pinned host, asynchronous)");
-    if (c == h) return tcsfm_refine_dense_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
+    if (c == h || h->lanes_serial) return tcsfm_refine_dense_window(h, o, B, S, tgt, srcs, depth_t, depth_s, K, pose_in, pose_out, depth_out, stats_out);
     DeviceGuard dev_guard(h->device);
     HIPCHK(h, hipEventRecord(c->in_ev, h->stream));
     HIPCHK(h, hipStreamWaitEvent(c->own_stream, c->in_ev, 0));
@@ -2261,7 +2318,7 @@ static int sequence_impl(tcsfm_handle h, const tcsfm_opts *o_in, int T, int S, c
     if (int rc_q = drain_queued(h)) return rc_q;
     if (!h) return TCSFM_E_ARG;
     if (!o_in) return fail(h, TCSFM_E_ARG, "opts is NULL");
-    const int N = 2 * S, L = (int)h->lanes.size() + 1;
+    const int N = 2 * S, L = h->lanes_serial ? 1 : (int)h->lanes.size() + 1;
     if (S < 1 || T <= S || N > h->max_pairs) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: need S >= 1, T > S and 2*S <= max_pairs");
     if (!frames || !depths || !K || (!pose_init && !pn) || !pose_out) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: NULL input");
     if (windows_per_call < 0) return fail(h, TCSFM_E_ARG, "tcsfm_refine_sequence: windows_per_call < 0");
@@ -2535,7 +2592,7 @@ int tcsfm_lane_event(tcsfm_handle h, int lane, void **event_out) {
     }
     hipEvent_t e = c->marks[c->mark_next];
     c->mark_next = (c->mark_next + 1) % kMarks;
-    HIPCHK(h, hipEventRecord(e, c == h ? h->stream : c->own_stream));
+    HIPCHK(h, hipEventRecord(e, (c == h || h->lanes_serial) ? h->stream : c->own_stream));      // (serial lanes: the lane's calls ran on the handle's stream)
     *event_out = (void *)e;
     return TCSFM_OK;
 }
@@ -2551,8 +2608,9 @@ int tcsfm_lane_synchronize(tcsfm_handle h, int lane) {
     tcsfm_ctx *c = lane_of(h, lane);
     if (!c) return h ? fail(h, TCSFM_E_ARG, "tcsfm_lane_synchronize: no such lane") : TCSFM_E_ARG;
     DeviceGuard dev_guard(h->device);
-    HIPCHK(h, hipStreamSynchronize(c == h ? h->stream : c->own_stream));
+    HIPCHK(h, hipStreamSynchronize((c == h || h->lanes_serial) ? h->stream : c->own_stream));
     if (int rc = pending_error(c)) { h->err = c->err; return rc; }
+    if (h->lanes_serial) return pending_error(h);
     return TCSFM_OK;
 }
 

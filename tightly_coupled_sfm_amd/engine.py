@@ -52,7 +52,9 @@ class Engine:
             raise RuntimeError(f"tcsfm_create failed ({rc}): {self.lib.tcsfm_last_error(None).decode()}")
         self._h = h
         self.lanes = 1
+        self.lanes_serial = False
         self.use_torch_stream()
+        _lib.hint_env(lanes)
         if lanes > 1:
             self.set_lanes(lanes)
 
@@ -425,6 +427,14 @@ class Engine:
         _lib.warn_if_queues_late(int(n))
         self._call(self.lib.tcsfm_set_lanes(self._h, int(n)))
         self.lanes = int(n)
+        self.lanes_serial = self.lane_probe()["serial"]
+
+    def lane_probe(self):
+        """tcsfm_lane_probe: what tcsfm_set_lanes measured -- {'serial': the streams of this process do not run side by side and lane calls
+        fall back to the handle's own stream, 'one_stream_us', 'two_streams_us': the probe's 16 stand-in launches}"""
+        s_, a, b = C.c_int(0), C.c_float(0), C.c_float(0)
+        self._call(self.lib.tcsfm_lane_probe(self._h, C.byref(s_), C.byref(a), C.byref(b)))
+        return {"serial": bool(s_.value), "one_stream_us": round(a.value * 1e3, 1), "two_streams_us": round(b.value * 1e3, 1)}
 
     def set_graph_replay(self, max_graphs: int = 4):
         """tcsfm_set_graph_replay: repeated device-pointer refine calls (same tensors, same options) are captured once and
