@@ -61,6 +61,7 @@ struct JointParams {
     // the scattered sums then come from the FORWARD pairs' samples of that map, in units of ext_c / ext_norm[0] = the forward factor a_f
     const int *ext_norm;     // null: the photometric part of ext2 carries the inverse term's factor 0.25 / K_i; else ext_c / ext_norm[0]
     float ext_c;
+    long long *dbg;          // diagnostic runs only (TCSFM_DEBUG_STAMPS=1): s_memrealtime stamps of the phases of workgroup (0, 0); null in production
 };
 
 // reduce N (<= 32) per-thread values over the workgroup and ADD them to LDS accumulators acc[slot(k)], k = 0..N-1
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     const float *depth_t = P.depth_t + (size_t)b * hw;          // the SHARED map: slot of forward pair (0, b)
     const int tid = threadIdx.x;
     stamp_begin(P.stamp, tid);
+#define TC_JSTAMP(i) if (J.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (i) < 8) J.dbg[i] = wall_clock64();
+    TC_JSTAMP(0)
     for (int i = tid; i < JL::NACC; i += NT) acc[i] = 0.f;
 
     const int oy = tid / TW, ox = tid - oy * TW;
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        TC_JSTAMP(1 + 3 * s)
 
         // ---------------- phase 2a: residual + adjoint coefficients for tile + 1-pixel halo ----------------
         float o_valid = 0.f, o_diff = 0.f, o_w = 0.f, o_m = 0.f, o_lxx = 0.f, o_lxy = 0.f, o_lyy = 0.f, o_l1x = 0.f, o_l1y = 0.f;
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        TC_JSTAMP(2 + 3 * s)
 
         // ---------------- phase 2b: adjoint gather; this source's gradient, curvature block and depth terms ----------------
         float v[29];      // H_ss (21, pre-Schur) | g_s (6) | share_s | n_mask_s
@@ -488,6 +493,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
         }, tid);          // (its barriers also protect rec1 / aux / coef for the next source)
         if (REF && ref_w0 && s > 0)          // the cross term: source 0's weight map on this source's pixels -> source 0's pose gradient
             joint_reduce_add<6, NT>(vx, red, acc, [&](int k) { return JL::OFF_G + k; }, tid);
+        TC_JSTAMP(3 + 3 * s)
     }
 
     // ---------------- after the sources: prior, per-pixel Schur elimination of the shared depth ----------------
@@ -566,6 +572,8 @@ __global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams 
     __syncthreads();
     float *myrec = J.jblockrec + ((size_t)b * (J.rec_stride > 0 ? J.rec_stride : nblk) + bid) * JL::NACC;
     for (int i = tid; i < JL::NACC; i += NT) myrec[i] = acc[i];
+    TC_JSTAMP(7)
+#undef TC_JSTAMP
     stamp_end(P.stamp, tid);
 }
 

@@ -1976,7 +1976,7 @@ __device__ __forceinline__ void solve_body(const SolveParams &P, const int n, co
     __shared__ double eul[NP * NP + NP];
     __shared__ double Ts[40];
     constexpr int NST = (int)(sizeof(PairState) / sizeof(double));
-    static_assert(sizeof(PairState) % sizeof(double) == 0 && NST <= 256, "PairState must be a whole number of doubles");
+    static_assert(sizeof(PairState) % sizeof(double) == 0 && NST <= NT, "PairState must be a whole number of doubles");
     __shared__ double sst[NST];
 #define TC_STAMP(i) if (P.dbg && tid == 0 && n == 0) P.dbg[i] = wall_clock64();
     TC_STAMP(0)
@@ -2010,7 +2010,10 @@ __device__ __forceinline__ void solve_body(const SolveParams &P, const int n, co
         double s = 0.0;
         if (c < nlive) {
             const float *p = P.partials + (size_t)n * P.ngrp * L::NACC + acc;
-            constexpr int NB = NT >= 1024 ? 16 : 32;       // loads in flight per thread and batch (1024 threads: 16 x 16 subsets cover 256 records)
+#ifndef TC_SOLVE_NB
+#define TC_SOLVE_NB 32
+#endif
+            constexpr int NB = NT >= 1024 ? 16 : TC_SOLVE_NB;       // loads in flight per thread and batch (1024 threads: 16 x 16 subsets cover 256 records)
             for (int r0 = q; r0 < P.ngrp; r0 += NB * parts) {
                 float v[NB];
 #pragma unroll
@@ -2226,8 +2229,17 @@ __device__ __forceinline__ void solve_body(const SolveParams &P, const int n, co
     TC_STAMP(6)
 #undef TC_STAMP
 }
+#ifndef TC_SOLVE_NT
+#define TC_SOLVE_NT 256
+#endif
 template <int NP>
-__global__ __launch_bounds__(256) void k_solve(SolveParams P) { solve_body<NP, 256>(P, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(TC_SOLVE_NT) void k_solve(SolveParams P) { solve_body<NP, TC_SOLVE_NT>(P, blockIdx.x, threadIdx.x); }
+// The common case -- SE(3) chart, no pose-consistency term -- with 1024 threads (round 5): the 240 workgroup records of a KITTI pair are summed
+// from ONE batch of loads per thread (16 record subsets of 15) instead of two dependent batches of 32, and the rare branches that set the
+// general kernel's register budget are compiled out.  Same sums in a different association: results differ from k_solve<NP> in the last bits,
+// so a call uses ONE of the two throughout (launch_solve decides on the options, not on the size).
+template <int NP>
+__global__ __launch_bounds__(1024) void k_solve_lean(SolveParams P) { solve_body<NP, 1024, true>(P, blockIdx.x, threadIdx.x); }
 
 // dense sequence calls: the refined depth maps of one call, stacked [pair index j][window b] by the window form, into the caller's
 // per-window order [window b][pair index j]

@@ -372,10 +372,17 @@ void launch_lin(tcsfm_ctx *h, const LinParams &P_in, int N, int np, bool dc, int
     }
 }
 
+// TCSFM_SOLVE_LEAN=1: the 1024-thread form of the solve kernel for SE(3) calls without the pose-consistency term -- measured SLOWER than
+// the 256-thread kernel (6.0 vs 5.3 us in-kernel, profiles/r05_solve_ab.txt): default off, kept for A/B runs
+bool use_lean_solve() {
+    static const int v = [] { const char *e = getenv("TCSFM_SOLVE_LEAN"); return e ? atoi(e) : 0; }();
+    return v != 0;
+}
 void launch_solve(tcsfm_ctx *h, const SolveParams &S, int N, int np) {
     ProfScope prof(h, 1);
-    if (np == 6) hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(256), 0, h->stream, S);
-    else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(256), 0, h->stream, S);
+    const bool lean = S.param == TCSFM_PARAM_SE3 && !(S.w_pc > 0.0) && use_lean_solve();      // (decided by the options of the call: every launch of a call takes the same kernel)
+    if (np == 6) { if (lean) hipLaunchKernelGGL((k_solve_lean<6>), dim3(N), dim3(1024), 0, h->stream, S); else hipLaunchKernelGGL((k_solve<6>), dim3(N), dim3(TC_SOLVE_NT), 0, h->stream, S); }
+    else { if (lean) hipLaunchKernelGGL((k_solve_lean<7>), dim3(N), dim3(1024), 0, h->stream, S); else hipLaunchKernelGGL((k_solve<7>), dim3(N), dim3(TC_SOLVE_NT), 0, h->stream, S); }
 }
 
 // decision trace (tcsfm_debug_trace) of linearisation `lin` of a call over N pairs: [lin][N][H*W] bits, [lin][N] decisions
@@ -621,14 +628,14 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
         lin_inv(it);
         const bool last = !lm && it == o->n_iters - 1;
         Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
-        hipLaunchKernelGGL((k_solve<6>), dim3(SB), dim3(256), 0, is, Si);
+        hipLaunchKernelGGL((k_solve<6>), dim3(SB), dim3(TC_SOLVE_NT), 0, is, Si);
         if (lm) hipLaunchKernelGGL(k_dense_update_lm, px_i, dim3(256), 0, is, Ul);
         else hipLaunchKernelGGL(k_dense_update, px_i, dim3(256), 0, is, Ui);
     }
     if (lm && o->n_iters > 0) {
         lin_inv(o->n_iters);
         Si.it = o->n_iters; Si.mode = 1; Si.pose_out = d_pose_out + (size_t)SB * 6; Si.log_scale_out = nullptr;
-        hipLaunchKernelGGL((k_solve<6>), dim3(SB), dim3(256), 0, is, Si);
+        hipLaunchKernelGGL((k_solve<6>), dim3(SB), dim3(TC_SOLVE_NT), 0, is, Si);
         hipLaunchKernelGGL(k_dense_final_lm, px_i, dim3(256), 0, is, (const int *)(h->lm_accept + SB), (const float *)(h->depth_acc + (size_t)SB * hw),
                            h->depth_work + (size_t)SB * hw, (int)hw);
     }
@@ -710,9 +717,17 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     int rc;
     if (ct && (ex || o->free_source_depths != 0 || o->n_iters < 1 || d_stats || h->trace_bits)) return fail(h, TCSFM_E_ARG, "internal: merged reference-loss calls are plain refinements with fixed source maps");
-    constexpr int DTW = 32, DTH = 16, DNT = 512;
-    static_assert(DTW == TILE_W && DTH == TILE_H, "the joint kernel and the pose kernel share the tile grid");
-    const int nblk = h->nblk;
+    // The joint kernel's own tile grid (round 5): 32 x 8 tiles of 256 threads by default.  At 256 VGPRs the kernel holds 8 waves per CU either
+    // way; as TWO independent 4-wave workgroups their barriers and load phases no longer coincide (one workgroup's gathers run under the
+    // other's arithmetic), which a single 8-wave workgroup cannot do -- at the price of a larger halo share (TC_JOINT_TILE_H=16: the round-4 grid).
+#ifndef TC_JOINT_TILE_H
+#define TC_JOINT_TILE_H 8
+#endif
+    constexpr int DTW = 32, DTH = TC_JOINT_TILE_H, DNT = DTW * DTH;
+    const int jtiles_x = (h->W + DTW - 1) / DTW, jtiles_y = (h->H + DTH - 1) / DTH;
+    const int nblk = jtiles_x * jtiles_y;              // workgroup records per target of the joint kernel
+    const int nblk_lin = h->nblk;                      // ... and of k_linearize (the inverse pairs' systems, the FRONT launch)
+    if (nblk > h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: the joint kernel's tile grid exceeds the scratch");
     const bool sel = o->argmin && S > 1, dc = o->w_dc > 0.f;
     if (!h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
     if (!h->dense_rec) {
@@ -793,7 +808,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     Si.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
     // ---- forward group: the joint kernel under the reference's rule
     LinParams Pj = lin_params(h, &oo, 6);
-    Pj.tiles_x = h->tiles_x; Pj.tiles_y = h->tiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
+    Pj.tiles_x = jtiles_x; Pj.tiles_y = jtiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
     if (sel) { Pj.ext_diff = maps_diff; Pj.ext_valid = maps_valid; Pj.n_ext = SB; Pj.ext_B = B; Pj.ext_S = S; }
     JointParams J;
     memset(&J, 0, sizeof(J));
@@ -802,6 +817,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     J.B = B; J.S = S; J.argmin = o->argmin ? 1 : 0;
     J.automask = o->argmin ? o->automask : 0;     // own masks: with one source the min is the source itself; without argmin no auto-mask (:71-73)
     J.norms = h->dref_norms; J.norm_B = norm_B; J.ext2 = h->dref_ext; J.c_f = o->argmin ? 1.f : 0.25f;
+    J.dbg = h->dbg_stamps; Si.dbg = nullptr;       // (diagnostic stamps: the joint kernel's phases in this mode, not the pair solve's)
     J.b_dc = o->w_dc / ((float)(S * Bc) * (float)hw); J.w_init_px = o->prior_init / ((float)Bc * (float)hw);
     J.sig_lo = 1.f / o->max_depth; J.sig_ir = 1.f / (1.f / o->min_depth - 1.f / o->max_depth);
     DrefSmoothParams Ds;
@@ -865,7 +881,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     JointUpdateParams Uj2 = Uj;
     if (free_src) {
         Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
-        Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
+        Pj2.tiles_x = jtiles_x; Pj2.tiles_y = jtiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
         J2.jrec = h->jrec_src; J2.depth0 = nullptr; J2.B = SB; J2.S = 1; J2.argmin = 0; J2.automask = o->automask;
         J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
         J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
@@ -886,7 +902,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     if (front) {
         F.front_fwd = SB; F.front_Bt = B; F.norm_B = norm_B; F.norms = h->dref_norms; F.ext2 = h->dref_ext;
         F.fwd_noauto = o->argmin ? 0 : SB;                       // optimizer.py:71-73: without argmin the forward term has no auto-mask
-        F.one_generation = (size_t)nblk * (SB + (sel ? B : SB)) <= 512;
+        F.one_generation = (size_t)nblk_lin * (SB + (sel ? B : SB)) <= 512;
         if (sel) { F.sel_B = B; F.sel_S = S; F.sel_out = maps_valid; Pj.ext_diff = nullptr; Pj.ext_valid = nullptr; Pj.n_ext = 0; Pj.sel_in = maps_valid; }
         Si.norms = h->dref_norms; Si.norm_Bt = B; Si.norm_B = norm_B;
     }
@@ -894,7 +910,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         F.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         F.stamp = nullptr;
         ProfScope prof(h, 2);
-        const dim3 grid(nblk, SB + (sel ? B : SB)), block(TILE_NT);     // inverse pairs, then the forward rows (under the selection: one per target)
+        const dim3 grid(nblk_lin, SB + (sel ? B : SB)), block(TILE_NT);     // inverse pairs, then the forward rows (under the selection: one per target)
         if (tr) {
             if (sel) hipLaunchKernelGGL((k_linearize<6, true, MODE_LIN, TILE_W, TILE_H, TILE_NT, true, true, false, true>), grid, block, 0, st, F);
             else hipLaunchKernelGGL((k_linearize<6, true, MODE_LIN, TILE_W, TILE_H, TILE_NT, false, true, false, true>), grid, block, 0, st, F);
@@ -940,7 +956,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             hipLaunchKernelGGL(k_dref_scatter_src, px_f, dim3(256), 0, st, Pp, Dp, h->dref_ext, J.c_f);
             LinParams Pj2 = lin_params(h, &oo, 6);
             Pj2.tgtpack += (size_t)SB * hw; Pj2.srcpack += (size_t)SB * (h->H + 2) * (h->W + 2); Pj2.depth_t += (size_t)SB * hw; Pj2.pc += SB;
-            Pj2.tiles_x = h->tiles_x; Pj2.tiles_y = h->tiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
+            Pj2.tiles_x = jtiles_x; Pj2.tiles_y = jtiles_y; Pj2.ngrp = (nblk + RG - 1) / RG; Pj2.direct = 1;
             JointParams J2 = J;
             J2.jrec = h->jrec_acc; J2.depth0 = nullptr; J2.B = SB; J2.S = 1; J2.argmin = 0; J2.automask = o->automask;
             J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
