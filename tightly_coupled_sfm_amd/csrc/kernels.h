@@ -984,6 +984,54 @@ __device__ __forceinline__ void ssim_l1_channel(T xc, T yc, T gxc, T gyc, T Sx, 
     o.lxx = w1 * gxc * gxc; o.lxy = w1 * gxc * gyc; o.lyy = w1 * gyc * gyc;
 }
 
+// TILE-SHIFTED form (round 5, k_linearize with TC_TILE_SHIFT): the staged colours of BOTH images carry a per-channel constant shift c (the
+// target colour of the tile's first pixel), so the window sums need no per-neighbour subtraction of the centre value (27 packed
+// subtractions per pixel): xs, ys = the centre's shifted values, Sx .. Sxy = plain sums of the shifted window values.  The same
+// mathematics; the variances cancel against |window mean - c| (the colour variation inside a 32 x 16 tile) instead of |window mean -
+// centre| -- measured against the float64 oracle before it was kept (profiles/r05_tile_shift_ab.txt).
+template <class T>
+__device__ __forceinline__ void ssim_l1_channel_ts(T xs, T ys, T c, T gxc, T gyc, T Sx, T Sy, T Sxx, T Syy, T Sxy, float ws, float wl,
+                                                   float eps, ChanTerms<T> &o) {
+    const float n9 = 1.f / 9.f;
+    const T zero = vsplat<T>(0.f), one = vsplat<T>(1.f);
+    T mx = Sx * n9, my = Sy * n9;                  // shifted window means
+    T mdx = mx - xs, mdy = my - ys;                // mean - centre
+    T mux = mx + c, muy = my + c;
+    T sigx = Sxx * n9 - mx * mx, sigy = Syy * n9 - my * my, sigxy = Sxy * n9 - mx * my;
+    T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+    T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+    T idn = vrcp(d1 * d2), ratio = n1 * n2 * idn;
+    T raw = (one - ratio) * 0.5f;
+    const T rawc = vclamp01(raw);
+    auto cl = rawc != raw;                         // clamped: the value is a constant there (no gradient)
+    o.e2 = ws * rawc;
+    T pre = vsel(cl, zero, idn * (-0.5f * n9 * ws));
+    o.cB = pre * (ratio * d1) * -2.f;
+    o.cC = pre * n1 * 2.f;
+    o.cA = pre * 2.f * (mux * n2 - ratio * muy * d2) - o.cB * mdy - o.cC * mdx;
+    T wi = vsel(cl, zero, idn * ws);
+    o.id1 = wi * d2; o.id2 = 1.125f * wi * d1;
+    // L1 term (differences of the two images: the shift cancels)
+    T rr = ys - xs, ar = vabs(rr);
+    auto inr = ar <= one;
+    o.e1 = wl * vmin(ar, one);
+    T sgn = l1_sign(rr, ar, wl);
+    o.l1x = sgn * gxc; o.l1y = sgn * gyc;
+    T w1 = vsel(inr, wl * vrcp(vmax(ar, vsplat<T>(eps))), zero);
+    o.lxx = w1 * gxc * gxc; o.lxy = w1 * gxc * gyc; o.lyy = w1 * gyc * gyc;
+}
+template <class T>
+__device__ __forceinline__ T ssim_l1_value_ts(T xs, T ys, T c, T Sx, T Sy, T Sxx, T Syy, T Sxy, float ws, float wl) {
+    const float n9 = 1.f / 9.f;
+    const T one = vsplat<T>(1.f);
+    T mx = Sx * n9, my = Sy * n9, mux = mx + c, muy = my + c;
+    T sigx = Sxx * n9 - mx * mx, sigy = Syy * n9 - my * my, sigxy = Sxy * n9 - mx * my;
+    T n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sigxy + SSIM_C2;
+    T d1 = mux * mux + muy * muy + SSIM_C1, d2 = sigx + sigy + SSIM_C2;
+    T raw = (one - n1 * n2 * vrcp(d1 * d2)) * 0.5f;
+    return ws * vclamp01(raw) + wl * vmin(vabs(ys - xs), one);
+}
+
 // value of the per-channel photometric error only (no gradient coefficients): the residual of ANOTHER source, for the
 // min-over-sources selection
 template <class T>
@@ -1091,6 +1139,10 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
 #ifndef TC_PASSB_J2
 #define TC_PASSB_J2 0
 #endif
+// Tile-constant colour shift of the staged records (round 5; see ssim_l1_channel_ts): 1 = production candidate, 0 = centre-shifted sums as in round 4
+#ifndef TC_TILE_SHIFT
+#define TC_TILE_SHIFT 0
+#endif
 template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false, bool FRONT = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
@@ -1127,6 +1179,12 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     int f_tap = 0;                                                           // FRONT, inverse pairs: top-left tap (x + 1) | (y + 1) << 16 of the own pixel's
     float f_wx = 0.f, f_wy = 0.f, f_dc = 0.f, f_ph = 0.f;                    // sample, its bilinear weights; scatter coefficients h(dd) ddd and M diff ddd
     const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
+    constexpr bool TS = TC_TILE_SHIFT && TC_PASSA_PIPELINED && TC_PROBE_PASSA_VISITS == 9 && !(ADJ && MODE == MODE_LIN);
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f;                                   // TS: the workgroup's colour shift = the target colour at its first pixel
+    if (TS) {                                                                // (a workgroup-uniform address: scalar load)
+        const float4 c0_ = tgtpack[(size_t)min(y00, H - 1) * W + min(x00, W - 1)];
+        cs0 = c0_.x; cs1 = c0_.y; cs2 = c0_.z;
+    }
     const bool cached = P.pair_src != nullptr;                               // wave-uniform
     const float4 *srcpack = P.srcpack + (size_t)(cached ? P.pair_src[n] : img) * (H + 2) * (W + 2);   // zero-bordered (tap4)
     const float *depth_t = P.depth_t + (size_t)(cached ? P.pair_dep[n] : img) * hw;
@@ -1164,8 +1222,8 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 float4 val, gx, gy;
                 tap4(spo, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, val, gx, gy);
                 float4 *rec = lds + ci * (LDS_REC / 4);
-                lds_write1(rec + 0, val.x, val.y, tp.x, tp.y);
-                lds_write1(rec + 2, val.z, tp.z, (g.oobx || g.ooby) ? 0.f : 1.f, tp.w);
+                lds_write1(rec + 0, val.x - cs0, val.y - cs1, tp.x - cs0, tp.y - cs1);
+                lds_write1(rec + 2, val.z - cs2, tp.z - cs2, (g.oobx || g.ooby) ? 0.f : 1.f, tp.w);
                 if (P.rule && so == 0) {   // that source's depth-consistency weight (train_mono.py:91-92), with its depth sample
                     const float pdo = co.es * val.w;
                     lds_write1(rec + 1, 1.f - clamp01(fabsf(g.Z - pdo) * frcp(g.Z + pdo)), 0.f, 0.f, 0.f);
@@ -1188,7 +1246,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                     const unsigned base = lds_addr(nb);
                     f32x4 u0, u2, w0, w2;
                     auto more = [&](const f32x4 &n0, const f32x4 &n2) {
-                        f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01), e2v = pk_sub(n2.lo, yx2c);
+                        f2 ey, ex, e2v;
+                        if (TS) { ey = n0.lo; ex = n0.hi; e2v = n2.lo; }
+                        else { ey = pk_sub(n0.lo, yc01); ex = pk_sub(n0.hi, xc01); e2v = pk_sub(n2.lo, yx2c); }
                         Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
                         S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
                     };
@@ -1215,8 +1275,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                     S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
                 }
 #endif
-                const f2 e01 = ssim_l1_value<f2>(xc01, yc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl);
-                const float d_o = e01.x + e01.y + ssim_l1_value<float>(yx2c.y, yx2c.x, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl);
+                const f2 e01 = TS ? ssim_l1_value_ts<f2>(xc01, yc01, f2{cs0, cs1}, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl)
+                                  : ssim_l1_value<f2>(xc01, yc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl);
+                const float d_o = e01.x + e01.y + (TS ? ssim_l1_value_ts<float>(yx2c.y, yx2c.x, cs2, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl)
+                                                      : ssim_l1_value<float>(yx2c.y, yx2c.x, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl));
                 if (so < s_own) sel_before = fminf(sel_before, d_o); else sel_after = fminf(sel_after, d_o);
                 if (FRONT) { if (so == 1) sel_d1 = d_o; else sel_d2 = d_o; }
                 sel_valid = fmaxf(sel_valid, q2.z);
@@ -1261,17 +1323,17 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         // iy only, see geo_jac), so they are not staged: (a0, b1) travel as one pair -- pass B spends one packed FMA on columns (0,1)
         // instead of two -- and the seventh column of the pose + depth-scale mode takes their place (six 16-byte rows for NP = 7 too)
         if (write) {
-            lds_write1(rec + 0, val.x, val.y, S.tp.x, S.tp.y);
+            lds_write1(rec + 0, val.x - cs0, val.y - cs1, S.tp.x - cs0, S.tp.y - cs1);      // (cs = 0 without the tile shift)
             if (MODE == MODE_LIN) {
                 lds_write1(rec + 1, gx.x, gy.x, gx.y, gy.y);     // (gx, gy) pairs per channel: pass B forms (sx, sy) with packed FMAs
-                lds_write1(rec + 2, val.z, S.tp.z, gx.z, gy.z);
+                lds_write1(rec + 2, val.z - cs2, S.tp.z - cs2, gx.z, gy.z);
                 if (!(FRONT && ffwd)) {
                     lds_write1(rec + 3, a[0], b[1], a[2], a[3]);
                     lds_write1(rec + 4, a[4], a[5], b[2], b[3]);
                     lds_write1(rec + 5, b[4], b[5], NP == 7 ? a[NP - 1] : 0.f, NP == 7 ? b[NP - 1] : 0.f);
                 }
             } else {
-                lds_write1(rec + 2, val.z, S.tp.z, 0.f, 0.f);
+                lds_write1(rec + 2, val.z - cs2, S.tp.z - cs2, 0.f, 0.f);
             }
         }
         if (centre) {
@@ -1356,15 +1418,16 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             const unsigned base = lds_addr(nbA);
             f32x4 u0, u2, w0, w2;
             auto first = [&](const f32x4 &n0, const f32x4 &n2) {
-                Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
+                if (TS) { Sy01 = n0.lo; Sx01 = n0.hi; S2 = n2.lo; }       // tile-shifted records: the window values as they are
+                else { Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01); S2 = pk_sub(n2.lo, yx2c); }            // (y2 - y2c, x2 - x2c)
                 Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
-                S2 = pk_sub(n2.lo, yx2c);            // (y2 - y2c, x2 - x2c)
                 SS2 = S2 * S2; Sxy2 = S2.x * S2.y;
             };
             auto more = [&](const f32x4 &n0, const f32x4 &n2) {
-                f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+                f2 ey, ex, e2v;
+                if (TS) { ey = n0.lo; ex = n0.hi; e2v = n2.lo; }
+                else { ey = pk_sub(n0.lo, yc01); ex = pk_sub(n0.hi, xc01); e2v = pk_sub(n2.lo, yx2c); }
                 Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
-                f2 e2v = pk_sub(n2.lo, yx2c);
                 S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y;
             };
             lds_issue02v_at<0>(base, u0, u2);
@@ -1414,8 +1477,13 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         // evaluation, channel 2 as a scalar one (same code, ssim_l1_channel<T>)
         ChanTerms<f2> t01;
         ChanTerms<float> t2;
-        ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
-        ssim_l1_channel<float>(yx2c.y, yx2c.x, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+        if (TS) {
+            ssim_l1_channel_ts<f2>(xc01, yc01, f2{cs0, cs1}, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
+            ssim_l1_channel_ts<float>(yx2c.y, yx2c.x, cs2, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+        } else {
+            ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
+            ssim_l1_channel<float>(yx2c.y, yx2c.x, g2c.x, g2c.y, S2.y, S2.x, SS2.y, SS2.x, Sxy2, P.ws, P.wl, P.eps, t2);
+        }
         const float cA[3] = {t01.cA.x, t01.cA.y, t2.cA}, cB[3] = {t01.cB.x, t01.cB.y, t2.cB}, cC[3] = {t01.cC.x, t01.cC.y, t2.cC};
         const float e1 = t01.e1.x + t01.e1.y + t2.e1, e2 = t01.e2.x + t01.e2.y + t2.e2;
         const float l1x = t01.l1x.x + t01.l1x.y + t2.l1x, l1y = t01.l1y.x + t01.l1y.y + t2.l1y;
@@ -1680,7 +1748,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 if (P.o_auto_mask) P.o_auto_mask[o] = diff < c_ae[k] ? 1.f : 0.f;
                 if (P.o_rec) {
                     size_t o3 = (size_t)n * 3 * hw + (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
-                    P.o_rec[o3] = yc[0]; P.o_rec[o3 + hw] = yc[1]; P.o_rec[o3 + 2 * hw] = yc[2];
+                    P.o_rec[o3] = yc[0] + cs0; P.o_rec[o3 + hw] = yc[1] + cs1; P.o_rec[o3 + 2 * hw] = yc[2] + cs2;
                 }
             }
             continue;
