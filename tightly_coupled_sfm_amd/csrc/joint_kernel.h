@@ -79,8 +79,14 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
     __syncthreads();
 }
 
+// Waves per SIMD the register allocation aims at: 2 (256 VGPRs).  TC_JOINT_OCC=3 (168 VGPRs: three 256-thread workgroups per CU, which the 50 KB
+// of LDS of the 32 x 8 tiling would allow) was measured: with S >= 2 the kernel then spills 90 registers and runs at HALF the speed (47 vs 26 us
+// per launch, 226 vs 178 us per window at minibatch 6; profiles/r05_joint_occupancy_ab.txt).  S = 1 needs 153 registers and gets three waves anyway.
+#ifndef TC_JOINT_OCC
+#define TC_JOINT_OCC 2
+#endif
 template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false>
-__global__ __launch_bounds__(NT, 2) void k_dense_joint(LinParams P, JointParams J) {
+__global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_joint(LinParams P, JointParams J) {
     using JL = JointLayout<NS>;
     constexpr int NP = 6;
     constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;
