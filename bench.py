@@ -136,7 +136,7 @@ def cpu_baseline(seconds: float):
 
 # The committed profiles this bench line cites (scripts/collect_profiles.sh <tag> on the GPU box, scripts/summarise_profiles.py <tag>):
 # exact file names of the NEWEST tag that has the file -- no globbing (r02's line picked up another mode's PMC file through sorted(glob)[-1]).
-PROFILE_TAGS = ("r04", "r03")
+PROFILE_TAGS = ("r05", "r04", "r03")
 KERNEL = "k_linearize<6, false, 1"       # the S = 1, no-depth-consistency, MODE_LIN instantiation the bench workload runs
 DISPATCH_OFFSET_US = 1.2                  # rocprofv3's kernel duration minus the in-kernel bracket (dispatch + completion), measured r02 / r03
 SOURCE_FILES = ("tightly_coupled_sfm_amd/csrc", "include/tcsfm.h")
