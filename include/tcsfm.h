@@ -277,7 +277,12 @@ int tcsfm_refine_dense(tcsfm_handle h, const tcsfm_opts *o, int N, const float *
  *     terms are gradient-only.  The inverse pairs take 6 x 6 pose steps under the window rule.  After every step the new map also
  *     replaces the depth the inverse pairs sample.  depth_out: the S forward slots hold the refined map, the inverse slots the
  *     source depths (unchanged; refined under o->free_source_depths).  stats rows of the forward pairs: [forward group's loss (forward + its depth consistency + prior),
- *     own share, own mask count, lambda, iterate]; of the inverse pairs: as tcsfm_refine_window under the rule. */
+ *     own share, own mask count, lambda, iterate]; of the inverse pairs: as tcsfm_refine_window under the rule.
+ *     LAUNCHES (round 5): with the source maps fixed an iteration is FOUR dependent launches -- one over all 2 S B directed pairs
+ *     (the forward pairs' mask / min-over-sources selection and its count K_f; the inverse pairs' 6 x 6 systems, K_i and the adjoint
+ *     scatter, whose two parts are summed without their factors so that no count has to precede it), the joint kernel, one launch
+ *     that solves the targets' 6S x 6S systems and the inverse pairs' 6 x 6 systems, the back-substitution (five with the quarter-
+ *     resolution unknown) -- and a call issues no memset or copy: csrc/dense_ref_kernel.h. */
 int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                               float *depth_out, float *stats_out);
@@ -416,8 +421,12 @@ int tcsfm_flush(tcsfm_handle h);
 int tcsfm_coalesce_counts(tcsfm_handle h, int *batches, int *calls);
 /* The dense counterpart (arguments of tcsfm_refine_dense_window, device pointers, no statistics): queued per-pair Gauss-Newton dense calls
  * with ONE source per target (S = 1, TCSFM_WINDOW_PAIR) of the same shape and options are merged like the pose calls -- every call's
- * refined poses and depth maps go to its own outputs, bit-identical to the call on its own; any other dense call (S > 1, LM, the
- * reference-loss mode) flushes what is waiting and runs at once.  Pose calls and dense calls are never merged with each other. */
+ * refined poses and depth maps go to its own outputs, bit-identical to the call on its own.  Round 5: calls under TCSFM_WINDOW_REFERENCE (the
+ * reference's own loss, optimizer.py:47-90; S <= 3, Gauss-Newton, fixed source maps, per-pixel or quarter-resolution unknown) are merged as
+ * well: that loss couples the windows of ONE call through its batch normalisers, so inside the merged sequence every call is a normaliser
+ * group of its own (mask counts, per-map weights) and its results are the bits of the call run alone.  Any other dense call (the joint mode
+ * for S > 1 under TCSFM_WINDOW_PAIR, LM, free_source_depths) flushes what is waiting and runs at once.  Pose calls and dense calls are never
+ * merged with each other. */
 int tcsfm_refine_dense_window_queued(tcsfm_handle h, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                                      const float *depth_t, const float *depth_s, const float *K, const float *pose_in, float *pose_out,
                                      float *depth_out);
