@@ -371,8 +371,8 @@ int tcsfm_solve_pose_iteratively(tcsfm_handle h, tcsfm_posenet *pn, int num_iter
  *                            input buffers: tcsfm_stream_wait_event(stream, mark) makes e.g. their copy stream wait, on the
  *                            device, until the lane has consumed the buffer */
 int tcsfm_set_lanes(tcsfm_handle h, int n_lanes);
-/* Round 5: tcsfm_set_lanes MEASURES whether this process's streams run side by side (16 launches of a stand-in kernel on one stream, then
- * alternating over two; ~0.5 ms).  If they do not -- the hazard above -- the handle falls back: lane calls (tcsfm_refine_window_async, the
+/* Round 5: tcsfm_set_lanes MEASURES whether lanes pay in this process (24 B=1 refinements of the handle's own kernels on stand-in images, one
+ * after the other on the handle's stream, then round-robin over all lanes; ~5 ms).  If they do not -- the hazard above -- the handle falls back: lane calls (tcsfm_refine_window_async, the
  * sequence calls, the merged sequences' second stream) run on the handle's own stream, one after the other, results unchanged, one line on
  * stderr.  tcsfm_lane_probe reports the outcome: *serial = 1 when the fallback is active, and the two probe times in ms.  The queued calls
  * (tcsfm_set_coalesce) keep the chip busy either way.  TCSFM_LANE_PROBE=0 in the environment skips the probe. */

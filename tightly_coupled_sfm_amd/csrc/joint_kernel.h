@@ -805,6 +805,14 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_front(JointSolveParams Pj, 
     else solve_body<6, JSOLVE_NT, true>(Pi, (int)blockIdx.x - Pj.B, threadIdx.x);
 }
 
+// Free source maps (round 5): the forward groups (NS sources each) and the inverse groups (one source each: the inverse pairs with their
+// source map) of one iteration are independent systems -- one launch solves both.  Workgroups [0, Pa.B): Pa; [Pa.B, Pa.B + Pb.B): Pb.
+template <int NS>
+__global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint2(JointSolveParams Pa, JointSolveParams Pb) {
+    if ((int)blockIdx.x < Pa.B) solve_joint_body<NS>(Pa, blockIdx.x, threadIdx.x);
+    else solve_joint_body<1>(Pb, (int)blockIdx.x - Pa.B, threadIdx.x);
+}
+
 // back-substitution of the shared map; LM: promote / roll back first (as k_dense_update_lm)
 struct JointUpdateParams {
     const float *jrec;        // [B][H*W][JREC] records of the linearisation just evaluated
@@ -826,9 +834,8 @@ struct JointUpdateParams {
 };
 
 template <int NS>
-__global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P) {
+__device__ __forceinline__ void joint_update_body(const JointUpdateParams &P, const int idx, const int b) {
     using JL = JointLayout<NS>;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (P.norms_zero && idx < P.norms_n && b == 0) P.norms_zero[idx] = 0;
     if (idx >= P.hw) return;
     const size_t o = (size_t)b * P.hw + idx;
@@ -874,6 +881,17 @@ __global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P)
         for (int s = 0; s < P.S; s++)
             P.srcpack_inv[((size_t)(s * P.B + b) * (P.H + 2) + v + 1) * (P.W + 2) + u + 1].w = dep;
     }
+}
+template <int NS>
+__global__ __launch_bounds__(256) void k_dense_joint_update(JointUpdateParams P) {
+    joint_update_body<NS>(P, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
+}
+// ... of the forward groups' maps (rows [0, Pa.B)) and of the inverse groups' source maps (rows behind them) in one launch
+template <int NS>
+__global__ __launch_bounds__(256) void k_dense_joint_update2(JointUpdateParams Pa, JointUpdateParams Pb) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((int)blockIdx.y < Pa.B) joint_update_body<NS>(Pa, idx, blockIdx.y);
+    else joint_update_body<1>(Pb, idx, (int)blockIdx.y - Pa.B);
 }
 
 }  // namespace tc

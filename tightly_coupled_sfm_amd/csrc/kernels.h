@@ -101,6 +101,12 @@ struct LinParams {
     int *norms;                 // [groups][2] K_f, K_i: zero when the launch starts
     long long *ext2;            // [front_Bt][H*W][2]: sum of h(dd) ddd w_tap and of M diff ddd w_tap over the inverse pixels that sample the
                                 // target pixel, 2^-40 fixed point (integer atomics: order-independent, bit-reproducible); zero when the launch starts
+    // FRONT with free source maps (front_light = 1, opts.free_source_depths): the inverse pairs are linearised by the joint kernel as groups
+    // of one source, so EVERY row is light here -- mask, count, scatter -- and the forward rows scatter too: the adjoint of the forward pairs'
+    // samples of the SOURCE maps -> ext2_src (what k_dref_scatter_src computed).  The sign of cd - pd is then the plain fp32 difference's,
+    // as the joint kernel that linearises both groups takes it.
+    int front_light;
+    long long *ext2_src;        // [front_fwd][H*W][2], zero when the launch starts
 };
 constexpr double DREF_FIX = 1099511627776.0;     // 2^40: fixed-point scale of the scatter sums
 
@@ -1175,6 +1181,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     const int x00 = txi * TW, y00 = tyi * TH;
     const int img = P.shared_image ? 0 : n;
     const bool ffwd = FRONT && n < P.front_fwd;                              // FRONT: a forward pair -- mask and count only (workgroup-uniform)
+    const bool flight = FRONT && (ffwd || P.front_light != 0);               // FRONT: a row without a linearisation
     bool front_m = false;                                                    // FRONT: this thread's pixel counts
     int f_tap = 0;                                                           // FRONT, inverse pairs: top-left tap (x + 1) | (y + 1) << 16 of the own pixel's
     float f_wx = 0.f, f_wy = 0.f, f_dc = 0.f, f_ph = 0.f;                    // sample, its bilinear weights; scatter coefficients h(dd) ddd and M diff ddd
@@ -1220,7 +1227,29 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 Geo g;
                 warp_geo(co, W, H, px, py, dto[gi], g);
                 float4 val, gx, gy;
-                tap4(spo, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, val, gx, gy);
+                Tap to;
+                tap4_fetch(spo, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, to);
+                tap4_lerp(to, val, gx, gy);
+                if (FRONT && P.front_light && lx >= 1 && lx <= TW && ly >= 1 && ly <= TH && x00 + lx - 1 < W && y00 + ly - 1 < H && !(g.oobx || g.ooby)) {
+                    // free source maps: forward pair (so, b) samples source map (so, b) here; under the min over the sources only source 0's
+                    // weight multiplies the photometric term, so this pair's sample enters through its depth-consistency term alone
+                    const float pdo = co.es * val.w, cdo = g.Z, iso = frcp(cdo + pdo), dfo = cdo - pdo, rwo = fabsf(dfo) * iso;
+                    if (rwo >= 0.f && rwo <= 1.f) {
+                        const float sgo = dfo > 0.f ? 1.f : (dfo < 0.f ? -1.f : 0.f);
+                        const float fdc = fminf(1.f, fminf(rwo, 1.f) * frcp(P.eps)) * (-sgo * 2.f * cdo * iso * iso * co.es);
+                        const int xi = px + (int)floorf(g.rx), yi = py + (int)floorf(g.ry);
+                        const float w4[4] = {(1.f - to.wx) * (1.f - to.wy), to.wx * (1.f - to.wy), (1.f - to.wx) * to.wy, to.wx * to.wy};
+                        long long *es_ = P.ext2_src + (size_t)no * hw * 2;
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; k4++) {
+                            const int xx = xi + (k4 & 1), yy = yi + (k4 >> 1);
+                            if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                                const long long a0 = (long long)llrint((double)(fdc * w4[k4]) * DREF_FIX);
+                                if (a0 != 0) atomicAdd(reinterpret_cast<unsigned long long *>(es_ + ((size_t)yy * W + xx) * 2), (unsigned long long)a0);
+                            }
+                        }
+                    }
+                }
                 float4 *rec = lds + ci * (LDS_REC / 4);
                 lds_write1(rec + 0, val.x - cs0, val.y - cs1, tp.x - cs0, tp.y - cs1);
                 lds_write1(rec + 2, val.z - cs2, tp.z - cs2, (g.oobx || g.ooby) ? 0.f : 1.f, tp.w);
@@ -1312,7 +1341,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         float4 val, gx, gy;
         tap4_lerp(S.t, val, gx, gy);
         float a[NP], b[NP], zc[NP];
-        if (FRONT && ffwd) {
+        if (FRONT && flight) {
 #pragma unroll
             for (int j = 0; j < NP; j++) { a[j] = 0.f; b[j] = 0.f; zc[j] = 0.f; }
         } else if (MODE == MODE_LIN) geo_jac<NP>(c, S.g, W, H, a, b, zc);   // cost / maps passes need neither Jacobians nor image gradients
@@ -1327,7 +1356,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (MODE == MODE_LIN) {
                 lds_write1(rec + 1, gx.x, gy.x, gx.y, gy.y);     // (gx, gy) pairs per channel: pass B forms (sx, sy) with packed FMAs
                 lds_write1(rec + 2, val.z - cs2, S.tp.z - cs2, gx.z, gy.z);
-                if (!(FRONT && ffwd)) {
+                if (!(FRONT && flight)) {
                     lds_write1(rec + 3, a[0], b[1], a[2], a[3]);
                     lds_write1(rec + 4, a[4], a[5], b[2], b[3]);
                     lds_write1(rec + 5, b[4], b[5], NP == 7 ? a[NP - 1] : 0.f, NP == 7 ? b[NP - 1] : 0.f);
@@ -1342,7 +1371,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
                 f_tap = ((S.px + (int)floorf(S.g.rx) + 1) & 0xffff) | ((S.py + (int)floorf(S.g.ry) + 1) << 16);
                 f_wx = S.t.wx; f_wy = S.t.wy;
             }
-            if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && c_in[0] && !ffwd)    // bilinear cell parity now, mask / validity bits in phase 2
+            if (TRACE && MODE != MODE_MAPS && P.trace != nullptr && c_in[0] && !flight)    // bilinear cell parity now, mask / validity bits in phase 2
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
             c_pd[0] = c.es * val.w; c_dgx[0] = c.es * gx.w; c_dgy[0] = c.es * gy.w; c_cd[0] = S.g.Z;
@@ -1504,8 +1533,21 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
 
         if (FRONT) front_m = m;
-        if (FRONT && ffwd) {       // a forward pair: k_dense_joint linearises it; here only its mask (the selection) and the count below
-            if (SEL) {             // the row of pair (0, b): the decision for EVERY source of target b (first minimum, as torch.min / ext_selected)
+        if (FRONT && P.front_light) {      // free source maps: the scatter coefficients of this row's own sample (plain fp32 sign, as the joint kernel's)
+            const float cd_ = c_cd[k], pd_ = c_pd[k], is_ = frcp(cd_ + pd_), df_ = cd_ - pd_, rw_ = fabsf(df_) * is_;
+            if (inimg && c_valid[k] && rw_ >= 0.f && rw_ <= 1.f) {
+                const float sg_ = df_ > 0.f ? 1.f : (df_ < 0.f ? -1.f : 0.f);
+                const float ddd_ = -sg_ * 2.f * cd_ * is_ * is_ * c.es;                  // d dd / d (sampled depth)
+                f_dc = fminf(1.f, fminf(rw_, 1.f) * frcp(P.eps)) * ddd_;
+                // photometric part: an inverse pair's own masked error; a forward pair's E = the error this sample's weight multiplies -- under
+                // the min over the sources (this row decides for all of them) the winning source's error wherever a source is selected
+                float E_ = m ? diff : 0.f;
+                if (SEL && ffwd) E_ = (inimg && sel_keep) ? fminf(diff, fminf(sel_before, sel_after)) : 0.f;
+                f_ph = E_ * ddd_;
+            }
+        }
+        if (FRONT && flight) {     // a row without a linearisation: its mask (the selection), the count and the scatter below
+            if (SEL && ffwd) {     // the row of pair (0, b): the decision for EVERY source of target b (first minimum, as torch.min / ext_selected)
                 front_m = inimg && sel_keep;                  // exactly one source keeps the pixel
                 if (inimg) {
                     const size_t o = (size_t)(y00 + ly - 1) * W + (x00 + lx - 1);
@@ -1862,15 +1904,58 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         }
     }
     if (MODE == MODE_MAPS) { stamp_end(P.stamp, tid); return; }
+    // FRONT: the ADJOINT of this tile's bilinear samples (an inverse row: of the target depth -> ext2; a forward row with free source maps: of
+    // its source map -> ext2_src).  The taps of the tile land in a window of the sampled image displaced by the tile's flow: they are summed
+    // in LDS first -- 64-bit fixed-point adds on a (TW + 2 M) x (TH + 2 M) window placed by the tap of the tile's centre pixel, two sums per
+    // entry -- then every non-zero entry goes out with one global atomic per sum; a tap outside the window goes to global memory directly.
+    // Called when every wave is past a workgroup barrier behind phase 2 (the staged records are dead: the window aliases them).
+    auto front_scatter = [&](long long *ext) {
+        constexpr int FM = 6, WW = TW + 2 * FM, WH = TH + 2 * FM, NWIN = WW * WH;
+        static_assert(2 * NWIN * sizeof(unsigned long long) <= sizeof(lds), "the scatter window aliases the staged records");
+        unsigned long long *win = reinterpret_cast<unsigned long long *>(lds);
+        for (int i = tid; i < 2 * NWIN; i += NT) win[i] = 0ull;
+        const int tx0 = (f_tap & 0xffff) - 1, ty0 = (f_tap >> 16) - 1;
+        if (tid == (TH / 2) * TW + TW / 2) { front_org[0] = tx0 - TW / 2 - FM; front_org[1] = ty0 - TH / 2 - FM; }
+        __syncthreads();
+        const int ox = front_org[0], oy = front_org[1];
+        if (f_dc != 0.f || f_ph != 0.f) {
+            const float w4[4] = {(1.f - f_wx) * (1.f - f_wy), f_wx * (1.f - f_wy), (1.f - f_wx) * f_wy, f_wx * f_wy};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xx = tx0 + (k & 1), yy = ty0 + (k >> 1);
+                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {         // (a tap in the zero border is no pixel of the sampled map)
+                    const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
+                    const int wxl = xx - ox, wyl = yy - oy;
+                    if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) {
+                        if (a0 != 0) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a0);
+                        if (a1 != 0) atomicAdd(&win[NWIN + wyl * WW + wxl], (unsigned long long)a1);
+                    } else {
+                        unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+                        if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
+                        if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < NWIN; i += NT) {
+            const unsigned long long a0 = win[i], a1 = win[NWIN + i];
+            const int yy = oy + i / WW, xx = ox + i % WW;
+            if ((a0 | a1) != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) {
+                unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
+                if (a0 != 0ull) atomicAdd(e, a0);
+                if (a1 != 0ull) atomicAdd(e + 1, a1);
+            }
+        }
+    };
     if (FRONT) {      // the tile's mask count -> the batch normaliser of the pair's group (one integer atomic per workgroup)
         const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(front_m));
         if ((tid & 63) == 0 && cnt != 0) atomicAdd(&front_cnt, cnt);
-        if (ffwd) {
+        if (flight) {
             __syncthreads();
-            if (tid == 0 && front_cnt != 0) {
-                const int b_ = (n % P.front_fwd) % P.front_Bt;
-                atomicAdd(P.norms + 2 * (P.norm_B > 0 ? b_ / P.norm_B : 0), front_cnt);
-            }
+            const int b_ = (n % P.front_fwd) % P.front_Bt;
+            if (tid == 0 && front_cnt != 0) atomicAdd(P.norms + 2 * (P.norm_B > 0 ? b_ / P.norm_B : 0) + (ffwd ? 0 : 1), front_cnt);
+            if (P.front_light) front_scatter(ffwd ? P.ext2_src + (size_t)n * hw * 2 : P.ext2 + (size_t)b_ * hw * 2);
             stamp_end(P.stamp, tid);
             return;
         }
@@ -1923,52 +2008,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
         v[NLIVE - 3] = sMWd; v[NLIVE - 2] = sM; v[NLIVE - 1] = sdd;
         block_reduce_publish<NP, NLIVE, (MODE == MODE_LIN), DC, NT>(P, v, red, n, bid, nblk, tid);
     }
-    if (FRONT) {
-        // ---------------- FRONT, inverse pair: count, and the ADJOINT of this tile's bilinear samples of the target depth ----------------
-        // (every wave is past the barrier inside the reduction: phase 2 is over, the staged records are dead and front_cnt is complete.)
-        // The taps of the tile land in a window of the TARGET image displaced by the tile's flow: they are summed in LDS first -- 64-bit
-        // fixed-point adds on a (TW + 2 M) x (TH + 2 M) window placed by the tap of the tile's centre pixel, two sums per entry -- then every
-        // non-zero entry goes out with one global atomic per sum; a tap outside the window goes to global memory directly.
-        constexpr int FM = 6, WW = TW + 2 * FM, WH = TH + 2 * FM, NWIN = WW * WH;
-        static_assert(2 * NWIN * sizeof(unsigned long long) <= sizeof(lds), "the scatter window aliases the staged records");
-        unsigned long long *win = reinterpret_cast<unsigned long long *>(lds);
+    if (FRONT) {      // FRONT, a linearised inverse pair: its count and its scatter (every wave is past the barrier inside the reduction)
         const int b_ = (n % P.front_fwd) % P.front_Bt;
         if (tid == 0 && front_cnt != 0) atomicAdd(P.norms + 2 * (P.norm_B > 0 ? b_ / P.norm_B : 0) + 1, front_cnt);
-        for (int i = tid; i < 2 * NWIN; i += NT) win[i] = 0ull;
-        const int tx0 = (f_tap & 0xffff) - 1, ty0 = (f_tap >> 16) - 1;
-        if (tid == (TH / 2) * TW + TW / 2) { front_org[0] = tx0 - TW / 2 - FM; front_org[1] = ty0 - TH / 2 - FM; }
-        __syncthreads();
-        const int ox = front_org[0], oy = front_org[1];
-        long long *ext = P.ext2 + (size_t)b_ * hw * 2;
-        if (f_dc != 0.f || f_ph != 0.f) {
-            const float w4[4] = {(1.f - f_wx) * (1.f - f_wy), f_wx * (1.f - f_wy), (1.f - f_wx) * f_wy, f_wx * f_wy};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int xx = tx0 + (k & 1), yy = ty0 + (k >> 1);
-                if (xx >= 0 && xx < W && yy >= 0 && yy < H) {         // (a tap in the zero border is no pixel of the target)
-                    const long long a0 = (long long)llrint((double)(f_dc * w4[k]) * DREF_FIX), a1 = (long long)llrint((double)(f_ph * w4[k]) * DREF_FIX);
-                    const int wxl = xx - ox, wyl = yy - oy;
-                    if (wxl >= 0 && wxl < WW && wyl >= 0 && wyl < WH) {
-                        if (a0 != 0) atomicAdd(&win[wyl * WW + wxl], (unsigned long long)a0);
-                        if (a1 != 0) atomicAdd(&win[NWIN + wyl * WW + wxl], (unsigned long long)a1);
-                    } else {
-                        unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
-                        if (a0 != 0) atomicAdd(e, (unsigned long long)a0);
-                        if (a1 != 0) atomicAdd(e + 1, (unsigned long long)a1);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < NWIN; i += NT) {
-            const unsigned long long a0 = win[i], a1 = win[NWIN + i];
-            const int yy = oy + i / WW, xx = ox + i % WW;
-            if ((a0 | a1) != 0ull && xx >= 0 && xx < W && yy >= 0 && yy < H) {
-                unsigned long long *e = reinterpret_cast<unsigned long long *>(ext + ((size_t)yy * W + xx) * 2);
-                if (a0 != 0ull) atomicAdd(e, a0);
-                if (a1 != 0ull) atomicAdd(e + 1, a1);
-            }
-        }
+        front_scatter(P.ext2 + (size_t)b_ * hw * 2);
     }
     stamp_end(P.stamp, tid);
 }

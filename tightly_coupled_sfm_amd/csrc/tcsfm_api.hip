@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <math.h>
 
 #include "../../include/tcsfm.h"
 #include "kernels.h"
@@ -764,10 +766,12 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     }
     if (free_src && qres && !h->qres_rho_src) {
         const size_t ng = n / 2;
-        HIPCHK(h, hipMalloc((void **)&h->qres_rho_src, ng * nq * sizeof(float)));
+        HIPCHK(h, hipMalloc((void **)&h->qres_rho_src, 2 * ng * nq * sizeof(float)));      // (two buffers: k_qres_step_up ping-pongs)
         HIPCHK(h, hipMalloc((void **)&h->qres_rec_src, ng * nq * JointLayout<1>::JREC * sizeof(float)));
     }
-    if (free_src && (size_t)SB * (nblk + nqblk) * JointLayout<1>::NACC > ((n + 3) / 4) * 2 * (size_t)h->nblk_alloc * JM::NACC)
+    // (the inverse groups' workgroup records follow the forward groups' in jblockrec: both joint launches of a linearisation run before the solve)
+    const size_t jrec2_off = (size_t)B * (nblk + nqblk) * JL::NACC;
+    if (free_src && jrec2_off + (size_t)SB * (nblk + nqblk) * JointLayout<1>::NACC > ((n + 3) / 4) * 2 * (size_t)h->nblk_alloc * JM::NACC)
         return fail(h, TCSFM_E_ARG, "internal: the inverse groups' records exceed the scratch");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
@@ -886,6 +890,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
         J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
         J2.ext2 = h->dref_ext_src; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
+        J2.jblockrec = h->jblockrec + jrec2_off; Sj2.jblockrec = h->jblockrec + jrec2_off; Q2.jblockrec = h->jblockrec + jrec2_off;
         if (qres) { J2.qres = 1; J2.rec_stride = nblk + nqblk; }
         Sj2.js = h->jstate_src; Sj2.st = h->state + SB; Sj2.pc = h->pconst + SB; Sj2.B = SB; Sj2.nblk = qres ? nblk + nqblk : nblk;
         Sj2.stats = d_stats ? d_stats + (size_t)SB * (o->n_iters + 1) * TCSFM_NSTAT : nullptr;
@@ -897,10 +902,13 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     // Round 5: with the source maps fixed a linearisation OPENS with one launch over all 2 S B pairs (k_linearize<FRONT>: the forward pairs'
     // selection and K_f, the inverse pairs' systems, K_i and their adjoint scatter) in place of the residual-map, count, scatter and
     // inverse-linearisation launches; the free-source-map mode keeps those (its inverse pairs are linearised by the joint kernel).
-    const bool front = !free_src;
+    // (second session: the free-source-map mode opens with the same launch -- every row light there, the forward rows scattering the adjoint
+    // of their samples of the source maps -- and its two joint groups share ONE solve launch and ONE update launch)
+    const bool front = true;
     LinParams F = lin_params(h, &oo, 6);
     if (front) {
         F.front_fwd = SB; F.front_Bt = B; F.norm_B = norm_B; F.norms = h->dref_norms; F.ext2 = h->dref_ext;
+        F.front_light = free_src ? 1 : 0; F.ext2_src = h->dref_ext_src;
         F.fwd_noauto = o->argmin ? 0 : SB;                       // optimizer.py:71-73: without argmin the forward term has no auto-mask
         F.one_generation = (size_t)nblk_lin * (SB + (sel ? B : SB)) <= 512;
         if (sel) { F.sel_B = B; F.sel_S = S; F.sel_out = maps_valid; Pj.ext_diff = nullptr; Pj.ext_valid = nullptr; Pj.n_ext = 0; Pj.sel_in = maps_valid; }
@@ -920,14 +928,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     auto linearise = [&](int lin) -> int {
         Pi.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
         Si.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N + SB : nullptr;
-        if (front) launch_front(lin);
-        else {
-            launch_lin(h, M, N, 6, false, MODE_MAPS, 2);
-            hipLaunchKernelGGL(k_dref_count, dim3(DREF_CNT_WG, N), dim3(256), 0, st, Pp, Dp);
-            hipLaunchKernelGGL(k_dref_scatter, dim3((unsigned)(((h->W + DREF_TW - 1) / DREF_TW) * ((h->H + DREF_TH - 1) / DREF_TH)), SB), dim3(DREF_TW * DREF_TH), 0, st, Pp, Dp);
-            // the adjoint of the forward pairs' samples of the source maps (before anything moves a forward pose)
-            hipLaunchKernelGGL(k_dref_scatter_src, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Pp, Dp, h->dref_ext_src, J.c_f);
-        }
+        launch_front(lin);
         Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
         if (smooth) hipLaunchKernelGGL(k_dref_smooth, dim3(B), dim3(1024), 0, st, Ds);
@@ -936,6 +937,15 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
         else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
         if (qres) hipLaunchKernelGGL((k_qres_schur<NS>), dim3(nqblk, B), dim3(256), 0, st, Q);
+        if (free_src) {
+            // every inverse pair as a group of one source WITHOUT argmin: that is the reference's inverse term (0.25 / K_i, own weights,
+            // valid x auto-mask, its depth-consistency term), its local unknowns the pair's pose and the source map it back-projects.
+            // Independent of the forward groups' launch above (own records behind theirs in jblockrec): one solve launch serves both.
+            Pj2.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
+            if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            if (qres) hipLaunchKernelGGL((k_qres_schur<1>), dim3(nqblk, SB), dim3(256), 0, st, Q2);
+        }
         return TCSFM_OK;
     };
     if (ex) {        // one linearisation, exported
@@ -993,21 +1003,14 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         const bool last = it == o->n_iters - 1;
         Si.it = it; Si.mode = 0; Si.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr; Si.log_scale_out = nullptr;
         Sj.it = it; Sj.mode = 0; Sj.pose_out = last ? d_pose_out : nullptr;
-        if (front) {      // the target groups' and the inverse pairs' systems: independent, one launch
+        if (free_src) {   // the forward groups' 6S x 6S systems and the inverse groups' (pose + source map) 6 x 6 systems: one launch
             ProfScope prof(h, 1);
-            hipLaunchKernelGGL((k_solve_front<NS>), dim3(B + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
-        } else hipLaunchKernelGGL((k_solve_joint<NS>), dim3(B), dim3(JSOLVE_NT), 0, st, Sj);
-        if (free_src) {
-            // every inverse pair as a group of one source WITHOUT argmin: that is the reference's inverse term (0.25 / K_i, own weights,
-            // valid x auto-mask, its depth-consistency term), its local unknowns the pair's pose and the source map it back-projects.  The
-            // workgroup records share jblockrec with the forward groups: the forward solve above has consumed them.
-            Pj2.trace = tr ? h->trace_bits + ((size_t)it * N + SB) * hw : nullptr;
-            if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
-            else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
-            if (qres) hipLaunchKernelGGL((k_qres_schur<1>), dim3(nqblk, SB), dim3(256), 0, st, Q2);
             Sj2.it = it; Sj2.mode = 0; Sj2.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr;
             Sj2.trace_decide = h->trace_decide ? h->trace_decide + (size_t)it * N + SB : nullptr;
-            hipLaunchKernelGGL((k_solve_joint<1>), dim3(SB), dim3(JSOLVE_NT), 0, st, Sj2);
+            hipLaunchKernelGGL((k_solve_joint2<NS>), dim3(B + SB), dim3(JSOLVE_NT), 0, st, Sj, Sj2);
+        } else {          // the target groups' and the inverse pairs' systems: independent, one launch
+            ProfScope prof(h, 1);
+            hipLaunchKernelGGL((k_solve_front<NS>), dim3(B + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
         }
         if (direct_out && last) {      // the last back-substitution also writes the caller's map (coalesced calls: every call's own)
             Uj.depth_out = d_depth_out; Q.depth_out = d_depth_out;
@@ -1016,19 +1019,20 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
                 for (int i = 0; i < ct->ncall; i++) { Uj.c_depth_out[i] = ct_depth[i]; Q.c_depth_out[i] = ct_depth[i]; }
             }
         }
-        if (qres && front) {      // cell step + x4 upsampling in one launch; the cell values ping-pong between the two halves of qres_rho
+        const unsigned qsu_tiles = (unsigned)(((h->W + QSU_TW - 1) / QSU_TW) * ((h->H + QSU_TH - 1) / QSU_TH));
+        if (qres) {       // cell step + x4 upsampling in one launch; the cell values ping-pong between the two halves of qres_rho
             const size_t half = ((n + 1) / 2) * (size_t)nq;
             Q.rho_q = h->qres_rho + (it & 1) * half; Q.rho_q_next = h->qres_rho + ((it + 1) & 1) * half;
-            hipLaunchKernelGGL((k_qres_step_up<NS>), dim3((unsigned)(((h->W + QSU_TW - 1) / QSU_TW) * ((h->H + QSU_TH - 1) / QSU_TH)), B), dim3(QSU_TW * QSU_TH), 0, st, Q);
-        } else if (qres) {
-            hipLaunchKernelGGL((k_qres_step<NS>), dim3((unsigned)((nq + 255) / 256), B), dim3(256), 0, st, Q);
-            hipLaunchKernelGGL(k_qres_upsample, px_t, dim3(256), 0, st, Q);
-        } else hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
-        if (free_src && qres) {
-            hipLaunchKernelGGL((k_qres_step<1>), dim3((unsigned)((nq + 255) / 256), SB), dim3(256), 0, st, Q2);
-            hipLaunchKernelGGL(k_qres_upsample, dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Q2);
-        } else if (free_src)        // the new source maps: the inverse pairs' own depth slots AND the depth channel of the packs the forward pairs sample
-            hipLaunchKernelGGL((k_dense_joint_update<1>), dim3((unsigned)((hw + 255) / 256), SB), dim3(256), 0, st, Uj2);
+            hipLaunchKernelGGL((k_qres_step_up<NS>), dim3(qsu_tiles, B), dim3(QSU_TW * QSU_TH), 0, st, Q);
+            if (free_src) {       // ... and the source maps' cells likewise (their upsampling refreshes the packs the forward pairs sample)
+                const size_t half2 = (n / 2) * (size_t)nq;
+                Q2.rho_q = h->qres_rho_src + (it & 1) * half2; Q2.rho_q_next = h->qres_rho_src + ((it + 1) & 1) * half2;
+                hipLaunchKernelGGL((k_qres_step_up<1>), dim3(qsu_tiles, SB), dim3(QSU_TW * QSU_TH), 0, st, Q2);
+            }
+        } else if (free_src)      // the targets' maps and the source maps (the inverse pairs' own depth slots AND the depth channel of the packs the
+                                  // forward pairs sample) in one launch
+            hipLaunchKernelGGL((k_dense_joint_update2<NS>), dim3((unsigned)((hw + 255) / 256), B + SB), dim3(256), 0, st, Uj, Uj2);
+        else hipLaunchKernelGGL((k_dense_joint_update<NS>), px_t, dim3(256), 0, st, Uj);
     }
     HIPCHK(h, hipGetLastError());
     if (o->n_iters == 0) {
@@ -2182,46 +2186,62 @@ int tcsfm_linearize_dense_window_sources(tcsfm_handle h, const tcsfm_opts *o, in
 
 // ---- lane self-probe.  MEASURED HAZARD (round 4): how well the streams of a process run side by side depends on the order
 // in which the process created them -- a handle created before the process's first device work gave four lanes that were SLOWER than one
-// (kernels of two overlapping lanes 40-55 us instead of 11).  The mechanism inside the runtime was not identified, so the library measures:
-// 16 launches of a stand-in kernel (480 workgroups of ~10 us of arithmetic: two of them fit the chip side by side) on the handle's stream,
-// then the same 16 alternating over the handle's stream and lane 1.  Streams that overlap finish the second run in about half the time of
-// the first; streams in the bad state take as long or longer.  ~0.5 ms, once per tcsfm_set_lanes.
-__global__ __launch_bounds__(256) void k_lane_probe(float *out, int iters) {
-    float a = (float)threadIdx.x * 1e-3f, b = 1.0001f;
-    for (int i = 0; i < iters; i++) { a = a * b + 1e-7f; b = b * 0.99999f + 1e-6f; }
-    if (a == 123.456f) out[0] = a + b;           // (never true: keeps the loop)
-}
+// (10 k against 13.5 k frame-pairs/s; kernels of overlapping lanes 40-55 us instead of 11).  The mechanism inside the runtime was not
+// identified, so the library measures the real thing: B = 1 refinements (the handle's own kernels, 4 Gauss-Newton iterations) on stand-in
+// images, first one after the other on the handle's stream, then round-robin over all lanes -- a stand-in kernel on two streams does NOT
+// show the state (it overlapped fine in a process whose four lanes ran at 0.72 of one: the first version of this probe).  Lanes that do
+// not beat one stream are switched off: their calls run on the handle's own stream.  ~5 ms, once per tcsfm_set_lanes.
 static int probe_lanes(tcsfm_ctx *h) {
     h->lanes_serial = false;
+    h->lane_probe[0] = h->lane_probe[1] = 0.f;
     if (h->lanes.empty()) return TCSFM_OK;
     if (const char *e = getenv("TCSFM_LANE_PROBE")) { if (atoi(e) == 0) return TCSFM_OK; }
-    tcsfm_ctx *c = h->lanes[0];
-    hipStream_t s0 = h->own_stream, s1 = c->own_stream;
-    hipEvent_t ev[4];
-    for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
-    float *sink = h->pose_dev;
-    const int iters = 6000, rounds = 16;
-    auto run = [&](bool two, float *ms) -> int {
-        for (int w = 0; w < 2; w++) {             // (first pass: warm-up)
-            HIPCHK(h, hipStreamSynchronize(s0)); HIPCHK(h, hipStreamSynchronize(s1));
-            HIPCHK(h, hipEventRecord(ev[0], s0));
-            if (two) { HIPCHK(h, hipEventRecord(ev[2], s0)); HIPCHK(h, hipStreamWaitEvent(s1, ev[2], 0)); }
-            for (int k = 0; k < rounds; k++) hipLaunchKernelGGL(k_lane_probe, dim3(480), dim3(256), 0, (two && (k & 1)) ? s1 : s0, sink, iters);
-            if (two) { HIPCHK(h, hipEventRecord(ev[3], s1)); HIPCHK(h, hipStreamWaitEvent(s0, ev[3], 0)); }
-            HIPCHK(h, hipEventRecord(ev[1], s0));
-            HIPCHK(h, hipEventSynchronize(ev[1]));
-            HIPCHK(h, hipEventElapsedTime(ms, ev[0], ev[1]));
+    const size_t hw = (size_t)h->H * h->W;
+    const int L = (int)h->lanes.size() + 1;
+    float *buf = nullptr;                                       // tgt | src [3 H W each], depth_t | depth_s [H W each], K [9], pose in [12], pose out [L][12]
+    const size_t nfl = 8 * hw + 9 + 12 + (size_t)L * 12;
+    HIPCHK(h, hipMalloc((void **)&buf, nfl * sizeof(float)));
+    float *tgt = buf, *src = buf + 3 * hw, *dt = buf + 6 * hw, *ds = buf + 7 * hw, *K = buf + 8 * hw, *pin = K + 9, *pout = pin + 12;
+    {
+        std::vector<float> img(8 * hw);
+        for (size_t i = 0; i < 6 * hw; i++) { const size_t p = i % hw; img[i] = 0.5f + 0.25f * sinf(0.05f * (float)(p % h->W) + 0.3f * (float)(i / hw)) * cosf(0.07f * (float)(p / h->W)); }
+        for (size_t i = 6 * hw; i < 8 * hw; i++) img[i] = 0.5f + 0.001f * (float)((i % hw) / h->W);
+        const float Kh[9] = {0.58f * h->W, 0.f, 0.5f * h->W, 0.f, 1.9f * h->H, 0.5f * h->H, 0.f, 0.f, 1.f};
+        const float ph[12] = {0.002f, -0.001f, -0.03f, 0.001f, -0.002f, 0.0005f, -0.002f, 0.001f, 0.03f, -0.001f, 0.002f, -0.0005f};
+        HIPCHK(h, hipMemcpy(buf, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(K, Kh, sizeof(Kh), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(pin, ph, sizeof(ph), hipMemcpyHostToDevice));
+    }
+    tcsfm_opts o; tcsfm_default_opts(&o);
+    hipStream_t keep = h->stream;
+    h->stream = h->own_stream;
+    int rc = TCSFM_OK;
+    auto run = [&](int nl, int calls, float *ms) -> int {
+        for (int pass = 0; pass < 2 && !rc; pass++) {           // (first pass: warm-up -- scratch allocations, intrinsics check)
+            HIPCHK(h, hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < calls && !rc; k++)
+                rc = tcsfm_refine_window_async(h, k % nl, &o, 1, 1, tgt, src, dt, ds, K, pin, nullptr, pout + (size_t)(k % nl) * 12, nullptr, nullptr);
+            HIPCHK(h, hipDeviceSynchronize());
+            *ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
-        return TCSFM_OK;
+        return rc;
     };
-    int rc = run(false, &h->lane_probe[0]);
-    if (!rc) rc = run(true, &h->lane_probe[1]);
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    const int calls = 24;
+    if (h->max_pairs >= 2) {
+        rc = run(1, calls, &h->lane_probe[0]);
+        if (!rc) rc = run(L, calls, &h->lane_probe[1]);
+    }
+    h->stream = keep;
+    (void)hipFree(buf);
+    k_forget(h);
+    for (tcsfm_ctx *c : h->lanes) k_forget(c);
     if (rc) return rc;
-    if (h->lane_probe[1] > 0.9f * h->lane_probe[0]) {
+    if (h->lane_probe[1] > 0.95f * h->lane_probe[0] && h->lane_probe[0] > 0.f) {
         h->lanes_serial = true;
-        fprintf(stderr, "tcsfm: lanes do not overlap in this process (probe: %.0f us on one stream, %.0f us over two): lane calls run on the handle's own "
-                        "stream; use the queued calls (tcsfm_set_coalesce) to keep the chip busy\n", h->lane_probe[0] * 1e3, h->lane_probe[1] * 1e3);
+        fprintf(stderr, "tcsfm: lanes do not overlap in this process (probe: %d B=1 refinements take %.0f us on one stream, %.0f us over %d lanes): lane "
+                        "calls run on the handle's own stream; use the queued calls (tcsfm_set_coalesce) to keep the chip busy\n", calls,
+                h->lane_probe[0] * 1e3, h->lane_probe[1] * 1e3, L);
     }
     return TCSFM_OK;
 }
