@@ -335,13 +335,13 @@ __global__ __launch_bounds__(256) void k_qres_upsample(QresParams P) {
 }
 
 template <int NS>
-__global__ __launch_bounds__(256) void k_qres_schur(QresParams P) {
+__device__ __forceinline__ void qres_schur_body(const QresParams &P, const int bx, const int b) {
     using JL = JointLayout<NS>;
     constexpr int NV = 2 + 6 * NS, NE = JL::NHJ + JL::NP, EPL = (NE + 63) / 64;
     __shared__ float cellv[4][32];
     __shared__ float wacc[4][EPL * 64];
     const int h = P.H / 4, w = P.W / 4, nq = h * w;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dy = lane >> 3, dx = lane & 7;
     // this lane's entries of the Schur sums: e < NHJ = the lower-triangle entry (r, c) of the pose block, then the right-hand side's
     int er[EPL], ec[EPL];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_qres_schur(QresParams P) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) acc[k] = 0.f;
     constexpr int CPW = QRES_CELLS_PER_WG / 4;
-    const int c_first = (blockIdx.x * 4 + wave) * CPW;
+    const int c_first = (bx * 4 + wave) * CPW;
     // all CPW cells' pixel records are requested before the first is used (unconditional loads from clamped addresses; weight 0 outside)
     float r[CPW][JL::JREC], wt[CPW];
 #pragma unroll
@@ -397,9 +397,18 @@ __global__ __launch_bounds__(256) void k_qres_schur(QresParams P) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) wacc[wave][lane + 64 * k] = acc[k];
     __syncthreads();
-    float *rec = P.jblockrec + ((size_t)b * P.rec_stride + P.rec_first + blockIdx.x) * JL::NACC;
+    float *rec = P.jblockrec + ((size_t)b * P.rec_stride + P.rec_first + bx) * JL::NACC;
     for (int e = tid; e < JL::NACC; e += 256)
         rec[e] = e < NE ? (wacc[0][e] + wacc[1][e]) + (wacc[2][e] + wacc[3][e]) : 0.f;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_qres_schur(QresParams P) { qres_schur_body<NS>(P, blockIdx.x, blockIdx.y); }
+// ... of the targets' cells (rows [0, Pa.B)) and of the source maps' cells (free source maps; rows behind them) in one launch
+template <int NS>
+__global__ __launch_bounds__(256) void k_qres_schur2(QresParams Pa, QresParams Pb) {
+    if ((int)blockIdx.y < Pa.B) qres_schur_body<NS>(Pa, blockIdx.x, blockIdx.y);
+    else qres_schur_body<1>(Pb, blockIdx.x, (int)blockIdx.y - Pa.B);
 }
 
 template <int NS>
@@ -427,15 +436,15 @@ __global__ __launch_bounds__(256) void k_qres_step(QresParams P) {
 // from LDS and writes its depth into the forward pairs' slots and the inverse pairs' packs, as k_qres_upsample.
 constexpr int QSU_TW = 32, QSU_TH = 8, QSU_CW = QSU_TW / 4 + 2, QSU_CH = QSU_TH / 4 + 2;
 template <int NS>
-__global__ __launch_bounds__(QSU_TW * QSU_TH) void k_qres_step_up(QresParams P) {
+__device__ __forceinline__ void qres_step_up_body(const QresParams &P, const int bx, const int b) {
     using JL = JointLayout<NS>;
     __shared__ float rq[QSU_CH * QSU_CW];
     const int h = P.H / 4, w = P.W / 4, nq = h * w, hw = P.H * P.W;
     const int tiles_x = (P.W + QSU_TW - 1) / QSU_TW;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x, b = blockIdx.y;
+    const int tyi = bx / tiles_x, txi = bx - tyi * tiles_x;
     const int tid = threadIdx.x;
     const int cx0 = txi * (QSU_TW / 4), cy0 = tyi * (QSU_TH / 4);
-    if (P.norms_zero && blockIdx.x == 0 && b == 0 && tid < P.norms_n) P.norms_zero[tid] = 0;
+    if (P.norms_zero && bx == 0 && b == 0 && tid < P.norms_n) P.norms_zero[tid] = 0;
     if (tid < QSU_CH * QSU_CW) {
         const int ly = tid / QSU_CW, lx = tid - ly * QSU_CW;
         const int cyr = cy0 - 1 + ly, cxr = cx0 - 1 + lx;
@@ -472,6 +481,14 @@ __global__ __launch_bounds__(QSU_TW * QSU_TH) void k_qres_step_up(QresParams P) 
         else if (P.depth_out) P.depth_out[(size_t)(s * P.B + b) * hw + idx] = dep;
         P.srcpack_inv[((size_t)(s * P.B + b) * (P.H + 2) + v + 1) * (P.W + 2) + u + 1].w = dep;
     }
+}
+template <int NS>
+__global__ __launch_bounds__(QSU_TW * QSU_TH) void k_qres_step_up(QresParams P) { qres_step_up_body<NS>(P, blockIdx.x, blockIdx.y); }
+// ... for the targets' cells and the source maps' cells (free source maps) in one launch
+template <int NS>
+__global__ __launch_bounds__(QSU_TW * QSU_TH) void k_qres_step_up2(QresParams Pa, QresParams Pb) {
+    if ((int)blockIdx.y < Pa.B) qres_step_up_body<NS>(Pa, blockIdx.x, blockIdx.y);
+    else qres_step_up_body<1>(Pb, blockIdx.x, (int)blockIdx.y - Pa.B);
 }
 
 }  // namespace tc

@@ -936,7 +936,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         ProfScope prof(h, 0);
         if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
         else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
-        if (qres) hipLaunchKernelGGL((k_qres_schur<NS>), dim3(nqblk, B), dim3(256), 0, st, Q);
+        if (qres && !free_src) hipLaunchKernelGGL((k_qres_schur<NS>), dim3(nqblk, B), dim3(256), 0, st, Q);
         if (free_src) {
             // every inverse pair as a group of one source WITHOUT argmin: that is the reference's inverse term (0.25 / K_i, own weights,
             // valid x auto-mask, its depth-consistency term), its local unknowns the pair's pose and the source map it back-projects.
@@ -944,7 +944,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             Pj2.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
             if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
             else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
-            if (qres) hipLaunchKernelGGL((k_qres_schur<1>), dim3(nqblk, SB), dim3(256), 0, st, Q2);
+            if (qres) hipLaunchKernelGGL((k_qres_schur2<NS>), dim3(nqblk, B + SB), dim3(256), 0, st, Q, Q2);      // both groups' cells
         }
         return TCSFM_OK;
     };
@@ -1023,12 +1023,11 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         if (qres) {       // cell step + x4 upsampling in one launch; the cell values ping-pong between the two halves of qres_rho
             const size_t half = ((n + 1) / 2) * (size_t)nq;
             Q.rho_q = h->qres_rho + (it & 1) * half; Q.rho_q_next = h->qres_rho + ((it + 1) & 1) * half;
-            hipLaunchKernelGGL((k_qres_step_up<NS>), dim3(qsu_tiles, B), dim3(QSU_TW * QSU_TH), 0, st, Q);
-            if (free_src) {       // ... and the source maps' cells likewise (their upsampling refreshes the packs the forward pairs sample)
+            if (free_src) {       // ... and the source maps' cells in the same launch (their upsampling refreshes the packs the forward pairs sample)
                 const size_t half2 = (n / 2) * (size_t)nq;
                 Q2.rho_q = h->qres_rho_src + (it & 1) * half2; Q2.rho_q_next = h->qres_rho_src + ((it + 1) & 1) * half2;
-                hipLaunchKernelGGL((k_qres_step_up<1>), dim3(qsu_tiles, SB), dim3(QSU_TW * QSU_TH), 0, st, Q2);
-            }
+                hipLaunchKernelGGL((k_qres_step_up2<NS>), dim3(qsu_tiles, B + SB), dim3(QSU_TW * QSU_TH), 0, st, Q, Q2);
+            } else hipLaunchKernelGGL((k_qres_step_up<NS>), dim3(qsu_tiles, B), dim3(QSU_TW * QSU_TH), 0, st, Q);
         } else if (free_src)      // the targets' maps and the source maps (the inverse pairs' own depth slots AND the depth channel of the packs the
                                   // forward pairs sample) in one launch
             hipLaunchKernelGGL((k_dense_joint_update2<NS>), dim3((unsigned)((hw + 255) / 256), B + SB), dim3(256), 0, st, Uj, Uj2);
