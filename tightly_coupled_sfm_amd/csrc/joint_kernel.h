@@ -609,11 +609,18 @@ struct JointSolveParams {
     // coalesced calls (CoalTab): the refined pose of forward pair n = s B + b goes to ITS call's output, at the pair's index in that call
     int c_ncall, c_B, c_S, c_pad;
     float *c_pose_out[TC_MAX_COAL];
+    // Split record sum (round 5): nsplit > 1 workgroups per target each sum a contiguous share of the target's workgroup records (the fetch
+    // of freshly written records by ONE workgroup is rate-bound: 186 KB for a KITTI target on 32 x 8 tiles took ~7 us), leave their
+    // partial sums in jpart [B][nsplit][NACC] (fp64, written through) and take a ticket; the LAST arriver adds the partials in index
+    // order (deterministic) and solves.  No workgroup waits for another.  jtick [B]: zero between launches (the last arriver resets it).
+    int nsplit;
+    double *jpart;
+    int *jtick;
 };
 
 constexpr int JSOLVE_NT = 1024;
 template <int NS>
-__device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, const int b, const int tid) {
+__device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, const int b, const int tid, const int split_k = 0) {
     using JL = JointLayout<NS>;
     constexpr int NP = JL::NP, NC = NP + 1;
     constexpr int APAD = JL::NACC <= 128 ? 128 : 256, PARTS = JSOLVE_NT / APAD;
@@ -641,15 +648,17 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
         // deterministic fp64 sum of the target's workgroup records, as in k_solve: thread = (accumulator, record subset), every
         // subset's loads issued in batches of 8 so that they are all in flight, subsets combined in fixed order
         const int c = tid & (APAD - 1), q = tid / APAD;
+        const int G = P.nsplit > 1 ? P.nsplit : 1;
+        const int chunk = (P.nblk + G - 1) / G, r_lo = split_k * chunk, r_hi = min(P.nblk, r_lo + chunk);      // this workgroup's share of the records
         double s = 0.0;
         if (c < JL::NACC) {
             const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + c;
-            for (int r0 = q; r0 < P.nblk; r0 += 32 * PARTS) {      // 32 loads per thread in flight (240 records of 192x640: one batch)
+            for (int r0 = r_lo + q; r0 < r_hi; r0 += 32 * PARTS) {      // 32 loads per thread in flight (240 records of 192x640: one batch)
                 float w[32];
 #pragma unroll
-                for (int k = 0; k < 32; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < P.nblk ? r : q) * JL::NACC]; }
+                for (int k = 0; k < 32; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < r_hi ? r : r_lo) * JL::NACC]; }
 #pragma unroll
-                for (int k = 0; k < 32; k++) s += (r0 + k * PARTS < P.nblk) ? (double)w[k] : 0.0;
+                for (int k = 0; k < 32; k++) s += (r0 + k * PARTS < r_hi) ? (double)w[k] : 0.0;
             }
         }
         part[tid] = s;
@@ -658,6 +667,30 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
             double t = 0.0;
             for (int k = 0; k < PARTS; k++) t += part[k * APAD + c];
             tot[c] = t;
+            if (G > 1) __hip_atomic_store(&P.jpart[((size_t)b * G + split_k) * JL::NACC + c], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written through
+        }
+        if (G > 1) {
+            // protocol of block_reduce_publish (kernels.h): write-through stores -> every storing wave drains vmcnt -> workgroup barrier -> one
+            // relaxed agent-scope ticket; the last arriver: agent-scope acquire -> barrier -> plain loads, fixed order
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int t = __hip_atomic_fetch_add(&P.jtick[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_flag[1] = (t == G - 1);
+            }
+            __syncthreads();
+            if (!s_flag[1]) return;               // (workgroup-uniform: the other shares' workgroups are done)
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                P.jtick[b] = 0;
+            }
+            __syncthreads();
+            if (tid < JL::NACC) {
+                double t = 0.0;
+                for (int k = 0; k < G; k++) t += P.jpart[((size_t)b * G + k) * JL::NACC + tid];
+                tot[tid] = t;
+            }
         }
     }
     __syncthreads();
@@ -793,7 +826,10 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
 }
 
 template <int NS>
-__global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) { solve_joint_body<NS>(P, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
+    const int G = P.nsplit > 1 ? P.nsplit : 1;
+    solve_joint_body<NS>(P, (int)blockIdx.x / G, threadIdx.x, (int)blockIdx.x % G);
+}
 
 // Dense mode on the reference's loss (round 5): the target groups' reduced systems AND the inverse pairs' 6 x 6 systems of one iteration
 // in ONE launch -- they are independent (different workgroups, different state), so a second dependent launch bought nothing but its
@@ -801,16 +837,18 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
 // the 1024 threads).
 template <int NS>
 __global__ __launch_bounds__(JSOLVE_NT) void k_solve_front(JointSolveParams Pj, SolveParams Pi) {
-    if ((int)blockIdx.x < Pj.B) solve_joint_body<NS>(Pj, blockIdx.x, threadIdx.x);
-    else solve_body<6, JSOLVE_NT, true>(Pi, (int)blockIdx.x - Pj.B, threadIdx.x);
+    const int G = Pj.nsplit > 1 ? Pj.nsplit : 1;      // (workgroups [0, B G): the targets' systems, G record shares each)
+    if ((int)blockIdx.x < Pj.B * G) solve_joint_body<NS>(Pj, (int)blockIdx.x / G, threadIdx.x, (int)blockIdx.x % G);
+    else solve_body<6, JSOLVE_NT, true>(Pi, (int)blockIdx.x - Pj.B * G, threadIdx.x);
 }
 
 // Free source maps (round 5): the forward groups (NS sources each) and the inverse groups (one source each: the inverse pairs with their
 // source map) of one iteration are independent systems -- one launch solves both.  Workgroups [0, Pa.B): Pa; [Pa.B, Pa.B + Pb.B): Pb.
 template <int NS>
 __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint2(JointSolveParams Pa, JointSolveParams Pb) {
-    if ((int)blockIdx.x < Pa.B) solve_joint_body<NS>(Pa, blockIdx.x, threadIdx.x);
-    else solve_joint_body<1>(Pb, (int)blockIdx.x - Pa.B, threadIdx.x);
+    const int Ga = Pa.nsplit > 1 ? Pa.nsplit : 1, Gb = Pb.nsplit > 1 ? Pb.nsplit : 1;
+    if ((int)blockIdx.x < Pa.B * Ga) solve_joint_body<NS>(Pa, (int)blockIdx.x / Ga, threadIdx.x, (int)blockIdx.x % Ga);
+    else { const int x = (int)blockIdx.x - Pa.B * Ga; solve_joint_body<1>(Pb, x / Gb, threadIdx.x, x % Gb); }
 }
 
 // back-substitution of the shared map; LM: promote / roll back first (as k_dense_update_lm)

@@ -56,6 +56,7 @@ struct tcsfm_ctx {
     float *jrec = nullptr, *jrec_acc = nullptr, *jblockrec = nullptr, *jdepth_acc = nullptr;
     JointState *jstate = nullptr;
     double *jdelta = nullptr;
+    double *jpart = nullptr; int *jtick = nullptr;     // split record sums of the joint solve (JointSolveParams::nsplit): [2 targets][8][NACC] fp64, tickets
     int jrec_S = 0;
     // dense mode on the reference's loss (dense_ref_kernel.h): mask counts, fixed-point scatter sums, linearisation export
     int *dref_norms = nullptr;
@@ -503,6 +504,7 @@ namespace {
 // (20 floats x max_pairs / 4 targets; S = 1 under the reference's loss needs 8 x max_pairs / 2).  The per-TARGET arrays (state, step,
 // accepted depth) are sized for the most targets any call can have: (max_pairs + 1) / 2, reached at S = 1 (they were sized
 // for S >= 2 and the S = 1 reference-loss mode indexed past them).
+constexpr int kJointSplitMax = 8;
 int joint_scratch(tcsfm_ctx *h) {
     if (h->jrec) return TCSFM_OK;
     using JM = JointLayout<JMAXS>;
@@ -516,6 +518,9 @@ int joint_scratch(tcsfm_ctx *h) {
     HIPCHK(h, hipMalloc((void **)&h->jblockrec, nb * 2 * h->nblk_alloc * JM::NACC * sizeof(float)));      // (tile records + the quarter-resolution mode's cell-group records)
     HIPCHK(h, hipMalloc((void **)&h->jstate, nt * sizeof(JointState)));
     HIPCHK(h, hipMalloc((void **)&h->jdelta, nt * 6 * JMAXS * sizeof(double)));
+    HIPCHK(h, hipMalloc((void **)&h->jpart, 2 * nt * kJointSplitMax * JM::NACC * sizeof(double)));      // (forward groups, then the free-source mode's inverse groups)
+    HIPCHK(h, hipMalloc((void **)&h->jtick, 2 * nt * sizeof(int)));
+    HIPCHK(h, hipMemset(h->jtick, 0, 2 * nt * sizeof(int)));
     h->jrec_S = JMAXS;
     return TCSFM_OK;
 }
@@ -690,6 +695,7 @@ int dref_clean(tcsfm_ctx *h) {
     const size_t hw = (size_t)h->H * h->W, n = h->max_pairs;
     if (h->dref_ext) HIPCHK(h, hipMemsetAsync(h->dref_ext, 0, ((n + 1) / 2) * hw * 2 * sizeof(long long), h->stream));
     if (h->dref_ext_src) HIPCHK(h, hipMemsetAsync(h->dref_ext_src, 0, (n / 2) * hw * 2 * sizeof(long long), h->stream));
+    if (h->jtick) HIPCHK(h, hipMemsetAsync(h->jtick, 0, 2 * ((n + 1) / 2) * sizeof(int), h->stream));      // (a call that failed midway may have left tickets behind)
     h->dref_dirty = false;
     return TCSFM_OK;
 }
@@ -998,6 +1004,16 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         ex->scal[4] = norms[0]; ex->scal[5] = norms[1]; ex->scal[6] = jx[1]; ex->scal[7] = 0.0;
         return TCSFM_OK;
     }
+    // the targets' record sums are split over several workgroups (JointSolveParams::nsplit: the last arriver solves) when a target has MANY records
+    // -- the quarter-resolution unknown's tile + cell-group records.  Measured (scripts/dense_ref_timing.py, TCSFM_JOINT_SPLIT=1 switches it off):
+    // 600-960 records: -2 ... -8 % per call; 150-480 records: the ticket costs what the faster fetch buys (+0 ... +2 %): not split.
+    auto split_of = [](int recs) { return recs >= 512 ? 8 : 1; };
+    static const int split_env = getenv("TCSFM_JOINT_SPLIT") ? atoi(getenv("TCSFM_JOINT_SPLIT")) : -1;       // (A/B hook: 1 = off)
+    {
+        const size_t nt = (n + 1) / 2;
+        Sj.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj.nblk); Sj.jpart = h->jpart; Sj.jtick = h->jtick;
+        Sj2.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj2.nblk); Sj2.jpart = h->jpart + nt * kJointSplitMax * JM::NACC; Sj2.jtick = h->jtick + nt;
+    }
     for (int it = 0; it < o->n_iters; it++) {
         if ((rc = linearise(it))) return rc;
         const bool last = it == o->n_iters - 1;
@@ -1007,10 +1023,10 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             ProfScope prof(h, 1);
             Sj2.it = it; Sj2.mode = 0; Sj2.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr;
             Sj2.trace_decide = h->trace_decide ? h->trace_decide + (size_t)it * N + SB : nullptr;
-            hipLaunchKernelGGL((k_solve_joint2<NS>), dim3(B + SB), dim3(JSOLVE_NT), 0, st, Sj, Sj2);
+            hipLaunchKernelGGL((k_solve_joint2<NS>), dim3(B * Sj.nsplit + SB * Sj2.nsplit), dim3(JSOLVE_NT), 0, st, Sj, Sj2);
         } else {          // the target groups' and the inverse pairs' systems: independent, one launch
             ProfScope prof(h, 1);
-            hipLaunchKernelGGL((k_solve_front<NS>), dim3(B + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
+            hipLaunchKernelGGL((k_solve_front<NS>), dim3(B * Sj.nsplit + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
         }
         if (direct_out && last) {      // the last back-substitution also writes the caller's map (coalesced calls: every call's own)
             Uj.depth_out = d_depth_out; Q.depth_out = d_depth_out;
@@ -1162,7 +1178,7 @@ void tcsfm_destroy(tcsfm_handle h) {
     for (auto &e : h->seq_done) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     void *ptrs[] = {h->stamp_buf, h->tgtpack, h->srcpack, h->depth_work, h->partials, h->blockrec, h->tickets, h->state, h->pconst, h->lin_out,
-                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth, h->jrec_src, h->jstate_src, h->jdelta_src, h->dref_ext_src, h->qres_rho_src, h->qres_rec_src,
+                    h->jrec, h->jrec_acc, h->jblockrec, h->jdepth_acc, h->jstate, h->jdelta, h->jpart, h->jtick, h->dref_norms, h->dref_ext, h->dref_export, h->qres_rho, h->qres_rec, h->pose_lin, h->dref_smooth, h->jrec_src, h->jstate_src, h->jdelta_src, h->dref_ext_src, h->qres_rho_src, h->qres_rec_src,
                     h->pose_dev, h->ls_dev, h->K_dev, h->stats_dev, h->dense_rec, h->depth0, h->dense_rec2, h->depth_alt, h->delta, h->scale_keys, h->scale_hist, h->sel_maps, h->dense_rec_acc, h->depth_acc, h->lm_accept,
                     h->seq_fpack, h->seq_fdepth, h->pair_idx, h->seq_img, h->seq_depth, h->seq_pose_in, h->seq_pose_out, h->seq_ls_out, h->seq_K, h->seq_dense, h->seq_dense_tmp};
     for (void *p : ptrs)
