@@ -8,7 +8,7 @@ test-cpu: build   ## oracle vs the reference's golden vectors, ABI, host logic (
 	$(PY) -m pytest tests -q -m "not gpu"
 test-gpu: build   ## HIP path vs oracle / golden vectors (needs an MI355X)
 	$(PY) -m pytest tests -q -m gpu
-test-asan: build ## AddressSanitizer + UBSan over the C oracle, the host SE(3) routines and examples/c_caller.c -> profiles/r04_asan.txt
+test-asan: build ## AddressSanitizer + UBSan over the C oracle, the host SE(3) routines and examples/c_caller.c -> profiles/r05_asan.txt
 	bash scripts/run_asan.sh
 bench: build      ## one JSON line: frame-pairs/s + roofline + cpu_baseline
 	$(PY) bench.py

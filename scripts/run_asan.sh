@@ -6,7 +6,7 @@
 #   bash scripts/run_asan.sh [report-file]
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=${1:-$ROOT/profiles/r04_asan.txt}
+OUT=${1:-$ROOT/profiles/r05_asan.txt}
 cd "$ROOT"
 LIBASAN=$(gcc -print-file-name=libasan.so)
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1"
