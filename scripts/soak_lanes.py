@@ -39,7 +39,7 @@ t0 = time.time(); n = 0; t_said = t0
 while time.time() - t0 < SECONDS:
     if time.time() - t_said > 60:       # (a long run must not look hung to the GPU box's watchdog)
         t_said = time.time(); print(f"... {n} rounds, {len(ref)} work items", file=sys.stderr, flush=True)
-    kind = rng.integers(0, 7)
+    kind = rng.integers(0, 9)
     if kind == 0:      # three pose windows in flight
         ws = rng.integers(0, T - 1, size=3)
         for l, w in enumerate(ws):
@@ -86,7 +86,24 @@ while time.time() - t0 < SECONDS:
         for w, p_, d_ in zip(ws, pq, dq):
             check(("dense", int(w)), [p_, d_])
         e.set_coalesce_lanes(1); e.set_coalesce(0)
-    elif kind == 5:    # round 4: dense window on the reference's loss, full- and quarter-resolution unknown
+    elif kind == 7:    # round 5: QUEUED dense calls on the reference's loss, merged with per-call normaliser groups (full- / quarter-resolution unknown):
+                       # the bits of the plain call of kind 5, whatever the grouping and the stream they ran on
+        q = int(rng.integers(0, 2))
+        e.set_coalesce(2); e.set_coalesce_lanes(int(rng.integers(1, 4)))
+        ws = rng.integers(0, T - 1, size=int(rng.integers(1, 6)))
+        pq = [torch.empty(2, 6, device="cuda") for _ in ws]; dq = [torch.empty(2, 1, H, W, device="cuda") for _ in ws]
+        oq = (odr, odq)[q]; oq.argmin = 1
+        for w, p_, d_ in zip(ws, pq, dq):
+            e.refine_dense_window_queued(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], p_, d_, oq)
+        if rng.integers(0, 2):      # a plain call behind queued ones: they are launched first (never overtaken)
+            w0 = int(rng.integers(0, T - 1))
+            p0 = e.refine_window(fd[w0][None], fd[w0 + 1][None, None], dd[w0][None], dd[w0 + 1][None, None], K, initd[w0], o)[0]
+            check(("pose", w0), [p0])
+        e.synchronize()
+        for w, p_, d_ in zip(ws, pq, dq):
+            check(("dref", q, int(w)), [p_, d_])
+        e.set_coalesce_lanes(1); e.set_coalesce(0)
+    elif kind == 5 or kind == 8:    # round 4: dense window on the reference's loss, full- and quarter-resolution unknown
         w = int(rng.integers(0, T - 1)); q = int(rng.integers(0, 3))           # (2: the reference's complete leaf set -- target and source maps, quarter resolution)
         p, d, _ = e.refine_dense_window(fd[w][None], fd[w + 1][None, None], dd[w][None], dd[w + 1][None, None], K, initd[w], (odr, odq, odf)[q], argmin=True)
         check(("dref", q, w), [p, d])
