@@ -23,7 +23,10 @@ using namespace tc;
 namespace {
 
 // tile geometry of the hot kernel (one place to retune)
-constexpr int TILE_W = 32, TILE_H = 16, TILE_NT = 512;
+#ifndef TC_TILE_H
+#define TC_TILE_H 16
+#endif
+constexpr int TILE_W = 32, TILE_H = TC_TILE_H, TILE_NT = TILE_W * TILE_H;      // (A/B builds: -DTC_TILE_H=8 -> 32 x 8 tiles of 256 threads)
 
 thread_local std::string g_create_error;
 
