@@ -469,7 +469,10 @@ __device__ inline float photo_err_planar(const float *__restrict__ x, const floa
 // The same value from an LDS tile (round 4): a workgroup owns a PT_W x PT_H tile of pixels, stages the tile + 1-pixel reflect halo of the six
 // colour planes once (about 9 coalesced loads per thread instead of 54 cache hits) and every thread reads its 3 x 3 window from LDS.  Same
 // neighbours (the halo is filled through refl_idx, as photo_err_planar indexes), same operation order -> the same bits.
-constexpr int PT_W = 64, PT_H = 4, PT_CW = PT_W + 2, PT_CH = PT_H + 2, PT_N = PT_CW * PT_CH;
+#ifndef TC_PACK_TW
+#define TC_PACK_TW 64
+#endif
+constexpr int PT_W = TC_PACK_TW, PT_H = 256 / PT_W, PT_CW = PT_W + 2, PT_CH = PT_H + 2, PT_N = PT_CW * PT_CH;      // (A/B: -DTC_PACK_TW=32 -> 32 x 8 tiles)
 __device__ __forceinline__ void pack_stage_tile(float (*tile)[PT_N], const float *__restrict__ x, const float *__restrict__ y, int H, int W, int x0, int y0) {
     const int hw = H * W;
     for (int e = threadIdx.x; e < PT_N; e += 256) {
