@@ -105,11 +105,15 @@ typedef struct tcsfm_opts {
     float prior_init;      /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_depth_init_weight'] if options['l_depth_init'] else 0
                               (optimizer.py:89-90): weight of mean SSIM(current, initial sigmoid disparity of the target); default 0.1  */
     int32_t depth_param;   /* TCSFM_DEPTH_*: dense window mode under TCSFM_WINDOW_REFERENCE (default FULL)                             */
-    float w_pose_consist;  /* pose window modes under TCSFM_WINDOW_REFERENCE, 6-DoF Gauss-Newton: 0.1 if options['l_pose_consist'] else 0
+    float w_pose_consist;  /* pose window modes AND the dense window mode under TCSFM_WINDOW_REFERENCE, 6-DoF Gauss-Newton on the SE(3) chart:
+                              0.1 if options['l_pose_consist'] else 0
                               (default 0, as the reference's drivers) -- w * mean |p_fwd + p_inv| over the S*B x 6 entries of the
                               reference's 6-vectors (optimizer.py:95-96).  Every pair gets the exact gradient w.r.t. its own pose (IRLS on
                               the L1 term, floor irls_eps) and the block-Jacobi majoriser of the curvature, its partner held at the
-                              linearisation point; value and gradient pinned on reference autograd (golden G13 `full_pc`)                */
+                              linearisation point; value and gradient pinned on reference autograd (golden G13 `full_pc`).  In the dense
+                              mode the term enters the REDUCED pose systems (it does not depend on the maps): the forward pairs' diagonal
+                              blocks of their target's joint system, the inverse pairs' own systems; tcsfm_linearize_dense_window leaves it
+                              out, and queued calls that carry it are not merged                                                         */
     float w_smooth;        /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_smooth_weight'] if options['l_smooth'] else 0 (default
                               0, as the reference's drivers) -- w * get_smooth_loss(target disparity, target image) (optimizer.py:92-93,
                               losses.py:43-61: edge-aware L1 smoothness of the mean-normalised sigmoid disparity).  Exact gradient incl. the

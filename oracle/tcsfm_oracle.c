@@ -2537,6 +2537,33 @@ void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const 
  * inverse pair's pose }, fixed damping lambda0 on the pose blocks (Marquardt-scaled) and lambda_depth on the depth block.
  * depth_io [B][n] in / out; pose_io [2SB][6]; stats [n_iters][7] (the scalars of every linearisation) or NULL;
  * bits [n_iters][2SB][n]: forced replay of the engine's decisions. */
+/* l_pose_consist in the dense mode on the reference's loss (optimizer.py:95-96 beside :235-268): the term of pose_consist_term added to the
+ * REDUCED pose systems (it does not depend on the depth maps) -- forward pair (s, b) to the diagonal 6 x 6 block s of target b's joint system,
+ * inverse pair m to its own 6 x 6 system (Hi / gi, or the free-source system Hs / gs).  Every pair sees its partner at this linearisation;
+ * returns the term's value (the pairs' halves add up to it). */
+static double dref_pose_consist(int B, int S, const orc_opts *op, const double *T, double *Hj, double *gj, double *Hi, double *gi) {
+    const int SB = S * B, NP = 6 * S;
+    const double c = op->w_pose_consist / (6.0 * SB);
+    double total = 0;
+    for (int m = 0; m < 2 * SB; m++) {
+        double pc, pg[6], pH[36];
+        pose_consist_term(T + 12 * m, T + 12 * (m < SB ? m + SB : m - SB), c, op->irls_eps, &pc, pg, pH);
+        total += pc;
+        if (m < SB) {
+            const int s = m / B, b = m % B;
+            for (int i = 0; i < 6; i++) {
+                gj[(size_t)b * NP + 6 * s + i] += pg[i];
+                for (int j = 0; j < 6; j++) Hj[(size_t)b * NP * NP + (size_t)(6 * s + i) * NP + 6 * s + j] += pH[6 * i + j];
+            }
+        } else {
+            for (int i = 0; i < 6; i++) {
+                gi[6 * (m - SB) + i] += pg[i];
+                for (int j = 0; j < 6; j++) Hi[36 * (m - SB) + 6 * i + j] += pH[6 * i + j];
+            }
+        }
+    }
+    return total;
+}
 static void refine_dense_ref_impl(int H, int W, int B, int S, const real *tgt, const real *srcs, real *depth_io, real *depth_s /* in / out when free_sources */,
                                   const real *K, const orc_opts *op, int argmin, double w_init, double lambda_depth, double min_depth, double max_depth,
                                   double *pose_io, double *stats, const unsigned short *bits, int free_sources) {
@@ -2567,6 +2594,7 @@ static void refine_dense_ref_impl(int H, int W, int B, int S, const real *tgt, c
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep,
                             bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s, free_sources ? &ss : NULL);
         g_lin_idx = -1;
+        if (op->w_pose_consist > 0) sc.loss += dref_pose_consist(B, S, op, T, Hj, gj, free_sources ? ss.Hs : Hi, free_sources ? ss.gs : gi);
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {       /* forward group: (S + lambda diag S + 1e-12 I) d = -gS, back-substitution of the depth map */
             double A[36 * JMAXS * JMAXS], dl[6 * JMAXS];
@@ -2750,6 +2778,7 @@ static void refine_dense_ref_q_impl(int H, int W, int B, int S, const real *tgt,
         linearize_dense_ref(H, W, B, S, tgt, srcs, depth_io, depth_s, d0, K, op, argmin, w_init, min_depth, max_depth, INFINITY, T, aep,
                             bits ? bits + (size_t)it * 2 * SB * n : NULL, &sc, g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s, free_sources ? &ss : NULL);
         g_lin_idx = -1;
+        if (op->w_pose_consist > 0) sc.loss += dref_pose_consist(B, S, op, T, Hj, gj, free_sources ? ss.Hs : Hi, free_sources ? ss.gs : gi);
         if (stats) { double *r = stats + 7 * it; r[0] = sc.loss; r[1] = sc.L_fwd; r[2] = sc.L_inv; r[3] = sc.L_dc; r[4] = sc.L_init; r[5] = sc.Kf; r[6] = sc.Ki; }
         for (int b = 0; b < B; b++) {
             for (int i = 0; i < n; i++) {

@@ -415,3 +415,49 @@ def test_dense_reference_with_smoothness_term_follows_the_oracle(quarter, orc):
     assert np.abs(d_plain[:B, 0].cpu().numpy() / depth[:B, 0] - 1).max() > 1e-4          # the term moves the map
     with pytest.raises(RuntimeError):
         e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, w_smooth=2.0), argmin=True)
+
+
+@pytest.mark.parametrize("mode", ["full", "quarter", "free"])
+def test_dense_reference_with_pose_consistency_term_follows_the_oracle(mode, orc):
+    """l_pose_consist as a term of the dense mode (opts.w_pose_consist; optimizer.py:95-96 beside :235-268): 0.1 mean |p_fwd + p_inv| added to the
+    reduced pose systems -- the forward pairs' diagonal blocks of the target's joint system, the inverse pairs' own systems (or their groups with
+    the source maps free).  The iterates follow the oracle with the term (its weight raised so that it matters), the term changes the poses and
+    pulls p_fwd + p_inv towards zero; under the PAIR rule it is refused"""
+    from tightly_coupled_sfm_amd.engine import Engine, default_opts
+    from tightly_coupled_sfm_amd import _lib
+    B, S, H, W, n_it, wpc = 2, 2, 48, 160, 3, 0.5
+    w = _window(B, S, H, W, seed=53)
+    N = 2 * S * B
+    w["pose"] = w["pose"].copy()
+    w["pose"][S * B:] += np.array([0.004, -0.003, 0.005, 0.002, 0.003, -0.002])      # the inverse poses start off the negated forward poses: r != 0
+    e = Engine(H, W, N)
+    kw = dict(n_iters=n_it, w_dc=0.15, prior_init=0.1, min_depth=0.06, max_depth=2.67, window_rule=_lib.WINDOW_REFERENCE, lambda_depth=1.0,
+              depth_param=_lib.DEPTH_QUARTER if mode == "quarter" else _lib.DEPTH_FULL, free_source_depths=1 if mode == "free" else 0)
+    t = {k: _dev(v) for k, v in w.items()}
+    dt4, ds5 = t["depth_t"][:, None].contiguous(), t["depth_s"][:, :, None].contiguous()
+    e.trace_begin(n_it, N)
+    pose, depth, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(w_pose_consist=wpc, **kw), stats=True, argmin=True)
+    bits, _ = e.trace_end()
+    pose = pose.cpu().numpy().astype(np.float64); depth = depth.cpu().numpy().astype(np.float64)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    orc.flip_stats_reset()
+    fn = {"full": orc.refine_dense_ref, "quarter": orc.refine_dense_ref_q, "free": orc.refine_dense_ref_free}[mode]
+    res = fn(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oracle_opts(n_iters=n_it, w_dc=0.15, w_pose_consist=wpc),
+             argmin=True, w_init=0.1, lambda_depth=1.0, min_depth=0.06, max_depth=2.67, bits=bits.reshape(n_it, N, H * W))
+    po, do, so = res[0], res[1], res[-1] if mode == "free" else res[2]
+    nf, hard = orc.flip_stats(n_it)
+    assert hard.sum() == 0, (nf, hard)
+    for m in range(N):
+        et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
+        assert et < 1e-4 and er < 1e-4, (m, et, er)
+    assert np.abs(depth[:B, 0] / do - 1).max() < 1e-4, np.abs(depth[:B, 0] / do - 1).max()
+    if mode == "free":
+        assert np.abs(depth[S * B:, 0].reshape(S, B, H, W) / res[2] - 1).max() < 1e-4
+    assert np.all(np.diff(so[:, 0]) < 0), so[:, 0]
+    p_plain, _, _ = e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(**kw), stats=True, argmin=True)
+    p_plain = p_plain.cpu().numpy().astype(np.float64)
+    r_with = np.abs(pose[:S * B] + pose[S * B:]).mean(); r_plain = np.abs(p_plain[:S * B] + p_plain[S * B:]).mean()
+    assert np.abs(p_plain - pose).max() > 1e-5 and r_with < r_plain, (r_with, r_plain)      # the term moves the poses, towards p_fwd = -p_inv
+    with pytest.raises(RuntimeError):
+        e.refine_dense_window(t["tgt"], t["srcs"], dt4, ds5, t["K"], t["pose"], default_opts(n_iters=1, w_pose_consist=wpc), argmin=True)
+    e.close()

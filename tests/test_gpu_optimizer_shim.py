@@ -136,6 +136,15 @@ def test_tuple_form_dense_mode_and_legacy_switches():
     for d0, d1 in zip(rs["depths_init"][1:], rs["depths_opt"][1:]):
         assert d1.shape == d0.shape and torch.isfinite(d1).all() and 1e-6 < float(((d1 - d0).abs() / d0).mean()) < 0.1 and bend(d1) < 1e-5
     assert np.all(rs["gn_cost"].numpy()[:, 3] < rs["gn_cost"].numpy()[:, 0])
+    # options['l_pose_consist'] (optimizer.py:95-96) is a term of this mode too (opts.w_pose_consist = 0.1): no warning, and the poses differ
+    pose_model, depth_model = standins.window_models(w, iters, device="cuda")
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error", UserWarning)
+        opc = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True, l_pose_consist=True), _config(B, iters), pose_model, depth_model, "09_02")
+    assert abs(opc._opts().w_pose_consist - 0.1) < 1e-7
+    rpc = opc.optimize_window(0, data)
+    assert torch.isfinite(rpc["poses_opt"]).all() and not torch.equal(rpc["poses_opt"], rq["poses_opt"])
     # options['window_rule'] = 'pair': the library's joint dense mode -- every frame's depth refined (the source frames by their inverse pair)
     pose_model, depth_model = standins.window_models(w, iters, device="cuda")
     rp = DepthOptimizer(dict(OPTIONS, optimize_depth_pred=True, window_rule="pair"), _config(B, iters), pose_model, depth_model, "09_02").optimize_window(0, data)

@@ -616,10 +616,17 @@ struct JointSolveParams {
     int nsplit;
     double *jpart;
     int *jtick;
+    // l_pose_consist (optimizer.py:95-96; kernels templated PC): c = weight / (6 S B); pose_lin [2][pc_np][12] holds every pair's transform
+    // at linearisation `it` in buffer it & 1 (SolveParams, kernels.h); forward pair n = s B + b sits at pc_self0 + n, its partner at pc_part0 + n
+    double w_pc, pc_eps;
+    double *pose_lin;
+    int pc_np, pc_self0, pc_part0;
 };
 
 constexpr int JSOLVE_NT = 1024;
-template <int NS>
+// PC: the pose-consistency term is added to the diagonal 6 x 6 blocks of the reduced system (it does not depend on the depth map); as in
+// k_solve every pair sees its partner at THIS linearisation and the block-Jacobi majoriser 2 c / max(|r|, eps) (oracle dref_pose_consist)
+template <int NS, bool PC = false>
 __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, const int b, const int tid, const int split_k = 0) {
     using JL = JointLayout<NS>;
     constexpr int NP = JL::NP, NC = NP + 1;
@@ -694,9 +701,58 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
         }
     }
     __syncthreads();
+    __shared__ double pcA[PC ? NS : 1][36], pcG[PC ? NS : 1][6], pcD[PC ? NS : 1][6], pcH[PC ? NS : 1][36], pcg[PC ? NS : 1][6], pcC[PC ? NS : 1];
+    double pc_cost = 0.0;
+    if constexpr (PC) {
+        const int g = tid >> 6, l = tid & 63;
+        if (g < NS && l == 0) {       // pose coordinates, A^-1 = [[-I, Tx], [0, -Je^-1]], IRLS gradient and majoriser (serial: one lane per source)
+            const int n = g * P.B + b;
+            const double *Tm = P.st[n].Ttry, *Tp = P.pose_lin + ((size_t)(P.it & 1) * P.pc_np + P.pc_part0 + n) * 12;
+            double tm[12], tp_[12], pm[6], pp[6];
+            for (int i = 0; i < 12; i++) { tm[i] = Tm[i]; tp_[i] = Tp[i]; }
+            T_to_pose(tm, pm); T_to_pose(tp_, pp);
+            const double cx = cos(-pm[3]), sx = sin(-pm[3]), cy = cos(-pm[4]), sy = sin(-pm[4]);
+            const double Je[9] = {1, 0, sy, 0, cx, -sx * cy, 0, sx, cx * cy};
+            const double id = 1.0 / cy;
+            const double Ji[9] = {(Je[4] * Je[8] - Je[5] * Je[7]) * id, -(Je[1] * Je[8] - Je[2] * Je[7]) * id, (Je[1] * Je[5] - Je[2] * Je[4]) * id,
+                                  -(Je[3] * Je[8] - Je[5] * Je[6]) * id, (Je[0] * Je[8] - Je[2] * Je[6]) * id, -(Je[0] * Je[5] - Je[2] * Je[3]) * id,
+                                  (Je[3] * Je[7] - Je[4] * Je[6]) * id, -(Je[0] * Je[7] - Je[1] * Je[6]) * id, (Je[0] * Je[4] - Je[1] * Je[3]) * id};
+            const double tq[3] = {-pm[0], -pm[1], -pm[2]};
+            const double Tx[9] = {0, -tq[2], tq[1], tq[2], 0, -tq[0], -tq[1], tq[0], 0};
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) {
+                    double v = 0.0;
+                    if (i < 3 && j < 3) v = (i == j) ? -1.0 : 0.0;
+                    else if (i < 3) v = Tx[3 * i + (j - 3)];
+                    else if (j >= 3) v = -Ji[3 * (i - 3) + (j - 3)];
+                    pcA[g][6 * i + j] = v;
+                }
+            double cc = 0.0;
+            for (int j = 0; j < 6; j++) {
+                const double rj = pm[j] + pp[j], a = fabs(rj), den = a > P.pc_eps ? a : P.pc_eps;
+                cc += 0.5 * P.w_pc * a;
+                pcG[g][j] = P.w_pc * rj / den; pcD[g][j] = 2.0 * P.w_pc / den;
+            }
+            pcC[g] = cc;
+        }
+        __syncthreads();
+        if (g < NS && l < 36) {
+            const int i = l / 6, j = l - 6 * i;
+            double v = 0.0;
+            for (int k = 0; k < 6; k++) v += pcA[g][6 * k + i] * pcD[g][k] * pcA[g][6 * k + j];
+            pcH[g][l] = v;
+        } else if (g < NS && l < 42) {
+            const int i = l - 36;
+            double v = 0.0;
+            for (int k = 0; k < 6; k++) v += pcA[g][6 * k + i] * pcG[g][k];
+            pcg[g][i] = v;
+        }
+        __syncthreads();
+        for (int g2 = 0; g2 < NS; g2++) pc_cost += pcC[g2];
+    }
     double Kn = tot[JL::OFF_S + 1], an = Kn > 0 ? 1.0 / Kn : 0.0;
     if (P.norms) { Kn = (double)P.norms[2 * (P.norm_B > 0 ? b / P.norm_B : 0)]; an = Kn > 0 ? P.c_f / Kn : 0.0; }      // the reference's batch normaliser (optimizer.py:69)
-    const double cost = an * tot[JL::OFF_S];
+    const double cost = an * tot[JL::OFF_S] + pc_cost;
     if (P.export_out) {       // one linearisation, exported (no step): cost, a_f and the pose gradients of the group's records
         if (tid == 0) { P.export_out[(size_t)b * (2 + 6 * JMAXS)] = cost; P.export_out[(size_t)b * (2 + 6 * JMAXS) + 1] = an; }
         if (tid < NP) P.export_out[(size_t)b * (2 + 6 * JMAXS) + 2 + tid] = an * tot[JL::OFF_G + tid];
@@ -734,7 +790,14 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
     for (int i = tid; i < NP * NC; i += NTS) {
         const int r = i / NC, c = i - r * NC;
         double v;
-        if (accept) { v = (c < NP) ? an * tot[JL::tri(r, c)] : -an * tot[JL::OFF_G + r]; S.M[i] = v; }
+        if (accept) {
+            v = (c < NP) ? an * tot[JL::tri(r, c)] : -an * tot[JL::OFF_G + r];
+            if constexpr (PC) {
+                if (c == NP) v -= pcg[r / 6][r % 6];
+                else if (r / 6 == c / 6) v += pcH[r / 6][(r % 6) * 6 + c % 6];
+            }
+            S.M[i] = v;
+        }
         else v = S.M[i];
         M[i] = v;
     }
@@ -807,6 +870,7 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
             T[24 + sub] = v;
             ps.Ttry[sub] = v;
             if (last_gn) ps.Tcur[sub] = v;
+            if constexpr (PC) P.pose_lin[((size_t)((P.it + 1) & 1) * P.pc_np + P.pc_self0 + n) * 12 + sub] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -835,20 +899,21 @@ __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint(JointSolveParams P) {
 // in ONE launch -- they are independent (different workgroups, different state), so a second dependent launch bought nothing but its
 // ~6 us.  Workgroups [0, B): solve_joint_body; [B, B + n_inv): solve_body of inverse pair blockIdx.x - B (its record sums spread over
 // the 1024 threads).
-template <int NS>
+// PC: with the pose-consistency term (both roles).
+template <int NS, bool PC = false>
 __global__ __launch_bounds__(JSOLVE_NT) void k_solve_front(JointSolveParams Pj, SolveParams Pi) {
     const int G = Pj.nsplit > 1 ? Pj.nsplit : 1;      // (workgroups [0, B G): the targets' systems, G record shares each)
-    if ((int)blockIdx.x < Pj.B * G) solve_joint_body<NS>(Pj, (int)blockIdx.x / G, threadIdx.x, (int)blockIdx.x % G);
-    else solve_body<6, JSOLVE_NT, true>(Pi, (int)blockIdx.x - Pj.B * G, threadIdx.x);
+    if ((int)blockIdx.x < Pj.B * G) solve_joint_body<NS, PC>(Pj, (int)blockIdx.x / G, threadIdx.x, (int)blockIdx.x % G);
+    else solve_body<6, JSOLVE_NT, true, PC>(Pi, (int)blockIdx.x - Pj.B * G, threadIdx.x);
 }
 
 // Free source maps (round 5): the forward groups (NS sources each) and the inverse groups (one source each: the inverse pairs with their
 // source map) of one iteration are independent systems -- one launch solves both.  Workgroups [0, Pa.B): Pa; [Pa.B, Pa.B + Pb.B): Pb.
-template <int NS>
+template <int NS, bool PC = false>
 __global__ __launch_bounds__(JSOLVE_NT) void k_solve_joint2(JointSolveParams Pa, JointSolveParams Pb) {
     const int Ga = Pa.nsplit > 1 ? Pa.nsplit : 1, Gb = Pb.nsplit > 1 ? Pb.nsplit : 1;
-    if ((int)blockIdx.x < Pa.B * Ga) solve_joint_body<NS>(Pa, (int)blockIdx.x / Ga, threadIdx.x, (int)blockIdx.x % Ga);
-    else { const int x = (int)blockIdx.x - Pa.B * Ga; solve_joint_body<1>(Pb, x / Gb, threadIdx.x, x % Gb); }
+    if ((int)blockIdx.x < Pa.B * Ga) solve_joint_body<NS, PC>(Pa, (int)blockIdx.x / Ga, threadIdx.x, (int)blockIdx.x % Ga);
+    else { const int x = (int)blockIdx.x - Pa.B * Ga; solve_joint_body<1, PC>(Pb, x / Gb, threadIdx.x, x % Gb); }
 }
 
 // back-substitution of the shared map; LM: promote / roll back first (as k_dense_update_lm)

@@ -2048,6 +2048,9 @@ struct SolveParams {
     // initialisation and by the previous launch: a pair never reads what its partner writes in the SAME launch)
     double w_pc, pc_eps;                // pc_eps: floor of |r| in the IRLS weights (opts.irls_eps)
     double *pose_lin;
+    // the same term with this launch's pairs a SLICE of the call's pairs (the inverse pairs of the dense mode on the reference's loss, solved
+    // as 0 .. S B - 1): pc_np > 0 = pairs per buffer, pair n sits at pc_self0 + n and its partner at pc_part0 + n
+    int pc_np, pc_self0, pc_part0;
     // coalesced calls (CoalTab): the refined pose of batch pair n goes to ITS call's output, at the pair's index in that call
     int c_ncall, c_B, c_S, c_pad;
     float *c_pose_out[TC_MAX_COAL];
@@ -2079,7 +2082,7 @@ __device__ inline void T_to_pose_f32(const double *T, float *pose) {
 // NT: threads that enter (256: k_solve; 1024: the pair role of k_solve_front, whose record sums are spread over four times the threads).
 // LEAN: the SE(3) chart without the pose-consistency term (what the dense mode on the reference's loss asks of it): the rare branches that
 // set the register budget of the general kernel are compiled out (k_solve_front runs 1024-thread workgroups: 128 VGPRs).
-template <int NP, int NT, bool LEAN = false>
+template <int NP, int NT, bool LEAN = false, bool PC = !LEAN>
 __device__ __forceinline__ void solve_body(const SolveParams &P, const int n, const int tid) {
     using L = AccLayout<NP>;
     constexpr int NPH = L::NH + NP;
@@ -2098,10 +2101,10 @@ __device__ __forceinline__ void solve_body(const SolveParams &P, const int n, co
     // wait on a global load (each first touch used to cost a miss in the middle of the dependent chain)
     if (tid < NST) sst[tid] = reinterpret_cast<const double *>(&P.st[n])[tid];
     __shared__ double pcT[12], pcA[36], pcD[6], pcG[6];
-    const bool pc_on = !LEAN && NP == 6 && P.rule && P.w_pc > 0.0 && P.pose_lin != nullptr;
+    const bool pc_on = PC && NP == 6 && P.rule && P.w_pc > 0.0 && P.pose_lin != nullptr;
     if (pc_on && tid >= 64 && tid < 76) {
-        const int partner = n < P.grp_fwd ? n + P.grp_fwd : n - P.grp_fwd;
-        pcT[tid - 64] = P.pose_lin[((size_t)(P.it & 1) * P.n_pairs + partner) * 12 + (tid - 64)];
+        const int partner = P.pc_np > 0 ? P.pc_part0 + n : (n < P.grp_fwd ? n + P.grp_fwd : n - P.grp_fwd);
+        pcT[tid - 64] = P.pose_lin[((size_t)(P.it & 1) * (P.pc_np > 0 ? P.pc_np : P.n_pairs) + partner) * 12 + (tid - 64)];
     }
     __shared__ double kpart[NT];
     if (P.rule && !P.norms) {   // batch-summed mask count of this pair's group: every record of every pair of the group, fixed order
@@ -2315,7 +2318,7 @@ __device__ __forceinline__ void solve_body(const SolveParams &P, const int n, co
         const bool last_gn = (P.solver == 0 && P.it == P.n_iters - 1);   // GN: the last step is always taken
         if (tid < 12) {
             const double v = Ts[24 + tid]; S.Ttry[tid] = v; if (last_gn) S.Tcur[tid] = v;
-            if (P.pose_lin) P.pose_lin[((size_t)((P.it + 1) & 1) * P.n_pairs + n) * 12 + tid] = v;
+            if (P.pose_lin) P.pose_lin[((size_t)((P.it + 1) & 1) * (P.pc_np > 0 ? P.pc_np : P.n_pairs) + (P.pc_np > 0 ? P.pc_self0 + n : n)) * 12 + tid] = v;
         }
         if (tid == 0) { S.stry = stry; if (last_gn) S.scur = stry; }
         write_const_lanes<NP>(tid, Lc.K, Ts + 24, stry, P.pc[n]);

@@ -785,8 +785,11 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the couplings are set explicitly below)
+    oo.w_pose_consist = 0.f;                     // (... and so is l_pose_consist: `pc` below)
+    const bool pc = o->w_pose_consist > 0.f && !ex;      // optimizer.py:95-96 as a term of this mode (the export of one linearisation leaves it out)
     InitParams I = init_params(h, &oo, N, d_pose_in, nullptr, d_K, 0);
     I.K_mod = B;
+    if (pc) I.pose_lin = h->pose_lin;            // buffer 0 of [2][N][12]: every pair's transform at the first linearisation
     // the pack also zeroes the batch counters and -- plain refinement with fixed source maps -- leaves the inputs in the caller's depth
     // output: its inverse slots (the source maps) are final, the forward slots are overwritten by the last back-substitution
     const bool direct_out = !ex && !(o->free_source_depths != 0) && o->n_iters > 0 && (d_depth_out != nullptr || ct != nullptr);
@@ -1017,6 +1020,12 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         Sj.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj.nblk); Sj.jpart = h->jpart; Sj.jtick = h->jtick;
         Sj2.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj2.nblk); Sj2.jpart = h->jpart + nt * kJointSplitMax * JM::NACC; Sj2.jtick = h->jtick + nt;
     }
+    if (pc) {     // c = weight / (6 S B) of the CALL (merged calls never carry the term); forward pairs at [0, SB), inverse pairs at [SB, 2 SB) of a buffer
+        const double c = (double)o->w_pose_consist / (6.0 * SB);
+        Sj.w_pc = c; Sj.pc_eps = (double)o->irls_eps; Sj.pose_lin = h->pose_lin; Sj.pc_np = N; Sj.pc_self0 = 0; Sj.pc_part0 = SB;
+        Sj2.w_pc = c; Sj2.pc_eps = (double)o->irls_eps; Sj2.pose_lin = h->pose_lin; Sj2.pc_np = N; Sj2.pc_self0 = SB; Sj2.pc_part0 = 0;
+        Si.w_pc = c; Si.pc_eps = (double)o->irls_eps; Si.pose_lin = h->pose_lin; Si.pc_np = N; Si.pc_self0 = SB; Si.pc_part0 = 0;
+    }
     for (int it = 0; it < o->n_iters; it++) {
         if ((rc = linearise(it))) return rc;
         const bool last = it == o->n_iters - 1;
@@ -1026,10 +1035,12 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             ProfScope prof(h, 1);
             Sj2.it = it; Sj2.mode = 0; Sj2.pose_out = last ? d_pose_out + (size_t)SB * 6 : nullptr;
             Sj2.trace_decide = h->trace_decide ? h->trace_decide + (size_t)it * N + SB : nullptr;
-            hipLaunchKernelGGL((k_solve_joint2<NS>), dim3(B * Sj.nsplit + SB * Sj2.nsplit), dim3(JSOLVE_NT), 0, st, Sj, Sj2);
+            if (pc) hipLaunchKernelGGL((k_solve_joint2<NS, true>), dim3(B * Sj.nsplit + SB * Sj2.nsplit), dim3(JSOLVE_NT), 0, st, Sj, Sj2);
+            else hipLaunchKernelGGL((k_solve_joint2<NS>), dim3(B * Sj.nsplit + SB * Sj2.nsplit), dim3(JSOLVE_NT), 0, st, Sj, Sj2);
         } else {          // the target groups' and the inverse pairs' systems: independent, one launch
             ProfScope prof(h, 1);
-            hipLaunchKernelGGL((k_solve_front<NS>), dim3(B * Sj.nsplit + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
+            if (pc) hipLaunchKernelGGL((k_solve_front<NS, true>), dim3(B * Sj.nsplit + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
+            else hipLaunchKernelGGL((k_solve_front<NS>), dim3(B * Sj.nsplit + SB), dim3(JSOLVE_NT), 0, st, Sj, Si);
         }
         if (direct_out && last) {      // the last back-substitution also writes the caller's map (coalesced calls: every call's own)
             Uj.depth_out = d_depth_out; Q.depth_out = d_depth_out;
@@ -1793,7 +1804,8 @@ static int dense_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, int
     if (o->w_dc > 0.f && !ref_mode) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_dc must be 0 (use prior_depth), except under window_rule = TCSFM_WINDOW_REFERENCE");
     if (ref_mode && (win_S > JMAXS || o->solver != TCSFM_SOLVER_GN || !(o->prior_init >= 0.f)))
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense_window: window_rule REFERENCE needs S <= 3, the Gauss-Newton solver and prior_init >= 0");
-    if (o->w_pose_consist > 0.f) return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_pose_consist is a term of the pose modes (tcsfm_refine_window)");
+    if (!(o->w_pose_consist >= 0.f) || (o->w_pose_consist > 0.f && (!ref_mode || o->param != TCSFM_PARAM_SE3)))
+        return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: w_pose_consist needs the window form under window_rule = TCSFM_WINDOW_REFERENCE and the SE(3) chart");
     if (o->free_source_depths != 0 && !ref_mode)
         return fail(h, TCSFM_E_ARG, "tcsfm_refine_dense: free_source_depths needs the window form under window_rule = TCSFM_WINDOW_REFERENCE");
     if (!(o->w_smooth >= 0.f) || (o->w_smooth > 0.f && !ref_mode))

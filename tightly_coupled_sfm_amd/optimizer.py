@@ -97,9 +97,10 @@ class DepthOptimizer:
             if options.get("strict_legacy", False):
                 raise NotImplementedError(msg)
             warnings.warn(msg)
-        # l_pose_consist IS a term of the pose modes under the window rule REFERENCE (opts.w_pose_consist, round 4); elsewhere it is ignored
+        # l_pose_consist IS a term of the pose mode (opts.w_pose_consist, round 4) and of the pose + depth mode (round 5) under the window rule
+        # REFERENCE; elsewhere it is ignored
         pc_ok = (options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm" and
-                 options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose" and options.get("param", "se3") == "se3")
+                 options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") in ("pose", "pose+depth") and options.get("param", "se3") == "se3")
         # l_smooth IS a term of the pose + depth mode on the reference's loss (opts.w_smooth, round 4)
         sm_ok = (options.get("refine", "pose+depth" if options.get("optimize_depth_pred", False) else "pose") == "pose+depth" and
                  options.get("window_rule", "reference") != "pair" and options.get("solver", "gn") != "lm")
@@ -142,6 +143,7 @@ class DepthOptimizer:
                                     w_dc=float(o.get("l_depth_consist_weight", 0.15)) if o.get("l_depth_consist", False) else 0.0,
                                     prior_init=float(o.get("l_depth_init_weight", 0.1)) if o.get("l_depth_init", True) else 0.0,
                                     w_smooth=float(o.get("l_smooth_weight", 2.0)) if o.get("l_smooth", False) else 0.0,      # optimizer.py:92-93
+                                    w_pose_consist=0.1 if (o.get("l_pose_consist", False) and o.get("param", "se3") == "se3") else 0.0,      # optimizer.py:95-96
                                     solver=_lib.SOLVER_GN, lambda0=float(o.get("lambda0", 1e-4)), min_depth=float(self.config["min_depth"]),
                                     max_depth=float(self.config["max_depth"]), window_rule=_lib.WINDOW_REFERENCE,
                                     # optimizer.py:194-198: the reference's leaf is ONE tensor with the disparities of the target AND of every
