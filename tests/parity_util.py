@@ -88,10 +88,27 @@ def check_first_masks(bits0, ph, automask, tag=None, max_frac=1e-3):
     return int(flip.sum())
 
 
-def check_flips_every_linearisation(orc, nit, pixels, tag=None, max_frac=1e-3):
+def _flip_report(tag, kind, frac, allowed):
+    """TCSFM_TEST_FLIP_REPORT=<file>: append the measured flip fraction of every check (how much of the allowance the near-ties really use)"""
+    import os
+    f = os.environ.get("TCSFM_TEST_FLIP_REPORT")
+    if f:
+        with open(f, "a") as fh:
+            fh.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{tag}\t{kind}\t{frac:.3e}\t{allowed:.1e}\n")
+
+
+def check_dense_ref_flips(nf, hard, pixels, max_frac=5e-4):
+    """dense mode on the reference's loss: no hard flip, at most max_frac of the decisions of a linearisation flip as near-ties"""
+    _flip_report("dense_ref", "every_lin", float(np.max(nf)) / pixels if len(nf) else 0.0, max_frac)
+    assert hard.sum() == 0 and nf.max() <= max_frac * pixels, (nf, hard)
+
+
+def check_flips_every_linearisation(orc, nit, pixels, tag=None, max_frac=5e-5):
     """after forced replays covering `pixels` mask decisions per linearisation: per linearisation, no hard (non-tie) flip and at
-    most 2 + max_frac * pixels flips in all -> total number of flips"""
+    most 2 + max_frac * pixels flips in all -> total number of flips.  The allowance was 1e-3 / 2e-3 until round 5; measured over the whole
+    GPU suite (profiles/r05_flip_report.tsv, TCSFM_TEST_FLIP_REPORT): at most 8.1e-6 of the decisions are near-ties that flip"""
     fn, fh = orc.flip_stats(nit)
+    _flip_report(tag, "every_lin", float(np.max(fn)) / pixels if len(fn) else 0.0, max_frac)
     assert not fh.any(), (tag, "non-tie mask flips per linearisation", fh.tolist(), fn.tolist())
     assert np.all(fn <= 2 + max_frac * pixels), (tag, fn.tolist(), pixels)
     return int(fn.sum())
@@ -143,7 +160,7 @@ def window_pair_views(w):
     return out
 
 
-def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale=None, max_flip_frac=2e-3, rule=0, joint=False):
+def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale=None, max_flip_frac=5e-5, rule=0, joint=False):
     """a window (B targets x S sources -> 2*S*B directed pairs) through Engine.refine_window / refine_dense_window with the
     decision trace on, then ONE oracle replay of the whole window.  w: dict(target, sources, depth_t, depth_s, K, first)."""
     S, B = w["sources"].shape[:2]
@@ -225,6 +242,7 @@ def replay_window(e, orc, w, o, oopts, tdev, argmin=True, dense=False, log_scale
                                                 w["first"][:S * B], oopts) > 0.5
         flip = ((bits[0] & 1) > 0) != own
         flips = int(flip.sum())
+        _flip_report("window", "first_lin_vs_own", flips / flip.size, max_flip_frac)
         assert flips <= 2 * N + max_flip_frac * flip.size, (flips, flip.sum((1, 2)))
     return dict(pose=pose, stats=st, bits=bits, decide=dec, depth=depth, ref_pose=rp, ref_stats=rst, ref_depth=rd, log_scale=ls,
                 mask_flips=flips, lm_flips=lm_flips, flips_all_lin=flips_all)

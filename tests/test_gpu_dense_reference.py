@@ -10,6 +10,7 @@ import torch
 
 from conftest import load_golden
 from oracle.oracle import Oracle, default_opts as oracle_opts
+from parity_util import check_dense_ref_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -126,7 +127,7 @@ def test_dense_reference_iterates_follow_the_oracle(H, W, S, mind, maxd, orc):
     po, do, so = orc.refine_dense_ref(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=True,
                                       w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
     nf, hard = orc.flip_stats(n_it)
-    assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
+    check_dense_ref_flips(nf, hard, N * H * W)
     for m in range(N):
         et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
         assert et < 1e-4 and er < 1e-4, (m, et, er)
@@ -206,7 +207,7 @@ def test_free_source_depth_maps_follow_the_oracle(B, H, W, S, mind, maxd, argmin
     po, do, dso, so = orc.refine_dense_ref_free(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=argmin,
                                                 w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
     nf, hard = orc.flip_stats(n_it)
-    assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
+    check_dense_ref_flips(nf, hard, N * H * W)
     for m in range(N):
         et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
         assert et < 1e-4 and er < 1e-4, (m, et, er)
@@ -284,7 +285,7 @@ def test_quarter_resolution_iterates_follow_the_oracle(H, W, S, mind, maxd, orc)
     po, do, so, rq = orc.refine_dense_ref_q(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=True,
                                             w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
     nf, hard = orc.flip_stats(n_it)
-    assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
+    check_dense_ref_flips(nf, hard, N * H * W)
     for m in range(N):
         et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
         assert et < 1e-4 and er < 1e-4, (m, et, er)
@@ -330,7 +331,7 @@ def test_the_reference_leaf_set_quarter_resolution_target_and_sources(B, S, H, W
     po, do, dso, so = orc.refine_dense_ref_q_free(f32(w["tgt"]), f32(w["srcs"]), f32(w["depth_t"]), f32(w["depth_s"]), f32(w["K"]), f32(w["pose"]), oo, argmin=True,
                                                   w_init=0.1, lambda_depth=1.0, min_depth=mind, max_depth=maxd, bits=bits.reshape(n_it, N, H * W))
     nf, hard = orc.flip_stats(n_it)
-    assert hard.sum() == 0 and nf.max() <= 5e-4 * N * H * W, (nf, hard)
+    check_dense_ref_flips(nf, hard, N * H * W)
     for m in range(N):
         et = np.linalg.norm(pose[m, :3] - po[m, :3]) / np.linalg.norm(po[m, :3]); er = np.linalg.norm(pose[m, 3:] - po[m, 3:]) / np.linalg.norm(po[m, 3:])
         assert et < 1e-4 and er < 1e-4, (m, et, er)
