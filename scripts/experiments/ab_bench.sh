@@ -9,7 +9,7 @@ cp $ROOT/tightly_coupled_sfm_amd/libtcsfm_hip.so /tmp/lib_keep.so
 for r in $(seq 1 $R); do
   for V in "$@"; do
     cp $ROOT/tightly_coupled_sfm_amd/variants/$V $ROOT/tightly_coupled_sfm_amd/libtcsfm_hip.so
-    python $ROOT/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sat-windows 32 2>/dev/null | python -c "
+    python $ROOT/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sat-windows 32 --modes-budget 0 --shim-sample 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r, s = d['roofline'], d['roofline_saturated']
 print('$V', 'lin_us', r['avg_launch_us'], 'in_flight_us', r['in_flight']['avg_launch_us'], 'sat_us', s['avg_launch_us'], 'value', d['value'], 'single', d['single_stream']['value'])"

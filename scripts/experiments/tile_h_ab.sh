@@ -4,11 +4,12 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 mkdir -p tightly_coupled_sfm_amd/variants
-for v in 16 8; do
+ALT=${TH_ALT:-8}      # TH_ALT=32: 32x32 tiles of 1024 threads (one workgroup per CU, 133 KB of LDS)
+for v in 16 $ALT; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=on -fPIC -shared -DTC_TILE_H=$v tightly_coupled_sfm_amd/csrc/tcsfm_api.hip -o tightly_coupled_sfm_amd/variants/th$v.so
 done
 cp tightly_coupled_sfm_amd/libtcsfm_hip.so /tmp/lib_keep0.so
-cp tightly_coupled_sfm_amd/variants/th8.so tightly_coupled_sfm_amd/libtcsfm_hip.so
+cp tightly_coupled_sfm_amd/variants/th$ALT.so tightly_coupled_sfm_amd/libtcsfm_hip.so
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_window_rule.py tests/test_gpu_coalesce.py -x -q 2>&1 | tail -3
 cp /tmp/lib_keep0.so tightly_coupled_sfm_amd/libtcsfm_hip.so
-bash scripts/experiments/ab_bench.sh ${1:-3} th16.so th8.so
+bash scripts/experiments/ab_bench.sh ${1:-3} th16.so th$ALT.so
