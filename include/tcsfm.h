@@ -381,6 +381,14 @@ int tcsfm_set_lanes(tcsfm_handle h, int n_lanes);
  * stderr.  tcsfm_lane_probe reports the outcome: *serial = 1 when the fallback is active, and the two probe times in ms.  The queued calls
  * (tcsfm_set_coalesce) keep the chip busy either way.  TCSFM_LANE_PROBE=0 in the environment skips the probe. */
 int tcsfm_lane_probe(tcsfm_handle h, int *serial, float *one_stream_ms, float *two_streams_ms);
+/* Debug aid (no reference counterpart; GPU AddressSanitizer is not available on the target pool): with TCSFM_DEBUG_GUARDS=1 in the environment
+ * when the library is loaded, every device allocation of the library carries a 4 KB pattern band in front of it and behind it.  This call
+ * synchronises the device, reads all bands back and reports (stderr, once per allocation) those a kernel wrote into: *n_allocations = live
+ * allocations checked (-1: guards are off), *n_damaged = how many have a damaged band.  The GPU test suite runs with the guards on. */
+int tcsfm_debug_check_guards(int *n_allocations, int *n_damaged);
+/* ... and its self-test: writes four bytes past the end of a scratch allocation of its own and says whether the bands caught it
+ * (*detected = 1 / 0; -1: guards are off) */
+int tcsfm_debug_guard_selftest(int *detected);
 int tcsfm_refine_window_async(tcsfm_handle h, int lane, const tcsfm_opts *o, int B, int S, const float *tgt, const float *srcs,
                               const float *depth_t, const float *depth_s, const float *K, const float *pose_in,
                               const float *log_scale_in, float *pose_out, float *log_scale_out, float *stats_out);

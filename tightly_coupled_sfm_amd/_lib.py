@@ -103,6 +103,8 @@ NSTAT = 10        # cost, cost_photo, n_mask, lambda, pose[6]  (include/tcsfm.h 
 _P = C.c_void_p
 _SIGNATURES = {
     "tcsfm_lane_probe": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tcsfm_debug_check_guards": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tcsfm_debug_guard_selftest": (C.c_int, [C.POINTER(C.c_int)]),
     "tcsfm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int]),
     "tcsfm_destroy": (None, [_P]),
     "tcsfm_last_error": (C.c_char_p, [_P]),
@@ -185,6 +187,15 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def check_guards():
+    """(live allocations checked, allocations with a damaged guard band); (-1, 0) when TCSFM_DEBUG_GUARDS is not set (include/tcsfm.h)"""
+    n, bad = C.c_int(0), C.c_int(0)
+    rc = load().tcsfm_debug_check_guards(C.byref(n), C.byref(bad))
+    if rc != 0:
+        raise RuntimeError(f"tcsfm_debug_check_guards failed ({rc})")
+    return n.value, bad.value
 
 
 def default_opts(**kw) -> Opts:

@@ -20,6 +20,62 @@
 
 using namespace tc;
 
+// ---- guard bands (TCSFM_DEBUG_GUARDS=1; tcsfm_debug_check_guards): every device allocation of this library gets 4 KB filled with a pattern
+// in front of it and behind it; the check reads the bands back and reports the allocations whose bands were written to.  A kernel's
+// out-of-bounds WRITE into neighbouring scratch corrupts results silently (ADVICE r04 #1 went unnoticed for a round: hipMalloc's granularity
+// hid it) and GPU AddressSanitizer is not available on this pool: the GPU test suite runs with the bands on instead (tests/conftest.py).
+// Off (the default) the two functions are hipMalloc / hipFree themselves.
+#include <mutex>
+namespace tcguard {
+constexpr size_t kBand = 4096;
+constexpr unsigned char kFill = 0xA5;
+struct Rec { char *base; size_t bytes; int line; bool reported; };
+inline std::mutex &mtx() { static std::mutex m; return m; }
+inline std::vector<Rec> &recs() { static std::vector<Rec> r; return r; }
+inline bool on() { static const bool v = getenv("TCSFM_DEBUG_GUARDS") && atoi(getenv("TCSFM_DEBUG_GUARDS")) != 0; return v; }
+inline hipError_t alloc(void **p, size_t bytes, int line) {
+    if (!on()) return (hipMalloc)(p, bytes);
+    char *base = nullptr;
+    const size_t padded = (bytes + 255) / 256 * 256;            // (the rear band starts at the next 256-byte boundary: the user pointer keeps hipMalloc's alignment)
+    hipError_t e = (hipMalloc)((void **)&base, padded + 2 * kBand);
+    if (e != hipSuccess) return e;
+    e = hipMemset(base, kFill, kBand);
+    if (e == hipSuccess) e = hipMemset(base + kBand + bytes, kFill, padded - bytes + kBand);
+    if (e != hipSuccess) { (void)(hipFree)(base); return e; }
+    std::lock_guard<std::mutex> lk(mtx());
+    recs().push_back({base, bytes, line, false});
+    *p = base + kBand;
+    return hipSuccess;
+}
+// number of bytes of the two bands of r that no longer hold the pattern (device synchronised by the copies)
+inline long damaged(const Rec &r, long *first_off) {
+    const size_t padded = (r.bytes + 255) / 256 * 256, rear = padded - r.bytes + kBand;
+    std::vector<unsigned char> host(kBand + rear);
+    if (hipMemcpy(host.data(), r.base, kBand, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(host.data() + kBand, r.base + kBand + r.bytes, rear, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    long bad = 0;
+    for (size_t i = 0; i < host.size(); i++)
+        if (host[i] != kFill) { if (!bad && first_off) *first_off = i < kBand ? (long)i - (long)kBand : (long)(r.bytes + (i - kBand)); bad++; }
+    return bad;
+}
+inline hipError_t release(void *p) {
+    if (!on() || !p) return (hipFree)(p);
+    std::lock_guard<std::mutex> lk(mtx());
+    for (size_t i = 0; i < recs().size(); i++)
+        if (recs()[i].base + kBand == (char *)p) {
+            long off = 0;
+            const long bad = recs()[i].reported ? 0 : damaged(recs()[i], &off);
+            if (bad > 0) fprintf(stderr, "tcsfm guard: allocation of %zu bytes (tcsfm_api.hip:%d) freed with %ld band bytes overwritten, first at offset %ld\n", recs()[i].bytes, recs()[i].line, bad, off);
+            char *base = recs()[i].base;
+            recs().erase(recs().begin() + i);
+            return (hipFree)(base);
+        }
+    return (hipFree)(p);      // (not one of ours)
+}
+}  // namespace tcguard
+#define hipMalloc(p, bytes) tcguard::alloc((void **)(p), (bytes), __LINE__)
+#define hipFree(p) tcguard::release((void *)(p))
+
 namespace {
 
 // tile geometry of the hot kernel (one place to retune)
@@ -2273,6 +2329,46 @@ static int probe_lanes(tcsfm_ctx *h) {
                         "calls run on the handle's own stream; use the queued calls (tcsfm_set_coalesce) to keep the chip busy\n", calls,
                 h->lane_probe[0] * 1e3, h->lane_probe[1] * 1e3, L);
     }
+    return TCSFM_OK;
+}
+
+int tcsfm_debug_check_guards(int *n_allocations, int *n_damaged) {
+    if (n_allocations) *n_allocations = -1;
+    if (n_damaged) *n_damaged = 0;
+    if (!tcguard::on()) return TCSFM_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return TCSFM_E_HIP;
+    std::lock_guard<std::mutex> lk(tcguard::mtx());
+    int bad_allocs = 0;
+    for (auto &r : tcguard::recs()) {
+        long off = 0;
+        const long bad = tcguard::damaged(r, &off);
+        if (bad < 0) return TCSFM_E_HIP;
+        if (bad > 0) {
+            bad_allocs++;
+            if (!r.reported)
+                fprintf(stderr, "tcsfm guard: allocation of %zu bytes (tcsfm_api.hip:%d): %ld band bytes overwritten, first at offset %ld of the allocation\n", r.bytes, r.line, bad, off);
+            r.reported = true;
+        }
+    }
+    if (n_allocations) *n_allocations = (int)tcguard::recs().size();
+    if (n_damaged) *n_damaged = bad_allocs;
+    return TCSFM_OK;
+}
+
+int tcsfm_debug_guard_selftest(int *detected) {
+    if (detected) *detected = -1;
+    if (!tcguard::on()) return TCSFM_OK;
+    char *p = nullptr;
+    if (hipMalloc(&p, 1000) != hipSuccess) return TCSFM_E_HIP;
+    if (hipMemset(p + 1000, 0, 4) != hipSuccess) return TCSFM_E_HIP;      // four bytes past the end
+    int found = 0;
+    {
+        std::lock_guard<std::mutex> lk(tcguard::mtx());
+        for (auto &r : tcguard::recs())
+            if (r.base + tcguard::kBand == p) { long off = 0; found = tcguard::damaged(r, &off) == 4 && off == 1000; r.reported = true; }
+    }
+    (void)hipFree(p);
+    if (detected) *detected = found;
     return TCSFM_OK;
 }
 
