@@ -112,8 +112,8 @@ typedef struct tcsfm_opts {
                               the L1 term, floor irls_eps) and the block-Jacobi majoriser of the curvature, its partner held at the
                               linearisation point; value and gradient pinned on reference autograd (golden G13 `full_pc`).  In the dense
                               mode the term enters the REDUCED pose systems (it does not depend on the maps): the forward pairs' diagonal
-                              blocks of their target's joint system, the inverse pairs' own systems; tcsfm_linearize_dense_window leaves it
-                              out, and queued calls that carry it are not merged                                                         */
+                              blocks of their target's joint system, the inverse pairs' own systems; tcsfm_linearize_dense_window exports
+                              its value and gradient with the loss; queued calls that carry it are not merged                            */
     float w_smooth;        /* dense window mode under TCSFM_WINDOW_REFERENCE: options['l_smooth_weight'] if options['l_smooth'] else 0 (default
                               0, as the reference's drivers) -- w * get_smooth_loss(target disparity, target image) (optimizer.py:92-93,
                               losses.py:43-61: edge-aware L1 smoothness of the mean-normalised sigmoid disparity).  Exact gradient incl. the
@@ -294,7 +294,8 @@ int tcsfm_refine_dense_window(tcsfm_handle h, const tcsfm_opts *o, int B, int S,
 /* ONE linearisation of tcsfm_refine_dense_window's REFERENCE-LOSS mode at `pose` and `depth_t` (nothing is updated): the loss and its
  * exact gradients, for pinning against the reference's loss and autograd (golden G13) -- the dense counterpart of
  * tcsfm_linearize_window.  Outputs (HOST pointers, float64): scal_out [8] = loss, forward group (forward term + its depth
- * consistency + prior), inverse photometric term, inverse depth-consistency term, K_f, K_i, a_f = c_f / K_f, 0;
+ * consistency + prior), inverse photometric term, inverse depth-consistency term, K_f, K_i, a_f = c_f / K_f, the l_pose_consist term
+ * (o->w_pose_consist; part of the loss and of g_pose_out, golden G13 `full_pc`);
  * g_pose_out [2*S*B][6] = d loss / d (left SE(3) perturbation of every directed pair's warp transform) in the stacked pair order;
  * g_rho_out [B][H*W] float32 (device or host pointer as o->host_ptrs says) = d loss / d (inverse depth of target b).
  * depth0 [B,1,H,W] (same kind of pointer as depth_t; DEPTH, not disparity) or NULL: the centre of the l_depth_init prior -- the

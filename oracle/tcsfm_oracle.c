@@ -2529,6 +2529,14 @@ void orc_linearize_dense_ref(int H, int W, int B, int S, const real *tgt, const 
     dref_scal sc;
     linearize_dense_ref(H, W, B, S, tgt, srcs, depth_t, depth_s, depth0, K, op, argmin, w_init, min_depth, max_depth, lambda_depth, T, aep, NULL, &sc,
                         g_xi, g_rho, Hj, gj, Dq, Bq, Hi, gi, g_rho_s, NULL);
+    if (op->w_pose_consist > 0) {      /* l_pose_consist (optimizer.py:95-96): value and the gradient w.r.t. every pair's left perturbation (pinned on golden G13 `full_pc`) */
+        for (int m = 0; m < 2 * SB; m++) {
+            double pc, pg[6], pH[36];
+            pose_consist_term(T + 12 * m, T + 12 * (m < SB ? m + SB : m - SB), op->w_pose_consist / (6.0 * SB), op->irls_eps, &pc, pg, pH);
+            sc.loss += pc;
+            for (int i = 0; i < 6; i++) g_xi[6 * m + i] += pg[i];
+        }
+    }
     scal[0] = sc.loss; scal[1] = sc.L_fwd; scal[2] = sc.L_inv; scal[3] = sc.L_dc; scal[4] = sc.L_init; scal[5] = sc.Kf; scal[6] = sc.Ki;
     free(ae); free(aep); free(T);
 }

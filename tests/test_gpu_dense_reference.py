@@ -35,9 +35,10 @@ def test_linearize_dense_window_vs_reference_autograd_G13(name, orc):
     rd = 1.0 / mind - 1.0 / maxd
     e = Engine(H, W, 2 * SB)
     t = dict(tgt=_dev(g["target"]), srcs=_dev(g["sources"]), depth_t=_dev(g["depth_t"]), depth_s=_dev(g["depth_s"]), K=_dev(g["K"]), pose=_dev(g["first"]))
-    for tag, argmin, w_init in (("full", True, 0.0), ("noargmin_full", False, 0.0), ("fullinit", True, 0.1), ("fullinit_smooth", True, 0.1)):
+    for tag, argmin, w_init in (("full", True, 0.0), ("noargmin_full", False, 0.0), ("fullinit", True, 0.1), ("fullinit_smooth", True, 0.1), ("full_pc", True, 0.0)):
         w_smooth = 2.0 if tag == "fullinit_smooth" else 0.0          # l_smooth_weight x get_smooth_loss (optimizer.py:92-93)
-        o = default_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, prior_init=w_init, min_depth=mind, max_depth=maxd, w_smooth=w_smooth)
+        w_pc = 0.1 if tag == "full_pc" else 0.0                      # 0.1 (poses + poses_inv).abs().mean() (optimizer.py:95-96)
+        o = default_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, prior_init=w_init, min_depth=mind, max_depth=maxd, w_smooth=w_smooth, w_pose_consist=w_pc)
         d0 = None if w_init == 0 else 1.0 / (1.0 / maxd + rd * g["sig_t0"])          # the golden's "initial" disparity as the prior's centre
         L = e.linearize_dense_window(t["tgt"], t["srcs"], t["depth_t"], t["depth_s"], t["K"], t["pose"], o, argmin=argmin,
                                      depth0=None if d0 is None else _dev(d0[:, None]))
@@ -54,7 +55,9 @@ def test_linearize_dense_window_vs_reference_autograd_G13(name, orc):
             gs, ref = g_rho * rd, g[f"{tag}_grad_sig_t"]
             assert np.abs(gs - ref).max() < 2e-4 * np.abs(ref).max(), (tag, np.abs(gs - ref).max(), np.abs(ref).max())
         # the engine against the oracle's restatement at the same point (float64, pinned to 1e-10 on the same goldens)
-        oo = oracle_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, w_smooth=w_smooth)
+        oo = oracle_opts(n_iters=1, w_dc=0.15, irls_eps=1e-7, w_smooth=w_smooth, w_pose_consist=w_pc)
+        if tag == "full_pc":
+            assert L["pose_consist"] > 1e-6 and abs(L["loss"] - L["pose_consist"] - float(g["full_loss"])) < 1e-5 * ref_loss
         Lo = orc.linearize_dense_ref(g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"], oo, argmin=argmin,
                                      w_init=w_init, depth0=d0, min_depth=mind, max_depth=maxd)
         assert abs(L["loss"] - Lo["loss"]) < 1e-5 * Lo["loss"] and L["K_f"] == Lo["K_f"] and L["K_i"] == Lo["K_i"]

@@ -571,10 +571,12 @@ def test_dense_reference_loss_and_gradients_vs_reference_autograd_G13(name, orac
     a = (g["target"], g["sources"], g["depth_t"][:, 0], g["depth_s"][:, :, 0], g["K"], g["first"])
     mind, maxd = (float(x) for x in g["min_max_depth"])
     rd = 1.0 / mind - 1.0 / maxd
-    for tag, argmin, w_init in (("full", True, 0.0), ("noargmin_full", False, 0.0), ("fullinit", True, 0.1), ("fullinit_smooth", True, 0.1)):
+    for tag, argmin, w_init in (("full", True, 0.0), ("noargmin_full", False, 0.0), ("fullinit", True, 0.1), ("fullinit_smooth", True, 0.1), ("full_pc", True, 0.0)):
         op = default_opts(n_iters=1, irls_eps=1e-12, w_dc=0.15)      # (irls_eps -> 0: no Huberisation of the depth-consistency gradient for the pin)
         if tag == "fullinit_smooth":
             op.w_smooth = 2.0          # round 4: + l_smooth_weight (2) x get_smooth_loss(target disparity, target image), optimizer.py:92-93
+        if tag == "full_pc":
+            op.w_pose_consist = 0.1    # round 5: + 0.1 (poses + poses_inv).abs().mean() as a term of the dense mode, optimizer.py:95-96
         depth0 = None if w_init == 0 else 1.0 / (1.0 / maxd + rd * g["sig_t0"])
         L = oracle64.linearize_dense_ref(*a, op, argmin=argmin, w_init=w_init, depth0=depth0, min_depth=mind, max_depth=maxd)
         ref_loss = float(g[f"{tag}_loss"])

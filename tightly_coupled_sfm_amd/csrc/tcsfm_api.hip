@@ -1062,8 +1062,42 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             for (int j = 0; j < 6; j++) ex->g_pose[(size_t)(SB + m) * 6 + j] = q[36 + j];
             inv_p += q[36 + 6 + 1]; inv_d += q[36 + 6 + 2];
         }
-        ex->scal[0] = fwd + inv_p + inv_d; ex->scal[1] = fwd; ex->scal[2] = inv_p; ex->scal[3] = inv_d;
-        ex->scal[4] = norms[0]; ex->scal[5] = norms[1]; ex->scal[6] = jx[1]; ex->scal[7] = 0.0;
+        double pc_total = 0.0;
+        if (o->w_pose_consist > 0.f) {
+            // l_pose_consist (optimizer.py:95-96) of the exported linearisation: a closed form of the 2 S B input poses, added on the host in double --
+            // value c sum |p_fwd + p_inv|, c = w / (6 S B); gradient c r / max(|r|, eps) in pose coordinates carried to the left perturbation
+            // by A^-T, A^-1 = [[-I, Tx], [0, -Je^-1]] (the oracle's pose_consist_term; the refinement's kernels hold the same term)
+            std::vector<float> ph((size_t)N * 6);
+            HIPCHK(h, hipMemcpy(ph.data(), d_pose_in, ph.size() * sizeof(float), hipMemcpyDeviceToHost));
+            const double c = (double)o->w_pose_consist / (6.0 * SB), eps = (double)o->irls_eps;
+            for (int m = 0; m < N; m++) {
+                const float *pm = &ph[(size_t)m * 6], *pp = &ph[(size_t)(m < SB ? m + SB : m - SB) * 6];
+                const double cx = cos(-(double)pm[3]), sx = sin(-(double)pm[3]), cy = cos(-(double)pm[4]), sy = sin(-(double)pm[4]);
+                const double Je[9] = {1, 0, sy, 0, cx, -sx * cy, 0, sx, cx * cy}, id = 1.0 / cy;
+                const double Ji[9] = {(Je[4] * Je[8] - Je[5] * Je[7]) * id, -(Je[1] * Je[8] - Je[2] * Je[7]) * id, (Je[1] * Je[5] - Je[2] * Je[4]) * id,
+                                      -(Je[3] * Je[8] - Je[5] * Je[6]) * id, (Je[0] * Je[8] - Je[2] * Je[6]) * id, -(Je[0] * Je[5] - Je[2] * Je[3]) * id,
+                                      (Je[3] * Je[7] - Je[4] * Je[6]) * id, -(Je[0] * Je[7] - Je[1] * Je[6]) * id, (Je[0] * Je[4] - Je[1] * Je[3]) * id};
+                const double tq[3] = {-(double)pm[0], -(double)pm[1], -(double)pm[2]};
+                const double Tx[9] = {0, -tq[2], tq[1], tq[2], 0, -tq[0], -tq[1], tq[0], 0};
+                double Ai[36] = {0}, gp[6];
+                for (int i = 0; i < 3; i++) {
+                    Ai[6 * i + i] = -1;
+                    for (int j = 0; j < 3; j++) { Ai[6 * i + 3 + j] = Tx[3 * i + j]; Ai[6 * (3 + i) + 3 + j] = -Ji[3 * i + j]; }
+                }
+                for (int j = 0; j < 6; j++) {
+                    const double r = (double)pm[j] + (double)pp[j], a = fabs(r), den = a > eps ? a : eps;
+                    pc_total += 0.5 * c * a;
+                    gp[j] = c * r / den;
+                }
+                for (int i = 0; i < 6; i++) {
+                    double v = 0.0;
+                    for (int k = 0; k < 6; k++) v += Ai[6 * k + i] * gp[k];
+                    ex->g_pose[(size_t)m * 6 + i] += v;
+                }
+            }
+        }
+        ex->scal[0] = fwd + inv_p + inv_d + pc_total; ex->scal[1] = fwd; ex->scal[2] = inv_p; ex->scal[3] = inv_d;
+        ex->scal[4] = norms[0]; ex->scal[5] = norms[1]; ex->scal[6] = jx[1]; ex->scal[7] = pc_total;
         return TCSFM_OK;
     }
     // the targets' record sums are split over several workgroups (JointSolveParams::nsplit: the last arriver solves) when a target has MANY records

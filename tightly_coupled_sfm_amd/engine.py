@@ -403,7 +403,7 @@ class Engine:
                                                              self._p(K), self._p(pose), self._p(d0), scal.ctypes.data_as(C.c_void_p),
                                                              gp.ctypes.data_as(C.c_void_p), self._p(g_rho)))
         torch.cuda.synchronize(self.device)
-        out = dict(loss=scal[0], fwd=scal[1], inv_photo=scal[2], inv_dc=scal[3], K_f=scal[4], K_i=scal[5], a_f=scal[6], g_pose=gp, g_rho=g_rho)
+        out = dict(loss=scal[0], fwd=scal[1], inv_photo=scal[2], inv_dc=scal[3], K_f=scal[4], K_i=scal[5], a_f=scal[6], pose_consist=scal[7], g_pose=gp, g_rho=g_rho)
         if sources:
             out["g_rho_src"] = g_src
         return out
