@@ -721,6 +721,13 @@ def main():
                       "achieved": round(alg_m / am / 1e9, 2), "frac": round(alg_m / am / 1e9 / HBM_PEAK_GBPS, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac_source": "this run: in-kernel s_memrealtime bracket of the merged k_linearize launches, as they run in the timed region "
                                      "(two sequences in flight on two streams: a launch shares the chip with the other sequence's kernels)"}
+        bm_ms, bm_n = prm.get("linearize_busy", (0.0, 0))
+        if bm_ms > 0 and bm_n == km_n:
+            # the launches of the two streams overlap: the chip's rate on the kernel = all their bytes / the time at least one of them ran
+            timed_mode["chip_level"] = {"busy_us": round(bm_ms * 1e3, 1), "launch_us_summed": round(km_ms * 1e3, 1), "overlap": round(km_ms / bm_ms, 3),
+                                        "achieved": round(alg_m * km_n / (bm_ms * 1e-3) / 1e9, 2), "frac": round(alg_m * km_n / (bm_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                                        "what": "algorithmic bytes of ALL merged k_linearize launches of the pass / the time during which at least one of them was "
+                                                "running (union of the in-kernel [start, end] brackets over both streams): what the chip sustains on the kernel in the timed mode"}
     per_rank = [mine]
     if distributed:
         per_rank = [None] * world

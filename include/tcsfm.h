@@ -516,6 +516,9 @@ int tcsfm_profile_end(tcsfm_handle h, double ms_sum[3], int64_t launches[3]);
  * rocprofv3's kernel duration.  Call after tcsfm_profile_end; launches beyond the stamp buffer (4 M workgroups per session)
  * are not counted. */
 int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches);
+/* ... and the time during which AT LEAST ONE of those launches was running (the union of their [start, end] intervals over the handle and
+ * its lanes, same counter): with launches of several streams sharing the chip, bytes / this = the chip's rate on the kernel. */
+int tcsfm_profile_kernel_busy(tcsfm_handle h, double *ms_busy, int64_t *launches);
 /* Parity-test hook.  The reference's masks are discontinuous (valid x [diff < auto_err], min over sources; helpers.py:17-19,
  * optimizer.py:47-69) and LM accepts / rejects on a cost comparison: near a tie the fp32 engine and a float64 checker may
  * decide differently.  While a trace is set, every linearisation `lin` of tcsfm_refine* / tcsfm_refine_dense* over N pairs

@@ -2,7 +2,7 @@
 # Round-5 profiles of the dense mode on the reference's loss, ON THE GPU BOX: bash scripts/collect_r05_dref.sh  (outputs under gpurun_out/r05_dref*)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
-for cfg in "192 640 2 full 1" "240 320 1 full 1" "192 640 2 quarter 1" "192 640 2 full 6" "240 320 1 full 6"; do
+for cfg in "192 640 2 full 1" "240 320 1 full 1" "192 640 2 quarter 1" "192 640 2 full 6" "240 320 1 full 6" "192 640 2 quarter_free 1" "192 640 2 free 1"; do
   set -- $cfg
   tag=r05_dref_$1x$2_S$3_$4_B$5
   rm -rf $ROOT/gpurun_out/$tag

@@ -72,6 +72,9 @@ def test_bench_single_process():
     if mg["timed"]:
         assert "queued" in d["config"]["timed_as"] and tm["pairs_per_launch"] == 20 and 0 < tm["frac"] <= 1 and tm["launches"] >= 4
         assert abs(tm["frac"] - tm["algorithmic_bytes_per_launch"] / tm["avg_launch_us"] * 1e-3 / 8000.0) < 1e-4
+        # the chip's rate on the kernel in that mode: all launches' bytes / the union of their in-kernel intervals (the two streams overlap)
+        cl = tm["chip_level"]
+        assert 1.0 <= cl["overlap"] <= 2.05 and tm["frac"] <= cl["frac"] <= 1 and cl["busy_us"] <= cl["launch_us_summed"] + 1e-6
     else:
         assert tm is None and "lanes" in d["config"]["timed_as"]
     md = d["modes"]

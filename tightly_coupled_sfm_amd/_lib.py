@@ -156,6 +156,7 @@ _SIGNATURES = {
     "tcsfm_profile_begin": (C.c_int, [_P]),
     "tcsfm_profile_end": (C.c_int, [_P, _P, _P]),
     "tcsfm_profile_kernel_time": (C.c_int, [_P, _P, _P]),
+    "tcsfm_profile_kernel_busy": (C.c_int, [_P, _P, _P]),
     "tcsfm_debug_stamps": (C.c_int, [_P, _P]),
     "tcsfm_debug_trace": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "tcsfm_pose_to_matrix": (None, [_P, _P]),

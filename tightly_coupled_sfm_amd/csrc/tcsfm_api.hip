@@ -2889,6 +2889,43 @@ int tcsfm_profile_kernel_time(tcsfm_handle h, double *ms_sum, int64_t *launches)
     return TCSFM_OK;
 }
 
+// [start, end] of every stamped launch of the handle and of its lanes, in 100 MHz ticks of the device's s_memrealtime counter
+static int profile_intervals(tcsfm_ctx *h, std::vector<std::pair<unsigned long long, unsigned long long>> &out) {
+    DeviceGuard dev_guard(h->device);
+    if (h->stamp_buf && h->stamp_used > 0) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> st(h->stamp_used * 2);
+        HIPCHK(h, hipMemcpy(st.data(), h->stamp_buf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (const auto &l : h->stamp_launch) {
+            unsigned long long t0 = ~0ull, t1 = 0ull;
+            for (size_t w = l.first; w < l.first + l.second; w++) { t0 = st[2 * w] < t0 ? st[2 * w] : t0; t1 = st[2 * w + 1] > t1 ? st[2 * w + 1] : t1; }
+            if (t1 > t0) out.push_back({t0, t1});
+        }
+    }
+    for (tcsfm_ctx *c : h->lanes)
+        if (int rc = profile_intervals(c, out)) { h->err = c->err; return rc; }
+    return TCSFM_OK;
+}
+
+int tcsfm_profile_kernel_busy(tcsfm_handle h, double *ms_busy, int64_t *launches) {
+    if (!h || !ms_busy || !launches) return TCSFM_E_ARG;
+    *ms_busy = 0.0; *launches = 0;
+    std::vector<std::pair<unsigned long long, unsigned long long>> iv;
+    if (int rc = profile_intervals(h, iv)) return rc;
+    std::sort(iv.begin(), iv.end());
+    unsigned long long busy = 0, lo = 0, hi = 0;
+    bool open = false;
+    for (const auto &x : iv) {
+        if (open && x.first <= hi) { hi = std::max(hi, x.second); continue; }
+        if (open) busy += hi - lo;
+        lo = x.first; hi = x.second; open = true;
+    }
+    if (open) busy += hi - lo;
+    *ms_busy = (double)busy * 1e-5;
+    *launches = (int64_t)iv.size();
+    return TCSFM_OK;
+}
+
 // ---- PoseNet (models/pose_models.py:88-147) and the coupled pose loop (train_mono.py:64-80) ---------------------------------
 struct tcsfm_posenet {
     tcsfm_ctx *h = nullptr;

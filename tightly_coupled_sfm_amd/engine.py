@@ -112,13 +112,17 @@ class Engine:
 
     def profile_end(self):
         """-> {'linearize'|'solve'|'pack': (summed ms, launches) from HIP event pairs,
-               'linearize_kernel': (summed ms, launches) from the in-kernel s_memrealtime bracket of the linearisation launches}"""
+               'linearize_kernel': (summed ms, launches) from the in-kernel s_memrealtime bracket of the linearisation launches,
+               'linearize_busy': (ms during which at least one of them ran, launches)}"""
         ms = (C.c_double * 3)(); cnt = (C.c_int64 * 3)()
         self._call(self.lib.tcsfm_profile_end(self._h, ms, cnt))
         out = {k: (ms[i], cnt[i]) for i, k in enumerate(("linearize", "solve", "pack"))}
         kms = C.c_double(); kn = C.c_int64()
         self._call(self.lib.tcsfm_profile_kernel_time(self._h, C.byref(kms), C.byref(kn)))
         out["linearize_kernel"] = (kms.value, kn.value)
+        bms = C.c_double(); bn = C.c_int64()
+        self._call(self.lib.tcsfm_profile_kernel_busy(self._h, C.byref(bms), C.byref(bn)))
+        out["linearize_busy"] = (bms.value, bn.value)      # union of the launches' intervals: (ms with >= 1 launch running, launches)
         return out
 
     def trace_begin(self, n_lin: int, n_pairs: int):
