@@ -12,7 +12,7 @@ for r in $(seq 1 $R); do
     python $ROOT/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sat-windows 32 --modes-budget 0 --shim-sample 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r, s = d['roofline'], d['roofline_saturated']
-print('$V', 'lin_us', r['avg_launch_us'], 'in_flight_us', r['in_flight']['avg_launch_us'], 'sat_us', s['avg_launch_us'], 'value', d['value'], 'single', d['single_stream']['value'])"
+print('$V', 'lin_us', r['avg_launch_us'], 'in_flight_us', r['in_flight']['avg_launch_us'], 'sat_us', s['avg_launch_us'], 'value', d['value'], 'single', d['single_stream']['value'], 'pack_us', r['other_kernels_avg_us_hip_events']['pack'])"
   done
 done
 cp /tmp/lib_keep.so $ROOT/tightly_coupled_sfm_amd/libtcsfm_hip.so

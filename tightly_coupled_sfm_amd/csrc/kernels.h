@@ -533,7 +533,18 @@ __device__ __forceinline__ void pack_write_src(const PackParams &P, int n, int u
 __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct) {
     __shared__ float tile[6][PT_N];
     const int tiles_x = (P.W + PT_W - 1) / PT_W;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+#ifndef TC_PACK_XCD
+#define TC_PACK_XCD 1
+#endif
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin, so with tiles in launch order the tiles above and below a tile --
+    // which share two of its six staged rows -- sit in OTHER XCDs' L2 and every halo row is fetched from memory again.  Workgroup i takes
+    // tile (i % 8) * (tiles / 8) + i / 8 (remainders spread over the first XCDs): the tiles of one XCD form a contiguous band of the image.
+    int tile_id = blockIdx.x;
+    if (TC_PACK_XCD) {
+        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = tile_id & 7, k = tile_id >> 3;
+        tile_id = x < r ? x * (q + 1) + k : r * (q + 1) + (x - r) * q + k;
+    }
+    const int tyi = tile_id / tiles_x, txi = tile_id - tyi * tiles_x;
     const int x0 = txi * PT_W, y0 = tyi * PT_H, tx = threadIdx.x & (PT_W - 1), ty = threadIdx.x / PT_W;
     int n = blockIdx.y;
     const int hw = P.H * P.W;
