@@ -50,6 +50,12 @@ struct PairState {
 
 struct LinParams {
     const float4 *tgtpack;  // [Nimg][H][W]  rgb + auto_err
+    // Window forms of the pose modes (round 5, `tshare`): every image of a window is the TARGET of one directed pair and the SOURCE of its
+    // partner (pair n <-> n +- tshare_sb), so k_pack writes each image ONCE -- the bordered (rgb, depth) pack the partner gathers from -- plus
+    // ONE auto-mask error plane per couple (in depth_t's buffer, at the forward pair's index; the error of (x, y) and of (y, x) is the same
+    // number).  The pair then reads its target colours and depth from srcpack[partner] and the error from that plane: the same two loads per
+    // pixel as tgtpack + depth_t, 36 instead of 72 bytes written per pixel and window, and the target rows share cache lines with the partner's taps.
+    int tshare, tshare_sb;
     const float4 *srcpack;  // [Nimg][H+2][W+2]  rgb + depth_s, 1-texel zero border
     const float *depth_t;   // [Nimg][H][W]
     const PairConst *pc;    // [N]
@@ -416,6 +422,8 @@ struct PackParams {
     float *depth_out3;                           // optional third copy (dense mode on the reference's loss: the CALLER's depth output, whose inverse
                                                  // slots -- the source maps, not unknowns there -- are final at once), or null
     int *zero_ints; int zero_n;                  // optional: words zeroed by this launch (the batch counters of that mode), or null
+    int tshare;                                  // window forms of the pose modes (LinParams::tshare): no tgtpack, no depth plane -- the bordered packs
+                                                 // of both images and ONE auto-mask error plane per couple (in depth_out, at the forward pair's index)
     float *c_depth_out3[TC_MAX_COAL];            // coalesced calls: depth_out3 per call (pair li of call c at c_depth_out3[c] + li H W); used when c_out3 != 0
     int c_out3;
     int H, W, N;
@@ -580,6 +588,12 @@ __device__ __forceinline__ void pack_body(const PackParams &P, const CoalTab *ct
         ds = 1.f / (P.min_disp + (P.max_disp - P.min_disp) * ds);
     }
     const float t0 = tc[0], t1 = tc[1], t2 = tc[2], s0 = sc[0], s1 = sc[1], s2 = sc[2];
+    if (P.tshare) {         // (both: see PackParams::tshare)
+        pack_write_src(P, n, u, v, make_float4(s0, s1, s2, ds));
+        pack_write_src(P, n_inv, u, v, make_float4(t0, t1, t2, dt));
+        P.depth_out[(size_t)n * hw + idx] = ae;
+        return;
+    }
     P.tgtpack[(size_t)n * hw + idx] = make_float4(t0, t1, t2, ae);
     pack_write_src(P, n, u, v, make_float4(s0, s1, s2, ds));
     P.depth_out[(size_t)n * hw + idx] = dt;
@@ -1199,7 +1213,9 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     bool front_m = false;                                                    // FRONT: this thread's pixel counts
     int f_tap = 0;                                                           // FRONT, inverse pairs: top-left tap (x + 1) | (y + 1) << 16 of the own pixel's
     float f_wx = 0.f, f_wy = 0.f, f_dc = 0.f, f_ph = 0.f;                    // sample, its bilinear weights; scatter coefficients h(dd) ddd and M diff ddd
-    const float4 *tgtpack = P.tgtpack + (size_t)img * hw;
+    const bool tsh = P.tshare != 0;                                          // wave-uniform (see LinParams)
+    const int tsh_part = n < P.tshare_sb ? n + P.tshare_sb : n - P.tshare_sb, tsh_ae = n < P.tshare_sb ? n : n - P.tshare_sb;
+    const float4 *tgtpack = tsh ? P.srcpack + (size_t)tsh_part * (H + 2) * (W + 2) : P.tgtpack + (size_t)img * hw;
     constexpr bool TS = TC_TILE_SHIFT && TC_PASSA_PIPELINED && TC_PROBE_PASSA_VISITS == 9 && !(ADJ && MODE == MODE_LIN);
     float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f;                                   // TS: the workgroup's colour shift = the target colour at its first pixel
     if (TS) {                                                                // (a workgroup-uniform address: scalar load)
@@ -1208,7 +1224,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     }
     const bool cached = P.pair_src != nullptr;                               // wave-uniform
     const float4 *srcpack = P.srcpack + (size_t)(cached ? P.pair_src[n] : img) * (H + 2) * (W + 2);   // zero-bordered (tap4)
-    const float *depth_t = P.depth_t + (size_t)(cached ? P.pair_dep[n] : img) * hw;
+    const float *depth_t = P.depth_t + (size_t)(tsh ? tsh_ae : (cached ? P.pair_dep[n] : img)) * hw;      // (tshare: the couple's auto-mask error plane)
     const int tid = threadIdx.x;
     stamp_begin(P.stamp, tid);
 
@@ -1232,14 +1248,19 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
             if (so == s_own) continue;
             const int no = so * P.sel_B + b_;
             const PairConst &co = P.pc[no];
-            const float4 *tpo = P.tgtpack + (size_t)no * hw, *spo = P.srcpack + (size_t)(cached ? P.pair_src[no] : no) * (H + 2) * (W + 2);
+            // (tshare: pair `no` is a forward pair here -- its target pack is its inverse partner's source pack, its error plane its own)
+            const float4 *tpo = tsh ? P.srcpack + (size_t)(no + P.tshare_sb) * (H + 2) * (W + 2) : P.tgtpack + (size_t)no * hw;
+            const float4 *spo = P.srcpack + (size_t)(cached ? P.pair_src[no] : no) * (H + 2) * (W + 2);
             const float *dto = P.depth_t + (size_t)(cached ? P.pair_dep[no] : no) * hw;
             for (int ci = tid; ci < NCOMP; ci += NT) {       // tile + ring, colours only (+ validity and auto-mask threshold)
                 const int ly = ci / CW, lx = ci - ly * CW;
                 const int px = refl_idx(x00 + lx - 1, W), py = refl_idx(y00 + ly - 1, H), gi = py * W + px;
-                const float4 tp = tpo[gi];
+                float4 tp;
+                float dpo;
+                if (tsh) { tp = tpo[(py + 1) * (W + 2) + px + 1]; dpo = tp.w; tp.w = dto[gi]; }
+                else { tp = tpo[gi]; dpo = dto[gi]; }
                 Geo g;
-                warp_geo(co, W, H, px, py, dto[gi], g);
+                warp_geo(co, W, H, px, py, dpo, g);
                 float4 val, gx, gy;
                 Tap to;
                 tap4_fetch(spo, W, H, px, py, g.rx, g.ry, g.oobx || g.ooby, to);
@@ -1344,8 +1365,15 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     auto s_load = [&](Stage &S) {
         S.px = refl_idx(x00 + S.lx - 1, W); S.py = refl_idx(y00 + S.ly - 1, H);
         const unsigned gi = (unsigned)(S.py * W + S.px);          // 32-bit offsets from the wave-uniform bases (see tap4_fetch)
-        S.tp = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tgtpack) + (gi << 4));
-        S.dep = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(depth_t) + (gi << 2));
+        if (tsh) {      // target colours + depth from the partner's bordered pack, the auto-mask error from the couple's plane
+            const unsigned gb = (unsigned)((S.py + 1) * (W + 2) + S.px + 1);
+            S.tp = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tgtpack) + (gb << 4));
+            S.dep = S.tp.w;
+            S.tp.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(depth_t) + (gi << 2));
+        } else {
+            S.tp = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(tgtpack) + (gi << 4));
+            S.dep = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(depth_t) + (gi << 2));
+        }
     };
     auto s_warp = [&](Stage &S) {
         warp_geo(c, W, H, S.px, S.py, S.dep, S.g);

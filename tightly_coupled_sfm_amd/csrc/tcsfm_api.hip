@@ -476,9 +476,12 @@ InitParams init_params(tcsfm_ctx *h, const tcsfm_opts *o, int N, const float *po
 // init == nullptr: pack only.  Otherwise the pair initialisation rides in the same launch (needs N == Nimg).
 int run_pack(tcsfm_ctx *h, const tcsfm_opts *o, int Nimg, const float *tgt, const float *src, const float *dt, const float *ds,
              const InitParams *init = nullptr, int win_B = 0, int win_S = 0, float *depth_copy = nullptr, const WinOff *wo = nullptr,
-             const CoalTab *ct = nullptr, float *depth_copy3 = nullptr, int *zero_ints = nullptr, int zero_n = 0, float *const *ct_depth3 = nullptr) {
+             const CoalTab *ct = nullptr, float *depth_copy3 = nullptr, int *zero_ints = nullptr, int zero_n = 0, float *const *ct_depth3 = nullptr,
+             bool tshare = false) {
     PackParams P;
     P.depth_out2 = depth_copy; P.depth_out3 = depth_copy3; P.zero_ints = zero_ints; P.zero_n = zero_n;
+    P.tshare = tshare ? 1 : 0;
+    if (tshare && !(ct || win_B > 0)) return fail(h, TCSFM_E_ARG, "internal: the shared-pack form needs a window-form pack");
     P.c_out3 = (ct && ct_depth3) ? 1 : 0;
     for (int i = 0; i < TC_MAX_COAL; i++) P.c_depth_out3[i] = (ct && ct_depth3 && i < ct->ncall) ? ct_depth3[i] : nullptr;
     if (wo) P.win_off = *wo; else P.win_off.on = 0;
@@ -1653,7 +1656,13 @@ static int refine_body(tcsfm_handle h, const tcsfm_opts *o, int N, int win_B, in
         }
         HIPCHK(h, hipGetLastError());
         P.srcpack = fc->fpack; P.depth_t = fc->fdepth; P.pair_src = C.pair_src; P.pair_dep = C.pair_dep;
-    } else if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo, ct))) return rc;
+    } else {
+        // window forms: every image packed ONCE (LinParams::tshare, kernels.h) -- TCSFM_TSHARE=0 keeps the round-4 layout (A/B hook)
+        static const bool tshare_env = !(getenv("TCSFM_TSHARE") && atoi(getenv("TCSFM_TSHARE")) == 0);
+        const bool tshare = tshare_env && (win_B > 0 || ct != nullptr);
+        if ((rc = run_pack(h, o, N, d_tgt, d_src, d_dt, d_ds, &I, win_B, win_S, nullptr, wo, ct, nullptr, nullptr, 0, nullptr, tshare))) return rc;
+        if (tshare) { P.tshare = 1; P.tshare_sb = N / 2; }
+    }
     SolveParams S = solve_params(h, o, np, 0);
     S.stats = d_stats;
     if (ct) {
