@@ -755,6 +755,9 @@ def main():
                 "avg_launch_us_chunks": chunk_us,
                 "valu_frac_of_bound": None if vb is None else vb["frac_of_bound"],
                 "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_bytes, 3),
+                "traffic_note": "below 1 since round 5: the algorithmic figure (32 B / pixel / directed pair: a target texel + the source taps) counts the two "
+                                "image packs of a window once per directed pair, and the window forms now pack every image ONCE -- a pair reads its target "
+                                "from its partner's source pack (LinParams::tshare), so the two pairs of a window fetch the same lines",
                 "kernel": "k_linearize", "launches": int(k_n), "algorithmic_bytes_per_launch": alg_bytes,
                 "rocprof_committed": committed,
                 "frac_consistent": None if committed is None else bool(consistent(mine["avg_launch_us"], committed["avg_launch_us"])),

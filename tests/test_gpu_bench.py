@@ -44,8 +44,10 @@ def test_bench_single_process():
     # the steps rotate over a ring of distinct windows larger than the Infinity Cache; the hot-cache protocol is reported beside it
     assert d["config"]["ring_calls"] >= 64 and d["config"]["ring_input_MB"] > 268.0
     assert d["hot_cache"]["value"] > 100 and 0.8 < d["hot_cache"]["value_over_ring_value"] < 1.5
-    if rf["traffic"] is not None:       # HBM bytes per launch of THIS workload: within 1.5x of the algorithmic bytes (r02 cited another mode's file)
-        assert rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.5 * rf["algorithmic_bytes_per_launch"], rf["traffic"]
+    if rf["traffic"] is not None:       # HBM bytes per launch of THIS workload (r02 cited another mode's file): at most 1.5x the algorithmic bytes, and at
+        # least the two bordered image packs + the error plane a window's two pairs share since round 5 (every image packed once)
+        floor = 2 * 194 * 642 * 16 + 192 * 640 * 4
+        assert floor <= rf["traffic"] <= 1.5 * rf["algorithmic_bytes_per_launch"], rf["traffic"]
     assert d["config"]["lanes"] == 4 and d["single_stream"]["value"] > 100 and d["value"] > 0.9 * d["single_stream"]["value"]
     # the steps also ran as queued calls merged by the library (10 per launch sequence): same bits; the faster way is the headline
     mg, ln = d["launch_mode"]["merged"], d["launch_mode"]["lanes"]

@@ -1202,7 +1202,10 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     }
     // FRONT: rows [0, S B) are the INVERSE pairs (the heavier role is dispatched first), the rows behind them the forward pairs -- all S B of
     // them, or under SEL one row per TARGET (pair (0, b)), which decides the selection for all S sources of its target
-    const int n = FRONT ? ((int)blockIdx.y < P.front_fwd ? P.front_fwd + (int)blockIdx.y : (int)blockIdx.y - P.front_fwd) : (int)blockIdx.y;
+    // (tshare: rows 2k and 2k + 1 are forward pair k and its inverse partner -- the two read the same two image packs, and rows that are
+    // dispatched one after the other find each other's lines in L2; with the pairs in index order a merged launch runs them S B rows apart)
+    const int n = FRONT ? ((int)blockIdx.y < P.front_fwd ? P.front_fwd + (int)blockIdx.y : (int)blockIdx.y - P.front_fwd)
+                        : (P.tshare ? (((int)blockIdx.y & 1) ? P.tshare_sb + ((int)blockIdx.y >> 1) : ((int)blockIdx.y >> 1)) : (int)blockIdx.y);
     const PairConst &c = P.pc[n];
     const int H = P.H, W = P.W, hw = H * W;
     const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
