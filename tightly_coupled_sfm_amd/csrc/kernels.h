@@ -1177,7 +1177,10 @@ __device__ __forceinline__ void block_reduce_publish(const LinParams &P, const f
 #ifndef TC_TILE_SHIFT
 #define TC_TILE_SHIFT 0
 #endif
-template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false, bool FRONT = false>
+// TSH: the shared-pack form (LinParams::tshare) folded at compile time -- the production instantiations; with the flag read at run time the
+// two sides of its branches cost the chip-filling launch 5 % (profiles/r05_shared_pack_ab.txt).  The TRACE / ADJ builds (tests, A/B) keep the
+// run-time flag; the host launches <TSH = true> exactly when P.tshare is set and neither TRACE nor ADJ is (launch_lin_a).
+template <int NP, bool DC, int MODE, int TW, int TH, int NT, bool SEL = false, bool TRACE = false, bool ADJ = false, bool FRONT = false, bool TSH = false>
 __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     constexpr int CW = TW + 2, CH = TH + 2, NCOMP = CW * CH, NCEN = TW * TH;
     constexpr int PPT = (NCEN + NT - 1) / NT;  // centre pixels per thread
@@ -1216,7 +1219,7 @@ __global__ __launch_bounds__(NT, 4) void k_linearize(LinParams P) {
     bool front_m = false;                                                    // FRONT: this thread's pixel counts
     int f_tap = 0;                                                           // FRONT, inverse pairs: top-left tap (x + 1) | (y + 1) << 16 of the own pixel's
     float f_wx = 0.f, f_wy = 0.f, f_dc = 0.f, f_ph = 0.f;                    // sample, its bilinear weights; scatter coefficients h(dd) ddd and M diff ddd
-    const bool tsh = P.tshare != 0;                                          // wave-uniform (see LinParams)
+    const bool tsh = TSH || ((TRACE || ADJ) && P.tshare != 0);               // wave-uniform (see LinParams); a compile-time constant in the production builds
     const int tsh_part = n < P.tshare_sb ? n + P.tshare_sb : n - P.tshare_sb, tsh_ae = n < P.tshare_sb ? n : n - P.tshare_sb;
     const float4 *tgtpack = tsh ? P.srcpack + (size_t)tsh_part * (H + 2) * (W + 2) : P.tgtpack + (size_t)img * hw;
     constexpr bool TS = TC_TILE_SHIFT && TC_PASSA_PIPELINED && TC_PROBE_PASSA_VISITS == 9 && !(ADJ && MODE == MODE_LIN);

@@ -405,6 +405,9 @@ void launch_lin_a(tcsfm_ctx *h, const LinParams &P, int N) {
     if (MODE != MODE_MAPS && P.trace != nullptr) {       // parity tests: the decision-recording build
         if (sel) hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, true, ADJ>), grid, block, 0, h->stream, P);
         else hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, false, true, ADJ>), grid, block, 0, h->stream, P);
+    } else if (MODE != MODE_MAPS && !ADJ && P.tshare != 0) {       // window forms of the pose modes: the shared-pack instantiations (kernels.h TSH)
+        if (sel) hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, false, false, false, MODE != MODE_MAPS>), grid, block, 0, h->stream, P);
+        else hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, false, false, false, false, MODE != MODE_MAPS>), grid, block, 0, h->stream, P);
     } else if (sel)
         hipLaunchKernelGGL((k_linearize<NP, DC, MODE, TILE_W, TILE_H, TILE_NT, true, false, ADJ>), grid, block, 0, h->stream, P);
     else
