@@ -199,8 +199,8 @@ def rocprof_avg_us(kernel_substr=KERNEL):
         if not f:
             continue
         try:
-            for row in csv.DictReader(open(f)):
-                if kernel_substr in row["Name"]:
+            for row in csv.DictReader(open(f)):       # (several instantiations may match -- the shared-pack and the two-pack form: the one the run used most)
+                if kernel_substr in row["Name"] and int(row["Calls"]) > out.get(key, {"calls": 0})["calls"]:
                     out[key] = {"us": round(float(row["AverageNs"]) * 1e-3, 3), "calls": int(row["Calls"]), "file": os.path.relpath(f, ROOT)}
         except Exception:
             pass
