@@ -15,14 +15,19 @@ def test_cited_profiles_belong_to_the_bench_workload():
     alg = 32 * bench.H * bench.W * 2                     # config 2: fwd + inv directed pair per launch
     t = bench.load_pmc()
     if t is not None:
-        assert alg <= t <= 1.5 * alg, (t, alg)            # 36 B/px actually read + halo re-reads: ~1.24x
+        # since round 5 a window's two directed pairs read the SAME two bordered image packs + one error plane (every image packed once):
+        # that, not the contract's 32 B / pixel / pair, is the floor of what a launch must fetch
+        floor = 2 * (bench.H + 2) * (bench.W + 2) * 16 + bench.H * bench.W * 4
+        assert floor <= t <= 1.5 * alg, (t, floor, alg)
         assert json.load(open(bench._profile("pmc_traffic.json")))["waves_per_linearize_launch"] == 2 * bench.H * bench.W / 64
     rp = bench.rocprof_avg_us()
     if rp:
         for key, v in rp.items():
             assert any(v["file"].startswith(f"profiles/{t}_") for t in bench.PROFILE_TAGS) and os.path.exists(os.path.join(REPO, v["file"]))
             rows = [r for r in csv.DictReader(open(os.path.join(REPO, v["file"]))) if bench.KERNEL in r["Name"]]
-            assert len(rows) == 1 and abs(float(rows[0]["AverageNs"]) * 1e-3 - v["us"]) < 1e-3
+            # (the shared-pack and the two-pack instantiation may both appear: bench.py cites the one the run called most)
+            rows.sort(key=lambda r: -int(r["Calls"]))
+            assert 1 <= len(rows) <= 2 and abs(float(rows[0]["AverageNs"]) * 1e-3 - v["us"]) < 1e-3 and int(rows[0]["Calls"]) == v["calls"]
         if "lanes_1" in rp:                                # one call in flight, the kernel has the chip: a B=1 launch takes 5 .. 20 us
             assert 5.0 < rp["lanes_1"]["us"] < 20.0
         if "saturated" in rp:                              # 64 directed pairs per launch
