@@ -85,8 +85,16 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
 #ifndef TC_JOINT_OCC
 #define TC_JOINT_OCC 2
 #endif
-template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false>
-__global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_joint(LinParams P, JointParams J) {
+// SM: the l_smooth term compiled in (off in the reference's drivers: the lean instantiation leaves its code and registers out).
+// LEAN (NS = 2 on the 256-thread tiling without l_smooth -- the KITTI window of the mirror's default mode): the loop over the two sources is
+// unrolled, so every `s == 0` / `s > 0` branch folds and the cross-source state that only one of the two bodies needs is not carried through
+// the other; together with the Jacobian rebuilt in phase 2b (below) the kernel fits 168 VGPRs = THREE workgroups per CU (was 256 / two).
+template <int NS, int NT, bool REF, bool SM> struct JointShape {
+    static constexpr bool LEAN = NS == 2 && NT <= 256 && REF && !SM;
+    static constexpr int OCC = NT > 256 ? 2 : ((NS == 1 || LEAN) ? (TC_JOINT_OCC > 3 ? TC_JOINT_OCC : 3) : TC_JOINT_OCC);
+};
+template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false, bool SM = REF>
+__global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dense_joint(LinParams P, JointParams J) {
     using JL = JointLayout<NS>;
     constexpr int NP = 6;
     constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
     }
     const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
     const bool ref_prior = REF && J.w_init_px > 0.f;
-    const bool ref_smooth = REF && J.smooth != nullptr && (J.w_smooth_x > 0.f || J.w_smooth_y > 0.f);
+    const bool ref_smooth = REF && SM && J.smooth != nullptr && (J.w_smooth_x > 0.f || J.w_smooth_y > 0.f);
     const bool ref_sig = ref_prior || ref_smooth;          // (sigma, sigma0) staged on tile + 2-pixel halo
 
     const int nblk = P.tiles_x * P.tiles_y;
@@ -136,7 +144,8 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
     const int oy = tid / TW, ox = tid - oy * TW;
     const int gxo = x00 + ox, gyo = y00 + oy;
     const bool inimg = gxo < W && gyo < H;
-    float *jr = J.jrec + ((size_t)b * hw + (inimg ? gyo * W + gxo : 0)) * JL::JREC;
+    // the pixel's record (formed where it is used: a pointer held from here to the end of the kernel costs two registers through every phase)
+    auto jrp = [&]() -> float * { return J.jrec + ((size_t)b * hw + (inimg ? gyo * W + gxo : 0)) * JL::JREC; };
 
     // per-pixel state across the sources
     float o_depth = 1.f, g_rho = 0.f, Dsum = 0.f, mcnt = 0.f;
@@ -152,13 +161,14 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
     constexpr int RING_THREADS = (NRING + 63) / 64 * 64;
     struct Stage { int lx, ly, px, py; float4 tp; float dep, dep0; Geo g; Tap t; };
 
-#pragma unroll 1
+#pragma unroll(JointShape<NS, NT, REF, SM>::LEAN ? 2 : 1)
     for (int s = 0; s < NS; s++) {
         const int n = s * J.B + b;
         const PairConst &c = P.pc[n];
         const float4 *tgtpack = P.tgtpack + (size_t)n * hw;
         const float4 *srcpack = P.srcpack + (size_t)n * (H + 2) * (W + 2);
         float a[7], bb[7], zc[7];
+        Geo o_g;                 // the own pixel's warp geometry: phase 2b rebuilds the 7-column Jacobian from it (16 registers not carried through phase 2a)
         float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f;
         bool o_dcin = false;     // this source's projected-depth sample is a real depth sample (no zero padding in its footprint)
 
@@ -198,8 +208,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
                 if (TRACE && P.trace != nullptr && inimg)
                     P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                         (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
-                geo_jac<7>(c, S.g, W, H, a, bb, zc);
-                a[6] *= -S.dep; bb[6] *= -S.dep; zc[6] *= -S.dep;      // scale column -> inverse-depth column
+                o_g = S.g;
                 o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
                 o_pad = o_pad || (!oob && !S.t.inside);
                 o_dcin = !oob && S.t.inside;
@@ -378,6 +387,8 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
 #pragma unroll
         for (int i = 0; i < 29; i++) v[i] = 0.f;
         if (inimg) {
+            geo_jac<7>(c, o_g, W, H, a, bb, zc);
+            a[6] *= -o_depth; bb[6] *= -o_depth; zc[6] *= -o_depth;      // scale column -> inverse-depth column
             float sg;
             {
                 float sum = o_cd + o_pd, dif = o_cd - o_pd, isum = frcp(sum), raw = fabsf(dif) * isum;
@@ -474,6 +485,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
                 if (bid == 0 && tid == 0) extra_cost += iaf_s * J.smooth[2 * b + 1];       // the term's value, booked once per target
             }
             // B_s goes straight into the pixel's record (read back for the Schur terms below and by the back-substitution)
+            float *jr = jrp();
             jr[2 + 6 * s + 0] = Bq[0]; jr[2 + 6 * s + 1] = Bq[1]; jr[2 + 6 * s + 2] = Bq[2];
             jr[2 + 6 * s + 3] = Bq[3]; jr[2 + 6 * s + 4] = Bq[4]; jr[2 + 6 * s + 5] = Bq[5];
             int h = 0;
@@ -529,6 +541,7 @@ __global__ __launch_bounds__(NT, (NT <= 256 ? TC_JOINT_OCC : 2)) void k_dense_jo
         const float Dd = (1.f + J.lambda_depth) * D;
         const bool elim = Dd > 1e-30f && !o_pad;         // (dense_kernel.h: pixels sampled across the zero padding keep their depth)
         iD = (elim && !J.qres) ? frcp(Dd) : 0.f;         // (quarter resolution: eliminated per CELL by k_qres_schur, nothing here)
+        float *jr = jrp();
         jr[0] = g_rho; jr[1] = elim ? Dd : 0.f;
 #pragma unroll
         for (int s = 0; s < NS; s++)

@@ -1008,16 +1008,20 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         if (smooth) hipLaunchKernelGGL(k_dref_smooth, dim3(B), dim3(1024), 0, st, Ds);
         take_stamp(h, Pj, (size_t)nblk * B);
         ProfScope prof(h, 0);
-        if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
-        else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+        // (l_smooth is compiled into its own instantiations: without it -- the reference's drivers -- the S = 2 kernel is the LEAN form, three workgroups per CU)
+        if (smooth) {
+            if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+            else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+        } else if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true, false>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
+        else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, false, true, false>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
         if (qres && !free_src) hipLaunchKernelGGL((k_qres_schur<NS>), dim3(nqblk, B), dim3(256), 0, st, Q);
         if (free_src) {
             // every inverse pair as a group of one source WITHOUT argmin: that is the reference's inverse term (0.25 / K_i, own weights,
             // valid x auto-mask, its depth-consistency term), its local unknowns the pair's pose and the source map it back-projects.
             // Independent of the forward groups' launch above (own records behind theirs in jblockrec): one solve launch serves both.
             Pj2.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
-            if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
-            else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            if (tr) hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, true, true, false>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            else hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true, false>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
             if (qres) hipLaunchKernelGGL((k_qres_schur2<NS>), dim3(nqblk, B + SB), dim3(256), 0, st, Q, Q2);      // both groups' cells
         }
         return TCSFM_OK;
@@ -1046,7 +1050,7 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
             J2.norms = h->dref_norms + 1;                 // the group's normaliser is K_i, its factor 0.25 (optimizer.py:79)
             J2.c_f = 0.25f; J2.w_init_px = 0.f; J2.smooth = nullptr; J2.w_smooth_x = J2.w_smooth_y = 0.f; J2.qres = 0; J2.rec_stride = 0;
             J2.ext2 = h->dref_ext; J2.ext_norm = h->dref_norms; J2.ext_c = J.c_f;
-            hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
+            hipLaunchKernelGGL((k_dense_joint<1, DTW, DTH, DNT, false, true, false>), dim3(nblk, SB), dim3(DNT), 0, st, Pj2, J2);
             hipLaunchKernelGGL(k_dref_export_grho_src, px_f, dim3(256), 0, st, (const float *)h->jrec_acc, (int)JointLayout<1>::JREC, (const int *)h->dref_norms, ex->d_g_rho_src, (int)hw);
         }
         HIPCHK(h, hipGetLastError());
