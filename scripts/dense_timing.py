@@ -6,6 +6,9 @@ import os as _os; _os.environ.setdefault("TCSFM_SET_ENV_DEFAULTS", "1")      # (
 from tightly_coupled_sfm_amd import synth
 from tightly_coupled_sfm_amd.engine import Engine, default_opts
 
+BASIC = "basic" in sys.argv[1:]        # only the per-call / per-launch rows (A/B runs: scripts/experiments/dense_ab.sh)
+
+
 def run(H, W, npairs, steps):
     b = synth.make_batch(2, H, W, seed0=0, both_directions=True)
     d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
@@ -58,6 +61,8 @@ def run_lanes(H, W, lanes, steps, replay=False):
 for H, W in ((240, 320), (256, 448)):
     run(H, W, 2, 300)
     run(H, W, 64, 30)
+    if BASIC:
+        continue
     for lanes in (1, 2, 3):
         run_lanes(H, W, lanes, 600)
     for lanes in (2, 3):
@@ -81,5 +86,5 @@ def run_sequence(H, W, lanes, wpc, T=120):
                       "us_per_window": round(t / (T - 1) * 1e6, 1), "windows_per_s": round((T - 1) / t, 1)}), flush=True)
     e.close()
 
-for lanes, wpc in ((1, 1), (2, 1), (1, 8), (2, 8)):
+for lanes, wpc in (() if BASIC else ((1, 1), (2, 1), (1, 8), (2, 8))):
     run_sequence(240, 320, lanes, wpc)

@@ -49,8 +49,22 @@ __device__ __forceinline__ float dense_advance(float dep, const float4 &r0, cons
     return 1.f / depth_step(1.f / dep, -(r0.x + bd) / r0.y, rho_lo, rho_hi);
 }
 
+// Software-pipelined window reads of phases 2a / 2b (round 5, third session; bit-identical to the rolled loops, kept for A/B: -DTC_DENSE_PIPELINED=0)
+#ifndef TC_DENSE_PIPELINED
+#define TC_DENSE_PIPELINED 1
+#endif
+#ifndef TC_DENSE_PIPE_A
+#define TC_DENSE_PIPE_A TC_DENSE_PIPELINED
+#endif
+#ifndef TC_DENSE_PIPE_B
+#define TC_DENSE_PIPE_B TC_DENSE_PIPELINED
+#endif
+// waves per SIMD the register allocation must leave room for: 4 = two 512-thread workgroups per CU (the LDS allows exactly two)
+#ifndef TC_DENSE_OCC
+#define TC_DENSE_OCC 4
+#endif
 template <int TW, int TH, int NT, bool TRACE = false>
-__global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DenseParams Dn) {
+__global__ __launch_bounds__(NT, TC_DENSE_OCC) void k_dense_linearize(LinParams P, DenseParams Dn) {
     constexpr int NP = 6;
     using L = AccLayout<NP>;
     constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;   // phase-1 region (2-pixel halo)
@@ -84,6 +98,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
     const int gxo = x00 + ox, gyo = y00 + oy;
     const bool inimg = gxo < W && gyo < H;
     float a[7], b[7], zc[7];
+    Geo o_g;                 // own pixel's warp geometry (phase 1 -> phase 2b)
     float o_pd = 0.f, o_cd = 1.f, o_dgx = 0.f, o_dgy = 0.f, o_depth = 1.f;
     bool o_pad = false;      // the pixel's own sample is valid but its bilinear footprint touches the zero padding (see `elim` below)
 
@@ -133,9 +148,7 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
             if (TRACE && P.trace != nullptr && inimg)    // bilinear cell parity now, mask / validity bits in phase 2b
                 P.trace[(size_t)n * hw + (size_t)S.py * W + S.px] =
                     (unsigned short)((((S.px + (int)floorf(S.g.rx)) & 1) << 2) | (((S.py + (int)floorf(S.g.ry)) & 1) << 3));
-            geo_jac<7>(c, S.g, W, H, a, b, zc);
-            // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
-            a[6] *= -S.dep; b[6] *= -S.dep; zc[6] *= -S.dep;
+            o_g = S.g;      // (the 7-column Jacobian is rebuilt from this in phase 2b: 14 registers less through phase 2a, which the pipelined window reads use)
             o_pd = pd; o_cd = cd; o_dgx = c.es * gx.w; o_dgy = c.es * gy.w; o_depth = S.dep;
             o_pad = !oob && !S.t.inside;
         }
@@ -191,27 +204,58 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, Gx01, Gy01, S2, SS2, G2;
         float Sxy2;
         const float4 *nbA = ctr - (W2 + 1) * 3;
-        {   // first neighbour initialises the accumulators (as in k_linearize)
-            f32x4 n0, n1, n2;
-            lds_read3v(nbA, n0, n1, n2);
-            nbA += 3;
+        // the first neighbour initialises the accumulators (as in k_linearize), the other eight are added -- same operations on the same values
+        // in the same order in both forms below
+        auto first = [&](const f32x4 &n0, const f32x4 &n1, const f32x4 &n2) {
             Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
             Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
             Gx01 = n1.lo; Gy01 = n1.hi;
             S2 = pk_sub(n2.lo, yx2c);
             SS2 = S2 * S2; Sxy2 = S2.x * S2.y; G2 = n2.hi;
+        };
+        auto more = [&](const f32x4 &n0, const f32x4 &n1, const f32x4 &n2) {
+            f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
+            Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
+            Gx01 += n1.lo; Gy01 += n1.hi;
+            f2 e2v = pk_sub(n2.lo, yx2c);
+            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
+        };
+#if TC_DENSE_PIPE_A
+        {   // software-pipelined (round 5, third session): the three reads of window position k + 1 are in flight while position k is accumulated
+            // (two register sets, counted waits: LDS returns in order; every position a compile-time offset from the window's first record)
+            constexpr int RB = 48, ROWB = W2 * 48;
+            const unsigned base = lds_addr(nbA);
+            f32x4 u0, u1, u2, w0, w1, w2;
+            // (the fence pins a position's accumulation in front of the reads that reuse its registers: left free, the scheduler keeps several
+            // positions' records alive at once and the kernel no longer fits four waves per SIMD)
+            auto fence = [&]() { asm volatile("" : "+v"(Sy01), "+v"(Sx01), "+v"(Syy01), "+v"(Sxx01), "+v"(Sxy01), "+v"(Gx01), "+v"(Gy01), "+v"(S2), "+v"(SS2), "+v"(Sxy2), "+v"(G2)); };
+            lds_issue3c_at<0>(base, u0, u1, u2);
+            lds_issue3c_at<RB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); first(u0, u1, u2); fence(); lds_issue3c_at<2 * RB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence(); lds_issue3c_at<ROWB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); more(u0, u1, u2); fence(); lds_issue3c_at<ROWB + RB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence(); lds_issue3c_at<ROWB + 2 * RB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); more(u0, u1, u2); fence(); lds_issue3c_at<2 * ROWB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence(); lds_issue3c_at<2 * ROWB + RB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); more(u0, u1, u2); fence(); lds_issue3c_at<2 * ROWB + 2 * RB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence();
+            lds_waitn<0>(u0, u1, u2); more(u0, u1, u2);
+        }
+#else
+        {
+            f32x4 n0, n1, n2;
+            lds_read3v(nbA, n0, n1, n2);
+            nbA += 3;
+            first(n0, n1, n2);
         }
 #pragma unroll 1
         for (int kk = 1; kk < 9; kk++) {
             f32x4 n0, n1, n2;
             lds_read3v(nbA, n0, n1, n2);
             nbA += (kk == 2 || kk == 5) ? (W2 - 2) * 3 : 3;
-            f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
-            Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
-            Gx01 += n1.lo; Gy01 += n1.hi;
-            f2 e2v = pk_sub(n2.lo, yx2c);
-            S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
+            more(n0, n1, n2);
         }
+#endif
         ChanTerms<f2> t01;
         ChanTerms<float> t2;
         ssim_l1_channel<f2>(xc01, yc01, gxc01, gyc01, Sx01, Sy01, Sxx01, Syy01, Sxy01, P.ws, P.wl, P.eps, t01);
@@ -270,6 +314,30 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
         const float myu = (gyo == 1) ? 2.f : 1.f, myd = (gyo == H - 2) ? 2.f : 1.f;
         const float yq[3] = {o_y[0] - 0.5f, o_y[1] - 0.5f, o_y[2] - 0.5f}, xq[3] = {o_x[0] - 0.5f, o_x[1] - 0.5f, o_x[2] - 0.5f};
         float sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0}, sC[3] = {0, 0, 0};     // multiplicity-weighted sums of the 9 coefficient records
+        auto gather = [&](const f32x4 &c0, const f32x4 &c1, const f32x4 &c2, const float fm) {
+            sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
+            sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
+            sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
+        };
+#if TC_DENSE_PIPE_B
+        {   // the nine coefficient records, raster order as the rolled loop below, the next record in flight under the current one's FMAs
+            constexpr int RB = 48, ROWB = W1 * 48;
+            const unsigned base = lds_addr(coef + (oy * W1 + ox) * 3);
+            f32x4 u0, u1, u2, w0, w1, w2;
+            auto fence = [&]() { asm volatile("" : "+v"(sA[0]), "+v"(sA[1]), "+v"(sA[2]), "+v"(sB[0]), "+v"(sB[1]), "+v"(sB[2]), "+v"(sC[0]), "+v"(sC[1]), "+v"(sC[2])); };
+            lds_issue3c_at<0>(base, u0, u1, u2);
+            lds_issue3c_at<RB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, mxl * myu); fence(); lds_issue3c_at<2 * RB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, 1.f * myu); fence(); lds_issue3c_at<ROWB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, mxr * myu); fence(); lds_issue3c_at<ROWB + RB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, mxl * 1.f); fence(); lds_issue3c_at<ROWB + 2 * RB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, 1.f * 1.f); fence(); lds_issue3c_at<2 * ROWB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, mxr * 1.f); fence(); lds_issue3c_at<2 * ROWB + RB>(base, w0, w1, w2);
+            lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, mxl * myd); fence(); lds_issue3c_at<2 * ROWB + 2 * RB>(base, u0, u1, u2);
+            lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, 1.f * myd); fence();
+            lds_waitn<0>(u0, u1, u2); gather(u0, u1, u2, mxr * myd);
+        }
+#else
 #pragma unroll 1
         for (int r = 0; r < 3; r++) {                      // rows rolled (a full unroll keeps all 27 LDS reads live: 172 VGPRs)
             const float fy = r == 0 ? myu : (r == 2 ? myd : 1.f);
@@ -279,11 +347,13 @@ __global__ __launch_bounds__(NT, 2) void k_dense_linearize(LinParams P, DensePar
                 float4 c0, c1, c2;
                 lds_read3(row + cx * 3, c0, c1, c2);
                 const float fm = (cx == 0 ? mxl : (cx == 2 ? mxr : 1.f)) * fy;
-                sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
-                sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
-                sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
+                gather(f32x4{c0.x, c0.y, c0.z, c0.w}, f32x4{c1.x, c1.y, c1.z, c1.w}, f32x4{c2.x, c2.y, c2.z, c2.w}, fm);
             }
         }
+#endif
+        geo_jac<7>(c, o_g, W, H, a, b, zc);
+        // scale column (dXp = Xp - t) -> inverse-depth column: dXp/drho = -depth (Xp - t)
+        a[6] *= -o_depth; b[6] *= -o_depth; zc[6] *= -o_depth;
         float lam[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) lam[ch] = sA[ch] + sB[ch] * yq[ch] + sC[ch] * xq[ch];

@@ -85,6 +85,9 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
 #ifndef TC_JOINT_OCC
 #define TC_JOINT_OCC 2
 #endif
+#ifndef TC_JOINT_LEAN_PIPE
+#define TC_JOINT_LEAN_PIPE 3
+#endif
 // SM: the l_smooth term compiled in (off in the reference's drivers: the lean instantiation leaves its code and registers out).
 // LEAN (NS = 2 on the 256-thread tiling without l_smooth -- the KITTI window of the mirror's default mode): the loop over the two sources is
 // unrolled, so every `s == 0` / `s > 0` branch folds and the cross-source state that only one of the two bodies needs is not carried through
@@ -92,6 +95,11 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
 template <int NS, int NT, bool REF, bool SM> struct JointShape {
     static constexpr bool LEAN = NS == 2 && NT <= 256 && REF && !SM;
     static constexpr int OCC = NT > 256 ? 2 : ((NS == 1 || LEAN) ? (TC_JOINT_OCC > 3 ? TC_JOINT_OCC : 3) : TC_JOINT_OCC);
+    // software-pipelined window reads of phases 2a / 2b (as k_dense_linearize).  In the LEAN form, whose 168 registers are taken, they cost nine
+    // more spilled registers and still win (joint launch 23.6 -> 22.5 us, minibatch-6 -1.6 %: profiles/r05_dense_pipe_ab.txt); TC_JOINT_LEAN_PIPE
+    // (bit 0 = phase 2a, bit 1 = phase 2b) keeps the rolled loops there for A/B
+    static constexpr bool PIPE_A = TC_DENSE_PIPE_A && (!LEAN || (TC_JOINT_LEAN_PIPE & 1));
+    static constexpr bool PIPE_B = TC_DENSE_PIPE_B && (!LEAN || (TC_JOINT_LEAN_PIPE & 2));
 };
 template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false, bool SM = REF>
 __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dense_joint(LinParams P, JointParams J) {
@@ -160,8 +168,9 @@ __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dens
     static_assert(NRING <= NT, "one ring round");
     constexpr int RING_THREADS = (NRING + 63) / 64 * 64;
     struct Stage { int lx, ly, px, py; float4 tp; float dep, dep0; Geo g; Tap t; };
+    constexpr int SRC_UNROLL = JointShape<NS, NT, REF, SM>::LEAN ? 2 : 1;
 
-#pragma unroll(JointShape<NS, NT, REF, SM>::LEAN ? 2 : 1)
+#pragma unroll SRC_UNROLL
     for (int s = 0; s < NS; s++) {
         const int n = s * J.B + b;
         const PairConst &c = P.pc[n];
@@ -263,26 +272,50 @@ __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dens
             f2 Sy01, Sx01, Syy01, Sxx01, Sxy01, Gx01, Gy01, S2, SS2, G2;
             float Sxy2;
             const float4 *nbA = ctr - (W2 + 1) * 3;
-            {
-                f32x4 n0, n1, n2;
-                lds_read3v(nbA, n0, n1, n2);
-                nbA += 3;
+            auto first = [&](const f32x4 &n0, const f32x4 &n1, const f32x4 &n2) {
                 Sy01 = pk_sub(n0.lo, yc01); Sx01 = pk_sub(n0.hi, xc01);
                 Syy01 = Sy01 * Sy01; Sxx01 = Sx01 * Sx01; Sxy01 = Sx01 * Sy01;
                 Gx01 = n1.lo; Gy01 = n1.hi;
                 S2 = pk_sub(n2.lo, yx2c);
                 SS2 = S2 * S2; Sxy2 = S2.x * S2.y; G2 = n2.hi;
-            }
-#pragma unroll 1
-            for (int kk = 1; kk < 9; kk++) {
-                f32x4 n0, n1, n2;
-                lds_read3v(nbA, n0, n1, n2);
-                nbA += (kk == 2 || kk == 5) ? (W2 - 2) * 3 : 3;
+            };
+            auto more = [&](const f32x4 &n0, const f32x4 &n1, const f32x4 &n2) {
                 f2 ey = pk_sub(n0.lo, yc01), ex = pk_sub(n0.hi, xc01);
                 Sy01 += ey; Sx01 += ex; Syy01 += ey * ey; Sxx01 += ex * ex; Sxy01 += ex * ey;
                 Gx01 += n1.lo; Gy01 += n1.hi;
                 f2 e2v = pk_sub(n2.lo, yx2c);
                 S2 += e2v; SS2 += e2v * e2v; Sxy2 += e2v.x * e2v.y; G2 += n2.hi;
+            };
+            if constexpr (JointShape<NS, NT, REF, SM>::PIPE_A) {   // software-pipelined window reads with scheduling fences, as in k_dense_linearize (dense_kernel.h): same operations, same order
+                constexpr int RB = 48, ROWB = W2 * 48;
+                const unsigned base = lds_addr(nbA);
+                f32x4 u0, u1, u2, w0, w1, w2;
+                auto fence = [&]() { asm volatile("" : "+v"(Sy01), "+v"(Sx01), "+v"(Syy01), "+v"(Sxx01), "+v"(Sxy01), "+v"(Gx01), "+v"(Gy01), "+v"(S2), "+v"(SS2), "+v"(Sxy2), "+v"(G2)); };
+                lds_issue3c_at<0>(base, u0, u1, u2);
+                lds_issue3c_at<RB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); first(u0, u1, u2); fence(); lds_issue3c_at<2 * RB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence(); lds_issue3c_at<ROWB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); more(u0, u1, u2); fence(); lds_issue3c_at<ROWB + RB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence(); lds_issue3c_at<ROWB + 2 * RB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); more(u0, u1, u2); fence(); lds_issue3c_at<2 * ROWB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence(); lds_issue3c_at<2 * ROWB + RB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); more(u0, u1, u2); fence(); lds_issue3c_at<2 * ROWB + 2 * RB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); more(w0, w1, w2); fence();
+                lds_waitn<0>(u0, u1, u2); more(u0, u1, u2);
+            } else {
+                {
+                    f32x4 n0, n1, n2;
+                    lds_read3v(nbA, n0, n1, n2);
+                    nbA += 3;
+                    first(n0, n1, n2);
+                }
+#pragma unroll 1
+                for (int kk = 1; kk < 9; kk++) {
+                    f32x4 n0, n1, n2;
+                    lds_read3v(nbA, n0, n1, n2);
+                    nbA += (kk == 2 || kk == 5) ? (W2 - 2) * 3 : 3;
+                    more(n0, n1, n2);
+                }
             }
             ChanTerms<f2> t01;
             ChanTerms<float> t2;
@@ -387,8 +420,6 @@ __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dens
 #pragma unroll
         for (int i = 0; i < 29; i++) v[i] = 0.f;
         if (inimg) {
-            geo_jac<7>(c, o_g, W, H, a, bb, zc);
-            a[6] *= -o_depth; bb[6] *= -o_depth; zc[6] *= -o_depth;      // scale column -> inverse-depth column
             float sg;
             {
                 float sum = o_cd + o_pd, dif = o_cd - o_pd, isum = frcp(sum), raw = fabsf(dif) * isum;
@@ -405,21 +436,47 @@ __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dens
             const float yq[3] = {o_y[0] - 0.5f, o_y[1] - 0.5f, o_y[2] - 0.5f}, xq[3] = {o_x[0] - 0.5f, o_x[1] - 0.5f, o_x[2] - 0.5f};
             float sA[3] = {0, 0, 0}, sB[3] = {0, 0, 0}, sC[3] = {0, 0, 0};
             float sP[3] = {0, 0, 0};          // REF: the prior's coefficient sums (source 0's records carry them)
+            auto gather = [&](const f32x4 &c0, const f32x4 &c1, const f32x4 &c2, const float fm) {
+                sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
+                sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
+                sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
+                if (REF) { sP[0] += fm * c2.y; sP[1] += fm * c2.z; sP[2] += fm * c2.w; }
+            };
+            if constexpr (JointShape<NS, NT, REF, SM>::PIPE_B) {
+                constexpr int RB = 48, ROWB = W1 * 48;
+                const unsigned base = lds_addr(coef + (oy * W1 + ox) * 3);
+                f32x4 u0, u1, u2, w0, w1, w2;
+                auto fence = [&]() {
+                    asm volatile("" : "+v"(sA[0]), "+v"(sA[1]), "+v"(sA[2]), "+v"(sB[0]), "+v"(sB[1]), "+v"(sB[2]), "+v"(sC[0]), "+v"(sC[1]), "+v"(sC[2]));
+                    if (REF) asm volatile("" : "+v"(sP[0]), "+v"(sP[1]), "+v"(sP[2]));
+                };
+                lds_issue3c_at<0>(base, u0, u1, u2);
+                lds_issue3c_at<RB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, mxl * myu); fence(); lds_issue3c_at<2 * RB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, 1.f * myu); fence(); lds_issue3c_at<ROWB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, mxr * myu); fence(); lds_issue3c_at<ROWB + RB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, mxl * 1.f); fence(); lds_issue3c_at<ROWB + 2 * RB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, 1.f * 1.f); fence(); lds_issue3c_at<2 * ROWB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, mxr * 1.f); fence(); lds_issue3c_at<2 * ROWB + RB>(base, w0, w1, w2);
+                lds_waitn<3>(u0, u1, u2); gather(u0, u1, u2, mxl * myd); fence(); lds_issue3c_at<2 * ROWB + 2 * RB>(base, u0, u1, u2);
+                lds_waitn<3>(w0, w1, w2); gather(w0, w1, w2, 1.f * myd); fence();
+                lds_waitn<0>(u0, u1, u2); gather(u0, u1, u2, mxr * myd);
+            } else {
 #pragma unroll 1
-            for (int r = 0; r < 3; r++) {
-                const float fy = r == 0 ? myu : (r == 2 ? myd : 1.f);
-                const float4 *row = coef + ((oy + r) * W1 + ox) * 3;
+                for (int r = 0; r < 3; r++) {
+                    const float fy = r == 0 ? myu : (r == 2 ? myd : 1.f);
+                    const float4 *row = coef + ((oy + r) * W1 + ox) * 3;
 #pragma unroll
-                for (int cx = 0; cx < 3; cx++) {
-                    float4 c0, c1, c2;
-                    lds_read3(row + cx * 3, c0, c1, c2);
-                    const float fm = (cx == 0 ? mxl : (cx == 2 ? mxr : 1.f)) * fy;
-                    sA[0] += fm * c0.x; sA[1] += fm * c0.y; sA[2] += fm * c0.z;
-                    sB[0] += fm * c0.w; sB[1] += fm * c1.x; sB[2] += fm * c1.y;
-                    sC[0] += fm * c1.z; sC[1] += fm * c1.w; sC[2] += fm * c2.x;
-                    if (REF) { sP[0] += fm * c2.y; sP[1] += fm * c2.z; sP[2] += fm * c2.w; }
+                    for (int cx = 0; cx < 3; cx++) {
+                        float4 c0, c1, c2;
+                        lds_read3(row + cx * 3, c0, c1, c2);
+                        const float fm = (cx == 0 ? mxl : (cx == 2 ? mxr : 1.f)) * fy;
+                        gather(f32x4{c0.x, c0.y, c0.z, c0.w}, f32x4{c1.x, c1.y, c1.z, c1.w}, f32x4{c2.x, c2.y, c2.z, c2.w}, fm);
+                    }
                 }
             }
+            geo_jac<7>(c, o_g, W, H, a, bb, zc);      // (rebuilt here, behind the coefficient gather: see o_g)
+            a[6] *= -o_depth; bb[6] *= -o_depth; zc[6] *= -o_depth;      // scale column -> inverse-depth column
             float sx = o_w * o_l1x, sy = o_w * o_l1y;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
