@@ -88,6 +88,9 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
 #ifndef TC_JOINT_LEAN_PIPE
 #define TC_JOINT_LEAN_PIPE 3
 #endif
+#ifndef TC_JOINT_NONREF_PIPE
+#define TC_JOINT_NONREF_PIPE 1
+#endif
 // SM: the l_smooth term compiled in (off in the reference's drivers: the lean instantiation leaves its code and registers out).
 // LEAN (NS = 2 on the 256-thread tiling without l_smooth -- the KITTI window of the mirror's default mode): the loop over the two sources is
 // unrolled, so every `s == 0` / `s > 0` branch folds and the cross-source state that only one of the two bodies needs is not carried through
@@ -98,8 +101,10 @@ template <int NS, int NT, bool REF, bool SM> struct JointShape {
     // software-pipelined window reads of phases 2a / 2b (as k_dense_linearize).  In the LEAN form, whose 168 registers are taken, they cost nine
     // more spilled registers and still win (joint launch 23.6 -> 22.5 us, minibatch-6 -1.6 %: profiles/r05_dense_pipe_ab.txt); TC_JOINT_LEAN_PIPE
     // (bit 0 = phase 2a, bit 1 = phase 2b) keeps the rolled loops there for A/B
-    static constexpr bool PIPE_A = TC_DENSE_PIPE_A && (!LEAN || (TC_JOINT_LEAN_PIPE & 1));
-    static constexpr bool PIPE_B = TC_DENSE_PIPE_B && (!LEAN || (TC_JOINT_LEAN_PIPE & 2));
+    // The reference-loss instantiations that already fill their 256 registers (S = 3, or S = 2 with l_smooth) keep the rolled loops: pipelined they spill.
+    static constexpr bool ROOM = NS == 1 || (!REF && TC_JOINT_NONREF_PIPE);
+    static constexpr bool PIPE_A = TC_DENSE_PIPE_A && (ROOM || (LEAN && (TC_JOINT_LEAN_PIPE & 1)));
+    static constexpr bool PIPE_B = TC_DENSE_PIPE_B && (ROOM || (LEAN && (TC_JOINT_LEAN_PIPE & 2)));
 };
 template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false, bool SM = REF>
 __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dense_joint(LinParams P, JointParams J) {
