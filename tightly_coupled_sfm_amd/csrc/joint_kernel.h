@@ -92,11 +92,11 @@ __device__ __forceinline__ void joint_reduce_add(const float *v, float *red, flo
 #define TC_JOINT_NONREF_PIPE 1
 #endif
 // SM: the l_smooth term compiled in (off in the reference's drivers: the lean instantiation leaves its code and registers out).
-// LEAN (NS = 2 on the 256-thread tiling without l_smooth -- the KITTI window of the mirror's default mode): the loop over the two sources is
+// LEAN (NS = 2 on the 256-thread tiling without l_smooth -- the KITTI window of the mirror's default mode and of the library's own joint mode): the loop over the two sources is
 // unrolled, so every `s == 0` / `s > 0` branch folds and the cross-source state that only one of the two bodies needs is not carried through
 // the other; together with the Jacobian rebuilt in phase 2b (below) the kernel fits 168 VGPRs = THREE workgroups per CU (was 256 / two).
 template <int NS, int NT, bool REF, bool SM> struct JointShape {
-    static constexpr bool LEAN = NS == 2 && NT <= 256 && REF && !SM;
+    static constexpr bool LEAN = NS == 2 && NT <= 256 && !SM;
     static constexpr int OCC = NT > 256 ? 2 : ((NS == 1 || LEAN) ? (TC_JOINT_OCC > 3 ? TC_JOINT_OCC : 3) : TC_JOINT_OCC);
     // software-pipelined window reads of phases 2a / 2b (as k_dense_linearize).  In the LEAN form, whose 168 registers are taken, they cost nine
     // more spilled registers and still win (joint launch 23.6 -> 22.5 us, minibatch-6 -1.6 %: profiles/r05_dense_pipe_ab.txt); TC_JOINT_LEAN_PIPE

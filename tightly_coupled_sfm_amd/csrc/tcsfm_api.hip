@@ -599,6 +599,11 @@ bool joint_scratch_fits(const tcsfm_ctx *h, int B, int recs_per_target) {
            (size_t)B * recs_per_target * JL::NACC <= nb * 2 * (size_t)h->nblk_alloc * JM::NACC;
 }
 
+// tile height of k_dense_joint's own grid (32 x 8 tiles of 256 threads by default; 16: the round-4 grid shared with the pair-form kernels)
+#ifndef TC_JOINT_TILE_H
+#define TC_JOINT_TILE_H 8
+#endif
+
 // JOINT dense mode of a window (include/tcsfm.h, tcsfm_refine_dense_window): the S forward pairs of every target share one depth map
 // and are solved together (k_dense_joint / k_solve_joint / k_dense_joint_update); the inverse pairs run the pair-form dense kernels on
 // offset views of the same scratch.  Inputs already on the device.
@@ -614,6 +619,10 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     int rc;
     constexpr int DTW = 32, DTH = 16, DNT = 512;
     const int tiles_x = (h->W + DTW - 1) / DTW, tiles_y = (h->H + DTH - 1) / DTH, nblk = tiles_x * tiles_y;
+    // the joint kernel runs on its own tile grid, as under the reference's loss (third session of round 5): 256-thread workgroups, for S = 2 the
+    // LEAN form of the kernel (161 VGPRs: three workgroups per CU instead of one 512-thread workgroup at 212-232)
+    constexpr int JTW = 32, JTH = TC_JOINT_TILE_H, JNT = JTW * JTH;
+    const int jtiles_x = (h->W + JTW - 1) / JTW, jtiles_y = (h->H + JTH - 1) / JTH, jnblk = jtiles_x * jtiles_y;
     if (n_sel && !h->sel_maps) HIPCHK(h, hipMalloc((void **)&h->sel_maps, (size_t)2 * h->max_pairs * hw * sizeof(float)));
     if (!h->dense_rec) {
         HIPCHK(h, hipMalloc((void **)&h->dense_rec, n * hw * 8 * sizeof(float)));
@@ -627,8 +636,8 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     }
     if ((rc = joint_scratch(h))) return rc;
     if (lm && !h->lm_accept) HIPCHK(h, hipMalloc((void **)&h->lm_accept, n * sizeof(int)));
-    if ((size_t)nblk > (size_t)h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
-    if (!joint_scratch_fits<NS>(h, B, nblk)) return fail(h, TCSFM_E_ARG, "internal: the joint dense scratch does not hold this many targets");
+    if ((size_t)nblk > (size_t)h->nblk_alloc || (size_t)jnblk > (size_t)h->nblk_alloc) return fail(h, TCSFM_E_ARG, "internal: dense tile grid exceeds scratch");
+    if (!joint_scratch_fits<NS>(h, B, jnblk)) return fail(h, TCSFM_E_ARG, "internal: the joint dense scratch does not hold this many targets");
     tcsfm_opts oo = *o;
     oo.refine = TCSFM_REFINE_POSE;
     oo.window_rule = TCSFM_WINDOW_PAIR;          // (the pose-mode coupling; the joint kernel takes the rule through JointParams)
@@ -637,7 +646,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     if ((rc = run_pack(h, &oo, N, d_tgt, d_src, d_dt, d_ds, &I, B, S, h->depth0, wo))) return rc;
     // ---- forward group: joint
     LinParams Pj = lin_params(h, &oo, 6);
-    Pj.tiles_x = tiles_x; Pj.tiles_y = tiles_y; Pj.ngrp = (nblk + RG - 1) / RG; Pj.direct = 1;
+    Pj.tiles_x = jtiles_x; Pj.tiles_y = jtiles_y; Pj.ngrp = (jnblk + RG - 1) / RG; Pj.direct = 1;
     float *sel_diff = h->sel_maps, *sel_valid = h->sel_maps ? h->sel_maps + (size_t)h->max_pairs * hw : nullptr;
     if (n_sel) { Pj.ext_diff = sel_diff; Pj.ext_valid = sel_valid; Pj.n_ext = n_sel; Pj.ext_B = B; Pj.ext_S = S; }
     JointParams J;
@@ -647,7 +656,7 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
     J.automask = 0;                             // own masks only without argmin, where the reference's forward term has no auto-mask (:71-73)
     JointSolveParams Sj;
     memset(&Sj, 0, sizeof(Sj));
-    Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
+    Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = jnblk; Sj.B = B;
     Sj.n_iters = o->n_iters; Sj.solver = o->solver; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
     Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = lm ? h->lm_accept : nullptr;
     JointUpdateParams Uj;
@@ -721,10 +730,10 @@ int dense_joint_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt
             M.o_diff = sel_diff; M.o_valid = sel_valid;
             launch_lin(h, M, n_sel, 6, false, MODE_MAPS, 2);      // (the selection itself: ext_selected, inside the joint kernel)
         }
-        take_stamp(h, Pj, (size_t)nblk * B);
+        take_stamp(h, Pj, (size_t)jnblk * B);
         ProfScope prof(h, 0);
-        if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true>), dim3(nblk, B), dim3(DNT), 0, fs, Pj, J);
-        else hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT>), dim3(nblk, B), dim3(DNT), 0, fs, Pj, J);
+        if (tr) hipLaunchKernelGGL((k_dense_joint<NS, JTW, JTH, JNT, true>), dim3(jnblk, B), dim3(JNT), 0, fs, Pj, J);
+        else hipLaunchKernelGGL((k_dense_joint<NS, JTW, JTH, JNT>), dim3(jnblk, B), dim3(JNT), 0, fs, Pj, J);
     };
     constexpr int SOLVE_NT = JSOLVE_NT;
     for (int it = 0; it < o->n_iters; it++) {
@@ -793,9 +802,6 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     // The joint kernel's own tile grid (round 5): 32 x 8 tiles of 256 threads by default.  At 256 VGPRs the kernel holds 8 waves per CU either
     // way; as TWO independent 4-wave workgroups their barriers and load phases no longer coincide (one workgroup's gathers run under the
     // other's arithmetic), which a single 8-wave workgroup cannot do -- at the price of a larger halo share (TC_JOINT_TILE_H=16: the round-4 grid).
-#ifndef TC_JOINT_TILE_H
-#define TC_JOINT_TILE_H 8
-#endif
     constexpr int DTW = 32, DTH = TC_JOINT_TILE_H, DNT = DTW * DTH;
     const int jtiles_x = (h->W + DTW - 1) / DTW, jtiles_y = (h->H + DTH - 1) / DTH;
     const int nblk = jtiles_x * jtiles_y;              // workgroup records per target of the joint kernel
