@@ -106,31 +106,39 @@ template <int NS, int NT, bool REF, bool SM> struct JointShape {
     static constexpr bool PIPE_A = TC_DENSE_PIPE_A && (ROOM || (LEAN && (TC_JOINT_LEAN_PIPE & 1)));
     static constexpr bool PIPE_B = TC_DENSE_PIPE_B && (ROOM || (LEAN && (TC_JOINT_LEAN_PIPE & 2)));
 };
-template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false, bool SM = REF>
-__global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dense_joint(LinParams P, JointParams J) {
+// LDS of one workgroup, carved from ONE array of float4 owned by the kernel: the two-role launch (k_dense_joint2) runs a body per role on the same storage
+template <int NS, int TW, int TH, int NT, bool REF> struct JointSmem {
+    static constexpr int N2 = (TW + 4) * (TH + 4), N1 = (TW + 2) * (TH + 2);
+    static constexpr int OFF_AUX = N2 * 3, OFF_COEF = OFF_AUX + N2, OFF_RED = OFF_COEF + N1 * 3;                 // in float4
+    static constexpr int F_RED = (NT / 64) * 32, F_ACC = (JointLayout<NS>::NACC + 3) / 4 * 4, F_W0 = REF ? (N2 + 3) / 4 * 4 : 4, F_SGQ = REF ? (2 * N2 + 3) / 4 * 4 : 4;      // in floats
+    static constexpr int N4 = OFF_RED + (F_RED + F_ACC + F_W0 + F_SGQ) / 4;
+};
+template <int NS, int TW, int TH, int NT, bool TRACE, bool REF, bool SM>
+__device__ __forceinline__ void dense_joint_body(const LinParams &P, const JointParams &J, const int by, float4 *smem) {
     using JL = JointLayout<NS>;
+    using SMEM = JointSmem<NS, TW, TH, NT, REF>;
     constexpr int NP = 6;
     constexpr int W2 = TW + 4, H2 = TH + 4, N2 = W2 * H2;
     constexpr int W1 = TW + 2, H1 = TH + 2, N1 = W1 * H1;
     constexpr int NCEN = TW * TH;
     static_assert(NCEN == NT, "one tile pixel per thread");
-    __shared__ float4 rec1[N2 * 3];
-    __shared__ float4 aux[N2];
-    __shared__ float4 coef[N1 * 3];
-    __shared__ float red[(NT / 64) * 32];
-    __shared__ float acc[JL::NACC];
-    __shared__ float w0[REF ? N2 : 1];             // REF: depth-consistency weight of SOURCE 0 on tile + 2-pixel halo (optimizer.py:69)
-    __shared__ float sgq[REF ? 2 * N2 : 1];        // REF: (sigma, sigma0) on tile + 2-pixel halo: the l_depth_init prior (optimizer.py:89-90)
+    float4 *rec1 = smem;                                        // [N2 * 3]
+    float4 *aux = smem + SMEM::OFF_AUX;                         // [N2]
+    float4 *coef = smem + SMEM::OFF_COEF;                       // [N1 * 3]
+    float *red = reinterpret_cast<float *>(smem + SMEM::OFF_RED);      // [(NT / 64) * 32]
+    float *acc = red + SMEM::F_RED;                             // [NACC]
+    float *w0 = acc + SMEM::F_ACC;                              // REF: depth-consistency weight of SOURCE 0 on tile + 2-pixel halo (optimizer.py:69)
+    float *sgq = w0 + SMEM::F_W0;                               // REF: (sigma, sigma0) on tile + 2-pixel halo: the l_depth_init prior (optimizer.py:89-90)
     // REF: everything is accumulated in units of the forward term's factor a_f = c_f / K_f (k_solve_joint multiplies by it)
     float r_dc = 0.f, r_init = 0.f, r_eph = 0.f, iaf_ = 0.f;
     if (REF) {
-        const int *nr = J.norms + 2 * (J.norm_B > 0 ? (int)blockIdx.y / J.norm_B : 0);      // the normaliser group of this target
+        const int *nr = J.norms + 2 * (J.norm_B > 0 ? by / J.norm_B : 0);      // the normaliser group of this target
         const float Kf = (float)nr[0], Ki = (float)nr[1];
         const float iaf = Kf > 0.f ? Kf / J.c_f : 0.f;                 // 1 / a_f
         iaf_ = iaf;
         r_dc = J.b_dc * iaf; r_init = J.w_init_px * iaf;
         r_eph = (Ki > 0.f ? 0.25f / Ki : 0.f) * iaf;                   // factor of the scattered photometric sums (the inverse term's a_i) over a_f
-        if (J.ext_norm) { const float Ke = (float)J.ext_norm[2 * (J.norm_B > 0 ? (int)blockIdx.y / J.norm_B : 0)]; r_eph = (Ke > 0.f ? J.ext_c / Ke : 0.f) * iaf; }
+        if (J.ext_norm) { const float Ke = (float)J.ext_norm[2 * (J.norm_B > 0 ? by / J.norm_B : 0)]; r_eph = (Ke > 0.f ? J.ext_c / Ke : 0.f) * iaf; }
     }
     const bool ref_w0 = REF && J.argmin;             // every source's pixels carry source 0's weight map
     const bool ref_prior = REF && J.w_init_px > 0.f;
@@ -143,14 +151,14 @@ __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dens
         int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int b = blockIdx.y;
+    const int b = by;
     const int H = P.H, W = P.W, hw = H * W;
     const int tyi = bid / P.tiles_x, txi = bid - tyi * P.tiles_x;
     const int x00 = txi * TW, y00 = tyi * TH;
     const float *depth_t = P.depth_t + (size_t)b * hw;          // the SHARED map: slot of forward pair (0, b)
     const int tid = threadIdx.x;
     stamp_begin(P.stamp, tid);
-#define TC_JSTAMP(i) if (J.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (i) < 8) J.dbg[i] = wall_clock64();
+#define TC_JSTAMP(i) if (J.dbg && tid == 0 && blockIdx.x == 0 && by == 0 && (i) < 8) J.dbg[i] = wall_clock64();
     TC_JSTAMP(0)
     for (int i = tid; i < JL::NACC; i += NT) acc[i] = 0.f;
 
@@ -656,6 +664,21 @@ __global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dens
     TC_JSTAMP(7)
 #undef TC_JSTAMP
     stamp_end(P.stamp, tid);
+}
+
+template <int NS, int TW, int TH, int NT, bool TRACE = false, bool REF = false, bool SM = REF>
+__global__ __launch_bounds__(NT, (JointShape<NS, NT, REF, SM>::OCC)) void k_dense_joint(LinParams P, JointParams J) {
+    __shared__ float4 smem[JointSmem<NS, TW, TH, NT, REF>::N4];
+    dense_joint_body<NS, TW, TH, NT, TRACE, REF, SM>(P, J, (int)blockIdx.y, smem);
+}
+// Free source maps under the reference's loss: the forward groups (S sources per target; rows [0, Ja.B)) and the inverse pairs as groups of one
+// source (rows behind them) in ONE launch -- independent work on disjoint records, LDS overlaid by role (third session of round 5; was two launches)
+template <int NS, int TW, int TH, int NT, bool TRACE = false>
+__global__ __launch_bounds__(NT, (JointShape<NS, NT, true, false>::OCC)) void k_dense_joint2(LinParams Pa, JointParams Ja, LinParams Pb, JointParams Jb) {
+    constexpr int NA = JointSmem<NS, TW, TH, NT, true>::N4, NB = JointSmem<1, TW, TH, NT, true>::N4;
+    __shared__ float4 smem[NA > NB ? NA : NB];
+    if ((int)blockIdx.y < Ja.B) dense_joint_body<NS, TW, TH, NT, TRACE, true, false>(Pa, Ja, (int)blockIdx.y, smem);
+    else dense_joint_body<1, TW, TH, NT, TRACE, true, false>(Pb, Jb, (int)blockIdx.y - Ja.B, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

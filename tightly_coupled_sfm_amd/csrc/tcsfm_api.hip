@@ -1012,8 +1012,17 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
         Pj.trace = tr ? h->trace_bits + (size_t)lin * N * hw : nullptr;
         Sj.trace_decide = h->trace_decide ? h->trace_decide + (size_t)lin * N : nullptr;
         if (smooth) hipLaunchKernelGGL(k_dref_smooth, dim3(B), dim3(1024), 0, st, Ds);
-        take_stamp(h, Pj, (size_t)nblk * B);
+        const bool both = free_src && !smooth;       // free source maps: the forward groups and the inverse pairs' groups of one source in ONE launch
+        take_stamp(h, Pj, (size_t)nblk * (both ? B + SB : B));
         ProfScope prof(h, 0);
+        if (both) {
+            Pj2.trace = tr ? h->trace_bits + ((size_t)lin * N + SB) * hw : nullptr;
+            Pj2.stamp = Pj.stamp;                    // (stamps are indexed by the launch's grid)
+            if (tr) hipLaunchKernelGGL((k_dense_joint2<NS, DTW, DTH, DNT, true>), dim3(nblk, B + SB), dim3(DNT), 0, st, Pj, J, Pj2, J2);
+            else hipLaunchKernelGGL((k_dense_joint2<NS, DTW, DTH, DNT, false>), dim3(nblk, B + SB), dim3(DNT), 0, st, Pj, J, Pj2, J2);
+            if (qres) hipLaunchKernelGGL((k_qres_schur2<NS>), dim3(nqblk, B + SB), dim3(256), 0, st, Q, Q2);      // both groups' cells
+            return TCSFM_OK;
+        }
         // (l_smooth is compiled into its own instantiations: without it -- the reference's drivers -- the S = 2 kernel is the LEAN form, three workgroups per CU)
         if (smooth) {
             if (tr) hipLaunchKernelGGL((k_dense_joint<NS, DTW, DTH, DNT, true, true, true>), dim3(nblk, B), dim3(DNT), 0, st, Pj, J);
