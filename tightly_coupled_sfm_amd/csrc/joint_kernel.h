@@ -719,6 +719,7 @@ struct JointSolveParams {
     double w_pc, pc_eps;
     double *pose_lin;
     int pc_np, pc_self0, pc_part0;
+    long long *dbg;           // diagnostic runs only (TCSFM_DEBUG_STAMPS=2): wall-clock stamps of the phases of target 0's solve; null in production
 };
 
 constexpr int JSOLVE_NT = 1024;
@@ -728,7 +729,10 @@ template <int NS, bool PC = false>
 __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, const int b, const int tid, const int split_k = 0) {
     using JL = JointLayout<NS>;
     constexpr int NP = JL::NP, NC = NP + 1;
-    constexpr int APAD = JL::NACC <= 128 ? 128 : 256, PARTS = JSOLVE_NT / APAD;
+    // thread = (accumulator, record subset).  S = 1 (32 accumulators): 32 subsets, so a target's 300-480 tile records are ONE batch of at most 16 loads per thread
+    // (third session of round 5: with 128 accumulator slots only a quarter of the threads loaded, in two dependent batches: 5.5 of the launch's 9.3 us)
+    constexpr int APAD = JL::NACC <= 32 ? 32 : (JL::NACC <= 128 ? 128 : 256), PARTS = JSOLVE_NT / APAD;
+    constexpr int NBATCH = PARTS >= 32 ? 16 : 32;        // loads in flight per thread and batch
     static_assert(JL::NACC <= 256 && NP * NC <= JSOLVE_NT, "k_solve_joint: one thread per accumulator column and per matrix entry");
     __shared__ double tot[JL::NACC];
     __shared__ double part[JSOLVE_NT];
@@ -739,6 +743,8 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
     const int NTS = JSOLVE_NT;
     // the optimiser state is fetched NOW, beside the records: the serial phases below never wait on a global load (as in k_solve)
     __shared__ double Ks[NS][12];
+#define TC_SSTAMP(i) if (P.dbg && tid == 0 && b == 0 && split_k == 0) P.dbg[i] = wall_clock64();
+    TC_SSTAMP(0)
     JointState &S = P.js[b];
     const double S_lambda = S.lambda, S_cost_cur = S.cost_cur;
     const int S_have_cur = S.have_cur;
@@ -758,12 +764,12 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
         double s = 0.0;
         if (c < JL::NACC) {
             const float *p = P.jblockrec + (size_t)b * P.nblk * JL::NACC + c;
-            for (int r0 = r_lo + q; r0 < r_hi; r0 += 32 * PARTS) {      // 32 loads per thread in flight (240 records of 192x640: one batch)
-                float w[32];
+            for (int r0 = r_lo + q; r0 < r_hi; r0 += NBATCH * PARTS) {      // NBATCH loads per thread in flight
+                float w[NBATCH];
 #pragma unroll
-                for (int k = 0; k < 32; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < r_hi ? r : r_lo) * JL::NACC]; }
+                for (int k = 0; k < NBATCH; k++) { const int r = r0 + k * PARTS; w[k] = p[(size_t)(r < r_hi ? r : r_lo) * JL::NACC]; }
 #pragma unroll
-                for (int k = 0; k < 32; k++) s += (r0 + k * PARTS < r_hi) ? (double)w[k] : 0.0;
+                for (int k = 0; k < NBATCH; k++) s += (r0 + k * PARTS < r_hi) ? (double)w[k] : 0.0;
             }
         }
         part[tid] = s;
@@ -799,6 +805,7 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
         }
     }
     __syncthreads();
+    TC_SSTAMP(1)
     __shared__ double pcA[PC ? NS : 1][36], pcG[PC ? NS : 1][6], pcD[PC ? NS : 1][6], pcH[PC ? NS : 1][36], pcg[PC ? NS : 1][6], pcC[PC ? NS : 1];
     double pc_cost = 0.0;
     if constexpr (PC) {
@@ -900,6 +907,7 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
         M[i] = v;
     }
     __syncthreads();
+    TC_SSTAMP(2)
     if (tid < NP) M[tid * NC + tid] += lambda * M[tid * NC + tid] + 1e-12;     // Marquardt damping
     if (tid == 0) { s_flag[0] = 1; }
     __syncthreads();
@@ -930,8 +938,10 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
         }
     }
     __syncthreads();
+    TC_SSTAMP(3)
     if (tid < NP) dl[tid] = s_flag[0] ? M[tid * NC + NP] / M[tid * NC + tid] : 0.0;
     __syncthreads();
+    TC_SSTAMP(4)
     if (tid == 0) {
         S.lambda = lambda;
         if (accept) { S.cost_cur = cost; S.have_cur = 1; }
@@ -985,6 +995,8 @@ __device__ __forceinline__ void solve_joint_body(const JointSolveParams &P, cons
             }
         }
     }
+    TC_SSTAMP(5)
+#undef TC_SSTAMP
 }
 
 template <int NS>

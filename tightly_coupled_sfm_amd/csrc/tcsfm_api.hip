@@ -915,6 +915,10 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     }
     JointSolveParams Sj;
     memset(&Sj, 0, sizeof(Sj));
+    {   // TCSFM_DEBUG_STAMPS=2: the phases of target 0's joint SOLVE instead (scripts/diag/solve_front_stamps.py)
+        static const int which = [] { const char *e = getenv("TCSFM_DEBUG_STAMPS"); return e ? atoi(e) : 0; }();
+        if (which == 2) { Sj.dbg = h->dbg_stamps; J.dbg = nullptr; }
+    }
     Sj.jblockrec = h->jblockrec; Sj.js = h->jstate; Sj.st = h->state; Sj.pc = h->pconst; Sj.stats = d_stats; Sj.nblk = nblk; Sj.B = B;
     Sj.n_iters = o->n_iters; Sj.solver = TCSFM_SOLVER_GN; Sj.lambda_up = o->lambda_up; Sj.lambda_down = o->lambda_down; Sj.lambda_min = o->lambda_min;
     Sj.lambda0 = o->lambda0; Sj.delta_out = h->jdelta; Sj.accept_out = nullptr;
@@ -1127,8 +1131,10 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     }
     // the targets' record sums are split over several workgroups (JointSolveParams::nsplit: the last arriver solves) when a target has MANY records
     // -- the quarter-resolution unknown's tile + cell-group records.  Measured (scripts/dense_ref_timing.py, TCSFM_JOINT_SPLIT=1 switches it off):
-    // 600-960 records: -2 ... -8 % per call; 150-480 records: the ticket costs what the faster fetch buys (+0 ... +2 %): not split.
-    auto split_of = [](int recs) { return recs >= 512 ? 8 : 1; };
+    // 600-960 records: -2 ... -8 % per call; 150-480 records: the ticket costs what the faster fetch buys (+0 ... +2 %): not split -- except the S >= 2
+    // targets' 480 records of 97+ floats, which two workgroups sum in one batch of loads each (third session: -0.8 % per B=1 KITTI window, -2.8 % at
+    // minibatch 6; with one source the 32-float records are one batch already and splitting costs 2-4 %: profiles/r05_joint_split_sweep.txt)
+    auto split_of = [](int recs) { return recs >= 512 ? 8 : ((NS >= 2 && recs >= 400) ? 2 : 1); };
     static const int split_env = getenv("TCSFM_JOINT_SPLIT") ? atoi(getenv("TCSFM_JOINT_SPLIT")) : -1;       // (A/B hook: 1 = off)
     {
         const size_t nt = (n + 1) / 2;
