@@ -1134,12 +1134,14 @@ int dense_ref_run(tcsfm_ctx *h, const tcsfm_opts *o, int B, const float *d_tgt, 
     // 600-960 records: -2 ... -8 % per call; 150-480 records: the ticket costs what the faster fetch buys (+0 ... +2 %): not split -- except the S >= 2
     // targets' 480 records of 97+ floats, which two workgroups sum in one batch of loads each (third session: -0.8 % per B=1 KITTI window, -2.8 % at
     // minibatch 6; with one source the 32-float records are one batch already and splitting costs 2-4 %: profiles/r05_joint_split_sweep.txt)
-    auto split_of = [](int recs) { return recs >= 512 ? 8 : ((NS >= 2 && recs >= 400) ? 2 : 1); };
+    // (after the S = 1 solve took 32 record subsets its 600-900 quarter-resolution records are best summed by ONE workgroup -- 185 -> 175 us per 240x320
+    // call -- and the S >= 2 targets' by four: profiles/r05_joint_split_sweep.txt)
+    auto split_of = [](int recs, int ns) { return ns == 1 ? 1 : (recs >= 512 ? 4 : (recs >= 400 ? 2 : 1)); };
     static const int split_env = getenv("TCSFM_JOINT_SPLIT") ? atoi(getenv("TCSFM_JOINT_SPLIT")) : -1;       // (A/B hook: 1 = off)
     {
         const size_t nt = (n + 1) / 2;
-        Sj.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj.nblk); Sj.jpart = h->jpart; Sj.jtick = h->jtick;
-        Sj2.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj2.nblk); Sj2.jpart = h->jpart + nt * kJointSplitMax * JM::NACC; Sj2.jtick = h->jtick + nt;
+        Sj.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj.nblk, NS); Sj.jpart = h->jpart; Sj.jtick = h->jtick;
+        Sj2.nsplit = split_env > 0 ? std::min(split_env, kJointSplitMax) : split_of(Sj2.nblk, 1); Sj2.jpart = h->jpart + nt * kJointSplitMax * JM::NACC; Sj2.jtick = h->jtick + nt;
     }
     if (pc) {     // c = weight / (6 S B) of the CALL (merged calls never carry the term); forward pairs at [0, SB), inverse pairs at [SB, 2 SB) of a buffer
         const double c = (double)o->w_pose_consist / (6.0 * SB);
