@@ -267,7 +267,7 @@ def modes_block(budget_s=12.0):
                                  "frac_source": "this run: in-kernel s_memrealtime bracket, one call in flight"}}
         return r
 
-    per = budget_s / 9.0
+    per = budget_s / 10.0
     # ---- BASELINE config 4: depth scale + 6-DoF pose, 8 iterations, 640x192, one window per call
     b = synth.make_batch(2, H, W, seed0=0, both_directions=True)
     d = {k: torch.as_tensor(v).cuda().contiguous() for k, v in b.items()}
@@ -294,6 +294,26 @@ def modes_block(budget_s=12.0):
     out["kitti_window_S2_reference_loss_dense_640x192"] = measure(e2, lambda: e2.refine_dense_window(tgt, srcs, dt4, ds5, Kw, pose_w, od, argmin=True),
                                                                     2 * S2, 4, H * W, 36, "k_dense_joint<2, REF> (forward pairs)", S2, per)
     e2.close(); e.close()
+    # ---- ... and the reference driver's own shape: a MINIBATCH of 6 such windows in one call (run_sequential_optimization.py:186; the loss couples them
+    # through its batch normalisers) -- the chip-filling figure of the mirror's default mode; the joint kernel's bracket is then a chip-full launch
+    MB = 6
+    bm = synth.make_batch(2 * S2 * MB, H, W, seed0=0)
+    dm = {k: torch.as_tensor(v).cuda().contiguous() for k, v in bm.items()}
+    tgt6 = dm["tgt"][:MB].contiguous()
+    srcs6 = dm["src"][:S2 * MB].reshape(S2, MB, 3, H, W).contiguous()
+    dt6 = dm["depth_t"][:MB].contiguous()
+    dt6 = dt6[:, None].contiguous() if dt6.dim() == 3 else dt6
+    ds6 = dm["depth_s"][:S2 * MB].reshape(S2, MB, 1, H, W).contiguous()
+    pose6 = torch.cat([dm["pose_init"][:S2 * MB], -dm["pose_init"][:S2 * MB]]).contiguous()
+    K6 = dm["K"][:MB].contiguous()
+    e6 = Engine(H, W, 2 * S2 * MB)
+    r6 = measure(e6, lambda: e6.refine_dense_window(tgt6, srcs6, dt6, ds6, K6, pose6, od, argmin=True),
+                 2 * S2 * MB, 4, H * W, 36, "k_dense_joint<2, REF> (forward pairs of 6 targets: a chip-filling launch)", S2 * MB, per)
+    r6["windows_per_call"] = MB
+    r6["windows_per_s"] = round(MB * r6["calls_per_s"], 1)
+    r6["dominant_kernel"]["frac_source"] = "this run: in-kernel s_memrealtime bracket of the 6-target launches"
+    out["kitti_window_S2_reference_loss_dense_minibatch6_640x192"] = r6
+    e6.close()
     # ---- BASELINE config 5: per-pixel inverse depth + pose, Schur complement: 320x240 and the reference's own ScanNet size 448x256
     for (hh, ww) in ((240, 320), (256, 448)):
         bb = synth.make_batch(2, hh, ww, seed0=0, both_directions=True)

@@ -82,12 +82,15 @@ def test_bench_single_process():
     md = d["modes"]
     want = {"config4_pose_scale_8it_640x192", "kitti_window_S2_pose_reference_rule_640x192", "kitti_window_S2_reference_loss_dense_640x192",
             "config5_dense_schur_320x240", "config5_dense_schur_448x256", "config5_reference_loss_full_320x240", "config5_reference_loss_quarter_320x240",
-            "config5_reference_loss_full_448x256", "config5_reference_loss_quarter_448x256"}
+            "config5_reference_loss_full_448x256", "config5_reference_loss_quarter_448x256",
+            "kitti_window_S2_reference_loss_dense_minibatch6_640x192"}      # (the reference driver's minibatch: the chip-filling figure of the mirror's default mode)
     assert want <= set(md)
     for k in want:
         m = md[k]
         assert m["us_per_call"] > 0 and m["frame_pairs_per_s"] > 100 and 0 < m["whole_call"]["frac"] <= 1 and 0 < m["dominant_kernel"]["frac"] <= 1, (k, m)
         assert m["whole_call"]["frac"] < m["dominant_kernel"]["frac"] * 1.5 + 0.05
+    m6, m1 = md["kitti_window_S2_reference_loss_dense_minibatch6_640x192"], md["kitti_window_S2_reference_loss_dense_640x192"]
+    assert m6["windows_per_call"] == 6 and m6["windows_per_s"] > 1.2 * m1["calls_per_s"]        # a minibatch fills the chip: well above one window per call
     sh = d["shim"]
     for k in ("pose", "pose_depth_reference_loss"):
         assert sh[k]["us_per_window"] > sh[k]["engine_call_us"] > 0 and sh[k]["windows"] >= 5
