@@ -32,6 +32,11 @@ for rep, tag in ((6, "12 pairs"), (32, "64 pairs")):
                     ("k_linearize<6, DC> (pose + depth-consistency term)", default_opts(n_iters=4, w_dc=0.15))):
         us = lin_us(e, lambda: e.refine_into(big["tgt"], big["src"], big["depth_t"], big["depth_s"], big["K"], big["pose_init"], out, o))
         print(json.dumps({"kernel": name, "pairs_per_launch": 2 * rep, "launch_us": round(us, 2), "us_per_pair": round(us / (2 * rep), 3)}), flush=True)
+    # the pair-form DENSE kernel (adjoint form of the SSIM gradient, per-pixel inverse depth eliminated per pair; 2-pixel halo): what a per-pair forward kernel
+    # of the reference-loss mode can realistically be -- the per-pixel depth column needs the adjoint gather, which k_linearize's pass B does not have
+    od = default_opts(n_iters=4, min_depth=0.06, max_depth=2.67)
+    us = lin_us(e, lambda: e.refine_dense(big["tgt"], big["src"], big["depth_t"], big["depth_s"], big["K"], big["pose_init"], od))
+    print(json.dumps({"kernel": "k_dense_linearize (pair-form dense, adjoint form)", "pairs_per_launch": 2 * rep, "launch_us": round(us, 2), "us_per_pair": round(us / (2 * rep), 3)}), flush=True)
     e.close()
 B, S = 6, 2
 w = T._window(B, S, H, W, seed=31)
